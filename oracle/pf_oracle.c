@@ -1,0 +1,759 @@
+/*
+ * pf_oracle.c -- CPU ORACLE (test infrastructure, see pf_oracle.h).
+ *
+ * Restates, function by function, the reference hot path.  Every routine
+ * cites the reference file:line it follows (paths relative to the reference
+ * tree).  Structure is deliberately the reference's own (one k-loop + one
+ * c2r per derivative, flat copies between user arrays and the FFT buffers,
+ * AoS float products), NOT the fused design of the HIP library, so that the
+ * two implementations are independent.
+ *
+ * The FFT is a textbook iterative radix-2 (power-of-two sizes only); the
+ * reference uses PFFT/FFTW, any correct FFT gives the same fields to fp64
+ * round-off.  3-D c2r semantics = complex inverse
+ * transforms along x and y on the half-spectrum, then a 1-D c2r along z that
+ * ignores the imaginary parts of the z-DC and z-Nyquist inputs (what FFTW /
+ * pocketfft compute).
+ */
+#define _POSIX_C_SOURCE 200809L
+#include "pf_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_PI 3.14159265358979323846 /* src/pinocchio.h:56 */
+#define ORC_SMALL ((double)1.e-20)     /* src/collapse_times.c:38 */
+
+struct orc_ctx {
+  int n, nzh, nthreads;
+  size_t n_r;   /* total_local_size      = n^3            (fmax-pfft.c:111) */
+  size_t n_fft; /* total_local_size_fft  = 2*n*n*(n/2+1)  (fmax-pfft.c:110) */
+  double norm;  /* 1/Ntotal (fmax-pfft.c:85) */
+  double *tw;   /* twiddles exp(+2 pi i j/n), interleaved */
+  int    *brev; /* bit-reversal permutation */
+
+  /* the reference's globals (src/variables.c) */
+  double *kdensity;                 /* kdensity[0] */
+  double *cvector, *rvector;        /* cvector_fft[0], rvector_fft[0] */
+  double *second_derivatives[6];    /* second_derivatives[0][0..5] */
+  double *kvector_2LPT, *kvector_3LPT_1, *kvector_3LPT_2;
+  double *source_2LPT, *source_3LPT_1, *source_3LPT_2; /* alias kvector_* (allocations.c:349,357) */
+  orc_product *products;
+  double Rsmooth;                   /* in cells */
+  int    sd_order;                  /* ScaleDep.order */
+  double growth[4];
+
+  /* inverse-growth natural cubic spline (GSL cspline restated) */
+  int nk;
+  double *sx, *sy, *sc;
+
+  double t_total, t_deriv, t_fft, t_coll, t_lpt;
+};
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* ------------------------------------------------------------------ FFT -- */
+
+/* in-place radix-2 DIT on n interleaved complex values; sign=+1 -> e^{+i..} */
+static void fft1d(double *a, int n, int sign, const double *tw, const int *brev) {
+  for (int i = 0; i < n; i++) {
+    int j = brev[i];
+    if (j > i) {
+      double tr = a[2 * i], ti = a[2 * i + 1];
+      a[2 * i] = a[2 * j]; a[2 * i + 1] = a[2 * j + 1];
+      a[2 * j] = tr; a[2 * j + 1] = ti;
+    }
+  }
+  for (int len = 2; len <= n; len <<= 1) {
+    int half = len >> 1, step = n / len;
+    for (int s = 0; s < n; s += len) {
+      for (int k = 0; k < half; k++) {
+        double wr = tw[2 * (k * step)], wi = sign * tw[2 * (k * step) + 1];
+        double *u = a + 2 * (s + k), *v = a + 2 * (s + k + half);
+        double xr = v[0] * wr - v[1] * wi, xi = v[0] * wi + v[1] * wr;
+        v[0] = u[0] - xr; v[1] = u[1] - xi;
+        u[0] += xr; u[1] += xi;
+      }
+    }
+  }
+}
+
+/* complex transforms along x and y of a half-spectrum array [n][n][nzh] */
+static void fft_xy(orc_ctx *c, double *spec, int sign) {
+  const int n = c->n, nzh = c->nzh;
+  /* y lines: fixed (x,kz), stride nzh */
+#pragma omp parallel num_threads(c->nthreads)
+  {
+    double *line = (double *)malloc(sizeof(double) * 2 * n);
+#pragma omp for schedule(static)
+    for (int x = 0; x < n; x++)
+      for (int kz = 0; kz < nzh; kz++) {
+        double *base = spec + 2 * ((size_t)x * n * nzh + kz);
+        for (int y = 0; y < n; y++) {
+          line[2 * y] = base[2 * (size_t)y * nzh];
+          line[2 * y + 1] = base[2 * (size_t)y * nzh + 1];
+        }
+        fft1d(line, n, sign, c->tw, c->brev);
+        for (int y = 0; y < n; y++) {
+          base[2 * (size_t)y * nzh] = line[2 * y];
+          base[2 * (size_t)y * nzh + 1] = line[2 * y + 1];
+        }
+      }
+    /* x lines: fixed (y,kz), stride n*nzh */
+#pragma omp for schedule(static)
+    for (int y = 0; y < n; y++)
+      for (int kz = 0; kz < nzh; kz++) {
+        double *base = spec + 2 * ((size_t)y * nzh + kz);
+        const size_t st = (size_t)n * nzh;
+        for (int x = 0; x < n; x++) {
+          line[2 * x] = base[2 * x * st];
+          line[2 * x + 1] = base[2 * x * st + 1];
+        }
+        fft1d(line, n, sign, c->tw, c->brev);
+        for (int x = 0; x < n; x++) {
+          base[2 * x * st] = line[2 * x];
+          base[2 * x * st + 1] = line[2 * x + 1];
+        }
+      }
+    free(line);
+  }
+}
+
+/* pfft_execute(reverse_plan): unnormalised c2r, cvector -> rvector.
+   (destroys the spectrum, as FFTW's c2r may) */
+static void c2r_3d(orc_ctx *c, double *spec, double *real_out) {
+  const int n = c->n, nzh = c->nzh;
+  fft_xy(c, spec, +1);
+#pragma omp parallel num_threads(c->nthreads)
+  {
+    double *line = (double *)malloc(sizeof(double) * 2 * n);
+#pragma omp for schedule(static)
+    for (int x = 0; x < n; x++)
+      for (int y = 0; y < n; y++) {
+        const double *h = spec + 2 * ((size_t)x * n + y) * nzh;
+        /* Hermitian extension; Im of DC and Nyquist do not reach the real part */
+        for (int k = 0; k < nzh; k++) { line[2 * k] = h[2 * k]; line[2 * k + 1] = h[2 * k + 1]; }
+        for (int k = nzh; k < n; k++) { line[2 * k] = h[2 * (n - k)]; line[2 * k + 1] = -h[2 * (n - k) + 1]; }
+        line[1] = 0.0; line[2 * (n / 2) + 1] = 0.0;
+        fft1d(line, n, +1, c->tw, c->brev);
+        double *r = real_out + ((size_t)x * n + y) * n;
+        for (int z = 0; z < n; z++) r[z] = line[2 * z];
+      }
+    free(line);
+  }
+}
+
+/* pfft_execute(forward_plan): unnormalised r2c, rvector -> cvector */
+static void r2c_3d(orc_ctx *c, const double *real_in, double *spec) {
+  const int n = c->n, nzh = c->nzh;
+#pragma omp parallel num_threads(c->nthreads)
+  {
+    double *line = (double *)malloc(sizeof(double) * 2 * n);
+#pragma omp for schedule(static)
+    for (int x = 0; x < n; x++)
+      for (int y = 0; y < n; y++) {
+        const double *r = real_in + ((size_t)x * n + y) * n;
+        for (int z = 0; z < n; z++) { line[2 * z] = r[z]; line[2 * z + 1] = 0.0; }
+        fft1d(line, n, -1, c->tw, c->brev);
+        double *h = spec + 2 * ((size_t)x * n + y) * nzh;
+        for (int k = 0; k < nzh; k++) { h[2 * k] = line[2 * k]; h[2 * k + 1] = line[2 * k + 1]; }
+      }
+    free(line);
+  }
+  fft_xy(c, spec, -1);
+}
+
+/* -------------------------------------------- src/fmax-pfft.c restated -- */
+
+/* fmax-pfft.c:191-200 */
+static double forward_transform(orc_ctx *c) {
+  double t = now_s();
+  r2c_3d(c, c->rvector, c->cvector);
+  return now_s() - t;
+}
+
+/* fmax-pfft.c:203-228.  The double application of norm on the last
+   total_local_size_fft%4 elements (quirk Q1) is inert: n even -> n_fft%4==0 */
+static double reverse_transform(orc_ctx *c) {
+  double t = now_s();
+  c2r_3d(c, c->cvector, c->rvector);
+  for (size_t i = c->n_fft - c->n_fft % 4; i < c->n_fft; i++) c->rvector[i] *= c->norm;
+  const size_t nr = c->n_r;
+#pragma omp parallel for num_threads(c->nthreads) schedule(static)
+  for (size_t i = 0; i < nr; i++) c->rvector[i] *= c->norm;
+  return now_s() - t;
+}
+
+/* fmax-pfft.c:444-456 */
+static double greens_function(const double *diff_comp, double k_squared, int first_derivative,
+                              int second_derivative) {
+  if (first_derivative == -1 && second_derivative == -1) return 1.0;
+  if (first_derivative == 0 && second_derivative == 0)
+    return -diff_comp[first_derivative] * diff_comp[second_derivative] / k_squared;
+  else
+    return diff_comp[first_derivative] * diff_comp[second_derivative] / k_squared;
+}
+
+/* fmax-pfft.c:255-441, non-transposed layout, single rank (start=0, local=global).
+   The reference's k-loop is serial; the oracle threads it over idx so that the
+   CPU baseline is not handicapped (results are identical, each mode is independent). */
+static int compute_derivative(orc_ctx *c, int first_derivative, int second_derivative) {
+  const int n = c->n, nzh = c->nzh;
+  const int Nhalf = n / 2;
+  const double knorm = 2. * ORC_PI / (double)n;
+  const int swap = ((first_derivative == 0 && second_derivative > 0) ||
+                    (first_derivative > 0 && second_derivative == 0));
+  const double Rsmooth = c->Rsmooth;
+  double growth_rate_order;
+  switch (c->sd_order) { /* fmax-pfft.c:344-364, scale-independent growth */
+    case 1: growth_rate_order = c->growth[0]; break;
+    case 2: growth_rate_order = c->growth[1]; break;
+    case 3: growth_rate_order = c->growth[2]; break;
+    case 4: growth_rate_order = c->growth[3]; break;
+    default: growth_rate_order = 1.0; break;
+  }
+  double *cv = c->cvector;
+
+#pragma omp parallel for num_threads(c->nthreads) schedule(static)
+  for (int idx = 0; idx < n; idx++) {
+    int ii[3];
+    ii[0] = idx;
+    if (ii[0] > Nhalf) ii[0] -= n;
+    double k_x = knorm * ii[0];
+    double k2_0 = k_x * k_x;
+    for (int idy = 0; idy < n; idy++) {
+      ii[1] = idy;
+      if (ii[1] > Nhalf) ii[1] -= n;
+      double k_y = knorm * ii[1];
+      double k2_1 = k2_0 + k_y * k_y;
+      for (int idz = 0; idz < nzh; idz++) {
+        ii[2] = idz;
+        if (ii[2] > Nhalf) ii[2] -= n;
+        double k_z = knorm * ii[2];
+        double k_squared = k2_1 + k_z * k_z;
+        double growth_rate = growth_rate_order;
+        size_t index = 2 * (((size_t)idx * n + idy) * nzh + idz);
+        if (k_squared != 0.) {
+          double smoothing = exp(-0.5 * k_squared * Rsmooth * Rsmooth);
+          double diff_comp[4];
+          diff_comp[0] = 1.0; diff_comp[1] = k_x; diff_comp[2] = k_y; diff_comp[3] = k_z;
+          double green = greens_function(diff_comp, k_squared, first_derivative, second_derivative);
+          cv[index] *= green * smoothing * growth_rate;
+          cv[index + 1] *= green * smoothing * growth_rate;
+        }
+        if (swap) {
+          double tmp = cv[index + 1];
+          cv[index + 1] = cv[index];
+          cv[index] = -tmp;
+        }
+      }
+    }
+  }
+  double time = reverse_transform(c);
+  c->t_fft += time;
+  return 0;
+}
+
+/* fmax-pfft.c:459-560: flat copies */
+static void write_in_cvector(orc_ctx *c, const double *v) { memcpy(c->cvector, v, sizeof(double) * c->n_fft); }
+static void write_from_cvector(orc_ctx *c, double *v) { memcpy(v, c->cvector, sizeof(double) * c->n_fft); }
+static void write_in_rvector(orc_ctx *c, const double *v) { memcpy(c->rvector, v, sizeof(double) * c->n_r); }
+static void write_from_rvector(orc_ctx *c, double *v) { memcpy(v, c->rvector, sizeof(double) * c->n_r); }
+
+/* fmax-pfft.c:563-631 */
+static void write_from_rvector_to_products(orc_ctx *c, int ia, int order) {
+  const size_t nr = c->n_r;
+  orc_product *p = c->products;
+  const double *rv = c->rvector;
+  switch (order) {
+    case 1:
+#pragma omp parallel for num_threads(c->nthreads) schedule(static)
+      for (size_t i = 0; i < nr; i++) p[i].Vel[ia] = rv[i];
+      break;
+    case 2:
+#pragma omp parallel for num_threads(c->nthreads) schedule(static)
+      for (size_t i = 0; i < nr; i++) p[i].Vel_2LPT[ia] = rv[i];
+      break;
+    case 3:
+#pragma omp parallel for num_threads(c->nthreads) schedule(static)
+      for (size_t i = 0; i < nr; i++) p[i].Vel_3LPT_1[ia] = rv[i];
+      break;
+    case 4:
+#pragma omp parallel for num_threads(c->nthreads) schedule(static)
+      for (size_t i = 0; i < nr; i++) p[i].Vel_3LPT_2[ia] = rv[i];
+      break;
+    default: break;
+  }
+}
+
+/* ------------------------------------------------- src/cosmo.c restated -- */
+
+/* GSL 2.7.1 (not vendored in the reference; pinned by HMF_Validation/
+   VALIDATION_log.txt:3) interpolation/cspline.c cspline_init: natural cubic
+   spline, c[0]=c[n-1]=0, interior c from the symmetric tridiagonal system
+   solved by linalg/tridiag.c solve_tridiag (LDL^t). */
+static int spline_init(orc_ctx *c, const double *xa, const double *ya, int size) {
+  free(c->sx); free(c->sy); free(c->sc);
+  c->nk = size;
+  c->sx = (double *)malloc(sizeof(double) * size);
+  c->sy = (double *)malloc(sizeof(double) * size);
+  c->sc = (double *)calloc(size, sizeof(double));
+  memcpy(c->sx, xa, sizeof(double) * size);
+  memcpy(c->sy, ya, sizeof(double) * size);
+  if (size < 3) return 1;
+  int max_index = size - 1, sys_size = max_index - 1;
+  double *g = (double *)malloc(sizeof(double) * sys_size);
+  double *diag = (double *)malloc(sizeof(double) * sys_size);
+  double *offdiag = (double *)malloc(sizeof(double) * sys_size);
+  for (int i = 0; i < sys_size; i++) {
+    const double h_i = xa[i + 1] - xa[i];
+    const double h_ip1 = xa[i + 2] - xa[i + 1];
+    const double ydiff_i = ya[i + 1] - ya[i];
+    const double ydiff_ip1 = ya[i + 2] - ya[i + 1];
+    const double g_i = (h_i != 0.0) ? 1.0 / h_i : 0.0;
+    const double g_ip1 = (h_ip1 != 0.0) ? 1.0 / h_ip1 : 0.0;
+    offdiag[i] = h_ip1;
+    diag[i] = 2.0 * (h_ip1 + h_i);
+    g[i] = 3.0 * (ydiff_ip1 * g_ip1 - ydiff_i * g_i);
+  }
+  if (sys_size == 1) {
+    c->sc[1] = g[0] / diag[0];
+  } else {
+    const int N = sys_size;
+    double *gamma = (double *)malloc(sizeof(double) * N);
+    double *alpha = (double *)malloc(sizeof(double) * N);
+    double *cc = (double *)malloc(sizeof(double) * N);
+    double *z = (double *)malloc(sizeof(double) * N);
+    double *x = c->sc + 1;
+    alpha[0] = diag[0];
+    gamma[0] = offdiag[0] / alpha[0];
+    for (int i = 1; i < N - 1; i++) {
+      alpha[i] = diag[i] - offdiag[i - 1] * gamma[i - 1];
+      gamma[i] = offdiag[i] / alpha[i];
+    }
+    if (N > 1) alpha[N - 1] = diag[N - 1] - offdiag[N - 2] * gamma[N - 2];
+    z[0] = g[0];
+    for (int i = 1; i < N; i++) z[i] = g[i] - gamma[i - 1] * z[i - 1];
+    for (int i = 0; i < N; i++) cc[i] = z[i] / alpha[i];
+    x[N - 1] = cc[N - 1];
+    if (N >= 2)
+      for (int i = N - 2, j = 0; j <= N - 2; j++, i--) x[i] = cc[i] - gamma[i] * x[i + 1];
+    free(gamma); free(alpha); free(cc); free(z);
+  }
+  free(g); free(diag); free(offdiag);
+  return 0;
+}
+
+/* GSL interpolation/bsearch.c gsl_interp_bsearch + cspline.c cspline_eval */
+static double gsl_spline_eval_restated(const orc_ctx *c, double x) {
+  const double *xa = c->sx, *ya = c->sy, *ca = c->sc;
+  size_t ilo = 0, ihi = (size_t)c->nk - 1;
+  while (ihi > ilo + 1) {
+    size_t i = (ihi + ilo) / 2;
+    if (xa[i] > x) ihi = i; else ilo = i;
+  }
+  const size_t index = ilo;
+  const double x_hi = xa[index + 1], x_lo = xa[index];
+  const double dx = x_hi - x_lo;
+  const double y_lo = ya[index], y_hi = ya[index + 1];
+  const double dy = y_hi - y_lo;
+  const double delx = x - x_lo;
+  const double c_i = ca[index], c_ip1 = ca[index + 1];
+  const double b_i = (dy / dx) - dx * (c_ip1 + 2.0 * c_i) / 3.0;
+  const double d_i = (c_ip1 - c_i) / (3.0 * dx);
+  return y_lo + delx * (b_i + delx * (c_i + delx * d_i));
+}
+
+/* cosmo.c:2016-2027 my_spline_eval: linear extrapolation beyond the knots */
+double orc_spline_eval(orc_ctx *c, double x) {
+  const double *sx = c->sx, *sy = c->sy;
+  const int size = c->nk;
+  if (x < sx[0])
+    return sy[0] + (x - sx[0]) * (sy[1] - sy[0]) / (sx[1] - sx[0]);
+  else if (x > sx[size - 1])
+    return sy[size - 1] + (x - sx[size - 1]) * (sy[size - 1] - sy[size - 2]) / (sx[size - 1] - sx[size - 2]);
+  else
+    return gsl_spline_eval_restated(c, x);
+}
+
+/* cosmo.c:1822-1832 (non SCALE_DEPENDENT branch) */
+double orc_inverse_growing_mode(orc_ctx *c, double D) {
+  return 1. / pow(10., orc_spline_eval(c, log10(D))) - 1.;
+}
+
+/* ---------------------------------------- src/collapse_times.c restated -- */
+
+/* collapse_times.c:114-221 */
+double orc_ell_classic(double l1, double l2, double l3) {
+  double ell;
+  double del = l1 + l2 + l3;
+  double det = l1 * l2 * l3;
+
+  if (fabs(l1) < ORC_SMALL) {
+    ell = -0.1;
+  } else {
+    double den = det / 126. + 5. * l1 * del * (del - l1) / 84.;
+    if (fabs(den) < ORC_SMALL) {
+      if (fabs(del - l1) < ORC_SMALL) {
+        if (l1 > 0.0) ell = 1. / l1; else ell = -.1;
+      } else {
+        double dis = 7. * l1 * (l1 + 6. * del);
+        if (dis < 0.0) {
+          ell = -.1;
+        } else {
+          ell = (7. * l1 - sqrt(dis)) / (3. * l1 * (l1 - del));
+          if (ell < 0.) ell = -.1;
+        }
+      }
+    } else {
+      double rden = 1.0 / den;
+      double a1 = 3. * l1 * (del - l1) / 14. * rden;
+      double a1_2 = a1 * a1;
+      double a2 = l1 * rden;
+      double a3 = -1.0 * rden;
+      double q = (a1_2 - 3. * a2) / 9.;
+      double r = (2. * a1_2 * a1 - 9. * a1 * a2 + 27. * a3) / 54.;
+      double r_2_q_3 = r * r - q * q * q;
+      if (r_2_q_3 > 0) {
+        double fabs_r = fabs(r);
+        double sq = pow(sqrt(r_2_q_3) + fabs_r, 0.333333333333333);
+        ell = -fabs_r / r * (sq + q / sq) - a1 / 3.;
+        if (ell < 0.) ell = -.1;
+      } else {
+        double sq = 2 * sqrt(q);
+        double inv_3 = 1.0 / 3;
+        double t = acos(2 * r / q / sq);
+        double s1 = -sq * cos(t * inv_3) - a1 * inv_3;
+        double s2 = -sq * cos((t + 2. * ORC_PI) * inv_3) - a1 * inv_3;
+        double s3 = -sq * cos((t + 4. * ORC_PI) * inv_3) - a1 * inv_3;
+        if (s1 < 0.) s1 = 1.e10;
+        if (s2 < 0.) s2 = 1.e10;
+        if (s3 < 0.) s3 = 1.e10;
+        ell = (s1 < s2 ? s1 : s2);
+        ell = (s3 < ell ? s3 : ell);
+        if (ell == 1.e10) ell = -.1;
+      }
+    }
+  }
+  if (del > 0. && ell > 0.) {
+    double inv_del = 1.0 / del;
+    ell += -.364 * inv_del * exp(-6.5 * (l1 - l2) * inv_del - 2.8 * (l2 - l3) * inv_del);
+  }
+  return ell;
+}
+
+/* collapse_times.c:404-415 (ELL_CLASSIC) */
+static double ell_fn(orc_ctx *c, double l1, double l2, double l3) {
+  double bc = orc_ell_classic(l1, l2, l3);
+  if (bc > 0.0) return 1. + orc_inverse_growing_mode(c, bc);
+  else return 0.0;
+}
+
+/* collapse_times.c:1354-1362 */
+static void ord(double *a, double *b, double *c) {
+  double lo, hi;
+  hi = (*a > *b ? *a : *b); hi = (hi > *c ? hi : *c);
+  lo = (*a < *b ? *a : *b); lo = (lo < *c ? lo : *c);
+  *b = *a + *b + *c - lo - hi;
+  *a = hi;
+  *c = lo;
+}
+
+/* collapse_times.c:679-776 */
+double orc_inverse_collapse_time(orc_ctx *c, const double *deformation_tensor, double *x1, double *x2,
+                                 double *x3, int *fail) {
+  double mu1, mu2, mu3;
+  double dtensor[6] = {deformation_tensor[0], deformation_tensor[1], deformation_tensor[2],
+                       deformation_tensor[3], deformation_tensor[4], deformation_tensor[5]};
+  *fail = 0;
+  mu1 = dtensor[0] + dtensor[1] + dtensor[2];
+  double mu1_2 = mu1 * mu1;
+  mu2 = 0.5 * mu1_2;
+  {
+    double add[3];
+    add[0] = dtensor[0] * dtensor[0];
+    add[1] = dtensor[1] * dtensor[1];
+    add[2] = dtensor[2] * dtensor[2];
+    mu2 -= 0.5 * (add[0] + add[1] + add[2]);
+  }
+  double add[3];
+  add[0] = dtensor[3] * dtensor[3];
+  add[1] = dtensor[4] * dtensor[4];
+  add[2] = dtensor[5] * dtensor[5];
+  mu2 -= add[0] + add[1] + add[2];
+  mu3 = dtensor[0] * dtensor[1] * dtensor[2] + 2. * dtensor[3] * dtensor[4] * dtensor[5] -
+        dtensor[0] * add[2] - dtensor[1] * add[1] - dtensor[2] * add[0];
+  double q;
+  q = (mu1_2 - 3.0 * mu2) / 9.0;
+  if (q == 0.) {
+    *x1 = dtensor[0]; *x2 = dtensor[1]; *x3 = dtensor[2];
+  } else {
+    double r = -(2. * mu1_2 * mu1 - 9.0 * mu1 * mu2 + 27.0 * mu3) / 54.;
+    if (q * q * q < r * r || q < 0.0) return -10.0;
+    double sq = 2 * sqrt(q);
+    double t = acos(2 * r / q / sq);
+    double inv_3 = 1.0 / 3.0;
+    *x1 = -sq * cos(t * inv_3) + mu1 * inv_3;
+    *x2 = -sq * cos((t + 2. * ORC_PI) * inv_3) + mu1 * inv_3;
+    *x3 = -sq * cos((t + 4. * ORC_PI) * inv_3) + mu1 * inv_3;
+  }
+  ord(x1, x2, x3);
+  return ell_fn(c, *x1, *x2, *x3);
+}
+
+/* collapse_times.c:431-673 */
+int orc_compute_collapse_times(orc_ctx *c, int ismooth, double *true_var) {
+  const size_t nr = c->n_r;
+  orc_product *products = c->products;
+  double local_variance = 0.0, local_average = 0.0;
+
+  if (!ismooth) {
+#pragma omp parallel for num_threads(c->nthreads) schedule(static)
+    for (size_t i = 0; i < nr; i++) {
+      products[i].Fmax = -10.0;
+      products[i].Rmax = -1;
+      for (int k = 0; k < 3; k++) {
+        products[i].Vel[k] = 0.0; products[i].Vel_2LPT[k] = 0.0;
+        products[i].Vel_3LPT_1[k] = 0.0; products[i].Vel_3LPT_2[k] = 0.0;
+      }
+    }
+  }
+  int all_fails = 0;
+  /* per-thread partial sums combined in thread order (deterministic for a
+     fixed thread count; the reference uses omp atomic, :602-606) */
+  int nt = c->nthreads;
+  double *pv = (double *)calloc(nt, sizeof(double)), *pa = (double *)calloc(nt, sizeof(double));
+#pragma omp parallel num_threads(nt)
+  {
+    int tid = 0;
+#ifdef _OPENMP
+    tid = omp_get_thread_num();
+#endif
+    double mylocal_average = 0, mylocal_variance = 0;
+    int fails = 0;
+#pragma omp for schedule(static) nowait
+    for (size_t index = 0; index < nr; index++) {
+      double diff_ten[6];
+      for (int i = 0; i < 6; i++) diff_ten[i] = c->second_derivatives[i][index];
+      double delta = diff_ten[0] + diff_ten[1] + diff_ten[2];
+      mylocal_average += delta;
+      mylocal_variance += delta * delta;
+      double lambda1, lambda2, lambda3;
+      int fail;
+      double Fnew = orc_inverse_collapse_time(c, diff_ten, &lambda1, &lambda2, &lambda3, &fail);
+      if (fail) fails = 1;
+      if (products[index].Fmax < Fnew) { /* float promoted to double (quirk Q2) */
+        products[index].Fmax = Fnew;
+        products[index].Rmax = ismooth;
+      }
+    }
+    pv[tid] = mylocal_variance; pa[tid] = mylocal_average;
+#pragma omp atomic
+    all_fails += fails;
+  }
+  for (int t = 0; t < nt; t++) { local_variance += pv[t]; local_average += pa[t]; }
+  free(pv); free(pa);
+  if (all_fails) {
+    printf("ERROR on task 0: failure in inverse_collapse_time\n");
+    return 1;
+  }
+  double global_variance = local_variance / (double)nr; /* Ntotal, :662 */
+  if (true_var) *true_var = global_variance;
+  return 0;
+}
+
+/* ----------------------------------------------- src/fmax.c restated ---- */
+
+/* fmax.c:225-258 */
+int orc_compute_second_derivatives(orc_ctx *c, double rs_cells) {
+  c->Rsmooth = rs_cells;
+  for (int ia = 1; ia <= 3; ia++)
+    for (int ib = ia; ib <= 3; ib++) {
+      int ider = (ia == ib ? ia : ia + ib + 1);
+      write_in_cvector(c, c->kdensity);
+      if (compute_derivative(c, ia, ib)) return 1;
+      write_from_rvector(c, c->second_derivatives[ider - 1]);
+    }
+  return 0;
+}
+
+/* fmax.c:193-222 */
+static int compute_first_derivatives(orc_ctx *c, double rs_cells, int order, const double *vector) {
+  c->Rsmooth = rs_cells;
+  for (int ia = 1; ia <= 3; ia++) {
+    write_in_cvector(c, vector);
+    if (compute_derivative(c, ia, 0)) return 1;
+    write_from_rvector_to_products(c, ia - 1, order);
+  }
+  return 0;
+}
+
+/* src/LPT.c:32-235 */
+static int compute_LPT_displacements(orc_ctx *c, int compute_sources) {
+  const size_t nr = c->n_r;
+  double **sd = c->second_derivatives;
+  if (compute_sources) {
+    c->sd_order = 0;
+    double *source_2LPT = c->source_2LPT, *source_3LPT_1 = c->source_3LPT_1, *source_3LPT_2 = c->source_3LPT_2;
+#pragma omp parallel for num_threads(c->nthreads) schedule(static)
+    for (size_t index = 0; index < nr; index++) {
+      source_2LPT[index] = sd[0][index] * sd[1][index] + sd[0][index] * sd[2][index] +
+                           sd[1][index] * sd[2][index] - sd[3][index] * sd[3][index] -
+                           sd[4][index] * sd[4][index] - sd[5][index] * sd[5][index];
+      source_3LPT_1[index] =
+          3.0 * (sd[0][index] * (sd[1][index] * sd[2][index] - sd[5][index] * sd[5][index]) -
+                 sd[3][index] * (sd[3][index] * sd[2][index] - sd[4][index] * sd[5][index]) +
+                 sd[4][index] * (sd[3][index] * sd[5][index] - sd[4][index] * sd[1][index]));
+      source_3LPT_2[index] = 2.0 * (sd[0][index] + sd[1][index] + sd[2][index]) * source_2LPT[index];
+    }
+    write_in_rvector(c, source_2LPT);
+    c->t_fft += forward_transform(c);
+    write_from_cvector(c, c->kvector_2LPT);
+
+    for (int ia = 1; ia <= 3; ia++)
+      for (int ib = ia; ib <= 3; ib++) {
+        int ider = (ia == ib ? ia : ia + ib + 1);
+        write_in_cvector(c, c->kvector_2LPT);
+        if (compute_derivative(c, ia, ib)) return 1;
+        const double *rv = c->rvector;
+        const double *sdi = sd[ider - 1];
+        const double f = 2.0 * (ider <= 3 ? 1.0 : 2.0);
+#pragma omp parallel for num_threads(c->nthreads) schedule(static)
+        for (size_t index = 0; index < nr; index++) source_3LPT_2[index] -= f * rv[index] * sdi[index];
+      }
+    write_in_rvector(c, source_3LPT_1);
+    c->t_fft += forward_transform(c);
+    write_from_cvector(c, c->kvector_3LPT_1);
+
+    write_in_rvector(c, source_3LPT_2);
+    c->t_fft += forward_transform(c);
+    write_from_cvector(c, c->kvector_3LPT_2);
+  }
+  c->sd_order = 2;
+  compute_first_derivatives(c, 0., 2, c->kvector_2LPT);
+  c->sd_order = 3;
+  compute_first_derivatives(c, 0., 3, c->kvector_3LPT_1);
+  c->sd_order = 4;
+  compute_first_derivatives(c, 0., 4, c->kvector_3LPT_2);
+  return 0;
+}
+
+/* fmax.c:292-367 with recompute_sd = 0 */
+int orc_compute_displacements(orc_ctx *c, int compute_sources) {
+  double t = now_s();
+  if (compute_LPT_displacements(c, compute_sources)) return 1;
+  c->t_lpt += now_s() - t;
+  t = now_s();
+  c->sd_order = 1;
+  if (compute_first_derivatives(c, 0.0, 1, c->kdensity)) return 1;
+  c->t_deriv += now_s() - t;
+  return 0;
+}
+
+/* fmax.c:36-190 */
+int orc_compute_fmax(orc_ctx *c, int ns, const double *rs_cells, int do_lpt, double *true_var) {
+  c->t_total = now_s();
+  c->t_deriv = c->t_fft = c->t_coll = c->t_lpt = 0.0;
+  c->sd_order = 0;
+  for (int ismooth = 0; ismooth < ns; ismooth++) {
+    double t = now_s();
+    if (orc_compute_second_derivatives(c, rs_cells[ismooth])) return 1;
+    c->t_deriv += now_s() - t;
+    t = now_s();
+    if (orc_compute_collapse_times(c, ismooth, true_var ? &true_var[ismooth] : NULL)) return 1;
+    c->t_coll += now_s() - t;
+  }
+  if (do_lpt)
+    if (orc_compute_displacements(c, 1)) return 1;
+  c->t_total = now_s() - c->t_total;
+  return 0;
+}
+
+/* fmax.c:509-550 */
+int orc_fmax_pdf(orc_ctx *c, unsigned long long hist[ORC_NBINS]) {
+  for (int i = 0; i < ORC_NBINS; i++) hist[i] = 0;
+  for (size_t i = 0; i < c->n_r; i++) {
+    int xF = (int)(c->products[i].Fmax * 10.);
+    if (xF < 0) xF = 0;
+    if (xF >= ORC_NBINS) xF = ORC_NBINS - 1;
+    hist[xF]++;
+  }
+  return 0;
+}
+
+/* ----------------------------------------------------------- plumbing --- */
+
+orc_ctx *orc_create(int n, int nthreads) {
+  if (n < 4 || (n & (n - 1))) return NULL;
+  orc_ctx *c = (orc_ctx *)calloc(1, sizeof(orc_ctx));
+  c->n = n; c->nzh = n / 2 + 1;
+#ifdef _OPENMP
+  c->nthreads = nthreads > 0 ? nthreads : omp_get_max_threads();
+#else
+  c->nthreads = 1;
+#endif
+  c->n_r = (size_t)n * n * n;
+  c->n_fft = 2 * (size_t)n * n * c->nzh;
+  c->norm = (double)1.0 / ((double)c->n_r);
+  c->tw = (double *)malloc(sizeof(double) * 2 * n);
+  for (int j = 0; j < n; j++) {
+    c->tw[2 * j] = cos(2. * ORC_PI * j / n);
+    c->tw[2 * j + 1] = sin(2. * ORC_PI * j / n);
+  }
+  c->brev = (int *)malloc(sizeof(int) * n);
+  int lg = 0; while ((1 << lg) < n) lg++;
+  for (int i = 0; i < n; i++) {
+    int r = 0;
+    for (int b = 0; b < lg; b++) if (i & (1 << b)) r |= 1 << (lg - 1 - b);
+    c->brev[i] = r;
+  }
+  size_t bf = sizeof(double) * c->n_fft;
+  c->kdensity = (double *)calloc(1, bf);
+  c->cvector = (double *)calloc(1, bf);
+  c->rvector = (double *)calloc(1, bf);
+  for (int i = 0; i < 6; i++) c->second_derivatives[i] = (double *)calloc(c->n_r, sizeof(double));
+  c->kvector_2LPT = (double *)calloc(1, bf);
+  c->kvector_3LPT_1 = (double *)calloc(1, bf);
+  c->kvector_3LPT_2 = (double *)calloc(1, bf);
+  c->source_2LPT = c->kvector_2LPT; c->source_3LPT_1 = c->kvector_3LPT_1; c->source_3LPT_2 = c->kvector_3LPT_2;
+  c->products = (orc_product *)calloc(c->n_r, sizeof(orc_product));
+  c->growth[0] = 1.0; c->growth[1] = 3. / 7.; c->growth[2] = -1. / 9.; c->growth[3] = 5. / 42.;
+  return c;
+}
+
+void orc_destroy(orc_ctx *c) {
+  if (!c) return;
+  free(c->tw); free(c->brev); free(c->kdensity); free(c->cvector); free(c->rvector);
+  for (int i = 0; i < 6; i++) free(c->second_derivatives[i]);
+  free(c->kvector_2LPT); free(c->kvector_3LPT_1); free(c->kvector_3LPT_2);
+  free(c->products); free(c->sx); free(c->sy); free(c->sc);
+  free(c);
+}
+
+int orc_set_density(orc_ctx *c, const double *dk) { memcpy(c->kdensity, dk, sizeof(double) * c->n_fft); return 0; }
+int orc_set_invgrow(orc_ctx *c, const double *x, const double *y, int nk) { return spline_init(c, x, y, nk); }
+int orc_set_growth(orc_ctx *c, const double g[4]) { memcpy(c->growth, g, sizeof(double) * 4); return 0; }
+const orc_product *orc_products(orc_ctx *c) { return c->products; }
+const double *orc_second_derivative(orc_ctx *c, int i) { return c->second_derivatives[i]; }
+const double *orc_kvector(orc_ctx *c, int which) {
+  return which == 0 ? c->kvector_2LPT : which == 1 ? c->kvector_3LPT_1 : c->kvector_3LPT_2;
+}
+int orc_c2r(orc_ctx *c, const double *spec, double *real_out) {
+  memcpy(c->cvector, spec, sizeof(double) * c->n_fft);
+  c2r_3d(c, c->cvector, real_out);
+  return 0;
+}
+int orc_r2c(orc_ctx *c, const double *real_in, double *spec_out) { r2c_3d(c, real_in, spec_out); return 0; }
+void orc_timers(orc_ctx *c, double t[5]) {
+  t[0] = c->t_total; t[1] = c->t_deriv; t[2] = c->t_fft; t[3] = c->t_coll; t[4] = c->t_lpt;
+}

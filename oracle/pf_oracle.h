@@ -1,0 +1,91 @@
+/*
+ * pf_oracle.h -- CPU ORACLE for the PINOCCHIO collapse-time hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a plain-C restatement of the reference
+ * algorithm (pigimonaco/Pinocchio V5.1: src/fmax.c, src/fmax-pfft.c,
+ * src/collapse_times.c, src/LPT.c, the spline evaluation in src/cosmo.c).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load it; the shipped library (libpinfmax_hip.so) never does.
+ *
+ * Parity pin: the per-cell solver (orc_ell_classic / orc_inverse_collapse_time)
+ * is pinned by the known-answer values captured from the compiled reference
+ * objects during the survey (SURVEY.md Appendix D -> tests/golden/
+ * collapse_kat.json).  The field-level path (k-filter, c2r, LPT) is pinned by
+ * an independent numpy/pocketfft restatement (tests/np_restatement.py) whose
+ * formulas SURVEY.md Appendix C.6 records as bit-identical to the running
+ * reference at N=32.  The reference itself is UNBUILDABLE in this image
+ * (needs GSL, FFTW3-MPI and PFFT, all absent; no stand-ins are written), so
+ * no oracle/_ref exists; see DESIGN.md "Oracle".
+ *
+ * Flags mirrored: -DTWO_LPT -DTHREE_LPT -DELL_CLASSIC (no SCALE_DEPENDENT,
+ * no RECOMPUTE_DISPLACEMENTS, float products) == HMF_Validation build.
+ */
+#ifndef PF_ORACLE_H
+#define PF_ORACLE_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_NBINS 210 /* src/pinocchio.h:65 */
+
+/* src/pinocchio.h:233-259 with -DTWO_LPT -DTHREE_LPT, float products: 56 B */
+typedef struct {
+  int   Rmax;
+  float Fmax, Vel[3];
+  float Vel_2LPT[3];
+  float Vel_3LPT_1[3], Vel_3LPT_2[3];
+} orc_product;
+
+typedef struct orc_ctx orc_ctx;
+
+/* single rank, cubic grid n^3 (n power of two >= 4); nthreads<=0 -> omp default */
+orc_ctx *orc_create(int n, int nthreads);
+void     orc_destroy(orc_ctx *c);
+
+/* kdensity[0]: half-spectrum [x][y][n/2+1][2] (src/fmax-pfft.c:366) */
+int orc_set_density(orc_ctx *c, const double *dk);
+/* SPLINE[SP_INVGROW] knots (src/cosmo.c:401): x = log10 D, y = log10 a */
+int orc_set_invgrow(orc_ctx *c, const double *x, const double *y, int nk);
+/* scale-independent growth multipliers at the target redshift:
+   g[0]=GrowingMode, g[1]=GrowingMode_2LPT, g[2]=GrowingMode_3LPT_1 (already
+   carrying its minus sign, src/cosmo.c:1810), g[3]=GrowingMode_3LPT_2 */
+int orc_set_growth(orc_ctx *c, const double g[4]);
+
+/* src/fmax.c:36-190: Ns radii (in CELL units: Rsmooth = R/CellSize, :233),
+   then compute_displacements(1,0,z) when do_lpt != 0.  true_var[Ns] out. */
+int orc_compute_fmax(orc_ctx *c, int ns, const double *rs_cells, int do_lpt,
+                     double *true_var);
+
+/* individual steps (same names as the reference, for unit tests) */
+int orc_compute_second_derivatives(orc_ctx *c, double rs_cells);  /* fmax.c:225 */
+int orc_compute_collapse_times(orc_ctx *c, int ismooth, double *true_var); /* collapse_times.c:431 */
+int orc_compute_displacements(orc_ctx *c, int compute_sources);   /* fmax.c:292 */
+int orc_fmax_pdf(orc_ctx *c, unsigned long long hist[ORC_NBINS]); /* fmax.c:509 */
+
+/* accessors */
+const orc_product *orc_products(orc_ctx *c);
+const double *orc_second_derivative(orc_ctx *c, int i); /* i=0..5, order 11,22,33,12,13,23 */
+const double *orc_kvector(orc_ctx *c, int which);       /* 0:2LPT 1:3LPT_1 2:3LPT_2 */
+
+/* stand-alone FFTs on caller buffers (for unit tests of the oracle itself) */
+int orc_c2r(orc_ctx *c, const double *spec, double *real_out); /* unnormalised */
+int orc_r2c(orc_ctx *c, const double *real_in, double *spec_out);
+
+/* per-cell functions (KAT entry points) */
+double orc_ell_classic(double l1, double l2, double l3);             /* collapse_times.c:114 */
+double orc_inverse_collapse_time(orc_ctx *c, const double *d,
+                                 double *x1, double *x2, double *x3, int *fail); /* :679 */
+double orc_inverse_growing_mode(orc_ctx *c, double D);               /* cosmo.c:1822 */
+double orc_spline_eval(orc_ctx *c, double x);                        /* cosmo.c:2016 */
+
+/* wall-clock breakdown of the last orc_compute_fmax, seconds:
+   [0] total [1] deriv (k-loop+fft+copies) [2] fft [3] collapse [4] lpt */
+void orc_timers(orc_ctx *c, double t[5]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

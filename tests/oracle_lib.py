@@ -1,0 +1,187 @@
+"""ctypes binding of the CPU oracle (oracle/libpf_oracle.so).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  Builds the oracle with `make -C oracle` on first
+use if the shared object is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+SO = os.path.join(ORACLE_DIR, "libpf_oracle.so")
+NBINS = 210
+
+PRODUCT_DTYPE = np.dtype(
+    [("Rmax", "<i4"), ("Fmax", "<f4"), ("Vel", "<f4", 3), ("Vel_2LPT", "<f4", 3),
+     ("Vel_3LPT_1", "<f4", 3), ("Vel_3LPT_2", "<f4", 3)], align=False)
+assert PRODUCT_DTYPE.itemsize == 56
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(ORACLE_DIR, "pf_oracle.c")
+    stale = (not os.path.exists(SO)) or os.path.getmtime(SO) < os.path.getmtime(src)
+    if force or stale:
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "-B"])
+    return SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(SO)
+        dp = C.POINTER(C.c_double)
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.c_int, C.c_int]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_set_density.argtypes = [C.c_void_p, dp]
+        L.orc_set_invgrow.argtypes = [C.c_void_p, dp, dp, C.c_int]
+        L.orc_set_growth.argtypes = [C.c_void_p, dp]
+        L.orc_compute_fmax.argtypes = [C.c_void_p, C.c_int, dp, C.c_int, dp]
+        L.orc_compute_second_derivatives.argtypes = [C.c_void_p, C.c_double]
+        L.orc_compute_collapse_times.argtypes = [C.c_void_p, C.c_int, dp]
+        L.orc_compute_displacements.argtypes = [C.c_void_p, C.c_int]
+        L.orc_fmax_pdf.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+        L.orc_products.restype = C.c_void_p
+        L.orc_products.argtypes = [C.c_void_p]
+        L.orc_second_derivative.restype = dp
+        L.orc_second_derivative.argtypes = [C.c_void_p, C.c_int]
+        L.orc_kvector.restype = dp
+        L.orc_kvector.argtypes = [C.c_void_p, C.c_int]
+        L.orc_c2r.argtypes = [C.c_void_p, dp, dp]
+        L.orc_r2c.argtypes = [C.c_void_p, dp, dp]
+        L.orc_ell_classic.restype = C.c_double
+        L.orc_ell_classic.argtypes = [C.c_double] * 3
+        L.orc_inverse_collapse_time.restype = C.c_double
+        L.orc_inverse_collapse_time.argtypes = [C.c_void_p, dp, dp, dp, dp, C.POINTER(C.c_int)]
+        L.orc_inverse_growing_mode.restype = C.c_double
+        L.orc_inverse_growing_mode.argtypes = [C.c_void_p, C.c_double]
+        L.orc_spline_eval.restype = C.c_double
+        L.orc_spline_eval.argtypes = [C.c_void_p, C.c_double]
+        L.orc_timers.argtypes = [C.c_void_p, dp]
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Oracle:
+    """One oracle context on an n^3 grid."""
+
+    def __init__(self, n: int, nthreads: int = 0):
+        self.L = lib()
+        self.n = n
+        self.h = self.L.orc_create(n, nthreads)
+        if not self.h:
+            raise ValueError("orc_create failed (n must be a power of two >= 4)")
+
+    def close(self):
+        if self.h:
+            self.L.orc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def set_density(self, dk: np.ndarray):
+        n = self.n
+        dk = np.ascontiguousarray(dk, dtype=np.complex128)
+        assert dk.shape == (n, n, n // 2 + 1)
+        self.L.orc_set_density(self.h, _dp(dk.view(np.float64)))
+
+    def set_invgrow(self, x, y):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        rc = self.L.orc_set_invgrow(self.h, _dp(x), _dp(y), len(x))
+        assert rc == 0
+
+    def set_growth(self, g):
+        g = np.ascontiguousarray(g, dtype=np.float64)
+        self.L.orc_set_growth(self.h, _dp(g))
+
+    def compute_fmax(self, radii_cells, do_lpt=True):
+        r = np.ascontiguousarray(radii_cells, dtype=np.float64)
+        tv = np.zeros(len(r))
+        rc = self.L.orc_compute_fmax(self.h, len(r), _dp(r), int(do_lpt), _dp(tv))
+        if rc:
+            raise RuntimeError("orc_compute_fmax failed")
+        return tv
+
+    def second_derivatives(self, rs_cells: float):
+        rc = self.L.orc_compute_second_derivatives(self.h, float(rs_cells))
+        assert rc == 0
+        n = self.n
+        return [np.ctypeslib.as_array(self.L.orc_second_derivative(self.h, i), shape=(n, n, n)).copy()
+                for i in range(6)]
+
+    def collapse_times(self, ismooth: int) -> float:
+        tv = C.c_double(0)
+        rc = self.L.orc_compute_collapse_times(self.h, ismooth, C.byref(tv))
+        assert rc == 0
+        return tv.value
+
+    def displacements(self, compute_sources=True):
+        rc = self.L.orc_compute_displacements(self.h, int(compute_sources))
+        assert rc == 0
+
+    def products(self) -> np.ndarray:
+        n = self.n
+        ptr = self.L.orc_products(self.h)
+        buf = (C.c_char * (PRODUCT_DTYPE.itemsize * n ** 3)).from_address(ptr)
+        return np.frombuffer(buf, dtype=PRODUCT_DTYPE).reshape(n, n, n).copy()
+
+    def kvector(self, which: int) -> np.ndarray:
+        n = self.n
+        a = np.ctypeslib.as_array(self.L.orc_kvector(self.h, which), shape=(n, n, n // 2 + 1, 2)).copy()
+        return a.view(np.complex128)[..., 0]
+
+    def fmax_pdf(self) -> np.ndarray:
+        h = (C.c_ulonglong * NBINS)()
+        self.L.orc_fmax_pdf(self.h, h)
+        return np.array(h[:], dtype=np.uint64)
+
+    def c2r(self, spec: np.ndarray) -> np.ndarray:
+        n = self.n
+        spec = np.ascontiguousarray(spec, dtype=np.complex128)
+        out = np.empty((n, n, n))
+        self.L.orc_c2r(self.h, _dp(spec.view(np.float64)), _dp(out))
+        return out
+
+    def r2c(self, real: np.ndarray) -> np.ndarray:
+        n = self.n
+        real = np.ascontiguousarray(real, dtype=np.float64)
+        out = np.empty((n, n, n // 2 + 1), dtype=np.complex128)
+        self.L.orc_r2c(self.h, _dp(real), _dp(out.view(np.float64)))
+        return out
+
+    def inverse_collapse_time(self, d):
+        d = np.ascontiguousarray(d, dtype=np.float64)
+        x1, x2, x3 = C.c_double(), C.c_double(), C.c_double()
+        fail = C.c_int()
+        f = self.L.orc_inverse_collapse_time(self.h, _dp(d), C.byref(x1), C.byref(x2), C.byref(x3), C.byref(fail))
+        return f, (x1.value, x2.value, x3.value), fail.value
+
+    def inverse_growing_mode(self, D: float) -> float:
+        return self.L.orc_inverse_growing_mode(self.h, float(D))
+
+    def spline_eval(self, x: float) -> float:
+        return self.L.orc_spline_eval(self.h, float(x))
+
+    def timers(self):
+        t = np.zeros(5)
+        self.L.orc_timers(self.h, _dp(t))
+        return dict(total=t[0], deriv=t[1], fft=t[2], coll=t[3], lpt=t[4])
+
+
+def ell_classic(l1, l2, l3) -> float:
+    return lib().orc_ell_classic(float(l1), float(l2), float(l3))

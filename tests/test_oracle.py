@@ -1,0 +1,170 @@
+"""Pins the CPU oracle (oracle/pf_oracle.c): reference known answers
+(SURVEY.md Appendix D), GSL-spline restatement vs scipy, own FFT vs pocketfft,
+and the whole field-level path vs the independent numpy restatement."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import np_restatement as npr
+import oracle_lib
+from pinocchio_amd import synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def kat():
+    with open(os.path.join(GOLD, "collapse_kat.json")) as f:
+        return json.load(f)
+
+
+def _eds_oracle(n=8):
+    o = oracle_lib.Oracle(n, 1)
+    x, y = synth.invgrow_table("eds")
+    o.set_invgrow(x, y)
+    return o
+
+
+def test_ell_classic_kat(kat):
+    for case in kat["ell_classic"]:
+        got = oracle_lib.ell_classic(*case["l"])
+        assert got == pytest.approx(case["bc"], rel=4e-16, abs=0), (case, got)
+
+
+def test_inverse_collapse_time_kat(kat):
+    o = _eds_oracle()
+    for case in kat["inverse_collapse_time"]:
+        f, eig, fail = o.inverse_collapse_time(case["d"])
+        assert fail == 0
+        # the EdS spline is the identity up to spline round-off: F = 1/b_c
+        assert f == pytest.approx(case["F"], rel=1e-14, abs=1e-15), (case, f)
+        if "degenerate" in case["branch"]:
+            # acos conditioning: reference itself is only good to 1e-8 here
+            assert np.allclose(eig, case["eig"], rtol=0, atol=5e-8)
+        else:
+            assert np.allclose(eig, case["eig"], rtol=1e-15, atol=1e-15), (case, eig)
+
+
+def test_fail_sentinel_and_nan_quirks():
+    o = _eds_oracle()
+    # q<0 cannot happen for real symmetric input, q^3<r^2 by round-off can: sentinel -10, fail=0 (quirk Q4)
+    f, _, fail = o.inverse_collapse_time([1.0, 1.0, 1.0 + 1e-9, 0, 0, 0])
+    assert fail == 0 and (f == -10.0 or f > 0)
+
+
+def test_spline_matches_scipy_natural():
+    from scipy.interpolate import CubicSpline
+    x, y = synth.invgrow_table("lcdm")
+    o = oracle_lib.Oracle(8, 1)
+    o.set_invgrow(x, y)
+    cs = CubicSpline(x, y, bc_type="natural")
+    xs = np.linspace(x[0], x[-1], 2001)
+    got = np.array([o.spline_eval(v) for v in xs])
+    assert np.max(np.abs(got - cs(xs))) < 5e-14
+    # knots are reproduced exactly
+    for i in (0, 1, 57, 208, 209):
+        assert o.spline_eval(x[i]) == pytest.approx(y[i], abs=1e-15)
+    # linear extrapolation outside the knots (src/cosmo.c:2016-2027)
+    lo = y[0] + (x[0] - 1.0 - x[0]) * (y[1] - y[0]) / (x[1] - x[0])
+    assert o.spline_eval(x[0] - 1.0) == pytest.approx(lo, rel=1e-15)
+    hi = y[-1] + 0.5 * (y[-1] - y[-2]) / (x[-1] - x[-2])
+    assert o.spline_eval(x[-1] + 0.5) == pytest.approx(hi, rel=1e-15)
+    # and against the numpy restatement's dense-solve spline
+    sp = npr.Spline(x, y)
+    assert np.max(np.abs(got - sp(xs))) < 5e-14
+
+
+def test_inverse_growing_mode_eds_identity():
+    o = _eds_oracle()
+    for d in (0.05, 0.3, 1.0, 1.4):
+        assert o.inverse_growing_mode(d) == pytest.approx(1.0 / d - 1.0, rel=1e-13)
+
+
+@pytest.mark.parametrize("n", [8, 16, 32])
+def test_fft_against_pocketfft(n):
+    rng = np.random.default_rng(n)
+    o = oracle_lib.Oracle(n, 2)
+    real = rng.standard_normal((n, n, n))
+    spec = o.r2c(real)
+    ref = np.fft.rfftn(real, axes=(0, 1, 2))
+    assert np.max(np.abs(spec - ref)) < 1e-12 * np.max(np.abs(ref))
+    # c2r of a NON-Hermitian half-spectrum: same semantics as irfftn (x,y c2c then z c2r)
+    junk = rng.standard_normal((n, n, n // 2 + 1)) + 1j * rng.standard_normal((n, n, n // 2 + 1))
+    got = o.c2r(junk)
+    want = np.fft.irfftn(junk, s=(n, n, n), axes=(0, 1, 2)) * n ** 3
+    assert np.max(np.abs(got - want)) < 1e-12 * np.max(np.abs(want))
+
+
+@pytest.mark.parametrize("n,rs", [(16, 0.0), (16, 1.5), (32, 2.8)])
+def test_second_derivatives_vs_numpy(n, rs):
+    dk = synth.make_density(n, seed=7 + n)
+    o = oracle_lib.Oracle(n, 2)
+    o.set_density(dk)
+    got = o.second_derivatives(rs)
+    want = npr.hessian(dk, rs)
+    scale = max(np.max(np.abs(w)) for w in want)
+    for g, w in zip(got, want):
+        assert np.max(np.abs(g - w)) < 1e-13 * scale
+
+
+@pytest.mark.parametrize("n,kind", [(16, "eds"), (32, "lcdm")])
+def test_full_sweep_and_lpt_vs_numpy(n, kind):
+    dk = synth.make_density(n, seed=synth.SEED)
+    radii = synth.radii_ladder(6) / 4.0
+    radii[-1] = 0.0
+    x, y = synth.invgrow_table(kind)
+    g = synth.growth_multipliers()
+    o = oracle_lib.Oracle(n, 2)
+    o.set_density(dk)
+    o.set_invgrow(x, y)
+    o.set_growth(g)
+    tv = o.compute_fmax(radii, do_lpt=True)
+    p = o.products()
+
+    fmax, rmax, tv_np, hes = npr.sweep(dk, radii, npr.Spline(x, y))
+    assert np.allclose(tv, tv_np, rtol=1e-12)
+    # Fmax: float32 of (nearly) the same double; allow 1 ulp on a tiny fraction
+    diff = np.abs(p["Fmax"].astype(np.float64) - fmax.astype(np.float64))
+    # tolerance: 2 ulp(fp32) evaluated at max(|F|,1); cells with F << 1 come from an
+    # ill-conditioned (cancelling) cubic root and are never used downstream (F>=1 only)
+    ulp = np.spacing(np.maximum(np.abs(fmax), 1.0).astype(np.float32)).astype(np.float64)
+    assert np.all(diff <= 2 * ulp)
+    assert np.mean(diff > 0) < 1e-3
+    assert np.mean(p["Rmax"] != rmax) < 1e-3
+    assert p["Fmax"].max() > 1.0  # something collapses
+
+    d = npr.lpt(dk, hes, g)
+    for name in ("Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+        a, b = p[name].astype(np.float64), d[name].astype(np.float64)
+        amp = np.max(np.abs(b))
+        assert amp > 0
+        assert np.max(np.abs(a - b)) <= 4e-7 * amp, name
+    k2, k31, k32 = d["_k"]
+    for which, kk in enumerate((k2, k31, k32)):
+        got = o.kvector(which)
+        assert np.max(np.abs(got - kk)) < 1e-11 * np.max(np.abs(kk))
+
+    # Fmax PDF (src/fmax.c:509-550)
+    h = o.fmax_pdf()
+    assert int(h.sum()) == n ** 3
+    xf = np.clip((p["Fmax"].astype(np.float64) * 10.0).astype(np.int64), 0, 209)
+    assert np.array_equal(h, np.bincount(xf.ravel(), minlength=210).astype(np.uint64))
+
+
+def test_thread_count_independence():
+    n = 16
+    dk = synth.make_density(n, seed=3)
+    radii = np.array([2.0, 1.0, 0.0])
+    x, y = synth.invgrow_table("lcdm")
+    res = []
+    for nt in (1, 4):
+        o = oracle_lib.Oracle(n, nt)
+        o.set_density(dk)
+        o.set_invgrow(x, y)
+        tv = o.compute_fmax(radii, do_lpt=True)
+        res.append((tv, o.products()))
+    assert np.allclose(res[0][0], res[1][0], rtol=1e-13)
+    for name in ("Fmax", "Rmax", "Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+        assert np.array_equal(res[0][1][name], res[1][1][name]), name
