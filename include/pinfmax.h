@@ -1,0 +1,169 @@
+/*
+ * pinfmax.h -- C ABI of libpinfmax_hip.so, the MI355X (gfx950) implementation
+ * of PINOCCHIO's collapse-time hot path (Fmax sweep + 2LPT/3LPT displacements).
+ *
+ * Plain C, plain pointers and sizes.  One context = one MPI rank = one GPU =
+ * one x-slab of the grid, exactly the reference's 1-D PFFT decomposition
+ * (src/initialization.c:1317-1325).  Every entry point names the reference
+ * interface it replaces (file:line relative to the reference tree).  The
+ * reference-side adapter that maps PINOCCHIO's globals onto these calls is
+ * pinocchio_amd/host/pf_compat.c; INTEGRATION.md shows the link line.
+ *
+ * Conventions (src/pinocchio.c:259-263, src/fmax.c): every function returns
+ * int, 0 = ok, non-zero = error after printing "ERROR on task %d: ..." on
+ * stdout; the caller aborts (MPI_Abort).  All ranks call every function
+ * collectively and in the same order (PFFT plans and reductions are collective
+ * in the reference too).  Not thread-safe per context (MPI_THREAD_FUNNELED).
+ * There is NO CPU fallback: without a HIP device pf_create fails.
+ */
+#ifndef PINFMAX_H
+#define PINFMAX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PF_NBINS 210     /* NBINS, src/pinocchio.h:65 (spline knots, Fmax PDF bins) */
+#define PF_MAX_SMOOTH 64 /* upper bound on Smoothing.Nsmooth accepted by pf_sweep */
+
+typedef struct pf_ctx pf_ctx;
+
+/* grid_data / FFT decomposition (src/pinocchio.h:295-308, src/fmax-pfft.c:80-134) */
+typedef struct {
+  int64_t n;        /* GSglobal[_x_] = [_y_] = [_z_] : cubic grid, power of two, 16..2048 */
+  int     rank;     /* ThisTask */
+  int     nranks;   /* NTasks; x-slabs, nranks must divide n */
+  int     device;   /* HIP device ordinal of this rank */
+  int     field_bytes; /* 8: fp64 density/derivative fields (reference); 4: fp32 fields, fp64 collapse solve */
+  int     flags;    /* PF_FLAG_* */
+} pf_config;
+
+#define PF_FLAG_TIMING 1  /* record per-kernel HIP-event timings (pf_kernel_stats) */
+
+/* layout of the caller's product_data record (src/pinocchio.h:233-259).
+   Offsets in bytes; a negative offset means "field absent".  pf_layout_3lpt()
+   fills the -DTWO_LPT -DTHREE_LPT float layout (56 B). */
+typedef struct {
+  size_t stride;     /* sizeof(product_data) */
+  int    off_Rmax, off_Fmax, off_Vel, off_Vel_2LPT, off_Vel_3LPT_1, off_Vel_3LPT_2;
+} pf_product_layout;
+void pf_layout_3lpt(pf_product_layout *l);
+
+/* cputime_data (src/pinocchio.h:368-378), seconds, device time by HIP events */
+typedef struct {
+  double fmax, deriv, fft, coll, lpt, mem_transf;
+} pf_cputime;
+
+/* --- life cycle: replaces set_one_grid + compute_fft_plans + the FFT-buffer
+       part of allocate_main_memory (src/fmax-pfft.c:80-188, src/allocations.c:382) --- */
+int  pf_create(pf_ctx **out, const pf_config *cfg);
+/* finalize_fft (src/fmax-pfft.c:231-252) + release of all device memory */
+int  pf_destroy(pf_ctx *ctx);
+const char *pf_last_error(void);
+
+/* --- multi-GPU exchange (replaces the MPI_Alltoall inside pfft_execute,
+       src/fmax-pfft.c:197,211).  One all-to-all per 3-D FFT: every rank sends
+       bytes_per_peer bytes from sendbuf + q*bytes_per_peer to rank q and
+       receives into recvbuf + p*bytes_per_peer from rank p, ordered on `stream`
+       (a hipStream_t).  Install either a callback or the built-in RCCL
+       exchange (grouped ncclSend/ncclRecv) created from a broadcast
+       ncclUniqueId (128 bytes).  Not needed when nranks == 1. --- */
+typedef int (*pf_alltoall_fn)(void *user, const void *sendbuf, void *recvbuf,
+                              size_t bytes_per_peer, void *stream);
+int pf_set_exchange(pf_ctx *ctx, pf_alltoall_fn fn, void *user);
+int pf_rccl_unique_id(void *id128);                 /* rank 0: ncclGetUniqueId */
+int pf_init_rccl(pf_ctx *ctx, const void *id128);   /* all ranks: ncclCommInitRank */
+/* small reductions (MPI_Reduce/MPI_Bcast at src/collapse_times.c:656-667,
+   src/fmax.c:527): sum `count` doubles / uint64 in place over all ranks */
+typedef int (*pf_allreduce_fn)(void *user, void *buf, size_t count, int is_u64, void *stream);
+int pf_set_allreduce(pf_ctx *ctx, pf_allreduce_fn fn, void *user);
+/* device pointers + size (bytes) of the exchange buffers, so that a host
+   harness can wrap them (e.g. torch tensors for torch.distributed) */
+int pf_exchange_buffers(pf_ctx *ctx, void **sendbuf, void **recvbuf, size_t *bytes);
+/* stream all work is enqueued on (hipStream_t); pf_set_stream adopts a caller stream */
+int pf_set_stream(pf_ctx *ctx, void *stream);
+void *pf_get_stream(pf_ctx *ctx);
+
+/* --- inputs --- */
+/* kdensity[0] (src/fmax-pfft.c:366): this rank's x-slab of the half-spectrum,
+   fp64 [n/nranks][n][n/2+1][2], pre-multiplied by N^3 (src/GenIC.c:430-445).
+   host pointer; uploaded (and converted to fp32 when field_bytes == 4). */
+int pf_set_density(pf_ctx *ctx, const double *kdensity_slab);
+/* synthetic delta(k) generated in HBM (bench / large property tests):
+   Philox-4x32 white noise, P(k) ~ k^slope inside the Nyquist sphere, DC and
+   Nyquist planes zero, sigma(R=0) = sigma0.  numpy mirror:
+   pinocchio_amd/synth.py philox_density. */
+int pf_synth_density(pf_ctx *ctx, uint64_t seed, double sigma0, double slope);
+/* SPLINE[SP_INVGROW] knots (src/cosmo.c:401): x = log10 D, y = log10 a, n knots
+   (natural cubic spline coefficients are computed on the host, GSL cspline).
+   ismooth = -1: one spline for every radius (non SCALE_DEPENDENT build);
+   ismooth >= 0: SPLINE_INVGROW[ismooth] (src/initialization.c:1704-1708). */
+int pf_set_invgrow(pf_ctx *ctx, int ismooth, const double *x, const double *y, int n);
+/* growth multipliers applied by compute_derivative when ScaleDep.order = 1..4
+   (src/fmax-pfft.c:344-364): g[0]=GrowingMode, g[1]=GrowingMode_2LPT,
+   g[2]=GrowingMode_3LPT_1 (carrying its minus sign, src/cosmo.c:1810),
+   g[3]=GrowingMode_3LPT_2, all at the target redshift, scale-independent. */
+int pf_set_growth(pf_ctx *ctx, const double g[4]);
+
+/* --- the path --- */
+/* compute_fmax's radius loop (src/fmax.c:66-150): for each radius (CELL units,
+   Rsmooth = Radius/CellSize, src/fmax.c:233) second derivatives + collapse
+   times; Smoothing.TrueVariance[0..ns-1] out (src/collapse_times.c:670). */
+int pf_sweep(pf_ctx *ctx, int ns, const double *radius_cells, double *true_variance);
+/* compute_second_derivatives (src/fmax.c:225-258): six Hessian fields at one radius */
+int pf_second_derivatives(pf_ctx *ctx, double radius_cells);
+/* compute_collapse_times (src/collapse_times.c:431-673) on the resident Hessian */
+int pf_collapse_times(pf_ctx *ctx, int ismooth, double *true_variance);
+/* compute_displacements(compute_sources, recompute_sd, z) (src/fmax.c:292-367):
+   2LPT/3LPT sources + 12 displacement fields; growth from pf_set_growth.
+   With compute_sources = 0 the resident LPT spectra are reused
+   (RECOMPUTE_DISPLACEMENTS re-entry, src/fragment.c:398-410). */
+int pf_displacements(pf_ctx *ctx, int compute_sources, int recompute_sd);
+/* Fmax_PDF (src/fmax.c:509-550): 210-bin histogram of (int)(Fmax*10), summed over ranks */
+int pf_fmax_pdf(pf_ctx *ctx, unsigned long long hist[PF_NBINS]);
+
+/* --- outputs --- */
+/* products[] of this rank's slab into the caller's AoS (host), index
+   i = z + n*(y + n*x_local) (src/pinocchio.h:84-85) */
+int pf_get_products(pf_ctx *ctx, void *products_host, const pf_product_layout *layout);
+/* debug / test taps (host copies, fp64): second_derivatives[0][i] of the last
+   pf_second_derivatives (i = 0..5 <-> 11,22,33,12,13,23; src/LPT.c:36-44),
+   compact [n/nranks][n][n]; LPT source spectra kvector_2LPT/3LPT_1/3LPT_2
+   (which = 0,1,2) gathered to the boundary layout [n/nranks][n][n/2+1][2]
+   (nranks == 1 only). */
+int pf_get_second_derivative(pf_ctx *ctx, int i, double *host);
+int pf_get_kvector(pf_ctx *ctx, int which, double *host);
+int pf_get_density(pf_ctx *ctx, double *host);  /* resident delta(k), boundary layout, nranks == 1 */
+/* stand-alone transforms on the resident buffers (forward_transform /
+   reverse_transform, src/fmax-pfft.c:191-228), host in/out, nranks == 1:
+   unnormalised r2c, and c2r followed by the 1/N^3 normalisation. */
+int pf_forward_transform(pf_ctx *ctx, const double *real_host, double *spec_host);
+int pf_reverse_transform(pf_ctx *ctx, const double *spec_host, double *real_host);
+/* per-cell solver on a list of Hessians d[6*count] -> F[count] (tests of
+   inverse_collapse_time, src/collapse_times.c:679-776), ismooth selects the spline */
+int pf_collapse_cells(pf_ctx *ctx, int ismooth, const double *d, size_t count, double *F);
+
+/* --- measurement --- */
+int pf_get_cputime(pf_ctx *ctx, pf_cputime *t);
+int pf_reset_cputime(pf_ctx *ctx);
+/* per-kernel-class HIP-event statistics over the launches since the last reset
+   (PF_FLAG_TIMING).  Fills up to `max` entries; returns the count in *n. */
+typedef struct {
+  char     name[48];
+  uint64_t launches;
+  double   total_ms;
+  double   alg_bytes;   /* algorithmic HBM bytes summed over those launches */
+} pf_kernel_stat;
+int pf_kernel_stats(pf_ctx *ctx, pf_kernel_stat *out, int max, int *n);
+int pf_reset_kernel_stats(pf_ctx *ctx);
+int pf_synchronize(pf_ctx *ctx);
+/* bytes of device memory held by the context */
+size_t pf_device_bytes(pf_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PINFMAX_H */

@@ -1,0 +1,97 @@
+"""ctypes loader of libpinfmax_hip.so (the C ABI declared in include/pinfmax.h).
+
+There is no Python or CPU implementation behind this module: if the shared
+object is missing it raises, and pf_create itself fails without a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(PKG, "libpinfmax_hip.so")
+NBINS = 210
+MAX_SMOOTH = 64
+
+FLAG_TIMING = 1
+
+
+class Config(C.Structure):
+    _fields_ = [("n", C.c_int64), ("rank", C.c_int), ("nranks", C.c_int), ("device", C.c_int),
+                ("field_bytes", C.c_int), ("flags", C.c_int)]
+
+
+class ProductLayout(C.Structure):
+    _fields_ = [("stride", C.c_size_t), ("off_Rmax", C.c_int), ("off_Fmax", C.c_int), ("off_Vel", C.c_int),
+                ("off_Vel_2LPT", C.c_int), ("off_Vel_3LPT_1", C.c_int), ("off_Vel_3LPT_2", C.c_int)]
+
+
+class CpuTime(C.Structure):
+    _fields_ = [("fmax", C.c_double), ("deriv", C.c_double), ("fft", C.c_double), ("coll", C.c_double),
+                ("lpt", C.c_double), ("mem_transf", C.c_double)]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double), ("alg_bytes", C.c_double)]
+
+
+ALLTOALL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+
+# every symbol include/pinfmax.h declares: name -> (restype, argtypes)
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+PROTOTYPES = {
+    "pf_layout_3lpt": (None, [C.POINTER(ProductLayout)]),
+    "pf_create": (C.c_int, [C.POINTER(_vp), C.POINTER(Config)]),
+    "pf_destroy": (C.c_int, [_vp]),
+    "pf_last_error": (C.c_char_p, []),
+    "pf_set_exchange": (C.c_int, [_vp, ALLTOALL_FN, _vp]),
+    "pf_rccl_unique_id": (C.c_int, [_vp]),
+    "pf_init_rccl": (C.c_int, [_vp, _vp]),
+    "pf_set_allreduce": (C.c_int, [_vp, ALLREDUCE_FN, _vp]),
+    "pf_exchange_buffers": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    "pf_set_stream": (C.c_int, [_vp, _vp]),
+    "pf_get_stream": (_vp, [_vp]),
+    "pf_set_density": (C.c_int, [_vp, _dp]),
+    "pf_synth_density": (C.c_int, [_vp, C.c_uint64, C.c_double, C.c_double]),
+    "pf_set_invgrow": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int]),
+    "pf_set_growth": (C.c_int, [_vp, _dp]),
+    "pf_sweep": (C.c_int, [_vp, C.c_int, _dp, _dp]),
+    "pf_second_derivatives": (C.c_int, [_vp, C.c_double]),
+    "pf_collapse_times": (C.c_int, [_vp, C.c_int, _dp]),
+    "pf_displacements": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "pf_fmax_pdf": (C.c_int, [_vp, C.POINTER(C.c_ulonglong)]),
+    "pf_get_products": (C.c_int, [_vp, _vp, C.POINTER(ProductLayout)]),
+    "pf_get_second_derivative": (C.c_int, [_vp, C.c_int, _dp]),
+    "pf_get_kvector": (C.c_int, [_vp, C.c_int, _dp]),
+    "pf_get_density": (C.c_int, [_vp, _dp]),
+    "pf_forward_transform": (C.c_int, [_vp, _dp, _dp]),
+    "pf_reverse_transform": (C.c_int, [_vp, _dp, _dp]),
+    "pf_collapse_cells": (C.c_int, [_vp, C.c_int, _dp, C.c_size_t, _dp]),
+    "pf_get_cputime": (C.c_int, [_vp, C.POINTER(CpuTime)]),
+    "pf_reset_cputime": (C.c_int, [_vp]),
+    "pf_kernel_stats": (C.c_int, [_vp, C.POINTER(KernelStat), C.c_int, C.POINTER(C.c_int)]),
+    "pf_reset_kernel_stats": (C.c_int, [_vp]),
+    "pf_synchronize": (C.c_int, [_vp]),
+    "pf_device_bytes": (C.c_size_t, [_vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO):
+            raise ImportError(
+                f"{SO} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). pinocchio_amd has no CPU fallback.")
+        L = C.CDLL(SO)
+        for name, (res, args) in PROTOTYPES.items():
+            f = getattr(L, name)  # AttributeError if the ABI and the header disagree
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib

@@ -1,0 +1,183 @@
+"""Host-side mirror of the reference's Fmax interface on top of the C ABI.
+
+Method names and argument meaning follow the reference (src/pinocchio.h:545-562,
+637-647): compute_fmax, compute_second_derivatives, compute_collapse_times,
+compute_displacements, Fmax_PDF.  All compute runs in libpinfmax_hip.so on the
+GPU; numpy is only the host container of inputs and outputs.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+PRODUCT_DTYPE = np.dtype(
+    [("Rmax", "<i4"), ("Fmax", "<f4"), ("Vel", "<f4", 3), ("Vel_2LPT", "<f4", 3),
+     ("Vel_3LPT_1", "<f4", 3), ("Vel_3LPT_2", "<f4", 3)], align=False)  # src/pinocchio.h:233-259, 56 B
+
+
+class PinfmaxError(RuntimeError):
+    pass
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Fmax:
+    """One rank's context: an x-slab of an n^3 grid on one MI355X."""
+
+    def __init__(self, n: int, rank: int = 0, nranks: int = 1, device: int = 0, field_bytes: int = 8,
+                 timing: bool = False):
+        self.L = _lib.load()
+        self.n, self.rank, self.nranks = int(n), int(rank), int(nranks)
+        self.nxl = self.n // self.nranks
+        cfg = _lib.Config(n=n, rank=rank, nranks=nranks, device=device, field_bytes=field_bytes,
+                          flags=_lib.FLAG_TIMING if timing else 0)
+        h = C.c_void_p()
+        self._chk(self.L.pf_create(C.byref(h), C.byref(cfg)))
+        self.h = h
+        self._keep = []
+
+    # -- plumbing ---------------------------------------------------------
+    def _chk(self, rc):
+        if rc:
+            raise PinfmaxError(self.L.pf_last_error().decode() or f"error {rc}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def synchronize(self):
+        self._chk(self.L.pf_synchronize(self.h))
+
+    @property
+    def device_bytes(self) -> int:
+        return int(self.L.pf_device_bytes(self.h))
+
+    # -- inputs -----------------------------------------------------------
+    def set_density(self, dk: np.ndarray):
+        """kdensity[0]: this rank's x-slab [nxl][n][n/2+1] complex128."""
+        dk = np.ascontiguousarray(dk, dtype=np.complex128)
+        if dk.shape != (self.nxl, self.n, self.n // 2 + 1):
+            raise ValueError(f"density slab shape {dk.shape}")
+        self._chk(self.L.pf_set_density(self.h, _dp(dk.view(np.float64))))
+
+    def synth_density(self, seed: int, sigma0: float = 2.5, slope: float = -2.0):
+        self._chk(self.L.pf_synth_density(self.h, C.c_uint64(seed), sigma0, slope))
+
+    def set_invgrow(self, x, y, ismooth: int = -1):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        self._chk(self.L.pf_set_invgrow(self.h, ismooth, _dp(x), _dp(y), len(x)))
+
+    def set_growth(self, g):
+        g = np.ascontiguousarray(g, dtype=np.float64)
+        assert g.shape == (4,)
+        self._chk(self.L.pf_set_growth(self.h, _dp(g)))
+
+    # -- the path (reference names) ----------------------------------------
+    def sweep(self, radii_cells) -> np.ndarray:
+        """radius loop of compute_fmax (src/fmax.c:66-150) -> TrueVariance[]"""
+        r = np.ascontiguousarray(radii_cells, dtype=np.float64)
+        tv = np.zeros(len(r))
+        self._chk(self.L.pf_sweep(self.h, len(r), _dp(r), _dp(tv)))
+        return tv
+
+    def compute_fmax(self, radii_cells, do_lpt: bool = True) -> np.ndarray:
+        """compute_fmax (src/fmax.c:36-190): sweep, then compute_displacements(1,0,z)"""
+        tv = self.sweep(radii_cells)
+        if do_lpt:
+            self.compute_displacements(1, 0)
+        return tv
+
+    def compute_second_derivatives(self, radius_cells: float):
+        self._chk(self.L.pf_second_derivatives(self.h, float(radius_cells)))
+
+    def compute_collapse_times(self, ismooth: int) -> float:
+        tv = C.c_double()
+        self._chk(self.L.pf_collapse_times(self.h, ismooth, C.byref(tv)))
+        return tv.value
+
+    def compute_displacements(self, compute_sources: int = 1, recompute_sd: int = 0):
+        self._chk(self.L.pf_displacements(self.h, int(compute_sources), int(recompute_sd)))
+
+    def Fmax_PDF(self) -> np.ndarray:
+        h = (C.c_ulonglong * _lib.NBINS)()
+        self._chk(self.L.pf_fmax_pdf(self.h, h))
+        return np.array(h[:], dtype=np.uint64)
+
+    # -- outputs ----------------------------------------------------------
+    def products(self) -> np.ndarray:
+        lay = _lib.ProductLayout()
+        self.L.pf_layout_3lpt(C.byref(lay))
+        out = np.zeros((self.nxl, self.n, self.n), dtype=PRODUCT_DTYPE)
+        self._chk(self.L.pf_get_products(self.h, out.ctypes.data_as(C.c_void_p), C.byref(lay)))
+        return out
+
+    def second_derivative(self, i: int) -> np.ndarray:
+        out = np.empty((self.nxl, self.n, self.n))
+        self._chk(self.L.pf_get_second_derivative(self.h, i, _dp(out)))
+        return out
+
+    def kvector(self, which: int) -> np.ndarray:
+        out = np.empty((self.n, self.n, self.n // 2 + 1), dtype=np.complex128)
+        self._chk(self.L.pf_get_kvector(self.h, which, _dp(out.view(np.float64))))
+        return out
+
+    def density(self) -> np.ndarray:
+        out = np.empty((self.n, self.n, self.n // 2 + 1), dtype=np.complex128)
+        self._chk(self.L.pf_get_density(self.h, _dp(out.view(np.float64))))
+        return out
+
+    def forward_transform(self, real: np.ndarray) -> np.ndarray:
+        real = np.ascontiguousarray(real, dtype=np.float64)
+        out = np.empty((self.n, self.n, self.n // 2 + 1), dtype=np.complex128)
+        self._chk(self.L.pf_forward_transform(self.h, _dp(real), _dp(out.view(np.float64))))
+        return out
+
+    def reverse_transform(self, spec: np.ndarray) -> np.ndarray:
+        spec = np.ascontiguousarray(spec, dtype=np.complex128)
+        out = np.empty((self.n, self.n, self.n))
+        self._chk(self.L.pf_reverse_transform(self.h, _dp(spec.view(np.float64)), _dp(out)))
+        return out
+
+    def collapse_cells(self, d: np.ndarray, ismooth: int = -1) -> np.ndarray:
+        d = np.ascontiguousarray(d, dtype=np.float64).reshape(-1, 6)
+        out = np.empty(len(d))
+        self._chk(self.L.pf_collapse_cells(self.h, ismooth, _dp(d), len(d), _dp(out)))
+        return out
+
+    # -- measurement ------------------------------------------------------
+    def cputime(self) -> dict:
+        t = _lib.CpuTime()
+        self._chk(self.L.pf_get_cputime(self.h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in t._fields_}
+
+    def reset_cputime(self):
+        self._chk(self.L.pf_reset_cputime(self.h))
+
+    def kernel_stats(self) -> list:
+        arr = (_lib.KernelStat * 32)()
+        n = C.c_int()
+        self._chk(self.L.pf_kernel_stats(self.h, arr, 32, C.byref(n)))
+        return [dict(name=arr[i].name.decode(), launches=int(arr[i].launches), total_ms=arr[i].total_ms,
+                     alg_bytes=arr[i].alg_bytes) for i in range(n.value)]
+
+    def reset_kernel_stats(self):
+        self._chk(self.L.pf_reset_kernel_stats(self.h))

@@ -1,0 +1,735 @@
+// pf_api.hip -- context, slab 3-D FFT pipelines and the C ABI of libpinfmax_hip.so.
+//
+// Data layout in HBM (per rank; P ranks, nxl = nyl = n/P, nzh = n/2+1,
+// nzp = n/2+8 so that every row of a half-spectrum starts on a 128-byte line):
+//   KY  k-space, y-distributed : [n (kx)][nyl (ky slab)][nzp]  complex F   (dk, A*, S* spectra)
+//   XS  x-slab, k in y and z   : [nxl][n (ky)][nzp]            complex F   (B*)
+//   R   real x-slab            : [nxl][n][2*nzp]               F, first n of a row used
+//       (a real row lives in the storage of the complex row it came from: c2r and
+//        r2c z-passes run in place)
+//   products                   : SoA  fmax f32, rmax i32, vel[12] f32, cell = z + n*(y + n*xl)
+//
+// One c2r 3-D transform = x-pass (KY) -> [all-to-all, P > 1] -> y-pass -> z-pass (XS -> R).
+// The six second derivatives share passes (the filter k_a k_b / k^2 * W(k) is
+// separable apart from W/k^2):  x-pass 1 -> 3 fields {1, kx, kx^2} * dk*W/k^2,
+// y-pass 3 -> 6, z-pass 6 -> 6: 4 + 9 + 12 = 25 field transfers instead of the
+// reference's 6 x (1 + 6) = 42 (src/fmax.c:225-258), and 3 all-to-alls instead of 6.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/pinfmax.h"
+#include "pf_collapse_core.h"
+#include "pf_internal.h"
+
+// ------------------------------------------------------------------ errors --
+static thread_local char g_err[512] = "";
+static int pf_fail(int task, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  printf("ERROR on task %d: %s\n", task, g_err);  // the reference's convention (src/fmax.c, src/collapse_times.c:575)
+  fflush(stdout);
+  return 1;
+}
+extern "C" const char *pf_last_error(void) { return g_err; }
+
+#define HIPCHK(ctx, call)                                                                          \
+  do {                                                                                             \
+    hipError_t e__ = (call);                                                                       \
+    if (e__ != hipSuccess)                                                                         \
+      return pf_fail((ctx) ? (ctx)->rank : 0, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+  } while (0)
+#define PFCHK(ctx, call)                                                                   \
+  do {                                                                                     \
+    int r__ = (call);                                                                      \
+    if (r__) return pf_fail((ctx)->rank, "%s failed (%d) (%s:%d)", #call, r__, __FILE__, __LINE__); \
+  } while (0)
+
+// ----------------------------------------------------------------- context --
+enum {
+  KS_XPASS_HESS = 0, KS_YPASS_HESS, KS_ZPASS_HESS, KS_COLLAPSE, KS_LPT_SRC, KS_LPT_ACC, KS_R2C_Z, KS_YPASS_FWD,
+  KS_XPASS_FWD, KS_XPASS_DISP, KS_YPASS_DISP, KS_ZPASS_DISP, KS_XPASS_PLAIN, KS_YPASS_PLAIN, KS_ZPASS_PLAIN,
+  KS_EXCHANGE, KS_MISC, KS_COUNT
+};
+static const char *ks_names[KS_COUNT] = {
+    "xpass_hess_1to3", "ypass_hess_3to6", "zpass_c2r_hess_6", "collapse", "lpt_sources", "lpt_accum", "zpass_r2c",
+    "ypass_fwd", "xpass_fwd", "xpass_disp_1to2", "ypass_disp_2to3", "zpass_c2r_disp_3", "xpass_plain", "ypass_plain",
+    "zpass_c2r_plain", "exchange", "misc"};
+
+struct EvPair { int kind; hipEvent_t a, b; double bytes; };
+
+struct SplineHost { std::vector<double> x, y, c; };
+
+struct pf_ctx {
+  pf_config cfg;
+  int n, nzh, nzp, P, rank, nxl, nyl, fb;
+  bool timing;
+  hipStream_t stream;
+  bool own_stream;
+  size_t field_bytes;  // one spectrum-sized field
+  size_t dev_bytes;
+  char *blockA;        // A[0..2] contiguous (also host<->device staging through A[1..2])
+  void *dk, *A[3], *B[6], *B2[6], *S[3];
+  void *recvA;         // P > 1: 3 fields, all-to-all destination
+  void *tw;
+  float *fmax, *vel12;
+  int *rmax;
+  double *partials;    // 2 * PF_NBLK
+  double *scal;        // device scalars, see SC_*
+  unsigned long long *hist;
+  double *spl;         // device spline tables: [slot][3][PF_KNOT_CAP]
+  int spl_n[PF_MAX_SMOOTH + 1];
+  bool spl_set[PF_MAX_SMOOTH + 1];
+  double growth[4];
+  bool have_density, have_hessian, have_sources, products_init;
+  int last_ns;
+  pf_alltoall_fn a2a; void *a2a_user;
+  pf_allreduce_fn ared; void *ared_user;
+  void *rccl;          // ncclComm_t when pf_init_rccl was used
+  // measurement
+  std::vector<EvPair> evs;
+  std::vector<hipEvent_t> evpool;
+  double ks_ms[KS_COUNT], ks_bytes[KS_COUNT];
+  unsigned long long ks_n[KS_COUNT];
+  pf_cputime cpu;
+  std::vector<EvPair> phase_evs;  // kind: 0 deriv 1 coll 2 lpt 3 mem
+};
+
+#define PF_NBLK 2048
+#define PF_KNOT_CAP 512
+enum { SC_SUM = 0, SC_SUM2 = 1, SC_DC_DK = 2, SC_DC_S2 = 3, SC_POWER = 4, SC_DSCALE = 5, SC_VAR0 = 8 /* 2 per radius */, SC_COUNT = 8 + 2 * PF_MAX_SMOOTH };
+
+static hipEvent_t ev_get(pf_ctx *c) {
+  if (!c->evpool.empty()) { hipEvent_t e = c->evpool.back(); c->evpool.pop_back(); return e; }
+  hipEvent_t e; hipEventCreate(&e); return e;
+}
+struct KTimer {
+  pf_ctx *c; int kind; double bytes; hipEvent_t a;
+  KTimer(pf_ctx *c_, int kind_, double bytes_) : c(c_), kind(kind_), bytes(bytes_), a(nullptr) {
+    if (c->timing) { a = ev_get(c); hipEventRecord(a, c->stream); }
+  }
+  ~KTimer() {
+    if (c->timing) { hipEvent_t b = ev_get(c); hipEventRecord(b, c->stream); c->evs.push_back({kind, a, b, bytes}); }
+  }
+};
+struct PhaseTimer {
+  pf_ctx *c; int kind; hipEvent_t a;
+  PhaseTimer(pf_ctx *c_, int kind_) : c(c_), kind(kind_) { a = ev_get(c); hipEventRecord(a, c->stream); }
+  ~PhaseTimer() { hipEvent_t b = ev_get(c); hipEventRecord(b, c->stream); c->phase_evs.push_back({kind, a, b, 0}); }
+};
+static void resolve_events(pf_ctx *c) {
+  hipStreamSynchronize(c->stream);
+  for (auto &e : c->evs) {
+    float ms = 0; hipEventElapsedTime(&ms, e.a, e.b);
+    c->ks_ms[e.kind] += ms; c->ks_bytes[e.kind] += e.bytes; c->ks_n[e.kind]++;
+    c->evpool.push_back(e.a); c->evpool.push_back(e.b);
+  }
+  c->evs.clear();
+  for (auto &e : c->phase_evs) {
+    float ms = 0; hipEventElapsedTime(&ms, e.a, e.b);
+    double s = 1e-3 * ms;
+    if (e.kind == 0) c->cpu.deriv += s; else if (e.kind == 1) c->cpu.coll += s; else if (e.kind == 2) c->cpu.lpt += s;
+    else if (e.kind == 3) c->cpu.mem_transf += s; else if (e.kind == 4) c->cpu.fmax += s;
+    c->evpool.push_back(e.a); c->evpool.push_back(e.b);
+  }
+  c->phase_evs.clear();
+}
+
+static int dev_alloc(pf_ctx *c, void **p, size_t bytes) {
+  HIPCHK(c, hipMalloc(p, bytes));
+  c->dev_bytes += bytes;
+  return 0;
+}
+
+extern "C" void pf_layout_3lpt(pf_product_layout *l) {
+  l->stride = 56; l->off_Rmax = 0; l->off_Fmax = 4; l->off_Vel = 8; l->off_Vel_2LPT = 20; l->off_Vel_3LPT_1 = 32; l->off_Vel_3LPT_2 = 44;
+}
+
+static size_t ncell(const pf_ctx *c) { return (size_t)c->nxl * c->n * c->n; }
+static double spec_bytes_alg(const pf_ctx *c) { return (double)c->n * c->nyl * c->nzh * 2.0 * c->fb; }  // one half-spectrum field
+static double real_bytes_alg(const pf_ctx *c) { return (double)ncell(c) * c->fb; }
+
+extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
+  if (!out || !cfg) return pf_fail(0, "pf_create: null argument");
+  *out = nullptr;
+  const int rank = cfg->rank;
+  const long long n = cfg->n;
+  if (n < 16 || n > 2048 || (n & (n - 1))) return pf_fail(rank, "pf_create: grid size %lld must be a power of two in [16, 2048]", n);
+  if (cfg->nranks < 1 || n % cfg->nranks || cfg->rank < 0 || cfg->rank >= cfg->nranks)
+    return pf_fail(rank, "pf_create: nranks %d must divide the grid size %lld (slab decomposition)", cfg->nranks, n);
+  if (cfg->field_bytes != 8 && cfg->field_bytes != 4) return pf_fail(rank, "pf_create: field_bytes must be 8 or 4");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return pf_fail(rank, "pf_create: no HIP device available (libpinfmax_hip has no CPU path)");
+  if (cfg->device < 0 || cfg->device >= ndev) return pf_fail(rank, "pf_create: device %d out of range (%d devices)", cfg->device, ndev);
+  pf_ctx *c = new pf_ctx();
+  c->cfg = *cfg; c->rank = rank; c->P = cfg->nranks; c->n = (int)n; c->nzh = c->n / 2 + 1; c->nzp = c->n / 2 + 8;
+  c->nxl = c->n / c->P; c->nyl = c->n / c->P; c->fb = cfg->field_bytes; c->timing = (cfg->flags & PF_FLAG_TIMING) != 0;
+  c->dev_bytes = 0; c->own_stream = true; c->stream = nullptr;
+  c->a2a = nullptr; c->ared = nullptr; c->a2a_user = c->ared_user = nullptr; c->rccl = nullptr;
+  c->have_density = c->have_hessian = c->have_sources = c->products_init = false; c->last_ns = 0;
+  memset(c->ks_ms, 0, sizeof(c->ks_ms)); memset(c->ks_bytes, 0, sizeof(c->ks_bytes)); memset(c->ks_n, 0, sizeof(c->ks_n));
+  memset(&c->cpu, 0, sizeof(c->cpu)); memset(c->spl_set, 0, sizeof(c->spl_set)); memset(c->spl_n, 0, sizeof(c->spl_n));
+  c->growth[0] = 1.0; c->growth[1] = 3. / 7.; c->growth[2] = -1. / 9.; c->growth[3] = 5. / 42.;
+  for (int i = 0; i < 6; i++) { c->B[i] = nullptr; c->B2[i] = nullptr; }
+  c->blockA = nullptr; c->dk = nullptr; c->recvA = nullptr; c->tw = nullptr;
+  for (int i = 0; i < 3; i++) { c->A[i] = nullptr; c->S[i] = nullptr; }
+
+  HIPCHK(c, hipSetDevice(cfg->device));
+  HIPCHK(c, hipStreamCreate(&c->stream));
+  c->field_bytes = (size_t)c->n * c->nyl * c->nzp * 2 * c->fb;
+  PFCHK(c, dev_alloc(c, &c->dk, c->field_bytes));
+  PFCHK(c, dev_alloc(c, (void **)&c->blockA, 3 * c->field_bytes));
+  for (int i = 0; i < 3; i++) c->A[i] = c->blockA + i * c->field_bytes;
+  for (int i = 0; i < 6; i++) PFCHK(c, dev_alloc(c, &c->B[i], c->field_bytes));
+  for (int i = 0; i < 3; i++) PFCHK(c, dev_alloc(c, &c->S[i], c->field_bytes));
+  if (c->P > 1) PFCHK(c, dev_alloc(c, &c->recvA, 3 * c->field_bytes));
+  const size_t nc = ncell(c);
+  PFCHK(c, dev_alloc(c, (void **)&c->fmax, nc * sizeof(float)));
+  PFCHK(c, dev_alloc(c, (void **)&c->rmax, nc * sizeof(int)));
+  PFCHK(c, dev_alloc(c, (void **)&c->vel12, 12 * nc * sizeof(float)));
+  PFCHK(c, dev_alloc(c, (void **)&c->partials, 2 * PF_NBLK * sizeof(double)));
+  PFCHK(c, dev_alloc(c, (void **)&c->scal, SC_COUNT * sizeof(double)));
+  PFCHK(c, dev_alloc(c, (void **)&c->hist, PF_NBINS * sizeof(unsigned long long)));
+  PFCHK(c, dev_alloc(c, (void **)&c->spl, (size_t)(PF_MAX_SMOOTH + 1) * 3 * PF_KNOT_CAP * sizeof(double)));
+  HIPCHK(c, hipMemsetAsync(c->scal, 0, SC_COUNT * sizeof(double), c->stream));
+  // twiddles exp(+2 pi i j / n), computed in long double on the host
+  {
+    std::vector<char> h((size_t)c->n * 2 * c->fb);
+    for (int j = 0; j < c->n; j++) {
+      long double a = 2.0L * 3.14159265358979323846264338327950288L * (long double)j / (long double)c->n;
+      double re = (double)cosl(a), im = (double)sinl(a);
+      if (j == 0) { re = 1; im = 0; } else if (4 * j == c->n) { re = 0; im = 1; } else if (2 * j == c->n) { re = -1; im = 0; } else if (4 * j == 3 * c->n) { re = 0; im = -1; }
+      if (c->fb == 8) { ((double *)h.data())[2 * j] = re; ((double *)h.data())[2 * j + 1] = im; }
+      else { ((float *)h.data())[2 * j] = (float)re; ((float *)h.data())[2 * j + 1] = (float)im; }
+    }
+    PFCHK(c, dev_alloc(c, &c->tw, h.size()));
+    HIPCHK(c, hipMemcpy(c->tw, h.data(), h.size(), hipMemcpyHostToDevice));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *out = c;
+  return 0;
+}
+
+extern "C" int pf_destroy(pf_ctx *c) {
+  if (!c) return 0;
+  hipStreamSynchronize(c->stream);
+  hipFree(c->dk); hipFree(c->blockA); hipFree(c->recvA); hipFree(c->tw);
+  for (int i = 0; i < 6; i++) { hipFree(c->B[i]); hipFree(c->B2[i]); }
+  for (int i = 0; i < 3; i++) hipFree(c->S[i]);
+  hipFree(c->fmax); hipFree(c->rmax); hipFree(c->vel12); hipFree(c->partials); hipFree(c->scal); hipFree(c->hist); hipFree(c->spl);
+  for (auto &e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+  for (auto &e : c->phase_evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+  for (auto e : c->evpool) hipEventDestroy(e);
+  if (c->own_stream) hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}
+
+extern "C" int pf_set_stream(pf_ctx *c, void *stream) {
+  if (!c) return 1;
+  hipStreamSynchronize(c->stream);
+  if (c->own_stream) hipStreamDestroy(c->stream);
+  c->stream = (hipStream_t)stream; c->own_stream = false;
+  return 0;
+}
+extern "C" void *pf_get_stream(pf_ctx *c) { return c ? (void *)c->stream : nullptr; }
+extern "C" int pf_synchronize(pf_ctx *c) { HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
+extern "C" size_t pf_device_bytes(pf_ctx *c) { return c ? c->dev_bytes : 0; }
+
+extern "C" int pf_set_exchange(pf_ctx *c, pf_alltoall_fn fn, void *user) { c->a2a = fn; c->a2a_user = user; return 0; }
+extern "C" int pf_set_allreduce(pf_ctx *c, pf_allreduce_fn fn, void *user) { c->ared = fn; c->ared_user = user; return 0; }
+extern "C" int pf_exchange_buffers(pf_ctx *c, void **sendbuf, void **recvbuf, size_t *bytes) {
+  if (sendbuf) *sendbuf = c->blockA;
+  if (recvbuf) *recvbuf = c->recvA;
+  if (bytes) *bytes = 3 * c->field_bytes;
+  return 0;
+}
+
+// all-to-all of one field (KY block q <-> XS block p); a no-op on one rank
+static int exchange(pf_ctx *c, const void *send, void *recv) {
+  if (c->P == 1) return 0;
+  if (!c->a2a) return pf_fail(c->rank, "no exchange installed for %d ranks (pf_set_exchange / pf_init_rccl)", c->P);
+  KTimer t(c, KS_EXCHANGE, (double)c->field_bytes);
+  if (c->a2a(c->a2a_user, send, recv, c->field_bytes / c->P, (void *)c->stream)) return pf_fail(c->rank, "all-to-all failed");
+  return 0;
+}
+static int allreduce_dev(pf_ctx *c, void *buf, size_t count, int is_u64) {
+  if (c->P == 1) return 0;
+  if (!c->ared) return pf_fail(c->rank, "no all-reduce installed for %d ranks (pf_set_allreduce / pf_init_rccl)", c->P);
+  if (c->ared(c->ared_user, buf, count, is_u64, (void *)c->stream)) return pf_fail(c->rank, "all-reduce failed");
+  return 0;
+}
+
+// ---------------------------------------------------------- pass helpers ----
+static PfAddr addr_ky_x(const pf_ctx *c) {  // KY layout, e = x, outer = y_local
+  PfAddr a; a.os = c->nzp; a.el = c->n; a.ehs = 0; a.els = (long long)c->nyl * c->nzp; return a;
+}
+static PfAddr addr_blocks_y(const pf_ctx *c) {  // P blocks [p][nxl][nyl][nzp], e = y = p*nyl + yl, outer = x_local
+  PfAddr a; a.os = (long long)c->nyl * c->nzp; a.el = c->nyl; a.ehs = (long long)c->nxl * c->nyl * c->nzp; a.els = c->nzp; return a;
+}
+static PfAddr addr_xs_y(const pf_ctx *c) {  // XS layout, e = y, outer = x_local
+  PfAddr a; a.os = (long long)c->n * c->nzp; a.el = c->n; a.ehs = 0; a.els = c->nzp; return a;
+}
+
+struct Job { const void *in; void *out; int mul; };
+
+static int xpass(pf_ctx *c, int kind, int dir, int njobs, const Job *jobs, int pre, double rs, double growth, int nin) {
+  PfStridedParams p; memset(&p, 0, sizeof(p));
+  p.njobs = njobs;
+  for (int j = 0; j < njobs; j++) { p.job[j].in = jobs[j].in; p.job[j].out = jobs[j].out; p.job[j].mul = jobs[j].mul; }
+  p.ain = p.aout = addr_ky_x(c);
+  p.ncols = c->nzh; p.nouter = c->nyl; p.pre = pre; p.outer_offset = c->rank * c->nyl; p.rs = rs; p.growth = growth; p.tw = c->tw;
+  KTimer t(c, kind, (nin + njobs) * spec_bytes_alg(c));
+  PFCHK(c, pf_launch_strided(c->fb, c->n, dir, p, c->stream));
+  return 0;
+}
+// in_blocks: input is the P received blocks (after an all-to-all) else XS; out_blocks likewise (forward direction)
+static int ypass(pf_ctx *c, int kind, int dir, int njobs, const Job *jobs, bool in_blocks, bool out_blocks, int nin) {
+  PfStridedParams p; memset(&p, 0, sizeof(p));
+  p.njobs = njobs;
+  for (int j = 0; j < njobs; j++) { p.job[j].in = jobs[j].in; p.job[j].out = jobs[j].out; p.job[j].mul = jobs[j].mul; }
+  p.ain = in_blocks ? addr_blocks_y(c) : addr_xs_y(c);
+  p.aout = out_blocks ? addr_blocks_y(c) : addr_xs_y(c);
+  p.ncols = c->nzh; p.nouter = c->nxl; p.pre = 0; p.outer_offset = 0; p.rs = 0; p.growth = 1; p.tw = c->tw;
+  KTimer t(c, kind, (nin + njobs) * spec_bytes_alg(c));
+  PFCHK(c, pf_launch_strided(c->fb, c->n, dir, p, c->stream));
+  return 0;
+}
+struct ZJob { const void *in; void *out; int mul; int f32; };
+static int zpass_c2r(pf_ctx *c, int kind, int njobs, const ZJob *jobs, const double *dc) {
+  PfC2RParams p; memset(&p, 0, sizeof(p));
+  p.njobs = njobs;
+  double outb = 0;
+  for (int j = 0; j < njobs; j++) {
+    p.job[j].in = jobs[j].in; p.job[j].out = jobs[j].out; p.job[j].mul = jobs[j].mul; p.job[j].out_f32 = jobs[j].f32;
+    outb += jobs[j].f32 ? (double)ncell(c) * 4.0 : real_bytes_alg(c);
+  }
+  p.nlines = (long long)c->nxl * c->n; p.in_pitch = c->nzp; p.out_pitch = 2 * c->nzp;
+  p.norm = 1.0 / ((double)c->n * c->n * c->n); p.dc = dc; p.tw = c->tw;
+  KTimer t(c, kind, njobs * spec_bytes_alg(c) + outb);
+  PFCHK(c, pf_launch_c2r(c->fb, c->n, p, c->stream));
+  return 0;
+}
+
+// six second derivatives of `spec` (KY layout) at smoothing rs -> six real fields out[0..5] (R layout)
+// order 11,22,33,12,13,23 (src/LPT.c:36-44); compute_second_derivatives, src/fmax.c:225-258
+static int hessian_of(pf_ctx *c, const void *spec, double rs, const double *dc, void *const out[6]) {
+  const Job xj[3] = {{spec, c->A[0], PF_MUL_ONE}, {spec, c->A[1], PF_MUL_K}, {spec, c->A[2], PF_MUL_K2}};
+  PFCHK(c, xpass(c, KS_XPASS_HESS, +1, 3, xj, 1, rs, 1.0, 1));
+  const void *R[3] = {c->A[0], c->A[1], c->A[2]};
+  if (c->P > 1) {
+    for (int f = 0; f < 3; f++) {
+      void *r = (char *)c->recvA + f * c->field_bytes;
+      PFCHK(c, exchange(c, c->A[f], r));
+      R[f] = r;
+    }
+  }
+  const Job yj[6] = {{R[2], out[0], PF_MUL_ONE}, {R[1], out[3], PF_MUL_K}, {R[1], out[4], PF_MUL_ONE},
+                     {R[0], out[1], PF_MUL_K2}, {R[0], out[5], PF_MUL_K},  {R[0], out[2], PF_MUL_ONE}};
+  PFCHK(c, ypass(c, KS_YPASS_HESS, +1, 6, yj, true, false, 3));
+  const ZJob zj[6] = {{out[0], out[0], PF_MUL_ONE, 0}, {out[1], out[1], PF_MUL_ONE, 0}, {out[2], out[2], PF_MUL_K2, 0},
+                      {out[3], out[3], PF_MUL_ONE, 0}, {out[4], out[4], PF_MUL_K, 0},   {out[5], out[5], PF_MUL_K, 0}};
+  PFCHK(c, zpass_c2r(c, KS_ZPASS_HESS, 6, zj, dc));
+  return 0;
+}
+
+// three first derivatives (displacement components) of `spec` times growth -> vel12[3*o .. 3*o+2]
+// compute_first_derivatives + write_from_rvector_to_products, src/fmax.c:193-222, src/fmax-pfft.c:563-631
+static int displacement_of(pf_ctx *c, const void *spec, double growth, int o, void *const tmp[3]) {
+  const Job xj[2] = {{spec, c->A[0], PF_MUL_ONE}, {spec, c->A[1], PF_MUL_IK}};
+  PFCHK(c, xpass(c, KS_XPASS_DISP, +1, 2, xj, 1, 0.0, growth, 1));
+  const void *R[2] = {c->A[0], c->A[1]};
+  if (c->P > 1) {
+    for (int f = 0; f < 2; f++) {
+      void *r = (char *)c->recvA + f * c->field_bytes;
+      PFCHK(c, exchange(c, c->A[f], r));
+      R[f] = r;
+    }
+  }
+  const Job yj[3] = {{R[1], tmp[0], PF_MUL_ONE}, {R[0], tmp[1], PF_MUL_IK}, {R[0], tmp[2], PF_MUL_ONE}};
+  PFCHK(c, ypass(c, KS_YPASS_DISP, +1, 3, yj, true, false, 2));
+  const size_t nc = ncell(c);
+  const ZJob zj[3] = {{tmp[0], c->vel12 + (size_t)(3 * o + 0) * nc, PF_MUL_ONE, 1},
+                      {tmp[1], c->vel12 + (size_t)(3 * o + 1) * nc, PF_MUL_ONE, 1},
+                      {tmp[2], c->vel12 + (size_t)(3 * o + 2) * nc, PF_MUL_IK, 1}};
+  PFCHK(c, zpass_c2r(c, KS_ZPASS_DISP, 3, zj, nullptr));
+  return 0;
+}
+
+// unnormalised r2c of the real field in `f` (R layout) -> spectrum in `f` (KY layout), in place
+// forward_transform, src/fmax-pfft.c:191-200
+static int forward_of(pf_ctx *c, void *f) {
+  {
+    PfR2CParams p; p.in = f; p.out = f; p.nlines = (long long)c->nxl * c->n; p.in_pitch = 2 * c->nzp; p.out_pitch = c->nzp; p.tw = c->tw;
+    KTimer t(c, KS_R2C_Z, real_bytes_alg(c) + spec_bytes_alg(c));
+    PFCHK(c, pf_launch_r2c(c->fb, c->n, p, c->stream));
+  }
+  if (c->P == 1) {
+    const Job yj[1] = {{f, f, PF_MUL_ONE}};
+    PFCHK(c, ypass(c, KS_YPASS_FWD, -1, 1, yj, false, false, 1));
+  } else {
+    const Job yj[1] = {{f, c->A[0], PF_MUL_ONE}};
+    PFCHK(c, ypass(c, KS_YPASS_FWD, -1, 1, yj, false, true, 1));
+    PFCHK(c, exchange(c, c->A[0], f));
+  }
+  const Job xj[1] = {{f, f, PF_MUL_ONE}};
+  PFCHK(c, xpass(c, KS_XPASS_FWD, -1, 1, xj, 0, 0.0, 1.0, 1));
+  return 0;
+}
+
+// plain c2r of the spectrum in `f` (KY) -> real in `f` (R) times 1/N^3, in place (reverse_transform)
+static int reverse_of(pf_ctx *c, void *f) {
+  const Job xj[1] = {{f, f, PF_MUL_ONE}};
+  PFCHK(c, xpass(c, KS_XPASS_PLAIN, +1, 1, xj, 0, 0.0, 1.0, 1));
+  const void *R = f;
+  if (c->P > 1) { PFCHK(c, exchange(c, f, c->recvA)); R = c->recvA; }
+  const Job yj[1] = {{R, f, PF_MUL_ONE}};
+  PFCHK(c, ypass(c, KS_YPASS_PLAIN, +1, 1, yj, true, false, 1));
+  const ZJob zj[1] = {{f, f, PF_MUL_ONE, 0}};
+  PFCHK(c, zpass_c2r(c, KS_ZPASS_PLAIN, 1, zj, nullptr));
+  return 0;
+}
+
+static char *staging(pf_ctx *c) { return (char *)c->A[1]; }  // 2 fields of scratch for fp64 host<->device traffic
+
+// ------------------------------------------------------------------ inputs --
+extern "C" int pf_set_density(pf_ctx *c, const double *kd) {
+  if (!c || !kd) return pf_fail(0, "pf_set_density: null argument");
+  if (c->P > 1) return pf_fail(c->rank, "pf_set_density: boundary->internal redistribution over %d ranks not available yet; use pf_synth_density", c->P);
+  PhaseTimer pt(c, 3);
+  const long long nrows = (long long)c->n * c->n;
+  const size_t hb = (size_t)nrows * c->nzh * 2 * sizeof(double);
+  HIPCHK(c, hipMemcpyAsync(staging(c), kd, hb, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->dk, 0, c->field_bytes, c->stream));
+  PFCHK(c, pf_launch_spec_import(c->fb, (const double *)staging(c), c->dk, nrows, c->nzh, c->nzp, c->stream));
+  // DC mode: untouched by the k-filter (k^2 = 0, src/fmax-pfft.c:368), so it adds Re(dk[0])/N^3 to every second derivative
+  const double dcv = kd[0] / ((double)c->n * c->n * c->n);
+  HIPCHK(c, hipMemcpyAsync(c->scal + SC_DC_DK, &dcv, sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->have_density = true; c->have_hessian = false; c->have_sources = false;
+  return 0;
+}
+
+extern "C" int pf_synth_density(pf_ctx *c, uint64_t seed, double sigma0, double slope) {
+  if (!c) return 1;
+  // white noise (R layout) -> r2c -> shape -> normalise
+  PFCHK(c, pf_launch_white(c->fb, c->dk, (long long)c->nxl * c->n, (long long)c->rank * c->nxl * c->n, c->n, 2 * c->nzp, seed, c->stream));
+  PFCHK(c, forward_of(c, c->dk));
+  PfShapeParams p; memset(&p, 0, sizeof(p));
+  p.spec = c->dk; p.n = c->n; p.nzp = c->nzp; p.nyl = c->nyl; p.y0 = c->rank * c->nyl; p.slope = slope; p.scale = 1.0;
+  p.partials = c->partials; p.nblocks = PF_NBLK; p.mode = 0; p.dscale = nullptr;
+  PFCHK(c, pf_launch_shape(c->fb, p, c->stream));
+  PFCHK(c, pf_launch_sum1(c->partials, PF_NBLK, 1.0, c->scal + SC_POWER, c->stream));
+  PFCHK(c, allreduce_dev(c, c->scal + SC_POWER, 1, 0));
+  PFCHK(c, pf_launch_sigma_scale(c->scal + SC_POWER, sigma0, (double)c->n * c->n * c->n, c->scal + SC_DSCALE, c->stream));
+  p.mode = 1; p.dscale = c->scal + SC_DSCALE;
+  PFCHK(c, pf_launch_shape(c->fb, p, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->scal + SC_DC_DK, 0, sizeof(double), c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->have_density = true; c->have_hessian = false; c->have_sources = false;
+  return 0;
+}
+
+extern "C" int pf_set_invgrow(pf_ctx *c, int ismooth, const double *x, const double *y, int n) {
+  if (!c || !x || !y) return pf_fail(0, "pf_set_invgrow: null argument");
+  if (n < 3 || n > PF_KNOT_CAP) return pf_fail(c->rank, "pf_set_invgrow: %d knots not in [3, %d]", n, PF_KNOT_CAP);
+  if (ismooth < -1 || ismooth >= PF_MAX_SMOOTH) return pf_fail(c->rank, "pf_set_invgrow: ismooth %d out of range", ismooth);
+  for (int i = 1; i < n; i++)
+    if (!(x[i] > x[i - 1])) return pf_fail(c->rank, "pf_set_invgrow: knots must be strictly increasing (i=%d)", i);
+  std::vector<double> h(3 * PF_KNOT_CAP, 0.0);
+  memcpy(&h[0], x, n * sizeof(double));
+  memcpy(&h[PF_KNOT_CAP], y, n * sizeof(double));
+  if (pf_spline_coeffs(x, y, n, &h[2 * PF_KNOT_CAP])) return pf_fail(c->rank, "pf_set_invgrow: spline set-up failed");
+  const int slot = ismooth + 1;  // slot 0 = shared spline
+  HIPCHK(c, hipMemcpy(c->spl + (size_t)slot * 3 * PF_KNOT_CAP, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+  c->spl_n[slot] = n; c->spl_set[slot] = true;
+  return 0;
+}
+static int spline_for(pf_ctx *c, int ismooth, PfSplineDev *s) {
+  int slot = (ismooth >= 0 && ismooth < PF_MAX_SMOOTH && c->spl_set[ismooth + 1]) ? ismooth + 1 : 0;
+  if (!c->spl_set[slot]) return pf_fail(c->rank, "inverse-growth spline not set (pf_set_invgrow)");
+  const double *b = c->spl + (size_t)slot * 3 * PF_KNOT_CAP;
+  s->x = b; s->y = b + PF_KNOT_CAP; s->c = b + 2 * PF_KNOT_CAP; s->n = c->spl_n[slot];
+  return 0;
+}
+
+extern "C" int pf_set_growth(pf_ctx *c, const double g[4]) {
+  if (!c || !g) return 1;
+  memcpy(c->growth, g, 4 * sizeof(double));
+  return 0;
+}
+
+// ---------------------------------------------------------------- the path --
+extern "C" int pf_second_derivatives(pf_ctx *c, double rs) {
+  if (!c) return 1;
+  if (!c->have_density) return pf_fail(c->rank, "pf_second_derivatives: density not set");
+  PhaseTimer pt(c, 0);
+  PFCHK(c, hessian_of(c, c->dk, rs, c->scal + SC_DC_DK, c->B));
+  c->have_hessian = true;
+  return 0;
+}
+
+static int collapse_enqueue(pf_ctx *c, int ismooth) {
+  PfCollapseParams p; memset(&p, 0, sizeof(p));
+  for (int i = 0; i < 6; i++) p.h[i] = c->B[i];
+  p.pitch = 2 * c->nzp; p.nrows = (long long)c->nxl * c->n; p.n = c->n; p.fmax = c->fmax; p.rmax = c->rmax; p.ismooth = ismooth;
+  if (spline_for(c, ismooth, &p.spline)) return 1;
+  p.partials = c->partials;
+  size_t nb = (ncell(c) + 255) / 256; if (nb > PF_NBLK) nb = PF_NBLK;
+  p.nblocks = (int)nb;
+  {
+    KTimer t(c, KS_COLLAPSE, (double)ncell(c) * (6.0 * c->fb + 16.0));
+    PFCHK(c, pf_launch_collapse(c->fb, p, c->stream));
+  }
+  PFCHK(c, pf_launch_final_sum(c->partials, p.nblocks, c->scal + SC_VAR0 + 2 * ismooth, c->stream));
+  return 0;
+}
+
+extern "C" int pf_collapse_times(pf_ctx *c, int ismooth, double *tv) {
+  if (!c) return 1;
+  if (!c->have_hessian) return pf_fail(c->rank, "pf_collapse_times: second derivatives not computed");
+  if (ismooth < 0 || ismooth >= PF_MAX_SMOOTH) return pf_fail(c->rank, "pf_collapse_times: ismooth %d out of range", ismooth);
+  if (ismooth == 0) {  // src/collapse_times.c:461-492
+    PFCHK(c, pf_launch_fill_products(c->fmax, c->rmax, c->vel12, ncell(c), c->stream));
+    c->products_init = true;
+  } else if (!c->products_init)
+    return pf_fail(c->rank, "pf_collapse_times: products not initialised (ismooth 0 must come first)");
+  {
+    PhaseTimer pt(c, 1);
+    if (collapse_enqueue(c, ismooth)) return 1;
+  }
+  PFCHK(c, allreduce_dev(c, c->scal + SC_VAR0 + 2 * ismooth, 2, 0));
+  double s[2];
+  HIPCHK(c, hipMemcpyAsync(s, c->scal + SC_VAR0 + 2 * ismooth, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (tv) *tv = s[1] / ((double)c->n * c->n * c->n);  // src/collapse_times.c:662,670
+  return 0;
+}
+
+extern "C" int pf_sweep(pf_ctx *c, int ns, const double *radius_cells, double *true_variance) {
+  if (!c || !radius_cells) return pf_fail(0, "pf_sweep: null argument");
+  if (ns < 1 || ns > PF_MAX_SMOOTH) return pf_fail(c->rank, "pf_sweep: Nsmooth %d not in [1, %d]", ns, PF_MAX_SMOOTH);
+  if (!c->have_density) return pf_fail(c->rank, "pf_sweep: density not set");
+  PhaseTimer ft(c, 4);
+  PFCHK(c, pf_launch_fill_products(c->fmax, c->rmax, c->vel12, ncell(c), c->stream));
+  c->products_init = true;
+  for (int ismooth = 0; ismooth < ns; ismooth++) {
+    {
+      PhaseTimer pt(c, 0);
+      PFCHK(c, hessian_of(c, c->dk, radius_cells[ismooth], c->scal + SC_DC_DK, c->B));
+    }
+    {
+      PhaseTimer pt(c, 1);
+      if (collapse_enqueue(c, ismooth)) return 1;
+    }
+  }
+  c->have_hessian = true; c->last_ns = ns;
+  PFCHK(c, allreduce_dev(c, c->scal + SC_VAR0, 2 * (size_t)ns, 0));
+  std::vector<double> s(2 * ns);
+  HIPCHK(c, hipMemcpyAsync(s.data(), c->scal + SC_VAR0, 2 * ns * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (true_variance)
+    for (int i = 0; i < ns; i++) true_variance[i] = s[2 * i + 1] / ((double)c->n * c->n * c->n);
+  return 0;
+}
+
+extern "C" int pf_displacements(pf_ctx *c, int compute_sources, int recompute_sd) {
+  if (!c) return 1;
+  if (!c->have_density) return pf_fail(c->rank, "pf_displacements: density not set");
+  for (int i = 0; i < 6; i++)
+    if (!c->B2[i]) PFCHK(c, dev_alloc(c, &c->B2[i], c->field_bytes));
+  if (!c->products_init) {
+    PFCHK(c, pf_launch_fill_products(c->fmax, c->rmax, c->vel12, ncell(c), c->stream));
+    c->products_init = true;
+  }
+  if (recompute_sd) {  // src/fmax.c:301-318
+    PhaseTimer pt(c, 0);
+    PFCHK(c, hessian_of(c, c->dk, 0.0, c->scal + SC_DC_DK, c->B));
+    c->have_hessian = true;
+  }
+  {
+    PhaseTimer pt(c, 2);
+    if (compute_sources) {  // src/LPT.c:46-175
+      if (!c->have_hessian) return pf_fail(c->rank, "pf_displacements: second derivatives at R=0 not in place");
+      PfLptSrcParams sp; memset(&sp, 0, sizeof(sp));
+      for (int i = 0; i < 6; i++) sp.h[i] = c->B[i];
+      sp.s2 = c->S[0]; sp.s3a = c->S[1]; sp.s3b = c->S[2]; sp.pitch = 2 * c->nzp; sp.nrows = (long long)c->nxl * c->n; sp.n = c->n;
+      sp.partials = c->partials;
+      size_t nb = (ncell(c) + 255) / 256; if (nb > PF_NBLK) nb = PF_NBLK;
+      sp.nblocks = (int)nb;
+      {
+        KTimer t(c, KS_LPT_SRC, 9.0 * real_bytes_alg(c));
+        PFCHK(c, pf_launch_lpt_sources(c->fb, sp, c->stream));
+      }
+      // DC of the 2LPT source spectrum = sum of S2; it passes the k-filter untouched (k^2 = 0)
+      PFCHK(c, pf_launch_sum1(c->partials, sp.nblocks, 1.0 / ((double)c->n * c->n * c->n), c->scal + SC_DC_S2, c->stream));
+      PFCHK(c, allreduce_dev(c, c->scal + SC_DC_S2, 1, 0));
+      PFCHK(c, forward_of(c, c->S[0]));
+      PFCHK(c, hessian_of(c, c->S[0], 0.0, c->scal + SC_DC_S2, c->B2));
+      PfLptAccParams ap; memset(&ap, 0, sizeof(ap));
+      for (int i = 0; i < 6; i++) { ap.h[i] = c->B[i]; ap.phi2[i] = c->B2[i]; }
+      ap.s3b = c->S[2]; ap.pitch = 2 * c->nzp; ap.nrows = (long long)c->nxl * c->n; ap.n = c->n;
+      {
+        KTimer t(c, KS_LPT_ACC, 14.0 * real_bytes_alg(c));
+        PFCHK(c, pf_launch_lpt_accum(c->fb, ap, c->stream));
+      }
+      PFCHK(c, forward_of(c, c->S[1]));
+      PFCHK(c, forward_of(c, c->S[2]));
+      c->have_sources = true;
+    } else if (!c->have_sources)
+      return pf_fail(c->rank, "pf_displacements: LPT sources not resident (call with compute_sources = 1 first)");
+    void *tmp[3] = {c->B2[0], c->B2[1], c->B2[2]};
+    PFCHK(c, displacement_of(c, c->S[0], c->growth[1], 1, tmp));  // ScaleDep.order = 2, src/LPT.c:181-184
+    PFCHK(c, displacement_of(c, c->S[1], c->growth[2], 2, tmp));  // order 3, :219-221
+    PFCHK(c, displacement_of(c, c->S[2], c->growth[3], 3, tmp));  // order 4, :226-228
+  }
+  {
+    PhaseTimer pt(c, 0);
+    void *tmp[3] = {c->B2[0], c->B2[1], c->B2[2]};
+    PFCHK(c, displacement_of(c, c->dk, c->growth[0], 0, tmp));    // Zel'dovich, src/fmax.c:342-345
+  }
+  return 0;
+}
+
+extern "C" int pf_fmax_pdf(pf_ctx *c, unsigned long long hist[PF_NBINS]) {
+  if (!c || !hist) return 1;
+  HIPCHK(c, hipMemsetAsync(c->hist, 0, PF_NBINS * sizeof(unsigned long long), c->stream));
+  PFCHK(c, pf_launch_fmax_pdf(c->fmax, ncell(c), c->hist, c->stream));
+  PFCHK(c, allreduce_dev(c, c->hist, PF_NBINS, 1));
+  HIPCHK(c, hipMemcpyAsync(hist, c->hist, PF_NBINS * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ----------------------------------------------------------------- outputs --
+extern "C" int pf_get_products(pf_ctx *c, void *host, const pf_product_layout *l) {
+  if (!c || !host || !l) return pf_fail(0, "pf_get_products: null argument");
+  if (l->stride < 8 || l->stride % 4) return pf_fail(c->rank, "pf_get_products: bad stride %zu", l->stride);
+  PhaseTimer pt(c, 3);
+  const size_t nc = ncell(c);
+  const size_t cap = (2 * c->field_bytes) / l->stride;  // records per chunk in the staging area
+  const int ov[4] = {l->off_Vel, l->off_Vel_2LPT, l->off_Vel_3LPT_1, l->off_Vel_3LPT_2};
+  for (size_t first = 0; first < nc; first += cap) {
+    const size_t cnt = (nc - first < cap) ? nc - first : cap;
+    HIPCHK(c, hipMemsetAsync(staging(c), 0, cnt * l->stride, c->stream));
+    PFCHK(c, pf_launch_pack_products(c->fmax, c->rmax, c->vel12, nc, first, cnt, staging(c), l->stride, l->off_Rmax, l->off_Fmax, ov, c->stream));
+    HIPCHK(c, hipMemcpyAsync((char *)host + first * l->stride, staging(c), cnt * l->stride, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return 0;
+}
+
+extern "C" int pf_get_second_derivative(pf_ctx *c, int i, double *host) {
+  if (!c || !host || i < 0 || i > 5) return pf_fail(0, "pf_get_second_derivative: bad argument");
+  if (!c->have_hessian) return pf_fail(c->rank, "pf_get_second_derivative: not computed");
+  const long long nrows = (long long)c->nxl * c->n;
+  PFCHK(c, pf_launch_real_export(c->fb, c->B[i], (double *)staging(c), nrows, c->n, 2 * c->nzp, c->stream));
+  HIPCHK(c, hipMemcpyAsync(host, staging(c), (size_t)nrows * c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+static int export_spec(pf_ctx *c, const void *spec, double *host) {
+  if (c->P > 1) return pf_fail(c->rank, "spectrum export to the boundary layout needs nranks == 1");
+  const long long nrows = (long long)c->n * c->n;
+  PFCHK(c, pf_launch_spec_export(c->fb, spec, (double *)staging(c), nrows, c->nzh, c->nzp, c->stream));
+  HIPCHK(c, hipMemcpyAsync(host, staging(c), (size_t)nrows * c->nzh * 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+extern "C" int pf_get_kvector(pf_ctx *c, int which, double *host) {
+  if (!c || !host || which < 0 || which > 2) return pf_fail(0, "pf_get_kvector: bad argument");
+  if (!c->have_sources) return pf_fail(c->rank, "pf_get_kvector: LPT sources not computed");
+  return export_spec(c, c->S[which], host);
+}
+extern "C" int pf_get_density(pf_ctx *c, double *host) {
+  if (!c || !host) return 1;
+  if (!c->have_density) return pf_fail(c->rank, "pf_get_density: density not set");
+  return export_spec(c, c->dk, host);
+}
+
+extern "C" int pf_forward_transform(pf_ctx *c, const double *real_host, double *spec_host) {
+  if (!c || !real_host || !spec_host) return 1;
+  if (c->P > 1) return pf_fail(c->rank, "pf_forward_transform: host in/out needs nranks == 1");
+  const long long nrows = (long long)c->n * c->n;
+  HIPCHK(c, hipMemcpyAsync(staging(c), real_host, (size_t)nrows * c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  PFCHK(c, pf_launch_real_import(c->fb, (const double *)staging(c), c->A[0], nrows, c->n, 2 * c->nzp, c->stream));
+  PFCHK(c, forward_of(c, c->A[0]));
+  return export_spec(c, c->A[0], spec_host);
+}
+extern "C" int pf_reverse_transform(pf_ctx *c, const double *spec_host, double *real_host) {
+  if (!c || !real_host || !spec_host) return 1;
+  if (c->P > 1) return pf_fail(c->rank, "pf_reverse_transform: host in/out needs nranks == 1");
+  const long long nrows = (long long)c->n * c->n;
+  HIPCHK(c, hipMemcpyAsync(staging(c), spec_host, (size_t)nrows * c->nzh * 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  PFCHK(c, pf_launch_spec_import(c->fb, (const double *)staging(c), c->A[0], nrows, c->nzh, c->nzp, c->stream));
+  PFCHK(c, reverse_of(c, c->A[0]));
+  PFCHK(c, pf_launch_real_export(c->fb, c->A[0], (double *)staging(c), nrows, c->n, 2 * c->nzp, c->stream));
+  HIPCHK(c, hipMemcpyAsync(real_host, staging(c), (size_t)nrows * c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int pf_collapse_cells(pf_ctx *c, int ismooth, const double *d, size_t count, double *F) {
+  if (!c || !d || !F) return 1;
+  if (count * 7 * sizeof(double) > 2 * c->field_bytes) return pf_fail(c->rank, "pf_collapse_cells: %zu cells exceed the staging area", count);
+  PfSplineDev s;
+  if (spline_for(c, ismooth, &s)) return 1;
+  double *dd = (double *)staging(c), *df = dd + 6 * count;
+  HIPCHK(c, hipMemcpyAsync(dd, d, 6 * count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  PFCHK(c, pf_launch_collapse_cells(dd, count, s, df, c->stream));
+  HIPCHK(c, hipMemcpyAsync(F, df, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ------------------------------------------------------------- measurement --
+extern "C" int pf_get_cputime(pf_ctx *c, pf_cputime *t) {
+  if (!c || !t) return 1;
+  resolve_events(c);
+  *t = c->cpu;
+  // FFT share: every pass kernel (src/fmax-pfft.c:195-199 times pfft_execute only)
+  resolve_events(c);
+  double fft = 0;
+  for (int k = 0; k < KS_COUNT; k++)
+    if (k != KS_COLLAPSE && k != KS_LPT_SRC && k != KS_LPT_ACC && k != KS_MISC) fft += 1e-3 * c->ks_ms[k];
+  t->fft = fft;
+  return 0;
+}
+extern "C" int pf_reset_cputime(pf_ctx *c) { if (!c) return 1; resolve_events(c); memset(&c->cpu, 0, sizeof(c->cpu)); return 0; }
+extern "C" int pf_kernel_stats(pf_ctx *c, pf_kernel_stat *out, int max, int *n) {
+  if (!c || !out || !n) return 1;
+  resolve_events(c);
+  int k = 0;
+  for (int i = 0; i < KS_COUNT && k < max; i++) {
+    if (!c->ks_n[i]) continue;
+    memset(&out[k], 0, sizeof(out[k]));
+    strncpy(out[k].name, ks_names[i], sizeof(out[k].name) - 1);
+    out[k].launches = c->ks_n[i]; out[k].total_ms = c->ks_ms[i]; out[k].alg_bytes = c->ks_bytes[i];
+    k++;
+  }
+  *n = k;
+  return 0;
+}
+extern "C" int pf_reset_kernel_stats(pf_ctx *c) {
+  if (!c) return 1;
+  resolve_events(c);
+  memset(c->ks_ms, 0, sizeof(c->ks_ms)); memset(c->ks_bytes, 0, sizeof(c->ks_bytes)); memset(c->ks_n, 0, sizeof(c->ks_n));
+  return 0;
+}
+
+// used by pf_rccl.cpp
+extern "C" int pf_ctx_rank_size(pf_ctx *c, int *rank, int *nranks) {
+  if (!c) return 1;
+  *rank = c->rank; *nranks = c->P;
+  return 0;
+}

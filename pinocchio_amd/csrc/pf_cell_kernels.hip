@@ -1,0 +1,315 @@
+// pf_cell_kernels.hip -- per-cell kernels of the path (gfx950): collapse-time
+// solve with running max (src/collapse_times.c:431-673), LPT sources
+// (src/LPT.c:64-93, :134-137), products init/pack (src/collapse_times.c:461-492,
+// src/fmax-pfft.c:563-631), Fmax PDF (src/fmax.c:509-550), layout converters.
+#include "pf_internal.h"
+#include "pf_collapse_core.h"
+
+#define PF_CELL_BLOCK 256
+#define PF_MAX_KNOTS 512
+
+// deterministic block reduction of two doubles: wave shuffle, then thread 0 sums the waves in order
+__device__ __forceinline__ void pf_block_sum2(double &a, double &b, double *sh /* 2*nwaves */) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_down(a, off, 64);
+    b += __shfl_down(b, off, 64);
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if (lane == 0) { sh[2 * w] = a; sh[2 * w + 1] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sa = 0, sb = 0;
+    for (int i = 0; i < nw; i++) { sa += sh[2 * i]; sb += sh[2 * i + 1]; }
+    a = sa; b = sb;
+  }
+}
+
+// K6: one thread per cell, grid-stride.  fp64 math whatever the field precision.
+template <typename F>
+__global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse(const PfCollapseParams p) {
+  __shared__ double sk[3 * PF_MAX_KNOTS];
+  __shared__ double red[2 * (PF_CELL_BLOCK / 64)];
+  const int nk = p.spline.n;
+  for (int i = threadIdx.x; i < nk; i += blockDim.x) {
+    sk[i] = p.spline.x[i];
+    sk[PF_MAX_KNOTS + i] = p.spline.y[i];
+    sk[2 * PF_MAX_KNOTS + i] = p.spline.c[i];
+  }
+  __syncthreads();
+  pf_spline_view sv;
+  sv.x = sk; sv.y = sk + PF_MAX_KNOTS; sv.c = sk + 2 * PF_MAX_KNOTS; sv.n = nk;
+
+  const F *__restrict__ h0 = (const F *)p.h[0], *__restrict__ h1 = (const F *)p.h[1],
+          *__restrict__ h2 = (const F *)p.h[2], *__restrict__ h3 = (const F *)p.h[3],
+          *__restrict__ h4 = (const F *)p.h[4], *__restrict__ h5 = (const F *)p.h[5];
+  const long long ncell = p.nrows * p.n;
+  double sum = 0.0, sum2 = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < ncell; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / p.n;
+    const long long a = row * p.pitch + (i - row * p.n);
+    double d[6] = {(double)h0[a], (double)h1[a], (double)h2[a], (double)h3[a], (double)h4[a], (double)h5[a]};
+    const double delta = d[0] + d[1] + d[2];
+    sum += delta;
+    sum2 += delta * delta;
+    double lam[3];
+    const double Fnew = pf_inverse_collapse_time(d, sv, lam);
+    // products[].Fmax is float, compared after promotion (quirk Q2); init -10 / -1 at ismooth 0
+    const float fold = p.ismooth ? p.fmax[i] : -10.0f;
+    if ((double)fold < Fnew) {
+      p.fmax[i] = (float)Fnew;
+      p.rmax[i] = p.ismooth;
+    } else if (!p.ismooth) {
+      p.fmax[i] = -10.0f;
+      p.rmax[i] = -1;
+    }
+  }
+  pf_block_sum2(sum, sum2, red);
+  if (threadIdx.x == 0) {
+    p.partials[2 * blockIdx.x] = sum;
+    p.partials[2 * blockIdx.x + 1] = sum2;
+  }
+}
+
+__global__ void k_final_sum2(const double *partials, int nblocks, double *out2) {
+  // single thread, fixed order: bitwise reproducible
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double a = 0, b = 0;
+    for (int i = 0; i < nblocks; i++) { a += partials[2 * i]; b += partials[2 * i + 1]; }
+    out2[0] = a; out2[1] = b;
+  }
+}
+
+__global__ void k_sum1(const double *partials, int nblocks, double scale, double *out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double a = 0;
+    for (int i = 0; i < nblocks; i++) a += partials[i];
+    out[0] = a * scale;
+  }
+}
+
+__global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse_cells(const double *d, size_t count, PfSplineDev s, double *F) {
+  pf_spline_view sv;
+  sv.x = s.x; sv.y = s.y; sv.c = s.c; sv.n = s.n;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    double t[6], lam[3];
+    for (int k = 0; k < 6; k++) t[k] = d[6 * i + k];
+    F[i] = pf_inverse_collapse_time(t, sv, lam);
+  }
+}
+
+// K7 (src/LPT.c:64-93)
+template <typename F>
+__global__ void __launch_bounds__(PF_CELL_BLOCK) k_lpt_sources(const PfLptSrcParams p) {
+  __shared__ double red[2 * (PF_CELL_BLOCK / 64)];
+  const F *__restrict__ h0 = (const F *)p.h[0], *__restrict__ h1 = (const F *)p.h[1],
+          *__restrict__ h2 = (const F *)p.h[2], *__restrict__ h3 = (const F *)p.h[3],
+          *__restrict__ h4 = (const F *)p.h[4], *__restrict__ h5 = (const F *)p.h[5];
+  F *__restrict__ s2 = (F *)p.s2, *__restrict__ s3a = (F *)p.s3a, *__restrict__ s3b = (F *)p.s3b;
+  const long long ncell = p.nrows * p.n;
+  double acc = 0.0, dummy = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < ncell; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / p.n;
+    const long long a = row * p.pitch + (i - row * p.n);
+    const double d0 = h0[a], d1 = h1[a], d2 = h2[a], d3 = h3[a], d4 = h4[a], d5 = h5[a];
+    const double src2 = d0 * d1 + d0 * d2 + d1 * d2 - d3 * d3 - d4 * d4 - d5 * d5;
+    const double src31 = 3.0 * (d0 * (d1 * d2 - d5 * d5) - d3 * (d3 * d2 - d4 * d5) + d4 * (d3 * d5 - d4 * d1));
+    const double src32 = 2.0 * (d0 + d1 + d2) * src2;
+    s2[a] = (F)src2;
+    s3a[a] = (F)src31;
+    s3b[a] = (F)src32;
+    acc += (double)(F)src2;
+  }
+  pf_block_sum2(acc, dummy, red);
+  if (threadIdx.x == 0) p.partials[blockIdx.x] = acc;
+}
+
+// K9 (src/LPT.c:134-137), all six components in one sweep
+template <typename F>
+__global__ void __launch_bounds__(PF_CELL_BLOCK) k_lpt_accum(const PfLptAccParams p) {
+  F *__restrict__ s3b = (F *)p.s3b;
+  const long long ncell = p.nrows * p.n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < ncell; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / p.n;
+    const long long a = row * p.pitch + (i - row * p.n);
+    double s = s3b[a];
+    // reference order of (ia,ib): 11,12,13,22,23,33 -> storage index 0,3,4,1,5,2
+    const int order[6] = {0, 3, 4, 1, 5, 2};
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      const int c = order[j];
+      const double f = 2.0 * (c < 3 ? 1.0 : 2.0);
+      s -= f * (double)((const F *)p.phi2[c])[a] * (double)((const F *)p.h[c])[a];
+    }
+    s3b[a] = (F)s;
+  }
+}
+
+__global__ void __launch_bounds__(PF_CELL_BLOCK) k_fill_products(float *fmax, int *rmax, float *vel12, size_t ncell) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncell; i += (size_t)gridDim.x * blockDim.x) {
+    fmax[i] = -10.0f;
+    rmax[i] = -1;
+#pragma unroll
+    for (int k = 0; k < 12; k++) vel12[(size_t)k * ncell + i] = 0.0f;
+  }
+}
+
+// device SoA -> the caller's AoS product_data (src/pinocchio.h:233-259)
+__global__ void __launch_bounds__(PF_CELL_BLOCK)
+    k_pack_products(const float *fmax, const int *rmax, const float *vel12, size_t ncell_total, size_t first, size_t count,
+                    char *aos, size_t stride, int off_rmax, int off_fmax, int ov0, int ov1, int ov2, int ov3) {
+  const int ov[4] = {ov0, ov1, ov2, ov3};
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += (size_t)gridDim.x * blockDim.x) {
+    const size_t i = first + j;
+    char *rec = aos + j * stride;
+    if (off_rmax >= 0) *reinterpret_cast<int *>(rec + off_rmax) = rmax[i];
+    if (off_fmax >= 0) *reinterpret_cast<float *>(rec + off_fmax) = fmax[i];
+#pragma unroll
+    for (int o = 0; o < 4; o++)
+      if (ov[o] >= 0) {
+        float *v = reinterpret_cast<float *>(rec + ov[o]);
+        v[0] = vel12[(size_t)(3 * o + 0) * ncell_total + i];
+        v[1] = vel12[(size_t)(3 * o + 1) * ncell_total + i];
+        v[2] = vel12[(size_t)(3 * o + 2) * ncell_total + i];
+      }
+  }
+}
+
+// K11 (src/fmax.c:517-525)
+__global__ void __launch_bounds__(PF_CELL_BLOCK) k_fmax_pdf(const float *fmax, size_t ncell, unsigned long long *hist) {
+  __shared__ unsigned int sh[210];
+  for (int i = threadIdx.x; i < 210; i += blockDim.x) sh[i] = 0;
+  __syncthreads();
+  // a block handles < 2^32 cells by construction (grid >= ncell / 2^31)
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncell; i += (size_t)gridDim.x * blockDim.x) {
+    int xF = (int)((double)fmax[i] * 10.);
+    if (xF < 0) xF = 0;
+    if (xF >= 210) xF = 209;
+    atomicAdd(&sh[xF], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 210; i += blockDim.x)
+    if (sh[i]) atomicAdd(&hist[i], (unsigned long long)sh[i]);
+}
+
+template <typename F>
+__global__ void k_spec_import(const double *src, F *dst, long long nrows, int nzh, int nzp) {
+  const long long total = nrows * nzh * 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / (2 * nzh);
+    const long long r = i - row * 2 * nzh;
+    dst[row * 2 * nzp + r] = (F)src[i];
+  }
+}
+template <typename F>
+__global__ void k_spec_export(const F *src, double *dst, long long nrows, int nzh, int nzp) {
+  const long long total = nrows * nzh * 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / (2 * nzh);
+    const long long r = i - row * 2 * nzh;
+    dst[i] = (double)src[row * 2 * nzp + r];
+  }
+}
+template <typename F>
+__global__ void k_real_import(const double *src, F *dst, long long nrows, int n, long long pitch) {
+  const long long total = nrows * n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / n;
+    dst[row * pitch + (i - row * n)] = (F)src[i];
+  }
+}
+template <typename F>
+__global__ void k_real_export(const F *src, double *dst, long long nrows, int n, long long pitch) {
+  const long long total = nrows * n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / n;
+    dst[i] = (double)src[row * pitch + (i - row * n)];
+  }
+}
+template <typename F>
+__global__ void k_extract_dc(const F *spec, double scale, double *out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (double)spec[0] * scale;
+}
+
+// ------------------------------------------------------------ launchers ----
+static inline int pf_grid_for(size_t n, int cap = 256 * 8) {
+  size_t b = (n + PF_CELL_BLOCK - 1) / PF_CELL_BLOCK;
+  if (b < 1) b = 1;
+  if (b > (size_t)cap) b = cap;
+  return (int)b;
+}
+#define PF_CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? 0 : 1)
+
+int pf_launch_collapse(int fb, const PfCollapseParams &p, hipStream_t st) {
+  if (p.spline.n > PF_MAX_KNOTS) return 2;
+  if (fb == 8) hipLaunchKernelGGL(k_collapse<double>, dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
+  else hipLaunchKernelGGL(k_collapse<float>, dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
+  return PF_CHECK_LAUNCH();
+}
+int pf_launch_final_sum(const double *partials, int nblocks, double *out2, hipStream_t st) {
+  hipLaunchKernelGGL(k_final_sum2, dim3(1), dim3(64), 0, st, partials, nblocks, out2);
+  return PF_CHECK_LAUNCH();
+}
+int pf_launch_sum1(const double *partials, int nblocks, double scale, double *out, hipStream_t st) {
+  hipLaunchKernelGGL(k_sum1, dim3(1), dim3(64), 0, st, partials, nblocks, scale, out);
+  return PF_CHECK_LAUNCH();
+}
+int pf_launch_collapse_cells(const double *d, size_t count, PfSplineDev s, double *F, hipStream_t st) {
+  hipLaunchKernelGGL(k_collapse_cells, dim3(pf_grid_for(count)), dim3(PF_CELL_BLOCK), 0, st, d, count, s, F);
+  return PF_CHECK_LAUNCH();
+}
+int pf_launch_lpt_sources(int fb, const PfLptSrcParams &p, hipStream_t st) {
+  if (fb == 8) hipLaunchKernelGGL(k_lpt_sources<double>, dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
+  else hipLaunchKernelGGL(k_lpt_sources<float>, dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
+  return PF_CHECK_LAUNCH();
+}
+int pf_launch_lpt_accum(int fb, const PfLptAccParams &p, hipStream_t st) {
+  const int g = pf_grid_for((size_t)(p.nrows * p.n));
+  if (fb == 8) hipLaunchKernelGGL(k_lpt_accum<double>, dim3(g), dim3(PF_CELL_BLOCK), 0, st, p);
+  else hipLaunchKernelGGL(k_lpt_accum<float>, dim3(g), dim3(PF_CELL_BLOCK), 0, st, p);
+  return PF_CHECK_LAUNCH();
+}
+int pf_launch_fill_products(float *fmax, int *rmax, float *vel12, size_t ncell, hipStream_t st) {
+  hipLaunchKernelGGL(k_fill_products, dim3(pf_grid_for(ncell)), dim3(PF_CELL_BLOCK), 0, st, fmax, rmax, vel12, ncell);
+  return PF_CHECK_LAUNCH();
+}
+int pf_launch_pack_products(const float *fmax, const int *rmax, const float *vel12, size_t ncell_total, size_t first,
+                            size_t count, char *aos, size_t stride, int off_rmax, int off_fmax, const int ov[4],
+                            hipStream_t st) {
+  hipLaunchKernelGGL(k_pack_products, dim3(pf_grid_for(count)), dim3(PF_CELL_BLOCK), 0, st, fmax, rmax, vel12,
+                     ncell_total, first, count, aos, stride, off_rmax, off_fmax, ov[0], ov[1], ov[2], ov[3]);
+  return PF_CHECK_LAUNCH();
+}
+int pf_launch_fmax_pdf(const float *fmax, size_t ncell, unsigned long long *hist, hipStream_t st) {
+  hipLaunchKernelGGL(k_fmax_pdf, dim3(pf_grid_for(ncell)), dim3(PF_CELL_BLOCK), 0, st, fmax, ncell, hist);
+  return PF_CHECK_LAUNCH();
+}
+int pf_launch_spec_import(int fb, const double *src, void *dst, long long nrows, int nzh, int nzp, hipStream_t st) {
+  const int g = pf_grid_for((size_t)(nrows * nzh * 2));
+  if (fb == 8) hipLaunchKernelGGL(k_spec_import<double>, dim3(g), dim3(PF_CELL_BLOCK), 0, st, src, (double *)dst, nrows, nzh, nzp);
+  else hipLaunchKernelGGL(k_spec_import<float>, dim3(g), dim3(PF_CELL_BLOCK), 0, st, src, (float *)dst, nrows, nzh, nzp);
+  return PF_CHECK_LAUNCH();
+}
+int pf_launch_spec_export(int fb, const void *src, double *dst, long long nrows, int nzh, int nzp, hipStream_t st) {
+  const int g = pf_grid_for((size_t)(nrows * nzh * 2));
+  if (fb == 8) hipLaunchKernelGGL(k_spec_export<double>, dim3(g), dim3(PF_CELL_BLOCK), 0, st, (const double *)src, dst, nrows, nzh, nzp);
+  else hipLaunchKernelGGL(k_spec_export<float>, dim3(g), dim3(PF_CELL_BLOCK), 0, st, (const float *)src, dst, nrows, nzh, nzp);
+  return PF_CHECK_LAUNCH();
+}
+int pf_launch_real_import(int fb, const double *src, void *dst, long long nrows, int n, long long pitch, hipStream_t st) {
+  const int g = pf_grid_for((size_t)(nrows * n));
+  if (fb == 8) hipLaunchKernelGGL(k_real_import<double>, dim3(g), dim3(PF_CELL_BLOCK), 0, st, src, (double *)dst, nrows, n, pitch);
+  else hipLaunchKernelGGL(k_real_import<float>, dim3(g), dim3(PF_CELL_BLOCK), 0, st, src, (float *)dst, nrows, n, pitch);
+  return PF_CHECK_LAUNCH();
+}
+int pf_launch_real_export(int fb, const void *src, double *dst, long long nrows, int n, long long pitch, hipStream_t st) {
+  const int g = pf_grid_for((size_t)(nrows * n));
+  if (fb == 8) hipLaunchKernelGGL(k_real_export<double>, dim3(g), dim3(PF_CELL_BLOCK), 0, st, (const double *)src, dst, nrows, n, pitch);
+  else hipLaunchKernelGGL(k_real_export<float>, dim3(g), dim3(PF_CELL_BLOCK), 0, st, (const float *)src, dst, nrows, n, pitch);
+  return PF_CHECK_LAUNCH();
+}
+int pf_launch_extract_dc(int fb, const void *spec, double scale, double *out, hipStream_t st) {
+  if (fb == 8) hipLaunchKernelGGL(k_extract_dc<double>, dim3(1), dim3(64), 0, st, (const double *)spec, scale, out);
+  else hipLaunchKernelGGL(k_extract_dc<float>, dim3(1), dim3(64), 0, st, (const float *)spec, scale, out);
+  return PF_CHECK_LAUNCH();
+}

@@ -1,0 +1,193 @@
+// pf_collapse_core.h -- per-cell ellipsoidal-collapse solve (fp64), device code.
+//
+// Follows the arithmetic of the reference operation by operation so that the
+// stored fp32 Fmax agrees with the CPU path:
+//   inverse_collapse_time  src/collapse_times.c:679-776
+//   ord                    src/collapse_times.c:1354-1362
+//   ell / ell_classic      src/collapse_times.c:404-427 / 114-221
+//   InverseGrowingMode     src/cosmo.c:1822-1832, my_spline_eval :2016-2027,
+//                          gsl_spline_eval of a natural cubic spline (GSL 2.7.1 cspline.c)
+// Quirks kept on purpose: pow(x, 0.333333333333333) not
+// cbrt (Q5); -10 sentinel without failure flag (Q4); acos argument may leave
+// [-1,1] by round-off -> NaN -> the Fmax comparison is false (Q4); arithmetic
+// middle in ord (A10).
+//
+// Also compiled for the host by tests/cpu_emul/collapse_emul.cpp (unit test of
+// this header against the oracle's known answers; not a CPU path of the library).
+#pragma once
+#include <math.h>
+
+#ifndef PF_HD
+#if defined(__HIPCC__)
+#define PF_HD __host__ __device__ __forceinline__
+#else
+#define PF_HD inline
+#endif
+#endif
+
+#define PF_PI 3.14159265358979323846 /* src/pinocchio.h:56 */
+#define PF_SMALL 1.e-20              /* src/collapse_times.c:38 */
+
+// natural cubic spline view: knots x,y and second-derivative coefficients c (host-computed)
+struct pf_spline_view {
+  const double *x, *y, *c;
+  int n;
+};
+
+PF_HD double pf_spline_eval(const pf_spline_view &s, double v) {
+  const double *xa = s.x, *ya = s.y, *ca = s.c;
+  const int last = s.n - 1;
+  if (v < xa[0]) return ya[0] + (v - xa[0]) * (ya[1] - ya[0]) / (xa[1] - xa[0]);
+  if (v > xa[last])
+    return ya[last] + (v - xa[last]) * (ya[last] - ya[last - 1]) / (xa[last] - xa[last - 1]);
+  // gsl_interp_bsearch(xa, v, 0, n-1)
+  int ilo = 0, ihi = last;
+  while (ihi > ilo + 1) {
+    int i = (ihi + ilo) >> 1;
+    if (xa[i] > v) ihi = i; else ilo = i;
+  }
+  const double x_lo = xa[ilo], x_hi = xa[ilo + 1];
+  const double dx = x_hi - x_lo;
+  const double y_lo = ya[ilo], y_hi = ya[ilo + 1];
+  const double dy = y_hi - y_lo;
+  const double delx = v - x_lo;
+  const double c_i = ca[ilo], c_ip1 = ca[ilo + 1];
+  const double b_i = (dy / dx) - dx * (c_ip1 + 2.0 * c_i) / 3.0;
+  const double d_i = (c_ip1 - c_i) / (3.0 * dx);
+  return y_lo + delx * (b_i + delx * (c_i + delx * d_i));
+}
+
+PF_HD double pf_inverse_growing_mode(const pf_spline_view &s, double D) {
+  return 1. / pow(10., pf_spline_eval(s, log10(D))) - 1.;
+}
+
+PF_HD double pf_ell_classic(double l1, double l2, double l3) {
+  double ell;
+  const double del = l1 + l2 + l3;
+  const double det = l1 * l2 * l3;
+  if (fabs(l1) < PF_SMALL) {
+    ell = -0.1;
+  } else {
+    const double den = det / 126. + 5. * l1 * del * (del - l1) / 84.;
+    if (fabs(den) < PF_SMALL) {
+      if (fabs(del - l1) < PF_SMALL) {
+        ell = (l1 > 0.0) ? 1. / l1 : -.1;
+      } else {
+        const double dis = 7. * l1 * (l1 + 6. * del);
+        if (dis < 0.0) {
+          ell = -.1;
+        } else {
+          ell = (7. * l1 - sqrt(dis)) / (3. * l1 * (l1 - del));
+          if (ell < 0.) ell = -.1;
+        }
+      }
+    } else {
+      const double rden = 1.0 / den;
+      const double a1 = 3. * l1 * (del - l1) / 14. * rden;
+      const double a1_2 = a1 * a1;
+      const double a2 = l1 * rden;
+      const double a3 = -1.0 * rden;
+      const double q = (a1_2 - 3. * a2) / 9.;
+      const double r = (2. * a1_2 * a1 - 9. * a1 * a2 + 27. * a3) / 54.;
+      const double r_2_q_3 = r * r - q * q * q;
+      if (r_2_q_3 > 0) {
+        const double fabs_r = fabs(r);
+        const double sq = pow(sqrt(r_2_q_3) + fabs_r, 0.333333333333333);
+        ell = -fabs_r / r * (sq + q / sq) - a1 / 3.;
+        if (ell < 0.) ell = -.1;
+      } else {
+        const double sq = 2 * sqrt(q);
+        const double inv_3 = 1.0 / 3;
+        const double t = acos(2 * r / q / sq);
+        double s1 = -sq * cos(t * inv_3) - a1 * inv_3;
+        double s2 = -sq * cos((t + 2. * PF_PI) * inv_3) - a1 * inv_3;
+        double s3 = -sq * cos((t + 4. * PF_PI) * inv_3) - a1 * inv_3;
+        if (s1 < 0.) s1 = 1.e10;
+        if (s2 < 0.) s2 = 1.e10;
+        if (s3 < 0.) s3 = 1.e10;
+        ell = (s1 < s2 ? s1 : s2);
+        ell = (s3 < ell ? s3 : ell);
+        if (ell == 1.e10) ell = -.1;
+      }
+    }
+  }
+  if (del > 0. && ell > 0.) {
+    const double inv_del = 1.0 / del;
+    ell += -.364 * inv_del * exp(-6.5 * (l1 - l2) * inv_del - 2.8 * (l2 - l3) * inv_del);
+  }
+  return ell;
+}
+
+// d = {11,22,33,12,13,23}.  Returns F = 1 + z_collapse (0: never collapses,
+// -10: eigen-solver sentinel).  lam[3] receives the ordered eigenvalues.
+PF_HD double pf_inverse_collapse_time(const double d[6], const pf_spline_view &s, double lam[3]) {
+  const double mu1 = d[0] + d[1] + d[2];
+  const double mu1_2 = mu1 * mu1;
+  double mu2 = 0.5 * mu1_2;
+  mu2 -= 0.5 * (d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  const double add0 = d[3] * d[3], add1 = d[4] * d[4], add2 = d[5] * d[5];
+  mu2 -= add0 + add1 + add2;
+  const double mu3 = d[0] * d[1] * d[2] + 2. * d[3] * d[4] * d[5] - d[0] * add2 - d[1] * add1 - d[2] * add0;
+  const double q = (mu1_2 - 3.0 * mu2) / 9.0;
+  double x1, x2, x3;
+  if (q == 0.) {
+    x1 = d[0]; x2 = d[1]; x3 = d[2];
+  } else {
+    const double r = -(2. * mu1_2 * mu1 - 9.0 * mu1 * mu2 + 27.0 * mu3) / 54.;
+    if (q * q * q < r * r || q < 0.0) {
+      lam[0] = lam[1] = lam[2] = 0.0;
+      return -10.0;
+    }
+    const double sq = 2 * sqrt(q);
+    const double t = acos(2 * r / q / sq);
+    const double inv_3 = 1.0 / 3.0;
+    x1 = -sq * cos(t * inv_3) + mu1 * inv_3;
+    x2 = -sq * cos((t + 2. * PF_PI) * inv_3) + mu1 * inv_3;
+    x3 = -sq * cos((t + 4. * PF_PI) * inv_3) + mu1 * inv_3;
+  }
+  // ord(): hi, lo by comparisons, middle arithmetically
+  double hi = (x1 > x2 ? x1 : x2); hi = (hi > x3 ? hi : x3);
+  double lo = (x1 < x2 ? x1 : x2); lo = (lo < x3 ? lo : x3);
+  const double mid = x1 + x2 + x3 - lo - hi;
+  lam[0] = hi; lam[1] = mid; lam[2] = lo;
+  const double bc = pf_ell_classic(hi, mid, lo);
+  if (bc > 0.0) return 1. + pf_inverse_growing_mode(s, bc);
+  return 0.0;
+}
+
+// host-side: natural cubic spline coefficients exactly as GSL's cspline_init
+// (tridiagonal LDL^t, linalg/tridiag.c solve_tridiag).  c must hold n doubles.
+inline int pf_spline_coeffs(const double *xa, const double *ya, int n, double *c) {
+  if (n < 3) return 1;
+  const int max_index = n - 1, sys = max_index - 1;
+  c[0] = 0.0; c[max_index] = 0.0;
+  double *g = new double[5 * sys];
+  double *diag = g + sys, *off = g + 2 * sys, *alpha = g + 3 * sys, *gamma = g + 4 * sys;
+  for (int i = 0; i < sys; i++) {
+    const double h_i = xa[i + 1] - xa[i], h_ip1 = xa[i + 2] - xa[i + 1];
+    const double yd_i = ya[i + 1] - ya[i], yd_ip1 = ya[i + 2] - ya[i + 1];
+    const double g_i = (h_i != 0.0) ? 1.0 / h_i : 0.0, g_ip1 = (h_ip1 != 0.0) ? 1.0 / h_ip1 : 0.0;
+    off[i] = h_ip1;
+    diag[i] = 2.0 * (h_ip1 + h_i);
+    g[i] = 3.0 * (yd_ip1 * g_ip1 - yd_i * g_i);
+  }
+  if (sys == 1) {
+    c[1] = g[0] / diag[0];
+  } else {
+    alpha[0] = diag[0];
+    gamma[0] = off[0] / alpha[0];
+    for (int i = 1; i < sys - 1; i++) {
+      alpha[i] = diag[i] - off[i - 1] * gamma[i - 1];
+      gamma[i] = off[i] / alpha[i];
+    }
+    alpha[sys - 1] = diag[sys - 1] - off[sys - 2] * gamma[sys - 2];
+    // forward substitution (z overwrites g), scaling, back substitution
+    for (int i = 1; i < sys; i++) g[i] = g[i] - gamma[i - 1] * g[i - 1];
+    for (int i = 0; i < sys; i++) g[i] = g[i] / alpha[i];
+    double *x = c + 1;
+    x[sys - 1] = g[sys - 1];
+    for (int i = sys - 2; i >= 0; i--) x[i] = g[i] - gamma[i] * x[i + 1];
+  }
+  delete[] g;
+  return 0;
+}

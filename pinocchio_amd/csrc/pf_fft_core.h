@@ -1,0 +1,133 @@
+// pf_fft_core.h -- register-resident Stockham FFT building blocks (gfx950).
+//
+// One thread owns 8 complex points of a length-N line (points tl + m*N/8,
+// m = 0..7, tl = thread index in the line, N/8 threads per line).  A stage does
+// 8/R radix-R butterflies per thread in registers (R = 8, or 2/4 for the last
+// stage), then the line is exchanged through LDS: write at pf_stage_pos(),
+// barrier, read back at tl + m*N/8.  The first stage reads HBM directly and the
+// last stage writes HBM directly, so a length-1024 line crosses LDS 3 times and
+// HBM once each way.  Twiddles come from one table exp(+2 pi i j / NTAB).
+//
+// The same header is compiled by g++ in tests/test_fft_core.py (a serial loop
+// over tl stands in for the wavefront) to unit-test the index algebra without a
+// GPU; that is a test of this header, not a CPU path of the library.
+#pragma once
+
+#if defined(__HIPCC__)
+#define PF_HD __host__ __device__ __forceinline__
+#else
+#define PF_HD inline
+#endif
+
+template <typename F>
+struct alignas(2 * sizeof(F)) pfc {
+  F x, y;
+};
+
+template <typename F> PF_HD pfc<F> pf_mk(F x, F y) { pfc<F> r; r.x = x; r.y = y; return r; }
+template <typename F> PF_HD pfc<F> operator+(pfc<F> a, pfc<F> b) { return pf_mk<F>(a.x + b.x, a.y + b.y); }
+template <typename F> PF_HD pfc<F> operator-(pfc<F> a, pfc<F> b) { return pf_mk<F>(a.x - b.x, a.y - b.y); }
+template <typename F> PF_HD pfc<F> pf_cmul(pfc<F> a, pfc<F> b) {
+  return pf_mk<F>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+template <typename F> PF_HD pfc<F> pf_scale(pfc<F> a, F s) { return pf_mk<F>(a.x * s, a.y * s); }
+template <typename F> PF_HD pfc<F> pf_conj(pfc<F> a) { return pf_mk<F>(a.x, -a.y); }
+// multiply by (DIR * i): DIR=+1 -> (-y, x); DIR=-1 -> (y, -x)
+template <int DIR, typename F> PF_HD pfc<F> pf_mul_i(pfc<F> a) {
+  return DIR > 0 ? pf_mk<F>(-a.y, a.x) : pf_mk<F>(a.y, -a.x);
+}
+
+constexpr int pf_ilog2(int n) { return n <= 1 ? 0 : 1 + pf_ilog2(n >> 1); }
+// stage plan for 8 points per thread: radix 8 as long as it fits, the remainder (2 or 4) last
+constexpr int pf_nstages(int n) { return (pf_ilog2(n) + 2) / 3; }
+constexpr int pf_radix(int n, int s) { return s < pf_ilog2(n) / 3 ? 8 : (1 << (pf_ilog2(n) - 3 * (pf_ilog2(n) / 3))); }
+constexpr int pf_ns(int n, int s) { return s == 0 ? 1 : pf_ns(n, s - 1) * pf_radix(n, s - 1); }
+
+// X_k = sum_t u_t w^{kt}, w = exp(DIR 2 pi i / R), natural order in and out
+template <int DIR, typename F> PF_HD void pf_bfly2(pfc<F> &a, pfc<F> &b) {
+  pfc<F> t = a - b;
+  a = a + b;
+  b = t;
+}
+template <int DIR, typename F> PF_HD void pf_bfly4(pfc<F> &v0, pfc<F> &v1, pfc<F> &v2, pfc<F> &v3) {
+  pfc<F> a = v0 + v2, b = v0 - v2, c = v1 + v3, d = pf_mul_i<DIR>(v1 - v3);
+  v0 = a + c;
+  v1 = b + d;
+  v2 = a - c;
+  v3 = b - d;
+}
+template <int DIR, typename F> PF_HD void pf_bfly8(pfc<F> (&u)[8]) {
+  pf_bfly4<DIR>(u[0], u[2], u[4], u[6]);  // E_0..3 in u[0],u[2],u[4],u[6]
+  pf_bfly4<DIR>(u[1], u[3], u[5], u[7]);  // O_0..3 in u[1],u[3],u[5],u[7]
+  const F h = (F)0.70710678118654752440;
+  pfc<F> o1 = pf_mk<F>(h * (u[3].x - DIR * u[3].y), h * (u[3].y + DIR * u[3].x));  // W8^1 = h(1, DIR)
+  pfc<F> o2 = pf_mul_i<DIR>(u[5]);                                                  // W8^2 = DIR i
+  pfc<F> o3 = pf_mk<F>(h * (-u[7].x - DIR * u[7].y), h * (-u[7].y + DIR * u[7].x)); // W8^3 = h(-1, DIR)
+  pfc<F> e0 = u[0], e1 = u[2], e2 = u[4], e3 = u[6], o0 = u[1];
+  u[0] = e0 + o0; u[4] = e0 - o0;
+  u[1] = e1 + o1; u[5] = e1 - o1;
+  u[2] = e2 + o2; u[6] = e2 - o2;
+  u[3] = e3 + o3; u[7] = e3 - o3;
+}
+
+// LDS/HBM position of register m of thread tl AFTER stage S of a length-N line
+template <int N, int S> PF_HD int pf_stage_pos(int tl, int m) {
+  constexpr int R = pf_radix(N, S), NS = pf_ns(N, S), Q = 8 / R, NT = N / 8;
+  const int q = m % Q, t = m / Q;
+  const int jb = tl + q * NT;
+  const int k = jb & (NS - 1);
+  return (jb - k) * R + k + t * NS;
+}
+
+// stage S on the 8 registers of thread tl.  tw[j] = exp(+2 pi i j / (N*TWS)).
+template <typename F, int N, int S, int DIR, int TWS>
+PF_HD void pf_stage(pfc<F> (&v)[8], int tl, const pfc<F> *__restrict__ tw) {
+  constexpr int R = pf_radix(N, S), NS = pf_ns(N, S), Q = 8 / R, NT = N / 8;
+  constexpr int TWM = (N / (NS * R)) * TWS;
+#pragma unroll
+  for (int q = 0; q < Q; q++) {
+    const int jb = tl + q * NT;
+    const int k = jb & (NS - 1);
+    if (NS > 1) {
+#pragma unroll
+      for (int t = 1; t < R; t++) {
+        pfc<F> w = tw[k * t * TWM];
+        if (DIR < 0) w.y = -w.y;
+        v[q + t * Q] = pf_cmul(v[q + t * Q], w);
+      }
+    }
+    if (R == 8) {
+      pf_bfly8<DIR>(v);
+    } else if (R == 4) {
+      pf_bfly4<DIR>(v[q], v[q + Q], v[q + 2 * Q], v[q + 3 * Q]);
+    } else if (R == 2) {
+      pf_bfly2<DIR>(v[q], v[q + Q]);
+    }
+  }
+}
+
+// LDS padding for contiguous-line kernels: breaks the stride-8 write pattern of stage 0
+PF_HD int pf_lpad(int p) { return p + (p >> 3); }
+
+// ---- real <-> half-complex glue (length-N real line as a length-M = N/2 complex FFT) ----
+// c2r, unnormalised: x[n] = sum_j Xt[j] e^{+2 pi i j n / N}, Xt the Hermitian extension of
+// X[0..M]; Im X[0], Im X[M] ignored (FFTW/pocketfft semantics).  With
+//   Zp[k] = (X[k] + conj X[M-k]) + i (X[k] - conj X[M-k]) e^{+2 pi i k / N},  k = 0..M-1
+// the inverse M-point FFT gives x[2n] + i x[2n+1].
+template <typename F> PF_HD pfc<F> pf_c2r_pre(pfc<F> xk, pfc<F> xmk, pfc<F> wk /* e^{+2 pi i k/N} */, bool k0) {
+  if (k0) {  // k = 0: only the real parts of X[0] and X[M]
+    return pf_mk<F>(xk.x + xmk.x, xk.x - xmk.x);
+  }
+  pfc<F> b = pf_conj(xmk);
+  pfc<F> s = xk + b, d = pf_cmul(xk - b, wk);
+  return pf_mk<F>(s.x - d.y, s.y + d.x);
+}
+// r2c, unnormalised, from Z = FFT_M(x[2n] + i x[2n+1]) (forward sign):
+//   X[k] = E + e^{-2 pi i k / N} O,  E = (Z[k] + conj Z[M-k])/2,  O = (Z[k] - conj Z[M-k])/(2i)
+template <typename F> PF_HD pfc<F> pf_r2c_post(pfc<F> zk, pfc<F> zmk, pfc<F> wk /* e^{+2 pi i k/N} */) {
+  pfc<F> b = pf_conj(zmk);
+  pfc<F> e = pf_scale(zk + b, (F)0.5);
+  pfc<F> d = pf_scale(zk - b, (F)0.5);
+  pfc<F> o = pf_mk<F>(d.y, -d.x);  // d / i
+  return e + pf_cmul(o, pf_conj(wk));
+}

@@ -1,0 +1,136 @@
+// pf_internal.h -- launch interface between the translation units of libpinfmax_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#define PF_MAX_JOBS 6
+
+// multiplier applied along the transformed axis before the 1-D transform
+// (k = 2 pi s / N, s the signed wavenumber of src/fmax-pfft.c:306-339)
+enum { PF_MUL_ONE = 0, PF_MUL_K = 1, PF_MUL_K2 = 2, PF_MUL_IK = 3 };
+
+// element address of (outer, e, col) in a strided pass:
+//   outer*os + (e / el)*ehs + (e % el)*els + col      (units: complex elements)
+// (e / el, e % el) lets the y-pass read the P received all-to-all blocks in place.
+struct PfAddr {
+  long long os;
+  int el;
+  long long ehs, els;
+};
+
+struct PfStridedJob {
+  const void *in;
+  void *out;
+  int mul;
+};
+
+struct PfStridedParams {
+  int njobs;
+  PfStridedJob job[PF_MAX_JOBS];
+  PfAddr ain, aout;
+  int ncols;         // valid columns (n/2+1)
+  int nouter;        // lines of tiles along the non-transformed slow axis
+  int pre;           // 1: multiply by exp(-k^2 rs^2/2) * growth / k^2 (0 at k = 0) on load
+  int outer_offset;  // global index of outer = 0 (k-space y-slab start)
+  double rs, growth;
+  const void *tw;    // exp(+2 pi i j / n), n entries of complex F
+};
+
+// one x- or y-pass: for every job, out = FFT_e[ in * pre * mul ]  (dir = +1 inverse, -1 forward)
+int pf_launch_strided(int field_bytes, int n, int dir, const PfStridedParams &p, hipStream_t st);
+
+struct PfC2RJob {
+  const void *in;   // complex rows
+  void *out;        // real rows (type F, pitch out_pitch) or float rows (pitch n) when out_f32
+  int mul;          // multiplier in kz
+  int out_f32;
+};
+
+struct PfC2RParams {
+  int njobs;
+  PfC2RJob job[PF_MAX_JOBS];
+  long long nlines;     // rows = nx_local * n
+  long long in_pitch;   // complex elements per input row
+  long long out_pitch;  // real elements per output row (F outputs)
+  double norm;          // 1/N^3 applied to the result (src/fmax-pfft.c:220-225)
+  const double *dc;     // device scalar added after normalisation (DC mode of 2nd derivatives), or null
+  const void *tw;       // exp(+2 pi i j / n)
+};
+int pf_launch_c2r(int field_bytes, int n, const PfC2RParams &p, hipStream_t st);
+
+struct PfR2CParams {
+  const void *in;       // real rows, pitch in_pitch reals
+  void *out;            // complex rows, pitch out_pitch complex (may alias in)
+  long long nlines, in_pitch, out_pitch;
+  const void *tw;
+};
+int pf_launch_r2c(int field_bytes, int n, const PfR2CParams &p, hipStream_t st);
+
+// ---- per-cell kernels (pf_cell_kernels.hip) ----
+struct PfSplineDev {
+  const double *x, *y, *c;
+  int n;
+};
+struct PfCollapseParams {
+  const void *h[6];     // Hessian fields, type F, rows of pitch reals
+  long long pitch;
+  long long nrows;      // nx_local * n
+  int n;                // row length
+  float *fmax;
+  int *rmax;
+  int ismooth;
+  PfSplineDev spline;
+  double *partials;     // [2*nblocks]: sum delta, sum delta^2 per block
+  int nblocks;
+};
+int pf_launch_collapse(int field_bytes, const PfCollapseParams &p, hipStream_t st);
+int pf_launch_final_sum(const double *partials, int nblocks, double *out2, hipStream_t st);
+int pf_launch_collapse_cells(const double *d, size_t count, PfSplineDev s, double *F, hipStream_t st);
+
+struct PfLptSrcParams {
+  const void *h[6];
+  void *s2, *s3a, *s3b;  // real rows, same pitch
+  long long pitch, nrows;
+  int n;
+  double *partials;      // per-block sum of s2 (its spectrum's DC), [nblocks]
+  int nblocks;
+};
+int pf_launch_lpt_sources(int field_bytes, const PfLptSrcParams &p, hipStream_t st);
+
+struct PfLptAccParams {
+  const void *h[6], *phi2[6];
+  void *s3b;
+  long long pitch, nrows;
+  int n;
+};
+int pf_launch_lpt_accum(int field_bytes, const PfLptAccParams &p, hipStream_t st);
+
+int pf_launch_sum1(const double *partials, int nblocks, double scale, double *out, hipStream_t st);
+int pf_launch_fill_products(float *fmax, int *rmax, float *vel12, size_t ncell, hipStream_t st);
+int pf_launch_pack_products(const float *fmax, const int *rmax, const float *vel12, size_t ncell_total,
+                            size_t first, size_t count, char *aos, size_t stride, int off_rmax, int off_fmax,
+                            const int off_vel[4], hipStream_t st);
+int pf_launch_fmax_pdf(const float *fmax, size_t ncell, unsigned long long *hist, hipStream_t st);
+// copy + pitch/precision conversion of a half-spectrum between the boundary layout
+// (fp64, rows of nzh complex) and the internal one (F, rows of nzp complex)
+int pf_launch_spec_import(int field_bytes, const double *src, void *dst, long long nrows, int nzh, int nzp, hipStream_t st);
+int pf_launch_spec_export(int field_bytes, const void *src, double *dst, long long nrows, int nzh, int nzp, hipStream_t st);
+int pf_launch_real_import(int field_bytes, const double *src, void *dst, long long nrows, int n, long long pitch, hipStream_t st);
+int pf_launch_real_export(int field_bytes, const void *src, double *dst, long long nrows, int n, long long pitch, hipStream_t st);
+int pf_launch_extract_dc(int field_bytes, const void *spec, double scale, double *out, hipStream_t st);
+
+// ---- synthetic density (pf_synth.hip) ----
+int pf_launch_white(int field_bytes, void *real, long long nrows, long long row0, int n, long long pitch,
+                    uint64_t seed, hipStream_t st);
+struct PfShapeParams {
+  void *spec;            // internal layout, rows (x, y_local) of nzp complex
+  int n, nzp, nyl, y0;   // y-slab
+  double slope, scale;   // amplitude k^(slope/2) * scale ; scale applied only when apply != 0
+  double *partials;      // per-block weighted sum |dk|^2
+  int nblocks;
+  int mode;              // 0: apply shape + accumulate power; 1: multiply by *dscale
+  const double *dscale;
+};
+int pf_launch_shape(int field_bytes, const PfShapeParams &p, hipStream_t st);
+int pf_launch_sigma_scale(const double *power_sum, double sigma0, double n3, double *dscale, hipStream_t st);

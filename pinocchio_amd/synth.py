@@ -131,8 +131,8 @@ def philox_white(n: int, seed: int = SEED, x0: int = 0, nx: int | None = None) -
     Philox call per PAIR of cells (global pair index as the counter), Box-Muller.
     Decomposition independent: any rank can generate its own slab."""
     nx = n if nx is None else nx
-    gidx = (np.arange(x0 * n * n, (x0 + nx) * n * n, dtype=np.uint64).reshape(nx, n, n)[:, :, None] * np.uint64(n // 2)
-            + np.arange(n // 2, dtype=np.uint64)[None, None, None, :]).reshape(nx, n, n // 2)
+    rows = np.arange(x0 * n, (x0 + nx) * n, dtype=np.uint64).reshape(nx, n)
+    gidx = rows[:, :, None] * np.uint64(n // 2) + np.arange(n // 2, dtype=np.uint64)[None, None, :]
     c0 = (gidx & _MASK32).astype(np.uint32)
     c1 = (gidx >> np.uint64(32)).astype(np.uint32)
     z = np.zeros_like(c0)
@@ -147,3 +147,10 @@ def philox_white(n: int, seed: int = SEED, x0: int = 0, nx: int | None = None) -
     out[:, :, 0::2] = rad * np.cos(ang)
     out[:, :, 1::2] = rad * np.sin(ang)
     return out
+
+
+def philox_density(n: int, seed: int = SEED, sigma0: float = 2.5, slope: float = -2.0) -> np.ndarray:
+    """numpy mirror of pf_synth_density (csrc/pf_synth.hip): Philox white noise in
+    real space -> r2c -> P(k) shaping -> sigma(R=0) = sigma0."""
+    wk = np.fft.rfftn(philox_white(n, seed), axes=(0, 1, 2))
+    return shape_spectrum(n, wk, sigma0, slope)

@@ -1,0 +1,77 @@
+"""Unit test of the device collapse header (pinocchio_amd/csrc/pf_collapse_core.h)
+compiled for the host, against the reference known answers and the oracle."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from pinocchio_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "cpu_emul", "collapse_emul.cpp")
+SO = os.path.join(HERE, "cpu_emul", "libcollapse_emul.so")
+dp = C.POINTER(C.c_double)
+
+
+def _dp(a):
+    return a.ctypes.data_as(dp)
+
+
+@pytest.fixture(scope="module")
+def emul():
+    hdr = os.path.join(HERE, "..", "pinocchio_amd", "csrc", "pf_collapse_core.h")
+    if (not os.path.exists(SO)) or os.path.getmtime(SO) < max(os.path.getmtime(SRC), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-o", SO, SRC])
+    L = C.CDLL(SO)
+    L.emul_collapse.argtypes = [dp, dp, C.c_int, dp, C.c_long, dp, dp]
+    L.emul_ell_classic.restype = C.c_double
+    L.emul_ell_classic.argtypes = [C.c_double] * 3
+    L.emul_spline.argtypes = [dp, dp, C.c_int, dp, C.c_long, dp]
+    return L
+
+
+def test_kat(emul):
+    with open(os.path.join(HERE, "golden", "collapse_kat.json")) as f:
+        kat = json.load(f)
+    for case in kat["ell_classic"]:
+        assert emul.emul_ell_classic(*case["l"]) == pytest.approx(case["bc"], rel=4e-16, abs=0)
+    x, y = synth.invgrow_table("eds")
+    d = np.array([c["d"] for c in kat["inverse_collapse_time"]], dtype=np.float64)
+    F = np.empty(len(d)); lam = np.empty((len(d), 3))
+    assert emul.emul_collapse(_dp(x), _dp(y), len(x), _dp(d), len(d), _dp(F), _dp(lam)) == 0
+    for i, case in enumerate(kat["inverse_collapse_time"]):
+        assert F[i] == pytest.approx(case["F"], rel=1e-14, abs=1e-15)
+
+
+def test_random_hessians_match_oracle_bitwise(emul):
+    """same libm, same operation order -> identical doubles, including sentinels and NaNs"""
+    rng = np.random.default_rng(5)
+    x, y = synth.invgrow_table("lcdm")
+    o = oracle_lib.Oracle(8, 1)
+    o.set_invgrow(x, y)
+    n = 20000
+    d = rng.standard_normal((n, 6)) * np.array([1.0, 1.0, 1.0, 0.5, 0.5, 0.5])
+    d[:50, 3:] = 0.0            # diagonal tensors
+    d[50:60] = 0.0              # all-zero
+    d[60:70, :3] = 0.4; d[60:70, 3:] = 0.0   # q == 0 branch
+    F = np.empty(n); lam = np.empty((n, 3))
+    assert emul.emul_collapse(_dp(x), _dp(y), len(x), _dp(d), n, _dp(F), _dp(lam)) == 0
+    want = np.array([o.inverse_collapse_time(row)[0] for row in d])
+    same = (F == want) | (np.isnan(F) & np.isnan(want))
+    assert same.all(), np.argwhere(~same)[:5]
+    assert (F > 1).sum() > 100 and (F == 0).sum() > 100
+
+
+def test_spline(emul):
+    x, y = synth.invgrow_table("lcdm")
+    o = oracle_lib.Oracle(8, 1)
+    o.set_invgrow(x, y)
+    v = np.concatenate([np.linspace(x[0] - 1, x[-1] + 1, 3001), x])
+    out = np.empty_like(v)
+    assert emul.emul_spline(_dp(x), _dp(y), len(x), _dp(v), len(v), _dp(out)) == 0
+    want = np.array([o.spline_eval(t) for t in v])
+    assert np.array_equal(out, want)

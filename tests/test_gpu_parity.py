@@ -1,0 +1,258 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle
+on identical inputs, plus size-independent properties at large grids.
+
+Tolerances (fp64 field path), as stated in DESIGN.md:
+  * Hessian fields, LPT spectra : max abs diff <= 1e-12 x field amplitude
+  * TrueVariance                : rel <= 1e-12
+  * Fmax (stored fp32)          : |diff| <= 2 ulp_fp32(max(|F|,1)), and > 0 on < 1e-3 of cells
+  * Rmax                        : identical on >= 99.9 % of cells
+  * displacements (stored fp32) : |diff| <= 4e-7 x amplitude (fp32 rounding of equal fp64 values)
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from pinocchio_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def api():
+    from pinocchio_amd import api as _api
+    return _api
+
+
+def _fmax_close(got, want):
+    ulp = np.spacing(np.maximum(np.abs(want), 1.0).astype(np.float32)).astype(np.float64)
+    d = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    assert np.all(d <= 2 * ulp), (d.max(), np.argwhere(d > 2 * ulp)[:3])
+    assert np.mean(d > 0) < 1e-3, np.mean(d > 0)
+
+
+@pytest.mark.parametrize("n", [16, 32, 64, 128, 256])
+def test_transforms_vs_pocketfft(api, n):
+    rng = np.random.default_rng(n)
+    real = rng.standard_normal((n, n, n))
+    with api.Fmax(n) as f:
+        spec = f.forward_transform(real)
+        want = np.fft.rfftn(real, axes=(0, 1, 2))
+        assert np.max(np.abs(spec - want)) < 1e-13 * np.max(np.abs(want)) * np.log2(n)
+        junk = rng.standard_normal((n, n, n // 2 + 1)) + 1j * rng.standard_normal((n, n, n // 2 + 1))
+        back = f.reverse_transform(junk)  # c2r then 1/N^3 (src/fmax-pfft.c:203-228)
+        want = np.fft.irfftn(junk, s=(n, n, n), axes=(0, 1, 2))
+        assert np.max(np.abs(back - want)) < 1e-13 * np.max(np.abs(want)) * np.log2(n)
+        # round trip
+        again = f.reverse_transform(f.forward_transform(real))
+        assert np.max(np.abs(again - real)) < 1e-13 * np.log2(n)
+
+
+def test_collapse_cells_kat_and_random(api):
+    with open(os.path.join(GOLD, "collapse_kat.json")) as fh:
+        kat = json.load(fh)
+    with api.Fmax(16) as f:
+        x, y = synth.invgrow_table("eds")
+        f.set_invgrow(x, y)
+        d = np.array([c["d"] for c in kat["inverse_collapse_time"]])
+        F = f.collapse_cells(d)
+        for i, case in enumerate(kat["inverse_collapse_time"]):
+            tol = 1e-7 if "degenerate" in case["branch"] else 1e-13
+            assert F[i] == pytest.approx(case["F"], rel=tol, abs=1e-14), case
+        # random Hessians incl. diagonal / zero / q==0 cases against the oracle (LCDM spline)
+        x, y = synth.invgrow_table("lcdm")
+        f.set_invgrow(x, y)
+        rng = np.random.default_rng(5)
+        m = 40000
+        d = rng.standard_normal((m, 6)) * np.array([1.0, 1.0, 1.0, 0.5, 0.5, 0.5])
+        d[:50, 3:] = 0.0
+        d[50:60] = 0.0
+        d[60:70, :3] = 0.4
+        d[60:70, 3:] = 0.0
+        F = f.collapse_cells(d)
+    o = oracle_lib.Oracle(8, 1)
+    o.set_invgrow(x, y)
+    want = np.array([o.inverse_collapse_time(row)[0] for row in d])
+    both_nan = np.isnan(F) & np.isnan(want)
+    sentinel_same = (F == -10.0) == (want == -10.0)
+    assert np.mean(sentinel_same) > 0.9999
+    ok = both_nan | ~sentinel_same | (np.abs(F - want) <= 1e-9 * np.maximum(1.0, np.abs(want)))
+    assert ok.all(), (np.argwhere(~ok)[:5], F[~ok][:5], want[~ok][:5])
+    # the bulk agrees to round-off
+    good = np.isfinite(F) & np.isfinite(want) & sentinel_same
+    assert np.median(np.abs(F[good] - want[good])) < 1e-14
+
+
+@pytest.mark.parametrize("n,rs", [(16, 0.0), (32, 1.5), (64, 2.8), (64, 0.0)])
+def test_second_derivatives_vs_oracle(api, n, rs):
+    dk = synth.make_density(n, seed=11 + n)
+    # put something in the DC mode: it must pass the filter untouched (k^2 = 0, src/fmax-pfft.c:368)
+    dk[0, 0, 0] = 0.37 * n ** 3
+    o = oracle_lib.Oracle(n, 0)
+    o.set_density(dk)
+    want = o.second_derivatives(rs)
+    with api.Fmax(n) as f:
+        f.set_density(dk)
+        f.compute_second_derivatives(rs)
+        got = [f.second_derivative(i) for i in range(6)]
+    amp = max(np.max(np.abs(w)) for w in want)
+    for i in range(6):
+        assert np.max(np.abs(got[i] - want[i])) < 1e-12 * amp, i
+
+
+def _run_both(api, n, radii, kind="lcdm", seed=synth.SEED, field_bytes=8, do_lpt=True):
+    dk = synth.make_density(n, seed=seed)
+    x, y = synth.invgrow_table(kind)
+    g = synth.growth_multipliers()
+    o = oracle_lib.Oracle(n, 0)
+    o.set_density(dk)
+    o.set_invgrow(x, y)
+    o.set_growth(g)
+    tv_o = o.compute_fmax(radii, do_lpt=do_lpt)
+    with api.Fmax(n, field_bytes=field_bytes) as f:
+        f.set_density(dk)
+        f.set_invgrow(x, y)
+        f.set_growth(g)
+        tv = f.compute_fmax(radii, do_lpt=do_lpt)
+        p = f.products()
+        pdf = f.Fmax_PDF()
+        kv = [f.kvector(w) for w in range(3)] if do_lpt else None
+    return (tv, p, pdf, kv), (tv_o, o.products(), o.fmax_pdf(), [o.kvector(w) for w in range(3)] if do_lpt else None)
+
+
+@pytest.mark.parametrize("n,ns,kind", [(16, 4, "eds"), (32, 6, "lcdm"), (64, 12, "lcdm"), (128, 5, "lcdm")])
+def test_full_path_vs_oracle(api, n, ns, kind):
+    radii = synth.radii_ladder(12) * (n / 256.0) if ns == 12 else synth.radii_ladder(ns) * (n / 128.0)
+    radii[-1] = 0.0
+    (tv, p, pdf, kv), (tv_o, po, pdf_o, kv_o) = _run_both(api, n, radii, kind)
+    assert np.allclose(tv, tv_o, rtol=1e-12), (tv, tv_o)
+    _fmax_close(p["Fmax"], po["Fmax"])
+    assert np.mean(p["Rmax"] != po["Rmax"]) < 1e-3
+    assert (po["Fmax"] >= 1).sum() > 0
+    for w in range(3):
+        assert np.max(np.abs(kv[w] - kv_o[w])) < 1e-12 * np.max(np.abs(kv_o[w])) * np.log2(n), w
+    for name in ("Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+        a, b = p[name].astype(np.float64), po[name].astype(np.float64)
+        amp = np.max(np.abs(b))
+        assert amp > 0
+        assert np.max(np.abs(a - b)) <= 4e-7 * amp, name
+        assert np.mean(a != b) < 0.02, name  # fp32 rounding of fp64 values equal to ~1e-15
+    # Fmax PDF (src/fmax.c:509-550): a cell 1 ulp across a bin edge may move one count
+    assert int(pdf.sum()) == n ** 3
+    assert np.abs(pdf.astype(np.int64) - pdf_o.astype(np.int64)).sum() <= max(2, int(2e-4 * n ** 3))
+
+
+def test_golden_fixture(api):
+    """committed vectors (tests/golden/make_golden.py wrote them from the oracle)"""
+    z = np.load(os.path.join(GOLD, "sweep_n16.npz"))
+    n = int(z["n"])
+    with api.Fmax(n) as f:
+        f.set_density(z["dk"])
+        f.set_invgrow(z["spline_x"], z["spline_y"])
+        f.set_growth(z["growth"])
+        tv = f.compute_fmax(z["radii"], do_lpt=True)
+        p = f.products()
+        pdf = f.Fmax_PDF()
+    assert np.allclose(tv, z["true_variance"], rtol=1e-12)
+    _fmax_close(p["Fmax"], z["Fmax"])
+    assert np.mean(p["Rmax"] != z["Rmax"]) < 1e-3
+    for name in ("Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+        amp = np.max(np.abs(z[name]))
+        assert np.max(np.abs(p[name].astype(np.float64) - z[name].astype(np.float64))) <= 4e-7 * amp
+    assert np.abs(pdf.astype(np.int64) - z["pdf"].astype(np.int64)).sum() <= 2
+
+
+def test_fmax_only_skips_lpt_and_reentry(api):
+    """config 'Fmax-only': no displacement build -> Vel* stay 0 (src/collapse_times.c:472-489);
+    compute_displacements(0,0,z) re-entry reuses the resident sources (src/fragment.c:398-410)"""
+    n = 32
+    radii = np.array([2.0, 1.0, 0.0])
+    (tv, p, _, _), (tv_o, po, _, _) = _run_both(api, n, radii, do_lpt=False)
+    assert np.allclose(tv, tv_o, rtol=1e-12)
+    _fmax_close(p["Fmax"], po["Fmax"])
+    for name in ("Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+        assert not p[name].any()
+    dk = synth.make_density(n, seed=3)
+    x, y = synth.invgrow_table("lcdm")
+    with api.Fmax(n) as f:
+        f.set_density(dk)
+        f.set_invgrow(x, y)
+        with pytest.raises(api.PinfmaxError):
+            f.compute_displacements(0, 0)  # sources not resident yet
+        f.set_growth(synth.growth_multipliers())
+        f.compute_fmax(radii, do_lpt=True)
+        p1 = f.products()
+        g2 = synth.growth_multipliers() * np.array([0.5, 0.25, 0.125, 0.125])
+        f.set_growth(g2)
+        f.compute_displacements(0, 0)
+        p2 = f.products()
+    assert np.array_equal(p1["Fmax"], p2["Fmax"])
+    assert np.allclose(p2["Vel"], 0.5 * p1["Vel"], rtol=2e-7, atol=0)
+    assert np.allclose(p2["Vel_2LPT"], 0.25 * p1["Vel_2LPT"], rtol=2e-7, atol=0)
+    assert np.allclose(p2["Vel_3LPT_2"], 0.125 * p1["Vel_3LPT_2"], rtol=2e-7, atol=0)
+
+
+def test_fp32_field_path(api):
+    """config 5: fp32 density/derivative fields, fp64 collapse solve.  Stated
+    tolerance: Hessian rel-L2 <= 1e-5; |dFmax| <= 1e-3 on 99.9 % of cells with F >= 0.5."""
+    n = 64
+    radii = np.array([4.0, 2.0, 1.0, 0.0])
+    (tv, p, pdf, _), (tv_o, po, pdf_o, _) = _run_both(api, n, radii, field_bytes=4)
+    assert np.allclose(tv, tv_o, rtol=1e-5)
+    sel = po["Fmax"] >= 0.5
+    d = np.abs(p["Fmax"][sel].astype(np.float64) - po["Fmax"][sel].astype(np.float64))
+    assert np.mean(d <= 1e-3) > 0.999
+    for name in ("Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+        a, b = p[name].astype(np.float64), po[name].astype(np.float64)
+        assert np.sqrt(np.mean((a - b) ** 2)) <= 2e-5 * np.sqrt(np.mean(b ** 2)), name
+    assert np.abs(pdf.astype(np.int64) - pdf_o.astype(np.int64)).sum() <= 2e-3 * n ** 3
+
+
+def test_synth_density_matches_numpy_mirror(api):
+    n = 32
+    with api.Fmax(n) as f:
+        f.synth_density(synth.SEED, 2.5, -2.0)
+        got = f.density()
+    want = synth.philox_density(n, synth.SEED, 2.5, -2.0)
+    assert np.max(np.abs(got - want)) < 1e-11 * np.max(np.abs(want))
+    h = n // 2
+    assert not got[h].any() and not got[:, h].any() and not got[:, :, h].any() and got[0, 0, 0] == 0
+
+
+@pytest.mark.parametrize("n", [256, 512])
+def test_properties_at_scale(api, n):
+    """size-independent checks where the oracle is too slow"""
+    x, y = synth.invgrow_table("lcdm")
+    radii = np.array([8.0, 2.0, 0.0])
+    with api.Fmax(n) as f:
+        f.synth_density(synth.SEED, 2.5, -2.0)
+        f.set_invgrow(x, y)
+        f.set_growth(synth.growth_multipliers())
+        tv = f.sweep(radii)
+        # sigma(R=0) was normalised to 2.5 by Parseval in k-space; here it is measured in real space
+        assert np.sqrt(tv[-1]) == pytest.approx(2.5, rel=1e-10)
+        assert tv[0] < tv[1] < tv[2]
+        pdf = f.Fmax_PDF()
+        assert int(pdf.sum()) == n ** 3
+        # Laplacian identity at R=0: H11+H22+H33 = delta, so its mean square is TrueVariance
+        f.compute_second_derivatives(0.0)
+        tr = f.second_derivative(0) + f.second_derivative(1) + f.second_derivative(2)
+        assert np.mean(tr ** 2) == pytest.approx(tv[-1], rel=1e-11)
+        assert abs(tr.mean()) < 1e-12
+        # displacement divergence: Zel'dovich displacement is -grad phi, so sum_a d_a Vel_a = -delta;
+        # checked in k-space through the transforms of the library itself
+        f.compute_displacements(1, 0)
+        p = f.products()
+        assert np.isfinite(p["Vel"]).all() and np.isfinite(p["Vel_3LPT_2"]).all()
+        kx, ky, kz = synth.kgrid(n)
+        div = np.zeros((n, n, n // 2 + 1), dtype=np.complex128)
+        for a, k in enumerate((kx[:, None, None], ky[None, :, None], kz[None, None, :])):
+            div += 1j * k * f.forward_transform(p["Vel"][..., a].astype(np.float64))
+        lap = f.reverse_transform(div)
+        # Nyquist planes break the identity (k = +pi has no -pi partner); the input has none
+        assert np.sqrt(np.mean((lap + tr) ** 2)) < 1e-5 * np.sqrt(tv[-1])  # fp32 storage of Vel
+        rmax = p["Rmax"]
+        assert rmax.min() >= 0 and rmax.max() <= 2
