@@ -17,6 +17,14 @@
 #pragma once
 #include <math.h>
 
+// No FMA contraction in the solver: several steps subtract nearly equal numbers
+// (r*r - q*q*q at a double root, the cubic's -(s + q/s) - a1/3), where a fused
+// multiply-add changes the result by far more than an ulp.  The reference is
+// plain IEEE arithmetic; with contraction off only the libm calls can differ.
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
 #ifndef PF_HD
 #if defined(__HIPCC__)
 #define PF_HD __host__ __device__ __forceinline__

@@ -4,7 +4,12 @@ on identical inputs, plus size-independent properties at large grids.
 Tolerances (fp64 field path), as stated in DESIGN.md:
   * Hessian fields, LPT spectra : max abs diff <= 1e-12 x field amplitude
   * TrueVariance                : rel <= 1e-12
-  * Fmax (stored fp32)          : |diff| <= 2 ulp_fp32(max(|F|,1)), and > 0 on < 1e-3 of cells
+  * Fmax (stored fp32)          : |diff| <= 2 ulp_fp32(max(|F|,1)) and > 0 on < 1e-3 of cells, EXCEPT on
+                                  <= 2e-5 of the cells, where the reference's own cubic is ill-conditioned
+                                  (den = det/126 + 5 l1 d (d-l1)/84 cancels when d = l1+l2+l3 ~ 0,
+                                  src/collapse_times.c:133): there |diff| <= 2e-3, and the oracle fed with
+                                  the GPU's Hessian (equal to its own to ~1e-15) reproduces the GPU value
+  * per-cell solver, equal input: identical sentinels and zeros; <= 1e-12 relative on > 99.95 % of random Hessians (libm ulps)
   * Rmax                        : identical on >= 99.9 % of cells
   * displacements (stored fp32) : |diff| <= 4e-7 x amplitude (fp32 rounding of equal fp64 values)
 """
@@ -28,10 +33,14 @@ def api():
 
 
 def _fmax_close(got, want):
+    """returns the indices of the ill-conditioned outlier cells (normally none below 64^3)"""
     ulp = np.spacing(np.maximum(np.abs(want), 1.0).astype(np.float32)).astype(np.float64)
     d = np.abs(got.astype(np.float64) - want.astype(np.float64))
-    assert np.all(d <= 2 * ulp), (d.max(), np.argwhere(d > 2 * ulp)[:3])
+    bad = d > 2 * ulp
+    assert bad.sum() <= max(0, int(2e-5 * d.size)), (int(bad.sum()), d.max(), np.argwhere(bad)[:3])
+    assert d.max() <= 2e-3, d.max()
     assert np.mean(d > 0) < 1e-3, np.mean(d > 0)
+    return np.argwhere(bad)
 
 
 @pytest.mark.parametrize("n", [16, 32, 64, 128, 256])
@@ -54,7 +63,7 @@ def test_transforms_vs_pocketfft(api, n):
 def test_collapse_cells_kat_and_random(api):
     with open(os.path.join(GOLD, "collapse_kat.json")) as fh:
         kat = json.load(fh)
-    with api.Fmax(16) as f:
+    with api.Fmax(64) as f:
         x, y = synth.invgrow_table("eds")
         f.set_invgrow(x, y)
         d = np.array([c["d"] for c in kat["inverse_collapse_time"]])
@@ -77,13 +86,14 @@ def test_collapse_cells_kat_and_random(api):
     o.set_invgrow(x, y)
     want = np.array([o.inverse_collapse_time(row)[0] for row in d])
     both_nan = np.isnan(F) & np.isnan(want)
-    sentinel_same = (F == -10.0) == (want == -10.0)
-    assert np.mean(sentinel_same) > 0.9999
-    ok = both_nan | ~sentinel_same | (np.abs(F - want) <= 1e-9 * np.maximum(1.0, np.abs(want)))
-    assert ok.all(), (np.argwhere(~ok)[:5], F[~ok][:5], want[~ok][:5])
-    # the bulk agrees to round-off
-    good = np.isfinite(F) & np.isfinite(want) & sentinel_same
-    assert np.median(np.abs(F[good] - want[good])) < 1e-14
+    # no FMA contraction in the device solver: same IEEE operations as the CPU, only libm differs
+    assert np.array_equal(F == -10.0, want == -10.0)
+    assert np.array_equal(F == 0.0, want == 0.0)
+    assert np.mean((F == want) | both_nan) > 0.5  # the rest: 1-ulp libm differences
+    ok = both_nan | (np.abs(F - want) <= 1e-12 * np.maximum(1.0, np.abs(want)))
+    # libm differences (<= 1-2 ulp in acos/cos/pow/exp/log10) are amplified where the cubic is ill-conditioned
+    assert np.mean(ok) > 0.9995, np.mean(ok)
+    assert np.all(both_nan | (np.abs(F - want) <= 1e-6 * np.maximum(1.0, np.abs(want))))
 
 
 @pytest.mark.parametrize("n,rs", [(16, 0.0), (32, 1.5), (64, 2.8), (64, 0.0)])
@@ -129,9 +139,27 @@ def test_full_path_vs_oracle(api, n, ns, kind):
     radii[-1] = 0.0
     (tv, p, pdf, kv), (tv_o, po, pdf_o, kv_o) = _run_both(api, n, radii, kind)
     assert np.allclose(tv, tv_o, rtol=1e-12), (tv, tv_o)
-    _fmax_close(p["Fmax"], po["Fmax"])
+    outliers = _fmax_close(p["Fmax"], po["Fmax"])
     assert np.mean(p["Rmax"] != po["Rmax"]) < 1e-3
     assert (po["Fmax"] >= 1).sum() > 0
+    if len(outliers):
+        # every outlier is explained by the ~1e-15 difference of the Hessians: the oracle's solver on the
+        # GPU's Hessian values gives the GPU's Fmax
+        dk = synth.make_density(n, seed=synth.SEED)
+        x, y = synth.invgrow_table(kind)
+        o = oracle_lib.Oracle(8, 1)
+        o.set_invgrow(x, y)
+        with api.Fmax(n) as f:
+            f.set_density(dk)
+            for ir in sorted(set(int(p["Rmax"][tuple(c)]) for c in outliers)):
+                f.compute_second_derivatives(radii[ir])
+                hg = [f.second_derivative(i) for i in range(6)]
+                for c in outliers:
+                    c = tuple(c)
+                    if p["Rmax"][c] != ir:
+                        continue
+                    fo = o.inverse_collapse_time(np.array([h[c] for h in hg]))[0]
+                    assert np.float32(fo) == p["Fmax"][c], (c, fo, p["Fmax"][c], po["Fmax"][c])
     for w in range(3):
         assert np.max(np.abs(kv[w] - kv_o[w])) < 1e-12 * np.max(np.abs(kv_o[w])) * np.log2(n), w
     for name in ("Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
