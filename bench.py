@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py -- grid-cells/s through the full multi-radius Fmax sweep + 3LPT
+displacement build (BASELINE.json metric), on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 3 --warmup 1
+
+One step = one pass of the hot path over one synthetic density field already
+resident in HBM: pf_sweep (Ns = 12 radii: six second derivatives + collapse
+times each) then pf_displacements (2LPT/3LPT sources + 12 displacement fields).
+Workload at every N: the 1024^3 fp64 box the metric is quoted on (fits one
+GPU: ~226 GB), sharded in x-slabs over the ranks -> strong scaling.  Rank 0
+prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+from pinocchio_amd import api, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def alg_bytes_per_cell(ns: int, w: int, lpt: bool) -> float:
+    """SURVEY.md section 8d contract figure: Ns*(49W+16) + 207W + 48"""
+    return ns * (49 * w + 16) + ((207 * w + 48) if lpt else 0)
+
+
+def cpu_baseline(n: int, ns: int, lpt: bool) -> dict:
+    """The CPU oracle (a port of the reference's structure: one k-loop + one c2r
+    per derivative, per-cell ell_classic, AoS fp32 products) timed on this box's
+    host cores on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)  # the slab loops of an n=256 grid do not scale past ~n/4 threads
+    dk = synth.philox_density(n, synth.SEED, 2.5, -2.0)
+    x, y = synth.invgrow_table("lcdm")
+    o = oracle_lib.Oracle(n, threads)
+    o.set_density(dk)
+    o.set_invgrow(x, y)
+    o.set_growth(synth.growth_multipliers())
+    radii = synth.radii_ladder(ns)
+    t0 = time.perf_counter()
+    o.compute_fmax(radii, do_lpt=lpt)
+    dt = time.perf_counter() - t0
+    tm = o.timers()
+    return {"value": n ** 3 / dt, "unit": "grid-cells/s", "cores": threads, "kind": "port",
+            "sample": f"{n}^3 box, {ns} radii{' + 3LPT' if lpt else ''}, same synthetic spectrum, {dt:.2f} s "
+                      f"(fft {tm['fft']:.2f} s, collapse {tm['coll']:.2f} s, lpt {tm['lpt']:.2f} s); host has {cores} hardware threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=1024, help="grid side (default: the 1024^3 box of the metric)")
+    ap.add_argument("--ns", type=int, default=12, help="number of smoothing radii")
+    ap.add_argument("--field-bytes", type=int, default=8, choices=(4, 8))
+    ap.add_argument("--no-lpt", action="store_true", help="Fmax-only (BASELINE config 2)")
+    ap.add_argument("--cpu-n", type=int, default=256, help="grid side of the CPU-baseline sample (0: skip)")
+    ap.add_argument("--exchange", default="rccl", choices=("rccl", "torch"))
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    lpt = not args.no_lpt
+    n, ns = args.n, args.ns
+
+    dist = torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    f = api.Fmax(n, rank=rank, nranks=world, device=local_rank, field_bytes=args.field_bytes, timing=True)
+    keep = []
+    if world > 1:
+        from pinocchio_amd import dist as pfdist
+        keep.append(pfdist.install_exchange(f, dist, torch, kind=args.exchange))
+
+    f.synth_density(synth.SEED, 2.5, -2.0)
+    x, y = synth.invgrow_table("lcdm")
+    f.set_invgrow(x, y)
+    f.set_growth(synth.growth_multipliers())
+    radii = synth.radii_ladder(ns)
+
+    def step():
+        tv = f.sweep(radii)
+        if lpt:
+            f.compute_displacements(1, 0)
+        return tv
+
+    def fence():
+        f.synchronize()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    tv = None
+    for _ in range(args.warmup):
+        tv = step()
+    f.reset_kernel_stats()
+    f.reset_cputime()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tv = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    stats = f.kernel_stats()
+    cput = f.cputime()
+
+    if rank == 0:
+        ms = 1e3 * dt / args.steps
+        cells = float(n) ** 3
+        value = cells * args.steps / dt
+        dom = max((s for s in stats if s["name"] != "exchange"), key=lambda s: s["total_ms"])
+        ach = dom["alg_bytes"] / (dom["total_ms"] * 1e-3) / 1e9
+        w = args.field_bytes
+        out = {
+            "metric": "grid-cells/sec for full Fmax sweep (all smoothing radii) + 3LPT, 1024^3 box"
+                      if (n == 1024 and lpt) else f"grid-cells/sec, Fmax sweep{' + 3LPT' if lpt else ''}, {n}^3 box",
+            "value": value, "unit": "grid-cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64" if w == 8 else "f32 fields / f64 collapse", "data": "synthetic",
+            "config": {"workload": f"{n}^3 box, {ns} smoothing radii, Fmax sweep{' + 2LPT/3LPT displacements' if lpt else ' only'}, "
+                                   f"{'fp64' if w == 8 else 'fp32-field'} path, Philox white noise with P(k)~k^-2, sigma(R=0)=2.5",
+                       "grid": n, "nsmooth": ns, "lpt": lpt, "parallelism": f"x-slabs over {world} GPU(s)",
+                       "device_GB": f.device_bytes / 1e9, "sigma_R0": float(np.sqrt(tv[-1]))},
+            "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "launches": dom["launches"], "avg_ms": dom["total_ms"] / dom["launches"],
+                         "alg_bytes_per_launch": dom["alg_bytes"] / dom["launches"]},
+            "path_roofline": {"contract_bytes_per_cell": alg_bytes_per_cell(ns, w, lpt),
+                              "frac_of_hbm_peak": alg_bytes_per_cell(ns, w, lpt) * cells / (ms * 1e-3) / world / (HBM_PEAK_GBS * 1e9)},
+            "kernels": [{"name": s["name"], "launches": s["launches"], "ms_per_step": s["total_ms"] / args.steps,
+                         "GBps": s["alg_bytes"] / max(s["total_ms"], 1e-9) / 1e6} for s in stats],
+            "phases_s_per_step": {k: v / args.steps for k, v in cput.items()},
+        }
+        if world == 1 and args.cpu_n:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_n, ns, lpt)
+        print(json.dumps(out))
+    f.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
