@@ -19,6 +19,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -57,12 +58,12 @@ extern "C" const char *pf_last_error(void) { return g_err; }
 enum {
   KS_XPASS_HESS = 0, KS_YPASS_HESS, KS_ZPASS_HESS, KS_COLLAPSE, KS_LPT_SRC, KS_LPT_ACC, KS_R2C_Z, KS_YPASS_FWD,
   KS_XPASS_FWD, KS_XPASS_DISP, KS_YPASS_DISP, KS_ZPASS_DISP, KS_XPASS_PLAIN, KS_YPASS_PLAIN, KS_ZPASS_PLAIN,
-  KS_EXCHANGE, KS_MISC, KS_COUNT
+  KS_EXCHANGE, KS_MISC, KS_ZCOLLAPSE, KS_COUNT
 };
 static const char *ks_names[KS_COUNT] = {
     "xpass_hess_1to3", "ypass_hess_3to6", "zpass_c2r_hess_6", "collapse", "lpt_sources", "lpt_accum", "zpass_r2c",
     "ypass_fwd", "xpass_fwd", "xpass_disp_1to2", "ypass_disp_2to3", "zpass_c2r_disp_3", "xpass_plain", "ypass_plain",
-    "zpass_c2r_plain", "exchange", "misc"};
+    "zpass_c2r_plain", "exchange", "misc", "zpass_collapse_fused"};
 
 struct EvPair { int kind; hipEvent_t a, b; double bytes; };
 
@@ -72,7 +73,12 @@ struct pf_ctx {
   pf_config cfg;
   int n, nzh, nzp, P, rank, nxl, nyl, fb;
   bool timing;
-  hipStream_t stream;
+  hipStream_t stream;   // FFT passes and everything else
+  hipStream_t stream2;  // collapse solve of radius i, overlapped with the passes of radius i+1 (pf_sweep)
+  hipEvent_t ev_h[2], ev_c[2];
+  int collapse_blocks;
+  bool overlap, fuse;
+  int ncu, fused_wg_per_cu, fused_skew_ns;
   bool own_stream;
   size_t field_bytes;  // one spectrum-sized field
   size_t dev_bytes;
@@ -112,21 +118,22 @@ static hipEvent_t ev_get(pf_ctx *c) {
   hipEvent_t e; hipEventCreate(&e); return e;
 }
 struct KTimer {
-  pf_ctx *c; int kind; double bytes; hipEvent_t a;
-  KTimer(pf_ctx *c_, int kind_, double bytes_) : c(c_), kind(kind_), bytes(bytes_), a(nullptr) {
-    if (c->timing) { a = ev_get(c); hipEventRecord(a, c->stream); }
+  pf_ctx *c; int kind; double bytes; hipEvent_t a; hipStream_t st;
+  KTimer(pf_ctx *c_, int kind_, double bytes_, hipStream_t st_ = nullptr) : c(c_), kind(kind_), bytes(bytes_), a(nullptr), st(st_ ? st_ : c_->stream) {
+    if (c->timing) { a = ev_get(c); hipEventRecord(a, st); }
   }
   ~KTimer() {
-    if (c->timing) { hipEvent_t b = ev_get(c); hipEventRecord(b, c->stream); c->evs.push_back({kind, a, b, bytes}); }
+    if (c->timing) { hipEvent_t b = ev_get(c); hipEventRecord(b, st); c->evs.push_back({kind, a, b, bytes}); }
   }
 };
 struct PhaseTimer {
-  pf_ctx *c; int kind; hipEvent_t a;
-  PhaseTimer(pf_ctx *c_, int kind_) : c(c_), kind(kind_) { a = ev_get(c); hipEventRecord(a, c->stream); }
-  ~PhaseTimer() { hipEvent_t b = ev_get(c); hipEventRecord(b, c->stream); c->phase_evs.push_back({kind, a, b, 0}); }
+  pf_ctx *c; int kind; hipEvent_t a; hipStream_t st;
+  PhaseTimer(pf_ctx *c_, int kind_, hipStream_t st_ = nullptr) : c(c_), kind(kind_), st(st_ ? st_ : c_->stream) { a = ev_get(c); hipEventRecord(a, st); }
+  ~PhaseTimer() { hipEvent_t b = ev_get(c); hipEventRecord(b, st); c->phase_evs.push_back({kind, a, b, 0}); }
 };
 static void resolve_events(pf_ctx *c) {
   hipStreamSynchronize(c->stream);
+  hipStreamSynchronize(c->stream2);
   for (auto &e : c->evs) {
     float ms = 0; hipEventElapsedTime(&ms, e.a, e.b);
     c->ks_ms[e.kind] += ms; c->ks_bytes[e.kind] += e.bytes; c->ks_n[e.kind]++;
@@ -165,6 +172,7 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   if (n < 16 || n > 2048 || (n & (n - 1))) return pf_fail(rank, "pf_create: grid size %lld must be a power of two in [16, 2048]", n);
   if (cfg->nranks < 1 || n % cfg->nranks || cfg->rank < 0 || cfg->rank >= cfg->nranks)
     return pf_fail(rank, "pf_create: nranks %d must divide the grid size %lld (slab decomposition)", cfg->nranks, n);
+  if (cfg->nranks & (cfg->nranks - 1)) return pf_fail(rank, "pf_create: nranks %d must be a power of two", cfg->nranks);
   if (cfg->field_bytes != 8 && cfg->field_bytes != 4) return pf_fail(rank, "pf_create: field_bytes must be 8 or 4");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -185,6 +193,32 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
 
   HIPCHK(c, hipSetDevice(cfg->device));
   HIPCHK(c, hipStreamCreate(&c->stream));
+  HIPCHK(c, hipStreamCreate(&c->stream2));
+  for (int i = 0; i < 2; i++) {
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_h[i], hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_c[i], hipEventDisableTiming));
+  }
+  {
+    // the collapse solve is fp64-ALU bound and runs beside the HBM-bound passes of the next radius:
+    // 2 workgroups (of 4 waves) per CU leave VGPRs for one pass workgroup per CU
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, cfg->device));
+    // Experiments kept behind switches (measured on MI355X at 1024^3, see DESIGN.md "What did not pay"):
+    // PF_OVERLAP=1: collapse of radius i on a second stream beside the passes of radius i+1 -- no gain, each kernel
+    //   loses in occupancy what the pair wins in overlap.
+    // PF_FUSE=1: z-pass fused with the solve in one persistent kernel -- slower (86 vs 74 ms per radius): the solve is
+    //   fp64-ALU bound, so the row transforms' instructions are exposed instead of hidden under HBM time.
+    c->overlap = getenv("PF_OVERLAP") && atoi(getenv("PF_OVERLAP"));
+    c->fuse = getenv("PF_FUSE") && atoi(getenv("PF_FUSE"));
+    c->ncu = prop.multiProcessorCount;
+    c->fused_wg_per_cu = 3;
+    c->fused_skew_ns = 12000;
+    if (const char *e = getenv("PF_FUSED_WG_PER_CU")) c->fused_wg_per_cu = atoi(e) > 0 ? atoi(e) : 3;
+    int per_cu = c->overlap ? 2 : 8;
+    if (const char *e = getenv("PF_COLLAPSE_WG_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
+    c->collapse_blocks = prop.multiProcessorCount * per_cu;
+    if (c->collapse_blocks > PF_NBLK) c->collapse_blocks = PF_NBLK;
+  }
   c->field_bytes = (size_t)c->n * c->nyl * c->nzp * 2 * c->fb;
   PFCHK(c, dev_alloc(c, &c->dk, c->field_bytes));
   PFCHK(c, dev_alloc(c, (void **)&c->blockA, 3 * c->field_bytes));
@@ -230,6 +264,8 @@ extern "C" int pf_destroy(pf_ctx *c) {
   for (auto &e : c->phase_evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   for (auto e : c->evpool) hipEventDestroy(e);
   if (c->own_stream) hipStreamDestroy(c->stream);
+  hipStreamDestroy(c->stream2);
+  for (int i = 0; i < 2; i++) { hipEventDestroy(c->ev_h[i]); hipEventDestroy(c->ev_c[i]); }
   delete c;
   return 0;
 }
@@ -242,7 +278,7 @@ extern "C" int pf_set_stream(pf_ctx *c, void *stream) {
   return 0;
 }
 extern "C" void *pf_get_stream(pf_ctx *c) { return c ? (void *)c->stream : nullptr; }
-extern "C" int pf_synchronize(pf_ctx *c) { HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
+extern "C" int pf_synchronize(pf_ctx *c) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2)); return 0; }
 extern "C" size_t pf_device_bytes(pf_ctx *c) { return c ? c->dev_bytes : 0; }
 
 extern "C" int pf_set_exchange(pf_ctx *c, pf_alltoall_fn fn, void *user) { c->a2a = fn; c->a2a_user = user; return 0; }
@@ -270,14 +306,15 @@ static int allreduce_dev(pf_ctx *c, void *buf, size_t count, int is_u64) {
 }
 
 // ---------------------------------------------------------- pass helpers ----
+static int ilog2i(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
 static PfAddr addr_ky_x(const pf_ctx *c) {  // KY layout, e = x, outer = y_local
-  PfAddr a; a.os = c->nzp; a.el = c->n; a.ehs = 0; a.els = (long long)c->nyl * c->nzp; return a;
+  PfAddr a; a.os = c->nzp; a.el_shift = ilog2i(c->n); a.ehs = 0; a.els = (long long)c->nyl * c->nzp; return a;
 }
 static PfAddr addr_blocks_y(const pf_ctx *c) {  // P blocks [p][nxl][nyl][nzp], e = y = p*nyl + yl, outer = x_local
-  PfAddr a; a.os = (long long)c->nyl * c->nzp; a.el = c->nyl; a.ehs = (long long)c->nxl * c->nyl * c->nzp; a.els = c->nzp; return a;
+  PfAddr a; a.os = (long long)c->nyl * c->nzp; a.el_shift = ilog2i(c->nyl); a.ehs = (long long)c->nxl * c->nyl * c->nzp; a.els = c->nzp; return a;
 }
 static PfAddr addr_xs_y(const pf_ctx *c) {  // XS layout, e = y, outer = x_local
-  PfAddr a; a.os = (long long)c->n * c->nzp; a.el = c->n; a.ehs = 0; a.els = c->nzp; return a;
+  PfAddr a; a.os = (long long)c->n * c->nzp; a.el_shift = ilog2i(c->n); a.ehs = 0; a.els = c->nzp; return a;
 }
 
 struct Job { const void *in; void *out; int mul; };
@@ -322,7 +359,7 @@ static int zpass_c2r(pf_ctx *c, int kind, int njobs, const ZJob *jobs, const dou
 
 // six second derivatives of `spec` (KY layout) at smoothing rs -> six real fields out[0..5] (R layout)
 // order 11,22,33,12,13,23 (src/LPT.c:36-44); compute_second_derivatives, src/fmax.c:225-258
-static int hessian_of(pf_ctx *c, const void *spec, double rs, const double *dc, void *const out[6]) {
+static int hessian_of(pf_ctx *c, const void *spec, double rs, const double *dc, void *const out[6], bool xy_only = false) {
   const Job xj[3] = {{spec, c->A[0], PF_MUL_ONE}, {spec, c->A[1], PF_MUL_K}, {spec, c->A[2], PF_MUL_K2}};
   PFCHK(c, xpass(c, KS_XPASS_HESS, +1, 3, xj, 1, rs, 1.0, 1));
   const void *R[3] = {c->A[0], c->A[1], c->A[2]};
@@ -336,6 +373,7 @@ static int hessian_of(pf_ctx *c, const void *spec, double rs, const double *dc, 
   const Job yj[6] = {{R[2], out[0], PF_MUL_ONE}, {R[1], out[3], PF_MUL_K}, {R[1], out[4], PF_MUL_ONE},
                      {R[0], out[1], PF_MUL_K2}, {R[0], out[5], PF_MUL_K},  {R[0], out[2], PF_MUL_ONE}};
   PFCHK(c, ypass(c, KS_YPASS_HESS, +1, 6, yj, true, false, 3));
+  if (xy_only) return 0;
   const ZJob zj[6] = {{out[0], out[0], PF_MUL_ONE, 0}, {out[1], out[1], PF_MUL_ONE, 0}, {out[2], out[2], PF_MUL_K2, 0},
                       {out[3], out[3], PF_MUL_ONE, 0}, {out[4], out[4], PF_MUL_K, 0},   {out[5], out[5], PF_MUL_K, 0}};
   PFCHK(c, zpass_c2r(c, KS_ZPASS_HESS, 6, zj, dc));
@@ -478,19 +516,42 @@ extern "C" int pf_second_derivatives(pf_ctx *c, double rs) {
   return 0;
 }
 
-static int collapse_enqueue(pf_ctx *c, int ismooth) {
+static int collapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], hipStream_t st) {
   PfCollapseParams p; memset(&p, 0, sizeof(p));
-  for (int i = 0; i < 6; i++) p.h[i] = c->B[i];
+  for (int i = 0; i < 6; i++) p.h[i] = H[i];
   p.pitch = 2 * c->nzp; p.nrows = (long long)c->nxl * c->n; p.n = c->n; p.fmax = c->fmax; p.rmax = c->rmax; p.ismooth = ismooth;
   if (spline_for(c, ismooth, &p.spline)) return 1;
   p.partials = c->partials;
-  size_t nb = (ncell(c) + 255) / 256; if (nb > PF_NBLK) nb = PF_NBLK;
+  size_t nb = (ncell(c) + 255) / 256; if (nb > (size_t)c->collapse_blocks) nb = c->collapse_blocks;
   p.nblocks = (int)nb;
   {
-    KTimer t(c, KS_COLLAPSE, (double)ncell(c) * (6.0 * c->fb + 16.0));
-    PFCHK(c, pf_launch_collapse(c->fb, p, c->stream));
+    KTimer t(c, KS_COLLAPSE, (double)ncell(c) * (6.0 * c->fb + 16.0), st);
+    PFCHK(c, pf_launch_collapse(c->fb, p, st));
   }
-  PFCHK(c, pf_launch_final_sum(c->partials, p.nblocks, c->scal + SC_VAR0 + 2 * ismooth, c->stream));
+  PFCHK(c, pf_launch_final_sum(c->partials, p.nblocks, c->scal + SC_VAR0 + 2 * ismooth, st));
+  return 0;
+}
+
+// z-pass of the six components fused with the collapse solve (pf_fused_kernels.hip); H holds the y-pass output
+static int zcollapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], const double *dc, bool write_h, hipStream_t st) {
+  PfFusedParams p; memset(&p, 0, sizeof(p));
+  const int mul[6] = {PF_MUL_ONE, PF_MUL_ONE, PF_MUL_K2, PF_MUL_ONE, PF_MUL_K, PF_MUL_K};
+  for (int i = 0; i < 6; i++) { p.in[i] = H[i]; p.out[i] = H[i]; p.mul[i] = mul[i]; }
+  p.write_h = write_h ? 1 : 0;
+  p.nlines = (long long)c->nxl * c->n; p.in_pitch = c->nzp; p.out_pitch = 2 * c->nzp;
+  p.norm = 1.0 / ((double)c->n * c->n * c->n); p.dc = dc; p.tw = c->tw;
+  p.fmax = c->fmax; p.rmax = c->rmax; p.ismooth = ismooth;
+  if (spline_for(c, ismooth, &p.spline)) return 1;
+  p.partials = c->partials; p.max_blocks = PF_NBLK;
+  p.debug_skip = getenv("PF_FUSED_DEBUG_SKIP") ? atoi(getenv("PF_FUSED_DEBUG_SKIP")) : 0;
+  p.skew_ns = getenv("PF_FUSED_SKEW_NS") ? atoi(getenv("PF_FUSED_SKEW_NS")) : c->fused_skew_ns;
+  p.ncu = c->ncu;
+  int nb = 0;
+  {
+    KTimer t(c, KS_ZCOLLAPSE, 6.0 * spec_bytes_alg(c) + (double)ncell(c) * 16.0 + (write_h ? 6.0 * real_bytes_alg(c) : 0.0), st);
+    PFCHK(c, pf_launch_zcollapse(c->fb, c->n, p, c->fused_wg_per_cu, c->ncu, st, &nb));
+  }
+  PFCHK(c, pf_launch_final_sum(c->partials, nb, c->scal + SC_VAR0 + 2 * ismooth, st));
   return 0;
 }
 
@@ -505,7 +566,7 @@ extern "C" int pf_collapse_times(pf_ctx *c, int ismooth, double *tv) {
     return pf_fail(c->rank, "pf_collapse_times: products not initialised (ismooth 0 must come first)");
   {
     PhaseTimer pt(c, 1);
-    if (collapse_enqueue(c, ismooth)) return 1;
+    if (collapse_enqueue(c, ismooth, c->B, c->stream)) return 1;
   }
   PFCHK(c, allreduce_dev(c, c->scal + SC_VAR0 + 2 * ismooth, 2, 0));
   double s[2];
@@ -519,19 +580,41 @@ extern "C" int pf_sweep(pf_ctx *c, int ns, const double *radius_cells, double *t
   if (!c || !radius_cells) return pf_fail(0, "pf_sweep: null argument");
   if (ns < 1 || ns > PF_MAX_SMOOTH) return pf_fail(c->rank, "pf_sweep: Nsmooth %d not in [1, %d]", ns, PF_MAX_SMOOTH);
   if (!c->have_density) return pf_fail(c->rank, "pf_sweep: density not set");
+  if (c->overlap)
+    for (int i = 0; i < 6; i++)
+      if (!c->B2[i]) PFCHK(c, dev_alloc(c, &c->B2[i], c->field_bytes));
   PhaseTimer ft(c, 4);
-  PFCHK(c, pf_launch_fill_products(c->fmax, c->rmax, c->vel12, ncell(c), c->stream));
+  // Two Hessian buffers (B, B2) and two streams: the collapse solve of radius i (fp64-ALU bound,
+  // stream2) runs beside the FFT passes of radius i+1 (HBM bound, stream).  The Fmax/Rmax running
+  // max stays in radius order because every collapse launch is on stream2.
+  HIPCHK(c, hipEventRecord(c->ev_h[0], c->stream));
+  HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_h[0], 0));
+  PFCHK(c, pf_launch_fill_products(c->fmax, c->rmax, c->vel12, ncell(c), c->overlap ? c->stream2 : c->stream));
   c->products_init = true;
   for (int ismooth = 0; ismooth < ns; ismooth++) {
+    const int b = c->overlap ? (ismooth & 1) : 0;
+    void **H = b ? c->B2 : c->B;
+    if (c->overlap && ismooth >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_c[b], 0));
     {
       PhaseTimer pt(c, 0);
-      PFCHK(c, hessian_of(c, c->dk, radius_cells[ismooth], c->scal + SC_DC_DK, c->B));
+      PFCHK(c, hessian_of(c, c->dk, radius_cells[ismooth], c->scal + SC_DC_DK, H, c->fuse));
     }
+    HIPCHK(c, hipEventRecord(c->ev_h[b], c->stream));
+    if (c->overlap) HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_h[b], 0));
+    hipStream_t cst = c->overlap ? c->stream2 : c->stream;
     {
-      PhaseTimer pt(c, 1);
-      if (collapse_enqueue(c, ismooth)) return 1;
+      PhaseTimer pt(c, 1, cst);
+      if (c->fuse) {
+        if (zcollapse_enqueue(c, ismooth, H, c->scal + SC_DC_DK, ismooth == ns - 1, cst)) return 1;
+      } else if (collapse_enqueue(c, ismooth, H, cst)) return 1;
     }
+    HIPCHK(c, hipEventRecord(c->ev_c[b], cst));
   }
+  // join; keep the R=0 Hessian (last radius) in B for the LPT sources
+  HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_c[(ns - 1) & 1], 0));
+  if (ns >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_c[(ns - 2) & 1], 0));
+  if (c->overlap && ((ns - 1) & 1))
+    for (int i = 0; i < 6; i++) { void *t = c->B[i]; c->B[i] = c->B2[i]; c->B2[i] = t; }
   c->have_hessian = true; c->last_ns = ns;
   PFCHK(c, allreduce_dev(c, c->scal + SC_VAR0, 2 * (size_t)ns, 0));
   std::vector<double> s(2 * ns);

@@ -71,21 +71,21 @@ __global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse(const PfCollapsePara
   }
 }
 
+// one wave, fixed association order: bitwise reproducible for a given launch geometry
 __global__ void k_final_sum2(const double *partials, int nblocks, double *out2) {
-  // single thread, fixed order: bitwise reproducible
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double a = 0, b = 0;
-    for (int i = 0; i < nblocks; i++) { a += partials[2 * i]; b += partials[2 * i + 1]; }
-    out2[0] = a; out2[1] = b;
-  }
+  double a = 0, b = 0;
+  for (int i = threadIdx.x; i < nblocks; i += 64) { a += partials[2 * i]; b += partials[2 * i + 1]; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
+  if (threadIdx.x == 0) { out2[0] = a; out2[1] = b; }
 }
 
 __global__ void k_sum1(const double *partials, int nblocks, double scale, double *out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double a = 0;
-    for (int i = 0; i < nblocks; i++) a += partials[i];
-    out[0] = a * scale;
-  }
+  double a = 0;
+  for (int i = threadIdx.x; i < nblocks; i += 64) a += partials[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+  if (threadIdx.x == 0) out[0] = a * scale;
 }
 
 __global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse_cells(const double *d, size_t count, PfSplineDev s, double *F) {

@@ -12,95 +12,91 @@
 //               and the DC mode; writes fp64/fp32 fields or fp32 product columns.
 //   k_r2c     : forward z-pass (real rows -> half-spectrum rows), LPT sources.
 //
-// Several (input, multiplier, output) jobs share one launch with the job index
-// fastest in blockIdx.x, so workgroups that read the same input tile run
-// concurrently and the re-reads are served by the Infinity Cache.
+// A strided launch carries several (input, multiplier, output) jobs grouped by
+// input: a workgroup reads its tile once and transforms it for every job on it.
 #include "pf_internal.h"
 #include "pf_fft_core.h"
 
-template <typename F> using C_t = pfc<F>;
-
-template <typename F, int N, int DIR, int TWS, int S = 0>
-struct PfStages {
-  template <typename WR, typename RD>
-  static __device__ __forceinline__ void run(pfc<F> (&v)[8], int tl, const pfc<F> *__restrict__ tw, WR wr, RD rd) {
-    pf_stage<F, N, S, DIR, TWS>(v, tl, tw);
-    if constexpr (S + 1 < pf_nstages(N)) {
-      constexpr int NT = N / 8;
-#pragma unroll
-      for (int m = 0; m < 8; m++) wr(pf_stage_pos<N, S>(tl, m), v[m]);
-      __syncthreads();
-#pragma unroll
-      for (int m = 0; m < 8; m++) v[m] = rd(tl + m * NT);
-      __syncthreads();
-      PfStages<F, N, DIR, TWS, S + 1>::run(v, tl, tw, wr, rd);
-    }
-  }
-};
+#include "pf_fft_stages.h"
 
 __device__ __forceinline__ long long pf_addr(const PfAddr &a, int outer, int e, int col) {
-  return (long long)outer * a.os + (long long)(e / a.el) * a.ehs + (long long)(e % a.el) * a.els + col;
+  return (long long)outer * a.os + (long long)(e >> a.el_shift) * a.ehs + (long long)(e & ((1 << a.el_shift) - 1)) * a.els + col;
 }
 
+// XCD-aware work-item id: hardware deals consecutive workgroups round-robin over the 8 XCDs
+// (speed only, never correctness); give each XCD a contiguous range of tiles so that
+// neighbouring tiles, which share 128-byte lines when T*sizeof(complex) < 128, meet in one L2.
+__device__ __forceinline__ long long pf_xcd_swizzle(long long b, long long per_xcd) { return (b & 7) * per_xcd + (b >> 3); }
+
 template <typename F, int N, int T, int DIR>
-__global__ void __launch_bounds__(T *N / 8) k_strided(const PfStridedParams p) {
+__global__ void __launch_bounds__(T *N / 8) k_strided(const PfStridedParams p, const long long nwork, const int ntiles) {
   using C = pfc<F>;
   constexpr int NT = N / 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   C *lds = reinterpret_cast<C *>(smem);  // [N][T]
+  const long long w = pf_xcd_swizzle(blockIdx.x, (nwork + 7) >> 3);
+  if (w >= nwork) return;
   const int tid = threadIdx.x;
   const int c = tid % T, tl = tid / T;
-  const int job = blockIdx.x % p.njobs;
-  const int tile = blockIdx.x / p.njobs;
-  const int outer = blockIdx.y;
+  const int tile = (int)(w % ntiles);
+  const int outer = (int)(w / ntiles);
   const int col = tile * T + c;
   const bool valid = col < p.ncols;
-  const C *__restrict__ in = reinterpret_cast<const C *>(p.job[job].in);
-  C *__restrict__ out = reinterpret_cast<C *>(p.job[job].out);
-  const int mul = p.job[job].mul;
   const C *__restrict__ tw = reinterpret_cast<const C *>(p.tw);
+  const double kf = 2.0 * 3.14159265358979323846 / (double)N;
 
-  C v[8];
+  C src[8], v[8];
+#pragma unroll 1
+  for (int j = 0; j < p.njobs; j++) {
+    // Everything below is loop invariant except the job; left to LICM the compiler hoists every
+    // twiddle, LDS position and address out of the loop (~250 VGPRs, half the occupancy).  An
+    // opaque copy of the thread coordinates per iteration keeps the index math where it is used.
+    int tlj = tl, cj = c;
+    asm volatile("" : "+v"(tlj), "+v"(cj));
+    const int colj = tile * T + cj;
+    // jobs are grouped by input: a tile is read from HBM once and transformed for every job that uses it
+    if (j == 0 || p.job[j].in != p.job[j - 1].in) {
+      const C *__restrict__ in = reinterpret_cast<const C *>(p.job[j].in);
 #pragma unroll
-  for (int m = 0; m < 8; m++) {
-    const int e = tl + m * NT;
-    v[m] = valid ? in[pf_addr(p.ain, outer, e, col)] : pf_mk<F>(0, 0);
-  }
-
-  if (p.pre || mul != PF_MUL_ONE) {
-    const double kf = 2.0 * 3.14159265358979323846 / (double)N;
-    double ko2kc2 = 0.0;
-    if (p.pre) {
-      int so = outer + p.outer_offset;
-      if (so > N / 2) so -= N;
-      const double ko = kf * so, kc = kf * col;
-      ko2kc2 = ko * ko + kc * kc;
-    }
-#pragma unroll
-    for (int m = 0; m < 8; m++) {
-      const int e = tl + m * NT;
-      const int se = e > N / 2 ? e - N : e;
-      const double ke = kf * se;
-      double fac = 1.0;
-      if (p.pre) {
-        const double k2 = ke * ke + ko2kc2;
-        fac = (k2 != 0.0) ? exp(-0.5 * k2 * p.rs * p.rs) * p.growth / k2 : 0.0;
+      for (int m = 0; m < 8; m++) {
+        const int e = tlj + m * NT;
+        src[m] = valid ? in[pf_addr(p.ain, outer, e, colj)] : pf_mk<F>(0, 0);
       }
-      if (mul == PF_MUL_K || mul == PF_MUL_IK) fac *= ke;
-      if (mul == PF_MUL_K2) fac *= ke * ke;
-      v[m] = pf_scale(v[m], (F)fac);
-      if (mul == PF_MUL_IK) v[m] = pf_mul_i<+1>(v[m]);
+      if (p.pre) {
+        int so = outer + p.outer_offset;
+        if (so > N / 2) so -= N;
+        const double ko = kf * so, kc = kf * colj;
+        const double ko2kc2 = ko * ko + kc * kc;
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          const int e = tlj + m * NT;
+          const double ke = kf * (e > N / 2 ? e - N : e);
+          const double k2 = ke * ke + ko2kc2;
+          const double fac = (k2 != 0.0) ? exp(-0.5 * k2 * p.rs * p.rs) * p.growth / k2 : 0.0;
+          src[m] = pf_scale(src[m], (F)fac);
+        }
+      }
     }
-  }
-
-  PfStages<F, N, DIR, 1>::run(
-      v, tl, tw, [&](int pos, C val) { lds[pos * T + c] = val; }, [&](int pos) { return lds[pos * T + c]; });
-
-  if (valid) {
+    const int mul = p.job[j].mul;
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-      const int e = tl + m * NT;
-      out[pf_addr(p.aout, outer, e, col)] = v[m];
+      const int e = tlj + m * NT;
+      const F ke = (F)(kf * (e > N / 2 ? e - N : e));
+      C x = src[m];
+      if (mul == PF_MUL_K) x = pf_scale(x, ke);
+      else if (mul == PF_MUL_K2) x = pf_scale(x, ke * ke);
+      else if (mul == PF_MUL_IK) x = pf_mul_i<+1>(pf_scale(x, ke));
+      v[m] = x;
+    }
+    PfStages<F, N, DIR, 1>::run(
+        v, tlj, tw, [&](int pos, C val) { lds[pos * T + cj] = val; }, [&](int pos) { return lds[pos * T + cj]; });
+    if (valid) {
+      C *__restrict__ out = reinterpret_cast<C *>(p.job[j].out);
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        const int e = tlj + m * NT;
+        out[pf_addr(p.aout, outer, e, colj)] = v[m];
+      }
     }
   }
 }
@@ -136,15 +132,7 @@ __global__ void __launch_bounds__(TL *(N / 16)) k_c2r(const PfC2RParams p) {
 #pragma unroll
   for (int m = 0; m < 8; m++) {
     const int e = tl + m * NT;
-    C xk = L[e], xmk = L[M - e];
-    if (mul != PF_MUL_ONE) {
-      F fk = kf * (F)e, fm = kf * (F)(M - e);
-      if (mul == PF_MUL_K2) { fk *= fk; fm *= fm; }
-      xk = pf_scale(xk, fk);
-      xmk = pf_scale(xmk, fm);
-      if (mul == PF_MUL_IK) { xk = pf_mul_i<+1>(xk); xmk = pf_mul_i<+1>(xmk); }
-    }
-    v[m] = pf_c2r_pre<F>(xk, xmk, tw[e], e == 0);
+    v[m] = pf_zfold<F>(L[e], L[M - e], e, M, mul, kf, tw[e]);
   }
   __syncthreads();
 
@@ -160,14 +148,14 @@ __global__ void __launch_bounds__(TL *(N / 16)) k_c2r(const PfC2RParams p) {
 #pragma unroll
       for (int m = 0; m < 8; m++) {
         const int n2 = tl + m * NT;
-        o[n2] = make_float2((float)(v[m].x * norm + dcv), (float)(v[m].y * norm + dcv));
+        o[n2] = make_float2((float)pf_norm_dc(v[m].x, norm, dcv), (float)pf_norm_dc(v[m].y, norm, dcv));
       }
     } else {
       C *o = reinterpret_cast<C *>(reinterpret_cast<F *>(p.job[job].out) + row * p.out_pitch);
 #pragma unroll
       for (int m = 0; m < 8; m++) {
         const int n2 = tl + m * NT;
-        o[n2] = pf_mk<F>(v[m].x * norm + dcv, v[m].y * norm + dcv);
+        o[n2] = pf_mk<F>(pf_norm_dc(v[m].x, norm, dcv), pf_norm_dc(v[m].y, norm, dcv));
       }
     }
   }
@@ -227,9 +215,10 @@ template <typename F, int N, int DIR>
 static int launch_strided_n(const PfStridedParams &p, hipStream_t st) {
   constexpr int T = PfTileCols<F, N>::value;
   const int ntiles = (p.ncols + T - 1) / T;
-  dim3 grid((unsigned)(ntiles * p.njobs), (unsigned)p.nouter, 1), block(T * N / 8, 1, 1);
+  const long long nwork = (long long)ntiles * p.nouter;
+  dim3 grid((unsigned)(((nwork + 7) >> 3) << 3), 1, 1), block(T * N / 8, 1, 1);
   const size_t shm = (size_t)N * T * sizeof(pfc<F>);
-  hipLaunchKernelGGL((k_strided<F, N, T, DIR>), grid, block, shm, st, p);
+  hipLaunchKernelGGL((k_strided<F, N, T, DIR>), grid, block, shm, st, p, nwork, ntiles);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 

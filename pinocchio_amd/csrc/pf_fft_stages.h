@@ -1,0 +1,38 @@
+// pf_fft_stages.h -- device-side driver of the register/LDS Stockham stages (pf_fft_core.h)
+#pragma once
+#include "pf_fft_core.h"
+
+template <typename F, int N, int DIR, int TWS, int S = 0>
+struct PfStages {
+  template <typename WR, typename RD>
+  static __device__ __forceinline__ void run(pfc<F> (&v)[8], int tl, const pfc<F> *__restrict__ tw, WR wr, RD rd) {
+    pf_stage<F, N, S, DIR, TWS>(v, tl, tw);
+    if constexpr (S + 1 < pf_nstages(N)) {
+      constexpr int NT = N / 8;
+#pragma unroll
+      for (int m = 0; m < 8; m++) wr(pf_stage_pos<N, S>(tl, m), v[m]);
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < 8; m++) v[m] = rd(tl + m * NT);
+      __syncthreads();
+      PfStages<F, N, DIR, TWS, S + 1>::run(v, tl, tw, wr, rd);
+    }
+  }
+};
+
+
+// 1/N^3 normalisation plus the DC mode, one definition for every z-pass so that they round alike
+template <typename F> __device__ __forceinline__ F pf_norm_dc(F v, F norm, F dc) { return v * norm + dc; }
+
+// kz factor + Hermitian fold of one element pair (k, M-k) of a half-spectrum row (see pf_c2r_pre)
+template <typename F>
+__device__ __forceinline__ pfc<F> pf_zfold(pfc<F> xk, pfc<F> xmk, int e, int M, int mul, F kf, pfc<F> wk) {
+  if (mul != 0 /* PF_MUL_ONE */) {
+    F fk = kf * (F)e, fm = kf * (F)(M - e);
+    if (mul == 2 /* PF_MUL_K2 */) { fk *= fk; fm *= fm; }
+    xk = pf_scale(xk, fk);
+    xmk = pf_scale(xmk, fm);
+    if (mul == 3 /* PF_MUL_IK */) { xk = pf_mul_i<+1>(xk); xmk = pf_mul_i<+1>(xmk); }
+  }
+  return pf_c2r_pre<F>(xk, xmk, wk, e == 0);
+}

@@ -11,11 +11,11 @@
 enum { PF_MUL_ONE = 0, PF_MUL_K = 1, PF_MUL_K2 = 2, PF_MUL_IK = 3 };
 
 // element address of (outer, e, col) in a strided pass:
-//   outer*os + (e / el)*ehs + (e % el)*els + col      (units: complex elements)
+//   outer*os + (e >> el_shift)*ehs + (e & (el-1))*els + col      (units: complex elements)
 // (e / el, e % el) lets the y-pass read the P received all-to-all blocks in place.
 struct PfAddr {
   long long os;
-  int el;
+  int el_shift;  // el = 1 << el_shift (slab thickness; a power of two because n and P are)
   long long ehs, els;
 };
 
@@ -87,6 +87,28 @@ struct PfCollapseParams {
 int pf_launch_collapse(int field_bytes, const PfCollapseParams &p, hipStream_t st);
 int pf_launch_final_sum(const double *partials, int nblocks, double *out2, hipStream_t st);
 int pf_launch_collapse_cells(const double *d, size_t count, PfSplineDev s, double *F, hipStream_t st);
+
+// fused z-pass + collapse (pf_fused_kernels.hip)
+struct PfFusedParams {
+  const void *in[6];    // six complex fields after the y-pass (XS layout)
+  int mul[6];           // kz factor per component
+  void *out[6];         // real rows written when write_h (may alias in)
+  int write_h;
+  long long nlines, in_pitch, out_pitch;
+  double norm;
+  const double *dc;
+  const void *tw;
+  float *fmax;
+  int *rmax;
+  int ismooth;
+  PfSplineDev spline;
+  double *partials;     // [2*nblocks]
+  int max_blocks;
+  int debug_skip;       // timing experiments only: 1 = skip the solve, 2 = skip the row transforms
+  int skew_ns, ncu;     // start-up stagger between the workgroups that share a CU
+};
+int pf_launch_zcollapse(int field_bytes, int n, const PfFusedParams &p, int blocks_per_cu, int ncu, hipStream_t st,
+                        int *nblocks_out);
 
 struct PfLptSrcParams {
   const void *h[6];
