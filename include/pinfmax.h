@@ -80,6 +80,13 @@ int pf_init_rccl(pf_ctx *ctx, const void *id128);   /* all ranks: ncclCommInitRa
    src/fmax.c:527): sum `count` doubles / uint64 in place over all ranks */
 typedef int (*pf_allreduce_fn)(void *user, void *buf, size_t count, int is_u64, void *stream);
 int pf_set_allreduce(pf_ctx *ctx, pf_allreduce_fn fn, void *user);
+/* in-process fabric: P contexts (ranks 0..P-1) driven by P host threads on ONE GPU meet in the
+   exchange through device-to-device copies.  Bring-up/test transport for the slab code path on a
+   single-GPU box; multi-GPU runs use pf_init_rccl. */
+typedef struct pf_fabric pf_fabric;
+pf_fabric *pf_fabric_create(int nranks);
+void pf_fabric_destroy(pf_fabric *f);
+int pf_fabric_attach(pf_fabric *f, pf_ctx *ctx);
 /* device pointers + size (bytes) of the exchange buffers, so that a host
    harness can wrap them (e.g. torch tensors for torch.distributed) */
 int pf_exchange_buffers(pf_ctx *ctx, void **sendbuf, void **recvbuf, size_t *bytes);

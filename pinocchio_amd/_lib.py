@@ -50,6 +50,9 @@ PROTOTYPES = {
     "pf_rccl_unique_id": (C.c_int, [_vp]),
     "pf_init_rccl": (C.c_int, [_vp, _vp]),
     "pf_set_allreduce": (C.c_int, [_vp, ALLREDUCE_FN, _vp]),
+    "pf_fabric_create": (_vp, [C.c_int]),
+    "pf_fabric_destroy": (None, [_vp]),
+    "pf_fabric_attach": (C.c_int, [_vp, _vp]),
     "pf_exchange_buffers": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "pf_set_stream": (C.c_int, [_vp, _vp]),
     "pf_get_stream": (_vp, [_vp]),

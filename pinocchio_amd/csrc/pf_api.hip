@@ -442,16 +442,27 @@ static char *staging(pf_ctx *c) { return (char *)c->A[1]; }  // 2 fields of scra
 // ------------------------------------------------------------------ inputs --
 extern "C" int pf_set_density(pf_ctx *c, const double *kd) {
   if (!c || !kd) return pf_fail(0, "pf_set_density: null argument");
-  if (c->P > 1) return pf_fail(c->rank, "pf_set_density: boundary->internal redistribution over %d ranks not available yet; use pf_synth_density", c->P);
   PhaseTimer pt(c, 3);
-  const long long nrows = (long long)c->n * c->n;
+  // boundary layout: this rank's x-slab [nxl][n][nzh] (non-transposed PFFT output, src/fmax-pfft.c:366)
+  const long long nrows = (long long)c->nxl * c->n;
   const size_t hb = (size_t)nrows * c->nzh * 2 * sizeof(double);
   HIPCHK(c, hipMemcpyAsync(staging(c), kd, hb, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->dk, 0, c->field_bytes, c->stream));
-  PFCHK(c, pf_launch_spec_import(c->fb, (const double *)staging(c), c->dk, nrows, c->nzh, c->nzp, c->stream));
-  // DC mode: untouched by the k-filter (k^2 = 0, src/fmax-pfft.c:368), so it adds Re(dk[0])/N^3 to every second derivative
-  const double dcv = kd[0] / ((double)c->n * c->n * c->n);
+  // DC mode: untouched by the k-filter (k^2 = 0, src/fmax-pfft.c:368), so it adds Re(dk[0])/N^3 to every second
+  // derivative; it lives on the rank that owns x = 0
+  const double dcv = (c->rank == 0) ? kd[0] / ((double)c->n * c->n * c->n) : 0.0;
+  if (c->P == 1) {
+    HIPCHK(c, hipMemsetAsync(c->dk, 0, c->field_bytes, c->stream));
+    PFCHK(c, pf_launch_spec_import(c->fb, (const double *)staging(c), c->dk, nrows, c->nzh, c->nzp, c->stream));
+  } else {
+    // x-slab -> k-space y-slab (KY): regroup into the P destination blocks, one all-to-all
+    HIPCHK(c, hipMemsetAsync(c->B[0], 0, c->field_bytes, c->stream));
+    PFCHK(c, pf_launch_spec_import(c->fb, (const double *)staging(c), c->B[0], nrows, c->nzh, c->nzp, c->stream));
+    PFCHK(c, pf_launch_to_blocks(c->fb, c->B[0], c->A[0], c->nxl, c->n, c->nyl, c->nzp, c->stream));
+    PFCHK(c, exchange(c, c->A[0], c->dk));
+  }
   HIPCHK(c, hipMemcpyAsync(c->scal + SC_DC_DK, &dcv, sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  PFCHK(c, allreduce_dev(c, c->scal + SC_DC_DK, 1, 0));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_density = true; c->have_hessian = false; c->have_sources = false;
   return 0;
