@@ -1,0 +1,368 @@
+/*
+ * pf_compat.c -- host side of the drop-in: the reference's own entry points
+ * (same names, arguments, return convention and log lines) implemented over
+ * the C ABI of libpinfmax_hip.so.  Linked INSTEAD of
+ *     fmax.o  collapse_times.o  fmax-pfft.o  LPT.o        (src/Makefile:222-224)
+ * it serves every caller of the path: main (src/pinocchio.c:146-150,186,229),
+ * initialization (src/initialization.c:139,512) and fragment (src/fragment.c:409).
+ *
+ *   reference symbol                         file:line            here
+ *   int  set_one_grid(int)                   fmax-pfft.c:80       geometry of this rank's x-slab
+ *   int  compute_fft_plans(void)             fmax-pfft.c:139      pf_create (+ RCCL exchange with MPI)
+ *   int  finalize_fft(void)                  fmax-pfft.c:231      pf_destroy
+ *   int  compute_fmax(void)                  fmax.c:36            upload, pf_sweep, displacements, download, PDF
+ *   int  compute_displacements(int,int,dbl)  fmax.c:292           pf_set_growth + pf_displacements
+ *   int  compute_collapse_times(int)         collapse_times.c:431 pf_collapse_times
+ *   int  compute_LPT_displacements(int,dbl)  LPT.c:32             (inside pf_displacements)
+ *   int  Fmax_PDF(void)                      fmax.c:509           pf_fmax_pdf + the same ASCII file
+ *   int  dump_products(void), read_dumps()   fmax.c:372,429       same files, same checks
+ *   char *fdate(void)                        fmax.c:261           same string
+ *
+ * Build modes: stand-alone (default; globals from pf_compat_types.h, defined in
+ * pf_compat_globals.c) or -DPF_IN_PINOCCHIO_TREE inside the reference source
+ * tree (globals and cosmology from the reference itself, MPI for the
+ * ncclUniqueId broadcast).  Host code is plain C99, as in the reference.
+ */
+#ifdef PF_IN_PINOCCHIO_TREE
+#include "pinocchio.h"
+#define PF_KNOTS_X (SPLINE[SP_INVGROW]->x)
+#define PF_KNOTS_Y (SPLINE[SP_INVGROW]->y)
+#define PF_KNOTS_N ((int)SPLINE[SP_INVGROW]->size)
+#define PF_GM(z) GrowingMode((z), params.k_for_GM)
+#define PF_GM2(z) GrowingMode_2LPT((z), params.k_for_GM)
+#define PF_GM31(z) GrowingMode_3LPT_1((z), params.k_for_GM)
+#define PF_GM32(z) GrowingMode_3LPT_2((z), params.k_for_GM)
+#else
+#include "pf_compat_types.h"
+#define PF_KNOTS_X (pf_invgrow_knots.x)
+#define PF_KNOTS_Y (pf_invgrow_knots.y)
+#define PF_KNOTS_N ((int)pf_invgrow_knots.size)
+#define PF_GM(z) pf_GrowingMode((z), 0.0)
+#define PF_GM2(z) pf_GrowingMode_2LPT((z), 0.0)
+#define PF_GM31(z) pf_GrowingMode_3LPT_1((z), 0.0)
+#define PF_GM32(z) pf_GrowingMode_3LPT_2((z), 0.0)
+#endif
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <time.h>
+
+#include "../../include/pinfmax.h"
+
+static pf_ctx *pf_context = NULL;
+static int pf_device_of_rank = -1; /* -1: rank % visible devices */
+
+/* lets a launcher pin ranks to devices before compute_fft_plans (e.g. from SLURM_LOCALID) */
+void pf_compat_set_device(int device) { pf_device_of_rank = device; }
+pf_ctx *pf_compat_context(void) { return pf_context; }
+
+static double pf_wtime(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* src/fmax.c:261-289 */
+char *fdate(void) {
+  time_t current_time;
+  char *string;
+  int n;
+  current_time = time(NULL);
+  string = ctime(&current_time);
+  for (n = 0; n < 10; n++) *(date_string + n) = *(string + n);
+  for (n = 10; n < 15; n++) *(date_string + n) = *(string + n + 9);
+  for (n = 10; n < 19; n++) *(date_string + n + 5) = *(string + n);
+  *(date_string + 24) = '\0';
+  return date_string;
+}
+
+/* src/fmax-pfft.c:80-134: x-slab decomposition (1-D PFFT, src/initialization.c:1317-1325) */
+int set_one_grid(int ThisGrid) {
+  grid_data *G = &MyGrids[ThisGrid];
+  const ptrdiff_t n = G->GSglobal[_x_];
+  if (G->GSglobal[_y_] != n || G->GSglobal[_z_] != n) {
+    printf("ERROR on task %d: the GPU path needs a cubic grid\n", ThisTask);
+    return 1;
+  }
+  if (n % NTasks) {
+    printf("ERROR on task %d: NTasks=%d must divide GridSize=%ld (slab decomposition)\n", ThisTask, NTasks, (long)n);
+    return 1;
+  }
+  G->norm = (double)1.0 / ((double)G->Ntotal);
+  G->CellSize = (double)G->BoxSize / G->GSglobal[_x_];
+  G->GSlocal[_x_] = n / NTasks; G->GSlocal[_y_] = n; G->GSlocal[_z_] = n;
+  G->GSstart[_x_] = ThisTask * (n / NTasks); G->GSstart[_y_] = 0; G->GSstart[_z_] = 0;
+  G->GSlocal_k[_x_] = n / NTasks; G->GSlocal_k[_y_] = n; G->GSlocal_k[_z_] = n / 2 + 1; /* non-transposed output */
+  G->GSstart_k[_x_] = G->GSstart[_x_]; G->GSstart_k[_y_] = 0; G->GSstart_k[_z_] = 0;
+  G->total_local_size_fft = (unsigned int)(2 * G->GSlocal_k[_x_] * n * (n / 2 + 1));
+  G->total_local_size = (unsigned int)(G->GSlocal[_x_] * n * n);
+  G->off = 0;
+  return 0;
+}
+
+/* src/fmax-pfft.c:139-188: the "plans" are the device context */
+int compute_fft_plans(void) {
+  pf_config cfg;
+  memset(&cfg, 0, sizeof(cfg));
+  cfg.n = MyGrids[0].GSglobal[_x_];
+  cfg.rank = ThisTask;
+  cfg.nranks = NTasks;
+  cfg.device = pf_device_of_rank >= 0 ? pf_device_of_rank : 0;
+  cfg.field_bytes = 8;
+  cfg.flags = PF_FLAG_TIMING; /* cputime.fft like the reference (src/fmax-pfft.c:195-199) */
+  if (pf_context) return 0;
+  if (pf_create(&pf_context, &cfg)) return 1;
+#if defined(PF_IN_PINOCCHIO_TREE)
+  if (NTasks > 1) { /* one rank per GPU: RCCL all-to-all replaces the MPI_Alltoall inside pfft_execute */
+    char id[128];
+    if (!ThisTask && pf_rccl_unique_id(id)) return 1;
+    MPI_Bcast(id, 128, MPI_BYTE, 0, MPI_COMM_WORLD);
+    if (pf_init_rccl(pf_context, id)) return 1;
+  }
+#else
+  if (NTasks > 1) {
+    printf("ERROR on task %d: stand-alone pf_compat build is single rank (use pf_fabric_attach or the in-tree build)\n", ThisTask);
+    return 1;
+  }
+#endif
+  return 0;
+}
+
+/* src/fmax-pfft.c:231-252 */
+int finalize_fft(void) {
+#ifndef RECOMPUTE_DISPLACEMENTS
+  if (pf_context) {
+    pf_destroy(pf_context);
+    pf_context = NULL;
+  }
+#endif
+  return 0;
+}
+
+static int pf_upload_inputs(void) {
+  if (!pf_context && compute_fft_plans()) return 1;
+  if (pf_set_density(pf_context, kdensity[0])) return 1;
+  if (pf_set_invgrow(pf_context, -1, PF_KNOTS_X, PF_KNOTS_Y, PF_KNOTS_N)) return 1;
+  return 0;
+}
+
+static void pf_collect_cputime(void) {
+  pf_cputime t;
+  if (!pf_get_cputime(pf_context, &t)) {
+    cputime.fft += t.fft; cputime.coll += t.coll; cputime.lpt += t.lpt; cputime.deriv += t.deriv;
+    cputime.mem_transf += t.mem_transf;
+    pf_reset_cputime(pf_context);
+  }
+}
+
+static int pf_download_products(void) {
+  pf_product_layout lay;
+  lay.stride = sizeof(product_data);
+  lay.off_Rmax = (int)offsetof(product_data, Rmax);
+  lay.off_Fmax = (int)offsetof(product_data, Fmax);
+  lay.off_Vel = (int)offsetof(product_data, Vel);
+  lay.off_Vel_2LPT = (int)offsetof(product_data, Vel_2LPT);
+  lay.off_Vel_3LPT_1 = (int)offsetof(product_data, Vel_3LPT_1);
+  lay.off_Vel_3LPT_2 = (int)offsetof(product_data, Vel_3LPT_2);
+  return pf_get_products(pf_context, products, &lay);
+}
+
+int Fmax_PDF(void);
+
+/* src/fmax.c:292-367.  recompute_sd: second derivatives at R=0 are recomputed on the device. */
+int compute_displacements(int compute_sources, int recompute_sd, double redshift) {
+  double cputmp = pf_wtime();
+  double g[4];
+  if (!ThisTask) printf("\n[%s] Computing LPT displacements\n", fdate());
+  if (!pf_context && pf_upload_inputs()) return 1;
+  /* growth multipliers of compute_derivative for ScaleDep.order = 1..4 (src/fmax-pfft.c:344-364) */
+  ScaleDep.redshift = redshift;
+  g[0] = PF_GM(redshift); g[1] = PF_GM2(redshift); g[2] = PF_GM31(redshift); g[3] = PF_GM32(redshift);
+  if (pf_set_growth(pf_context, g)) return 1;
+  if (pf_displacements(pf_context, compute_sources, recompute_sd)) return 1;
+  ScaleDep.order = 1;
+  cputmp = pf_wtime() - cputmp;
+  if (!ThisTask) printf("[%s] Done LPT displacements and first derivatives, cpu time = %f s\n", fdate(), cputmp);
+  return 0;
+}
+
+/* src/LPT.c:32 -- kept for callers that link it directly; the work is inside pf_displacements */
+int compute_LPT_displacements(int compute_sources, double redshift) { return compute_displacements(compute_sources, 0, redshift); }
+
+/* src/collapse_times.c:431: one radius, on the second derivatives resident on the device */
+int compute_collapse_times(int ismooth) {
+  double tv = 0.0;
+  if (pf_collapse_times(pf_context, ismooth, &tv)) return 1;
+  Smoothing.TrueVariance[ismooth] = tv;
+  return 0;
+}
+
+/* src/fmax.c:36-190 */
+int compute_fmax(void) {
+  int ismooth;
+  double *rs;
+  cputime.fmax = pf_wtime();
+  if (!ThisTask) printf("[%s] First part: computation of collapse times\n", fdate());
+  ScaleDep.order = 0;
+  ScaleDep.redshift = 0.0;
+  if (pf_upload_inputs()) return 1;
+
+  /* CYCLE ON SMOOTHING RADII: radii in grid units, Rsmooth = R / CellSize (src/fmax.c:233) */
+  rs = (double *)malloc(sizeof(double) * Smoothing.Nsmooth);
+  for (ismooth = 0; ismooth < Smoothing.Nsmooth; ismooth++) rs[ismooth] = Smoothing.Radius[ismooth] / MyGrids[0].CellSize;
+  Rsmooth = rs[Smoothing.Nsmooth - 1];
+  if (pf_sweep(pf_context, Smoothing.Nsmooth, rs, Smoothing.TrueVariance)) { free(rs); return 1; }
+  free(rs);
+  if (!ThisTask)
+    for (ismooth = 0; ismooth < Smoothing.Nsmooth; ismooth++)
+      printf("[%s] Completed, R=%6.3f, expected sigma: %7.4f, computed sigma: %7.4f\n", fdate(), Smoothing.Radius[ismooth],
+             Smoothing.Variance ? sqrt(Smoothing.Variance[ismooth]) : 0.0, sqrt(Smoothing.TrueVariance[ismooth]));
+
+  /* COMPUTATION OF DISPLACEMENTS for the first (or only) redshift segment (src/fmax.c:160-169) */
+  if (!ThisTask) printf("\n[%s] Computing displacements  for redshift %f\n", fdate(), ScaleDep.z[0]);
+  if (compute_displacements(1, 0, ScaleDep.z[0])) return 1;
+
+  if (pf_download_products()) return 1;
+  pf_collect_cputime();
+  if (Fmax_PDF()) return 1; /* needs the device histogram: before finalize_fft */
+  if (finalize_fft()) return 1;
+
+  cputime.fmax = pf_wtime() - cputime.fmax;
+  if (!ThisTask)
+    printf("[%s] Finishing fmax, total fmax cpu time = %14.6f\n"
+           "\t\t IO       : %14.6f (%14.6f total time without I/O)\n"
+           "\t\t FFT      : %14.6f\n"
+           "\t\t COLLAPSE : %14.6f\n",
+           fdate(), cputime.fmax, cputime.io, cputime.fmax - cputime.io, cputime.fft, cputime.coll);
+  return 0;
+}
+
+/* src/fmax.c:509-550 */
+int Fmax_PDF(void) {
+  unsigned long long counter[NBINS], coll;
+  int i;
+  if (pf_context) {
+    if (pf_fmax_pdf(pf_context, counter)) return 1; /* already summed over ranks */
+  } else { /* products only on the host (after read_dumps): the reference's own loop */
+    for (i = 0; i < NBINS; i++) counter[i] = 0;
+    for (i = 0; i < (int)MyGrids[0].total_local_size; i++) {
+      int xF = (int)(products[i].Fmax * 10.);
+      if (xF < 0) xF = 0;
+      if (xF >= NBINS) xF = NBINS - 1;
+      counter[xF]++;
+    }
+#ifdef PF_IN_PINOCCHIO_TREE
+    {
+      unsigned long long mine[NBINS];
+      memcpy(mine, counter, sizeof(mine));
+      MPI_Reduce(mine, counter, NBINS, MPI_UNSIGNED_LONG_LONG, MPI_SUM, 0, MPI_COMM_WORLD);
+    }
+#endif
+  }
+  if (!ThisTask) {
+    char filename[LBLENGTH];
+    FILE *file;
+    coll = 0;
+    for (i = 10; i < NBINS; i++) coll += counter[i];
+    printf("[%s] Number of collapsed particles to z=0: %llu\n", fdate(), coll);
+    sprintf(filename, "pinocchio.%s.FmaxPDF.out", params.RunFlag);
+    file = fopen(filename, "w");
+    if (!file) { printf("ERROR on task %d: could not open file %s\n", ThisTask, filename); return 1; }
+    fprintf(file, "# Fmax PDF over %llu particles\n", MyGrids[0].Ntotal);
+    fprintf(file, "# 1-2: F interval\n");
+    fprintf(file, "# 3: number of particles in that interval\n");
+    fprintf(file, "#\n");
+    for (i = 0; i < NBINS; i++)
+      fprintf(file, " %6.1f   %6.1f  %llu\n", (double)i / 10., (i == NBINS - 1 ? 999.0 : (double)(i + 1) / 10.), counter[i]);
+    fclose(file);
+  }
+  return 0;
+}
+
+/* src/fmax.c:372-426 */
+int dump_products(void) {
+  struct stat dr;
+  FILE *file;
+  char fname[LBLENGTH];
+  if (!ThisTask) {
+    if (stat(params.DumpDir, &dr)) {
+      printf("Creating directory %s\n", params.DumpDir);
+      if (mkdir(params.DumpDir, 0755)) {
+        printf("ERROR IN CREATING DIRECTORY %s (task 0)\n", params.DumpDir);
+        return 1;
+      }
+    }
+    sprintf(fname, "%ssummary", params.DumpDir);
+    file = fopen(fname, "w");
+    fprintf(file, "%d   # NTasks\n", NTasks);
+    fprintf(file, "%d   # random seed\n", params.RandomSeed);
+    fprintf(file, "%d   # grid size\n", params.GridSize[0]);
+    fprintf(file, "%d   # length of product_data\n", (int)sizeof(product_data));
+    fclose(file);
+    sprintf(fname, "%sTrueVariance", params.DumpDir);
+    file = fopen(fname, "wb");
+    fwrite(Smoothing.TrueVariance, sizeof(double), Smoothing.Nsmooth, file);
+    fclose(file);
+  }
+#ifdef PF_IN_PINOCCHIO_TREE
+  MPI_Barrier(MPI_COMM_WORLD);
+#endif
+  sprintf(fname, "%sTask.%d", params.DumpDir, ThisTask);
+  file = fopen(fname, "wb");
+  if (file == 0x0) {
+    printf("ERROR on Task %d: could not open file %s\n", ThisTask, fname);
+    return 1;
+  }
+  fwrite(products, sizeof(product_data), MyGrids[0].total_local_size, file);
+  fclose(file);
+  return 0;
+}
+
+/* src/fmax.c:429-506 */
+int read_dumps(void) {
+  FILE *file;
+  char fname[LBLENGTH], buf[SBLENGTH];
+  int myNTasks, myRandomSeed, myGridSize, myPDlength;
+  if (!ThisTask) {
+    int error = 0;
+    sprintf(fname, "%ssummary", params.DumpDir);
+    file = fopen(fname, "r");
+    if (file == 0x0) {
+      printf("ERROR on Task 0: could not open file %s\n", fname);
+      return 1;
+    }
+    (void)!fgets(buf, SBLENGTH, file); sscanf(buf, "%d", &myNTasks);
+    (void)!fgets(buf, SBLENGTH, file); sscanf(buf, "%d", &myRandomSeed);
+    (void)!fgets(buf, SBLENGTH, file); sscanf(buf, "%d", &myGridSize);
+    (void)!fgets(buf, SBLENGTH, file); sscanf(buf, "%d", &myPDlength);
+    fclose(file);
+    if (NTasks != myNTasks) { printf("ERROR: the number of tasks in %s does not match - %d vs %d\n", fname, myNTasks, NTasks); error++; }
+    if (params.RandomSeed != myRandomSeed) { printf("ERROR: the random seed in %s does not match - %d vs %d\n", fname, myRandomSeed, params.RandomSeed); error++; }
+    if (params.GridSize[0] != myGridSize) { printf("ERROR: the grid size in %s does not match - %d vs %d\n", fname, myGridSize, params.GridSize[0]); error++; }
+    if (myPDlength != (int)sizeof(product_data)) { printf("ERROR: the length of product_data in %s does not match - %d vs %d\n", fname, myPDlength, (int)sizeof(product_data)); error++; }
+    if (error) return 1;
+    sprintf(fname, "%sTrueVariance", params.DumpDir);
+    file = fopen(fname, "rb");
+    if (file == 0x0) {
+      printf("ERROR on Task 0: could not open file %s\n", fname);
+      return 1;
+    }
+    if (fread(Smoothing.TrueVariance, sizeof(double), Smoothing.Nsmooth, file) != (size_t)Smoothing.Nsmooth) return 1;
+    fclose(file);
+  }
+#ifdef PF_IN_PINOCCHIO_TREE
+  MPI_Bcast(Smoothing.TrueVariance, Smoothing.Nsmooth, MPI_DOUBLE, 0, MPI_COMM_WORLD);
+#endif
+  sprintf(fname, "%sTask.%d", params.DumpDir, ThisTask);
+  file = fopen(fname, "rb");
+  if (file == 0x0) {
+    printf("ERROR on Task %d: could not open file %s\n", ThisTask, fname);
+    return 1;
+  }
+  if (fread(products, sizeof(product_data), MyGrids[0].total_local_size, file) != MyGrids[0].total_local_size) return 1;
+  fclose(file);
+  return 0;
+}

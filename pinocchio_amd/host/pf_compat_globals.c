@@ -1,0 +1,21 @@
+/* pf_compat_globals.c -- stand-alone definitions of the reference globals that
+ * pf_compat.c uses (in the reference tree they come from src/variables.c). */
+#include "pf_compat_types.h"
+
+int ThisTask = 0, NTasks = 1;
+product_data *products = 0;
+static double *kdensity_slots[1] = {0};
+double **kdensity = kdensity_slots;
+smoothing_data Smoothing;
+static grid_data grid0;
+grid_data *MyGrids = &grid0;
+ScaleDep_data ScaleDep;
+cputime_data cputime;
+param_data params;
+double Rsmooth;
+char date_string[25];
+pf_spline_knots pf_invgrow_knots;
+double (*pf_GrowingMode)(double, double) = 0;
+double (*pf_GrowingMode_2LPT)(double, double) = 0;
+double (*pf_GrowingMode_3LPT_1)(double, double) = 0;
+double (*pf_GrowingMode_3LPT_2)(double, double) = 0;

@@ -1,0 +1,151 @@
+"""The reference-named C host layer (pinocchio_amd/host/pf_compat.c): reads like
+the reference's own driver -- fill the globals, set_one_grid, compute_fft_plans,
+compute_fmax -- and is checked against the oracle."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from pinocchio_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "pinocchio_amd", "libpf_compat.so")
+
+GROWTH_FN = C.CFUNCTYPE(C.c_double, C.c_double, C.c_double)
+
+
+class Smoothing(C.Structure):
+    _fields_ = [("Nsmooth", C.c_int), ("Radius", C.POINTER(C.c_double)), ("Variance", C.POINTER(C.c_double)),
+                ("TrueVariance", C.POINTER(C.c_double))]
+
+
+class Grid(C.Structure):
+    _fields_ = [("total_local_size", C.c_uint), ("total_local_size_fft", C.c_uint), ("off", C.c_uint),
+                ("ParticlesPerTask", C.c_uint), ("GSglobal", C.c_ssize_t * 3), ("GSlocal", C.c_ssize_t * 3),
+                ("GSstart", C.c_ssize_t * 3), ("GSlocal_k", C.c_ssize_t * 3), ("GSstart_k", C.c_ssize_t * 3),
+                ("lower_k_cutoff", C.c_double), ("upper_k_cutoff", C.c_double), ("norm", C.c_double),
+                ("BoxSize", C.c_double), ("CellSize", C.c_double), ("Ntotal", C.c_ulonglong)]
+
+
+class ScaleDep(C.Structure):
+    _fields_ = [("nseg", C.c_int), ("myseg", C.c_int), ("no_interp", C.c_int), ("order", C.c_int),
+                ("z", C.c_double * 100), ("D", C.c_double * 100), ("D2", C.c_double * 100), ("D31", C.c_double * 100),
+                ("D32", C.c_double * 100), ("redshift", C.c_double)]
+
+
+class Params(C.Structure):
+    _fields_ = [("RunFlag", C.c_char * 100), ("DumpDir", C.c_char * 100), ("GridSize", C.c_int * 3), ("RandomSeed", C.c_int)]
+
+
+class Knots(C.Structure):
+    _fields_ = [("size", C.c_size_t), ("x", C.POINTER(C.c_double)), ("y", C.POINTER(C.c_double))]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    if not os.path.exists(SO) or not os.path.exists(os.path.join(ROOT, "pinocchio_amd", "libpinfmax_hip.so")):
+        g.build()
+    return C.CDLL(SO)
+
+
+def test_reference_symbols_and_geometry(lib):
+    for name in ("set_one_grid", "compute_fft_plans", "finalize_fft", "compute_fmax", "compute_displacements",
+                 "compute_collapse_times", "compute_LPT_displacements", "Fmax_PDF", "dump_products", "read_dumps", "fdate"):
+        assert hasattr(lib, name), name
+    grid = Grid.in_dll(lib, "grid0") if hasattr(lib, "grid0") else C.cast(C.c_void_p.in_dll(lib, "MyGrids"), C.POINTER(Grid)).contents
+    n = 64
+    for i in range(3):
+        grid.GSglobal[i] = n
+    grid.Ntotal = n ** 3
+    grid.BoxSize = 128.0
+    assert lib.set_one_grid(0) == 0
+    # src/fmax-pfft.c:80-134 for one rank: local = global, half-spectrum on z, norm = 1/N^3, CellSize = Box/N
+    assert list(grid.GSlocal) == [n, n, n] and list(grid.GSlocal_k) == [n, n, n // 2 + 1]
+    assert grid.total_local_size == n ** 3 and grid.total_local_size_fft == 2 * n * n * (n // 2 + 1)
+    assert grid.norm == 1.0 / n ** 3 and grid.CellSize == 2.0
+    lib.fdate.restype = C.c_char_p
+    assert len(lib.fdate()) == 24
+
+
+@pytest.mark.gpu
+def test_compute_fmax_like_the_reference_driver(lib, tmp_path):
+    n = 32
+    cell = 2.0                                     # Mpc per cell
+    dk = np.ascontiguousarray(synth.make_density(n, seed=synth.SEED))
+    radii_mpc = np.array([4.0, 2.0, 1.0, 0.0])     # Smoothing.Radius in Mpc; Rsmooth = R / CellSize
+    x, y = synth.invgrow_table("lcdm")
+    g = synth.growth_multipliers()
+
+    grid = C.cast(C.c_void_p.in_dll(lib, "MyGrids"), C.POINTER(Grid)).contents
+    for i in range(3):
+        grid.GSglobal[i] = n
+    grid.Ntotal = n ** 3
+    grid.BoxSize = n * cell
+    assert lib.set_one_grid(0) == 0
+
+    # sizeof(product_data) = 56: the aligned(32) attribute sits on the typedef, it does not pad the record
+    prod = np.zeros(n ** 3 * 56 + 64, dtype=np.uint8)
+    prod = prod[(-prod.ctypes.data) % 32:][:n ** 3 * 56]
+    C.c_void_p.in_dll(lib, "products").value = prod.ctypes.data
+    kd = C.cast(C.c_void_p.in_dll(lib, "kdensity"), C.POINTER(C.c_void_p))
+    kd[0] = dk.ctypes.data
+    sm = Smoothing.in_dll(lib, "Smoothing")
+    tv = np.zeros(len(radii_mpc)); var = np.ones(len(radii_mpc))
+    sm.Nsmooth = len(radii_mpc)
+    sm.Radius = radii_mpc.ctypes.data_as(C.POINTER(C.c_double))
+    sm.Variance = var.ctypes.data_as(C.POINTER(C.c_double))
+    sm.TrueVariance = tv.ctypes.data_as(C.POINTER(C.c_double))
+    sd = ScaleDep.in_dll(lib, "ScaleDep")
+    sd.nseg = 1
+    sd.z[0] = 0.0
+    kn = Knots.in_dll(lib, "pf_invgrow_knots")
+    kn.size = len(x)
+    kn.x = x.ctypes.data_as(C.POINTER(C.c_double))
+    kn.y = y.ctypes.data_as(C.POINTER(C.c_double))
+    fns = [GROWTH_FN(lambda z, k, v=v: float(v)) for v in g]
+    for name, fn in zip(("pf_GrowingMode", "pf_GrowingMode_2LPT", "pf_GrowingMode_3LPT_1", "pf_GrowingMode_3LPT_2"), fns):
+        C.c_void_p.in_dll(lib, name).value = C.cast(fn, C.c_void_p).value
+    par = Params.in_dll(lib, "params")
+    par.RunFlag = b"pftest"
+    par.DumpDir = (str(tmp_path) + "/").encode()
+    par.GridSize[0] = par.GridSize[1] = par.GridSize[2] = n
+    par.RandomSeed = synth.SEED
+
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        assert lib.compute_fft_plans() == 0
+        assert lib.compute_fmax() == 0
+        assert lib.dump_products() == 0
+    finally:
+        os.chdir(cwd)
+
+    p = prod.view(oracle_lib.PRODUCT_DTYPE).reshape(n, n, n)
+
+    o = oracle_lib.Oracle(n, 0)
+    o.set_density(dk); o.set_invgrow(x, y); o.set_growth(g)
+    tv_o = o.compute_fmax(radii_mpc / cell, do_lpt=True)
+    po = o.products()
+    assert np.allclose(tv, tv_o, rtol=1e-12)
+    ulp = np.spacing(np.maximum(np.abs(po["Fmax"]), 1.0).astype(np.float32)).astype(np.float64)
+    assert np.all(np.abs(p["Fmax"].astype(np.float64) - po["Fmax"]) <= 2 * ulp)
+    assert np.mean(p["Rmax"] != po["Rmax"]) < 1e-3
+    for name in ("Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+        assert np.max(np.abs(p[name].astype(np.float64) - po[name])) <= 4e-7 * np.max(np.abs(po[name]))
+    # the FmaxPDF file has the reference's format (src/fmax.c:537-546)
+    lines = open(tmp_path / "pinocchio.pftest.FmaxPDF.out").read().splitlines()
+    assert lines[0] == "# Fmax PDF over %d particles" % n ** 3 and len(lines) == 4 + 210
+    counts = np.array([int(l.split()[2]) for l in lines[4:]])
+    assert counts.sum() == n ** 3 and np.abs(counts - o.fmax_pdf().astype(np.int64)).sum() <= 2
+    # dump files (src/fmax.c:372-426) and their reload (:429-506)
+    assert open(tmp_path / "summary").read().split("\n")[3].startswith("56 ")
+    dumped = np.fromfile(tmp_path / "Task.0", dtype=np.uint8)
+    assert dumped.size == n ** 3 * 56 and np.array_equal(dumped, prod)
+    prod[:] = 0
+    tv[:] = 0
+    assert lib.read_dumps() == 0
+    assert np.array_equal(dumped, prod) and np.allclose(tv, tv_o, rtol=1e-12)
