@@ -78,7 +78,8 @@ struct pf_ctx {
   hipEvent_t ev_h[2], ev_c[2];
   int collapse_blocks;
   bool overlap, fuse;
-  int ncu, fused_wg_per_cu, fused_skew_ns;
+  int ncu, fused_wg_per_cu, fused_skew_ns, last_band;
+  double prune_eps;
   bool own_stream;
   size_t field_bytes;  // one spectrum-sized field
   size_t dev_bytes;
@@ -211,6 +212,9 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
     c->overlap = getenv("PF_OVERLAP") && atoi(getenv("PF_OVERLAP"));
     c->fuse = getenv("PF_FUSE") && atoi(getenv("PF_FUSE"));
     c->ncu = prop.multiProcessorCount;
+    c->prune_eps = 8.673617379884035e-19;  // 2^-60; PF_PRUNE_EPS=0 transforms every mode
+    if (const char *e = getenv("PF_PRUNE_EPS")) c->prune_eps = atof(e);
+    c->last_band = 1 << 30;
     c->fused_wg_per_cu = 3;
     c->fused_skew_ns = 12000;
     if (const char *e = getenv("PF_FUSED_WG_PER_CU")) c->fused_wg_per_cu = atoi(e) > 0 ? atoi(e) : 3;
@@ -319,30 +323,44 @@ static PfAddr addr_xs_y(const pf_ctx *c) {  // XS layout, e = y, outer = x_local
 
 struct Job { const void *in; void *out; int mul; };
 
-static int xpass(pf_ctx *c, int kind, int dir, int njobs, const Job *jobs, int pre, double rs, double growth, int nin) {
+static int xpass(pf_ctx *c, int kind, int dir, int njobs, const Job *jobs, int pre, double rs, double growth, int nin, int band = 1 << 30) {
   PfStridedParams p; memset(&p, 0, sizeof(p));
   p.njobs = njobs;
   for (int j = 0; j < njobs; j++) { p.job[j].in = jobs[j].in; p.job[j].out = jobs[j].out; p.job[j].mul = jobs[j].mul; }
   p.ain = p.aout = addr_ky_x(c);
   p.ncols = c->nzh; p.nouter = c->nyl; p.pre = pre; p.outer_offset = c->rank * c->nyl; p.rs = rs; p.growth = growth; p.tw = c->tw;
-  KTimer t(c, kind, (nin + njobs) * spec_bytes_alg(c));
+  p.band_e = p.band_outer = c->n;
+  double frac_cols = 1.0, frac_in = 1.0, frac_outer = 1.0;
+  if (band < c->n / 2) {  // pruned: in-band columns (kz, ky) only, in-band x read, all x written
+    p.band_e = p.band_outer = band;
+    p.ncols = band + 1;
+    frac_cols = (double)(band + 1) / c->nzh; frac_in = frac_outer = (double)(2 * band + 1) / c->n;
+  }
+  KTimer t(c, kind, (nin * frac_in + njobs) * frac_cols * frac_outer * spec_bytes_alg(c));
   PFCHK(c, pf_launch_strided(c->fb, c->n, dir, p, c->stream));
   return 0;
 }
 // in_blocks: input is the P received blocks (after an all-to-all) else XS; out_blocks likewise (forward direction)
-static int ypass(pf_ctx *c, int kind, int dir, int njobs, const Job *jobs, bool in_blocks, bool out_blocks, int nin) {
+static int ypass(pf_ctx *c, int kind, int dir, int njobs, const Job *jobs, bool in_blocks, bool out_blocks, int nin, int band = 1 << 30) {
   PfStridedParams p; memset(&p, 0, sizeof(p));
   p.njobs = njobs;
   for (int j = 0; j < njobs; j++) { p.job[j].in = jobs[j].in; p.job[j].out = jobs[j].out; p.job[j].mul = jobs[j].mul; }
   p.ain = in_blocks ? addr_blocks_y(c) : addr_xs_y(c);
   p.aout = out_blocks ? addr_blocks_y(c) : addr_xs_y(c);
   p.ncols = c->nzh; p.nouter = c->nxl; p.pre = 0; p.outer_offset = 0; p.rs = 0; p.growth = 1; p.tw = c->tw;
-  KTimer t(c, kind, (nin + njobs) * spec_bytes_alg(c));
+  p.band_e = p.band_outer = c->n;
+  double frac_cols = 1.0, frac_in = 1.0;
+  if (band < c->n / 2) {  // pruned: kz columns in band, in-band ky read, all y written, every x
+    p.band_e = band;
+    p.ncols = band + 1;
+    frac_cols = (double)(band + 1) / c->nzh; frac_in = (double)(2 * band + 1) / c->n;
+  }
+  KTimer t(c, kind, (nin * frac_in + njobs) * frac_cols * spec_bytes_alg(c));
   PFCHK(c, pf_launch_strided(c->fb, c->n, dir, p, c->stream));
   return 0;
 }
 struct ZJob { const void *in; void *out; int mul; int f32; };
-static int zpass_c2r(pf_ctx *c, int kind, int njobs, const ZJob *jobs, const double *dc) {
+static int zpass_c2r(pf_ctx *c, int kind, int njobs, const ZJob *jobs, const double *dc, int band = 1 << 30) {
   PfC2RParams p; memset(&p, 0, sizeof(p));
   p.njobs = njobs;
   double outb = 0;
@@ -352,7 +370,10 @@ static int zpass_c2r(pf_ctx *c, int kind, int njobs, const ZJob *jobs, const dou
   }
   p.nlines = (long long)c->nxl * c->n; p.in_pitch = c->nzp; p.out_pitch = 2 * c->nzp;
   p.norm = 1.0 / ((double)c->n * c->n * c->n); p.dc = dc; p.tw = c->tw;
-  KTimer t(c, kind, njobs * spec_bytes_alg(c) + outb);
+  p.band_k = c->n;
+  double frac_in = 1.0;
+  if (band < c->n / 2) { p.band_k = band; frac_in = (double)(band + 1) / c->nzh; }
+  KTimer t(c, kind, njobs * frac_in * spec_bytes_alg(c) + outb);
   PFCHK(c, pf_launch_c2r(c->fb, c->n, p, c->stream));
   return 0;
 }
@@ -360,8 +381,16 @@ static int zpass_c2r(pf_ctx *c, int kind, int njobs, const ZJob *jobs, const dou
 // six second derivatives of `spec` (KY layout) at smoothing rs -> six real fields out[0..5] (R layout)
 // order 11,22,33,12,13,23 (src/LPT.c:36-44); compute_second_derivatives, src/fmax.c:225-258
 static int hessian_of(pf_ctx *c, const void *spec, double rs, const double *dc, void *const out[6], bool xy_only = false) {
+  // Gaussian window exp(-k^2 rs^2/2) < prune_eps (2^-60) beyond |k| = sqrt(-2 ln eps)/rs: those modes are dropped
+  // (pruned FFT).  Their total contribution is < 2^-56 of the unsmoothed rms: below the rounding of the transform.
+  int band = 1 << 30;
+  if (rs > 0.0 && c->prune_eps > 0.0 && !xy_only) {  // (the experimental fused z-pass reads full rows)
+    const double kc = sqrt(-2.0 * log(c->prune_eps)) / rs;
+    const double kb = kc * c->n / (2.0 * 3.14159265358979323846);
+    if (kb < c->n / 2 - 1) band = (int)kb + 1;
+  }
   const Job xj[3] = {{spec, c->A[0], PF_MUL_ONE}, {spec, c->A[1], PF_MUL_K}, {spec, c->A[2], PF_MUL_K2}};
-  PFCHK(c, xpass(c, KS_XPASS_HESS, +1, 3, xj, 1, rs, 1.0, 1));
+  PFCHK(c, xpass(c, KS_XPASS_HESS, +1, 3, xj, 1, rs, 1.0, 1, band));
   const void *R[3] = {c->A[0], c->A[1], c->A[2]};
   if (c->P > 1) {
     for (int f = 0; f < 3; f++) {
@@ -372,11 +401,11 @@ static int hessian_of(pf_ctx *c, const void *spec, double rs, const double *dc, 
   }
   const Job yj[6] = {{R[2], out[0], PF_MUL_ONE}, {R[1], out[3], PF_MUL_K}, {R[1], out[4], PF_MUL_ONE},
                      {R[0], out[1], PF_MUL_K2}, {R[0], out[5], PF_MUL_K},  {R[0], out[2], PF_MUL_ONE}};
-  PFCHK(c, ypass(c, KS_YPASS_HESS, +1, 6, yj, true, false, 3));
-  if (xy_only) return 0;
+  PFCHK(c, ypass(c, KS_YPASS_HESS, +1, 6, yj, true, false, 3, band));
+  if (xy_only) { c->last_band = band; return 0; }
   const ZJob zj[6] = {{out[0], out[0], PF_MUL_ONE, 0}, {out[1], out[1], PF_MUL_ONE, 0}, {out[2], out[2], PF_MUL_K2, 0},
                       {out[3], out[3], PF_MUL_ONE, 0}, {out[4], out[4], PF_MUL_K, 0},   {out[5], out[5], PF_MUL_K, 0}};
-  PFCHK(c, zpass_c2r(c, KS_ZPASS_HESS, 6, zj, dc));
+  PFCHK(c, zpass_c2r(c, KS_ZPASS_HESS, 6, zj, dc, band));
   return 0;
 }
 

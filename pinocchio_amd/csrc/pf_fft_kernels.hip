@@ -44,6 +44,11 @@ __global__ void __launch_bounds__(T *N / 8) k_strided(const PfStridedParams p, c
   const bool valid = col < p.ncols;
   const C *__restrict__ tw = reinterpret_cast<const C *>(p.tw);
   const double kf = 2.0 * 3.14159265358979323846 / (double)N;
+  if (p.band_outer < N / 2) {  // whole line of tiles outside the band of the smoothed spectrum: its output is never read
+    int so = outer + p.outer_offset;
+    if (so > N / 2) so -= N;
+    if (so > p.band_outer || so < -p.band_outer) return;
+  }
 
   C src[8], v[8];
 #pragma unroll 1
@@ -60,7 +65,9 @@ __global__ void __launch_bounds__(T *N / 8) k_strided(const PfStridedParams p, c
 #pragma unroll
       for (int m = 0; m < 8; m++) {
         const int e = tlj + m * NT;
-        src[m] = valid ? in[pf_addr(p.ain, outer, e, colj)] : pf_mk<F>(0, 0);
+        const int se = e > N / 2 ? e - N : e;
+        const bool inband = se <= p.band_e && se >= -p.band_e;
+        src[m] = (valid && inband) ? in[pf_addr(p.ain, outer, e, colj)] : pf_mk<F>(0, 0);
       }
       if (p.pre) {
         int so = outer + p.outer_offset;
@@ -121,7 +128,7 @@ __global__ void __launch_bounds__(TL *(N / 16)) k_c2r(const PfC2RParams p) {
   for (int idx = tid; idx < TL * (M + 1); idx += NTHR) {
     const int ll = idx / (M + 1), k = idx % (M + 1);
     const long long row = line0 + ll;
-    lds[ll * LPL + k] = row < p.nlines ? in[row * p.in_pitch + k] : pf_mk<F>(0, 0);
+    lds[ll * LPL + k] = (row < p.nlines && k <= p.band_k) ? in[row * p.in_pitch + k] : pf_mk<F>(0, 0);
   }
   __syncthreads();
 

@@ -35,6 +35,10 @@ struct PfStridedParams {
   int outer_offset;  // global index of outer = 0 (k-space y-slab start)
   double rs, growth;
   const void *tw;    // exp(+2 pi i j / n), n entries of complex F
+  // pruned transform of a band-limited (Gaussian-smoothed) spectrum: wavenumbers |s| > band carry a
+  // weight below 2^-60 and are treated as exact zeros.  band_e masks the loads along the transformed
+  // axis, band_outer skips whole workgroups; columns are pruned by ncols.  band >= n/2 disables.
+  int band_e, band_outer;
 };
 
 // one x- or y-pass: for every job, out = FFT_e[ in * pre * mul ]  (dir = +1 inverse, -1 forward)
@@ -56,6 +60,7 @@ struct PfC2RParams {
   double norm;          // 1/N^3 applied to the result (src/fmax-pfft.c:220-225)
   const double *dc;     // device scalar added after normalisation (DC mode of 2nd derivatives), or null
   const void *tw;       // exp(+2 pi i j / n)
+  int band_k;           // input columns kz > band_k are zero (pruned), not read
 };
 int pf_launch_c2r(int field_bytes, int n, const PfC2RParams &p, hipStream_t st);
 

