@@ -77,7 +77,7 @@ struct pf_ctx {
   hipStream_t stream2;  // collapse solve of radius i, overlapped with the passes of radius i+1 (pf_sweep)
   hipEvent_t ev_h[2], ev_c[2];
   int collapse_blocks;
-  bool overlap, fuse;
+  bool overlap, fuse, fast_libm;
   int ncu, fused_wg_per_cu, fused_skew_ns, last_band;
   double prune_eps;
   bool own_stream;
@@ -211,6 +211,9 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
     //   fp64-ALU bound, so the row transforms' instructions are exposed instead of hidden under HBM time.
     c->overlap = getenv("PF_OVERLAP") && atoi(getenv("PF_OVERLAP"));
     c->fuse = getenv("PF_FUSE") && atoi(getenv("PF_FUSE"));
+    // Default: the sincos / cbrt / exp10 forms of the solver's transcendental hot spots (pf_collapse_core.h), 25 %
+    // fewer fp64 instructions.  PF_EXACT_LIBM=1: the reference's own calls (cos x3, pow, pow), bit-comparable with the CPU.
+    c->fast_libm = !(getenv("PF_EXACT_LIBM") && atoi(getenv("PF_EXACT_LIBM")));
     c->ncu = prop.multiProcessorCount;
     c->prune_eps = 8.673617379884035e-19;  // 2^-60; PF_PRUNE_EPS=0 transforms every mode
     if (const char *e = getenv("PF_PRUNE_EPS")) c->prune_eps = atof(e);
@@ -561,7 +564,7 @@ static int collapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], hipStream_
   for (int i = 0; i < 6; i++) p.h[i] = H[i];
   p.pitch = 2 * c->nzp; p.nrows = (long long)c->nxl * c->n; p.n = c->n; p.fmax = c->fmax; p.rmax = c->rmax; p.ismooth = ismooth;
   if (spline_for(c, ismooth, &p.spline)) return 1;
-  p.partials = c->partials;
+  p.partials = c->partials; p.fast = c->fast_libm ? 1 : 0;
   size_t nb = (ncell(c) + 255) / 256; if (nb > (size_t)c->collapse_blocks) nb = c->collapse_blocks;
   p.nblocks = (int)nb;
   {
@@ -809,7 +812,7 @@ extern "C" int pf_collapse_cells(pf_ctx *c, int ismooth, const double *d, size_t
   if (spline_for(c, ismooth, &s)) return 1;
   double *dd = (double *)staging(c), *df = dd + 6 * count;
   HIPCHK(c, hipMemcpyAsync(dd, d, 6 * count * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  PFCHK(c, pf_launch_collapse_cells(dd, count, s, df, c->stream));
+  PFCHK(c, pf_launch_collapse_cells(dd, count, s, df, c->fast_libm ? 1 : 0, c->stream));
   HIPCHK(c, hipMemcpyAsync(F, df, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;

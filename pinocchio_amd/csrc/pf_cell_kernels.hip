@@ -26,7 +26,7 @@ __device__ __forceinline__ void pf_block_sum2(double &a, double &b, double *sh /
 }
 
 // K6: one thread per cell, grid-stride.  fp64 math whatever the field precision.
-template <typename F>
+template <typename F, bool FAST>
 __global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse(const PfCollapseParams p) {
   __shared__ double sk[3 * PF_MAX_KNOTS];
   __shared__ double red[2 * (PF_CELL_BLOCK / 64)];
@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse(const PfCollapsePara
     sum += delta;
     sum2 += delta * delta;
     double lam[3];
-    const double Fnew = pf_inverse_collapse_time(d, sv, lam);
+    const double Fnew = pf_inverse_collapse_time<FAST>(d, sv, lam);
     // products[].Fmax is float, compared after promotion (quirk Q2); init -10 / -1 at ismooth 0
     const float fold = p.ismooth ? p.fmax[i] : -10.0f;
     if ((double)fold < Fnew) {
@@ -88,13 +88,14 @@ __global__ void k_sum1(const double *partials, int nblocks, double scale, double
   if (threadIdx.x == 0) out[0] = a * scale;
 }
 
+template <bool FAST>
 __global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse_cells(const double *d, size_t count, PfSplineDev s, double *F) {
   pf_spline_view sv;
   sv.x = s.x; sv.y = s.y; sv.c = s.c; sv.n = s.n;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
     double t[6], lam[3];
     for (int k = 0; k < 6; k++) t[k] = d[6 * i + k];
-    F[i] = pf_inverse_collapse_time(t, sv, lam);
+    F[i] = pf_inverse_collapse_time<FAST>(t, sv, lam);
   }
 }
 
@@ -255,8 +256,13 @@ static inline int pf_grid_for(size_t n, int cap = 256 * 8) {
 
 int pf_launch_collapse(int fb, const PfCollapseParams &p, hipStream_t st) {
   if (p.spline.n > PF_MAX_KNOTS) return 2;
-  if (fb == 8) hipLaunchKernelGGL(k_collapse<double>, dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
-  else hipLaunchKernelGGL(k_collapse<float>, dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
+  if (fb == 8) {
+    if (p.fast) hipLaunchKernelGGL((k_collapse<double, true>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
+    else hipLaunchKernelGGL((k_collapse<double, false>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
+  } else {
+    if (p.fast) hipLaunchKernelGGL((k_collapse<float, true>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
+    else hipLaunchKernelGGL((k_collapse<float, false>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
+  }
   return PF_CHECK_LAUNCH();
 }
 int pf_launch_final_sum(const double *partials, int nblocks, double *out2, hipStream_t st) {
@@ -267,8 +273,9 @@ int pf_launch_sum1(const double *partials, int nblocks, double scale, double *ou
   hipLaunchKernelGGL(k_sum1, dim3(1), dim3(64), 0, st, partials, nblocks, scale, out);
   return PF_CHECK_LAUNCH();
 }
-int pf_launch_collapse_cells(const double *d, size_t count, PfSplineDev s, double *F, hipStream_t st) {
-  hipLaunchKernelGGL(k_collapse_cells, dim3(pf_grid_for(count)), dim3(PF_CELL_BLOCK), 0, st, d, count, s, F);
+int pf_launch_collapse_cells(const double *d, size_t count, PfSplineDev s, double *F, int fast, hipStream_t st) {
+  if (fast) hipLaunchKernelGGL(k_collapse_cells<true>, dim3(pf_grid_for(count)), dim3(PF_CELL_BLOCK), 0, st, d, count, s, F);
+  else hipLaunchKernelGGL(k_collapse_cells<false>, dim3(pf_grid_for(count)), dim3(PF_CELL_BLOCK), 0, st, d, count, s, F);
   return PF_CHECK_LAUNCH();
 }
 int pf_launch_lpt_sources(int fb, const PfLptSrcParams &p, hipStream_t st) {

@@ -65,11 +65,46 @@ PF_HD double pf_spline_eval(const pf_spline_view &s, double v) {
   return y_lo + delx * (b_i + delx * (c_i + delx * d_i));
 }
 
-PF_HD double pf_inverse_growing_mode(const pf_spline_view &s, double D) {
-  return 1. / pow(10., pf_spline_eval(s, log10(D))) - 1.;
+// ---- the three transcendental hot spots, in two flavours ---------------------------------------
+// FAST = false: the reference's own calls (cos x3, pow(x, 0.333333333333333), pow(10., y)).
+// FAST = true : algebraically identical forms that cost ~1/3 of the instructions on gfx950
+//   cos(t/3), cos((t+2pi)/3), cos((t+4pi)/3)  ->  one sincos and a rotation by 2pi/3
+//   pow(x, 0.333333333333333)                 ->  cbrt(x) * (1 - d ln x), d = 1/3 - 0.333333333333333
+//   pow(10., y)                               ->  exp10(y)
+// Each differs from the reference call by about one ulp, like the device libm differs from glibc.
+template <bool FAST> PF_HD void pf_cos3(double t, double &c1, double &c2, double &c3) {
+  const double inv_3 = 1.0 / 3.0;
+  if (!FAST) {
+    c1 = cos(t * inv_3);
+    c2 = cos((t + 2. * PF_PI) * inv_3);
+    c3 = cos((t + 4. * PF_PI) * inv_3);
+  } else {
+    double sn, cs;
+    sincos(t * inv_3, &sn, &cs);
+    const double h = 0.86602540378443864676 * sn;  // sin(2 pi / 3) sin(t/3)
+    c1 = cs;
+    c2 = -0.5 * cs - h;
+    c3 = -0.5 * cs + h;
+  }
+}
+template <bool FAST> PF_HD double pf_pow_third(double x) {
+  if (!FAST) return pow(x, 0.333333333333333);
+  // x^(1/3 - d) = cbrt(x) exp(-d ln x), d = 3.33e-16: ln x is needed to ~1e-2 only
+  int e;
+  const double m = frexp(x, &e);
+  const double lnx = 0.6931471805599453 * (double)e + (double)logf((float)m);
+  return cbrt(x) * (1.0 - 3.3306690738754696e-16 * lnx);
+}
+template <bool FAST> PF_HD double pf_pow10(double y) {
+  if (!FAST) return pow(10., y);
+  return exp10(y);
 }
 
-PF_HD double pf_ell_classic(double l1, double l2, double l3) {
+template <bool FAST = false> PF_HD double pf_inverse_growing_mode(const pf_spline_view &s, double D) {
+  return 1. / pf_pow10<FAST>(pf_spline_eval(s, log10(D))) - 1.;
+}
+
+template <bool FAST = false> PF_HD double pf_ell_classic(double l1, double l2, double l3) {
   double ell;
   const double del = l1 + l2 + l3;
   const double det = l1 * l2 * l3;
@@ -100,16 +135,18 @@ PF_HD double pf_ell_classic(double l1, double l2, double l3) {
       const double r_2_q_3 = r * r - q * q * q;
       if (r_2_q_3 > 0) {
         const double fabs_r = fabs(r);
-        const double sq = pow(sqrt(r_2_q_3) + fabs_r, 0.333333333333333);
+        const double sq = pf_pow_third<FAST>(sqrt(r_2_q_3) + fabs_r);
         ell = -fabs_r / r * (sq + q / sq) - a1 / 3.;
         if (ell < 0.) ell = -.1;
       } else {
         const double sq = 2 * sqrt(q);
         const double inv_3 = 1.0 / 3;
         const double t = acos(2 * r / q / sq);
-        double s1 = -sq * cos(t * inv_3) - a1 * inv_3;
-        double s2 = -sq * cos((t + 2. * PF_PI) * inv_3) - a1 * inv_3;
-        double s3 = -sq * cos((t + 4. * PF_PI) * inv_3) - a1 * inv_3;
+        double c1, c2, c3;
+        pf_cos3<FAST>(t, c1, c2, c3);
+        double s1 = -sq * c1 - a1 * inv_3;
+        double s2 = -sq * c2 - a1 * inv_3;
+        double s3 = -sq * c3 - a1 * inv_3;
         if (s1 < 0.) s1 = 1.e10;
         if (s2 < 0.) s2 = 1.e10;
         if (s3 < 0.) s3 = 1.e10;
@@ -128,7 +165,7 @@ PF_HD double pf_ell_classic(double l1, double l2, double l3) {
 
 // d = {11,22,33,12,13,23}.  Returns F = 1 + z_collapse (0: never collapses,
 // -10: eigen-solver sentinel).  lam[3] receives the ordered eigenvalues.
-PF_HD double pf_inverse_collapse_time(const double d[6], const pf_spline_view &s, double lam[3]) {
+template <bool FAST = false> PF_HD double pf_inverse_collapse_time(const double d[6], const pf_spline_view &s, double lam[3]) {
   const double mu1 = d[0] + d[1] + d[2];
   const double mu1_2 = mu1 * mu1;
   double mu2 = 0.5 * mu1_2;
@@ -149,17 +186,19 @@ PF_HD double pf_inverse_collapse_time(const double d[6], const pf_spline_view &s
     const double sq = 2 * sqrt(q);
     const double t = acos(2 * r / q / sq);
     const double inv_3 = 1.0 / 3.0;
-    x1 = -sq * cos(t * inv_3) + mu1 * inv_3;
-    x2 = -sq * cos((t + 2. * PF_PI) * inv_3) + mu1 * inv_3;
-    x3 = -sq * cos((t + 4. * PF_PI) * inv_3) + mu1 * inv_3;
+    double c1, c2, c3;
+    pf_cos3<FAST>(t, c1, c2, c3);
+    x1 = -sq * c1 + mu1 * inv_3;
+    x2 = -sq * c2 + mu1 * inv_3;
+    x3 = -sq * c3 + mu1 * inv_3;
   }
   // ord(): hi, lo by comparisons, middle arithmetically
   double hi = (x1 > x2 ? x1 : x2); hi = (hi > x3 ? hi : x3);
   double lo = (x1 < x2 ? x1 : x2); lo = (lo < x3 ? lo : x3);
   const double mid = x1 + x2 + x3 - lo - hi;
   lam[0] = hi; lam[1] = mid; lam[2] = lo;
-  const double bc = pf_ell_classic(hi, mid, lo);
-  if (bc > 0.0) return 1. + pf_inverse_growing_mode(s, bc);
+  const double bc = pf_ell_classic<FAST>(hi, mid, lo);
+  if (bc > 0.0) return 1. + pf_inverse_growing_mode<FAST>(s, bc);
   return 0.0;
 }
 

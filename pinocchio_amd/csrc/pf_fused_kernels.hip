@@ -25,7 +25,7 @@ __device__ __forceinline__ double pf_solve_cell(double d0, double d1, double d2,
   sv.x = sx; sv.y = sy; sv.c = sc; sv.n = nk;
   const double d[6] = {d0, d1, d2, d3, d4, d5};
   double lam[3];
-  return pf_inverse_collapse_time(d, sv, lam);
+  return pf_inverse_collapse_time<false>(d, sv, lam);
 }
 
 template <typename F, int N> struct PfFusedGeom {

@@ -88,10 +88,11 @@ struct PfCollapseParams {
   PfSplineDev spline;
   double *partials;     // [2*nblocks]: sum delta, sum delta^2 per block
   int nblocks;
+  int fast;             // 1: sincos/cbrt/exp10 forms of the transcendental hot spots (pf_collapse_core.h)
 };
 int pf_launch_collapse(int field_bytes, const PfCollapseParams &p, hipStream_t st);
 int pf_launch_final_sum(const double *partials, int nblocks, double *out2, hipStream_t st);
-int pf_launch_collapse_cells(const double *d, size_t count, PfSplineDev s, double *F, hipStream_t st);
+int pf_launch_collapse_cells(const double *d, size_t count, PfSplineDev s, double *F, int fast, hipStream_t st);
 
 // fused z-pass + collapse (pf_fused_kernels.hip)
 struct PfFusedParams {

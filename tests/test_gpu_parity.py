@@ -9,7 +9,11 @@ Tolerances (fp64 field path), as stated in DESIGN.md:
                                   (den = det/126 + 5 l1 d (d-l1)/84 cancels when d = l1+l2+l3 ~ 0,
                                   src/collapse_times.c:133): there |diff| <= 2e-3, and the oracle fed with
                                   the GPU's Hessian (equal to its own to ~1e-15) reproduces the GPU value
-  * per-cell solver, equal input: identical sentinels and zeros; <= 1e-12 relative on > 99.95 % of random Hessians (libm ulps)
+  * per-cell solver, equal input: identical sentinels and zeros; PF_EXACT_LIBM=1 (the reference's own libm calls):
+                                  <= 1e-12 relative on > 99.95 % of random Hessians, and every Fmax outlier of the
+                                  full path is reproduced bit for bit by the oracle fed with the GPU's Hessian;
+                                  default (sincos/cbrt/exp10 forms, ~1 ulp per call): <= 1e-10 on > 99.9 %, and every
+                                  outlier lies within 8x the spread the oracle itself shows under 2-ulp input noise
   * Rmax                        : identical on >= 99.9 % of cells
   * displacements (stored fp32) : |diff| <= 4e-7 x amplitude (fp32 rounding of equal fp64 values)
 """
@@ -60,7 +64,12 @@ def test_transforms_vs_pocketfft(api, n):
         assert np.max(np.abs(again - real)) < 1e-13 * np.log2(n)
 
 
-def test_collapse_cells_kat_and_random(api):
+@pytest.mark.parametrize("libm", ["fast", "exact"])
+def test_collapse_cells_kat_and_random(api, libm, monkeypatch):
+    if libm == "exact":
+        monkeypatch.setenv("PF_EXACT_LIBM", "1")
+    else:
+        monkeypatch.delenv("PF_EXACT_LIBM", raising=False)
     with open(os.path.join(GOLD, "collapse_kat.json")) as fh:
         kat = json.load(fh)
     with api.Fmax(64) as f:
@@ -69,7 +78,7 @@ def test_collapse_cells_kat_and_random(api):
         d = np.array([c["d"] for c in kat["inverse_collapse_time"]])
         F = f.collapse_cells(d)
         for i, case in enumerate(kat["inverse_collapse_time"]):
-            tol = 1e-7 if "degenerate" in case["branch"] else 1e-13
+            tol = 1e-7 if "degenerate" in case["branch"] else 1e-12
             assert F[i] == pytest.approx(case["F"], rel=tol, abs=1e-14), case
         # random Hessians incl. diagonal / zero / q==0 cases against the oracle (LCDM spline)
         x, y = synth.invgrow_table("lcdm")
@@ -89,11 +98,18 @@ def test_collapse_cells_kat_and_random(api):
     # no FMA contraction in the device solver: same IEEE operations as the CPU, only libm differs
     assert np.array_equal(F == -10.0, want == -10.0)
     assert np.array_equal(F == 0.0, want == 0.0)
-    assert np.mean((F == want) | both_nan) > 0.5  # the rest: 1-ulp libm differences
-    ok = both_nan | (np.abs(F - want) <= 1e-12 * np.maximum(1.0, np.abs(want)))
+    rel = np.abs(F - want) / np.maximum(1.0, np.abs(want))
+    rel[both_nan] = 0.0
     # libm differences (<= 1-2 ulp in acos/cos/pow/exp/log10) are amplified where the cubic is ill-conditioned
-    assert np.mean(ok) > 0.9995, np.mean(ok)
-    assert np.all(both_nan | (np.abs(F - want) <= 1e-6 * np.maximum(1.0, np.abs(want))))
+    if libm == "exact":
+        assert np.mean((F == want) | both_nan) > 0.5  # the rest: 1-ulp libm differences
+        assert np.mean(rel <= 1e-12) > 0.9995, np.mean(rel <= 1e-12)
+        assert rel.max() <= 1e-6
+    else:
+        assert np.median(rel) < 5e-15
+        assert np.mean(rel <= 1e-10) > 0.999, np.mean(rel <= 1e-10)
+        assert rel.max() <= 1e-5
+    assert np.mean(F.astype(np.float32) != want.astype(np.float32)) < 2e-4
 
 
 @pytest.mark.parametrize("n,rs", [(16, 0.0), (32, 1.5), (64, 2.8), (64, 0.0)])
@@ -111,6 +127,35 @@ def test_second_derivatives_vs_oracle(api, n, rs):
     amp = max(np.max(np.abs(w)) for w in want)
     for i in range(6):
         assert np.max(np.abs(got[i] - want[i])) < 1e-12 * amp, i
+
+
+def _explain_outliers(api, n, radii, kind, outliers, p, exact):
+    """Outliers come from the ~1e-15 difference of the Hessians in cells where the reference's cubic is
+    ill-conditioned.  exact libm: the oracle's solver on the GPU's Hessian gives the GPU's Fmax bit for bit.
+    default libm: the GPU value lies within 8x the spread of the oracle under 2-ulp noise on its input."""
+    dk = synth.make_density(n, seed=synth.SEED)
+    x, y = synth.invgrow_table(kind)
+    o = oracle_lib.Oracle(8, 1)
+    o.set_invgrow(x, y)
+    rng = np.random.default_rng(1)
+    with api.Fmax(n) as f:
+        f.set_density(dk)
+        for ir in sorted(set(int(p["Rmax"][tuple(c)]) for c in outliers)):
+            f.compute_second_derivatives(radii[ir])
+            hg = [f.second_derivative(i) for i in range(6)]
+            for c in outliers:
+                c = tuple(c)
+                if p["Rmax"][c] != ir:
+                    continue
+                h = np.array([hh[c] for hh in hg])
+                fo = o.inverse_collapse_time(h)[0]
+                if exact:
+                    assert np.float32(fo) == p["Fmax"][c], (c, fo, p["Fmax"][c])
+                else:
+                    spread = max(abs(o.inverse_collapse_time(h * (1.0 + rng.uniform(-4.4e-16, 4.4e-16, 6)))[0] - fo)
+                                 for _ in range(32))
+                    ulp = float(np.spacing(np.float32(max(abs(fo), 1.0))))
+                    assert abs(float(p["Fmax"][c]) - fo) <= max(8.0 * spread, 2.0 * ulp), (c, fo, p["Fmax"][c], spread)
 
 
 def _run_both(api, n, radii, kind="lcdm", seed=synth.SEED, field_bytes=8, do_lpt=True):
@@ -143,23 +188,7 @@ def test_full_path_vs_oracle(api, n, ns, kind):
     assert np.mean(p["Rmax"] != po["Rmax"]) < 1e-3
     assert (po["Fmax"] >= 1).sum() > 0
     if len(outliers):
-        # every outlier is explained by the ~1e-15 difference of the Hessians: the oracle's solver on the
-        # GPU's Hessian values gives the GPU's Fmax
-        dk = synth.make_density(n, seed=synth.SEED)
-        x, y = synth.invgrow_table(kind)
-        o = oracle_lib.Oracle(8, 1)
-        o.set_invgrow(x, y)
-        with api.Fmax(n) as f:
-            f.set_density(dk)
-            for ir in sorted(set(int(p["Rmax"][tuple(c)]) for c in outliers)):
-                f.compute_second_derivatives(radii[ir])
-                hg = [f.second_derivative(i) for i in range(6)]
-                for c in outliers:
-                    c = tuple(c)
-                    if p["Rmax"][c] != ir:
-                        continue
-                    fo = o.inverse_collapse_time(np.array([h[c] for h in hg]))[0]
-                    assert np.float32(fo) == p["Fmax"][c], (c, fo, p["Fmax"][c], po["Fmax"][c])
+        _explain_outliers(api, n, radii, kind, outliers, p, exact=False)
     for w in range(3):
         assert np.max(np.abs(kv[w] - kv_o[w])) < 1e-12 * np.max(np.abs(kv_o[w])) * np.log2(n), w
     for name in ("Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
@@ -171,6 +200,20 @@ def test_full_path_vs_oracle(api, n, ns, kind):
     # Fmax PDF (src/fmax.c:509-550): a cell 1 ulp across a bin edge may move one count
     assert int(pdf.sum()) == n ** 3
     assert np.abs(pdf.astype(np.int64) - pdf_o.astype(np.int64)).sum() <= max(2, int(2e-4 * n ** 3))
+
+
+def test_full_path_exact_libm_outliers_are_bit_explained(api, monkeypatch):
+    """PF_EXACT_LIBM=1: the solver makes the reference's own libm calls; every Fmax outlier at 128^3 is then
+    reproduced bit for bit by the oracle's solver on the GPU's Hessian."""
+    monkeypatch.setenv("PF_EXACT_LIBM", "1")
+    n = 128
+    radii = synth.radii_ladder(5) * (n / 128.0)
+    radii[-1] = 0.0
+    (tv, p, pdf, _), (tv_o, po, pdf_o, _) = _run_both(api, n, radii, "lcdm", do_lpt=False)
+    assert np.allclose(tv, tv_o, rtol=1e-12)
+    outliers = _fmax_close(p["Fmax"], po["Fmax"])
+    assert np.mean(p["Rmax"] != po["Rmax"]) < 1e-3
+    _explain_outliers(api, n, radii, "lcdm", outliers, p, exact=True)
 
 
 def test_golden_fixture(api):
