@@ -92,9 +92,26 @@ def main():
 
     f = api.Fmax(n, rank=rank, nranks=world, device=local_rank, field_bytes=args.field_bytes, timing=True)
     keep = []
+    exchange_kind = None
     if world > 1:
         from pinocchio_amd import dist as pfdist
-        keep.append(pfdist.install_exchange(f, dist, torch, kind=args.exchange))
+        # built-in RCCL exchange first; if it cannot be set up or fails its self-test on this node, the same
+        # collectives go through torch.distributed (also RCCL) on tensors aliasing the library's buffers
+        kinds = [args.exchange] + [k for k in ("rccl", "torch") if k != args.exchange]
+        for kind in kinds:
+            ok = 1
+            try:
+                keep.append(pfdist.install_exchange(f, dist, torch, kind=kind))
+                ok = f.L.pf_debug_exchange(f.h, 1 << 20)
+            except Exception as e:  # noqa: BLE001
+                print(f"[rank {rank}] exchange '{kind}' unavailable: {e}", file=sys.stderr, flush=True)
+            t = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if int(t.item()) == 0:
+                exchange_kind = kind
+                break
+        if exchange_kind is None:
+            raise SystemExit("no working multi-GPU exchange")
 
     f.synth_density(synth.SEED, 2.5, -2.0)
     x, y = synth.invgrow_table("lcdm")
@@ -148,7 +165,7 @@ def main():
             "dtype": "f64" if w == 8 else "f32 fields / f64 collapse", "data": "synthetic",
             "config": {"workload": f"{n}^3 box, {ns} smoothing radii, Fmax sweep{' + 2LPT/3LPT displacements' if lpt else ' only'}, "
                                    f"{'fp64' if w == 8 else 'fp32-field'} path, Philox white noise with P(k)~k^-2, sigma(R=0)=2.5",
-                       "grid": n, "nsmooth": ns, "lpt": lpt, "parallelism": f"x-slabs over {world} GPU(s)",
+                       "grid": n, "nsmooth": ns, "lpt": lpt, "parallelism": f"x-slabs over {world} GPU(s)" + (f", all-to-all via {exchange_kind}" if exchange_kind else ""),
                        "device_GB": f.device_bytes / 1e9, "sigma_R0": float(np.sqrt(tv[-1]))},
             "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": None,

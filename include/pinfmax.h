@@ -87,6 +87,8 @@ typedef struct pf_fabric pf_fabric;
 pf_fabric *pf_fabric_create(int nranks);
 void pf_fabric_destroy(pf_fabric *f);
 int pf_fabric_attach(pf_fabric *f, pf_ctx *ctx);
+/* self-test of the installed exchange (pattern through the all-to-all and the all-reduce), any nranks >= 1 */
+int pf_debug_exchange(pf_ctx *ctx, size_t bytes_per_peer);
 /* device pointers + size (bytes) of the exchange buffers, so that a host
    harness can wrap them (e.g. torch tensors for torch.distributed) */
 int pf_exchange_buffers(pf_ctx *ctx, void **sendbuf, void **recvbuf, size_t *bytes);

@@ -853,6 +853,38 @@ extern "C" int pf_reset_kernel_stats(pf_ctx *c) {
   return 0;
 }
 
+// Exchange self-test: fills the send blocks with a rank/block pattern, runs the installed all-to-all (also on one
+// rank, where the path itself never calls it) and checks what arrived.  Returns 0 when every word is right.
+extern "C" int pf_debug_exchange(pf_ctx *c, size_t bytes_per_peer) {
+  if (!c) return 1;
+  if (!c->a2a) return pf_fail(c->rank, "pf_debug_exchange: no exchange installed");
+  if (bytes_per_peer % 8 || bytes_per_peer * c->P > c->field_bytes) return pf_fail(c->rank, "pf_debug_exchange: bad size");
+  const size_t nw = bytes_per_peer / 8;
+  std::vector<unsigned long long> h(nw * c->P);
+  for (int q = 0; q < c->P; q++)
+    for (size_t i = 0; i < nw; i++) h[q * nw + i] = ((unsigned long long)c->rank << 48) | ((unsigned long long)q << 40) | i;
+  void *recv = c->P > 1 ? c->recvA : c->A[1];
+  HIPCHK(c, hipMemcpyAsync(c->A[0], h.data(), h.size() * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(recv, 0, h.size() * 8, c->stream));
+  if (c->a2a(c->a2a_user, c->A[0], recv, bytes_per_peer, (void *)c->stream)) return pf_fail(c->rank, "pf_debug_exchange: all-to-all failed");
+  HIPCHK(c, hipMemcpyAsync(h.data(), recv, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int p = 0; p < c->P; p++)
+    for (size_t i = 0; i < nw; i++)
+      if (h[p * nw + i] != (((unsigned long long)p << 48) | ((unsigned long long)c->rank << 40) | i))
+        return pf_fail(c->rank, "pf_debug_exchange: wrong word from rank %d at %zu", p, i);
+  if (c->ared) {
+    double v[2] = {1.0 + c->rank, 2.0};
+    HIPCHK(c, hipMemcpyAsync(c->scal, v, sizeof(v), hipMemcpyHostToDevice, c->stream));
+    if (c->ared(c->ared_user, c->scal, 2, 0, (void *)c->stream)) return pf_fail(c->rank, "pf_debug_exchange: all-reduce failed");
+    HIPCHK(c, hipMemcpyAsync(v, c->scal, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (v[0] != 0.5 * c->P * (c->P + 1) || v[1] != 2.0 * c->P) return pf_fail(c->rank, "pf_debug_exchange: wrong all-reduce result");
+    HIPCHK(c, hipMemsetAsync(c->scal, 0, 2 * sizeof(double), c->stream));
+  }
+  return 0;
+}
+
 // used by pf_rccl.cpp
 extern "C" int pf_ctx_rank_size(pf_ctx *c, int *rank, int *nranks) {
   if (!c) return 1;

@@ -41,7 +41,7 @@ static int load_rccl() {
   }
   for (const char *nm : names) {
     if (h) break;
-    h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    h = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
   }
   if (!h) { printf("ERROR on task 0: cannot load librccl (%s)\n", dlerror()); return 1; }
 #define SYM(field, name) *(void **)(&g_api.field) = dlsym(h, name); if (!g_api.field) { printf("ERROR on task 0: missing %s in librccl\n", name); return 1; }

@@ -147,3 +147,61 @@ def test_fp32_fields_two_ranks(api):
         sl = slice(r * nxl, (r + 1) * nxl)
         assert np.array_equal(res[r]["Fmax"], p1["Fmax"][sl])
         assert np.array_equal(res[r]["Vel"], p1["Vel"][sl])
+
+
+def test_fabric_exchange_selftest(api):
+    def body(f, r):
+        return f.L.pf_debug_exchange(f.h, 4096)
+    assert run_ranks(api, 64, 4, body) == [0, 0, 0, 0]
+
+
+_RCCL_CODE = """
+import ctypes as C, sys
+sys.path.insert(0, %r)
+from pinocchio_amd import api
+with api.Fmax(64) as f:
+    idbuf = (C.c_ubyte * 128)()
+    assert f.L.pf_rccl_unique_id(C.cast(idbuf, C.c_void_p)) == 0
+    assert f.L.pf_init_rccl(f.h, C.cast(idbuf, C.c_void_p)) == 0
+    assert f.L.pf_debug_exchange(f.h, 1 << 20) == 0
+print("RCCL_OK")
+"""
+
+_TORCH_CODE = """
+import os, socket, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from pinocchio_amd import api, dist as pfdist
+s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+for kind in ("torch", "rccl"):
+    with api.Fmax(64) as f:
+        keep = pfdist.install_exchange(f, dist, torch, kind=kind)
+        assert f.L.pf_debug_exchange(f.h, 1 << 20) == 0, kind
+        del keep
+dist.destroy_process_group()
+print("TORCH_OK")
+"""
+
+
+def _run_isolated(code, token):
+    """own process: the ROCm RCCL and the copy bundled with torch must not meet in one address space"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code % root], capture_output=True, text=True, timeout=600)
+    assert token in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_rccl_exchange_single_rank():
+    """the built-in RCCL exchange (dlopen, ncclCommInitRank, grouped send/recv, all-reduce) on a 1-rank communicator"""
+    _run_isolated(_RCCL_CODE, "RCCL_OK")
+
+
+def test_torch_exchange_single_rank():
+    """bench.py's two exchange kinds after torch.distributed (backend nccl = RCCL) is up: `torch` = collectives on
+    tensors aliasing the library's device buffers on the library's stream, `rccl` = the built-in exchange"""
+    _run_isolated(_TORCH_CODE, "TORCH_OK")
