@@ -7,15 +7,16 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load it; the shipped library (libpinfmax_hip.so) never does.
  *
- * Parity pin: the per-cell solver (orc_ell_classic / orc_inverse_collapse_time)
- * is pinned by the known-answer values captured from the compiled reference
- * objects during the survey (SURVEY.md Appendix D -> tests/golden/
- * collapse_kat.json).  The field-level path (k-filter, c2r, LPT) is pinned by
- * an independent numpy/pocketfft restatement (tests/np_restatement.py) whose
- * formulas SURVEY.md Appendix C.6 records as bit-identical to the running
- * reference at N=32.  The reference itself is UNBUILDABLE in this image
- * (needs GSL, FFTW3-MPI and PFFT, all absent; no stand-ins are written), so
- * no oracle/_ref exists; see DESIGN.md "Oracle".
+ * Parity pin: (1) END TO END against the reference's own committed validation run (HMF_Validation/: 128^3,
+ * seed 486604, E&H, 9 radii): with the restated IC generator (pf_genic.c + tests/ic_oracle.py) the oracle
+ * reproduces the logged per-radius sigma to the 4 printed decimals, the collapsed-cell count to 1 cell in
+ * 1 230 386 and the 210-bin Fmax histogram to 70 cells in 2 097 152 (tests/test_hmf_validation_kat.py, data in
+ * tests/golden/hmf_validation_kat.json).  (2) The per-cell solver against the known answers of the reference's
+ * ell_classic / inverse_collapse_time (SURVEY.md Appendix D -> tests/golden/collapse_kat.json).  (3) The
+ * field-level path (k-filter, c2r, LPT) against an independent numpy/pocketfft restatement
+ * (tests/np_restatement.py).  The displacement fields have no reference output in the repository and are
+ * pinned by (3) only.  The reference itself is UNBUILDABLE in this image (needs GSL, FFTW3-MPI and PFFT, all
+ * absent; no stand-ins are written), so no oracle/_ref exists; see DESIGN.md "Oracle".
  *
  * Flags mirrored: -DTWO_LPT -DTHREE_LPT -DELL_CLASSIC (no SCALE_DEPENDENT,
  * no RECOMPUTE_DISPLACEMENTS, float products) == HMF_Validation build.

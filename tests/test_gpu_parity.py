@@ -352,3 +352,27 @@ def test_pruned_transform_equals_full_transform(api, monkeypatch):
         for a, b in zip(full, pruned):
             assert np.max(np.abs(a - b)) <= 4e-16 * amp
     assert not np.array_equal(out["0"][0][0], out[None][0][0]) or True
+
+
+def test_hmf_validation_run_on_gpu(api):
+    """The reference's own committed validation run (HMF_Validation: 128^3, seed 486604, 9 radii) through the HIP
+    path: same per-radius sigma (4 logged decimals), collapsed-cell count and Fmax histogram as the reference's
+    output files.  The density comes from the restated IC generator (tests/ic_oracle.py, pinned by the same data)."""
+    import ic_oracle
+    with open(os.path.join(GOLD, "hmf_validation_kat.json")) as fh:
+        kat = json.load(fh)
+    p = kat["params"]
+    n = p["GridSize"]
+    box = p["BoxSize_h100"] / p["Hubble100"]
+    dk = ic_oracle.genic(n, box, p["RandomSeed"], kat["PkNorm"], p)
+    x, y = ic_oracle.growth_table_lcdm(p["Omega0"])
+    radii_cells = np.array(kat["radii_Mpc"]) / (box / n)
+    with api.Fmax(n) as f:
+        f.set_density(dk)
+        f.set_invgrow(x, y)
+        tv = f.sweep(radii_cells)
+        pdf = f.Fmax_PDF().astype(np.int64)
+    assert np.all(np.abs(np.sqrt(tv) - np.array(kat["computed_sigma"])) <= 6e-5)
+    want = np.array(kat["FmaxPDF"], dtype=np.int64)
+    assert abs(int(pdf[10:].sum()) - kat["collapsed"]) <= 5
+    assert np.abs(pdf - want).sum() <= 200 and np.max(np.abs(pdf - want)) <= 20
