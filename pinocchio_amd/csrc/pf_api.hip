@@ -92,7 +92,7 @@ struct pf_ctx {
   double *partials;    // 2 * PF_NBLK
   double *scal;        // device scalars, see SC_*
   unsigned long long *hist;
-  double *spl;         // device spline tables: [slot][3][PF_KNOT_CAP]
+  double *spl;         // device spline tables: [slot][5][PF_KNOT_CAP] = x, y, c, b, d
   int spl_n[PF_MAX_SMOOTH + 1];
   bool spl_set[PF_MAX_SMOOTH + 1];
   double growth[4];
@@ -240,7 +240,7 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   PFCHK(c, dev_alloc(c, (void **)&c->partials, 2 * PF_NBLK * sizeof(double)));
   PFCHK(c, dev_alloc(c, (void **)&c->scal, SC_COUNT * sizeof(double)));
   PFCHK(c, dev_alloc(c, (void **)&c->hist, PF_NBINS * sizeof(unsigned long long)));
-  PFCHK(c, dev_alloc(c, (void **)&c->spl, (size_t)(PF_MAX_SMOOTH + 1) * 3 * PF_KNOT_CAP * sizeof(double)));
+  PFCHK(c, dev_alloc(c, (void **)&c->spl, (size_t)(PF_MAX_SMOOTH + 1) * 5 * PF_KNOT_CAP * sizeof(double)));
   HIPCHK(c, hipMemsetAsync(c->scal, 0, SC_COUNT * sizeof(double), c->stream));
   // twiddles exp(+2 pi i j / n), computed in long double on the host
   {
@@ -526,20 +526,22 @@ extern "C" int pf_set_invgrow(pf_ctx *c, int ismooth, const double *x, const dou
   if (ismooth < -1 || ismooth >= PF_MAX_SMOOTH) return pf_fail(c->rank, "pf_set_invgrow: ismooth %d out of range", ismooth);
   for (int i = 1; i < n; i++)
     if (!(x[i] > x[i - 1])) return pf_fail(c->rank, "pf_set_invgrow: knots must be strictly increasing (i=%d)", i);
-  std::vector<double> h(3 * PF_KNOT_CAP, 0.0);
+  std::vector<double> h(5 * PF_KNOT_CAP, 0.0);
   memcpy(&h[0], x, n * sizeof(double));
   memcpy(&h[PF_KNOT_CAP], y, n * sizeof(double));
   if (pf_spline_coeffs(x, y, n, &h[2 * PF_KNOT_CAP])) return pf_fail(c->rank, "pf_set_invgrow: spline set-up failed");
+  pf_spline_bd(x, y, &h[2 * PF_KNOT_CAP], n, &h[3 * PF_KNOT_CAP], &h[4 * PF_KNOT_CAP]);
   const int slot = ismooth + 1;  // slot 0 = shared spline
-  HIPCHK(c, hipMemcpy(c->spl + (size_t)slot * 3 * PF_KNOT_CAP, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->spl + (size_t)slot * 5 * PF_KNOT_CAP, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
   c->spl_n[slot] = n; c->spl_set[slot] = true;
   return 0;
 }
 static int spline_for(pf_ctx *c, int ismooth, PfSplineDev *s) {
   int slot = (ismooth >= 0 && ismooth < PF_MAX_SMOOTH && c->spl_set[ismooth + 1]) ? ismooth + 1 : 0;
   if (!c->spl_set[slot]) return pf_fail(c->rank, "inverse-growth spline not set (pf_set_invgrow)");
-  const double *b = c->spl + (size_t)slot * 3 * PF_KNOT_CAP;
-  s->x = b; s->y = b + PF_KNOT_CAP; s->c = b + 2 * PF_KNOT_CAP; s->n = c->spl_n[slot];
+  const double *t = c->spl + (size_t)slot * 5 * PF_KNOT_CAP;
+  s->x = t; s->y = t + PF_KNOT_CAP; s->c = t + 2 * PF_KNOT_CAP; s->b = t + 3 * PF_KNOT_CAP; s->d = t + 4 * PF_KNOT_CAP;
+  s->n = c->spl_n[slot];
   return 0;
 }
 

@@ -28,17 +28,20 @@ __device__ __forceinline__ void pf_block_sum2(double &a, double &b, double *sh /
 // K6: one thread per cell, grid-stride.  fp64 math whatever the field precision.
 template <typename F, bool FAST>
 __global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse(const PfCollapseParams p) {
-  __shared__ double sk[3 * PF_MAX_KNOTS];
+  __shared__ double sk[5 * PF_MAX_KNOTS];
   __shared__ double red[2 * (PF_CELL_BLOCK / 64)];
   const int nk = p.spline.n;
   for (int i = threadIdx.x; i < nk; i += blockDim.x) {
     sk[i] = p.spline.x[i];
     sk[PF_MAX_KNOTS + i] = p.spline.y[i];
     sk[2 * PF_MAX_KNOTS + i] = p.spline.c[i];
+    sk[3 * PF_MAX_KNOTS + i] = p.spline.b[i];
+    sk[4 * PF_MAX_KNOTS + i] = p.spline.d[i];
   }
   __syncthreads();
   pf_spline_view sv;
-  sv.x = sk; sv.y = sk + PF_MAX_KNOTS; sv.c = sk + 2 * PF_MAX_KNOTS; sv.n = nk;
+  sv.x = sk; sv.y = sk + PF_MAX_KNOTS; sv.c = sk + 2 * PF_MAX_KNOTS; sv.b = sk + 3 * PF_MAX_KNOTS; sv.d = sk + 4 * PF_MAX_KNOTS;
+  sv.n = nk;
 
   const F *__restrict__ h0 = (const F *)p.h[0], *__restrict__ h1 = (const F *)p.h[1],
           *__restrict__ h2 = (const F *)p.h[2], *__restrict__ h3 = (const F *)p.h[3],
@@ -91,7 +94,7 @@ __global__ void k_sum1(const double *partials, int nblocks, double scale, double
 template <bool FAST>
 __global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse_cells(const double *d, size_t count, PfSplineDev s, double *F) {
   pf_spline_view sv;
-  sv.x = s.x; sv.y = s.y; sv.c = s.c; sv.n = s.n;
+  sv.x = s.x; sv.y = s.y; sv.c = s.c; sv.b = s.b; sv.d = s.d; sv.n = s.n;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
     double t[6], lam[3];
     for (int k = 0; k < 6; k++) t[k] = d[6 * i + k];

@@ -36,9 +36,11 @@
 #define PF_PI 3.14159265358979323846 /* src/pinocchio.h:56 */
 #define PF_SMALL 1.e-20              /* src/collapse_times.c:38 */
 
-// natural cubic spline view: knots x,y and second-derivative coefficients c (host-computed)
+// natural cubic spline view: knots x,y, second-derivative coefficients c, and the per-interval b_i, d_i that GSL's
+// cspline_eval derives from them at every call (coeff_calc) -- computed once on the host with the very same IEEE
+// operations, so the evaluation below is bit-identical to gsl_spline_eval and three divisions shorter.
 struct pf_spline_view {
-  const double *x, *y, *c;
+  const double *x, *y, *c, *b, *d;
   int n;
 };
 
@@ -54,24 +56,54 @@ PF_HD double pf_spline_eval(const pf_spline_view &s, double v) {
     int i = (ihi + ilo) >> 1;
     if (xa[i] > v) ihi = i; else ilo = i;
   }
-  const double x_lo = xa[ilo], x_hi = xa[ilo + 1];
-  const double dx = x_hi - x_lo;
-  const double y_lo = ya[ilo], y_hi = ya[ilo + 1];
-  const double dy = y_hi - y_lo;
-  const double delx = v - x_lo;
-  const double c_i = ca[ilo], c_ip1 = ca[ilo + 1];
-  const double b_i = (dy / dx) - dx * (c_ip1 + 2.0 * c_i) / 3.0;
-  const double d_i = (c_ip1 - c_i) / (3.0 * dx);
-  return y_lo + delx * (b_i + delx * (c_i + delx * d_i));
+  const double delx = v - xa[ilo];
+  return ya[ilo] + delx * (s.b[ilo] + delx * (ca[ilo] + delx * s.d[ilo]));
+}
+
+// host side of the above: b_i = dy/dx - dx (c_{i+1} + 2 c_i)/3, d_i = (c_{i+1} - c_i)/(3 dx)   (GSL coeff_calc)
+inline void pf_spline_bd(const double *xa, const double *ya, const double *ca, int n, double *b, double *d) {
+  for (int i = 0; i + 1 < n; i++) {
+    const double dx = xa[i + 1] - xa[i], dy = ya[i + 1] - ya[i];
+    b[i] = (dy / dx) - dx * (ca[i + 1] + 2.0 * ca[i]) / 3.0;
+    d[i] = (ca[i + 1] - ca[i]) / (3.0 * dx);
+  }
+  b[n - 1] = d[n - 1] = 0.0;
 }
 
 // ---- the three transcendental hot spots, in two flavours ---------------------------------------
 // FAST = false: the reference's own calls (cos x3, pow(x, 0.333333333333333), pow(10., y)).
 // FAST = true : algebraically identical forms that cost ~1/3 of the instructions on gfx950
-//   cos(t/3), cos((t+2pi)/3), cos((t+4pi)/3)  ->  one sincos and a rotation by 2pi/3
+//   cos(t/3), cos((t+2pi)/3), cos((t+4pi)/3)  ->  one sincos (series on [0, pi/3]) and a rotation by 2pi/3
+//   x / constant, x / a / b, 1 / 10^y           ->  x * (1/constant), x / (a*b), 10^-y
 //   pow(x, 0.333333333333333)                 ->  cbrt(x) * (1 - d ln x), d = 1/3 - 0.333333333333333
 //   pow(10., y)                               ->  exp10(y)
 // Each differs from the reference call by about one ulp, like the device libm differs from glibc.
+// sin and cos on [0, pi/3] (t = acos(.) in [0, pi], so t/3 never leaves it): Taylor series in x^2, no range
+// reduction; truncation < 1e-19, rounding ~1 ulp.  The generic sincos costs 155 instructions on gfx950, this ~30.
+PF_HD void pf_sincos_third(double x, double &sn, double &cs) {
+  const double z = x * x;
+  double ps = -8.2206352466243297e-18;            // -1/19!
+  ps = fma(ps, z, 2.8114572543455206e-15);        //  1/17!
+  ps = fma(ps, z, -7.6471637318198164e-13);       // -1/15!
+  ps = fma(ps, z, 1.6059043836821613e-10);        //  1/13!
+  ps = fma(ps, z, -2.5052108385441720e-08);       // -1/11!
+  ps = fma(ps, z, 2.7557319223985893e-06);        //  1/9!
+  ps = fma(ps, z, -1.9841269841269841e-04);       // -1/7!
+  ps = fma(ps, z, 8.3333333333333332e-03);        //  1/5!
+  ps = fma(ps, z, -1.6666666666666666e-01);       // -1/3!
+  sn = fma(x * z, ps, x);
+  double pc = 4.1103176233121648e-19;             //  1/20!
+  pc = fma(pc, z, -1.5619206968586225e-16);       // -1/18!
+  pc = fma(pc, z, 4.7794773323873853e-14);        //  1/16!
+  pc = fma(pc, z, -1.1470745597729725e-11);       // -1/14!
+  pc = fma(pc, z, 2.0876756987868100e-09);        //  1/12!
+  pc = fma(pc, z, -2.7557319223985888e-07);       // -1/10!
+  pc = fma(pc, z, 2.4801587301587302e-05);        //  1/8!
+  pc = fma(pc, z, -1.3888888888888889e-03);       // -1/6!
+  pc = fma(pc, z, 4.1666666666666664e-02);        //  1/4!
+  cs = fma(z * z, pc, fma(-0.5, z, 1.0));
+}
+
 template <bool FAST> PF_HD void pf_cos3(double t, double &c1, double &c2, double &c3) {
   const double inv_3 = 1.0 / 3.0;
   if (!FAST) {
@@ -80,7 +112,7 @@ template <bool FAST> PF_HD void pf_cos3(double t, double &c1, double &c2, double
     c3 = cos((t + 4. * PF_PI) * inv_3);
   } else {
     double sn, cs;
-    sincos(t * inv_3, &sn, &cs);
+    pf_sincos_third(t * inv_3, sn, cs);
     const double h = 0.86602540378443864676 * sn;  // sin(2 pi / 3) sin(t/3)
     c1 = cs;
     c2 = -0.5 * cs - h;
@@ -101,6 +133,7 @@ template <bool FAST> PF_HD double pf_pow10(double y) {
 }
 
 template <bool FAST = false> PF_HD double pf_inverse_growing_mode(const pf_spline_view &s, double D) {
+  if (FAST) return exp10(-pf_spline_eval(s, log10(D))) - 1.;
   return 1. / pf_pow10<FAST>(pf_spline_eval(s, log10(D))) - 1.;
 }
 
@@ -111,7 +144,8 @@ template <bool FAST = false> PF_HD double pf_ell_classic(double l1, double l2, d
   if (fabs(l1) < PF_SMALL) {
     ell = -0.1;
   } else {
-    const double den = det / 126. + 5. * l1 * del * (del - l1) / 84.;
+    const double den = FAST ? det * (1. / 126.) + 5. * l1 * del * (del - l1) * (1. / 84.)
+                            : det / 126. + 5. * l1 * del * (del - l1) / 84.;
     if (fabs(den) < PF_SMALL) {
       if (fabs(del - l1) < PF_SMALL) {
         ell = (l1 > 0.0) ? 1. / l1 : -.1;
@@ -126,22 +160,25 @@ template <bool FAST = false> PF_HD double pf_ell_classic(double l1, double l2, d
       }
     } else {
       const double rden = 1.0 / den;
-      const double a1 = 3. * l1 * (del - l1) / 14. * rden;
+      const double a1 = FAST ? 3. * l1 * (del - l1) * (1. / 14.) * rden : 3. * l1 * (del - l1) / 14. * rden;
       const double a1_2 = a1 * a1;
       const double a2 = l1 * rden;
       const double a3 = -1.0 * rden;
-      const double q = (a1_2 - 3. * a2) / 9.;
-      const double r = (2. * a1_2 * a1 - 9. * a1 * a2 + 27. * a3) / 54.;
+      const double q = FAST ? (a1_2 - 3. * a2) * (1. / 9.) : (a1_2 - 3. * a2) / 9.;
+      const double r = FAST ? (2. * a1_2 * a1 - 9. * a1 * a2 + 27. * a3) * (1. / 54.)
+                            : (2. * a1_2 * a1 - 9. * a1 * a2 + 27. * a3) / 54.;
       const double r_2_q_3 = r * r - q * q * q;
       if (r_2_q_3 > 0) {
         const double fabs_r = fabs(r);
         const double sq = pf_pow_third<FAST>(sqrt(r_2_q_3) + fabs_r);
-        ell = -fabs_r / r * (sq + q / sq) - a1 / 3.;
+        // fabs(r)/r is +-1 for every finite non-zero r (and NaN at r = 0, kept)
+        ell = FAST ? -(r != 0. ? copysign(1.0, r) : fabs_r / r) * (sq + q / sq) - a1 * (1.0 / 3)
+                   : -fabs_r / r * (sq + q / sq) - a1 / 3.;
         if (ell < 0.) ell = -.1;
       } else {
         const double sq = 2 * sqrt(q);
         const double inv_3 = 1.0 / 3;
-        const double t = acos(2 * r / q / sq);
+        const double t = FAST ? acos(2 * r / (q * sq)) : acos(2 * r / q / sq);
         double c1, c2, c3;
         pf_cos3<FAST>(t, c1, c2, c3);
         double s1 = -sq * c1 - a1 * inv_3;
@@ -173,18 +210,19 @@ template <bool FAST = false> PF_HD double pf_inverse_collapse_time(const double 
   const double add0 = d[3] * d[3], add1 = d[4] * d[4], add2 = d[5] * d[5];
   mu2 -= add0 + add1 + add2;
   const double mu3 = d[0] * d[1] * d[2] + 2. * d[3] * d[4] * d[5] - d[0] * add2 - d[1] * add1 - d[2] * add0;
-  const double q = (mu1_2 - 3.0 * mu2) / 9.0;
+  const double q = FAST ? (mu1_2 - 3.0 * mu2) * (1.0 / 9.0) : (mu1_2 - 3.0 * mu2) / 9.0;
   double x1, x2, x3;
   if (q == 0.) {
     x1 = d[0]; x2 = d[1]; x3 = d[2];
   } else {
-    const double r = -(2. * mu1_2 * mu1 - 9.0 * mu1 * mu2 + 27.0 * mu3) / 54.;
+    const double r = FAST ? -(2. * mu1_2 * mu1 - 9.0 * mu1 * mu2 + 27.0 * mu3) * (1. / 54.)
+                          : -(2. * mu1_2 * mu1 - 9.0 * mu1 * mu2 + 27.0 * mu3) / 54.;
     if (q * q * q < r * r || q < 0.0) {
       lam[0] = lam[1] = lam[2] = 0.0;
       return -10.0;
     }
     const double sq = 2 * sqrt(q);
-    const double t = acos(2 * r / q / sq);
+    const double t = FAST ? acos(2 * r / (q * sq)) : acos(2 * r / q / sq);
     const double inv_3 = 1.0 / 3.0;
     double c1, c2, c3;
     pf_cos3<FAST>(t, c1, c2, c3);

@@ -20,9 +20,7 @@
 // The solve is fp64-ALU bound and wants ILP (~165 VGPRs when inlined); the kernel is bounded to 3 waves
 // per SIMD (168 VGPRs), which matches the 3 workgroups per CU that the LDS rows allow.
 __device__ __forceinline__ double pf_solve_cell(double d0, double d1, double d2, double d3, double d4, double d5,
-                                                          const double *sx, const double *sy, const double *sc, int nk) {
-  pf_spline_view sv;
-  sv.x = sx; sv.y = sy; sv.c = sc; sv.n = nk;
+                                                 const pf_spline_view &sv) {
   const double d[6] = {d0, d1, d2, d3, d4, d5};
   double lam[3];
   return pf_inverse_collapse_time<false>(d, sv, lam);
@@ -45,17 +43,19 @@ __global__ void __launch_bounds__(PF_FUSED_THREADS, 3) k_zcollapse(const PfFused
   constexpr int M = GEO::M, NT = GEO::NT, G = GEO::G, L = GEO::L, ROUNDS = GEO::ROUNDS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   C *Hc = reinterpret_cast<C *>(smem);                                   // [6*L] rows of M+1 complex (half-spectrum in, N reals out)
-  double *sk = reinterpret_cast<double *>(smem + (size_t)6 * L * (M + 1) * sizeof(C));  // spline x,y,c : 3*nk
-  double *red = sk + 3 * p.spline.n;                                     // 2 * nwaves
+  double *sk = reinterpret_cast<double *>(smem + (size_t)6 * L * (M + 1) * sizeof(C));  // spline x,y,c,b,d : 5*nk
+  double *red = sk + 5 * p.spline.n;                                     // 2 * nwaves
   const int tid = threadIdx.x;
   const int nk = p.spline.n;
   for (int i = tid; i < nk; i += PF_FUSED_THREADS) {
     sk[i] = p.spline.x[i];
     sk[nk + i] = p.spline.y[i];
     sk[2 * nk + i] = p.spline.c[i];
+    sk[3 * nk + i] = p.spline.b[i];
+    sk[4 * nk + i] = p.spline.d[i];
   }
   pf_spline_view sv;
-  sv.x = sk; sv.y = sk + nk; sv.c = sk + 2 * nk; sv.n = nk;
+  sv.x = sk; sv.y = sk + nk; sv.c = sk + 2 * nk; sv.b = sk + 3 * nk; sv.d = sk + 4 * nk; sv.n = nk;
 
   const C *__restrict__ tw = reinterpret_cast<const C *>(p.tw);
   const int g = tid / NT, tl0 = tid % NT;
@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(PF_FUSED_THREADS, 3) k_zcollapse(const PfFused
       const double delta = d[0] + d[1] + d[2];
       sum += delta;
       sum2 += delta * delta;
-      const double Fnew = pf_solve_cell(d[0], d[1], d[2], d[3], d[4], d[5], sv.x, sv.y, sv.c, sv.n);
+      const double Fnew = pf_solve_cell(d[0], d[1], d[2], d[3], d[4], d[5], sv);
       const long long i = row * N + z;
       const float fold = p.ismooth ? p.fmax[i] : -10.0f;
       if ((double)fold < Fnew) {
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(PF_FUSED_THREADS, 3) k_zcollapse(const PfFused
 template <typename F, int N>
 static int launch_fused_n(const PfFusedParams &p, int blocks_per_cu, int ncu, hipStream_t st, int *nblocks_out) {
   using GEO = PfFusedGeom<F, N>;
-  const size_t shm = (size_t)6 * GEO::L * (N / 2 + 1) * sizeof(pfc<F>) + (size_t)3 * p.spline.n * sizeof(double) + 2 * (PF_FUSED_THREADS / 64) * sizeof(double);
+  const size_t shm = (size_t)6 * GEO::L * (N / 2 + 1) * sizeof(pfc<F>) + (size_t)5 * p.spline.n * sizeof(double) + 2 * (PF_FUSED_THREADS / 64) * sizeof(double);
   if (shm > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_zcollapse<F, N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return 3;
   }

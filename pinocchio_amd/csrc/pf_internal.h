@@ -74,7 +74,7 @@ int pf_launch_r2c(int field_bytes, int n, const PfR2CParams &p, hipStream_t st);
 
 // ---- per-cell kernels (pf_cell_kernels.hip) ----
 struct PfSplineDev {
-  const double *x, *y, *c;
+  const double *x, *y, *c, *b, *d;  // knots, GSL cspline c_i, and the per-interval b_i, d_i (pf_spline_bd)
   int n;
 };
 struct PfCollapseParams {
