@@ -89,11 +89,22 @@ PF_HD void pf_stage(pfc<F> (&v)[8], int tl, const pfc<F> *__restrict__ tw) {
     const int jb = tl + q * NT;
     const int k = jb & (NS - 1);
     if (NS > 1) {
-#pragma unroll
-      for (int t = 1; t < R; t++) {
-        pfc<F> w = tw[k * t * TWM];
-        if (DIR < 0) w.y = -w.y;
-        v[q + t * Q] = pf_cmul(v[q + t * Q], w);
+      // one table load per butterfly: w^2..w^(R-1) by products of depth <= 3 (error <= ~4 ulp, far inside the
+      // transform's own rounding) instead of R-1 dependent L1 loads
+      pfc<F> w1 = tw[k * TWM];
+      if (DIR < 0) w1.y = -w1.y;
+      v[q + 1 * Q] = pf_cmul(v[q + 1 * Q], w1);
+      if (R >= 4) {
+        const pfc<F> w2 = pf_cmul(w1, w1), w3 = pf_cmul(w2, w1);
+        v[q + 2 * Q] = pf_cmul(v[q + 2 * Q], w2);
+        v[q + 3 * Q] = pf_cmul(v[q + 3 * Q], w3);
+        if (R == 8) {
+          const pfc<F> w4 = pf_cmul(w2, w2), w5 = pf_cmul(w4, w1), w6 = pf_cmul(w3, w3), w7 = pf_cmul(w4, w3);
+          v[q + 4 * Q] = pf_cmul(v[q + 4 * Q], w4);
+          v[q + 5 * Q] = pf_cmul(v[q + 5 * Q], w5);
+          v[q + 6 * Q] = pf_cmul(v[q + 6 * Q], w6);
+          v[q + 7 * Q] = pf_cmul(v[q + 7 * Q], w7);
+        }
       }
     }
     if (R == 8) {

@@ -29,7 +29,7 @@ __device__ __forceinline__ long long pf_addr(const PfAddr &a, int outer, int e, 
 __device__ __forceinline__ long long pf_xcd_swizzle(long long b, long long per_xcd) { return (b & 7) * per_xcd + (b >> 3); }
 
 template <typename F, int N, int T, int DIR>
-__global__ void __launch_bounds__(T *N / 8) k_strided(const PfStridedParams p, const long long nwork, const int ntiles) {
+__global__ void __launch_bounds__(T *N / 8) __attribute__((amdgpu_waves_per_eu(4))) k_strided(const PfStridedParams p, const long long nwork, const int ntiles) {
   using C = pfc<F>;
   constexpr int NT = N / 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
