@@ -567,6 +567,7 @@ static int collapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], hipStream_
   p.pitch = 2 * c->nzp; p.nrows = (long long)c->nxl * c->n; p.n = c->n; p.fmax = c->fmax; p.rmax = c->rmax; p.ismooth = ismooth;
   if (spline_for(c, ismooth, &p.spline)) return 1;
   p.partials = c->partials; p.fast = c->fast_libm ? 1 : 0;
+  p.wpe = getenv("PF_COLLAPSE_WPE") ? atoi(getenv("PF_COLLAPSE_WPE")) : 0;
   size_t nb = (ncell(c) + 255) / 256; if (nb > (size_t)c->collapse_blocks) nb = c->collapse_blocks;
   p.nblocks = (int)nb;
   {

@@ -27,7 +27,7 @@ __device__ __forceinline__ void pf_block_sum2(double &a, double &b, double *sh /
 
 // K6: one thread per cell, grid-stride.  fp64 math whatever the field precision.
 template <typename F, bool FAST>
-__global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse(const PfCollapseParams p) {
+__device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
   __shared__ double sk[5 * PF_MAX_KNOTS];
   __shared__ double red[2 * (PF_CELL_BLOCK / 64)];
   const int nk = p.spline.n;
@@ -73,6 +73,14 @@ __global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse(const PfCollapsePara
     p.partials[2 * blockIdx.x + 1] = sum2;
   }
 }
+
+template <typename F, bool FAST>
+__global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse(const PfCollapseParams p) { pf_collapse_body<F, FAST>(p); }
+// occupancy experiments (PF_COLLAPSE_WPE): the same body under a register cap
+template <typename F, bool FAST>
+__global__ void __launch_bounds__(PF_CELL_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) k_collapse_w4(const PfCollapseParams p) { pf_collapse_body<F, FAST>(p); }
+template <typename F, bool FAST>
+__global__ void __launch_bounds__(PF_CELL_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) k_collapse_w5(const PfCollapseParams p) { pf_collapse_body<F, FAST>(p); }
 
 // one wave, fixed association order: bitwise reproducible for a given launch geometry
 __global__ void k_final_sum2(const double *partials, int nblocks, double *out2) {
@@ -259,6 +267,8 @@ static inline int pf_grid_for(size_t n, int cap = 256 * 8) {
 
 int pf_launch_collapse(int fb, const PfCollapseParams &p, hipStream_t st) {
   if (p.spline.n > PF_MAX_KNOTS) return 2;
+  if (fb == 8 && p.fast && p.wpe == 4) { hipLaunchKernelGGL((k_collapse_w4<double, true>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p); return PF_CHECK_LAUNCH(); }
+  if (fb == 8 && p.fast && p.wpe == 5) { hipLaunchKernelGGL((k_collapse_w5<double, true>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p); return PF_CHECK_LAUNCH(); }
   if (fb == 8) {
     if (p.fast) hipLaunchKernelGGL((k_collapse<double, true>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
     else hipLaunchKernelGGL((k_collapse<double, false>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);

@@ -89,6 +89,7 @@ struct PfCollapseParams {
   double *partials;     // [2*nblocks]: sum delta, sum delta^2 per block
   int nblocks;
   int fast;             // 1: sincos/cbrt/exp10 forms of the transcendental hot spots (pf_collapse_core.h)
+  int wpe;              // occupancy experiment: 0 default, 4 / 5 = register-capped builds
 };
 int pf_launch_collapse(int field_bytes, const PfCollapseParams &p, hipStream_t st);
 int pf_launch_final_sum(const double *partials, int nblocks, double *out2, hipStream_t st);
