@@ -156,6 +156,15 @@ def main():
         value = cells * args.steps / dt
         dom = max((s for s in stats if s["name"] != "exchange"), key=lambda s: s["total_ms"])
         ach = dom["alg_bytes"] / (dom["total_ms"] * 1e-3) / 1e9
+        traffic = None  # HBM bytes per launch from the PMC counters (rocprofv3 passes, profiles/*_pmc_traffic.json)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                pmc = json.load(fh)
+            if pmc["config"] == {"grid": n, "field_bytes": args.field_bytes} and dom["name"] in pmc["kernels"]:
+                k = pmc["kernels"][dom["name"]]
+                traffic = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         w = args.field_bytes
         out = {
             "metric": "grid-cells/sec for full Fmax sweep (all smoothing radii) + 3LPT, 1024^3 box"
@@ -168,7 +177,8 @@ def main():
                        "grid": n, "nsmooth": ns, "lpt": lpt, "parallelism": f"x-slabs over {world} GPU(s)" + (f", all-to-all via {exchange_kind}" if exchange_kind else ""),
                        "device_GB": f.device_bytes / 1e9, "sigma_R0": float(np.sqrt(tv[-1]))},
             "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "note": "collapse is fp64-VALU bound (~800 instructions per cell); its HBM stream is a consequence, see DESIGN.md section 6",
                          "launches": dom["launches"], "avg_ms": dom["total_ms"] / dom["launches"],
                          "alg_bytes_per_launch": dom["alg_bytes"] / dom["launches"]},
             "path_roofline": {"contract_bytes_per_cell": alg_bytes_per_cell(ns, w, lpt),
