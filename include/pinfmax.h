@@ -106,6 +106,20 @@ int pf_set_density(pf_ctx *ctx, const double *kdensity_slab);
    Nyquist planes zero, sigma(R=0) = sigma0.  numpy mirror:
    pinocchio_amd/synth.py philox_density. */
 int pf_synth_density(pf_ctx *ctx, uint64_t seed, double sigma0, double slope);
+/* GenIC_large (src/GenIC.c:73-460) on the device: PINOCCHIO's own Gaussian initial conditions generated straight
+   into HBM -- one gsl_rng_ranlxd1 stream per (kx,ky) column seeded from the MT19937 seed plane along the spiral
+   (src/GenIC.c:840-990), Eisenstein & Hu P(k) (src/cosmo.c:1443-1497) times PkNorm, Hermitian kz = 0 plane, Nyquist
+   planes and DC zero, final factor N^3.  Replaces GenIC + pf_set_density (no host array, no 8.6 GB upload at 1024^3);
+   every rank generates its own k-space slab.  BoxSize in true Mpc (params.BoxSize_htrue), PkNorm as printed by
+   normalize_PowerSpectrum (src/cosmo.c:1058-1075) or from pf_pk_norm (sigma8^2 / top-hat variance at 8/h Mpc). */
+typedef struct {
+  double Omega0, OmegaBaryon, Hubble100, PrimordialIndex;
+  double BoxSize_true_Mpc;
+  double PkNorm;
+  unsigned int RandomSeed;
+} pf_genic_params;
+int pf_pk_norm(const pf_genic_params *p, double sigma8, double *pknorm);
+int pf_genic_density(pf_ctx *ctx, const pf_genic_params *p);
 /* SPLINE[SP_INVGROW] knots (src/cosmo.c:401): x = log10 D, y = log10 a, n knots
    (natural cubic spline coefficients are computed on the host, GSL cspline).
    ismooth = -1: one spline for every radius (non SCALE_DEPENDENT build);

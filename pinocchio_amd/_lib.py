@@ -26,6 +26,12 @@ class ProductLayout(C.Structure):
                 ("off_Vel_2LPT", C.c_int), ("off_Vel_3LPT_1", C.c_int), ("off_Vel_3LPT_2", C.c_int)]
 
 
+class GenicParams(C.Structure):
+    _fields_ = [("Omega0", C.c_double), ("OmegaBaryon", C.c_double), ("Hubble100", C.c_double),
+                ("PrimordialIndex", C.c_double), ("BoxSize_true_Mpc", C.c_double), ("PkNorm", C.c_double),
+                ("RandomSeed", C.c_uint)]
+
+
 class CpuTime(C.Structure):
     _fields_ = [("fmax", C.c_double), ("deriv", C.c_double), ("fft", C.c_double), ("coll", C.c_double),
                 ("lpt", C.c_double), ("mem_transf", C.c_double)]
@@ -59,6 +65,8 @@ PROTOTYPES = {
     "pf_get_stream": (_vp, [_vp]),
     "pf_set_density": (C.c_int, [_vp, _dp]),
     "pf_synth_density": (C.c_int, [_vp, C.c_uint64, C.c_double, C.c_double]),
+    "pf_pk_norm": (C.c_int, [C.POINTER(GenicParams), C.c_double, _dp]),
+    "pf_genic_density": (C.c_int, [_vp, C.POINTER(GenicParams)]),
     "pf_set_invgrow": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int]),
     "pf_set_growth": (C.c_int, [_vp, _dp]),
     "pf_sweep": (C.c_int, [_vp, C.c_int, _dp, _dp]),

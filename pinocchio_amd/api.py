@@ -81,6 +81,18 @@ class Fmax:
     def synth_density(self, seed: int, sigma0: float = 2.5, slope: float = -2.0):
         self._chk(self.L.pf_synth_density(self.h, C.c_uint64(seed), sigma0, slope))
 
+    def genic_density(self, seed: int, box_true_mpc: float, omega0: float, omega_baryon: float, hubble100: float,
+                      primordial_index: float, sigma8: float = 0.0, pknorm: float = 0.0) -> float:
+        """GenIC_large (src/GenIC.c:73) on the device.  Give PkNorm, or sigma8 to have it computed
+        (normalize_PowerSpectrum, src/cosmo.c:1058).  Returns the PkNorm used."""
+        p = _lib.GenicParams(omega0, omega_baryon, hubble100, primordial_index, box_true_mpc, pknorm, seed)
+        if pknorm <= 0.0:
+            v = C.c_double()
+            self._chk(self.L.pf_pk_norm(C.byref(p), sigma8, C.byref(v)))
+            p.PkNorm = v.value
+        self._chk(self.L.pf_genic_density(self.h, C.byref(p)))
+        return p.PkNorm
+
     def set_invgrow(self, x, y, ismooth: int = -1):
         x = np.ascontiguousarray(x, dtype=np.float64)
         y = np.ascontiguousarray(y, dtype=np.float64)

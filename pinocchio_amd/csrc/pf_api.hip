@@ -520,6 +520,22 @@ extern "C" int pf_synth_density(pf_ctx *c, uint64_t seed, double sigma0, double 
   return 0;
 }
 
+extern "C" int pf_genic_density(pf_ctx *c, const pf_genic_params *p) {
+  if (!c || !p) return pf_fail(0, "pf_genic_density: null argument");
+  if (!(p->BoxSize_true_Mpc > 0) || !(p->PkNorm > 0) || !(p->Omega0 > 0) || !(p->Hubble100 > 0))
+    return pf_fail(c->rank, "pf_genic_density: BoxSize, PkNorm, Omega0 and Hubble100 must be positive");
+  unsigned int *dseed = nullptr;
+  if (pf_genic_launch(c->fb, c->dk, c->n, c->nzp, c->nyl, c->rank * c->nyl, p, c->stream, &dseed)) {
+    hipFree(dseed);
+    return pf_fail(c->rank, "pf_genic_density: launch failed");
+  }
+  HIPCHK(c, hipMemsetAsync(c->scal + SC_DC_DK, 0, sizeof(double), c->stream));  // the DC mode is left at zero
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  hipFree(dseed);
+  c->have_density = true; c->have_hessian = false; c->have_sources = false;
+  return 0;
+}
+
 extern "C" int pf_set_invgrow(pf_ctx *c, int ismooth, const double *x, const double *y, int n) {
   if (!c || !x || !y) return pf_fail(0, "pf_set_invgrow: null argument");
   if (n < 3 || n > PF_KNOT_CAP) return pf_fail(c->rank, "pf_set_invgrow: %d knots not in [3, %d]", n, PF_KNOT_CAP);

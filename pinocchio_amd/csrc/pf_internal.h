@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "../../include/pinfmax.h"
+
 #define PF_MAX_JOBS 6
 
 // multiplier applied along the transformed axis before the 1-D transform
@@ -164,3 +166,7 @@ struct PfShapeParams {
 };
 int pf_launch_shape(int field_bytes, const PfShapeParams &p, hipStream_t st);
 int pf_launch_sigma_scale(const double *power_sum, double sigma0, double n3, double *dscale, hipStream_t st);
+
+// ---- GenIC on the device (pf_genic.hip) ----
+int pf_genic_launch(int field_bytes, void *dk, int n, int nzp, int nyl, int y0, const pf_genic_params *p, hipStream_t st,
+                    unsigned int **seed_dev_out);

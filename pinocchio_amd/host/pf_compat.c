@@ -17,6 +17,7 @@
  *   int  Fmax_PDF(void)                      fmax.c:509           pf_fmax_pdf + the same ASCII file
  *   int  dump_products(void), read_dumps()   fmax.c:372,429       same files, same checks
  *   char *fdate(void)                        fmax.c:261           same string
+ *   (optional) int pf_compat_genic(double)   GenIC.c:73           GenIC_large on the device instead of the host
  *
  * Build modes: stand-alone (default; globals from pf_compat_types.h, defined in
  * pf_compat_globals.c) or -DPF_IN_PINOCCHIO_TREE inside the reference source
@@ -53,6 +54,7 @@
 #include "../../include/pinfmax.h"
 
 static pf_ctx *pf_context = NULL;
+static int pf_density_on_device = 0; /* set by pf_compat_genic: kdensity[0] is not uploaded */
 static int pf_device_of_rank = -1; /* -1: rank % visible devices */
 
 /* lets a launcher pin ranks to devices before compute_fft_plans (e.g. from SLURM_LOCALID) */
@@ -137,14 +139,34 @@ int finalize_fft(void) {
   if (pf_context) {
     pf_destroy(pf_context);
     pf_context = NULL;
+    pf_density_on_device = 0;
   }
 #endif
   return 0;
 }
 
+/* Optional replacement of GenIC_large(0) (src/GenIC.c:73, called from src/initialization.c:461): the same
+   realisation (spiral seed table, ranlxd1 streams, E&H spectrum) generated in HBM; kdensity[0] is then neither
+   filled nor uploaded.  PkNorm: the constant of src/cosmo.c:1058-1072 (static there; the value it prints), or
+   <= 0 to have it integrated here from params.Sigma8. */
+int pf_compat_genic(double PkNorm) {
+  pf_genic_params g;
+  if (!pf_context && compute_fft_plans()) return 1;
+  memset(&g, 0, sizeof(g));
+  g.Omega0 = params.Omega0; g.OmegaBaryon = params.OmegaBaryon; g.Hubble100 = params.Hubble100;
+  g.PrimordialIndex = params.PrimordialIndex; g.BoxSize_true_Mpc = params.BoxSize_htrue;
+  g.RandomSeed = (unsigned int)params.RandomSeed;
+  g.PkNorm = PkNorm;
+  if (PkNorm <= 0.0 && pf_pk_norm(&g, params.Sigma8, &g.PkNorm)) return 1;
+  if (!ThisTask) printf("[%s] Generating the linear density field on the device, PkNorm=%g\n", fdate(), g.PkNorm);
+  if (pf_genic_density(pf_context, &g)) return 1;
+  pf_density_on_device = 1;
+  return 0;
+}
+
 static int pf_upload_inputs(void) {
   if (!pf_context && compute_fft_plans()) return 1;
-  if (pf_set_density(pf_context, kdensity[0])) return 1;
+  if (!pf_density_on_device && pf_set_density(pf_context, kdensity[0])) return 1;
   if (pf_set_invgrow(pf_context, -1, PF_KNOTS_X, PF_KNOTS_Y, PF_KNOTS_N)) return 1;
   return 0;
 }

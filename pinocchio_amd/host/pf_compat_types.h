@@ -67,6 +67,7 @@ typedef struct /* the tags of param_data (:311-352) the path uses */
 {
   char RunFlag[SBLENGTH], DumpDir[SBLENGTH];
   int GridSize[3], RandomSeed;
+  double Omega0, OmegaBaryon, Hubble100, Sigma8, PrimordialIndex, BoxSize_htrue; /* read by pf_compat_genic only */
 } param_data;
 
 /* gsl_spline as far as my_spline_eval dereferences it (src/cosmo.c:2016-2027) */

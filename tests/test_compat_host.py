@@ -37,7 +37,9 @@ class ScaleDep(C.Structure):
 
 
 class Params(C.Structure):
-    _fields_ = [("RunFlag", C.c_char * 100), ("DumpDir", C.c_char * 100), ("GridSize", C.c_int * 3), ("RandomSeed", C.c_int)]
+    _fields_ = [("RunFlag", C.c_char * 100), ("DumpDir", C.c_char * 100), ("GridSize", C.c_int * 3), ("RandomSeed", C.c_int),
+                ("Omega0", C.c_double), ("OmegaBaryon", C.c_double), ("Hubble100", C.c_double), ("Sigma8", C.c_double),
+                ("PrimordialIndex", C.c_double), ("BoxSize_htrue", C.c_double)]
 
 
 class Knots(C.Structure):
@@ -149,3 +151,74 @@ def test_compute_fmax_like_the_reference_driver(lib, tmp_path):
     tv[:] = 0
     assert lib.read_dumps() == 0
     assert np.array_equal(dumped, prod) and np.allclose(tv, tv_o, rtol=1e-12)
+
+
+@pytest.mark.gpu
+def test_genic_on_device_through_the_reference_driver(lib, tmp_path):
+    """GenIC_large replaced by pf_compat_genic: no kdensity[0] on the host at all; same sigma and Fmax as the oracle
+    fed with the restated generator's field"""
+    import json
+    import ic_oracle
+    with open(os.path.join(ROOT, "tests", "golden", "hmf_validation_kat.json")) as fh:
+        kp = json.load(fh)["params"]
+    n, seed, pkn = 32, 486604, 2.0e7
+    box = n * 2.0 / kp["Hubble100"]                # true Mpc
+    cell = box / n
+    radii_mpc = np.array([3.0 * cell, 1.5 * cell, 0.0])
+    x, y = ic_oracle.growth_table_lcdm(kp["Omega0"])
+    g = synth.growth_multipliers()
+
+    grid = C.cast(C.c_void_p.in_dll(lib, "MyGrids"), C.POINTER(Grid)).contents
+    for i in range(3):
+        grid.GSglobal[i] = n
+    grid.Ntotal = n ** 3
+    grid.BoxSize = box
+    assert lib.set_one_grid(0) == 0
+    prod = np.zeros(n ** 3 * 56 + 64, dtype=np.uint8)
+    prod = prod[(-prod.ctypes.data) % 32:][:n ** 3 * 56]
+    C.c_void_p.in_dll(lib, "products").value = prod.ctypes.data
+    kd = C.cast(C.c_void_p.in_dll(lib, "kdensity"), C.POINTER(C.c_void_p))
+    kd[0] = None                                   # would fault if the adapter touched it
+    sm = Smoothing.in_dll(lib, "Smoothing")
+    tv = np.zeros(len(radii_mpc)); var = np.ones(len(radii_mpc))
+    sm.Nsmooth = len(radii_mpc)
+    sm.Radius = radii_mpc.ctypes.data_as(C.POINTER(C.c_double))
+    sm.Variance = var.ctypes.data_as(C.POINTER(C.c_double))
+    sm.TrueVariance = tv.ctypes.data_as(C.POINTER(C.c_double))
+    sd = ScaleDep.in_dll(lib, "ScaleDep")
+    sd.nseg = 1
+    sd.z[0] = 0.0
+    kn = Knots.in_dll(lib, "pf_invgrow_knots")
+    kn.size = len(x)
+    kn.x = x.ctypes.data_as(C.POINTER(C.c_double))
+    kn.y = y.ctypes.data_as(C.POINTER(C.c_double))
+    fns = [GROWTH_FN(lambda z, k, v=v: float(v)) for v in g]
+    for name, fn in zip(("pf_GrowingMode", "pf_GrowingMode_2LPT", "pf_GrowingMode_3LPT_1", "pf_GrowingMode_3LPT_2"), fns):
+        C.c_void_p.in_dll(lib, name).value = C.cast(fn, C.c_void_p).value
+    par = Params.in_dll(lib, "params")
+    par.RunFlag = b"pfgenic"
+    par.GridSize[0] = par.GridSize[1] = par.GridSize[2] = n
+    par.RandomSeed = seed
+    par.Omega0, par.OmegaBaryon, par.Hubble100 = kp["Omega0"], kp["OmegaBaryon"], kp["Hubble100"]
+    par.Sigma8, par.PrimordialIndex, par.BoxSize_htrue = kp["Sigma8"], kp["PrimordialIndex"], box
+
+    lib.pf_compat_genic.argtypes = [C.c_double]
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        assert lib.compute_fft_plans() == 0
+        assert lib.pf_compat_genic(pkn) == 0
+        assert lib.compute_fmax() == 0
+    finally:
+        os.chdir(cwd)
+    p = prod.view(oracle_lib.PRODUCT_DTYPE).reshape(n, n, n)
+
+    dk = ic_oracle.genic(n, box, seed, pkn, kp)
+    o = oracle_lib.Oracle(n, 0)
+    o.set_density(dk); o.set_invgrow(x, y); o.set_growth(g)
+    tv_o = o.compute_fmax(radii_mpc / cell, do_lpt=True)
+    po = o.products()
+    assert tv_o[-1] > 0 and np.allclose(tv, tv_o, rtol=1e-11)
+    ulp = np.spacing(np.maximum(np.abs(po["Fmax"]), 1.0).astype(np.float32)).astype(np.float64)
+    assert np.mean(np.abs(p["Fmax"].astype(np.float64) - po["Fmax"]) > 2 * ulp) < 1e-4
+    assert np.max(np.abs(p["Vel"].astype(np.float64) - po["Vel"])) <= 4e-7 * np.max(np.abs(po["Vel"]))

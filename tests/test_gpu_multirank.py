@@ -205,3 +205,28 @@ def test_torch_exchange_single_rank():
     """bench.py's two exchange kinds after torch.distributed (backend nccl = RCCL) is up: `torch` = collectives on
     tensors aliasing the library's device buffers on the library's stream, `rccl` = the built-in exchange"""
     _run_isolated(_TORCH_CODE, "TORCH_OK")
+
+
+def test_genic_slabs_match_single_rank(api):
+    """every rank generates its own k-space slab of the reference's initial conditions: same field as one rank"""
+    n, P = 64, 4
+    args = (486604, 64 / 0.7, 0.25, 0.044, 0.7, 0.96)
+    radii = np.array([2.0, 0.0])
+    x, y = synth.invgrow_table("lcdm")
+
+    def body(f, r):
+        f.genic_density(*args, pknorm=2.0e7)
+        f.set_invgrow(x, y)
+        tv = f.sweep(radii)
+        return tv, f.products()["Fmax"]
+
+    with api.Fmax(n) as f1:
+        f1.genic_density(*args, pknorm=2.0e7)
+        f1.set_invgrow(x, y)
+        tv1 = f1.sweep(radii)
+        fm1 = f1.products()["Fmax"]
+    res = run_ranks(api, n, P, body)
+    nxl = n // P
+    for r in range(P):
+        assert np.allclose(res[r][0], tv1, rtol=1e-13)
+        assert np.array_equal(res[r][1], fm1[r * nxl:(r + 1) * nxl])

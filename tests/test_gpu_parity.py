@@ -376,3 +376,46 @@ def test_hmf_validation_run_on_gpu(api):
     want = np.array(kat["FmaxPDF"], dtype=np.int64)
     assert abs(int(pdf[10:].sum()) - kat["collapsed"]) <= 5
     assert np.abs(pdf - want).sum() <= 200 and np.max(np.abs(pdf - want)) <= 20
+
+
+def test_genic_on_device_vs_oracle(api):
+    """pf_genic_density (GenIC_large on the device) against the restated CPU generator, same seed and cosmology"""
+    import ic_oracle
+    with open(os.path.join(GOLD, "hmf_validation_kat.json")) as fh:
+        p = json.load(fh)["params"]
+    for n, seed in ((32, 7), (64, p["RandomSeed"])):
+        box = float(n) / p["Hubble100"]
+        pkn = 1.7e7
+        want = ic_oracle.genic(n, box, seed, pkn, p)
+        with api.Fmax(n) as f:
+            f.genic_density(seed, box, p["Omega0"], p["OmegaBaryon"], p["Hubble100"], p["PrimordialIndex"], pknorm=pkn)
+            got = f.density()
+        assert np.count_nonzero(want) > n ** 3 // 8
+        assert np.array_equal(got == 0, want == 0)                       # same blind points and Nyquist planes
+        assert np.max(np.abs(got - want)) <= 1e-12 * np.max(np.abs(want))  # device libm vs glibc in log/cos/sin/pow
+
+
+def test_hmf_validation_run_entirely_on_device(api):
+    """seed + cosmology -> pf_genic_density -> pf_sweep -> Fmax PDF, nothing but parameters from the host: the
+    reference's committed validation numbers again (sigma per radius, collapsed count, histogram)"""
+    import ic_oracle
+    with open(os.path.join(GOLD, "hmf_validation_kat.json")) as fh:
+        kat = json.load(fh)
+    p = kat["params"]
+    n = p["GridSize"]
+    box = p["BoxSize_h100"] / p["Hubble100"]
+    x, y = ic_oracle.growth_table_lcdm(p["Omega0"])
+    radii_cells = np.array(kat["radii_Mpc"]) / (box / n)
+    with api.Fmax(n) as f:
+        f.genic_density(p["RandomSeed"], box, p["Omega0"], p["OmegaBaryon"], p["Hubble100"], p["PrimordialIndex"],
+                        pknorm=kat["PkNorm"])
+        f.set_invgrow(x, y)
+        tv = f.sweep(radii_cells)
+        pdf = f.Fmax_PDF().astype(np.int64)
+        # the library's own normalisation (Gauss-Legendre to 1e-10; the reference's QAGS runs at 1e-4)
+        assert f.genic_density(p["RandomSeed"], box, p["Omega0"], p["OmegaBaryon"], p["Hubble100"], p["PrimordialIndex"],
+                               sigma8=p["Sigma8"]) == pytest.approx(kat["PkNorm"], rel=1e-5)
+    assert np.all(np.abs(np.sqrt(tv) - np.array(kat["computed_sigma"])) <= 6e-5)
+    want = np.array(kat["FmaxPDF"], dtype=np.int64)
+    assert abs(int(pdf[10:].sum()) - kat["collapsed"]) <= 5
+    assert np.abs(pdf - want).sum() <= 200
