@@ -86,6 +86,13 @@ struct pf_ctx {
   char *blockA;        // A[0..2] contiguous (also host<->device staging through A[1..2])
   void *dk, *A[3], *B[6], *B2[6], *S[3];
   void *recvA;         // P > 1: 3 fields, all-to-all destination
+  // P > 1: second set of send/receive fields and a communication stream, so that the all-to-all of transform i+1
+  // runs beside the y/z passes (and the collapse solve) of transform i (pipelined(), PF_PIPELINE=0 to disable)
+  bool pipeline;
+  hipStream_t cstream;
+  char *blockA2;
+  void *recvA2;
+  hipEvent_t ev_x[2], ev_r[2];
   void *tw;
   float *fmax, *vel12;
   int *rmax;
@@ -135,6 +142,7 @@ struct PhaseTimer {
 static void resolve_events(pf_ctx *c) {
   hipStreamSynchronize(c->stream);
   hipStreamSynchronize(c->stream2);
+  hipStreamSynchronize(c->cstream);
   for (auto &e : c->evs) {
     float ms = 0; hipEventElapsedTime(&ms, e.a, e.b);
     c->ks_ms[e.kind] += ms; c->ks_bytes[e.kind] += e.bytes; c->ks_n[e.kind]++;
@@ -190,14 +198,19 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   c->growth[0] = 1.0; c->growth[1] = 3. / 7.; c->growth[2] = -1. / 9.; c->growth[3] = 5. / 42.;
   for (int i = 0; i < 6; i++) { c->B[i] = nullptr; c->B2[i] = nullptr; }
   c->blockA = nullptr; c->dk = nullptr; c->recvA = nullptr; c->tw = nullptr;
+  c->blockA2 = nullptr; c->recvA2 = nullptr; c->cstream = nullptr;
+  c->pipeline = c->P > 1 && !(getenv("PF_PIPELINE") && !atoi(getenv("PF_PIPELINE")));
   for (int i = 0; i < 3; i++) { c->A[i] = nullptr; c->S[i] = nullptr; }
 
   HIPCHK(c, hipSetDevice(cfg->device));
   HIPCHK(c, hipStreamCreate(&c->stream));
   HIPCHK(c, hipStreamCreate(&c->stream2));
+  HIPCHK(c, hipStreamCreate(&c->cstream));
   for (int i = 0; i < 2; i++) {
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_h[i], hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_c[i], hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_x[i], hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_r[i], hipEventDisableTiming));
   }
   {
     // the collapse solve is fp64-ALU bound and runs beside the HBM-bound passes of the next radius:
@@ -233,6 +246,10 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   for (int i = 0; i < 6; i++) PFCHK(c, dev_alloc(c, &c->B[i], c->field_bytes));
   for (int i = 0; i < 3; i++) PFCHK(c, dev_alloc(c, &c->S[i], c->field_bytes));
   if (c->P > 1) PFCHK(c, dev_alloc(c, &c->recvA, 3 * c->field_bytes));
+  if (c->pipeline) {
+    PFCHK(c, dev_alloc(c, (void **)&c->blockA2, 3 * c->field_bytes));
+    PFCHK(c, dev_alloc(c, &c->recvA2, 3 * c->field_bytes));
+  }
   const size_t nc = ncell(c);
   PFCHK(c, dev_alloc(c, (void **)&c->fmax, nc * sizeof(float)));
   PFCHK(c, dev_alloc(c, (void **)&c->rmax, nc * sizeof(int)));
@@ -263,7 +280,8 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
 extern "C" int pf_destroy(pf_ctx *c) {
   if (!c) return 0;
   hipStreamSynchronize(c->stream);
-  hipFree(c->dk); hipFree(c->blockA); hipFree(c->recvA); hipFree(c->tw);
+  hipStreamSynchronize(c->stream2); hipStreamSynchronize(c->cstream);
+  hipFree(c->dk); hipFree(c->blockA); hipFree(c->recvA); hipFree(c->tw); hipFree(c->blockA2); hipFree(c->recvA2);
   for (int i = 0; i < 6; i++) { hipFree(c->B[i]); hipFree(c->B2[i]); }
   for (int i = 0; i < 3; i++) hipFree(c->S[i]);
   hipFree(c->fmax); hipFree(c->rmax); hipFree(c->vel12); hipFree(c->partials); hipFree(c->scal); hipFree(c->hist); hipFree(c->spl);
@@ -272,7 +290,8 @@ extern "C" int pf_destroy(pf_ctx *c) {
   for (auto e : c->evpool) hipEventDestroy(e);
   if (c->own_stream) hipStreamDestroy(c->stream);
   hipStreamDestroy(c->stream2);
-  for (int i = 0; i < 2; i++) { hipEventDestroy(c->ev_h[i]); hipEventDestroy(c->ev_c[i]); }
+  hipStreamDestroy(c->cstream);
+  for (int i = 0; i < 2; i++) { hipEventDestroy(c->ev_h[i]); hipEventDestroy(c->ev_c[i]); hipEventDestroy(c->ev_x[i]); hipEventDestroy(c->ev_r[i]); }
   delete c;
   return 0;
 }
@@ -285,7 +304,10 @@ extern "C" int pf_set_stream(pf_ctx *c, void *stream) {
   return 0;
 }
 extern "C" void *pf_get_stream(pf_ctx *c) { return c ? (void *)c->stream : nullptr; }
-extern "C" int pf_synchronize(pf_ctx *c) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2)); return 0; }
+extern "C" int pf_synchronize(pf_ctx *c) {
+  HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2)); HIPCHK(c, hipStreamSynchronize(c->cstream));
+  return 0;
+}
 extern "C" size_t pf_device_bytes(pf_ctx *c) { return c ? c->dev_bytes : 0; }
 
 extern "C" int pf_set_exchange(pf_ctx *c, pf_alltoall_fn fn, void *user) { c->a2a = fn; c->a2a_user = user; return 0; }
@@ -298,11 +320,12 @@ extern "C" int pf_exchange_buffers(pf_ctx *c, void **sendbuf, void **recvbuf, si
 }
 
 // all-to-all of one field (KY block q <-> XS block p); a no-op on one rank
-static int exchange(pf_ctx *c, const void *send, void *recv) {
+static int exchange(pf_ctx *c, const void *send, void *recv, hipStream_t st = nullptr) {
   if (c->P == 1) return 0;
   if (!c->a2a) return pf_fail(c->rank, "no exchange installed for %d ranks (pf_set_exchange / pf_init_rccl)", c->P);
-  KTimer t(c, KS_EXCHANGE, (double)c->field_bytes);
-  if (c->a2a(c->a2a_user, send, recv, c->field_bytes / c->P, (void *)c->stream)) return pf_fail(c->rank, "all-to-all failed");
+  if (!st) st = c->stream;
+  KTimer t(c, KS_EXCHANGE, (double)c->field_bytes, st);
+  if (c->a2a(c->a2a_user, send, recv, c->field_bytes / c->P, (void *)st)) return pf_fail(c->rank, "all-to-all failed");
   return 0;
 }
 static int allreduce_dev(pf_ctx *c, void *buf, size_t count, int is_u64) {
@@ -381,27 +404,67 @@ static int zpass_c2r(pf_ctx *c, int kind, int njobs, const ZJob *jobs, const dou
   return 0;
 }
 
+// ---- software pipeline over transforms that share the exchange buffers ----
+// pre(i, A) fills the send fields A[0..nf-1] (x-pass side, compute stream); the all-to-all moves field f to
+// dst(i, set, f); post(i, R) consumes R[0..nf-1] (compute stream).  P = 1: R = A, no exchange.  P > 1 with the
+// pipeline on: two buffer sets; the exchange of item i+1 is enqueued on the communication stream before post(i), so
+// the wire time hides behind the y/z passes and the collapse solve of item i ("overlap transposes of
+// field i with passes of field i+-1").  Hazards: pre(i) reuses the send set of item i-2, whose exchange post(i-2)
+// waited for; exchange(i) overwrites the receive set of item i-2 after ev_x(i), recorded behind post(i-2).
+template <class Pre, class Dst, class Post>
+static int pipelined(pf_ctx *c, int count, int nf, Pre pre, Dst dst, Post post) {
+  void *A[2][3];
+  const void *R[3];
+  for (int f = 0; f < 3; f++) { A[0][f] = c->A[f]; A[1][f] = c->pipeline ? (void *)(c->blockA2 + f * c->field_bytes) : c->A[f]; }
+  if (c->P == 1 || !c->pipeline) {
+    for (int i = 0; i < count; i++) {
+      if (pre(i, A[0])) return 1;
+      for (int f = 0; f < nf; f++) {
+        R[f] = A[0][f];
+        if (c->P > 1) { void *d = dst(i, 0, f); PFCHK(c, exchange(c, A[0][f], d)); R[f] = d; }
+      }
+      if (post(i, R)) return 1;
+    }
+    return 0;
+  }
+  auto issue = [&](int i) -> int {
+    const int s = i & 1;
+    if (pre(i, A[s])) return 1;
+    HIPCHK(c, hipEventRecord(c->ev_x[s], c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->cstream, c->ev_x[s], 0));
+    for (int f = 0; f < nf; f++) PFCHK(c, exchange(c, A[s][f], dst(i, s, f), c->cstream));
+    HIPCHK(c, hipEventRecord(c->ev_r[s], c->cstream));
+    return 0;
+  };
+  if (issue(0)) return 1;
+  for (int i = 0; i < count; i++) {
+    if (i + 1 < count && issue(i + 1)) return 1;
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_r[i & 1], 0));
+    for (int f = 0; f < nf; f++) R[f] = dst(i, i & 1, f);
+    if (post(i, R)) return 1;
+  }
+  return 0;
+}
+static void *recv_field(pf_ctx *c, int set, int f) { return (char *)(set ? c->recvA2 : c->recvA) + (size_t)f * c->field_bytes; }
+
 // six second derivatives of `spec` (KY layout) at smoothing rs -> six real fields out[0..5] (R layout)
 // order 11,22,33,12,13,23 (src/LPT.c:36-44); compute_second_derivatives, src/fmax.c:225-258
-static int hessian_of(pf_ctx *c, const void *spec, double rs, const double *dc, void *const out[6], bool xy_only = false) {
-  // Gaussian window exp(-k^2 rs^2/2) < prune_eps (2^-60) beyond |k| = sqrt(-2 ln eps)/rs: those modes are dropped
-  // (pruned FFT).  Their total contribution is < 2^-56 of the unsmoothed rms: below the rounding of the transform.
+// Gaussian window exp(-k^2 rs^2/2) < prune_eps (2^-60) beyond |k| = sqrt(-2 ln eps)/rs: those modes are dropped
+// (pruned FFT).  Their total contribution is < 2^-56 of the unsmoothed rms: below the rounding of the transform.
+static int hess_band(const pf_ctx *c, double rs, bool xy_only) {
   int band = 1 << 30;
   if (rs > 0.0 && c->prune_eps > 0.0 && !xy_only) {  // (the experimental fused z-pass reads full rows)
     const double kc = sqrt(-2.0 * log(c->prune_eps)) / rs;
     const double kb = kc * c->n / (2.0 * 3.14159265358979323846);
     if (kb < c->n / 2 - 1) band = (int)kb + 1;
   }
-  const Job xj[3] = {{spec, c->A[0], PF_MUL_ONE}, {spec, c->A[1], PF_MUL_K}, {spec, c->A[2], PF_MUL_K2}};
-  PFCHK(c, xpass(c, KS_XPASS_HESS, +1, 3, xj, 1, rs, 1.0, 1, band));
-  const void *R[3] = {c->A[0], c->A[1], c->A[2]};
-  if (c->P > 1) {
-    for (int f = 0; f < 3; f++) {
-      void *r = (char *)c->recvA + f * c->field_bytes;
-      PFCHK(c, exchange(c, c->A[f], r));
-      R[f] = r;
-    }
-  }
+  return band;
+}
+static int hess_x(pf_ctx *c, const void *spec, double rs, void *const A[3], int band) {
+  const Job xj[3] = {{spec, A[0], PF_MUL_ONE}, {spec, A[1], PF_MUL_K}, {spec, A[2], PF_MUL_K2}};
+  return xpass(c, KS_XPASS_HESS, +1, 3, xj, 1, rs, 1.0, 1, band);
+}
+static int hess_yz(pf_ctx *c, const void *const R[3], const double *dc, void *const out[6], int band, bool xy_only) {
   const Job yj[6] = {{R[2], out[0], PF_MUL_ONE}, {R[1], out[3], PF_MUL_K}, {R[1], out[4], PF_MUL_ONE},
                      {R[0], out[1], PF_MUL_K2}, {R[0], out[5], PF_MUL_K},  {R[0], out[2], PF_MUL_ONE}};
   PFCHK(c, ypass(c, KS_YPASS_HESS, +1, 6, yj, true, false, 3, band));
@@ -411,50 +474,69 @@ static int hessian_of(pf_ctx *c, const void *spec, double rs, const double *dc, 
   PFCHK(c, zpass_c2r(c, KS_ZPASS_HESS, 6, zj, dc, band));
   return 0;
 }
+static int hessian_of(pf_ctx *c, const void *spec, double rs, const double *dc, void *const out[6], bool xy_only = false) {
+  const int band = hess_band(c, rs, xy_only);
+  return pipelined(c, 1, 3,
+                   [&](int, void *const *A) { return hess_x(c, spec, rs, A, band); },
+                   [&](int, int set, int f) { return recv_field(c, set, f); },
+                   [&](int, const void *const *R) { return hess_yz(c, R, dc, out, band, xy_only); });
+}
 
-// three first derivatives (displacement components) of `spec` times growth -> vel12[3*o .. 3*o+2]
+// three first derivatives (displacement components) of specs[j] times growths[j] -> vel12[3*orders[j] .. +2]
 // compute_first_derivatives + write_from_rvector_to_products, src/fmax.c:193-222, src/fmax-pfft.c:563-631
-static int displacement_of(pf_ctx *c, const void *spec, double growth, int o, void *const tmp[3]) {
-  const Job xj[2] = {{spec, c->A[0], PF_MUL_ONE}, {spec, c->A[1], PF_MUL_IK}};
-  PFCHK(c, xpass(c, KS_XPASS_DISP, +1, 2, xj, 1, 0.0, growth, 1));
-  const void *R[2] = {c->A[0], c->A[1]};
-  if (c->P > 1) {
-    for (int f = 0; f < 2; f++) {
-      void *r = (char *)c->recvA + f * c->field_bytes;
-      PFCHK(c, exchange(c, c->A[f], r));
-      R[f] = r;
-    }
-  }
-  const Job yj[3] = {{R[1], tmp[0], PF_MUL_ONE}, {R[0], tmp[1], PF_MUL_IK}, {R[0], tmp[2], PF_MUL_ONE}};
-  PFCHK(c, ypass(c, KS_YPASS_DISP, +1, 3, yj, true, false, 2));
+static int displacements_of(pf_ctx *c, int count, const void *const *specs, const double *growths, const int *orders, void *const tmp[3]) {
   const size_t nc = ncell(c);
-  const ZJob zj[3] = {{tmp[0], c->vel12 + (size_t)(3 * o + 0) * nc, PF_MUL_ONE, 1},
-                      {tmp[1], c->vel12 + (size_t)(3 * o + 1) * nc, PF_MUL_ONE, 1},
-                      {tmp[2], c->vel12 + (size_t)(3 * o + 2) * nc, PF_MUL_IK, 1}};
-  PFCHK(c, zpass_c2r(c, KS_ZPASS_DISP, 3, zj, nullptr));
-  return 0;
+  return pipelined(c, count, 2,
+                   [&](int j, void *const *A) {
+                     const Job xj[2] = {{specs[j], A[0], PF_MUL_ONE}, {specs[j], A[1], PF_MUL_IK}};
+                     return xpass(c, KS_XPASS_DISP, +1, 2, xj, 1, 0.0, growths[j], 1);
+                   },
+                   [&](int, int set, int f) { return recv_field(c, set, f); },
+                   [&](int j, const void *const *R) {
+                     const int o = orders[j];
+                     const Job yj[3] = {{R[1], tmp[0], PF_MUL_ONE}, {R[0], tmp[1], PF_MUL_IK}, {R[0], tmp[2], PF_MUL_ONE}};
+                     PFCHK(c, ypass(c, KS_YPASS_DISP, +1, 3, yj, true, false, 2));
+                     const ZJob zj[3] = {{tmp[0], c->vel12 + (size_t)(3 * o + 0) * nc, PF_MUL_ONE, 1},
+                                         {tmp[1], c->vel12 + (size_t)(3 * o + 1) * nc, PF_MUL_ONE, 1},
+                                         {tmp[2], c->vel12 + (size_t)(3 * o + 2) * nc, PF_MUL_IK, 1}};
+                     PFCHK(c, zpass_c2r(c, KS_ZPASS_DISP, 3, zj, nullptr));
+                     return 0;
+                   });
 }
 
-// unnormalised r2c of the real field in `f` (R layout) -> spectrum in `f` (KY layout), in place
+// unnormalised r2c of the real fields fs[i] (R layout) -> spectra in place (KY layout)
 // forward_transform, src/fmax-pfft.c:191-200
-static int forward_of(pf_ctx *c, void *f) {
-  {
-    PfR2CParams p; p.in = f; p.out = f; p.nlines = (long long)c->nxl * c->n; p.in_pitch = 2 * c->nzp; p.out_pitch = c->nzp; p.tw = c->tw;
-    KTimer t(c, KS_R2C_Z, real_bytes_alg(c) + spec_bytes_alg(c));
-    PFCHK(c, pf_launch_r2c(c->fb, c->n, p, c->stream));
-  }
-  if (c->P == 1) {
-    const Job yj[1] = {{f, f, PF_MUL_ONE}};
-    PFCHK(c, ypass(c, KS_YPASS_FWD, -1, 1, yj, false, false, 1));
-  } else {
-    const Job yj[1] = {{f, c->A[0], PF_MUL_ONE}};
-    PFCHK(c, ypass(c, KS_YPASS_FWD, -1, 1, yj, false, true, 1));
-    PFCHK(c, exchange(c, c->A[0], f));
-  }
-  const Job xj[1] = {{f, f, PF_MUL_ONE}};
-  PFCHK(c, xpass(c, KS_XPASS_FWD, -1, 1, xj, 0, 0.0, 1.0, 1));
+static int forward_r2c(pf_ctx *c, void *f) {
+  PfR2CParams p; p.in = f; p.out = f; p.nlines = (long long)c->nxl * c->n; p.in_pitch = 2 * c->nzp; p.out_pitch = c->nzp; p.tw = c->tw;
+  KTimer t(c, KS_R2C_Z, real_bytes_alg(c) + spec_bytes_alg(c));
+  PFCHK(c, pf_launch_r2c(c->fb, c->n, p, c->stream));
   return 0;
 }
+static int forward_many(pf_ctx *c, int count, void *const *fs) {
+  if (c->P == 1) {  // y-pass in place, nothing to exchange
+    for (int i = 0; i < count; i++) {
+      void *f = fs[i];
+      PFCHK(c, forward_r2c(c, f));
+      const Job yj[1] = {{f, f, PF_MUL_ONE}};
+      PFCHK(c, ypass(c, KS_YPASS_FWD, -1, 1, yj, false, false, 1));
+      const Job xj[1] = {{f, f, PF_MUL_ONE}};
+      PFCHK(c, xpass(c, KS_XPASS_FWD, -1, 1, xj, 0, 0.0, 1.0, 1));
+    }
+    return 0;
+  }
+  return pipelined(c, count, 1,
+                   [&](int i, void *const *A) {
+                     PFCHK(c, forward_r2c(c, fs[i]));
+                     const Job yj[1] = {{fs[i], A[0], PF_MUL_ONE}};
+                     return ypass(c, KS_YPASS_FWD, -1, 1, yj, false, true, 1);
+                   },
+                   [&](int i, int, int) { return fs[i]; },
+                   [&](int i, const void *const *) {
+                     const Job xj[1] = {{fs[i], fs[i], PF_MUL_ONE}};
+                     return xpass(c, KS_XPASS_FWD, -1, 1, xj, 0, 0.0, 1.0, 1);
+                   });
+}
+static int forward_of(pf_ctx *c, void *f) { return forward_many(c, 1, &f); }
 
 // plain c2r of the spectrum in `f` (KY) -> real in `f` (R) times 1/N^3, in place (reverse_transform)
 static int reverse_of(pf_ctx *c, void *f) {
@@ -653,13 +735,18 @@ extern "C" int pf_sweep(pf_ctx *c, int ns, const double *radius_cells, double *t
   HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_h[0], 0));
   PFCHK(c, pf_launch_fill_products(c->fmax, c->rmax, c->vel12, ncell(c), c->overlap ? c->stream2 : c->stream));
   c->products_init = true;
-  for (int ismooth = 0; ismooth < ns; ismooth++) {
+  const bool xy_only = c->fuse;
+  auto pre = [&](int ismooth, void *const *A) {
+    PhaseTimer pt(c, 0);
+    return hess_x(c, c->dk, radius_cells[ismooth], A, hess_band(c, radius_cells[ismooth], xy_only));
+  };
+  auto post = [&](int ismooth, const void *const *R) {
     const int b = c->overlap ? (ismooth & 1) : 0;
     void **H = b ? c->B2 : c->B;
     if (c->overlap && ismooth >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_c[b], 0));
     {
       PhaseTimer pt(c, 0);
-      PFCHK(c, hessian_of(c, c->dk, radius_cells[ismooth], c->scal + SC_DC_DK, H, c->fuse));
+      PFCHK(c, hess_yz(c, R, c->scal + SC_DC_DK, H, hess_band(c, radius_cells[ismooth], xy_only), xy_only));
     }
     HIPCHK(c, hipEventRecord(c->ev_h[b], c->stream));
     if (c->overlap) HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_h[b], 0));
@@ -671,7 +758,9 @@ extern "C" int pf_sweep(pf_ctx *c, int ns, const double *radius_cells, double *t
       } else if (collapse_enqueue(c, ismooth, H, cst)) return 1;
     }
     HIPCHK(c, hipEventRecord(c->ev_c[b], cst));
-  }
+    return 0;
+  };
+  if (pipelined(c, ns, 3, pre, [&](int, int set, int f) { return recv_field(c, set, f); }, post)) return 1;
   // join; keep the R=0 Hessian (last radius) in B for the LPT sources
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_c[(ns - 1) & 1], 0));
   if (ns >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_c[(ns - 2) & 1], 0));
@@ -727,20 +816,18 @@ extern "C" int pf_displacements(pf_ctx *c, int compute_sources, int recompute_sd
         KTimer t(c, KS_LPT_ACC, 14.0 * real_bytes_alg(c));
         PFCHK(c, pf_launch_lpt_accum(c->fb, ap, c->stream));
       }
-      PFCHK(c, forward_of(c, c->S[1]));
-      PFCHK(c, forward_of(c, c->S[2]));
+      void *const s12[2] = {c->S[1], c->S[2]};
+      PFCHK(c, forward_many(c, 2, s12));
       c->have_sources = true;
     } else if (!c->have_sources)
       return pf_fail(c->rank, "pf_displacements: LPT sources not resident (call with compute_sources = 1 first)");
+    // ScaleDep.order = 2, 3, 4 (src/LPT.c:181-184, 219-221, 226-228), then Zel'dovich (src/fmax.c:342-345); one
+    // pipeline so that with P > 1 each exchange runs beside the y/z passes of the previous field
     void *tmp[3] = {c->B2[0], c->B2[1], c->B2[2]};
-    PFCHK(c, displacement_of(c, c->S[0], c->growth[1], 1, tmp));  // ScaleDep.order = 2, src/LPT.c:181-184
-    PFCHK(c, displacement_of(c, c->S[1], c->growth[2], 2, tmp));  // order 3, :219-221
-    PFCHK(c, displacement_of(c, c->S[2], c->growth[3], 3, tmp));  // order 4, :226-228
-  }
-  {
-    PhaseTimer pt(c, 0);
-    void *tmp[3] = {c->B2[0], c->B2[1], c->B2[2]};
-    PFCHK(c, displacement_of(c, c->dk, c->growth[0], 0, tmp));    // Zel'dovich, src/fmax.c:342-345
+    const void *const specs[4] = {c->S[0], c->S[1], c->S[2], c->dk};
+    const double gr[4] = {c->growth[1], c->growth[2], c->growth[3], c->growth[0]};
+    const int orders[4] = {1, 2, 3, 0};
+    PFCHK(c, displacements_of(c, 4, specs, gr, orders, tmp));
   }
   return 0;
 }

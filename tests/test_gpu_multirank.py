@@ -53,11 +53,14 @@ def api():
     return _api
 
 
-@pytest.mark.parametrize("n,P", [(32, 2), (64, 4), (64, 8)])
-def test_slab_ranks_match_single_rank(api, n, P):
+@pytest.mark.parametrize("n,P,pipeline", [(32, 2, 1), (64, 4, 1), (64, 8, 1), (64, 4, 0)])
+def test_slab_ranks_match_single_rank(api, n, P, pipeline, monkeypatch):
+    # pipeline = 1 (default): double-buffered exchange on the communication stream, the all-to-all of transform i+1
+    # issued before the y/z passes of transform i; 0: one buffer set, everything on one stream
+    monkeypatch.setenv("PF_PIPELINE", str(pipeline))
     dk = synth.make_density(n, seed=17 + P)
     dk[0, 0, 0] = 0.21 * n ** 3  # DC mode lives on rank 0 and must reach every rank
-    radii = np.array([2.0, 1.0, 0.0])
+    radii = np.array([4.0, 2.0, 1.4, 1.0, 0.0])       # odd count: both buffer sets end up last
     x, y = synth.invgrow_table("lcdm")
     g = synth.growth_multipliers()
     nxl = n // P
