@@ -130,6 +130,13 @@ int pf_set_invgrow(pf_ctx *ctx, int ismooth, const double *x, const double *y, i
    g[2]=GrowingMode_3LPT_1 (carrying its minus sign, src/cosmo.c:1810),
    g[3]=GrowingMode_3LPT_2, all at the target redshift, scale-independent. */
 int pf_set_growth(pf_ctx *ctx, const double g[4]);
+/* SCALE_DEPENDENT build: the multiplier of ScaleDep.order = order (1..4) depends on |k| --
+   GrowingMode*(z, k_module) = sign * pow(10., InterpolateGrowth(z, k, SP_GROW*)) (src/cosmo.c:1728-1755, 1789-1819),
+   log-linear between nk k-bins at 10^(logkmin + j dlogk) (NkBINS = 10, LOGKMIN = -3, DELTALOGK = 0.5,
+   src/def_splines.h:40-42).  log10_growth[j] = my_spline_eval(SPLINE[SP_GROW* + j], -log10(1+z)) evaluated by the
+   caller at the target redshift; sign = -1 for order 3 (src/cosmo.c:1810).  |k| is taken in rad/cell exactly as
+   compute_derivative passes it (src/fmax-pfft.c:315-359).  nk = 0 returns to the scalar of pf_set_growth. */
+int pf_set_growth_table(pf_ctx *ctx, int order, const double *log10_growth, int nk, double logkmin, double dlogk, double sign);
 
 /* --- the path --- */
 /* compute_fmax's radius loop (src/fmax.c:66-150): for each radius (CELL units,
@@ -152,6 +159,11 @@ int pf_fmax_pdf(pf_ctx *ctx, unsigned long long hist[PF_NBINS]);
 /* products[] of this rank's slab into the caller's AoS (host), index
    i = z + n*(y + n*x_local) (src/pinocchio.h:84-85) */
 int pf_get_products(pf_ctx *ctx, void *products_host, const pf_product_layout *layout);
+/* the same columns merged into records the caller already holds: bytes of the record not named by a
+   non-negative offset keep their host value (Fmax/Rmax, the *_prev copies of a RECOMPUTE_DISPLACEMENTS
+   build filled by shift_all_displacements, src/fragment.c:832-850).  Used after a re-entrant
+   compute_displacements(0, 0, z) (src/fragment.c:398-410), which rewrites only the Vel* fields. */
+int pf_update_products(pf_ctx *ctx, void *products_host, const pf_product_layout *layout);
 /* debug / test taps (host copies, fp64): second_derivatives[0][i] of the last
    pf_second_derivatives (i = 0..5 <-> 11,22,33,12,13,23; src/LPT.c:36-44),
    compact [n/nranks][n][n]; LPT source spectra kvector_2LPT/3LPT_1/3LPT_2

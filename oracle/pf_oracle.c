@@ -28,6 +28,8 @@
 #endif
 
 #define ORC_PI 3.14159265358979323846 /* src/pinocchio.h:56 */
+#define ORC_MAX_SMOOTH 64
+#define ORC_MAX_KBINS 32
 #define ORC_SMALL ((double)1.e-20)     /* src/collapse_times.c:38 */
 
 struct orc_ctx {
@@ -52,9 +54,35 @@ struct orc_ctx {
   /* inverse-growth natural cubic spline (GSL cspline restated) */
   int nk;
   double *sx, *sy, *sc;
+  /* SCALE_DEPENDENT build: one inverse-growth spline per smoothing radius, SPLINE_INVGROW[ismooth]
+     (src/initialization.c:1551-1553, 1704-1708; src/cosmo.c:1828), and the k-binned growth tables behind
+     InterpolateGrowth (src/cosmo.c:1728-1755): T[j] = spline_j(-log10(1+z)), j = 0..NkBINS-1 */
+  int rnk[ORC_MAX_SMOOTH];
+  double *rsx[ORC_MAX_SMOOTH], *rsy[ORC_MAX_SMOOTH], *rsc[ORC_MAX_SMOOTH];
+  int gt_n[4];
+  double gt_T[4][ORC_MAX_KBINS], gt_logkmin[4], gt_dlogk[4], gt_sign[4];
 
   double t_total, t_deriv, t_fft, t_coll, t_lpt;
 };
+
+/* InterpolateGrowth (src/cosmo.c:1728-1755, SCALE_DEPENDENT branch) followed by the +-pow(10., .) of
+   GrowingMode* (src/cosmo.c:1789-1819).  k is whatever compute_derivative passes: |k| in rad/cell (quirk Q3). */
+static double growth_of_k(const orc_ctx *c, int o, double k) {
+  const double *T = c->gt_T[o];
+  const int nk = c->gt_n[o];
+  const double LOGKMIN = c->gt_logkmin[o], DELTALOGK = c->gt_dlogk[o];
+  const double kmin = pow(10., LOGKMIN), kmax = pow(10., LOGKMIN + (nk - 1) * DELTALOGK);
+  double v;
+  if (k < kmin) v = T[0];
+  else if (k > kmax) v = T[nk - 1];
+  else {
+    double dk = (log10(k) - LOGKMIN) / DELTALOGK;
+    int kk = (int)dk;
+    dk -= kk;
+    v = (kk >= nk - 1) ? T[nk - 1] : dk * T[kk + 1] + (1 - dk) * T[kk];
+  }
+  return c->gt_sign[o] * pow(10., v);
+}
 
 static double now_s(void) {
   struct timespec ts;
@@ -242,6 +270,8 @@ static int compute_derivative(orc_ctx *c, int first_derivative, int second_deriv
         double k_z = knorm * ii[2];
         double k_squared = k2_1 + k_z * k_z;
         double growth_rate = growth_rate_order;
+        if (c->sd_order >= 1 && c->sd_order <= 4 && c->gt_n[c->sd_order - 1] > 0)
+          growth_rate = growth_of_k(c, c->sd_order - 1, sqrt(k_squared)); /* fmax-pfft.c:339-364 */
         size_t index = 2 * (((size_t)idx * n + idy) * nzh + idz);
         if (k_squared != 0.) {
           double smoothing = exp(-0.5 * k_squared * Rsmooth * Rsmooth);
@@ -512,7 +542,7 @@ double orc_inverse_collapse_time(orc_ctx *c, const double *deformation_tensor, d
 }
 
 /* collapse_times.c:431-673 */
-int orc_compute_collapse_times(orc_ctx *c, int ismooth, double *true_var) {
+static int compute_collapse_times_with_current_spline(orc_ctx *c, int ismooth, double *true_var) {
   const size_t nr = c->n_r;
   orc_product *products = c->products;
   double local_variance = 0.0, local_average = 0.0;
@@ -570,6 +600,17 @@ int orc_compute_collapse_times(orc_ctx *c, int ismooth, double *true_var) {
   double global_variance = local_variance / (double)nr; /* Ntotal, :662 */
   if (true_var) *true_var = global_variance;
   return 0;
+}
+
+/* collapse_times.c:431; in a SCALE_DEPENDENT build InverseGrowingMode(D, ismooth) reads SPLINE_INVGROW[ismooth] */
+int orc_compute_collapse_times(orc_ctx *c, int ismooth, double *true_var) {
+  if (ismooth < 0 || ismooth >= ORC_MAX_SMOOTH || !c->rnk[ismooth]) return compute_collapse_times_with_current_spline(c, ismooth, true_var);
+  double *dx = c->sx, *dy = c->sy, *dc = c->sc;
+  const int dn = c->nk;
+  c->sx = c->rsx[ismooth]; c->sy = c->rsy[ismooth]; c->sc = c->rsc[ismooth]; c->nk = c->rnk[ismooth];
+  const int rc = compute_collapse_times_with_current_spline(c, ismooth, true_var);
+  c->sx = dx; c->sy = dy; c->sc = dc; c->nk = dn;
+  return rc;
 }
 
 /* ----------------------------------------------- src/fmax.c restated ---- */
@@ -737,11 +778,30 @@ void orc_destroy(orc_ctx *c) {
   for (int i = 0; i < 6; i++) free(c->second_derivatives[i]);
   free(c->kvector_2LPT); free(c->kvector_3LPT_1); free(c->kvector_3LPT_2);
   free(c->products); free(c->sx); free(c->sy); free(c->sc);
+  for (int i = 0; i < ORC_MAX_SMOOTH; i++) { free(c->rsx[i]); free(c->rsy[i]); free(c->rsc[i]); }
   free(c);
 }
 
 int orc_set_density(orc_ctx *c, const double *dk) { memcpy(c->kdensity, dk, sizeof(double) * c->n_fft); return 0; }
 int orc_set_invgrow(orc_ctx *c, const double *x, const double *y, int nk) { return spline_init(c, x, y, nk); }
+int orc_set_invgrow_radius(orc_ctx *c, int ismooth, const double *x, const double *y, int nk) {
+  if (ismooth < 0 || ismooth >= ORC_MAX_SMOOTH) return 1;
+  double *dx = c->sx, *dy = c->sy, *dc = c->sc;
+  const int dn = c->nk;
+  c->sx = c->sy = c->sc = NULL;
+  const int rc = spline_init(c, x, y, nk);
+  free(c->rsx[ismooth]); free(c->rsy[ismooth]); free(c->rsc[ismooth]);
+  c->rsx[ismooth] = c->sx; c->rsy[ismooth] = c->sy; c->rsc[ismooth] = c->sc; c->rnk[ismooth] = nk;
+  c->sx = dx; c->sy = dy; c->sc = dc; c->nk = dn;
+  return rc;
+}
+int orc_set_growth_table(orc_ctx *c, int order, const double *T, int nk, double logkmin, double dlogk, double sign) {
+  if (order < 1 || order > 4 || nk < 0 || nk > ORC_MAX_KBINS) return 1;
+  c->gt_n[order - 1] = nk;
+  if (nk) memcpy(c->gt_T[order - 1], T, sizeof(double) * nk);
+  c->gt_logkmin[order - 1] = logkmin; c->gt_dlogk[order - 1] = dlogk; c->gt_sign[order - 1] = sign;
+  return 0;
+}
 int orc_set_growth(orc_ctx *c, const double g[4]) { memcpy(c->growth, g, sizeof(double) * 4); return 0; }
 const orc_product *orc_products(orc_ctx *c) { return c->products; }
 const double *orc_second_derivative(orc_ctx *c, int i) { return c->second_derivatives[i]; }

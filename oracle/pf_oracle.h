@@ -54,6 +54,11 @@ int orc_set_invgrow(orc_ctx *c, const double *x, const double *y, int nk);
    g[0]=GrowingMode, g[1]=GrowingMode_2LPT, g[2]=GrowingMode_3LPT_1 (already
    carrying its minus sign, src/cosmo.c:1810), g[3]=GrowingMode_3LPT_2 */
 int orc_set_growth(orc_ctx *c, const double g[4]);
+/* SCALE_DEPENDENT build (rows f-3): SPLINE_INVGROW[ismooth] (src/initialization.c:1704-1708), and the k-binned
+   growth of InterpolateGrowth (src/cosmo.c:1728-1755) for ScaleDep.order = 1..4: T[j] = log10 growth in k-bin j at the
+   target redshift, k bins at 10^(logkmin + j dlogk), sign = -1 for GrowingMode_3LPT_1.  nk = 0: back to the scalar. */
+int orc_set_invgrow_radius(orc_ctx *c, int ismooth, const double *x, const double *y, int nk);
+int orc_set_growth_table(orc_ctx *c, int order, const double *T, int nk, double logkmin, double dlogk, double sign);
 
 /* src/fmax.c:36-190: Ns radii (in CELL units: Rsmooth = R/CellSize, :233),
    then compute_displacements(1,0,z) when do_lpt != 0.  true_var[Ns] out. */

@@ -103,6 +103,11 @@ class Fmax:
         assert g.shape == (4,)
         self._chk(self.L.pf_set_growth(self.h, _dp(g)))
 
+    def set_growth_table(self, order: int, log10_growth, logkmin: float = -3.0, dlogk: float = 0.5, sign: float = 1.0):
+        """k-binned growth of ScaleDep.order = order (SCALE_DEPENDENT build, src/cosmo.c:1728-1755); empty: scalar"""
+        t = np.ascontiguousarray(log10_growth, dtype=np.float64)
+        self._chk(self.L.pf_set_growth_table(self.h, int(order), _dp(t) if len(t) else None, len(t), logkmin, dlogk, sign))
+
     # -- the path (reference names) ----------------------------------------
     def sweep(self, radii_cells) -> np.ndarray:
         """radius loop of compute_fmax (src/fmax.c:66-150) -> TrueVariance[]"""
@@ -141,6 +146,12 @@ class Fmax:
         out = np.zeros((self.nxl, self.n, self.n), dtype=PRODUCT_DTYPE)
         self._chk(self.L.pf_get_products(self.h, out.ctypes.data_as(C.c_void_p), C.byref(lay)))
         return out
+
+    def update_products(self, records: np.ndarray, layout) -> np.ndarray:
+        """merge the device columns named by `layout` (a _lib.ProductLayout) into caller-held AoS records"""
+        assert records.flags.c_contiguous and records.nbytes == self.nxl * self.n * self.n * layout.stride
+        self._chk(self.L.pf_update_products(self.h, records.ctypes.data_as(C.c_void_p), C.byref(layout)))
+        return records
 
     def second_derivative(self, i: int) -> np.ndarray:
         out = np.empty((self.nxl, self.n, self.n))

@@ -103,6 +103,10 @@ struct pf_ctx {
   int spl_n[PF_MAX_SMOOTH + 1];
   bool spl_set[PF_MAX_SMOOTH + 1];
   double growth[4];
+  // k-binned growth (SCALE_DEPENDENT build): per order log10-growth table on the device, 0 entries = scalar
+  int gt_n[4];
+  double gt_logkmin[4], gt_dlogk[4], gt_sign[4];
+  double *gtab;        // [4][PF_KBIN_CAP]
   bool have_density, have_hessian, have_sources, products_init;
   int last_ns;
   pf_alltoall_fn a2a; void *a2a_user;
@@ -119,6 +123,7 @@ struct pf_ctx {
 
 #define PF_NBLK 2048
 #define PF_KNOT_CAP 512
+#define PF_KBIN_CAP 32
 enum { SC_SUM = 0, SC_SUM2 = 1, SC_DC_DK = 2, SC_DC_S2 = 3, SC_POWER = 4, SC_DSCALE = 5, SC_VAR0 = 8 /* 2 per radius */, SC_COUNT = 8 + 2 * PF_MAX_SMOOTH };
 
 static hipEvent_t ev_get(pf_ctx *c) {
@@ -258,6 +263,8 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   PFCHK(c, dev_alloc(c, (void **)&c->scal, SC_COUNT * sizeof(double)));
   PFCHK(c, dev_alloc(c, (void **)&c->hist, PF_NBINS * sizeof(unsigned long long)));
   PFCHK(c, dev_alloc(c, (void **)&c->spl, (size_t)(PF_MAX_SMOOTH + 1) * 5 * PF_KNOT_CAP * sizeof(double)));
+  PFCHK(c, dev_alloc(c, (void **)&c->gtab, 4 * PF_KBIN_CAP * sizeof(double)));
+  memset(c->gt_n, 0, sizeof(c->gt_n));
   HIPCHK(c, hipMemsetAsync(c->scal, 0, SC_COUNT * sizeof(double), c->stream));
   // twiddles exp(+2 pi i j / n), computed in long double on the host
   {
@@ -284,7 +291,7 @@ extern "C" int pf_destroy(pf_ctx *c) {
   hipFree(c->dk); hipFree(c->blockA); hipFree(c->recvA); hipFree(c->tw); hipFree(c->blockA2); hipFree(c->recvA2);
   for (int i = 0; i < 6; i++) { hipFree(c->B[i]); hipFree(c->B2[i]); }
   for (int i = 0; i < 3; i++) hipFree(c->S[i]);
-  hipFree(c->fmax); hipFree(c->rmax); hipFree(c->vel12); hipFree(c->partials); hipFree(c->scal); hipFree(c->hist); hipFree(c->spl);
+  hipFree(c->fmax); hipFree(c->rmax); hipFree(c->vel12); hipFree(c->partials); hipFree(c->scal); hipFree(c->hist); hipFree(c->spl); hipFree(c->gtab);
   for (auto &e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   for (auto &e : c->phase_evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   for (auto e : c->evpool) hipEventDestroy(e);
@@ -484,12 +491,24 @@ static int hessian_of(pf_ctx *c, const void *spec, double rs, const double *dc, 
 
 // three first derivatives (displacement components) of specs[j] times growths[j] -> vel12[3*orders[j] .. +2]
 // compute_first_derivatives + write_from_rvector_to_products, src/fmax.c:193-222, src/fmax-pfft.c:563-631
-static int displacements_of(pf_ctx *c, int count, const void *const *specs, const double *growths, const int *orders, void *const tmp[3]) {
+// The growth multiplier of ScaleDep.order = orders[j] + 1 is a scalar (c->growth) or, with a k-binned table
+// installed (pf_set_growth_table), applied per mode by k_apply_growth into the spare send field first.
+static int displacements_of(pf_ctx *c, int count, const void *const *specs, const int *orders, void *const tmp[3]) {
   const size_t nc = ncell(c);
   return pipelined(c, count, 2,
                    [&](int j, void *const *A) {
-                     const Job xj[2] = {{specs[j], A[0], PF_MUL_ONE}, {specs[j], A[1], PF_MUL_IK}};
-                     return xpass(c, KS_XPASS_DISP, +1, 2, xj, 1, 0.0, growths[j], 1);
+                     const int o = orders[j];
+                     const void *spec = specs[j];
+                     double growth = c->growth[o];
+                     if (c->gt_n[o]) {
+                       KTimer t(c, KS_MISC, 2.0 * spec_bytes_alg(c));
+                       PFCHK(c, pf_launch_apply_growth(c->fb, spec, A[2], c->n, c->nyl, c->nzh, c->nzp, c->rank * c->nyl, c->gtab + o * PF_KBIN_CAP,
+                                                       c->gt_n[o], c->gt_logkmin[o], c->gt_dlogk[o], c->gt_sign[o], c->stream));
+                       spec = A[2];
+                       growth = 1.0;
+                     }
+                     const Job xj[2] = {{spec, A[0], PF_MUL_ONE}, {spec, A[1], PF_MUL_IK}};
+                     return xpass(c, KS_XPASS_DISP, +1, 2, xj, 1, 0.0, growth, 1);
                    },
                    [&](int, int set, int f) { return recv_field(c, set, f); },
                    [&](int j, const void *const *R) {
@@ -646,6 +665,16 @@ static int spline_for(pf_ctx *c, int ismooth, PfSplineDev *s) {
 extern "C" int pf_set_growth(pf_ctx *c, const double g[4]) {
   if (!c || !g) return 1;
   memcpy(c->growth, g, 4 * sizeof(double));
+  return 0;
+}
+
+extern "C" int pf_set_growth_table(pf_ctx *c, int order, const double *log10_growth, int nk, double logkmin, double dlogk, double sign) {
+  if (!c || order < 1 || order > 4) return pf_fail(0, "pf_set_growth_table: order must be 1..4");
+  if (nk < 0 || nk == 1 || nk > PF_KBIN_CAP || (nk && !log10_growth)) return pf_fail(c->rank, "pf_set_growth_table: %d k-bins not in {0, 2..%d}", nk, PF_KBIN_CAP);
+  const int o = order - 1;
+  if (nk) HIPCHK(c, hipMemcpyAsync(c->gtab + o * PF_KBIN_CAP, log10_growth, nk * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->gt_n[o] = nk; c->gt_logkmin[o] = logkmin; c->gt_dlogk[o] = dlogk; c->gt_sign[o] = sign;
   return 0;
 }
 
@@ -825,9 +854,8 @@ extern "C" int pf_displacements(pf_ctx *c, int compute_sources, int recompute_sd
     // pipeline so that with P > 1 each exchange runs beside the y/z passes of the previous field
     void *tmp[3] = {c->B2[0], c->B2[1], c->B2[2]};
     const void *const specs[4] = {c->S[0], c->S[1], c->S[2], c->dk};
-    const double gr[4] = {c->growth[1], c->growth[2], c->growth[3], c->growth[0]};
     const int orders[4] = {1, 2, 3, 0};
-    PFCHK(c, displacements_of(c, 4, specs, gr, orders, tmp));
+    PFCHK(c, displacements_of(c, 4, specs, orders, tmp));
   }
   return 0;
 }
@@ -853,6 +881,27 @@ extern "C" int pf_get_products(pf_ctx *c, void *host, const pf_product_layout *l
   for (size_t first = 0; first < nc; first += cap) {
     const size_t cnt = (nc - first < cap) ? nc - first : cap;
     HIPCHK(c, hipMemsetAsync(staging(c), 0, cnt * l->stride, c->stream));
+    PFCHK(c, pf_launch_pack_products(c->fmax, c->rmax, c->vel12, nc, first, cnt, staging(c), l->stride, l->off_Rmax, l->off_Fmax, ov, c->stream));
+    HIPCHK(c, hipMemcpyAsync((char *)host + first * l->stride, staging(c), cnt * l->stride, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return 0;
+}
+
+// Same columns into records the caller already holds: each chunk goes host -> device, the selected fields are
+// overwritten, and it goes back, so every other byte of the record (Fmax/Rmax when their offsets are negative, the
+// *_prev copies of a RECOMPUTE_DISPLACEMENTS build, padding) is preserved.  The re-entrant compute_displacements
+// of src/fragment.c:398-410 writes only the twelve Vel* columns.
+extern "C" int pf_update_products(pf_ctx *c, void *host, const pf_product_layout *l) {
+  if (!c || !host || !l) return pf_fail(0, "pf_update_products: null argument");
+  if (l->stride < 8 || l->stride % 4) return pf_fail(c->rank, "pf_update_products: bad stride %zu", l->stride);
+  PhaseTimer pt(c, 3);
+  const size_t nc = ncell(c);
+  const size_t cap = (2 * c->field_bytes) / l->stride;
+  const int ov[4] = {l->off_Vel, l->off_Vel_2LPT, l->off_Vel_3LPT_1, l->off_Vel_3LPT_2};
+  for (size_t first = 0; first < nc; first += cap) {
+    const size_t cnt = (nc - first < cap) ? nc - first : cap;
+    HIPCHK(c, hipMemcpyAsync(staging(c), (const char *)host + first * l->stride, cnt * l->stride, hipMemcpyHostToDevice, c->stream));
     PFCHK(c, pf_launch_pack_products(c->fmax, c->rmax, c->vel12, nc, first, cnt, staging(c), l->stride, l->off_Rmax, l->off_Fmax, ov, c->stream));
     HIPCHK(c, hipMemcpyAsync((char *)host + first * l->stride, staging(c), cnt * l->stride, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

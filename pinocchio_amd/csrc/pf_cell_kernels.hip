@@ -3,6 +3,7 @@
 // (src/LPT.c:64-93, :134-137), products init/pack (src/collapse_times.c:461-492,
 // src/fmax-pfft.c:563-631), Fmax PDF (src/fmax.c:509-550), layout converters.
 #include "pf_internal.h"
+#include "pf_fft_core.h"
 #include "pf_collapse_core.h"
 
 #define PF_CELL_BLOCK 256
@@ -166,6 +167,41 @@ __global__ void __launch_bounds__(PF_CELL_BLOCK) k_fill_products(float *fmax, in
   }
 }
 
+// K2's growth multiplier when it depends on |k| (SCALE_DEPENDENT build: src/fmax-pfft.c:339-364 calling
+// GrowingMode*(z, k_module), i.e. InterpolateGrowth src/cosmo.c:1728-1755 and +-pow(10., .) :1789-1819):
+// out(k) = in(k) * sign * 10^{lerp(T; log10 |k|)}, |k| in rad/cell as in the reference (quirk Q3).  KY layout.
+template <typename F>
+__global__ void __launch_bounds__(PF_CELL_BLOCK)
+    k_apply_growth(const pfc<F> *__restrict__ in, pfc<F> *__restrict__ out, int n, int nyl, int nzh, int nzp, int y0,
+                   const double *__restrict__ T, int nk, double logkmin, double dlogk, double sign) {
+  const double knorm = 2. * PF_PI / (double)n;
+  const double kmin = pow(10., logkmin), kmax = pow(10., logkmin + (nk - 1) * dlogk);
+  const size_t total = (size_t)n * nyl * nzh;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int iz = (int)(i % nzh);
+    const size_t r = i / nzh;
+    const int yl = (int)(r % nyl), ix = (int)(r / nyl);
+    int sx = ix, sy = yl + y0;
+    if (sx > n / 2) sx -= n;
+    if (sy > n / 2) sy -= n;
+    const double kx = knorm * sx, ky = knorm * sy, kz = knorm * iz;
+    const double k2_1 = kx * kx + ky * ky;
+    const double k = sqrt(k2_1 + kz * kz);
+    double v;
+    if (k < kmin) v = T[0];
+    else if (k > kmax) v = T[nk - 1];
+    else {
+      double dk = (log10(k) - logkmin) / dlogk;
+      const int kk = (int)dk;
+      dk -= kk;
+      v = (kk >= nk - 1) ? T[nk - 1] : dk * T[kk + 1] + (1 - dk) * T[kk];
+    }
+    const double g = sign * pow(10., v);
+    const size_t a = r * (size_t)nzp + iz;
+    out[a] = pf_mk<F>((F)((double)in[a].x * g), (F)((double)in[a].y * g));
+  }
+}
+
 // device SoA -> the caller's AoS product_data (src/pinocchio.h:233-259)
 __global__ void __launch_bounds__(PF_CELL_BLOCK)
     k_pack_products(const float *fmax, const int *rmax, const float *vel12, size_t ncell_total, size_t first, size_t count,
@@ -311,6 +347,13 @@ int pf_launch_pack_products(const float *fmax, const int *rmax, const float *vel
                             hipStream_t st) {
   hipLaunchKernelGGL(k_pack_products, dim3(pf_grid_for(count)), dim3(PF_CELL_BLOCK), 0, st, fmax, rmax, vel12,
                      ncell_total, first, count, aos, stride, off_rmax, off_fmax, ov[0], ov[1], ov[2], ov[3]);
+  return PF_CHECK_LAUNCH();
+}
+int pf_launch_apply_growth(int fb, const void *in, void *out, int n, int nyl, int nzh, int nzp, int y0, const double *T, int nk,
+                           double logkmin, double dlogk, double sign, hipStream_t st) {
+  const int g = pf_grid_for((size_t)n * nyl * nzh);
+  if (fb == 8) hipLaunchKernelGGL(k_apply_growth<double>, dim3(g), dim3(PF_CELL_BLOCK), 0, st, (const pfc<double> *)in, (pfc<double> *)out, n, nyl, nzh, nzp, y0, T, nk, logkmin, dlogk, sign);
+  else hipLaunchKernelGGL(k_apply_growth<float>, dim3(g), dim3(PF_CELL_BLOCK), 0, st, (const pfc<float> *)in, (pfc<float> *)out, n, nyl, nzh, nzp, y0, T, nk, logkmin, dlogk, sign);
   return PF_CHECK_LAUNCH();
 }
 int pf_launch_fmax_pdf(const float *fmax, size_t ncell, unsigned long long *hist, hipStream_t st) {

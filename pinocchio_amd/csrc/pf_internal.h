@@ -139,6 +139,8 @@ int pf_launch_lpt_accum(int field_bytes, const PfLptAccParams &p, hipStream_t st
 
 int pf_launch_sum1(const double *partials, int nblocks, double scale, double *out, hipStream_t st);
 int pf_launch_fill_products(float *fmax, int *rmax, float *vel12, size_t ncell, hipStream_t st);
+int pf_launch_apply_growth(int fb, const void *in, void *out, int n, int nyl, int nzh, int nzp, int y0, const double *T, int nk,
+                           double logkmin, double dlogk, double sign, hipStream_t st);
 int pf_launch_pack_products(const float *fmax, const int *rmax, const float *vel12, size_t ncell_total,
                             size_t first, size_t count, char *aos, size_t stride, int off_rmax, int off_fmax,
                             const int off_vel[4], hipStream_t st);

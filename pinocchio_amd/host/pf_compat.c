@@ -167,8 +167,55 @@ int pf_compat_genic(double PkNorm) {
 static int pf_upload_inputs(void) {
   if (!pf_context && compute_fft_plans()) return 1;
   if (!pf_density_on_device && pf_set_density(pf_context, kdensity[0])) return 1;
+#if defined(PF_IN_PINOCCHIO_TREE) && defined(SCALE_DEPENDENT)
+  { /* one inverse-growth spline per smoothing radius, src/initialization.c:1704-1708, src/cosmo.c:1828 */
+    int ismooth;
+    for (ismooth = 0; ismooth < Smoothing.Nsmooth; ismooth++)
+      if (pf_set_invgrow(pf_context, ismooth, SPLINE_INVGROW[ismooth]->x, SPLINE_INVGROW[ismooth]->y, (int)SPLINE_INVGROW[ismooth]->size)) return 1;
+  }
+#elif defined(PF_IN_PINOCCHIO_TREE)
   if (pf_set_invgrow(pf_context, -1, PF_KNOTS_X, PF_KNOTS_Y, PF_KNOTS_N)) return 1;
+#else
+  if (pf_compat_scale_dependent) {
+    int ismooth;
+    for (ismooth = 0; ismooth < Smoothing.Nsmooth; ismooth++)
+      if (pf_set_invgrow(pf_context, ismooth, pf_invgrow_knots_radius[ismooth].x, pf_invgrow_knots_radius[ismooth].y,
+                         (int)pf_invgrow_knots_radius[ismooth].size)) return 1;
+  } else if (pf_set_invgrow(pf_context, -1, PF_KNOTS_X, PF_KNOTS_Y, PF_KNOTS_N)) return 1;
+#endif
   return 0;
+}
+
+/* growth multipliers of compute_derivative for ScaleDep.order = 1..4 (src/fmax-pfft.c:344-364) at `redshift`:
+   scalars, or in a SCALE_DEPENDENT build the NkBINS-entry tables InterpolateGrowth interpolates in
+   (src/cosmo.c:1728-1755), each entry one spline evaluation on the host */
+#define PF_NKBINS 10
+#define PF_LOGKMIN (-3.0)
+#define PF_DELTALOGK 0.5
+static int pf_upload_growth(double redshift) {
+  double g[4];
+#if defined(PF_IN_PINOCCHIO_TREE) && defined(SCALE_DEPENDENT)
+  static const int first[4] = {SP_GROW1, SP_GROW2, SP_GROW31, SP_GROW32};
+  int o, j;
+  for (o = 0; o < 4; o++) {
+    double T[NkBINS];
+    for (j = 0; j < NkBINS; j++) T[j] = my_spline_eval(SPLINE[first[o] + j], -log10(1. + redshift), ACCEL[first[o] + j]);
+    if (pf_set_growth_table(pf_context, o + 1, T, NkBINS, LOGKMIN, DELTALOGK, o == 2 ? -1.0 : 1.0)) return 1;
+  }
+#elif !defined(PF_IN_PINOCCHIO_TREE)
+  if (pf_compat_scale_dependent) {
+    double (*fn[4])(double, double);
+    int o, j;
+    fn[0] = pf_GrowingMode; fn[1] = pf_GrowingMode_2LPT; fn[2] = pf_GrowingMode_3LPT_1; fn[3] = pf_GrowingMode_3LPT_2;
+    for (o = 0; o < 4; o++) {
+      double T[PF_NKBINS], sign = fn[o](redshift, 1.0) < 0.0 ? -1.0 : 1.0;
+      for (j = 0; j < PF_NKBINS; j++) T[j] = log10(sign * fn[o](redshift, pow(10., PF_LOGKMIN + j * PF_DELTALOGK)));
+      if (pf_set_growth_table(pf_context, o + 1, T, PF_NKBINS, PF_LOGKMIN, PF_DELTALOGK, sign)) return 1;
+    }
+  }
+#endif
+  g[0] = PF_GM(redshift); g[1] = PF_GM2(redshift); g[2] = PF_GM31(redshift); g[3] = PF_GM32(redshift);
+  return pf_set_growth(pf_context, g);
 }
 
 static void pf_collect_cputime(void) {
@@ -178,6 +225,21 @@ static void pf_collect_cputime(void) {
     cputime.mem_transf += t.mem_transf;
     pf_reset_cputime(pf_context);
   }
+}
+
+static int pf_inside_compute_fmax = 0;
+
+/* re-entrant compute_displacements (src/fragment.c:398-410): only the Vel* fields of the host records change */
+static int pf_download_velocities(void) {
+  pf_product_layout lay;
+  lay.stride = sizeof(product_data);
+  lay.off_Rmax = -1;
+  lay.off_Fmax = -1;
+  lay.off_Vel = (int)offsetof(product_data, Vel);
+  lay.off_Vel_2LPT = (int)offsetof(product_data, Vel_2LPT);
+  lay.off_Vel_3LPT_1 = (int)offsetof(product_data, Vel_3LPT_1);
+  lay.off_Vel_3LPT_2 = (int)offsetof(product_data, Vel_3LPT_2);
+  return pf_update_products(pf_context, products, &lay);
 }
 
 static int pf_download_products(void) {
@@ -197,14 +259,15 @@ int Fmax_PDF(void);
 /* src/fmax.c:292-367.  recompute_sd: second derivatives at R=0 are recomputed on the device. */
 int compute_displacements(int compute_sources, int recompute_sd, double redshift) {
   double cputmp = pf_wtime();
-  double g[4];
   if (!ThisTask) printf("\n[%s] Computing LPT displacements\n", fdate());
   if (!pf_context && pf_upload_inputs()) return 1;
-  /* growth multipliers of compute_derivative for ScaleDep.order = 1..4 (src/fmax-pfft.c:344-364) */
   ScaleDep.redshift = redshift;
-  g[0] = PF_GM(redshift); g[1] = PF_GM2(redshift); g[2] = PF_GM31(redshift); g[3] = PF_GM32(redshift);
-  if (pf_set_growth(pf_context, g)) return 1;
+  if (pf_upload_growth(redshift)) return 1;
   if (pf_displacements(pf_context, compute_sources, recompute_sd)) return 1;
+  if (!pf_inside_compute_fmax) { /* called from fragment: the host records take the new displacements now */
+    if (pf_download_velocities()) return 1;
+    pf_collect_cputime();
+  }
   ScaleDep.order = 1;
   cputmp = pf_wtime() - cputmp;
   if (!ThisTask) printf("[%s] Done LPT displacements and first derivatives, cpu time = %f s\n", fdate(), cputmp);
@@ -245,7 +308,9 @@ int compute_fmax(void) {
 
   /* COMPUTATION OF DISPLACEMENTS for the first (or only) redshift segment (src/fmax.c:160-169) */
   if (!ThisTask) printf("\n[%s] Computing displacements  for redshift %f\n", fdate(), ScaleDep.z[0]);
-  if (compute_displacements(1, 0, ScaleDep.z[0])) return 1;
+  pf_inside_compute_fmax = 1;
+  if (compute_displacements(1, 0, ScaleDep.z[0])) { pf_inside_compute_fmax = 0; return 1; }
+  pf_inside_compute_fmax = 0;
 
   if (pf_download_products()) return 1;
   pf_collect_cputime();

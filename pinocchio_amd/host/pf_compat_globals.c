@@ -19,3 +19,5 @@ double (*pf_GrowingMode)(double, double) = 0;
 double (*pf_GrowingMode_2LPT)(double, double) = 0;
 double (*pf_GrowingMode_3LPT_1)(double, double) = 0;
 double (*pf_GrowingMode_3LPT_2)(double, double) = 0;
+int pf_compat_scale_dependent = 0;
+pf_spline_knots pf_invgrow_knots_radius[64];

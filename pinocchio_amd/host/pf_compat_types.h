@@ -30,6 +30,11 @@ typedef struct /* src/pinocchio.h:233-259 */
   PRODFLOAT Fmax, Vel[3];
   PRODFLOAT Vel_2LPT[3];
   PRODFLOAT Vel_3LPT_1[3], Vel_3LPT_2[3];
+#ifdef RECOMPUTE_DISPLACEMENTS /* the reference's default Makefile flags: 104-byte record */
+  PRODFLOAT Vel_prev[3];
+  PRODFLOAT Vel_2LPT_prev[3];
+  PRODFLOAT Vel_3LPT_1_prev[3], Vel_3LPT_2_prev[3];
+#endif
 } product_data __attribute__((aligned(ALIGN)));
 
 typedef struct /* :284-292 */
@@ -90,5 +95,9 @@ extern double (*pf_GrowingMode)(double z, double k);
 extern double (*pf_GrowingMode_2LPT)(double z, double k);
 extern double (*pf_GrowingMode_3LPT_1)(double z, double k);
 extern double (*pf_GrowingMode_3LPT_2)(double z, double k);
+/* non-zero: behave like a -DSCALE_DEPENDENT build -- the growth functions above are sampled at the NkBINS k-bins
+   (src/def_splines.h:40-42) and applied per mode; pf_invgrow_knots_radius[ismooth] = SPLINE_INVGROW[ismooth] */
+extern int pf_compat_scale_dependent;
+extern pf_spline_knots pf_invgrow_knots_radius[64];
 
 #endif

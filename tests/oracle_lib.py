@@ -45,6 +45,8 @@ def lib():
         L.orc_set_density.argtypes = [C.c_void_p, dp]
         L.orc_set_invgrow.argtypes = [C.c_void_p, dp, dp, C.c_int]
         L.orc_set_growth.argtypes = [C.c_void_p, dp]
+        L.orc_set_invgrow_radius.argtypes = [C.c_void_p, C.c_int, dp, dp, C.c_int]
+        L.orc_set_growth_table.argtypes = [C.c_void_p, C.c_int, dp, C.c_int, C.c_double, C.c_double, C.c_double]
         L.orc_compute_fmax.argtypes = [C.c_void_p, C.c_int, dp, C.c_int, dp]
         L.orc_compute_second_derivatives.argtypes = [C.c_void_p, C.c_double]
         L.orc_compute_collapse_times.argtypes = [C.c_void_p, C.c_int, dp]
@@ -108,6 +110,15 @@ class Oracle:
     def set_growth(self, g):
         g = np.ascontiguousarray(g, dtype=np.float64)
         self.L.orc_set_growth(self.h, _dp(g))
+
+    def set_invgrow_radius(self, ismooth, x, y):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        assert self.L.orc_set_invgrow_radius(self.h, int(ismooth), _dp(x), _dp(y), len(x)) == 0
+
+    def set_growth_table(self, order, log10_growth, logkmin=-3.0, dlogk=0.5, sign=1.0):
+        t = np.ascontiguousarray(log10_growth, dtype=np.float64)
+        assert self.L.orc_set_growth_table(self.h, int(order), _dp(t), len(t), logkmin, dlogk, sign) == 0
 
     def compute_fmax(self, radii_cells, do_lpt=True):
         r = np.ascontiguousarray(radii_cells, dtype=np.float64)

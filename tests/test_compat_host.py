@@ -222,3 +222,99 @@ def test_genic_on_device_through_the_reference_driver(lib, tmp_path):
     ulp = np.spacing(np.maximum(np.abs(po["Fmax"]), 1.0).astype(np.float32)).astype(np.float64)
     assert np.mean(np.abs(p["Fmax"].astype(np.float64) - po["Fmax"]) > 2 * ulp) < 1e-4
     assert np.max(np.abs(p["Vel"].astype(np.float64) - po["Vel"])) <= 4e-7 * np.max(np.abs(po["Vel"]))
+
+
+@pytest.mark.gpu
+def test_reentrant_displacements_recompute_build(tmp_path):
+    """The adapter built with the reference's default -DRECOMPUTE_DISPLACEMENTS (104-byte product_data, context kept
+    after compute_fmax): fragment's sequence shift_all_displacements(); compute_displacements(0, 0, z)
+    (src/fragment.c:398-410) rewrites the Vel* fields of the host records and nothing else; with
+    pf_compat_scale_dependent the growth functions are sampled into the NkBINS tables (src/cosmo.c:1728-1755)."""
+    import __graft_entry__ as g_entry
+    so = os.path.join(ROOT, "pinocchio_amd", "libpf_compat_recompute.so")
+    if not os.path.exists(so):
+        g_entry.build()
+    lib = C.CDLL(so)
+    rec = np.dtype([("Rmax", "<i4"), ("Fmax", "<f4"), ("Vel", "<f4", 3), ("Vel_2LPT", "<f4", 3), ("Vel_3LPT_1", "<f4", 3),
+                    ("Vel_3LPT_2", "<f4", 3), ("Vel_prev", "<f4", 3), ("Vel_2LPT_prev", "<f4", 3),
+                    ("Vel_3LPT_1_prev", "<f4", 3), ("Vel_3LPT_2_prev", "<f4", 3)])
+    n, cell = 32, 2.0
+    dk = np.ascontiguousarray(synth.make_density(n, seed=31))
+    radii_mpc = np.array([4.0, 2.0, 0.0])
+    x, y = synth.invgrow_table("lcdm")
+    g0 = synth.growth_multipliers()
+    scale = {0.0: np.ones(4), 1.0: np.array([0.6, 0.36, 0.216, 0.216])}     # growth at the two "redshifts"
+
+    def growth(o, z, k):    # mildly k-dependent, like an f(R) table; k in rad/cell (quirk Q3)
+        return float(g0[o] * scale[z][o] * (1.0 + 0.03 * (o + 1) * np.log10(max(k, 1e-3) / 1e-3)))
+
+    grid = C.cast(C.c_void_p.in_dll(lib, "MyGrids"), C.POINTER(Grid)).contents
+    for i in range(3):
+        grid.GSglobal[i] = n
+    grid.Ntotal = n ** 3
+    grid.BoxSize = n * cell
+    assert lib.set_one_grid(0) == 0
+    raw = np.zeros(n ** 3 * 104 + 64, dtype=np.uint8)
+    raw = raw[(-raw.ctypes.data) % 32:][:n ** 3 * 104]
+    C.c_void_p.in_dll(lib, "products").value = raw.ctypes.data
+    kd = C.cast(C.c_void_p.in_dll(lib, "kdensity"), C.POINTER(C.c_void_p))
+    kd[0] = dk.ctypes.data
+    sm = Smoothing.in_dll(lib, "Smoothing")
+    tv = np.zeros(len(radii_mpc)); var = np.ones(len(radii_mpc))
+    sm.Nsmooth = len(radii_mpc)
+    sm.Radius = radii_mpc.ctypes.data_as(C.POINTER(C.c_double))
+    sm.Variance = var.ctypes.data_as(C.POINTER(C.c_double))
+    sm.TrueVariance = tv.ctypes.data_as(C.POINTER(C.c_double))
+    sd = ScaleDep.in_dll(lib, "ScaleDep")
+    sd.nseg = 2
+    sd.z[0], sd.z[1] = 0.0, 1.0
+    C.c_int.in_dll(lib, "pf_compat_scale_dependent").value = 1
+    knots = (Knots * 64).in_dll(lib, "pf_invgrow_knots_radius")
+    for i in range(len(radii_mpc)):
+        knots[i].size = len(x)
+        knots[i].x = x.ctypes.data_as(C.POINTER(C.c_double))
+        knots[i].y = y.ctypes.data_as(C.POINTER(C.c_double))
+    fns = [GROWTH_FN(lambda z, k, o=o: growth(o, z, k)) for o in range(4)]
+    for name, fn in zip(("pf_GrowingMode", "pf_GrowingMode_2LPT", "pf_GrowingMode_3LPT_1", "pf_GrowingMode_3LPT_2"), fns):
+        C.c_void_p.in_dll(lib, name).value = C.cast(fn, C.c_void_p).value
+    par = Params.in_dll(lib, "params")
+    par.RunFlag = b"pfrecomp"
+    par.GridSize[0] = par.GridSize[1] = par.GridSize[2] = n
+    par.RandomSeed = 31
+
+    lib.compute_displacements.argtypes = [C.c_int, C.c_int, C.c_double]
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        assert lib.compute_fft_plans() == 0
+        assert lib.compute_fmax() == 0
+        recs = raw.view(rec).reshape(n, n, n)
+        first = recs.copy()
+        for name in ("Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):       # shift_all_displacements
+            recs[name + "_prev"] = recs[name]
+        assert lib.compute_displacements(0, 0, 1.0) == 0
+    finally:
+        os.chdir(cwd)
+
+    kbin = 10.0 ** (-3.0 + 0.5 * np.arange(10))
+    o = oracle_lib.Oracle(n, 0)
+    o.set_density(dk); o.set_invgrow(x, y)
+    want = {}
+    for z in (0.0, 1.0):
+        for k in range(4):
+            t = np.array([growth(k, z, kk) for kk in kbin])
+            o.set_growth_table(k + 1, np.log10(np.abs(t)), sign=float(np.sign(t[0])))
+        if z == 0.0:
+            o.compute_fmax(radii_mpc / cell, do_lpt=True)
+        else:
+            o.displacements(compute_sources=False)
+        want[z] = o.products()
+    for name in ("Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+        amp = np.max(np.abs(want[0.0][name]))
+        assert np.max(np.abs(first[name].astype(np.float64) - want[0.0][name])) <= 4e-7 * amp, name
+        assert np.max(np.abs(recs[name].astype(np.float64) - want[1.0][name])) <= 4e-7 * amp, name
+        assert np.array_equal(recs[name + "_prev"], first[name])
+        assert np.max(np.abs(recs[name] - first[name])) > 0.1 * amp
+    assert np.array_equal(recs["Fmax"], first["Fmax"]) and np.array_equal(recs["Rmax"], first["Rmax"])
+    ulp = np.spacing(np.maximum(np.abs(want[0.0]["Fmax"]), 1.0).astype(np.float32)).astype(np.float64)
+    assert np.mean(np.abs(first["Fmax"].astype(np.float64) - want[0.0]["Fmax"]) > 2 * ulp) < 1e-4

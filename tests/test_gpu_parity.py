@@ -17,6 +17,7 @@ Tolerances (fp64 field path), as stated in DESIGN.md:
   * Rmax                        : identical on >= 99.9 % of cells
   * displacements (stored fp32) : |diff| <= 4e-7 x amplitude (fp32 rounding of equal fp64 values)
 """
+import ctypes as C
 import json
 import os
 
@@ -419,3 +420,88 @@ def test_hmf_validation_run_entirely_on_device(api):
     want = np.array(kat["FmaxPDF"], dtype=np.int64)
     assert abs(int(pdf[10:].sum()) - kat["collapsed"]) <= 5
     assert np.abs(pdf - want).sum() <= 200
+
+
+def test_scale_dependent_build_vs_oracle(api):
+    """rows f-3: what a -DSCALE_DEPENDENT build changes on the path -- one inverse-growth spline per smoothing radius
+    (SPLINE_INVGROW[ismooth], src/cosmo.c:1828) and growth multipliers interpolated per mode in the 10 k-bins of
+    InterpolateGrowth (src/cosmo.c:1728-1755) with |k| in rad/cell (src/fmax-pfft.c:315-359)"""
+    n = 32
+    radii = np.array([3.0, 1.5, 0.0])
+    dk = synth.make_density(n, seed=21)
+    splines = [synth.invgrow_table("lcdm", omega0=om) for om in (0.25, 0.30, 0.35)]
+    g = synth.growth_multipliers()
+    j = np.arange(10)
+    # grid |k| spans 0.2 .. 5.4 rad/cell: bins 4..8 of 10^(-3 + 0.5 j); every order gets its own k-dependence
+    tabs = [np.log10(abs(g[o]) * (1.0 + 0.04 * (o + 1) * j)) for o in range(4)]
+    signs = [1.0, 1.0, -1.0, 1.0]
+    with api.Fmax(n) as f:
+        f.set_density(dk)
+        for i, (x, y) in enumerate(splines):
+            f.set_invgrow(x, y, ismooth=i)
+        for o in range(4):
+            f.set_growth_table(o + 1, tabs[o], sign=signs[o])
+        tv = f.compute_fmax(radii, do_lpt=True)
+        p = f.products()
+        f.set_growth_table(1, [])                       # back to the scalar for the Zel'dovich order
+        f.set_growth(g)
+        f.compute_displacements(0, 0)
+        p_scalar = f.products()
+    o = oracle_lib.Oracle(n, 0)
+    o.set_density(dk)
+    o.set_invgrow(*splines[0])
+    for i, (x, y) in enumerate(splines):
+        o.set_invgrow_radius(i, x, y)
+    for k in range(4):
+        o.set_growth_table(k + 1, tabs[k], sign=signs[k])
+    tv_o = o.compute_fmax(radii, do_lpt=True)
+    po = o.products()
+    assert np.allclose(tv, tv_o, rtol=1e-12)
+    _fmax_close(p["Fmax"], po["Fmax"])
+    assert np.mean(p["Rmax"] != po["Rmax"]) < 1e-3
+    for name in ("Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+        assert np.max(np.abs(p[name].astype(np.float64) - po[name])) <= 4e-7 * np.max(np.abs(po[name])), name
+    # the per-radius splines and the k-dependence really were in play
+    o1 = oracle_lib.Oracle(n, 0)
+    o1.set_density(dk); o1.set_invgrow(*splines[0]); o1.set_growth(g)
+    o1.compute_fmax(radii, do_lpt=True)
+    p1 = o1.products()
+    assert np.mean(p1["Fmax"] != po["Fmax"]) > 0.1
+    assert np.max(np.abs(p1["Vel"] - po["Vel"])) > 1e-2 * np.max(np.abs(po["Vel"]))
+    assert np.max(np.abs(p_scalar["Vel"].astype(np.float64) - p1["Vel"])) <= 4e-7 * np.max(np.abs(p1["Vel"]))
+    assert np.array_equal(p_scalar["Vel_2LPT"], p["Vel_2LPT"])
+
+
+def test_update_products_merges_into_recompute_records(api):
+    """pf_update_products writes only the named columns: a 104-byte RECOMPUTE_DISPLACEMENTS record keeps its *_prev
+    copies, Fmax and Rmax (src/pinocchio.h:233-259; shift_all_displacements src/fragment.c:832-850)"""
+    from pinocchio_amd import _lib
+    n = 32
+    rec = np.dtype([("Rmax", "<i4"), ("Fmax", "<f4"), ("Vel", "<f4", 3), ("Vel_2LPT", "<f4", 3), ("Vel_3LPT_1", "<f4", 3),
+                    ("Vel_3LPT_2", "<f4", 3), ("Vel_prev", "<f4", 3), ("Vel_2LPT_prev", "<f4", 3),
+                    ("Vel_3LPT_1_prev", "<f4", 3), ("Vel_3LPT_2_prev", "<f4", 3)])
+    assert rec.itemsize == 104
+    dk = synth.make_density(n, seed=8)
+    x, y = synth.invgrow_table("lcdm")
+    g = synth.growth_multipliers()
+    with api.Fmax(n) as f:
+        f.set_density(dk); f.set_invgrow(x, y); f.set_growth(g)
+        f.compute_fmax(np.array([2.0, 0.0]), do_lpt=True)
+        p0 = f.products()
+        full = _lib.ProductLayout(104, 0, 4, 8, 20, 32, 44)
+        recs = np.zeros((n, n, n), dtype=rec)
+        f._chk(f.L.pf_get_products(f.h, recs.ctypes.data_as(C.c_void_p), C.byref(full)))
+        for name in ("Rmax", "Fmax", "Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+            assert np.array_equal(recs[name], p0[name])
+        # the host shifts (fragment.c), the device recomputes at another redshift, only Vel* come back
+        for name in ("Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+            recs[name + "_prev"] = recs[name]
+        recs["Fmax"] += 100.0
+        f.set_growth(g * 0.5)
+        f.compute_displacements(0, 0)
+        f.update_products(recs, _lib.ProductLayout(104, -1, -1, 8, 20, 32, 44))
+        p1 = f.products()
+    for name in ("Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+        assert np.array_equal(recs[name], p1[name]) and np.array_equal(recs[name + "_prev"], p0[name])
+        assert np.allclose(p1[name], 0.5 * p0[name], rtol=2e-7, atol=0)
+    assert np.array_equal(recs["Fmax"], p0["Fmax"] + np.float32(100.0)) and np.array_equal(recs["Rmax"], p0["Rmax"])

@@ -168,3 +168,75 @@ def test_thread_count_independence():
     assert np.allclose(res[0][0], res[1][0], rtol=1e-13)
     for name in ("Fmax", "Rmax", "Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
         assert np.array_equal(res[0][1][name], res[1][1][name]), name
+
+
+def _interpolate_growth(k, T, logkmin=-3.0, dlogk=0.5):
+    """InterpolateGrowth, SCALE_DEPENDENT branch (src/cosmo.c:1728-1755), vectorised"""
+    T = np.asarray(T)
+    nk = len(T)
+    kmin, kmax = 10.0 ** logkmin, 10.0 ** (logkmin + (nk - 1) * dlogk)
+    dk = (np.log10(np.maximum(k, kmin)) - logkmin) / dlogk
+    kk = np.clip(dk.astype(np.int64), 0, nk - 2)
+    fr = dk - kk
+    v = fr * T[kk + 1] + (1 - fr) * T[kk]
+    v = np.where(k < kmin, T[0], v)
+    return np.where(k > kmax, T[-1], v)
+
+
+def test_scale_dependent_growth_and_per_radius_splines_vs_numpy():
+    """the SCALE_DEPENDENT additions of the oracle: growth per mode from the k-binned tables (|k| in rad/cell as in
+    src/fmax-pfft.c:339-364) against a numpy restatement, and SPLINE_INVGROW[ismooth] selection"""
+    n = 16
+    dk = synth.make_density(n, seed=12)
+    radii = np.array([2.0, 1.0, 0.0])
+    x, y = synth.invgrow_table("lcdm")
+    g = synth.growth_multipliers()
+    j = np.arange(10)
+    tabs = [np.log10(abs(g[o]) * (1.0 + 0.05 * (o + 1) * j)) for o in range(4)]
+    signs = [1.0, 1.0, -1.0, 1.0]
+    o = oracle_lib.Oracle(n, 2)
+    o.set_density(dk); o.set_invgrow(x, y)
+    for k in range(4):
+        o.set_growth_table(k + 1, tabs[k], sign=signs[k])
+    o.compute_fmax(radii, do_lpt=True)
+    p = o.products()
+    kx, ky, kz = npr.kvecs(n)
+    kmod = np.sqrt(kx ** 2 + ky ** 2 + kz ** 2)
+    gk = [signs[k] * 10.0 ** _interpolate_growth(kmod, tabs[k]) for k in range(4)]
+    assert gk[0].max() / gk[0].min() > 1.05            # the grid's |k| range crosses several bins
+    hes = npr.hessian(dk, 0.0)
+    d = npr.lpt(dk, hes, gk)
+    for name in ("Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+        a, b = p[name].astype(np.float64), d[name].astype(np.float64)
+        assert np.max(np.abs(a - b)) <= 4e-7 * np.max(np.abs(b)), name
+    # a constant table is the scalar multiplier
+    o2 = oracle_lib.Oracle(n, 2)
+    o2.set_density(dk); o2.set_invgrow(x, y); o2.set_growth(g)
+    o2.compute_fmax(radii, do_lpt=True)
+    p2 = o2.products()
+    for k in range(4):
+        o.set_growth_table(k + 1, np.full(10, np.log10(abs(g[k]))), sign=signs[k])
+    o.displacements(compute_sources=False)
+    pc = o.products()
+    for name in ("Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+        assert np.max(np.abs(pc[name] - p2[name])) <= 2e-7 * np.max(np.abs(p2[name]))
+    # per-radius splines: identical ones change nothing, a different one at radius 1 changes Fmax where Rmax == 1
+    for i in range(3):
+        o2.set_invgrow_radius(i, x, y)
+    o2.compute_fmax(radii, do_lpt=False)
+    assert np.array_equal(o2.products()["Fmax"], p2["Fmax"])
+    x3, y3 = synth.invgrow_table("lcdm", omega0=0.4)
+    o2.set_invgrow_radius(1, x3, y3)
+    o2.compute_fmax(radii, do_lpt=False)
+    p3 = o2.products()
+    per = [npr.sweep(dk, radii[i:i + 1], npr.Spline(*(x3, y3) if i == 1 else (x, y)))[0] for i in range(3)]
+    want = np.full((n, n, n), -10.0, dtype=np.float32)
+    rwant = np.full((n, n, n), -1, dtype=np.int32)
+    for i in range(3):                                  # the running max of src/collapse_times.c:640-652
+        upd = per[i] > want
+        want = np.where(upd, per[i], want)
+        rwant = np.where(upd, np.int32(i), rwant)
+    assert np.any(p3["Fmax"] != p2["Fmax"])
+    ulp = np.spacing(np.maximum(np.abs(want), 1.0).astype(np.float32)).astype(np.float64)
+    assert np.all(np.abs(p3["Fmax"].astype(np.float64) - want) <= 2 * ulp)
+    assert np.mean(p3["Rmax"] != rwant) < 1e-3
