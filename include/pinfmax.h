@@ -167,16 +167,26 @@ int pf_update_products(pf_ctx *ctx, void *products_host, const pf_product_layout
 /* debug / test taps (host copies, fp64): second_derivatives[0][i] of the last
    pf_second_derivatives (i = 0..5 <-> 11,22,33,12,13,23; src/LPT.c:36-44),
    compact [n/nranks][n][n]; LPT source spectra kvector_2LPT/3LPT_1/3LPT_2
-   (which = 0,1,2) gathered to the boundary layout [n/nranks][n][n/2+1][2]
-   (nranks == 1 only). */
+   (which = 0,1,2) regrouped to the boundary layout [n/nranks][n][n/2+1][2]
+   (one all-to-all when nranks > 1; collective). */
 int pf_get_second_derivative(pf_ctx *ctx, int i, double *host);
 int pf_get_kvector(pf_ctx *ctx, int which, double *host);
-int pf_get_density(pf_ctx *ctx, double *host);  /* resident delta(k), boundary layout, nranks == 1 */
-/* stand-alone transforms on the resident buffers (forward_transform /
-   reverse_transform, src/fmax-pfft.c:191-228), host in/out, nranks == 1:
-   unnormalised r2c, and c2r followed by the 1/N^3 normalisation. */
+int pf_get_density(pf_ctx *ctx, double *host);  /* resident delta(k), boundary layout */
+/* The FFT-module seam of the reference (src/pinocchio.h:551-562), host in and host out in the boundary layouts
+   (this rank's x-slab: real [n/nranks][n][n], spectrum [n/nranks][n][n/2+1][2]); collective over the ranks.
+   forward_transform / reverse_transform (src/fmax-pfft.c:191-228): unnormalised r2c, and c2r followed by the
+   1/N^3 normalisation.  Callers outside the hot path: the density writer (src/pinocchio.c:146-150) and
+   ReadWhiteNoise.c:161-222. */
 int pf_forward_transform(pf_ctx *ctx, const double *real_host, double *spec_host);
 int pf_reverse_transform(pf_ctx *ctx, const double *spec_host, double *real_host);
+/* compute_derivative(ThisGrid, first_derivative, second_derivative) (src/fmax-pfft.c:255-441) on a caller-held
+   spectrum: real = c2r[ spec * G * exp(-k^2 rs^2/2) * growth(order) ] / N^3, with G = k_a k_b / k^2 (a, b in 1..3),
+   i k_a / k^2 (one of them 0), -1/k^2 (both 0) (greens_function :444-456, the re/im swap :379-384); the k = 0 mode
+   is left as it is.  rs in cells (Rsmooth); order = ScaleDep.order: 0 no growth, 1..4 the multiplier of
+   pf_set_growth / pf_set_growth_table.  The spectrum on the host is not modified (the reference filters
+   cvector_fft in place; nothing reads it afterwards). */
+int pf_derivative(pf_ctx *ctx, const double *spec_host, int first_derivative, int second_derivative, double rs_cells,
+                  int order, double *real_host);
 /* per-cell solver on a list of Hessians d[6*count] -> F[count] (tests of
    inverse_collapse_time, src/collapse_times.c:679-776), ismooth selects the spline */
 int pf_collapse_cells(pf_ctx *ctx, int ismooth, const double *d, size_t count, double *F);

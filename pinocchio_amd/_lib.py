@@ -75,6 +75,7 @@ PROTOTYPES = {
     "pf_displacements": (C.c_int, [_vp, C.c_int, C.c_int]),
     "pf_fmax_pdf": (C.c_int, [_vp, C.POINTER(C.c_ulonglong)]),
     "pf_get_products": (C.c_int, [_vp, _vp, C.POINTER(ProductLayout)]),
+    "pf_derivative": (C.c_int, [_vp, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_double)]),
     "pf_update_products": (C.c_int, [_vp, _vp, C.POINTER(ProductLayout)]),
     "pf_set_growth_table": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_double, C.c_double, C.c_double]),
     "pf_get_second_derivative": (C.c_int, [_vp, C.c_int, _dp]),

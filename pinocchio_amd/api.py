@@ -159,25 +159,37 @@ class Fmax:
         return out
 
     def kvector(self, which: int) -> np.ndarray:
-        out = np.empty((self.n, self.n, self.n // 2 + 1), dtype=np.complex128)
+        out = np.empty((self.nxl, self.n, self.n // 2 + 1), dtype=np.complex128)
         self._chk(self.L.pf_get_kvector(self.h, which, _dp(out.view(np.float64))))
         return out
 
     def density(self) -> np.ndarray:
-        out = np.empty((self.n, self.n, self.n // 2 + 1), dtype=np.complex128)
+        out = np.empty((self.nxl, self.n, self.n // 2 + 1), dtype=np.complex128)
         self._chk(self.L.pf_get_density(self.h, _dp(out.view(np.float64))))
         return out
 
     def forward_transform(self, real: np.ndarray) -> np.ndarray:
         real = np.ascontiguousarray(real, dtype=np.float64)
-        out = np.empty((self.n, self.n, self.n // 2 + 1), dtype=np.complex128)
+        assert real.shape == (self.nxl, self.n, self.n)
+        out = np.empty((self.nxl, self.n, self.n // 2 + 1), dtype=np.complex128)
         self._chk(self.L.pf_forward_transform(self.h, _dp(real), _dp(out.view(np.float64))))
         return out
 
     def reverse_transform(self, spec: np.ndarray) -> np.ndarray:
         spec = np.ascontiguousarray(spec, dtype=np.complex128)
-        out = np.empty((self.n, self.n, self.n))
+        assert spec.shape == (self.nxl, self.n, self.n // 2 + 1)
+        out = np.empty((self.nxl, self.n, self.n))
         self._chk(self.L.pf_reverse_transform(self.h, _dp(spec.view(np.float64)), _dp(out)))
+        return out
+
+    def compute_derivative(self, spec: np.ndarray, first_derivative: int, second_derivative: int, rs_cells: float = 0.0,
+                           order: int = 0) -> np.ndarray:
+        """compute_derivative (src/fmax-pfft.c:255-441) of a caller-held spectrum slab -> real slab"""
+        spec = np.ascontiguousarray(spec, dtype=np.complex128)
+        assert spec.shape == (self.nxl, self.n, self.n // 2 + 1)
+        out = np.empty((self.nxl, self.n, self.n))
+        self._chk(self.L.pf_derivative(self.h, _dp(spec.view(np.float64)), first_derivative, second_derivative,
+                                       float(rs_cells), int(order), _dp(out)))
         return out
 
     def collapse_cells(self, d: np.ndarray, ismooth: int = -1) -> np.ndarray:

@@ -124,7 +124,7 @@ struct pf_ctx {
 #define PF_NBLK 2048
 #define PF_KNOT_CAP 512
 #define PF_KBIN_CAP 32
-enum { SC_SUM = 0, SC_SUM2 = 1, SC_DC_DK = 2, SC_DC_S2 = 3, SC_POWER = 4, SC_DSCALE = 5, SC_VAR0 = 8 /* 2 per radius */, SC_COUNT = 8 + 2 * PF_MAX_SMOOTH };
+enum { SC_SUM = 0, SC_SUM2 = 1, SC_DC_DK = 2, SC_DC_S2 = 3, SC_POWER = 4, SC_DSCALE = 5, SC_DC_TMP = 6, SC_VAR0 = 8 /* 2 per radius */, SC_COUNT = 8 + 2 * PF_MAX_SMOOTH };
 
 static hipEvent_t ev_get(pf_ctx *c) {
   if (!c->evpool.empty()) { hipEvent_t e = c->evpool.back(); c->evpool.pop_back(); return e; }
@@ -572,31 +572,56 @@ static int reverse_of(pf_ctx *c, void *f) {
 
 static char *staging(pf_ctx *c) { return (char *)c->A[1]; }  // 2 fields of scratch for fp64 host<->device traffic
 
+// boundary layout (this rank's x-slab [nxl][n][nzh] fp64 complex, host) <-> KY layout on the device.  With P > 1 the
+// regrouping is one all-to-all; scratch: the staging fields A[1..2] and receive fields 1, 2 (never A[0], receive
+// field 0 or the Hessian buffers, so the transform taps can run between sweep and displacements).
+static int import_spec(pf_ctx *c, const double *host, void *dst) {
+  const long long nrows = (long long)c->nxl * c->n;
+  HIPCHK(c, hipMemcpyAsync(staging(c), host, (size_t)nrows * c->nzh * 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (c->P == 1) {
+    HIPCHK(c, hipMemsetAsync(dst, 0, c->field_bytes, c->stream));
+    PFCHK(c, pf_launch_spec_import(c->fb, (const double *)staging(c), dst, nrows, c->nzh, c->nzp, c->stream));
+    return 0;
+  }
+  void *rows = recv_field(c, 0, 1), *blocks = recv_field(c, 0, 2);
+  HIPCHK(c, hipMemsetAsync(rows, 0, c->field_bytes, c->stream));
+  PFCHK(c, pf_launch_spec_import(c->fb, (const double *)staging(c), rows, nrows, c->nzh, c->nzp, c->stream));
+  PFCHK(c, pf_launch_to_blocks(c->fb, rows, blocks, c->nxl, c->n, c->nyl, c->nzp, 0, c->stream));
+  PFCHK(c, exchange(c, blocks, dst));
+  return 0;
+}
+static int export_spec(pf_ctx *c, const void *spec, double *host) {
+  const long long nrows = (long long)c->nxl * c->n;
+  const void *rows = spec;
+  if (c->P > 1) {  // KY has x slowest: the block for the owner of an x-slab is contiguous, no pack
+    void *blocks = recv_field(c, 0, 1), *r = recv_field(c, 0, 2);
+    PFCHK(c, exchange(c, spec, blocks));
+    PFCHK(c, pf_launch_to_blocks(c->fb, blocks, r, c->nxl, c->n, c->nyl, c->nzp, 1, c->stream));
+    rows = r;
+  }
+  PFCHK(c, pf_launch_spec_export(c->fb, rows, (double *)staging(c), nrows, c->nzh, c->nzp, c->stream));
+  HIPCHK(c, hipMemcpyAsync(host, staging(c), (size_t)nrows * c->nzh * 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+// Re of the k = 0 mode / N^3 on every rank: the k-filter leaves that mode untouched (k^2 = 0, src/fmax-pfft.c:368), so a
+// second derivative carries it as a constant; it lives on the rank that owns x = 0
+static int dc_of_host_spec(pf_ctx *c, const double *host, int slot) {
+  const double dcv = (c->rank == 0) ? host[0] / ((double)c->n * c->n * c->n) : 0.0;
+  HIPCHK(c, hipMemcpyAsync(c->scal + slot, &dcv, sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  PFCHK(c, allreduce_dev(c, c->scal + slot, 1, 0));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 // ------------------------------------------------------------------ inputs --
 extern "C" int pf_set_density(pf_ctx *c, const double *kd) {
   if (!c || !kd) return pf_fail(0, "pf_set_density: null argument");
   PhaseTimer pt(c, 3);
   // boundary layout: this rank's x-slab [nxl][n][nzh] (non-transposed PFFT output, src/fmax-pfft.c:366)
-  const long long nrows = (long long)c->nxl * c->n;
-  const size_t hb = (size_t)nrows * c->nzh * 2 * sizeof(double);
-  HIPCHK(c, hipMemcpyAsync(staging(c), kd, hb, hipMemcpyHostToDevice, c->stream));
-  // DC mode: untouched by the k-filter (k^2 = 0, src/fmax-pfft.c:368), so it adds Re(dk[0])/N^3 to every second
-  // derivative; it lives on the rank that owns x = 0
-  const double dcv = (c->rank == 0) ? kd[0] / ((double)c->n * c->n * c->n) : 0.0;
-  if (c->P == 1) {
-    HIPCHK(c, hipMemsetAsync(c->dk, 0, c->field_bytes, c->stream));
-    PFCHK(c, pf_launch_spec_import(c->fb, (const double *)staging(c), c->dk, nrows, c->nzh, c->nzp, c->stream));
-  } else {
-    // x-slab -> k-space y-slab (KY): regroup into the P destination blocks, one all-to-all
-    HIPCHK(c, hipMemsetAsync(c->B[0], 0, c->field_bytes, c->stream));
-    PFCHK(c, pf_launch_spec_import(c->fb, (const double *)staging(c), c->B[0], nrows, c->nzh, c->nzp, c->stream));
-    PFCHK(c, pf_launch_to_blocks(c->fb, c->B[0], c->A[0], c->nxl, c->n, c->nyl, c->nzp, c->stream));
-    PFCHK(c, exchange(c, c->A[0], c->dk));
-  }
-  HIPCHK(c, hipMemcpyAsync(c->scal + SC_DC_DK, &dcv, sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  PFCHK(c, allreduce_dev(c, c->scal + SC_DC_DK, 1, 0));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  PFCHK(c, import_spec(c, kd, c->dk));
+  PFCHK(c, dc_of_host_spec(c, kd, SC_DC_DK));
   c->have_density = true; c->have_hessian = false; c->have_sources = false;
   return 0;
 }
@@ -919,14 +944,6 @@ extern "C" int pf_get_second_derivative(pf_ctx *c, int i, double *host) {
   return 0;
 }
 
-static int export_spec(pf_ctx *c, const void *spec, double *host) {
-  if (c->P > 1) return pf_fail(c->rank, "spectrum export to the boundary layout needs nranks == 1");
-  const long long nrows = (long long)c->n * c->n;
-  PFCHK(c, pf_launch_spec_export(c->fb, spec, (double *)staging(c), nrows, c->nzh, c->nzp, c->stream));
-  HIPCHK(c, hipMemcpyAsync(host, staging(c), (size_t)nrows * c->nzh * 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  return 0;
-}
 extern "C" int pf_get_kvector(pf_ctx *c, int which, double *host) {
   if (!c || !host || which < 0 || which > 2) return pf_fail(0, "pf_get_kvector: bad argument");
   if (!c->have_sources) return pf_fail(c->rank, "pf_get_kvector: LPT sources not computed");
@@ -938,26 +955,70 @@ extern "C" int pf_get_density(pf_ctx *c, double *host) {
   return export_spec(c, c->dk, host);
 }
 
+static int import_real(pf_ctx *c, const double *host, void *dst) {
+  const long long nrows = (long long)c->nxl * c->n;
+  HIPCHK(c, hipMemcpyAsync(staging(c), host, (size_t)nrows * c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  PFCHK(c, pf_launch_real_import(c->fb, (const double *)staging(c), dst, nrows, c->n, 2 * c->nzp, c->stream));
+  return 0;
+}
+static int export_real(pf_ctx *c, const void *src, double *host) {
+  const long long nrows = (long long)c->nxl * c->n;
+  PFCHK(c, pf_launch_real_export(c->fb, src, (double *)staging(c), nrows, c->n, 2 * c->nzp, c->stream));
+  HIPCHK(c, hipMemcpyAsync(host, staging(c), (size_t)nrows * c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
 extern "C" int pf_forward_transform(pf_ctx *c, const double *real_host, double *spec_host) {
   if (!c || !real_host || !spec_host) return 1;
-  if (c->P > 1) return pf_fail(c->rank, "pf_forward_transform: host in/out needs nranks == 1");
-  const long long nrows = (long long)c->n * c->n;
-  HIPCHK(c, hipMemcpyAsync(staging(c), real_host, (size_t)nrows * c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  PFCHK(c, pf_launch_real_import(c->fb, (const double *)staging(c), c->A[0], nrows, c->n, 2 * c->nzp, c->stream));
-  PFCHK(c, forward_of(c, c->A[0]));
-  return export_spec(c, c->A[0], spec_host);
+  // P > 1: the y-pass writes the send blocks into A[0], so the field itself lives in receive field 0
+  void *f = c->P > 1 ? recv_field(c, 0, 0) : c->A[0];
+  PFCHK(c, import_real(c, real_host, f));
+  PFCHK(c, forward_of(c, f));
+  return export_spec(c, f, spec_host);
 }
 extern "C" int pf_reverse_transform(pf_ctx *c, const double *spec_host, double *real_host) {
   if (!c || !real_host || !spec_host) return 1;
-  if (c->P > 1) return pf_fail(c->rank, "pf_reverse_transform: host in/out needs nranks == 1");
-  const long long nrows = (long long)c->n * c->n;
-  HIPCHK(c, hipMemcpyAsync(staging(c), spec_host, (size_t)nrows * c->nzh * 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  PFCHK(c, pf_launch_spec_import(c->fb, (const double *)staging(c), c->A[0], nrows, c->nzh, c->nzp, c->stream));
+  PFCHK(c, import_spec(c, spec_host, c->A[0]));
   PFCHK(c, reverse_of(c, c->A[0]));
-  PFCHK(c, pf_launch_real_export(c->fb, c->A[0], (double *)staging(c), nrows, c->n, 2 * c->nzp, c->stream));
-  HIPCHK(c, hipMemcpyAsync(real_host, staging(c), (size_t)nrows * c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  return 0;
+  return export_real(c, c->A[0], real_host);
+}
+
+// compute_derivative (src/fmax-pfft.c:255-441) on a caller-held spectrum: one component, host in and out.  The
+// multiplier k_a k_b / k^2 (or i k_a / k^2, or -1/k^2) factorises over the three passes like the shared-pass
+// transforms of the sweep: x-pass applies the window, 1/k^2, the growth of ScaleDep.order and its own k power.
+extern "C" int pf_derivative(pf_ctx *c, const double *spec_host, int first_derivative, int second_derivative, double rs_cells,
+                             int order, double *real_host) {
+  if (!c || !spec_host || !real_host) return pf_fail(0, "pf_derivative: null argument");
+  const int a = first_derivative, b = second_derivative;
+  if (a < 0 || a > 3 || b < 0 || b > 3) return pf_fail(c->rank, "pf_derivative: components (%d,%d) not in 0..3", a, b);
+  if (order < 0 || order > 4) return pf_fail(c->rank, "pf_derivative: ScaleDep.order %d not in 0..4", order);
+  const bool swap = (a == 0) != (b == 0);  // first derivative: multiply by i (src/fmax-pfft.c:299-300, 379-384)
+  int mul[3] = {PF_MUL_ONE, PF_MUL_ONE, PF_MUL_ONE};
+  for (int ax = 1; ax <= 3; ax++) {
+    const int cnt = (a == ax) + (b == ax);
+    mul[ax - 1] = cnt == 2 ? PF_MUL_K2 : cnt == 1 ? (swap ? PF_MUL_IK : PF_MUL_K) : PF_MUL_ONE;
+  }
+  double growth = order ? c->growth[order - 1] : 1.0;
+  if (a == 0 && b == 0) growth = -growth;     // greens_function: -1/k^2 (src/fmax-pfft.c:449-450)
+  void *f = c->A[0];
+  PFCHK(c, import_spec(c, spec_host, f));
+  PFCHK(c, dc_of_host_spec(c, spec_host, SC_DC_TMP));
+  if (order && c->gt_n[order - 1]) {
+    const int o = order - 1;
+    PFCHK(c, pf_launch_apply_growth(c->fb, f, f, c->n, c->nyl, c->nzh, c->nzp, c->rank * c->nyl, c->gtab + o * PF_KBIN_CAP, c->gt_n[o],
+                                    c->gt_logkmin[o], c->gt_dlogk[o], c->gt_sign[o], c->stream));
+    growth = (a == 0 && b == 0) ? -1.0 : 1.0;
+  }
+  const Job xj[1] = {{f, f, mul[0]}};
+  PFCHK(c, xpass(c, KS_XPASS_PLAIN, +1, 1, xj, 1, rs_cells, growth, 1));
+  const void *R = f;
+  if (c->P > 1) { PFCHK(c, exchange(c, f, c->recvA)); R = c->recvA; }
+  const Job yj[1] = {{R, f, mul[1]}};
+  PFCHK(c, ypass(c, KS_YPASS_PLAIN, +1, 1, yj, true, false, 1));
+  const ZJob zj[1] = {{f, f, mul[2], 0}};
+  // the untouched k = 0 mode survives only without the swap (then Im of the DC mode is ignored by the c2r)
+  PFCHK(c, zpass_c2r(c, KS_ZPASS_PLAIN, 1, zj, swap ? nullptr : c->scal + SC_DC_TMP));
+  return export_real(c, f, real_host);
 }
 
 extern "C" int pf_collapse_cells(pf_ctx *c, int ismooth, const double *d, size_t count, double *F) {

@@ -274,16 +274,17 @@ __global__ void k_real_export(const F *src, double *dst, long long nrows, int n,
     dst[i] = (double)src[row * pitch + (i - row * n)];
   }
 }
-// x-slab rows [xl][y][nzp] -> the P all-to-all blocks [q][xl][yl][nzp], y = q*nyl + yl
+// x-slab rows [xl][y][nzp] -> the P all-to-all blocks [q][xl][yl][nzp], y = q*nyl + yl (back: the inverse gather)
 template <typename F>
-__global__ void k_to_blocks(const F *src, F *dst, int nxl, int n, int nyl, int nzp) {
+__global__ void k_to_blocks(const F *src, F *dst, int nxl, int n, int nyl, int nzp, int back) {
   const long long total = (long long)nxl * n * nzp * 2;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long r = i % (2 * nzp);
     const long long row = i / (2 * nzp);
     const int y = (int)(row % n), xl = (int)(row / n);
     const int q = y / nyl, yl = y - q * nyl;
-    dst[(((long long)q * nxl + xl) * nyl + yl) * 2 * nzp + r] = src[i];
+    const long long b = (((long long)q * nxl + xl) * nyl + yl) * 2 * nzp + r;
+    if (back) dst[i] = src[b]; else dst[b] = src[i];
   }
 }
 
@@ -384,10 +385,10 @@ int pf_launch_real_export(int fb, const void *src, double *dst, long long nrows,
   else hipLaunchKernelGGL(k_real_export<float>, dim3(g), dim3(PF_CELL_BLOCK), 0, st, (const float *)src, dst, nrows, n, pitch);
   return PF_CHECK_LAUNCH();
 }
-int pf_launch_to_blocks(int fb, const void *src, void *dst, int nxl, int n, int nyl, int nzp, hipStream_t st) {
+int pf_launch_to_blocks(int fb, const void *src, void *dst, int nxl, int n, int nyl, int nzp, int back, hipStream_t st) {
   const int g = pf_grid_for((size_t)nxl * n * nzp * 2);
-  if (fb == 8) hipLaunchKernelGGL(k_to_blocks<double>, dim3(g), dim3(PF_CELL_BLOCK), 0, st, (const double *)src, (double *)dst, nxl, n, nyl, nzp);
-  else hipLaunchKernelGGL(k_to_blocks<float>, dim3(g), dim3(PF_CELL_BLOCK), 0, st, (const float *)src, (float *)dst, nxl, n, nyl, nzp);
+  if (fb == 8) hipLaunchKernelGGL(k_to_blocks<double>, dim3(g), dim3(PF_CELL_BLOCK), 0, st, (const double *)src, (double *)dst, nxl, n, nyl, nzp, back);
+  else hipLaunchKernelGGL(k_to_blocks<float>, dim3(g), dim3(PF_CELL_BLOCK), 0, st, (const float *)src, (float *)dst, nxl, n, nyl, nzp, back);
   return PF_CHECK_LAUNCH();
 }
 int pf_launch_extract_dc(int fb, const void *spec, double scale, double *out, hipStream_t st) {

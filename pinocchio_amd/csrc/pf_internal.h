@@ -151,7 +151,7 @@ int pf_launch_spec_import(int field_bytes, const double *src, void *dst, long lo
 int pf_launch_spec_export(int field_bytes, const void *src, double *dst, long long nrows, int nzh, int nzp, hipStream_t st);
 int pf_launch_real_import(int field_bytes, const double *src, void *dst, long long nrows, int n, long long pitch, hipStream_t st);
 int pf_launch_real_export(int field_bytes, const void *src, double *dst, long long nrows, int n, long long pitch, hipStream_t st);
-int pf_launch_to_blocks(int field_bytes, const void *src, void *dst, int nxl, int n, int nyl, int nzp, hipStream_t st);
+int pf_launch_to_blocks(int field_bytes, const void *src, void *dst, int nxl, int n, int nyl, int nzp, int back, hipStream_t st);
 int pf_launch_extract_dc(int field_bytes, const void *spec, double scale, double *out, hipStream_t st);
 
 // ---- synthetic density (pf_synth.hip) ----

@@ -19,6 +19,16 @@
  *   char *fdate(void)                        fmax.c:261           same string
  *   (optional) int pf_compat_genic(double)   GenIC.c:73           GenIC_large on the device instead of the host
  *
+ * The FFT-module seam (src/pinocchio.h:551-562), which the density writer (src/pinocchio.c:146-150) and
+ * ReadWhiteNoise.c:161-222 also call, works on the reference's host arrays cvector_fft / rvector_fft:
+ *   double forward_transform(int), reverse_transform(int)   fmax-pfft.c:191-228    pf_forward/reverse_transform
+ *   int  compute_derivative(int,int,int)       fmax-pfft.c:255      pf_derivative
+ *   void write_in/from_cvector, _rvector       fmax-pfft.c:459-560  flat host copies (unchanged semantics)
+ *   void write_from_rvector_to_products        fmax-pfft.c:563-631  host loop
+ *   int  compute_first_derivatives(double,int,int,double*)  fmax.c:193   the three above, per axis
+ *   int  compute_second_derivatives(double,int)             fmax.c:225   pf_second_derivatives + 6 downloads
+ * Each transform makes a host round trip: a bring-up / tools seam, not what compute_fmax uses.
+ *
  * Build modes: stand-alone (default; globals from pf_compat_types.h, defined in
  * pf_compat_globals.c) or -DPF_IN_PINOCCHIO_TREE inside the reference source
  * tree (globals and cosmology from the reference itself, MPI for the
@@ -451,5 +461,96 @@ int read_dumps(void) {
   }
   if (fread(products, sizeof(product_data), MyGrids[0].total_local_size, file) != MyGrids[0].total_local_size) return 1;
   fclose(file);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------------------
+ * The FFT-module seam on the reference's host arrays (src/fmax-pfft.c:191-228, 255-441, 459-631; src/fmax.c:193-258)
+ * ------------------------------------------------------------------------------------------------------------ */
+void write_in_cvector(int ThisGrid, double *vector) {
+  memcpy(cvector_fft[ThisGrid], vector, sizeof(double) * MyGrids[ThisGrid].total_local_size_fft);
+}
+void write_from_cvector(int ThisGrid, double *vector) {
+  memcpy(vector, cvector_fft[ThisGrid], sizeof(double) * MyGrids[ThisGrid].total_local_size_fft);
+}
+void write_in_rvector(int ThisGrid, double *vector) {
+  memcpy(rvector_fft[ThisGrid], vector, sizeof(double) * MyGrids[ThisGrid].total_local_size);
+}
+void write_from_rvector(int ThisGrid, double *vector) {
+  memcpy(vector, rvector_fft[ThisGrid], sizeof(double) * MyGrids[ThisGrid].total_local_size);
+}
+
+/* elapsed seconds, like the reference; a failure is reported on stdout and returns a negative time */
+double forward_transform(int ThisGrid) {
+  double t = pf_wtime();
+  if ((!pf_context && compute_fft_plans()) || pf_forward_transform(pf_context, rvector_fft[ThisGrid], (double *)cvector_fft[ThisGrid])) {
+    printf("ERROR on task %d: forward_transform failed: %s\n", ThisTask, pf_last_error());
+    return -1.0;
+  }
+  return pf_wtime() - t;
+}
+double reverse_transform(int ThisGrid) {
+  double t = pf_wtime();
+  if ((!pf_context && compute_fft_plans()) || pf_reverse_transform(pf_context, (double *)cvector_fft[ThisGrid], rvector_fft[ThisGrid])) {
+    printf("ERROR on task %d: reverse_transform failed: %s\n", ThisTask, pf_last_error());
+    return -1.0;
+  }
+  return pf_wtime() - t;
+}
+
+/* cvector_fft[ThisGrid] -> rvector_fft[ThisGrid]; reads the reference's Rsmooth, ScaleDep.order, ScaleDep.redshift */
+int compute_derivative(int ThisGrid, int first_derivative, int second_derivative) {
+  double t = pf_wtime();
+  if (!pf_context && compute_fft_plans()) return 1;
+  if (ScaleDep.order >= 1 && pf_upload_growth(ScaleDep.redshift)) return 1;
+  if (pf_derivative(pf_context, (double *)cvector_fft[ThisGrid], first_derivative, second_derivative, Rsmooth, ScaleDep.order,
+                    rvector_fft[ThisGrid]))
+    return 1;
+  cputime.fft += pf_wtime() - t;
+  return 0;
+}
+
+void write_from_rvector_to_products(int ThisGrid, int ia, int order) {
+  unsigned int index;
+  const unsigned int nloc = MyGrids[ThisGrid].total_local_size;
+  const double *r = rvector_fft[ThisGrid];
+  switch (order) {
+    case 1: for (index = 0; index < nloc; index++) products[index].Vel[ia] = r[index]; break;
+    case 2: for (index = 0; index < nloc; index++) products[index].Vel_2LPT[ia] = r[index]; break;
+    case 3: for (index = 0; index < nloc; index++) products[index].Vel_3LPT_1[ia] = r[index]; break;
+    case 4: for (index = 0; index < nloc; index++) products[index].Vel_3LPT_2[ia] = r[index]; break;
+    default: break;
+  }
+}
+
+/* src/fmax.c:193-222 */
+int compute_first_derivatives(double R, int ThisGrid, int order, double *vector) {
+  int ia;
+  double timetmp = 0;
+  Rsmooth = R / MyGrids[ThisGrid].CellSize;
+  for (ia = 1; ia <= 3; ia++) {
+    double tmp;
+    if (!ThisTask) printf("[%s] Computing 1st derivative: %d\n", fdate(), ia);
+    tmp = pf_wtime();
+    write_in_cvector(ThisGrid, vector);
+    timetmp += pf_wtime() - tmp;
+    if (compute_derivative(ThisGrid, ia, 0)) return 1;
+    tmp = pf_wtime();
+    write_from_rvector_to_products(ThisGrid, ia - 1, order);
+    timetmp += pf_wtime() - tmp;
+  }
+  cputime.mem_transf += timetmp;
+  return 0;
+}
+
+/* src/fmax.c:225-258: the six fields land in second_derivatives[ThisGrid][0..5] on the host; the shared-pass
+   transforms of the sweep are used (one upload of kdensity, six downloads) */
+int compute_second_derivatives(double R, int ThisGrid) {
+  int i;
+  Rsmooth = R / MyGrids[ThisGrid].CellSize;
+  if (pf_upload_inputs()) return 1;
+  if (pf_second_derivatives(pf_context, Rsmooth)) return 1;
+  for (i = 0; i < 6; i++)
+    if (pf_get_second_derivative(pf_context, i, second_derivatives[ThisGrid][i])) return 1;
   return 0;
 }

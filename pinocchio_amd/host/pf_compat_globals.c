@@ -21,3 +21,9 @@ double (*pf_GrowingMode_3LPT_1)(double, double) = 0;
 double (*pf_GrowingMode_3LPT_2)(double, double) = 0;
 int pf_compat_scale_dependent = 0;
 pf_spline_knots pf_invgrow_knots_radius[64];
+double **density = 0;
+double ***first_derivatives = 0, ***second_derivatives = 0;
+static pfft_complex *cvector_slots[1] = {0};
+static double *rvector_slots[1] = {0};
+pfft_complex **cvector_fft = cvector_slots;
+double **rvector_fft = rvector_slots;

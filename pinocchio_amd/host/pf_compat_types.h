@@ -78,9 +78,17 @@ typedef struct /* the tags of param_data (:311-352) the path uses */
 /* gsl_spline as far as my_spline_eval dereferences it (src/cosmo.c:2016-2027) */
 typedef struct { size_t size; double *x, *y; } pf_spline_knots;
 
+typedef double pfft_complex[2];
+
 extern int ThisTask, NTasks;
 extern product_data *products;
 extern double **kdensity;
+/* host work arrays of the FFT-module seam (src/pinocchio.h:270-272, 310-311; allocated by the reference in
+   src/allocations.c:327-383): only the fine-seam functions below touch them */
+extern double **density;
+extern double ***first_derivatives, ***second_derivatives;
+extern pfft_complex **cvector_fft;
+extern double **rvector_fft;
 extern smoothing_data Smoothing;
 extern grid_data *MyGrids;
 extern ScaleDep_data ScaleDep;

@@ -318,3 +318,82 @@ def test_reentrant_displacements_recompute_build(tmp_path):
     assert np.array_equal(recs["Fmax"], first["Fmax"]) and np.array_equal(recs["Rmax"], first["Rmax"])
     ulp = np.spacing(np.maximum(np.abs(want[0.0]["Fmax"]), 1.0).astype(np.float32)).astype(np.float64)
     assert np.mean(np.abs(first["Fmax"].astype(np.float64) - want[0.0]["Fmax"]) > 2 * ulp) < 1e-4
+
+
+@pytest.mark.gpu
+def test_fft_module_seam_like_the_density_writer(lib):
+    """src/pinocchio.c:146-150: write_in_cvector(kdensity); reverse_transform; write_from_rvector(density) -- and the
+    per-component drivers compute_first_derivatives / compute_second_derivatives (src/fmax.c:193-258) on host arrays"""
+    import np_restatement as npr
+    n, cell = 32, 2.0
+    dk = np.ascontiguousarray(synth.make_density(n, seed=13))
+    x, y = synth.invgrow_table("lcdm")
+    g = synth.growth_multipliers()
+    grid = C.cast(C.c_void_p.in_dll(lib, "MyGrids"), C.POINTER(Grid)).contents
+    for i in range(3):
+        grid.GSglobal[i] = n
+    grid.Ntotal = n ** 3
+    grid.BoxSize = n * cell
+    assert lib.set_one_grid(0) == 0
+    cvec = np.zeros((n, n, n // 2 + 1), dtype=np.complex128)
+    rvec = np.zeros(2 * n * n * (n // 2 + 1))          # the reference sizes rvector_fft like the complex array
+    C.cast(C.c_void_p.in_dll(lib, "cvector_fft"), C.POINTER(C.c_void_p))[0] = cvec.ctypes.data
+    C.cast(C.c_void_p.in_dll(lib, "rvector_fft"), C.POINTER(C.c_void_p))[0] = rvec.ctypes.data
+    kd = C.cast(C.c_void_p.in_dll(lib, "kdensity"), C.POINTER(C.c_void_p))
+    kd[0] = dk.ctypes.data
+    kn = Knots.in_dll(lib, "pf_invgrow_knots")
+    kn.size = len(x)
+    kn.x = x.ctypes.data_as(C.POINTER(C.c_double))
+    kn.y = y.ctypes.data_as(C.POINTER(C.c_double))
+    fns = [GROWTH_FN(lambda z, k, v=v: float(v)) for v in g]
+    for name, fn in zip(("pf_GrowingMode", "pf_GrowingMode_2LPT", "pf_GrowingMode_3LPT_1", "pf_GrowingMode_3LPT_2"), fns):
+        C.c_void_p.in_dll(lib, name).value = C.cast(fn, C.c_void_p).value
+    dp = C.POINTER(C.c_double)
+    lib.write_in_cvector.argtypes = [C.c_int, dp]
+    lib.write_from_cvector.argtypes = [C.c_int, dp]
+    lib.write_in_rvector.argtypes = [C.c_int, dp]
+    lib.write_from_rvector.argtypes = [C.c_int, dp]
+    lib.reverse_transform.restype = C.c_double
+    lib.forward_transform.restype = C.c_double
+    lib.compute_first_derivatives.argtypes = [C.c_double, C.c_int, C.c_int, dp]
+    lib.compute_second_derivatives.argtypes = [C.c_double, C.c_int]
+
+    assert lib.compute_fft_plans() == 0
+    density = np.zeros((n, n, n))
+    lib.write_in_cvector(0, dk.view(np.float64).ctypes.data_as(dp))
+    assert lib.reverse_transform(0) >= 0.0
+    lib.write_from_rvector(0, density.ctypes.data_as(dp))
+    want = np.fft.irfftn(dk, s=(n, n, n), axes=(0, 1, 2))
+    assert np.max(np.abs(density - want)) <= 1e-13 * np.max(np.abs(want))
+    # and back: ReadWhiteNoise.c:161-222 (forward_transform, write_from_cvector)
+    lib.write_in_rvector(0, want.ctypes.data_as(dp))
+    assert lib.forward_transform(0) >= 0.0
+    spec = np.zeros_like(dk)
+    lib.write_from_cvector(0, spec.view(np.float64).ctypes.data_as(dp))
+    ref = np.fft.rfftn(want, axes=(0, 1, 2))
+    assert np.max(np.abs(spec - ref)) <= 1e-12 * np.max(np.abs(ref))
+
+    prod = np.zeros(n ** 3 * 56 + 64, dtype=np.uint8)
+    prod = prod[(-prod.ctypes.data) % 32:][:n ** 3 * 56]
+    C.c_void_p.in_dll(lib, "products").value = prod.ctypes.data
+    sd = ScaleDep.in_dll(lib, "ScaleDep")
+    sd.order, sd.redshift = 1, 0.0
+    assert lib.compute_first_derivatives(0.0, 0, 1, dk.view(np.float64).ctypes.data_as(dp)) == 0
+    p = prod.view(oracle_lib.PRODUCT_DTYPE).reshape(n, n, n)
+    for ia in (1, 2, 3):
+        w = npr.derivative(dk, 0.0, ia, 0, g[0])
+        assert np.max(np.abs(p["Vel"][..., ia - 1] - w)) <= 2e-7 * np.max(np.abs(w))
+    assert not p["Vel_2LPT"].any()
+
+    hes = [np.zeros((n, n, n)) for _ in range(6)]
+    ptrs = (dp * 6)(*[h.ctypes.data_as(dp) for h in hes])
+    pp = (C.POINTER(dp) * 1)(C.cast(ptrs, C.POINTER(dp)))
+    C.c_void_p.in_dll(lib, "second_derivatives").value = C.cast(pp, C.c_void_p).value
+    sd.order = 0
+    assert lib.compute_second_derivatives(3.0, 0) == 0     # R in Mpc: Rsmooth = R / CellSize = 1.5 cells
+    o = oracle_lib.Oracle(n, 0)
+    o.set_density(dk)
+    ho = o.second_derivatives(1.5)
+    for i in range(6):
+        assert np.max(np.abs(hes[i] - ho[i])) <= 1e-12 * np.max(np.abs(ho[i]))
+    assert lib.finalize_fft() == 0

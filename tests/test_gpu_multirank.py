@@ -233,3 +233,36 @@ def test_genic_slabs_match_single_rank(api):
     for r in range(P):
         assert np.allclose(res[r][0], tv1, rtol=1e-13)
         assert np.array_equal(res[r][1], fm1[r * nxl:(r + 1) * nxl])
+
+
+def test_fft_module_seam_on_slabs(api):
+    """forward / reverse transform, compute_derivative and the spectrum taps with host slabs in the boundary layout on
+    P ranks (import and export regroup through one all-to-all each): bitwise the single-rank slabs"""
+    n, P = 32, 4
+    nxl = n // P
+    rng = np.random.default_rng(5)
+    real = rng.standard_normal((n, n, n))
+    dk = synth.make_density(n, seed=9)
+    dk[0, 0, 0] = -0.2 * n ** 3
+    with api.Fmax(n) as f1:
+        spec1 = f1.forward_transform(real)
+        back1 = f1.reverse_transform(dk)
+        d12 = f1.compute_derivative(dk, 1, 2, 1.0, 0)
+        d30 = f1.compute_derivative(dk, 3, 0, 0.0, 1)
+        f1.set_density(dk)
+        dens1 = f1.density()
+
+    def body(f, r):
+        sl = slice(r * nxl, (r + 1) * nxl)
+        out = [f.forward_transform(real[sl]), f.reverse_transform(dk[sl]), f.compute_derivative(dk[sl], 1, 2, 1.0, 0),
+               f.compute_derivative(dk[sl], 3, 0, 0.0, 1)]
+        f.set_density(dk[sl])
+        out.append(f.density())
+        return out
+
+    res = run_ranks(api, n, P, body)
+    for r in range(P):
+        sl = slice(r * nxl, (r + 1) * nxl)
+        for got, want in zip(res[r], (spec1, back1, d12, d30, dens1)):
+            assert np.array_equal(got, want[sl])
+    assert np.array_equal(dens1, dk)

@@ -505,3 +505,32 @@ def test_update_products_merges_into_recompute_records(api):
         assert np.array_equal(recs[name], p1[name]) and np.array_equal(recs[name + "_prev"], p0[name])
         assert np.allclose(p1[name], 0.5 * p0[name], rtol=2e-7, atol=0)
     assert np.array_equal(recs["Fmax"], p0["Fmax"] + np.float32(100.0)) and np.array_equal(recs["Rmax"], p0["Rmax"])
+
+
+def test_fft_module_seam_single_components(api):
+    """pf_derivative = compute_derivative(ThisGrid, a, b) (src/fmax-pfft.c:255-441) for every (a, b) the reference can be
+    called with: second derivatives, first derivatives (re/im swap), the potential (-1/k^2), with smoothing and growth"""
+    import np_restatement as npr
+    n = 32
+    dk = synth.make_density(n, seed=77)
+    dk[0, 0, 0] = 0.37 * n ** 3            # the k = 0 mode is left untouched by the filter
+    g = synth.growth_multipliers()
+    o = oracle_lib.Oracle(n, 0)
+    o.set_density(dk)
+    hes_o = o.second_derivatives(1.3)
+    with api.Fmax(n) as f:
+        f.set_growth(g)
+        for (a, b, rs, order) in [(1, 1, 1.3, 0), (2, 2, 1.3, 0), (3, 3, 1.3, 0), (1, 2, 1.3, 0), (1, 3, 1.3, 0), (2, 3, 1.3, 0),
+                                  (2, 1, 0.0, 0), (1, 0, 0.0, 1), (2, 0, 0.0, 2), (3, 0, 0.7, 3), (0, 3, 0.0, 4), (0, 0, 0.0, 0),
+                                  (0, 0, 2.0, 1)]:
+            got = f.compute_derivative(dk, a, b, rs, order)
+            growth = g[order - 1] if order else 1.0
+            want = npr.derivative(dk, rs, a, b, growth)
+            if a == 0 and b == 0:            # greens_function returns -1/k^2 for (0,0) (src/fmax-pfft.c:449-450)
+                want = 2.0 * dk[0, 0, 0].real / n ** 3 - want
+            assert np.max(np.abs(got - want)) <= 1e-12 * np.max(np.abs(want)), (a, b, rs, order)
+            if order == 0 and rs == 1.3:
+                ider = a if a == b else a + b + 1
+                assert np.max(np.abs(got - hes_o[ider - 1])) <= 1e-12 * np.max(np.abs(hes_o[ider - 1]))
+        with pytest.raises(api.PinfmaxError):
+            f.compute_derivative(dk, 4, 0)
