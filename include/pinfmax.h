@@ -164,6 +164,16 @@ int pf_get_products(pf_ctx *ctx, void *products_host, const pf_product_layout *l
    build filled by shift_all_displacements, src/fragment.c:832-850).  Used after a re-entrant
    compute_displacements(0, 0, z) (src/fragment.c:398-410), which rewrites only the Vel* fields. */
 int pf_update_products(pf_ctx *ctx, void *products_host, const pf_product_layout *layout);
+/* First stage of fragmentation on the device: the cells of this rank's slab with Fmax >= flast (update_distmap,
+   src/distribute.c:695) in order of descending Fmax (sort_and_organize, src/fragment.c:484-503; index_compare_F
+   :118-126; equal keys, which qsort leaves unspecified, by ascending index).  cell_index = z + n*(y + n*x_local)
+   (src/pinocchio.h:84-85).  *count receives the number selected; the first min(*count, capacity) entries are
+   copied (either array may be NULL). */
+int pf_select_sorted(pf_ctx *ctx, float flast, size_t capacity, unsigned int *cell_index, float *fmax, size_t *count);
+/* Per-particle payload of one block of the "timeless snapshot" (write_timeless_snapshot, src/write_snapshot.c:207-342)
+   for this rank's slab, from the SoA columns in HBM: name = "ID  " (1 + global index as MYIDTYPE of id_bytes = 4 or 8,
+   :648-664), "FMAX" float, "RMAX" int, "ZEL " / "2LPT" / "31PT" / "32PT" float[3] per particle (:700-855). */
+int pf_get_block(pf_ctx *ctx, const char *name, int id_bytes, void *host);
 /* debug / test taps (host copies, fp64): second_derivatives[0][i] of the last
    pf_second_derivatives (i = 0..5 <-> 11,22,33,12,13,23; src/LPT.c:36-44),
    compact [n/nranks][n][n]; LPT source spectra kvector_2LPT/3LPT_1/3LPT_2

@@ -817,3 +817,26 @@ int orc_r2c(orc_ctx *c, const double *real_in, double *spec_out) { r2c_3d(c, rea
 void orc_timers(orc_ctx *c, double t[5]) {
   t[0] = c->t_total; t[1] = c->t_deriv; t[2] = c->t_fft; t[3] = c->t_coll; t[4] = c->t_lpt;
 }
+
+/* ----------------------------------------------------------------------------------------------------------------
+ * Row f-2: the first stage of fragmentation on the products -- selection Fmax >= Flast (update_distmap,
+ * src/distribute.c:695) and sort_and_organize's first qsort (src/fragment.c:484-503) with index_compare_F (:118-126).
+ * qsort leaves the order of equal keys unspecified; the comparator below breaks ties by ascending index so that the
+ * result is unique (and is one of the orders the reference's qsort may return).
+ * ---------------------------------------------------------------------------------------------------------------- */
+static const orc_product *sort_products;
+static int index_compare_F(const void *a, const void *b) {
+  const unsigned int ia = *(const unsigned int *)a, ib = *(const unsigned int *)b;
+  if (sort_products[ia].Fmax == sort_products[ib].Fmax) return (ia > ib) - (ia < ib);
+  else if (sort_products[ia].Fmax > sort_products[ib].Fmax) return -1;
+  else return 1;
+}
+size_t orc_select_sorted(orc_ctx *c, float flast, unsigned int *indices, float *fmax) {
+  size_t m = 0;
+  for (size_t i = 0; i < c->n_r; i++)
+    if (c->products[i].Fmax >= flast) indices[m++] = (unsigned int)i;
+  sort_products = c->products;
+  qsort((void *)indices, m, sizeof(unsigned int), index_compare_F);
+  for (size_t i = 0; i < m; i++) fmax[i] = c->products[indices[i]].Fmax;
+  return m;
+}

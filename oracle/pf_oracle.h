@@ -94,4 +94,8 @@ void orc_timers(orc_ctx *c, double t[5]);
 #ifdef __cplusplus
 }
 #endif
+/* Fmax >= flast (src/distribute.c:695), indices by descending Fmax (src/fragment.c:484-503, 118-126; ties by index).
+   indices / fmax hold n^3 entries; returns the number selected. */
+size_t orc_select_sorted(orc_ctx *c, float flast, unsigned int *indices, float *fmax);
+
 #endif

@@ -153,6 +153,31 @@ class Fmax:
         self._chk(self.L.pf_update_products(self.h, records.ctypes.data_as(C.c_void_p), C.byref(layout)))
         return records
 
+    def select_sorted(self, flast: float):
+        """cells with Fmax >= flast by descending Fmax (src/distribute.c:695, src/fragment.c:484-503) -> (index, Fmax)"""
+        cnt = C.c_size_t()
+        self._chk(self.L.pf_select_sorted(self.h, flast, 0, None, None, C.byref(cnt)))
+        idx = np.empty(cnt.value, dtype=np.uint32)
+        f = np.empty(cnt.value, dtype=np.float32)
+        if cnt.value:
+            self._chk(self.L.pf_select_sorted(self.h, flast, cnt.value, idx.ctypes.data_as(C.POINTER(C.c_uint)),
+                                              f.ctypes.data_as(C.POINTER(C.c_float)), C.byref(cnt)))
+        return idx, f
+
+    def block(self, name: str, id_bytes: int = 4) -> np.ndarray:
+        """one block of the timeless snapshot (src/write_snapshot.c:207-342) for this rank's slab"""
+        nc = self.nxl * self.n * self.n
+        if name == "ID  ":
+            out = np.empty(nc, dtype=np.uint64 if id_bytes == 8 else np.uint32)
+        elif name == "RMAX":
+            out = np.empty(nc, dtype=np.int32)
+        elif name == "FMAX":
+            out = np.empty(nc, dtype=np.float32)
+        else:
+            out = np.empty((nc, 3), dtype=np.float32)
+        self._chk(self.L.pf_get_block(self.h, name.encode(), id_bytes, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def second_derivative(self, i: int) -> np.ndarray:
         out = np.empty((self.nxl, self.n, self.n))
         self._chk(self.L.pf_get_second_derivative(self.h, i, _dp(out)))

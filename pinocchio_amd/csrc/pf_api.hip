@@ -934,6 +934,50 @@ extern "C" int pf_update_products(pf_ctx *c, void *host, const pf_product_layout
   return 0;
 }
 
+// first stage of fragmentation on the device (pf_select_sort.hip)
+extern "C" int pf_select_sorted(pf_ctx *c, float flast, size_t capacity, unsigned int *cell_index, float *fmax, size_t *count) {
+  if (!c || !count) return pf_fail(0, "pf_select_sorted: null argument");
+  if (!c->products_init) return pf_fail(c->rank, "pf_select_sorted: products not computed");
+  if (ncell(c) > 0xFFFFFFFFull) return pf_fail(c->rank, "pf_select_sorted: more than 2^32 cells on one rank");
+  unsigned int *d_idx = nullptr; float *d_f = nullptr;
+  if (pf_select_sort_device(c->fmax, ncell(c), flast, &d_idx, &d_f, count, c->stream)) return pf_fail(c->rank, "pf_select_sorted: device sort failed (out of memory?)");
+  const size_t m = *count < capacity ? *count : capacity;
+  if (m && cell_index) HIPCHK(c, hipMemcpyAsync(cell_index, d_idx, m * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+  if (m && fmax) HIPCHK(c, hipMemcpyAsync(fmax, d_f, m * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  hipFree(d_idx);
+  return 0;
+}
+
+// per-particle payload of one block of the timeless snapshot (src/write_snapshot.c:207-342, 620-855)
+extern "C" int pf_get_block(pf_ctx *c, const char *name, int id_bytes, void *host) {
+  if (!c || !name || !host) return pf_fail(0, "pf_get_block: null argument");
+  if (!c->products_init) return pf_fail(c->rank, "pf_get_block: products not computed");
+  const size_t nc = ncell(c);
+  if (!strncmp(name, "FMAX", 4)) { HIPCHK(c, hipMemcpyAsync(host, c->fmax, nc * sizeof(float), hipMemcpyDeviceToHost, c->stream)); }
+  else if (!strncmp(name, "RMAX", 4)) { HIPCHK(c, hipMemcpyAsync(host, c->rmax, nc * sizeof(int), hipMemcpyDeviceToHost, c->stream)); }
+  else {
+    static const char *vec[4] = {"ZEL ", "2LPT", "31PT", "32PT"};
+    int o = -1;
+    for (int i = 0; i < 4; i++) if (!strncmp(name, vec[i], 4)) o = i;
+    const bool id = !strncmp(name, "ID  ", 4);
+    if (o < 0 && !id) return pf_fail(c->rank, "pf_get_block: unknown block '%.4s'", name);
+    if (id && id_bytes != 4 && id_bytes != 8) return pf_fail(c->rank, "pf_get_block: MYIDTYPE is 4 or 8 bytes");
+    const size_t rec = id ? (size_t)id_bytes : 3 * sizeof(float);
+    const size_t cap = (2 * c->field_bytes) / rec;
+    const unsigned long long gfirst = (unsigned long long)c->rank * nc;  // x-slabs: global index = rank * ncell + local
+    for (size_t first = 0; first < nc; first += cap) {
+      const size_t cnt = (nc - first < cap) ? nc - first : cap;
+      if (id) PFCHK(c, pf_launch_block_id(id_bytes, gfirst + first, cnt, staging(c), c->stream));
+      else PFCHK(c, pf_launch_block_vec3(c->vel12, nc, o, first, cnt, (float *)staging(c), c->stream));
+      HIPCHK(c, hipMemcpyAsync((char *)host + first * rec, staging(c), cnt * rec, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 extern "C" int pf_get_second_derivative(pf_ctx *c, int i, double *host) {
   if (!c || !host || i < 0 || i > 5) return pf_fail(0, "pf_get_second_derivative: bad argument");
   if (!c->have_hessian) return pf_fail(c->rank, "pf_get_second_derivative: not computed");

@@ -151,6 +151,10 @@ int pf_launch_spec_import(int field_bytes, const double *src, void *dst, long lo
 int pf_launch_spec_export(int field_bytes, const void *src, double *dst, long long nrows, int nzh, int nzp, hipStream_t st);
 int pf_launch_real_import(int field_bytes, const double *src, void *dst, long long nrows, int n, long long pitch, hipStream_t st);
 int pf_launch_real_export(int field_bytes, const void *src, double *dst, long long nrows, int n, long long pitch, hipStream_t st);
+// pf_select_sort.hip
+int pf_select_sort_device(const float *fmax, size_t ncell, float flast, unsigned int **d_idx, float **d_f, size_t *count, hipStream_t st);
+int pf_launch_block_vec3(const float *vel12, size_t ncell, int o, size_t first, size_t count, float *out, hipStream_t st);
+int pf_launch_block_id(int id_bytes, unsigned long long global_first, size_t count, void *out, hipStream_t st);
 int pf_launch_to_blocks(int field_bytes, const void *src, void *dst, int nxl, int n, int nyl, int nzp, int back, hipStream_t st);
 int pf_launch_extract_dc(int field_bytes, const void *spec, double scale, double *out, hipStream_t st);
 

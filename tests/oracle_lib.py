@@ -69,6 +69,8 @@ def lib():
         L.orc_spline_eval.restype = C.c_double
         L.orc_spline_eval.argtypes = [C.c_void_p, C.c_double]
         L.orc_timers.argtypes = [C.c_void_p, dp]
+        L.orc_select_sorted.restype = C.c_size_t
+        L.orc_select_sorted.argtypes = [C.c_void_p, C.c_float, C.POINTER(C.c_uint), C.POINTER(C.c_float)]
         _lib = L
     return _lib
 
@@ -144,6 +146,12 @@ class Oracle:
     def displacements(self, compute_sources=True):
         rc = self.L.orc_compute_displacements(self.h, int(compute_sources))
         assert rc == 0
+
+    def select_sorted(self, flast: float):
+        idx = np.empty(self.n ** 3, dtype=np.uint32)
+        f = np.empty(self.n ** 3, dtype=np.float32)
+        m = self.L.orc_select_sorted(self.h, flast, idx.ctypes.data_as(C.POINTER(C.c_uint)), f.ctypes.data_as(C.POINTER(C.c_float)))
+        return idx[:m].copy(), f[:m].copy()
 
     def products(self) -> np.ndarray:
         n = self.n

@@ -266,3 +266,25 @@ def test_fft_module_seam_on_slabs(api):
         for got, want in zip(res[r], (spec1, back1, d12, d30, dens1)):
             assert np.array_equal(got, want[sl])
     assert np.array_equal(dens1, dk)
+
+
+def test_snapshot_blocks_and_selection_on_slabs(api):
+    """particle IDs are global (1 + global cell index, src/write_snapshot.c:648-664); selection and sort are per slab,
+    like the reference's per-task sort"""
+    n, P = 32, 4
+    nxl = n // P
+    x, y = synth.invgrow_table("lcdm")
+
+    def body(f, r):
+        f.synth_density(synth.SEED, 2.5, -2.0)
+        f.set_invgrow(x, y)
+        f.sweep(np.array([2.0, 0.0]))
+        return f.block("ID  "), f.block("FMAX"), f.select_sorted(1.0)
+
+    res = run_ranks(api, n, P, body)
+    for r in range(P):
+        ids, fm, (idx, fs) = res[r]
+        assert np.array_equal(ids, 1 + r * nxl * n * n + np.arange(nxl * n * n, dtype=np.uint32))
+        sel = np.flatnonzero(fm >= np.float32(1.0))
+        order = sel[np.lexsort((sel, -fm[sel].astype(np.float64)))]
+        assert len(idx) > 0 and np.array_equal(idx, order.astype(np.uint32)) and np.array_equal(fs, fm[order])

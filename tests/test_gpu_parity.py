@@ -534,3 +534,40 @@ def test_fft_module_seam_single_components(api):
                 assert np.max(np.abs(got - hes_o[ider - 1])) <= 1e-12 * np.max(np.abs(hes_o[ider - 1]))
         with pytest.raises(api.PinfmaxError):
             f.compute_derivative(dk, 4, 0)
+
+
+def test_select_sorted_and_snapshot_blocks(api):
+    """row f-2: what the consumers of `products` read -- the fragmentation order (Fmax >= Flast by descending Fmax,
+    src/distribute.c:695, src/fragment.c:484-503) and the blocks of the timeless snapshot (src/write_snapshot.c:207-342)
+    -- produced on the device; checked on the device's own products (exact) and against the oracle's ordering"""
+    n = 64
+    radii = np.array([4.0, 2.0, 1.0, 0.0])
+    dk = synth.make_density(n, seed=3)
+    x, y = synth.invgrow_table("lcdm")
+    o = oracle_lib.Oracle(n, 0)
+    o.set_density(dk); o.set_invgrow(x, y); o.set_growth(synth.growth_multipliers())
+    o.compute_fmax(radii, do_lpt=True)
+    with api.Fmax(n) as f:
+        f.set_density(dk); f.set_invgrow(x, y); f.set_growth(synth.growth_multipliers())
+        f.compute_fmax(radii, do_lpt=True)
+        p = f.products()
+        F = p["Fmax"].ravel()
+        for flast in (1.0, 2.5, -20.0, 1e9):
+            idx, fs = f.select_sorted(flast)
+            sel = np.flatnonzero(F >= np.float32(flast))
+            order = sel[np.lexsort((sel, -F[sel].astype(np.float64)))]
+            assert np.array_equal(idx, order.astype(np.uint32)) and np.array_equal(fs, F[order]), flast
+        idx, fs = f.select_sorted(1.0)
+        blocks = {k: f.block(k) for k in ("ID  ", "FMAX", "RMAX", "ZEL ", "2LPT", "31PT", "32PT")}
+        id8 = f.block("ID  ", id_bytes=8)
+        with pytest.raises(api.PinfmaxError):
+            f.block("XXXX")
+    # same selection as the reference path's: the oracle's order differs only where its Fmax differs (fp32 ulps)
+    io, fo = o.select_sorted(1.0)
+    assert abs(len(io) - len(idx)) <= 2 and np.all(np.diff(fs) <= 0)
+    m = min(len(io), len(idx))
+    assert np.mean(io[:m] == idx[:m]) > 0.99
+    assert np.array_equal(blocks["ID  "], 1 + np.arange(n ** 3, dtype=np.uint32)) and np.array_equal(id8, blocks["ID  "].astype(np.uint64))
+    assert np.array_equal(blocks["FMAX"], F) and np.array_equal(blocks["RMAX"], p["Rmax"].ravel())
+    for name, col in (("ZEL ", "Vel"), ("2LPT", "Vel_2LPT"), ("31PT", "Vel_3LPT_1"), ("32PT", "Vel_3LPT_2")):
+        assert np.array_equal(blocks[name], p[col].reshape(-1, 3))

@@ -240,3 +240,19 @@ def test_scale_dependent_growth_and_per_radius_splines_vs_numpy():
     ulp = np.spacing(np.maximum(np.abs(want), 1.0).astype(np.float32)).astype(np.float64)
     assert np.all(np.abs(p3["Fmax"].astype(np.float64) - want) <= 2 * ulp)
     assert np.mean(p3["Rmax"] != rwant) < 1e-3
+
+
+def test_select_sorted_is_the_fragmentation_order():
+    """orc_select_sorted against numpy: Fmax >= Flast, descending Fmax, ties by index"""
+    n = 16
+    o = oracle_lib.Oracle(n, 2)
+    o.set_density(synth.make_density(n, seed=4))
+    o.set_invgrow(*synth.invgrow_table("lcdm"))
+    o.compute_fmax(np.array([2.0, 1.0, 0.0]), do_lpt=False)
+    F = o.products()["Fmax"].ravel()
+    for flast in (1.0, 1.5, -20.0, 1e9):
+        idx, f = o.select_sorted(flast)
+        sel = np.flatnonzero(F >= np.float32(flast))
+        order = sel[np.lexsort((sel, -F[sel].astype(np.float64)))]
+        assert np.array_equal(idx, order.astype(np.uint32)) and np.array_equal(f, F[order])
+    assert len(o.select_sorted(-20.0)[0]) == n ** 3 and len(o.select_sorted(1e9)[0]) == 0
