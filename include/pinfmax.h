@@ -138,6 +138,20 @@ int pf_set_growth(pf_ctx *ctx, const double g[4]);
    compute_derivative passes it (src/fmax-pfft.c:315-359).  nk = 0 returns to the scalar of pf_set_growth. */
 int pf_set_growth_table(pf_ctx *ctx, int order, const double *log10_growth, int nk, double logkmin, double dlogk, double sign);
 
+/* TABULATED_CT build (src/collapse_times.c:780-1231, the BILINEAR_SPLINE interpolation of :40): per smoothing radius
+   a table of ell() on 100 x 50 x 50 nodes in (delta, x, y) = (l1+l2+l3, l1-l2, l2-l3) / sqrt(Smoothing.Variance[ismooth])
+   and one natural cubic spline in delta per (x, y) node; the per-cell pass then interpolates instead of solving.
+   pf_set_tabulated_ct(ns, Smoothing.Variance): pf_sweep builds the table of each radius right before its
+   collapse-time pass (src/fmax.c:103-106); ns = 0 returns to the direct solve.
+   pf_ct_build = initialize_collapse_times(ismooth, .) alone: the table is computed on the device (with the
+   inverse-growth spline of that radius) and, if table_host is not NULL, copied out as CT_table
+   [iy][ix][id] (100*50*50 doubles, what the reference writes to its CTtable file);
+   pf_ct_load installs a table read from such a file (params.CTtableFile) instead of computing it.
+   A following pf_collapse_times(ismooth) uses the table in place. */
+int pf_set_tabulated_ct(pf_ctx *ctx, int nsmooth, const double *variance);
+int pf_ct_build(pf_ctx *ctx, int ismooth, double variance, double *table_host);
+int pf_ct_load(pf_ctx *ctx, int ismooth, double variance, const double *table_host);
+
 /* --- the path --- */
 /* compute_fmax's radius loop (src/fmax.c:66-150): for each radius (CELL units,
    Rsmooth = Radius/CellSize, src/fmax.c:233) second derivatives + collapse

@@ -61,6 +61,12 @@ struct orc_ctx {
   double *rsx[ORC_MAX_SMOOTH], *rsy[ORC_MAX_SMOOTH], *rsc[ORC_MAX_SMOOTH];
   int gt_n[4];
   double gt_T[4][ORC_MAX_KBINS], gt_logkmin[4], gt_dlogk[4], gt_sign[4];
+  /* TABULATED_CT build (src/collapse_times.c:780-1231, BILINEAR_SPLINE flavour :40): per radius a table of ell() on
+     a (delta, x, y) grid and one natural cubic spline in delta per (x, y) node */
+  int tab_ns;
+  double tab_var[ORC_MAX_SMOOTH]; /* Smoothing.Variance[] */
+  double tab_ampl;                /* sqrt(Smoothing.Variance[ismooth]) of the table in place */
+  double *ct_table, *ct_c, *ct_delta;
 
   double t_total, t_deriv, t_fft, t_coll, t_lpt;
 };
@@ -332,14 +338,8 @@ static void write_from_rvector_to_products(orc_ctx *c, int ia, int order) {
    VALIDATION_log.txt:3) interpolation/cspline.c cspline_init: natural cubic
    spline, c[0]=c[n-1]=0, interior c from the symmetric tridiagonal system
    solved by linalg/tridiag.c solve_tridiag (LDL^t). */
-static int spline_init(orc_ctx *c, const double *xa, const double *ya, int size) {
-  free(c->sx); free(c->sy); free(c->sc);
-  c->nk = size;
-  c->sx = (double *)malloc(sizeof(double) * size);
-  c->sy = (double *)malloc(sizeof(double) * size);
-  c->sc = (double *)calloc(size, sizeof(double));
-  memcpy(c->sx, xa, sizeof(double) * size);
-  memcpy(c->sy, ya, sizeof(double) * size);
+static int natural_cspline(const double *xa, const double *ya, int size, double *sc) {
+  for (int i = 0; i < size; i++) sc[i] = 0.0;
   if (size < 3) return 1;
   int max_index = size - 1, sys_size = max_index - 1;
   double *g = (double *)malloc(sizeof(double) * sys_size);
@@ -357,14 +357,14 @@ static int spline_init(orc_ctx *c, const double *xa, const double *ya, int size)
     g[i] = 3.0 * (ydiff_ip1 * g_ip1 - ydiff_i * g_i);
   }
   if (sys_size == 1) {
-    c->sc[1] = g[0] / diag[0];
+    sc[1] = g[0] / diag[0];
   } else {
     const int N = sys_size;
     double *gamma = (double *)malloc(sizeof(double) * N);
     double *alpha = (double *)malloc(sizeof(double) * N);
     double *cc = (double *)malloc(sizeof(double) * N);
     double *z = (double *)malloc(sizeof(double) * N);
-    double *x = c->sc + 1;
+    double *x = sc + 1;
     alpha[0] = diag[0];
     gamma[0] = offdiag[0] / alpha[0];
     for (int i = 1; i < N - 1; i++) {
@@ -383,11 +383,20 @@ static int spline_init(orc_ctx *c, const double *xa, const double *ya, int size)
   free(g); free(diag); free(offdiag);
   return 0;
 }
+static int spline_init(orc_ctx *c, const double *xa, const double *ya, int size) {
+  free(c->sx); free(c->sy); free(c->sc);
+  c->nk = size;
+  c->sx = (double *)malloc(sizeof(double) * size);
+  c->sy = (double *)malloc(sizeof(double) * size);
+  c->sc = (double *)calloc(size, sizeof(double));
+  memcpy(c->sx, xa, sizeof(double) * size);
+  memcpy(c->sy, ya, sizeof(double) * size);
+  return natural_cspline(xa, ya, size, c->sc);
+}
 
 /* GSL interpolation/bsearch.c gsl_interp_bsearch + cspline.c cspline_eval */
-static double gsl_spline_eval_restated(const orc_ctx *c, double x) {
-  const double *xa = c->sx, *ya = c->sy, *ca = c->sc;
-  size_t ilo = 0, ihi = (size_t)c->nk - 1;
+static double gsl_spline_eval_arrays(const double *xa, const double *ya, const double *ca, int nk, double x) {
+  size_t ilo = 0, ihi = (size_t)nk - 1;
   while (ihi > ilo + 1) {
     size_t i = (ihi + ilo) / 2;
     if (xa[i] > x) ihi = i; else ilo = i;
@@ -402,6 +411,17 @@ static double gsl_spline_eval_restated(const orc_ctx *c, double x) {
   const double b_i = (dy / dx) - dx * (c_ip1 + 2.0 * c_i) / 3.0;
   const double d_i = (c_ip1 - c_i) / (3.0 * dx);
   return y_lo + delx * (b_i + delx * (c_i + delx * d_i));
+}
+
+static double gsl_spline_eval_restated(const orc_ctx *c, double x) { return gsl_spline_eval_arrays(c->sx, c->sy, c->sc, c->nk, x); }
+/* my_spline_eval (src/cosmo.c:2016-2027) on explicit arrays */
+static double my_spline_eval_arrays(const double *sx, const double *sy, const double *sc, int size, double x) {
+  if (x < sx[0])
+    return sy[0] + (x - sx[0]) * (sy[1] - sy[0]) / (sx[1] - sx[0]);
+  else if (x > sx[size - 1])
+    return sy[size - 1] + (x - sx[size - 1]) * (sy[size - 1] - sy[size - 2]) / (sx[size - 1] - sx[size - 2]);
+  else
+    return gsl_spline_eval_arrays(sx, sy, sc, size, x);
 }
 
 /* cosmo.c:2016-2027 my_spline_eval: linear extrapolation beyond the knots */
@@ -489,6 +509,90 @@ static double ell_fn(orc_ctx *c, double l1, double l2, double l3) {
   else return 0.0;
 }
 
+/* ------------------------------------------------ TABULATED_CT (src/collapse_times.c:780-1231), restated ---- */
+#define CT_NBINS_XY (50)
+#define CT_NBINS_D (100)
+#define CT_SQUEEZE (1.2)
+#define CT_EXPO (1.75)
+#define CT_RANGE_D (7.0)
+#define CT_RANGE_X (3.5)
+#define CT_DELTA0 (-1.0)
+
+/* the sampling in delta, finer around CT_DELTA0 (collapse_times.c:836-876; CT_EXPO is neither 1 nor 2) */
+static void ct_delta_vector(double *delta_vector) {
+  double deltaf = pow(CT_SQUEEZE / CT_EXPO, 1. / (CT_EXPO - 1.));
+  double ref_interval = ((pow(CT_RANGE_D - CT_DELTA0, 2. - CT_EXPO) + pow(CT_RANGE_D + CT_DELTA0, 2. - CT_EXPO)
+                          - 2. * pow(deltaf, 2. - CT_EXPO)) / CT_EXPO / (2. - CT_EXPO) + 2. * deltaf / CT_SQUEEZE) / (CT_NBINS_D - 2.0);
+  double del = -CT_RANGE_D, interval;
+  int id = 0;
+  do {
+    delta_vector[id] = del;
+    interval = CT_EXPO * ref_interval * pow(fabs(del - CT_DELTA0), CT_EXPO - 1.0);
+    interval = (interval / ref_interval < CT_SQUEEZE ? ref_interval * CT_SQUEEZE : interval);
+    del += interval;
+    id++;
+  } while (id < CT_NBINS_D);
+}
+
+/* initialize_collapse_times(ismooth, 0) with params.CTtableFile == "none" (collapse_times.c:820-1043): the table of
+   ell() and the CT_NBINS_XY^2 splines in delta; single task, so the MPI split of the computations is not restated */
+static int ct_initialize(orc_ctx *c, int ismooth) {
+  const int Ncomputations = CT_NBINS_D * CT_NBINS_XY * CT_NBINS_XY;
+  if (!c->ct_table) {
+    c->ct_table = (double *)calloc(Ncomputations, sizeof(double));
+    c->ct_c = (double *)calloc(Ncomputations, sizeof(double));
+    c->ct_delta = (double *)malloc(CT_NBINS_D * sizeof(double));
+    ct_delta_vector(c->ct_delta);
+  }
+  const double bin_x = CT_RANGE_X / (double)(CT_NBINS_XY);
+  const double ampl = sqrt(c->tab_var[ismooth]);
+  c->tab_ampl = ampl;
+  const int was = c->tab_ns;
+  c->tab_ns = 0; /* the table itself is made of true ell() values */
+#pragma omp parallel for num_threads(c->nthreads) schedule(static)
+  for (int i = 0; i < Ncomputations; ++i) {
+    int id = i % CT_NBINS_D;
+    int ix = (i / CT_NBINS_D) % CT_NBINS_XY;
+    int iy = i / CT_NBINS_D / CT_NBINS_XY;
+    double x = ix * bin_x;
+    double y = iy * bin_x;
+    double l1 = (c->ct_delta[id] + 2. * x + y) / 3.0 * ampl;
+    double l2 = (c->ct_delta[id] - x + y) / 3.0 * ampl;
+    double l3 = (c->ct_delta[id] - x - 2. * y) / 3.0 * ampl;
+    c->ct_table[i] = ell_fn(c, l1, l2, l3);
+  }
+  c->tab_ns = was;
+  /* gsl_spline_init(CT_Spline[i][j], delta_vector, &CT_table[i*CT_NBINS_D + j*CT_NBINS_D*CT_NBINS_XY], CT_NBINS_D) */
+  for (int i = 0; i < CT_NBINS_XY; ++i)
+    for (int j = 0; j < CT_NBINS_XY; ++j) {
+      const size_t off = (size_t)i * CT_NBINS_D + (size_t)j * CT_NBINS_D * CT_NBINS_XY;
+      natural_cspline(c->ct_delta, c->ct_table + off, CT_NBINS_D, c->ct_c + off);
+    }
+  return 0;
+}
+
+/* interpolate_collapse_time, BILINEAR_SPLINE (collapse_times.c:1110-1126, 1219-1231) */
+double orc_interpolate_collapse_time(orc_ctx *c, double l1, double l2, double l3) {
+  const double bin_x = CT_RANGE_X / (double)(CT_NBINS_XY);
+  double ampl = c->tab_ampl;
+  double d = (l1 + l2 + l3) / ampl;
+  double x = (l1 - l2) / ampl;
+  double y = (l2 - l3) / ampl;
+  int ix = (int)(x / bin_x);
+  int iy = (int)(y / bin_x);
+  ix = (ix >= CT_NBINS_XY - 1) ? CT_NBINS_XY - 2 : (ix < 0) ? 0 : ix;
+  iy = (iy >= CT_NBINS_XY - 1) ? CT_NBINS_XY - 2 : (iy < 0) ? 0 : iy;
+  double dx = x / bin_x - ix;
+  double dy = y / bin_x - iy;
+#define CT_SPL(I, J) my_spline_eval_arrays(c->ct_delta, c->ct_table + (size_t)(I) * CT_NBINS_D + (size_t)(J) * CT_NBINS_D * CT_NBINS_XY, \
+                                           c->ct_c + (size_t)(I) * CT_NBINS_D + (size_t)(J) * CT_NBINS_D * CT_NBINS_XY, CT_NBINS_D, d)
+  return ((1. - dx) * (1. - dy) * CT_SPL(ix, iy) +
+          (dx) * (1. - dy) * CT_SPL(ix + 1, iy) +
+          (1. - dx) * (dy) * CT_SPL(ix, iy + 1) +
+          (dx) * (dy) * CT_SPL(ix + 1, iy + 1));
+#undef CT_SPL
+}
+
 /* collapse_times.c:1354-1362 */
 static void ord(double *a, double *b, double *c) {
   double lo, hi;
@@ -538,12 +642,14 @@ double orc_inverse_collapse_time(orc_ctx *c, const double *deformation_tensor, d
     *x3 = -sq * cos((t + 4. * ORC_PI) * inv_3) + mu1 * inv_3;
   }
   ord(x1, x2, x3);
+  if (c->tab_ns > 0) return orc_interpolate_collapse_time(c, *x1, *x2, *x3); /* #ifdef TABULATED_CT, :749 */
   return ell_fn(c, *x1, *x2, *x3);
 }
 
 /* collapse_times.c:431-673 */
 static int compute_collapse_times_with_current_spline(orc_ctx *c, int ismooth, double *true_var) {
   const size_t nr = c->n_r;
+  if (c->tab_ns > 0 && ct_initialize(c, ismooth)) return 1; /* src/fmax.c:103-106 */
   orc_product *products = c->products;
   double local_variance = 0.0, local_average = 0.0;
 
@@ -779,6 +885,7 @@ void orc_destroy(orc_ctx *c) {
   free(c->kvector_2LPT); free(c->kvector_3LPT_1); free(c->kvector_3LPT_2);
   free(c->products); free(c->sx); free(c->sy); free(c->sc);
   for (int i = 0; i < ORC_MAX_SMOOTH; i++) { free(c->rsx[i]); free(c->rsy[i]); free(c->rsc[i]); }
+  free(c->ct_table); free(c->ct_c); free(c->ct_delta);
   free(c);
 }
 
@@ -795,6 +902,19 @@ int orc_set_invgrow_radius(orc_ctx *c, int ismooth, const double *x, const doubl
   c->sx = dx; c->sy = dy; c->sc = dc; c->nk = dn;
   return rc;
 }
+int orc_set_tabulated_ct(orc_ctx *c, int ns, const double *variance) {
+  if (ns < 0 || ns > ORC_MAX_SMOOTH) return 1;
+  c->tab_ns = ns;
+  if (ns) memcpy(c->tab_var, variance, sizeof(double) * ns);
+  return 0;
+}
+int orc_ct_build(orc_ctx *c, int ismooth, double variance) {
+  if (ismooth < 0 || ismooth >= ORC_MAX_SMOOTH) return 1;
+  c->tab_var[ismooth] = variance;
+  return ct_initialize(c, ismooth);
+}
+const double *orc_ct_table(orc_ctx *c) { return c->ct_table; }
+const double *orc_ct_delta(orc_ctx *c) { return c->ct_delta; }
 int orc_set_growth_table(orc_ctx *c, int order, const double *T, int nk, double logkmin, double dlogk, double sign) {
   if (order < 1 || order > 4 || nk < 0 || nk > ORC_MAX_KBINS) return 1;
   c->gt_n[order - 1] = nk;

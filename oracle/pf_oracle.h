@@ -94,6 +94,18 @@ void orc_timers(orc_ctx *c, double t[5]);
 #ifdef __cplusplus
 }
 #endif
+/* PARITY UNPINNED for the two build options below (SCALE_DEPENDENT additions above, TABULATED_CT here): the reference
+   commits no output produced with them; these restatements are checked against numpy / scipy only.
+   TABULATED_CT build (row f-4; src/collapse_times.c:780-1231 with the BILINEAR_SPLINE interpolation of :40):
+   orc_set_tabulated_ct(ns, Smoothing.Variance[]) makes every following collapse-time pass build the table of ell()
+   for its radius (100 x 50 x 50 nodes in (delta, x, y) / sqrt(variance)) and interpolate in it; ns = 0 returns to the
+   direct solve.  orc_ct_build does the table alone; orc_ct_table / orc_ct_delta expose it ([iy][ix][id] / [id]). */
+int orc_set_tabulated_ct(orc_ctx *c, int ns, const double *variance);
+int orc_ct_build(orc_ctx *c, int ismooth, double variance);
+const double *orc_ct_table(orc_ctx *c);
+const double *orc_ct_delta(orc_ctx *c);
+double orc_interpolate_collapse_time(orc_ctx *c, double l1, double l2, double l3);
+
 /* Fmax >= flast (src/distribute.c:695), indices by descending Fmax (src/fragment.c:484-503, 118-126; ties by index).
    indices / fmax hold n^3 entries; returns the number selected. */
 size_t orc_select_sorted(orc_ctx *c, float flast, unsigned int *indices, float *fmax);

@@ -108,6 +108,22 @@ class Fmax:
         t = np.ascontiguousarray(log10_growth, dtype=np.float64)
         self._chk(self.L.pf_set_growth_table(self.h, int(order), _dp(t) if len(t) else None, len(t), logkmin, dlogk, sign))
 
+    def set_tabulated_ct(self, variance):
+        """TABULATED_CT build: Smoothing.Variance[] per radius ([] = direct solve), src/collapse_times.c:780-1231"""
+        v = np.ascontiguousarray(variance, dtype=np.float64)
+        self._chk(self.L.pf_set_tabulated_ct(self.h, len(v), _dp(v) if len(v) else None))
+
+    def ct_build(self, ismooth: int, variance: float) -> np.ndarray:
+        """initialize_collapse_times(ismooth): -> CT_table[iy][ix][id]"""
+        t = np.empty((50, 50, 100))
+        self._chk(self.L.pf_ct_build(self.h, ismooth, variance, _dp(t)))
+        return t
+
+    def ct_load(self, ismooth: int, variance: float, table: np.ndarray):
+        t = np.ascontiguousarray(table, dtype=np.float64)
+        assert t.shape == (50, 50, 100)
+        self._chk(self.L.pf_ct_load(self.h, ismooth, variance, _dp(t)))
+
     # -- the path (reference names) ----------------------------------------
     def sweep(self, radii_cells) -> np.ndarray:
         """radius loop of compute_fmax (src/fmax.c:66-150) -> TrueVariance[]"""

@@ -107,6 +107,13 @@ struct pf_ctx {
   int gt_n[4];
   double gt_logkmin[4], gt_dlogk[4], gt_sign[4];
   double *gtab;        // [4][PF_KBIN_CAP]
+  // TABULATED_CT build: variance per radius (0 radii = direct solve) and the table of the radius in place
+  int tab_ns;
+  double tab_var[PF_MAX_SMOOTH];
+  bool tab_ready;
+  int tab_ismooth;
+  PfCtDev ct;
+  double *ct_block;    // delta | alpha | gamma | y | b | c | d
   bool have_density, have_hessian, have_sources, products_init;
   int last_ns;
   pf_alltoall_fn a2a; void *a2a_user;
@@ -265,6 +272,7 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   PFCHK(c, dev_alloc(c, (void **)&c->spl, (size_t)(PF_MAX_SMOOTH + 1) * 5 * PF_KNOT_CAP * sizeof(double)));
   PFCHK(c, dev_alloc(c, (void **)&c->gtab, 4 * PF_KBIN_CAP * sizeof(double)));
   memset(c->gt_n, 0, sizeof(c->gt_n));
+  c->tab_ns = 0; c->tab_ready = false; c->tab_ismooth = -1; c->ct_block = nullptr; memset(&c->ct, 0, sizeof(c->ct));
   HIPCHK(c, hipMemsetAsync(c->scal, 0, SC_COUNT * sizeof(double), c->stream));
   // twiddles exp(+2 pi i j / n), computed in long double on the host
   {
@@ -291,7 +299,7 @@ extern "C" int pf_destroy(pf_ctx *c) {
   hipFree(c->dk); hipFree(c->blockA); hipFree(c->recvA); hipFree(c->tw); hipFree(c->blockA2); hipFree(c->recvA2);
   for (int i = 0; i < 6; i++) { hipFree(c->B[i]); hipFree(c->B2[i]); }
   for (int i = 0; i < 3; i++) hipFree(c->S[i]);
-  hipFree(c->fmax); hipFree(c->rmax); hipFree(c->vel12); hipFree(c->partials); hipFree(c->scal); hipFree(c->hist); hipFree(c->spl); hipFree(c->gtab);
+  hipFree(c->fmax); hipFree(c->rmax); hipFree(c->vel12); hipFree(c->partials); hipFree(c->scal); hipFree(c->hist); hipFree(c->spl); hipFree(c->gtab); hipFree(c->ct_block);
   for (auto &e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   for (auto &e : c->phase_evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   for (auto e : c->evpool) hipEventDestroy(e);
@@ -703,6 +711,63 @@ extern "C" int pf_set_growth_table(pf_ctx *c, int order, const double *log10_gro
   return 0;
 }
 
+// ---- TABULATED_CT (src/collapse_times.c:780-1231) ----
+static int ct_alloc(pf_ctx *c) {
+  if (c->ct_block) return 0;
+  const size_t nd = PF_CT_NBINS_D, nt = (size_t)PF_CT_NBINS_D * PF_CT_NBINS_XY * PF_CT_NBINS_XY;
+  PFCHK(c, dev_alloc(c, (void **)&c->ct_block, (3 * nd + 4 * nt) * sizeof(double)));
+  double h[3 * PF_CT_NBINS_D];
+  memset(h, 0, sizeof(h));
+  pf_ct_delta_vector(h);
+  pf_ct_tridiag(h, PF_CT_NBINS_D, h + nd, h + 2 * nd);
+  HIPCHK(c, hipMemcpy(c->ct_block, h, sizeof(h), hipMemcpyHostToDevice));
+  c->ct.delta = c->ct_block; c->ct.alpha = c->ct_block + nd; c->ct.gamma = c->ct_block + 2 * nd;
+  c->ct.y = c->ct_block + 3 * nd; c->ct.b = c->ct.y + nt; c->ct.c = c->ct.b + nt; c->ct.d = c->ct.c + nt;
+  return 0;
+}
+// initialize_collapse_times(ismooth, .): table of ell() for this radius (or the caller's table) + the node splines
+static int ct_build(pf_ctx *c, int ismooth, double variance, const double *table_host, hipStream_t st = nullptr) {
+  if (!st) st = c->stream;
+  if (!(variance > 0.0)) return pf_fail(c->rank, "collapse-time table: Smoothing.Variance[%d] = %g must be positive", ismooth, variance);
+  PFCHK(c, ct_alloc(c));
+  c->ct.ampl = sqrt(variance);
+  PfSplineDev sp; memset(&sp, 0, sizeof(sp));
+  if (table_host) HIPCHK(c, hipMemcpyAsync(c->ct.y, table_host, (size_t)PF_CT_NBINS_D * PF_CT_NBINS_XY * PF_CT_NBINS_XY * sizeof(double), hipMemcpyHostToDevice, st));
+  else if (spline_for(c, ismooth, &sp)) return 1;
+  {
+    KTimer t(c, KS_MISC, 0.0, st);
+    PFCHK(c, pf_launch_ct_build(sp, c->ct, c->fast_libm ? 1 : 0, table_host ? 0 : 1, st));
+  }
+  c->tab_ready = true; c->tab_ismooth = ismooth;
+  return 0;
+}
+extern "C" int pf_set_tabulated_ct(pf_ctx *c, int nsmooth, const double *variance) {
+  if (!c) return 1;
+  if (nsmooth < 0 || nsmooth > PF_MAX_SMOOTH || (nsmooth && !variance)) return pf_fail(c->rank, "pf_set_tabulated_ct: bad argument");
+  c->tab_ns = nsmooth; c->tab_ready = false;
+  if (nsmooth) memcpy(c->tab_var, variance, nsmooth * sizeof(double));
+  return 0;
+}
+extern "C" int pf_ct_build(pf_ctx *c, int ismooth, double variance, double *table_host) {
+  if (!c) return 1;
+  if (ismooth < 0 || ismooth >= PF_MAX_SMOOTH) return pf_fail(c->rank, "pf_ct_build: ismooth %d out of range", ismooth);
+  PFCHK(c, ct_build(c, ismooth, variance, nullptr));
+  if (table_host) HIPCHK(c, hipMemcpyAsync(table_host, c->ct.y, (size_t)PF_CT_NBINS_D * PF_CT_NBINS_XY * PF_CT_NBINS_XY * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (ismooth < PF_MAX_SMOOTH && c->tab_ns <= ismooth) c->tab_ns = ismooth + 1;
+  c->tab_var[ismooth] = variance;
+  return 0;
+}
+extern "C" int pf_ct_load(pf_ctx *c, int ismooth, double variance, const double *table_host) {
+  if (!c || !table_host) return 1;
+  if (ismooth < 0 || ismooth >= PF_MAX_SMOOTH) return pf_fail(c->rank, "pf_ct_load: ismooth %d out of range", ismooth);
+  PFCHK(c, ct_build(c, ismooth, variance, table_host));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->tab_ns <= ismooth) c->tab_ns = ismooth + 1;
+  c->tab_var[ismooth] = variance;
+  return 0;
+}
+
 // ---------------------------------------------------------------- the path --
 extern "C" int pf_second_derivatives(pf_ctx *c, double rs) {
   if (!c) return 1;
@@ -713,13 +778,21 @@ extern "C" int pf_second_derivatives(pf_ctx *c, double rs) {
   return 0;
 }
 
-static int collapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], hipStream_t st) {
+static int collapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], hipStream_t st, bool build_table = true) {
   PfCollapseParams p; memset(&p, 0, sizeof(p));
   for (int i = 0; i < 6; i++) p.h[i] = H[i];
   p.pitch = 2 * c->nzp; p.nrows = (long long)c->nxl * c->n; p.n = c->n; p.fmax = c->fmax; p.rmax = c->rmax; p.ismooth = ismooth;
   if (spline_for(c, ismooth, &p.spline)) return 1;
   p.partials = c->partials; p.fast = c->fast_libm ? 1 : 0;
   p.wpe = getenv("PF_COLLAPSE_WPE") ? atoi(getenv("PF_COLLAPSE_WPE")) : 0;
+  if (c->tab_ns > 0) {  // TABULATED_CT build: the table of this radius is made right before its pass (src/fmax.c:103-106)
+    if (build_table) {
+      if (ismooth >= c->tab_ns) return pf_fail(c->rank, "collapse-time table: no variance for radius %d (pf_set_tabulated_ct)", ismooth);
+      if (ct_build(c, ismooth, c->tab_var[ismooth], nullptr, st)) return 1;
+    } else if (!c->tab_ready)
+      return pf_fail(c->rank, "collapse-time table not built (pf_ct_build / pf_ct_load)");
+    p.tabulated = 1; p.ct = c->ct;
+  }
   size_t nb = (ncell(c) + 255) / 256; if (nb > (size_t)c->collapse_blocks) nb = c->collapse_blocks;
   p.nblocks = (int)nb;
   {
@@ -764,7 +837,8 @@ extern "C" int pf_collapse_times(pf_ctx *c, int ismooth, double *tv) {
     return pf_fail(c->rank, "pf_collapse_times: products not initialised (ismooth 0 must come first)");
   {
     PhaseTimer pt(c, 1);
-    if (collapse_enqueue(c, ismooth, c->B, c->stream)) return 1;
+    // a table already in place for this radius (pf_ct_build / pf_ct_load, the reference's initialize_collapse_times) is used as it is
+    if (collapse_enqueue(c, ismooth, c->B, c->stream, !(c->tab_ready && c->tab_ismooth == ismooth))) return 1;
   }
   PFCHK(c, allreduce_dev(c, c->scal + SC_VAR0 + 2 * ismooth, 2, 0));
   double s[2];

@@ -27,21 +27,29 @@ __device__ __forceinline__ void pf_block_sum2(double &a, double &b, double *sh /
 }
 
 // K6: one thread per cell, grid-stride.  fp64 math whatever the field precision.
-template <typename F, bool FAST>
+template <typename F, bool FAST, bool TAB = false>
 __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
-  __shared__ double sk[5 * PF_MAX_KNOTS];
+  __shared__ double sk[TAB ? PF_CT_NBINS_D : 5 * PF_MAX_KNOTS];
   __shared__ double red[2 * (PF_CELL_BLOCK / 64)];
   const int nk = p.spline.n;
-  for (int i = threadIdx.x; i < nk; i += blockDim.x) {
-    sk[i] = p.spline.x[i];
-    sk[PF_MAX_KNOTS + i] = p.spline.y[i];
-    sk[2 * PF_MAX_KNOTS + i] = p.spline.c[i];
-    sk[3 * PF_MAX_KNOTS + i] = p.spline.b[i];
-    sk[4 * PF_MAX_KNOTS + i] = p.spline.d[i];
+  if (TAB) {
+    for (int i = threadIdx.x; i < PF_CT_NBINS_D; i += blockDim.x) sk[i] = p.ct.delta[i];
+  } else {
+    for (int i = threadIdx.x; i < nk; i += blockDim.x) {
+      sk[i] = p.spline.x[i];
+      sk[PF_MAX_KNOTS + i] = p.spline.y[i];
+      sk[2 * PF_MAX_KNOTS + i] = p.spline.c[i];
+      sk[3 * PF_MAX_KNOTS + i] = p.spline.b[i];
+      sk[4 * PF_MAX_KNOTS + i] = p.spline.d[i];
+    }
   }
   __syncthreads();
+  pf_ct_view tv;
+  tv.delta = sk; tv.y = p.ct.y; tv.b = p.ct.b; tv.c = p.ct.c; tv.d = p.ct.d; tv.ampl = p.ct.ampl;
   pf_spline_view sv;
-  sv.x = sk; sv.y = sk + PF_MAX_KNOTS; sv.c = sk + 2 * PF_MAX_KNOTS; sv.b = sk + 3 * PF_MAX_KNOTS; sv.d = sk + 4 * PF_MAX_KNOTS;
+  sv.x = sk;
+  if (!TAB) { sv.y = sk + PF_MAX_KNOTS; sv.c = sk + 2 * PF_MAX_KNOTS; sv.b = sk + 3 * PF_MAX_KNOTS; sv.d = sk + 4 * PF_MAX_KNOTS; }
+  else sv.y = sv.c = sv.b = sv.d = sk;
   sv.n = nk;
 
   const F *__restrict__ h0 = (const F *)p.h[0], *__restrict__ h1 = (const F *)p.h[1],
@@ -57,7 +65,9 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
     sum += delta;
     sum2 += delta * delta;
     double lam[3];
-    const double Fnew = pf_inverse_collapse_time<FAST>(d, sv, lam);
+    // TABULATED_CT: the same eigenvalues, then the table instead of ell() (src/collapse_times.c:749)
+    const double Fnew = TAB ? (pf_ordered_eigenvalues<FAST>(d, lam) ? pf_interpolate_collapse_time(tv, lam[0], lam[1], lam[2]) : -10.0)
+                            : pf_inverse_collapse_time<FAST>(d, sv, lam);
     // products[].Fmax is float, compared after promotion (quirk Q2); init -10 / -1 at ismooth 0
     const float fold = p.ismooth ? p.fmax[i] : -10.0f;
     if ((double)fold < Fnew) {
@@ -82,6 +92,37 @@ template <typename F, bool FAST>
 __global__ void __launch_bounds__(PF_CELL_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) k_collapse_w4(const PfCollapseParams p) { pf_collapse_body<F, FAST>(p); }
 template <typename F, bool FAST>
 __global__ void __launch_bounds__(PF_CELL_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) k_collapse_w5(const PfCollapseParams p) { pf_collapse_body<F, FAST>(p); }
+
+template <typename F, bool FAST>
+__global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse_tab(const PfCollapseParams p) { pf_collapse_body<F, FAST, true>(p); }
+
+// initialize_collapse_times (src/collapse_times.c:956-972): CT_table[i] = ell(ismooth, l1, l2, l3) on the
+// (delta, x, y) grid, i = id + 100 * (ix + 50 * iy)
+template <bool FAST>
+__global__ void __launch_bounds__(PF_CELL_BLOCK) k_ct_table(PfSplineDev s, PfCtDev ct) {
+  pf_spline_view sv;
+  sv.x = s.x; sv.y = s.y; sv.c = s.c; sv.b = s.b; sv.d = s.d; sv.n = s.n;
+  const double bin_x = PF_CT_RANGE_X / (double)(PF_CT_NBINS_XY);
+  const int total = PF_CT_NBINS_D * PF_CT_NBINS_XY * PF_CT_NBINS_XY;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int id = i % PF_CT_NBINS_D;
+    const int ix = (i / PF_CT_NBINS_D) % PF_CT_NBINS_XY;
+    const int iy = i / PF_CT_NBINS_D / PF_CT_NBINS_XY;
+    const double x = ix * bin_x, y = iy * bin_x, del = ct.delta[id];
+    const double l1 = (del + 2. * x + y) / 3.0 * ct.ampl;
+    const double l2 = (del - x + y) / 3.0 * ct.ampl;
+    const double l3 = (del - x - 2. * y) / 3.0 * ct.ampl;
+    ct.y[i] = pf_ell<FAST>(sv, l1, l2, l3);
+  }
+}
+// gsl_spline_init of the 50 x 50 node splines (src/collapse_times.c:1037-1041): GSL's cspline_init per node -- right-hand
+// side, forward and back substitution with the shared factors -- then the b, d of pf_spline_bd.  One thread per node.
+__global__ void __launch_bounds__(PF_CELL_BLOCK) k_ct_splines(PfCtDev ct) {
+  const int node = blockIdx.x * blockDim.x + threadIdx.x;
+  if (node >= PF_CT_NBINS_XY * PF_CT_NBINS_XY) return;
+  const size_t o = (size_t)node * PF_CT_NBINS_D;
+  pf_ct_node_spline(ct.delta, ct.alpha, ct.gamma, ct.y + o, ct.c + o, ct.b + o, ct.d + o);
+}
 
 // one wave, fixed association order: bitwise reproducible for a given launch geometry
 __global__ void k_final_sum2(const double *partials, int nblocks, double *out2) {
@@ -302,8 +343,27 @@ static inline int pf_grid_for(size_t n, int cap = 256 * 8) {
 }
 #define PF_CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? 0 : 1)
 
+int pf_launch_ct_build(const PfSplineDev &sp, const PfCtDev &ct, int fast, int compute_table, hipStream_t st) {
+  if (compute_table) {
+    const int g = pf_grid_for((size_t)PF_CT_NBINS_D * PF_CT_NBINS_XY * PF_CT_NBINS_XY);
+    if (fast) hipLaunchKernelGGL(k_ct_table<true>, dim3(g), dim3(PF_CELL_BLOCK), 0, st, sp, ct);
+    else hipLaunchKernelGGL(k_ct_table<false>, dim3(g), dim3(PF_CELL_BLOCK), 0, st, sp, ct);
+  }
+  hipLaunchKernelGGL(k_ct_splines, dim3((PF_CT_NBINS_XY * PF_CT_NBINS_XY + PF_CELL_BLOCK - 1) / PF_CELL_BLOCK), dim3(PF_CELL_BLOCK), 0, st, ct);
+  return PF_CHECK_LAUNCH();
+}
 int pf_launch_collapse(int fb, const PfCollapseParams &p, hipStream_t st) {
   if (p.spline.n > PF_MAX_KNOTS) return 2;
+  if (p.tabulated) {
+    if (fb == 8) {
+      if (p.fast) hipLaunchKernelGGL((k_collapse_tab<double, true>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
+      else hipLaunchKernelGGL((k_collapse_tab<double, false>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
+    } else {
+      if (p.fast) hipLaunchKernelGGL((k_collapse_tab<float, true>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
+      else hipLaunchKernelGGL((k_collapse_tab<float, false>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
+    }
+    return PF_CHECK_LAUNCH();
+  }
   if (fb == 8 && p.fast && p.wpe == 4) { hipLaunchKernelGGL((k_collapse_w4<double, true>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p); return PF_CHECK_LAUNCH(); }
   if (fb == 8 && p.fast && p.wpe == 5) { hipLaunchKernelGGL((k_collapse_w5<double, true>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p); return PF_CHECK_LAUNCH(); }
   if (fb == 8) {

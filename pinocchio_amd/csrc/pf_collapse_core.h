@@ -200,9 +200,9 @@ template <bool FAST = false> PF_HD double pf_ell_classic(double l1, double l2, d
   return ell;
 }
 
-// d = {11,22,33,12,13,23}.  Returns F = 1 + z_collapse (0: never collapses,
-// -10: eigen-solver sentinel).  lam[3] receives the ordered eigenvalues.
-template <bool FAST = false> PF_HD double pf_inverse_collapse_time(const double d[6], const pf_spline_view &s, double lam[3]) {
+// Eigenvalues of the symmetric tensor d = {11,22,33,12,13,23} by the trigonometric formula, ordered by ord()
+// (src/collapse_times.c:679-745).  Returns false for the -10 sentinel branch (q^3 < r^2 or q < 0).
+template <bool FAST = false> PF_HD bool pf_ordered_eigenvalues(const double d[6], double lam[3]) {
   const double mu1 = d[0] + d[1] + d[2];
   const double mu1_2 = mu1 * mu1;
   double mu2 = 0.5 * mu1_2;
@@ -219,7 +219,7 @@ template <bool FAST = false> PF_HD double pf_inverse_collapse_time(const double 
                           : -(2. * mu1_2 * mu1 - 9.0 * mu1 * mu2 + 27.0 * mu3) / 54.;
     if (q * q * q < r * r || q < 0.0) {
       lam[0] = lam[1] = lam[2] = 0.0;
-      return -10.0;
+      return false;
     }
     const double sq = 2 * sqrt(q);
     const double t = FAST ? acos(2 * r / (q * sq)) : acos(2 * r / q / sq);
@@ -235,9 +235,125 @@ template <bool FAST = false> PF_HD double pf_inverse_collapse_time(const double 
   double lo = (x1 < x2 ? x1 : x2); lo = (lo < x3 ? lo : x3);
   const double mid = x1 + x2 + x3 - lo - hi;
   lam[0] = hi; lam[1] = mid; lam[2] = lo;
-  const double bc = pf_ell_classic<FAST>(hi, mid, lo);
+  return true;
+}
+
+// ell (src/collapse_times.c:404-427, ELL_CLASSIC): F = 1 + z_collapse, or 0 when the ellipsoid never collapses
+template <bool FAST = false> PF_HD double pf_ell(const pf_spline_view &s, double l1, double l2, double l3) {
+  const double bc = pf_ell_classic<FAST>(l1, l2, l3);
   if (bc > 0.0) return 1. + pf_inverse_growing_mode<FAST>(s, bc);
   return 0.0;
+}
+
+// d = {11,22,33,12,13,23}.  Returns F = 1 + z_collapse (0: never collapses,
+// -10: eigen-solver sentinel).  lam[3] receives the ordered eigenvalues.
+template <bool FAST = false> PF_HD double pf_inverse_collapse_time(const double d[6], const pf_spline_view &s, double lam[3]) {
+  if (!pf_ordered_eigenvalues<FAST>(d, lam)) return -10.0;
+  return pf_ell<FAST>(s, lam[0], lam[1], lam[2]);
+}
+
+// ---- TABULATED_CT (src/collapse_times.c:780-1231, BILINEAR_SPLINE flavour :40) --------------------------------
+#define PF_CT_NBINS_XY 50
+#define PF_CT_NBINS_D 100
+#define PF_CT_RANGE_X 3.5
+// the table of one radius: delta knots (shared by all splines), and per (ix, iy) node the values y and the cubic
+// coefficients b, c, d of its natural spline in delta; node (ix, iy) starts at (ix + iy * 50) * 100
+struct pf_ct_view {
+  const double *delta;          // [100]
+  const double *y, *b, *c, *d;  // [50*50*100]
+  double ampl;                  // sqrt(Smoothing.Variance[ismooth])
+};
+// interpolate_collapse_time (:1110-1126, 1219-1231): bilinear in (x, y) of four my_spline_eval's in delta
+PF_HD double pf_interpolate_collapse_time(const pf_ct_view &t, double l1, double l2, double l3) {
+  const double bin_x = PF_CT_RANGE_X / (double)(PF_CT_NBINS_XY);
+  const double d = (l1 + l2 + l3) / t.ampl;
+  const double x = (l1 - l2) / t.ampl;
+  const double y = (l2 - l3) / t.ampl;
+  int ix = (int)(x / bin_x);
+  int iy = (int)(y / bin_x);
+  ix = (ix >= PF_CT_NBINS_XY - 1) ? PF_CT_NBINS_XY - 2 : (ix < 0) ? 0 : ix;
+  iy = (iy >= PF_CT_NBINS_XY - 1) ? PF_CT_NBINS_XY - 2 : (iy < 0) ? 0 : iy;
+  const double dx = x / bin_x - ix;
+  const double dy = y / bin_x - iy;
+  // the four splines share their knots: one search (GSL's accelerator lookup returns the same interval)
+  const double *xa = t.delta;
+  const int last = PF_CT_NBINS_D - 1;
+  int mode = 0, ilo = 0;  // 0 inside, -1 below, +1 above the knot range (my_spline_eval extrapolates linearly)
+  if (d < xa[0]) mode = -1;
+  else if (d > xa[last]) mode = 1;
+  else {
+    int ihi = last;
+    while (ihi > ilo + 1) {
+      const int i = (ihi + ilo) >> 1;
+      if (xa[i] > d) ihi = i; else ilo = i;
+    }
+  }
+  double s[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int node = ((ix + (k & 1)) + (iy + (k >> 1)) * PF_CT_NBINS_XY) * PF_CT_NBINS_D;
+    const double *ya = t.y + node;
+    if (mode < 0) s[k] = ya[0] + (d - xa[0]) * (ya[1] - ya[0]) / (xa[1] - xa[0]);
+    else if (mode > 0) s[k] = ya[last] + (d - xa[last]) * (ya[last] - ya[last - 1]) / (xa[last] - xa[last - 1]);
+    else {
+      const double delx = d - xa[ilo];
+      s[k] = ya[ilo] + delx * (t.b[node + ilo] + delx * (t.c[node + ilo] + delx * t.d[node + ilo]));
+    }
+  }
+  return ((1. - dx) * (1. - dy) * s[0] + (dx) * (1. - dy) * s[1] + (1. - dx) * (dy) * s[2] + (dx) * (dy) * s[3]);
+}
+
+// GSL's cspline_init for one (x, y) node of the collapse-time table (gsl_spline_init, src/collapse_times.c:1037-1041):
+// right-hand side, forward and back substitution with the shared LDL^t factors (pf_ct_tridiag), then the b, d that
+// cspline_eval derives from c.  c doubles as the work array of the substitutions.
+PF_HD void pf_ct_node_spline(const double *xa, const double *alpha, const double *gamma, const double *ya, double *c, double *b, double *d) {
+  const int n = PF_CT_NBINS_D, sys = n - 2;
+  double *z = c + 1;  // the interior unknowns live in c[1..n-2]
+  for (int i = 0; i < sys; i++) {
+    const double h_i = xa[i + 1] - xa[i], h_ip1 = xa[i + 2] - xa[i + 1];
+    const double ydiff_i = ya[i + 1] - ya[i], ydiff_ip1 = ya[i + 2] - ya[i + 1];
+    const double g_i = (h_i != 0.0) ? 1.0 / h_i : 0.0, g_ip1 = (h_ip1 != 0.0) ? 1.0 / h_ip1 : 0.0;
+    const double g = 3.0 * (ydiff_ip1 * g_ip1 - ydiff_i * g_i);
+    z[i] = (i == 0) ? g : g - gamma[i - 1] * z[i - 1];
+  }
+  for (int i = 0; i < sys; i++) z[i] = z[i] / alpha[i];
+  for (int i = sys - 2; i >= 0; i--) z[i] = z[i] - gamma[i] * z[i + 1];
+  c[0] = 0.0; c[n - 1] = 0.0;
+  for (int i = 0; i + 1 < n; i++) {
+    const double dx = xa[i + 1] - xa[i], dy = ya[i + 1] - ya[i];
+    b[i] = (dy / dx) - dx * (c[i + 1] + 2.0 * c[i]) / 3.0;
+    d[i] = (c[i + 1] - c[i]) / (3.0 * dx);
+  }
+  b[n - 1] = d[n - 1] = 0.0;
+}
+
+// host side of the TABULATED_CT splines: every node's spline has the same knots, so the LDL^t factors of GSL's
+// tridiagonal solve (alpha, gamma of solve_tridiag) are computed once here; k_ct_splines does the two substitutions
+// per node with the same operations in the same order as cspline_init.  n knots -> n - 2 entries each.
+inline void pf_ct_tridiag(const double *xa, int n, double *alpha, double *gamma) {
+  const int sys = n - 2;
+  for (int i = 0; i < sys; i++) {
+    const double h_i = xa[i + 1] - xa[i], h_ip1 = xa[i + 2] - xa[i + 1];
+    const double diag_i = 2.0 * (h_ip1 + h_i);
+    if (i == 0) alpha[0] = diag_i;
+    else alpha[i] = diag_i - (xa[i + 1] - xa[i]) * gamma[i - 1];  // offdiag[i-1] = h_i
+    gamma[i] = h_ip1 / alpha[i];                                  // offdiag[i] = h_ip1 (unused for the last row)
+  }
+}
+// the sampling in delta of initialize_collapse_times (src/collapse_times.c:836-876; CT_EXPO = 1.75, CT_SQUEEZE = 1.2,
+// CT_RANGE_D = 7, CT_DELTA0 = -1): finest around CT_DELTA0.  Host libm, like the reference.
+inline void pf_ct_delta_vector(double *delta_vector) {
+  const double CT_SQUEEZE = 1.2, CT_EXPO = 1.75, CT_RANGE_D = 7.0, CT_DELTA0 = -1.0;
+  const double deltaf = pow(CT_SQUEEZE / CT_EXPO, 1. / (CT_EXPO - 1.));
+  const double ref_interval = ((pow(CT_RANGE_D - CT_DELTA0, 2. - CT_EXPO) + pow(CT_RANGE_D + CT_DELTA0, 2. - CT_EXPO)
+                                - 2. * pow(deltaf, 2. - CT_EXPO)) / CT_EXPO / (2. - CT_EXPO) + 2. * deltaf / CT_SQUEEZE) / (PF_CT_NBINS_D - 2.0);
+  double del = -CT_RANGE_D;
+  for (int id = 0; id < PF_CT_NBINS_D; id++) {
+    delta_vector[id] = del;
+    double interval = CT_EXPO * ref_interval * pow(fabs(del - CT_DELTA0), CT_EXPO - 1.0);
+    interval = (interval / ref_interval < CT_SQUEEZE ? ref_interval * CT_SQUEEZE : interval);
+    del += interval;
+  }
 }
 
 // host-side: natural cubic spline coefficients exactly as GSL's cspline_init

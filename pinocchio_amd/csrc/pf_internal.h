@@ -79,6 +79,12 @@ struct PfSplineDev {
   const double *x, *y, *c, *b, *d;  // knots, GSL cspline c_i, and the per-interval b_i, d_i (pf_spline_bd)
   int n;
 };
+// TABULATED_CT table of one radius on the device (pf_collapse_core.h pf_ct_view)
+struct PfCtDev {
+  double *delta, *y, *b, *c, *d;   // [100], 4 x [50*50*100]
+  const double *alpha, *gamma;     // [98] factors of the shared tridiagonal system
+  double ampl;
+};
 struct PfCollapseParams {
   const void *h[6];     // Hessian fields, type F, rows of pitch reals
   long long pitch;
@@ -92,7 +98,10 @@ struct PfCollapseParams {
   int nblocks;
   int fast;             // 1: sincos/cbrt/exp10 forms of the transcendental hot spots (pf_collapse_core.h)
   int wpe;              // occupancy experiment: 0 default, 4 / 5 = register-capped builds
+  int tabulated;        // 1: F from the collapse-time table `ct` (TABULATED_CT build) instead of the direct solve
+  PfCtDev ct;
 };
+int pf_launch_ct_build(const PfSplineDev &sp, const PfCtDev &ct, int fast, int compute_table, hipStream_t st);
 int pf_launch_collapse(int field_bytes, const PfCollapseParams &p, hipStream_t st);
 int pf_launch_final_sum(const double *partials, int nblocks, double *out2, hipStream_t st);
 int pf_launch_collapse_cells(const double *d, size_t count, PfSplineDev s, double *F, int fast, hipStream_t st);

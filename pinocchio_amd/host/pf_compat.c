@@ -29,6 +29,11 @@
  *   int  compute_second_derivatives(double,int)             fmax.c:225   pf_second_derivatives + 6 downloads
  * Each transform makes a host round trip: a bring-up / tools seam, not what compute_fmax uses.
  *
+ * With -DTABULATED_CT (stand-alone build: pf_compat_tabulated_ct != 0) also
+ *   int initialize_collapse_times(int ismooth, int onlycompute)   collapse_times.c:820   pf_ct_build / pf_ct_load + the
+ *                                                                                        CTtable file, same format
+ *   int reset_collapse_times(int)                                 collapse_times.c:1046  nothing to reset
+ *
  * Build modes: stand-alone (default; globals from pf_compat_types.h, defined in
  * pf_compat_globals.c) or -DPF_IN_PINOCCHIO_TREE inside the reference source
  * tree (globals and cosmology from the reference itself, MPI for the
@@ -62,6 +67,24 @@
 #include <time.h>
 
 #include "../../include/pinfmax.h"
+
+#if defined(PF_IN_PINOCCHIO_TREE)
+#ifdef TABULATED_CT
+#define PF_TABULATED 1
+#else
+#define PF_TABULATED 0
+#endif
+#else
+#define PF_TABULATED pf_compat_tabulated_ct
+#endif
+#if !defined(PF_IN_PINOCCHIO_TREE) || defined(TABULATED_CT)
+#define PF_HAVE_CT 1
+int initialize_collapse_times(int ismooth, int onlycompute);
+int reset_collapse_times(int ismooth);
+#else
+#define initialize_collapse_times(a, b) 0
+#define reset_collapse_times(a) 0
+#endif
 
 static pf_ctx *pf_context = NULL;
 static int pf_density_on_device = 0; /* set by pf_compat_genic: kdensity[0] is not uploaded */
@@ -309,7 +332,12 @@ int compute_fmax(void) {
   rs = (double *)malloc(sizeof(double) * Smoothing.Nsmooth);
   for (ismooth = 0; ismooth < Smoothing.Nsmooth; ismooth++) rs[ismooth] = Smoothing.Radius[ismooth] / MyGrids[0].CellSize;
   Rsmooth = rs[Smoothing.Nsmooth - 1];
-  if (pf_sweep(pf_context, Smoothing.Nsmooth, rs, Smoothing.TrueVariance)) { free(rs); return 1; }
+  if (PF_TABULATED) { /* src/fmax.c:66-150 radius by radius: derivatives, table of this radius, collapse times */
+    for (ismooth = 0; ismooth < Smoothing.Nsmooth; ismooth++) {
+      if (pf_second_derivatives(pf_context, rs[ismooth]) || initialize_collapse_times(ismooth, 0) ||
+          compute_collapse_times(ismooth) || reset_collapse_times(ismooth)) { free(rs); return 1; }
+    }
+  } else if (pf_sweep(pf_context, Smoothing.Nsmooth, rs, Smoothing.TrueVariance)) { free(rs); return 1; }
   free(rs);
   if (!ThisTask)
     for (ismooth = 0; ismooth < Smoothing.Nsmooth; ismooth++)
@@ -554,3 +582,97 @@ int compute_second_derivatives(double R, int ThisGrid) {
     if (pf_get_second_derivative(pf_context, i, second_derivatives[ThisGrid][i])) return 1;
   return 0;
 }
+
+#ifdef PF_HAVE_CT
+/* ------------------------------------------------------------------------------------------------------------
+ * TABULATED_CT (src/collapse_times.c:780-1231): the table of each radius is computed on the device (or read from
+ * params.CTtableFile) and the node splines are built there; the table file keeps the reference's binary format:
+ *   header  int type (1 = ELL_CLASSIC), double Omega0, OmegaLambda, Hubble100, int Ncomputations, CT_NBINS_D, CT_NBINS_XY
+ *   per radius  int ismooth, double CT_table[Ncomputations]
+ * ------------------------------------------------------------------------------------------------------------ */
+#define PF_CT_NBINS_XY 50
+#define PF_CT_NBINS_D 100
+#define PF_CT_NCOMP (PF_CT_NBINS_D * PF_CT_NBINS_XY * PF_CT_NBINS_XY)
+static FILE *CTtableFilePointer = NULL;
+static double *pf_ct_host = NULL;
+
+static int check_CTtable_header(void) { /* :1235-1296, ELL_CLASSIC */
+  int fail = 0, dummy = 0;
+  double fdummy = 0;
+  if (fread(&dummy, sizeof(int), 1, CTtableFilePointer) != 1) return 1;
+  if (dummy != 1) { printf("ERROR: CT table not constructed for ELL_CLASSIC, %d\n", dummy); fail = 1; }
+  if (fread(&fdummy, sizeof(double), 1, CTtableFilePointer) != 1) return 1;
+  if (fabs(fdummy - params.Omega0) > 1.e-10) { printf("ERROR: CT table constructed for the wrong Omega0, %f in place of %f\n", fdummy, params.Omega0); fail = 1; }
+  if (fread(&fdummy, sizeof(double), 1, CTtableFilePointer) != 1) return 1;
+  if (fabs(fdummy - params.OmegaLambda) > 1.e-10) { printf("ERROR: CT table constructed for the wrong OmegaLambda, %f in place of %f\n", fdummy, params.OmegaLambda); fail = 1; }
+  if (fread(&fdummy, sizeof(double), 1, CTtableFilePointer) != 1) return 1;
+  if (fabs(fdummy - params.Hubble100) > 1.e-10) { printf("ERROR: CT table constructed for the wrong Hubble100, %f in place of %f\n", fdummy, params.Hubble100); fail = 1; }
+  if (fread(&dummy, sizeof(int), 1, CTtableFilePointer) != 1) return 1;
+  if (dummy != PF_CT_NCOMP) { printf("ERROR: CT table has the wrong size, %d in place of %d\n", dummy, PF_CT_NCOMP); fail = 1; }
+  if (fread(&dummy, sizeof(int), 1, CTtableFilePointer) != 1) return 1;
+  if (dummy != PF_CT_NBINS_D) { printf("ERROR: CT table has the wrong density sampling, %d in place of %d\n", dummy, PF_CT_NBINS_D); fail = 1; }
+  if (fread(&dummy, sizeof(int), 1, CTtableFilePointer) != 1) return 1;
+  if (dummy != PF_CT_NBINS_XY) { printf("ERROR: CT table has the wrong x and y sampling, %d in place of %d\n", dummy, PF_CT_NBINS_XY); fail = 1; }
+  return fail;
+}
+static void write_CTtable_header(void) { /* :1300-1340 */
+  int dummy = 1;
+  fwrite(&dummy, sizeof(int), 1, CTtableFilePointer);
+  fwrite(&params.Omega0, sizeof(double), 1, CTtableFilePointer);
+  fwrite(&params.OmegaLambda, sizeof(double), 1, CTtableFilePointer);
+  fwrite(&params.Hubble100, sizeof(double), 1, CTtableFilePointer);
+  dummy = PF_CT_NCOMP; fwrite(&dummy, sizeof(int), 1, CTtableFilePointer);
+  dummy = PF_CT_NBINS_D; fwrite(&dummy, sizeof(int), 1, CTtableFilePointer);
+  dummy = PF_CT_NBINS_XY; fwrite(&dummy, sizeof(int), 1, CTtableFilePointer);
+}
+
+/* src/collapse_times.c:820-1043 */
+int initialize_collapse_times(int ismooth, int onlycompute) {
+  int fail = 0, dummy;
+  char fname[LBLENGTH];
+  if (!pf_context && pf_upload_inputs()) return 1;
+  if (!pf_ct_host) pf_ct_host = (double *)malloc(sizeof(double) * PF_CT_NCOMP);
+  if (!ismooth && !ThisTask)
+    printf("[%s] Grid for interpolating collapse times: CT_NBINS_D=%d, CT_NBINS_XY=%d\n", fdate(), PF_CT_NBINS_D, PF_CT_NBINS_XY);
+  if (strcmp(params.CTtableFile, "none") && !onlycompute) { /* read the table of this radius from the file */
+    if (!ismooth) {
+      if (!ThisTask) {
+        CTtableFilePointer = fopen(params.CTtableFile, "r");
+        fail = CTtableFilePointer ? check_CTtable_header() : 1;
+        if (!CTtableFilePointer) printf("ERROR on task %d: could not open file %s\n", ThisTask, params.CTtableFile);
+      }
+#ifdef PF_IN_PINOCCHIO_TREE
+      MPI_Bcast(&fail, sizeof(int), MPI_BYTE, 0, MPI_COMM_WORLD);
+#endif
+      if (fail) return 1;
+    }
+    if (!ThisTask) {
+      if (fread(&dummy, sizeof(int), 1, CTtableFilePointer) != 1 ||
+          fread(pf_ct_host, sizeof(double), PF_CT_NCOMP, CTtableFilePointer) != (size_t)PF_CT_NCOMP) fail = 1;
+      if (ismooth == Smoothing.Nsmooth - 1) { fclose(CTtableFilePointer); CTtableFilePointer = NULL; }
+    }
+#ifdef PF_IN_PINOCCHIO_TREE
+    MPI_Bcast(&fail, sizeof(int), MPI_BYTE, 0, MPI_COMM_WORLD);
+    MPI_Bcast(pf_ct_host, PF_CT_NCOMP, MPI_DOUBLE, 0, MPI_COMM_WORLD);
+#endif
+    if (fail) { printf("ERROR on task %d: short read of the collapse-time table\n", ThisTask); return 1; }
+    return pf_ct_load(pf_context, ismooth, Smoothing.Variance[ismooth], pf_ct_host);
+  }
+  /* compute the table of this radius: every task computes all of it on its GPU (0.25 M evaluations) instead of the
+     reference's split over tasks + MPI_Allgatherv; task 0 writes the file */
+  if (pf_ct_build(pf_context, ismooth, Smoothing.Variance[ismooth], pf_ct_host)) return 1;
+  if (!ThisTask) {
+    if (onlycompute) strcpy(fname, params.CTtableFile);
+    else sprintf(fname, "pinocchio.%s.CTtable.out", params.RunFlag);
+    CTtableFilePointer = fopen(fname, ismooth ? "a" : "w");
+    if (!CTtableFilePointer) { printf("ERROR on task %d: could not open file %s\n", ThisTask, fname); return 1; }
+    if (!ismooth) write_CTtable_header();
+    fwrite(&ismooth, sizeof(int), 1, CTtableFilePointer);
+    fwrite(pf_ct_host, sizeof(double), PF_CT_NCOMP, CTtableFilePointer);
+    fclose(CTtableFilePointer);
+    CTtableFilePointer = NULL;
+  }
+  return 0;
+}
+int reset_collapse_times(int ismooth) { (void)ismooth; return 0; } /* :1046-1108: debug statistics only */
+#endif

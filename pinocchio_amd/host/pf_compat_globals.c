@@ -27,3 +27,4 @@ static pfft_complex *cvector_slots[1] = {0};
 static double *rvector_slots[1] = {0};
 pfft_complex **cvector_fft = cvector_slots;
 double **rvector_fft = rvector_slots;
+int pf_compat_tabulated_ct = 0;

@@ -73,6 +73,8 @@ typedef struct /* the tags of param_data (:311-352) the path uses */
   char RunFlag[SBLENGTH], DumpDir[SBLENGTH];
   int GridSize[3], RandomSeed;
   double Omega0, OmegaBaryon, Hubble100, Sigma8, PrimordialIndex, BoxSize_htrue; /* read by pf_compat_genic only */
+  double OmegaLambda;        /* with Omega0 and Hubble100 in the header of the collapse-time table file */
+  char CTtableFile[LBLENGTH]; /* "none": compute the tables (TABULATED_CT build) */
 } param_data;
 
 /* gsl_spline as far as my_spline_eval dereferences it (src/cosmo.c:2016-2027) */
@@ -105,6 +107,8 @@ extern double (*pf_GrowingMode_3LPT_1)(double z, double k);
 extern double (*pf_GrowingMode_3LPT_2)(double z, double k);
 /* non-zero: behave like a -DSCALE_DEPENDENT build -- the growth functions above are sampled at the NkBINS k-bins
    (src/def_splines.h:40-42) and applied per mode; pf_invgrow_knots_radius[ismooth] = SPLINE_INVGROW[ismooth] */
+/* non-zero: behave like a -DTABULATED_CT build (src/collapse_times.c:780-1231) */
+extern int pf_compat_tabulated_ct;
 extern int pf_compat_scale_dependent;
 extern pf_spline_knots pf_invgrow_knots_radius[64];
 

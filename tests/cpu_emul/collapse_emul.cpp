@@ -30,3 +30,19 @@ extern "C" int emul_spline(const double *sx, const double *sy, int nk, const dou
   for (long i = 0; i < count; i++) out[i] = pf_spline_eval(s, v[i]);
   return 0;
 }
+
+// TABULATED_CT pieces of the header: delta sampling, shared tridiagonal factors, node splines, interpolation
+extern "C" int emul_ct(const double *table /*[50*50*100]*/, double ampl, const double *lam /*[3*count]*/, long count,
+                       double *delta_out /*[100]*/, double *F) {
+  const int nd = PF_CT_NBINS_D, nn = PF_CT_NBINS_XY * PF_CT_NBINS_XY;
+  std::vector<double> delta(nd), alpha(nd), gamma(nd), c((size_t)nn * nd), b((size_t)nn * nd), d((size_t)nn * nd);
+  pf_ct_delta_vector(delta.data());
+  pf_ct_tridiag(delta.data(), nd, alpha.data(), gamma.data());
+  for (int node = 0; node < nn; node++)
+    pf_ct_node_spline(delta.data(), alpha.data(), gamma.data(), table + (size_t)node * nd, c.data() + (size_t)node * nd,
+                      b.data() + (size_t)node * nd, d.data() + (size_t)node * nd);
+  pf_ct_view t{delta.data(), table, b.data(), c.data(), d.data(), ampl};
+  for (long i = 0; i < count; i++) F[i] = pf_interpolate_collapse_time(t, lam[3 * i], lam[3 * i + 1], lam[3 * i + 2]);
+  for (int i = 0; i < nd; i++) delta_out[i] = delta[i];
+  return 0;
+}

@@ -69,6 +69,14 @@ def lib():
         L.orc_spline_eval.restype = C.c_double
         L.orc_spline_eval.argtypes = [C.c_void_p, C.c_double]
         L.orc_timers.argtypes = [C.c_void_p, dp]
+        L.orc_set_tabulated_ct.argtypes = [C.c_void_p, C.c_int, dp]
+        L.orc_ct_build.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        L.orc_ct_table.restype = dp
+        L.orc_ct_table.argtypes = [C.c_void_p]
+        L.orc_ct_delta.restype = dp
+        L.orc_ct_delta.argtypes = [C.c_void_p]
+        L.orc_interpolate_collapse_time.restype = C.c_double
+        L.orc_interpolate_collapse_time.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
         L.orc_select_sorted.restype = C.c_size_t
         L.orc_select_sorted.argtypes = [C.c_void_p, C.c_float, C.POINTER(C.c_uint), C.POINTER(C.c_float)]
         _lib = L
@@ -146,6 +154,20 @@ class Oracle:
     def displacements(self, compute_sources=True):
         rc = self.L.orc_compute_displacements(self.h, int(compute_sources))
         assert rc == 0
+
+    def set_tabulated_ct(self, variance):
+        v = np.ascontiguousarray(variance, dtype=np.float64)
+        assert self.L.orc_set_tabulated_ct(self.h, len(v), _dp(v) if len(v) else None) == 0
+
+    def ct_build(self, ismooth: int, variance: float):
+        """-> (CT_table[iy][ix][id], delta_vector[id]) of initialize_collapse_times (src/collapse_times.c:820)"""
+        assert self.L.orc_ct_build(self.h, ismooth, variance) == 0
+        t = np.ctypeslib.as_array(self.L.orc_ct_table(self.h), shape=(50, 50, 100)).copy()
+        d = np.ctypeslib.as_array(self.L.orc_ct_delta(self.h), shape=(100,)).copy()
+        return t, d
+
+    def interpolate_collapse_time(self, l1, l2, l3):
+        return self.L.orc_interpolate_collapse_time(self.h, l1, l2, l3)
 
     def select_sorted(self, flast: float):
         idx = np.empty(self.n ** 3, dtype=np.uint32)

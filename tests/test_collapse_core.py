@@ -103,3 +103,26 @@ def test_fast_flavour_agrees_to_ulps(emul):
     assert rel.max() < 1e-5
     # stored value: fp32
     assert np.mean(F0.astype(np.float32) != F1.astype(np.float32)) < 2e-4
+
+
+def test_tabulated_ct_header_matches_oracle_bitwise(emul):
+    """delta sampling, node splines (shared LDL^t factors + GSL's substitutions) and the bilinear-of-splines lookup of
+    the device header on the host against the oracle's restatement of src/collapse_times.c:780-1231: identical doubles"""
+    x, y = synth.invgrow_table("lcdm")
+    o = oracle_lib.Oracle(8, 2)
+    o.set_invgrow(x, y)
+    var = 2.3
+    tab, dv = o.ct_build(0, var)
+    rng = np.random.default_rng(11)
+    n = 5000
+    ampl = np.sqrt(var)
+    d = rng.uniform(-9.0, 9.0, n)              # beyond +-7: my_spline_eval's linear extrapolation
+    xx = rng.uniform(0.0, 4.0, n)              # beyond 3.5: index clamp
+    yy = rng.uniform(0.0, 4.0, n)
+    lam = np.stack([(d + 2 * xx + yy) / 3.0 * ampl, (d - xx + yy) / 3.0 * ampl, (d - xx - 2 * yy) / 3.0 * ampl], axis=1).copy()
+    F = np.empty(n); delta = np.empty(100)
+    emul.emul_ct.argtypes = [dp, C.c_double, dp, C.c_long, dp, dp]
+    assert emul.emul_ct(_dp(np.ascontiguousarray(tab)), ampl, _dp(lam), n, _dp(delta), _dp(F)) == 0
+    assert np.array_equal(delta, dv)
+    want = np.array([o.interpolate_collapse_time(*l) for l in lam])
+    assert np.array_equal(F, want)

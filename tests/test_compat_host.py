@@ -39,7 +39,8 @@ class ScaleDep(C.Structure):
 class Params(C.Structure):
     _fields_ = [("RunFlag", C.c_char * 100), ("DumpDir", C.c_char * 100), ("GridSize", C.c_int * 3), ("RandomSeed", C.c_int),
                 ("Omega0", C.c_double), ("OmegaBaryon", C.c_double), ("Hubble100", C.c_double), ("Sigma8", C.c_double),
-                ("PrimordialIndex", C.c_double), ("BoxSize_htrue", C.c_double)]
+                ("PrimordialIndex", C.c_double), ("BoxSize_htrue", C.c_double), ("OmegaLambda", C.c_double),
+                ("CTtableFile", C.c_char * 400)]
 
 
 class Knots(C.Structure):
@@ -397,3 +398,91 @@ def test_fft_module_seam_like_the_density_writer(lib):
     for i in range(6):
         assert np.max(np.abs(hes[i] - ho[i])) <= 1e-12 * np.max(np.abs(ho[i]))
     assert lib.finalize_fft() == 0
+
+
+@pytest.mark.gpu
+def test_tabulated_ct_build_through_the_reference_driver(lib, tmp_path):
+    """-DTABULATED_CT flow of compute_fmax (src/fmax.c:66-150): per radius second derivatives, initialize_collapse_times
+    (table on the device, written to pinocchio.<run>.CTtable.out in the reference's binary format), collapse times by
+    interpolation; then the same run reading the table back through params.CTtableFile"""
+    n, cell = 32, 2.0
+    dk = np.ascontiguousarray(synth.make_density(n, seed=23))
+    radii_mpc = np.array([4.0, 2.0, 0.0])
+    x, y = synth.invgrow_table("lcdm")
+    g = synth.growth_multipliers()
+    o = oracle_lib.Oracle(n, 0)
+    o.set_density(dk); o.set_invgrow(x, y); o.set_growth(g)
+    var = o.compute_fmax(radii_mpc / cell, do_lpt=False) * 1.05      # stands in for the expected variance
+    o.set_tabulated_ct(var)
+    tv_o = o.compute_fmax(radii_mpc / cell, do_lpt=True)
+    po = o.products()
+
+    grid = C.cast(C.c_void_p.in_dll(lib, "MyGrids"), C.POINTER(Grid)).contents
+    for i in range(3):
+        grid.GSglobal[i] = n
+    grid.Ntotal = n ** 3
+    grid.BoxSize = n * cell
+    assert lib.set_one_grid(0) == 0
+    prod = np.zeros(n ** 3 * 56 + 64, dtype=np.uint8)
+    prod = prod[(-prod.ctypes.data) % 32:][:n ** 3 * 56]
+    C.c_void_p.in_dll(lib, "products").value = prod.ctypes.data
+    kd = C.cast(C.c_void_p.in_dll(lib, "kdensity"), C.POINTER(C.c_void_p))
+    kd[0] = dk.ctypes.data
+    sm = Smoothing.in_dll(lib, "Smoothing")
+    tv = np.zeros(len(radii_mpc))
+    sm.Nsmooth = len(radii_mpc)
+    sm.Radius = radii_mpc.ctypes.data_as(C.POINTER(C.c_double))
+    sm.Variance = var.ctypes.data_as(C.POINTER(C.c_double))
+    sm.TrueVariance = tv.ctypes.data_as(C.POINTER(C.c_double))
+    sd = ScaleDep.in_dll(lib, "ScaleDep")
+    sd.nseg = 1
+    sd.z[0] = 0.0
+    kn = Knots.in_dll(lib, "pf_invgrow_knots")
+    kn.size = len(x)
+    kn.x = x.ctypes.data_as(C.POINTER(C.c_double))
+    kn.y = y.ctypes.data_as(C.POINTER(C.c_double))
+    fns = [GROWTH_FN(lambda z, k, v=v: float(v)) for v in g]
+    for name, fn in zip(("pf_GrowingMode", "pf_GrowingMode_2LPT", "pf_GrowingMode_3LPT_1", "pf_GrowingMode_3LPT_2"), fns):
+        C.c_void_p.in_dll(lib, name).value = C.cast(fn, C.c_void_p).value
+    par = Params.in_dll(lib, "params")
+    par.RunFlag = b"pfct"
+    par.GridSize[0] = par.GridSize[1] = par.GridSize[2] = n
+    par.Omega0, par.OmegaLambda, par.Hubble100 = 0.25, 0.75, 0.7
+    par.CTtableFile = b"none"
+    C.c_int.in_dll(lib, "pf_compat_scale_dependent").value = 0
+    C.c_int.in_dll(lib, "pf_compat_tabulated_ct").value = 1
+
+    def check():
+        p = prod.view(oracle_lib.PRODUCT_DTYPE).reshape(n, n, n)
+        assert np.allclose(tv, tv_o, rtol=1e-12)
+        ulp = np.spacing(np.maximum(np.abs(po["Fmax"]), 1.0).astype(np.float32)).astype(np.float64)
+        assert np.mean(np.abs(p["Fmax"].astype(np.float64) - po["Fmax"]) > 2 * ulp) < 1e-4
+        assert np.mean(p["Rmax"] != po["Rmax"]) < 1e-3
+        assert np.max(np.abs(p["Vel_2LPT"].astype(np.float64) - po["Vel_2LPT"])) <= 4e-7 * np.max(np.abs(po["Vel_2LPT"]))
+        return p["Fmax"].copy()
+
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        assert lib.compute_fft_plans() == 0
+        assert lib.compute_fmax() == 0
+        first = check()
+        fname = tmp_path / "pinocchio.pfct.CTtable.out"
+        assert fname.stat().st_size == 4 + 3 * 8 + 3 * 4 + len(radii_mpc) * (4 + 8 * 250000)
+        raw = fname.read_bytes()
+        assert np.frombuffer(raw[:4], dtype=np.int32)[0] == 1 and np.frombuffer(raw[28:40], dtype=np.int32).tolist() == [250000, 100, 50]
+        tab1 = np.frombuffer(raw[40 + 4 + 2000000 + 4:40 + 2 * (4 + 2000000)], dtype=np.float64).reshape(50, 50, 100)
+        t_o, _ = o.ct_build(1, var[1])
+        nz = (tab1 != 0) & (t_o != 0)
+        assert np.mean(np.abs(tab1[nz] - t_o[nz]) > 1e-11 * np.maximum(1.0, t_o[nz])) < 3e-3
+        # second run: the table comes from the file
+        par.CTtableFile = str(fname).encode()
+        prod[:] = 0
+        tv[:] = 0
+        assert lib.compute_fft_plans() == 0
+        assert lib.compute_fmax() == 0
+        assert np.array_equal(check(), first)
+    finally:
+        os.chdir(cwd)
+        C.c_int.in_dll(lib, "pf_compat_tabulated_ct").value = 0
+        par.CTtableFile = b"none"

@@ -571,3 +571,52 @@ def test_select_sorted_and_snapshot_blocks(api):
     assert np.array_equal(blocks["FMAX"], F) and np.array_equal(blocks["RMAX"], p["Rmax"].ravel())
     for name, col in (("ZEL ", "Vel"), ("2LPT", "Vel_2LPT"), ("31PT", "Vel_3LPT_1"), ("32PT", "Vel_3LPT_2")):
         assert np.array_equal(blocks[name], p[col].reshape(-1, 3))
+
+
+def test_tabulated_ct_build_vs_oracle(api):
+    """row f-4, TABULATED_CT build (src/collapse_times.c:780-1231): the table of ell() made on the device, the node
+    splines and the interpolating collapse-time pass against the oracle's restatement (there is no reference output
+    for this build option; the restatement is checked against scipy in tests/test_oracle.py)"""
+    n = 64
+    dk = synth.make_density(n, seed=41)
+    x, y = synth.invgrow_table("lcdm")
+    radii = np.array([3.0, 1.5, 0.0])
+    o = oracle_lib.Oracle(n, 0)
+    o.set_density(dk); o.set_invgrow(x, y)
+    var = o.compute_fmax(radii, do_lpt=False) * 1.1          # stands in for Smoothing.Variance (the expected variance)
+    direct = o.products()
+    o.set_tabulated_ct(var)
+    tv_o = o.compute_fmax(radii, do_lpt=False)
+    po = o.products()
+    tab_o, dv = o.ct_build(1, var[1])
+    with api.Fmax(n) as f:
+        f.set_density(dk); f.set_invgrow(x, y)
+        tab = f.ct_build(1, var[1])
+        # table entries: the device's libm (and the sincos / cbrt / exp10 forms) against glibc
+        nz = (tab_o != 0) & (tab != 0)
+        assert np.mean((tab_o != 0) != (tab != 0)) < 1e-4 and nz.mean() > 0.3
+        err = np.abs(tab[nz] - tab_o[nz]) / np.maximum(1.0, tab_o[nz])
+        # the regular grid puts ~0.1 % of its nodes next to the surface den = 0, the ill-conditioned branch of the
+        # cubic (DESIGN.md section 4), where one ulp in the libm calls moves ell() by up to 1e-5
+        assert np.mean(err > 1e-11) < 3e-3 and np.mean(err > 1e-7) < 3e-4 and err.max() < 2e-3, (np.mean(err > 1e-11), np.mean(err > 1e-7), err.max())
+        f.set_tabulated_ct(var)
+        tv = f.sweep(radii)
+        p = f.products()
+        assert np.allclose(tv, tv_o, rtol=1e-12)
+        _fmax_close(p["Fmax"], po["Fmax"])
+        assert np.mean(p["Rmax"] != po["Rmax"]) < 1e-3
+        assert np.mean(po["Fmax"] != direct["Fmax"]) > 0.5   # the table really replaced the direct solve
+        # the reference's own order of calls with a table read from a file (params.CTtableFile):
+        # compute_second_derivatives; initialize_collapse_times; compute_collapse_times
+        f.set_tabulated_ct([])
+        fm = None
+        for i, r in enumerate(radii):
+            f.compute_second_derivatives(r)
+            t_i, _ = o.ct_build(i, var[i])
+            f.ct_load(i, var[i], t_i)
+            f.compute_collapse_times(i)
+        p2 = f.products()
+    # same table bit for bit on both sides: only the Hessian's rounding is left
+    ulp = np.spacing(np.maximum(np.abs(po["Fmax"]), 1.0).astype(np.float32)).astype(np.float64)
+    assert np.mean(np.abs(p2["Fmax"].astype(np.float64) - po["Fmax"]) > 2 * ulp) < 2e-5
+    assert np.mean(p2["Rmax"] != po["Rmax"]) < 1e-3

@@ -256,3 +256,61 @@ def test_select_sorted_is_the_fragmentation_order():
         order = sel[np.lexsort((sel, -F[sel].astype(np.float64)))]
         assert np.array_equal(idx, order.astype(np.uint32)) and np.array_equal(f, F[order])
     assert len(o.select_sorted(-20.0)[0]) == n ** 3 and len(o.select_sorted(1e9)[0]) == 0
+
+
+def test_tabulated_ct_restatement_vs_scipy():
+    """TABULATED_CT (row f-4; no reference output exists for it, so this restatement is pinned only by construction):
+    the delta sampling, the table of ell() and the bilinear-of-splines interpolation against scipy's natural spline"""
+    from scipy.interpolate import CubicSpline
+    n = 16
+    x, y = synth.invgrow_table("lcdm")
+    o = oracle_lib.Oracle(n, 4)
+    o.set_invgrow(x, y)
+    var = 1.7
+    tab, dv = o.ct_build(0, var)
+    # sampling (src/collapse_times.c:836-876): starts at -CT_RANGE_D, finest (1.2 ref_interval) around CT_DELTA0 = -1
+    assert dv[0] == -7.0 and np.all(np.diff(dv) > 0) and 6.0 < dv[-1] < 8.0
+    steps = np.diff(dv)
+    fine = dv[:-1][steps <= steps.min() * (1 + 1e-12)]      # the plateau of smallest steps straddles CT_DELTA0
+    assert fine.min() < -1.0 < fine.max() + steps.min() and steps.max() / steps.min() > 2.0
+    # table nodes are ell() of the (delta, x, y) grid scaled by sqrt(variance)
+    ampl, bin_x = np.sqrt(var), 3.5 / 50
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        iy, ix, idd = rng.integers(0, 50), rng.integers(0, 50), rng.integers(0, 100)
+        xx, yy = ix * bin_x, iy * bin_x
+        l = [(dv[idd] + 2 * xx + yy) / 3.0 * ampl, (dv[idd] - xx + yy) / 3.0 * ampl, (dv[idd] - xx - 2 * yy) / 3.0 * ampl]
+        bc = o.L.orc_ell_classic(*l)
+        want = 1.0 + o.L.orc_inverse_growing_mode(o.h, bc) if bc > 0 else 0.0
+        assert tab[iy, ix, idd] == want
+    assert (tab > 0).mean() > 0.3 and (tab == 0).mean() > 0.05
+    # interpolation: four natural splines in delta, bilinear in (x, y)
+    for _ in range(300):
+        d, xx, yy = rng.uniform(-6.5, 6.5), rng.uniform(0, 3.4), rng.uniform(0, 3.4)
+        l1, l2, l3 = (d + 2 * xx + yy) / 3.0 * ampl, (d - xx + yy) / 3.0 * ampl, (d - xx - 2 * yy) / 3.0 * ampl
+        dd, x2, y2 = (l1 + l2 + l3) / ampl, (l1 - l2) / ampl, (l2 - l3) / ampl
+        ix, iy = min(int(x2 / bin_x), 48), min(int(y2 / bin_x), 48)
+        fx, fy = x2 / bin_x - ix, y2 / bin_x - iy
+        sp = lambda i, j: float(CubicSpline(dv, tab[j, i], bc_type="natural")(dd))
+        want = (1 - fx) * (1 - fy) * sp(ix, iy) + fx * (1 - fy) * sp(ix + 1, iy) + (1 - fx) * fy * sp(ix, iy + 1) + fx * fy * sp(ix + 1, iy + 1)
+        got = o.interpolate_collapse_time(l1, l2, l3)
+        assert abs(got - want) <= 1e-10 * max(1.0, abs(want))
+    # beyond the delta range my_spline_eval extrapolates linearly from the end knots
+    l = [(9.0 + 0.2) / 3.0 * ampl, (9.0 - 0.1) / 3.0 * ampl, (9.0 - 0.1) / 3.0 * ampl]
+    t0 = tab[0, 1, :]  # not exactly at a node; only continuity matters here
+    assert np.isfinite(o.interpolate_collapse_time(*l))
+    # the sweep with the table in place: same cells collapse, F close to the direct solve where F >= 1
+    dk = synth.make_density(n, seed=12)
+    radii = np.array([2.0, 0.0])
+    o.set_density(dk)
+    tv = o.compute_fmax(radii, do_lpt=False)
+    direct = o.products()["Fmax"].copy()
+    o.set_tabulated_ct(tv)          # the reference uses the expected variance; the measured one will do here
+    o.compute_fmax(radii, do_lpt=False)
+    tabbed = o.products()["Fmax"]
+    both = (direct >= 1.0) & (tabbed >= 1.0)
+    assert both.mean() > 0.05 and np.mean((direct >= 1.0) != (tabbed >= 1.0)) < 0.02
+    assert np.median(np.abs(tabbed[both] - direct[both]) / direct[both]) < 5e-3
+    o.set_tabulated_ct([])
+    o.compute_fmax(radii, do_lpt=False)
+    assert np.array_equal(o.products()["Fmax"], direct)
