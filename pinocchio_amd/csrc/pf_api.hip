@@ -115,6 +115,7 @@ struct pf_ctx {
   PfCtDev ct;
   double *ct_block;    // delta | alpha | gamma | y | b | c | d
   bool have_density, have_hessian, have_sources, products_init;
+  bool vel_zero_pending;  // the Vel* columns are to read as zero (src/collapse_times.c:472-489) but have not been cleared yet
   int last_ns;
   pf_alltoall_fn a2a; void *a2a_user;
   pf_allreduce_fn ared; void *ared_user;
@@ -205,6 +206,7 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   c->dev_bytes = 0; c->own_stream = true; c->stream = nullptr;
   c->a2a = nullptr; c->ared = nullptr; c->a2a_user = c->ared_user = nullptr; c->rccl = nullptr;
   c->have_density = c->have_hessian = c->have_sources = c->products_init = false; c->last_ns = 0;
+  c->vel_zero_pending = false;
   memset(c->ks_ms, 0, sizeof(c->ks_ms)); memset(c->ks_bytes, 0, sizeof(c->ks_bytes)); memset(c->ks_n, 0, sizeof(c->ks_n));
   memset(&c->cpu, 0, sizeof(c->cpu)); memset(c->spl_set, 0, sizeof(c->spl_set)); memset(c->spl_n, 0, sizeof(c->spl_n));
   c->growth[0] = 1.0; c->growth[1] = 3. / 7.; c->growth[2] = -1. / 9.; c->growth[3] = 5. / 42.;
@@ -826,13 +828,29 @@ static int zcollapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], const dou
   return 0;
 }
 
+// compute_collapse_times at ismooth = 0 resets the products (src/collapse_times.c:461-492: Fmax = -10, Rmax = -1, every
+// Vel = 0).  The collapse kernel of the first radius writes Fmax/Rmax of every cell itself; the 48 bytes per cell of
+// velocities are cleared only if somebody reads them before pf_displacements has rewritten all twelve columns.
+static int products_reset(pf_ctx *c, hipStream_t st) {
+  if (c->fuse) { PFCHK(c, pf_launch_fill_products(c->fmax, c->rmax, c->vel12, ncell(c), st)); c->vel_zero_pending = false; }
+  else c->vel_zero_pending = true;
+  c->products_init = true;
+  return 0;
+}
+static int velocities_ready(pf_ctx *c) {
+  if (c->vel_zero_pending) {
+    HIPCHK(c, hipMemsetAsync(c->vel12, 0, 12 * ncell(c) * sizeof(float), c->stream));
+    c->vel_zero_pending = false;
+  }
+  return 0;
+}
+
 extern "C" int pf_collapse_times(pf_ctx *c, int ismooth, double *tv) {
   if (!c) return 1;
   if (!c->have_hessian) return pf_fail(c->rank, "pf_collapse_times: second derivatives not computed");
   if (ismooth < 0 || ismooth >= PF_MAX_SMOOTH) return pf_fail(c->rank, "pf_collapse_times: ismooth %d out of range", ismooth);
   if (ismooth == 0) {  // src/collapse_times.c:461-492
-    PFCHK(c, pf_launch_fill_products(c->fmax, c->rmax, c->vel12, ncell(c), c->stream));
-    c->products_init = true;
+    PFCHK(c, products_reset(c, c->stream));
   } else if (!c->products_init)
     return pf_fail(c->rank, "pf_collapse_times: products not initialised (ismooth 0 must come first)");
   {
@@ -861,8 +879,7 @@ extern "C" int pf_sweep(pf_ctx *c, int ns, const double *radius_cells, double *t
   // max stays in radius order because every collapse launch is on stream2.
   HIPCHK(c, hipEventRecord(c->ev_h[0], c->stream));
   HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_h[0], 0));
-  PFCHK(c, pf_launch_fill_products(c->fmax, c->rmax, c->vel12, ncell(c), c->overlap ? c->stream2 : c->stream));
-  c->products_init = true;
+  PFCHK(c, products_reset(c, c->overlap ? c->stream2 : c->stream));
   const bool xy_only = c->fuse;
   auto pre = [&](int ismooth, void *const *A) {
     PhaseTimer pt(c, 0);
@@ -955,6 +972,7 @@ extern "C" int pf_displacements(pf_ctx *c, int compute_sources, int recompute_sd
     const void *const specs[4] = {c->S[0], c->S[1], c->S[2], c->dk};
     const int orders[4] = {1, 2, 3, 0};
     PFCHK(c, displacements_of(c, 4, specs, orders, tmp));
+    c->vel_zero_pending = false;  // all twelve columns rewritten
   }
   return 0;
 }
@@ -973,6 +991,7 @@ extern "C" int pf_fmax_pdf(pf_ctx *c, unsigned long long hist[PF_NBINS]) {
 extern "C" int pf_get_products(pf_ctx *c, void *host, const pf_product_layout *l) {
   if (!c || !host || !l) return pf_fail(0, "pf_get_products: null argument");
   if (l->stride < 8 || l->stride % 4) return pf_fail(c->rank, "pf_get_products: bad stride %zu", l->stride);
+  PFCHK(c, velocities_ready(c));
   PhaseTimer pt(c, 3);
   const size_t nc = ncell(c);
   const size_t cap = (2 * c->field_bytes) / l->stride;  // records per chunk in the staging area
@@ -994,6 +1013,7 @@ extern "C" int pf_get_products(pf_ctx *c, void *host, const pf_product_layout *l
 extern "C" int pf_update_products(pf_ctx *c, void *host, const pf_product_layout *l) {
   if (!c || !host || !l) return pf_fail(0, "pf_update_products: null argument");
   if (l->stride < 8 || l->stride % 4) return pf_fail(c->rank, "pf_update_products: bad stride %zu", l->stride);
+  PFCHK(c, velocities_ready(c));
   PhaseTimer pt(c, 3);
   const size_t nc = ncell(c);
   const size_t cap = (2 * c->field_bytes) / l->stride;
@@ -1027,6 +1047,7 @@ extern "C" int pf_select_sorted(pf_ctx *c, float flast, size_t capacity, unsigne
 extern "C" int pf_get_block(pf_ctx *c, const char *name, int id_bytes, void *host) {
   if (!c || !name || !host) return pf_fail(0, "pf_get_block: null argument");
   if (!c->products_init) return pf_fail(c->rank, "pf_get_block: products not computed");
+  PFCHK(c, velocities_ready(c));
   const size_t nc = ncell(c);
   if (!strncmp(name, "FMAX", 4)) { HIPCHK(c, hipMemcpyAsync(host, c->fmax, nc * sizeof(float), hipMemcpyDeviceToHost, c->stream)); }
   else if (!strncmp(name, "RMAX", 4)) { HIPCHK(c, hipMemcpyAsync(host, c->rmax, nc * sizeof(int), hipMemcpyDeviceToHost, c->stream)); }
