@@ -149,6 +149,15 @@ int pf_set_growth_table(pf_ctx *ctx, int order, const double *log10_growth, int 
    pf_ct_load installs a table read from such a file (params.CTtableFile) instead of computing it.
    A following pf_collapse_times(ismooth) uses the table in place. */
 int pf_set_tabulated_ct(pf_ctx *ctx, int nsmooth, const double *variance);
+/* What fills the table: model 0 = ELL_CLASSIC (ell_classic + InverseGrowingMode, src/collapse_times.c:114-221, 404-415);
+   model 1 = ELL_SNG (src/collapse_times.c:222-400, 416-426): per node one adaptive RKF45 integration of the
+   nine-equation system of Nadkarni-Ghosh & Singhal (2016) -- the step, error control and accept/reject logic of
+   gsl_odeiv2_step_rkf45 / control_standard_new(1e-6, 1e-6, 1, 1) / evolve_apply -- with
+   cosmo = {Omega0, OmegaLambda, OmegaRad, OmegaK} for OmegaMatter(z) / OmegaLambda(z) (src/cosmo.c:1675-1718) and
+   D_in[ismooth] = GrowingMode(1/1e-5 - 1, k of the radius) (:353-361).  ELL_SNG exists only together with the table
+   (250 000 integrations per radius on the device; per cell it would be ~10^9 of them): pf_sweep fails without
+   pf_set_tabulated_ct.  Standard gravity only (no MOD_GRAV_FR force modification). */
+int pf_set_collapse_model(pf_ctx *ctx, int model, const double cosmo[4], int nsmooth, const double *D_in);
 int pf_ct_build(pf_ctx *ctx, int ismooth, double variance, double *table_host);
 int pf_ct_load(pf_ctx *ctx, int ismooth, double variance, const double *table_host);
 

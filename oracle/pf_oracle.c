@@ -63,6 +63,9 @@ struct orc_ctx {
   double gt_T[4][ORC_MAX_KBINS], gt_logkmin[4], gt_dlogk[4], gt_sign[4];
   /* TABULATED_CT build (src/collapse_times.c:780-1231, BILINEAR_SPLINE flavour :40): per radius a table of ell() on
      a (delta, x, y) grid and one natural cubic spline in delta per (x, y) node */
+  int model;                      /* 0 ELL_CLASSIC, 1 ELL_SNG (oracle/pf_sng.c) */
+  double sng_cosmo[4], sng_Din[ORC_MAX_SMOOTH];
+  int cur_ismooth;
   int tab_ns;
   double tab_var[ORC_MAX_SMOOTH]; /* Smoothing.Variance[] */
   double tab_ampl;                /* sqrt(Smoothing.Variance[ismooth]) of the table in place */
@@ -504,6 +507,7 @@ double orc_ell_classic(double l1, double l2, double l3) {
 
 /* collapse_times.c:404-415 (ELL_CLASSIC) */
 static double ell_fn(orc_ctx *c, double l1, double l2, double l3) {
+  if (c->model == 1) return orc_ell_sng_F(l1, l2, l3, c->sng_Din[c->cur_ismooth], c->sng_cosmo); /* #ifdef ELL_SNG, :416 */
   double bc = orc_ell_classic(l1, l2, l3);
   if (bc > 0.0) return 1. + orc_inverse_growing_mode(c, bc);
   else return 0.0;
@@ -537,6 +541,7 @@ static void ct_delta_vector(double *delta_vector) {
 /* initialize_collapse_times(ismooth, 0) with params.CTtableFile == "none" (collapse_times.c:820-1043): the table of
    ell() and the CT_NBINS_XY^2 splines in delta; single task, so the MPI split of the computations is not restated */
 static int ct_initialize(orc_ctx *c, int ismooth) {
+  c->cur_ismooth = ismooth;
   const int Ncomputations = CT_NBINS_D * CT_NBINS_XY * CT_NBINS_XY;
   if (!c->ct_table) {
     c->ct_table = (double *)calloc(Ncomputations, sizeof(double));
@@ -649,6 +654,7 @@ double orc_inverse_collapse_time(orc_ctx *c, const double *deformation_tensor, d
 /* collapse_times.c:431-673 */
 static int compute_collapse_times_with_current_spline(orc_ctx *c, int ismooth, double *true_var) {
   const size_t nr = c->n_r;
+  c->cur_ismooth = ismooth;
   if (c->tab_ns > 0 && ct_initialize(c, ismooth)) return 1; /* src/fmax.c:103-106 */
   orc_product *products = c->products;
   double local_variance = 0.0, local_average = 0.0;
@@ -901,6 +907,15 @@ int orc_set_invgrow_radius(orc_ctx *c, int ismooth, const double *x, const doubl
   c->rsx[ismooth] = c->sx; c->rsy[ismooth] = c->sy; c->rsc[ismooth] = c->sc; c->rnk[ismooth] = nk;
   c->sx = dx; c->sy = dy; c->sc = dc; c->nk = dn;
   return rc;
+}
+int orc_set_collapse_model(orc_ctx *c, int model, const double cosmo[4], int ns, const double *D_in) {
+  if (model < 0 || model > 1 || ns < 0 || ns > ORC_MAX_SMOOTH) return 1;
+  c->model = model;
+  if (model == 1) {
+    memcpy(c->sng_cosmo, cosmo, sizeof(double) * 4);
+    memcpy(c->sng_Din, D_in, sizeof(double) * ns);
+  }
+  return 0;
 }
 int orc_set_tabulated_ct(orc_ctx *c, int ns, const double *variance) {
   if (ns < 0 || ns > ORC_MAX_SMOOTH) return 1;

@@ -106,6 +106,14 @@ const double *orc_ct_table(orc_ctx *c);
 const double *orc_ct_delta(orc_ctx *c);
 double orc_interpolate_collapse_time(orc_ctx *c, double l1, double l2, double l3);
 
+/* ELL_SNG collapse model (oracle/pf_sng.c; src/collapse_times.c:222-400): scale factor of collapse of the ellipsoid
+   (0: none, -1: integrator failure) and the F = 1/b_c of ell().  cosmo = {Omega0, OmegaLambda, OmegaRad, OmegaK};
+   D_in = GrowingMode(z(a = 1e-5), k of the radius).  orc_set_collapse_model(1, ...) makes ell() use it (the table of a
+   TABULATED_CT build is then filled with it); model 0 = ELL_CLASSIC. */
+double orc_ell_sng(double l1, double l2, double l3, double D_in, const double cosmo[4]);
+double orc_ell_sng_F(double l1, double l2, double l3, double D_in, const double cosmo[4]);
+int orc_set_collapse_model(orc_ctx *c, int model, const double cosmo[4], int ns, const double *D_in);
+
 /* Fmax >= flast (src/distribute.c:695), indices by descending Fmax (src/fragment.c:484-503, 118-126; ties by index).
    indices / fmax hold n^3 entries; returns the number selected. */
 size_t orc_select_sorted(orc_ctx *c, float flast, unsigned int *indices, float *fmax);

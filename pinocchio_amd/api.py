@@ -108,6 +108,13 @@ class Fmax:
         t = np.ascontiguousarray(log10_growth, dtype=np.float64)
         self._chk(self.L.pf_set_growth_table(self.h, int(order), _dp(t) if len(t) else None, len(t), logkmin, dlogk, sign))
 
+    def set_collapse_model(self, model: int, cosmo=None, d_in=None):
+        """0: ELL_CLASSIC; 1: ELL_SNG (table only) with cosmo = (Omega0, OmegaLambda, OmegaRad, OmegaK), D_in per radius"""
+        cs = np.ascontiguousarray(cosmo, dtype=np.float64) if cosmo is not None else None
+        di = np.ascontiguousarray(d_in, dtype=np.float64) if d_in is not None else None
+        self._chk(self.L.pf_set_collapse_model(self.h, model, _dp(cs) if cs is not None else None, len(di) if di is not None else 0,
+                                               _dp(di) if di is not None else None))
+
     def set_tabulated_ct(self, variance):
         """TABULATED_CT build: Smoothing.Variance[] per radius ([] = direct solve), src/collapse_times.c:780-1231"""
         v = np.ascontiguousarray(variance, dtype=np.float64)

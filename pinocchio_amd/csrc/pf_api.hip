@@ -112,6 +112,9 @@ struct pf_ctx {
   double tab_var[PF_MAX_SMOOTH];
   bool tab_ready;
   int tab_ismooth;
+  int model;           // 0 ELL_CLASSIC, 1 ELL_SNG (only through the collapse-time table)
+  double sng_cosmo[4], sng_Din[PF_MAX_SMOOTH];
+  int sng_ns;
   PfCtDev ct;
   double *ct_block;    // delta | alpha | gamma | y | b | c | d
   bool have_density, have_hessian, have_sources, products_init;
@@ -274,7 +277,7 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   PFCHK(c, dev_alloc(c, (void **)&c->spl, (size_t)(PF_MAX_SMOOTH + 1) * 5 * PF_KNOT_CAP * sizeof(double)));
   PFCHK(c, dev_alloc(c, (void **)&c->gtab, 4 * PF_KBIN_CAP * sizeof(double)));
   memset(c->gt_n, 0, sizeof(c->gt_n));
-  c->tab_ns = 0; c->tab_ready = false; c->tab_ismooth = -1; c->ct_block = nullptr; memset(&c->ct, 0, sizeof(c->ct));
+  c->tab_ns = 0; c->tab_ready = false; c->tab_ismooth = -1; c->ct_block = nullptr; c->model = 0; c->sng_ns = 0; memset(&c->ct, 0, sizeof(c->ct));
   HIPCHK(c, hipMemsetAsync(c->scal, 0, SC_COUNT * sizeof(double), c->stream));
   // twiddles exp(+2 pi i j / n), computed in long double on the host
   {
@@ -733,14 +736,32 @@ static int ct_build(pf_ctx *c, int ismooth, double variance, const double *table
   if (!(variance > 0.0)) return pf_fail(c->rank, "collapse-time table: Smoothing.Variance[%d] = %g must be positive", ismooth, variance);
   PFCHK(c, ct_alloc(c));
   c->ct.ampl = sqrt(variance);
+  c->ct.model = c->model;
+  if (c->model == 1 && !table_host) {
+    if (ismooth >= c->sng_ns) return pf_fail(c->rank, "collapse-time table: no ELL_SNG growth factor for radius %d (pf_set_collapse_model)", ismooth);
+    memcpy(c->ct.sng_cosmo, c->sng_cosmo, sizeof(c->sng_cosmo));
+    c->ct.sng_Din = c->sng_Din[ismooth];
+  }
   PfSplineDev sp; memset(&sp, 0, sizeof(sp));
   if (table_host) HIPCHK(c, hipMemcpyAsync(c->ct.y, table_host, (size_t)PF_CT_NBINS_D * PF_CT_NBINS_XY * PF_CT_NBINS_XY * sizeof(double), hipMemcpyHostToDevice, st));
-  else if (spline_for(c, ismooth, &sp)) return 1;
+  else if (c->model == 0 && spline_for(c, ismooth, &sp)) return 1;
   {
     KTimer t(c, KS_MISC, 0.0, st);
     PFCHK(c, pf_launch_ct_build(sp, c->ct, c->fast_libm ? 1 : 0, table_host ? 0 : 1, st));
   }
   c->tab_ready = true; c->tab_ismooth = ismooth;
+  return 0;
+}
+extern "C" int pf_set_collapse_model(pf_ctx *c, int model, const double cosmo[4], int nsmooth, const double *D_in) {
+  if (!c) return 1;
+  if (model != 0 && model != 1) return pf_fail(c->rank, "pf_set_collapse_model: model %d (0 ELL_CLASSIC, 1 ELL_SNG)", model);
+  if (model == 1) {
+    if (!cosmo || !D_in || nsmooth < 1 || nsmooth > PF_MAX_SMOOTH) return pf_fail(c->rank, "pf_set_collapse_model: ELL_SNG needs the cosmology and D_in per radius");
+    memcpy(c->sng_cosmo, cosmo, 4 * sizeof(double));
+    memcpy(c->sng_Din, D_in, nsmooth * sizeof(double));
+    c->sng_ns = nsmooth;
+  }
+  c->model = model; c->tab_ready = false;
   return 0;
 }
 extern "C" int pf_set_tabulated_ct(pf_ctx *c, int nsmooth, const double *variance) {
@@ -787,6 +808,8 @@ static int collapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], hipStream_
   if (spline_for(c, ismooth, &p.spline)) return 1;
   p.partials = c->partials; p.fast = c->fast_libm ? 1 : 0;
   p.wpe = getenv("PF_COLLAPSE_WPE") ? atoi(getenv("PF_COLLAPSE_WPE")) : 0;
+  if (c->model == 1 && c->tab_ns == 0)
+    return pf_fail(c->rank, "ELL_SNG is evaluated through the collapse-time table only: call pf_set_tabulated_ct (TABULATED_CT build)");
   if (c->tab_ns > 0) {  // TABULATED_CT build: the table of this radius is made right before its pass (src/fmax.c:103-106)
     if (build_table) {
       if (ismooth >= c->tab_ns) return pf_fail(c->rank, "collapse-time table: no variance for radius %d (pf_set_tabulated_ct)", ismooth);

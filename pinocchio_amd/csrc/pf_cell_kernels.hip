@@ -5,6 +5,7 @@
 #include "pf_internal.h"
 #include "pf_fft_core.h"
 #include "pf_collapse_core.h"
+#include "pf_sng_core.h"
 
 #define PF_CELL_BLOCK 256
 #define PF_MAX_KNOTS 512
@@ -113,6 +114,23 @@ __global__ void __launch_bounds__(PF_CELL_BLOCK) k_ct_table(PfSplineDev s, PfCtD
     const double l2 = (del - x + y) / 3.0 * ct.ampl;
     const double l3 = (del - x - 2. * y) / 3.0 * ct.ampl;
     ct.y[i] = pf_ell<FAST>(sv, l1, l2, l3);
+  }
+}
+// the same table filled by the ELL_SNG model: one adaptive RKF45 integration of the nine-equation system per node
+__global__ void __launch_bounds__(64) k_ct_table_sng(PfCtDev ct) {
+  const double bin_x = PF_CT_RANGE_X / (double)(PF_CT_NBINS_XY);
+  const int total = PF_CT_NBINS_D * PF_CT_NBINS_XY * PF_CT_NBINS_XY;
+  pf_sng_cosmo c;
+  c.Omega0 = ct.sng_cosmo[0]; c.OmegaLambda = ct.sng_cosmo[1]; c.OmegaRad = ct.sng_cosmo[2]; c.OmegaK = ct.sng_cosmo[3];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int id = i % PF_CT_NBINS_D;
+    const int ix = (i / PF_CT_NBINS_D) % PF_CT_NBINS_XY;
+    const int iy = i / PF_CT_NBINS_D / PF_CT_NBINS_XY;
+    const double x = ix * bin_x, y = iy * bin_x, del = ct.delta[id];
+    const double l1 = (del + 2. * x + y) / 3.0 * ct.ampl;
+    const double l2 = (del - x + y) / 3.0 * ct.ampl;
+    const double l3 = (del - x - 2. * y) / 3.0 * ct.ampl;
+    ct.y[i] = pf_ell_sng_F(l1, l2, l3, ct.sng_Din, c);
   }
 }
 // gsl_spline_init of the 50 x 50 node splines (src/collapse_times.c:1037-1041): GSL's cspline_init per node -- right-hand
@@ -344,7 +362,9 @@ static inline int pf_grid_for(size_t n, int cap = 256 * 8) {
 #define PF_CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? 0 : 1)
 
 int pf_launch_ct_build(const PfSplineDev &sp, const PfCtDev &ct, int fast, int compute_table, hipStream_t st) {
-  if (compute_table) {
+  if (compute_table && ct.model == 1) {
+    hipLaunchKernelGGL(k_ct_table_sng, dim3((PF_CT_NBINS_D * PF_CT_NBINS_XY * PF_CT_NBINS_XY + 63) / 64), dim3(64), 0, st, ct);
+  } else if (compute_table) {
     const int g = pf_grid_for((size_t)PF_CT_NBINS_D * PF_CT_NBINS_XY * PF_CT_NBINS_XY);
     if (fast) hipLaunchKernelGGL(k_ct_table<true>, dim3(g), dim3(PF_CELL_BLOCK), 0, st, sp, ct);
     else hipLaunchKernelGGL(k_ct_table<false>, dim3(g), dim3(PF_CELL_BLOCK), 0, st, sp, ct);

@@ -84,6 +84,8 @@ struct PfCtDev {
   double *delta, *y, *b, *c, *d;   // [100], 4 x [50*50*100]
   const double *alpha, *gamma;     // [98] factors of the shared tridiagonal system
   double ampl;
+  int model;                       // what fills the table: 0 ell_classic + InverseGrowingMode, 1 ell_sng (pf_sng_core.h)
+  double sng_cosmo[4], sng_Din;    // ELL_SNG: Omega0, OmegaLambda, OmegaRad, OmegaK; GrowingMode at a = 1e-5 for this radius
 };
 struct PfCollapseParams {
   const void *h[6];     // Hessian fields, type F, rows of pitch reals

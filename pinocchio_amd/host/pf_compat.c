@@ -45,6 +45,7 @@
 #define PF_KNOTS_Y (SPLINE[SP_INVGROW]->y)
 #define PF_KNOTS_N ((int)SPLINE[SP_INVGROW]->size)
 #define PF_GM(z) GrowingMode((z), params.k_for_GM)
+#define PF_GM_K(z, k) GrowingMode((z), (k))
 #define PF_GM2(z) GrowingMode_2LPT((z), params.k_for_GM)
 #define PF_GM31(z) GrowingMode_3LPT_1((z), params.k_for_GM)
 #define PF_GM32(z) GrowingMode_3LPT_2((z), params.k_for_GM)
@@ -54,6 +55,7 @@
 #define PF_KNOTS_Y (pf_invgrow_knots.y)
 #define PF_KNOTS_N ((int)pf_invgrow_knots.size)
 #define PF_GM(z) pf_GrowingMode((z), 0.0)
+#define PF_GM_K(z, k) pf_GrowingMode((z), (k))
 #define PF_GM2(z) pf_GrowingMode_2LPT((z), 0.0)
 #define PF_GM31(z) pf_GrowingMode_3LPT_1((z), 0.0)
 #define PF_GM32(z) pf_GrowingMode_3LPT_2((z), 0.0)
@@ -76,6 +78,17 @@
 #endif
 #else
 #define PF_TABULATED pf_compat_tabulated_ct
+#endif
+#if defined(PF_IN_PINOCCHIO_TREE)
+#ifdef ELL_SNG
+#define PF_ELL_SNG 1
+#else
+#define PF_ELL_SNG 0
+#endif
+#define PF_HUBBLE(z) Hubble(z)
+#else
+#define PF_ELL_SNG pf_compat_ell_sng
+#define PF_HUBBLE(z) pf_Hubble(z)
 #endif
 #if !defined(PF_IN_PINOCCHIO_TREE) || defined(TABULATED_CT)
 #define PF_HAVE_CT 1
@@ -217,6 +230,26 @@ static int pf_upload_inputs(void) {
   } else if (pf_set_invgrow(pf_context, -1, PF_KNOTS_X, PF_KNOTS_Y, PF_KNOTS_N)) return 1;
 #endif
   return 0;
+}
+
+/* -DELL_SNG: the model of the collapse-time table (src/collapse_times.c:222-400).  OmegaRad and OmegaK are static in
+   src/cosmo.c; they are recovered from the public Hubble(z): E^2(z) - Omega0 (1+z)^3 - OmegaLambda =
+   OmegaRad (1+z)^4 + OmegaK (1+z)^2 at two redshifts (params.simpleLambda). */
+static int pf_upload_collapse_model(void) {
+  double cosmo[4], D_in[64], h0, r1, r3;
+  int ismooth;
+  if (!PF_ELL_SNG) return pf_set_collapse_model(pf_context, 0, NULL, 0, NULL);
+  h0 = PF_HUBBLE(0.0);
+  r1 = pow(PF_HUBBLE(1.0) / h0, 2.) * 1.0 - params.Omega0 * 8. - params.OmegaLambda;   /* = 16 Or + 4 Ok, E^2 normalised to E(0) = 1 */
+  r3 = pow(PF_HUBBLE(3.0) / h0, 2.) * 1.0 - params.Omega0 * 64. - params.OmegaLambda;  /* = 256 Or + 16 Ok */
+  cosmo[0] = params.Omega0; cosmo[1] = params.OmegaLambda;
+  cosmo[2] = (r3 - 4. * r1) / 192.;
+  cosmo[3] = (r1 - 16. * cosmo[2]) / 4.;
+  if (fabs(cosmo[2]) < 1e-12) cosmo[2] = 0.0;
+  if (fabs(cosmo[3]) < 1e-12) cosmo[3] = 0.0;
+  for (ismooth = 0; ismooth < Smoothing.Nsmooth; ismooth++) /* GrowingMode(1/amin - 1, 1/Radius), :353-361 */
+    D_in[ismooth] = PF_GM_K(1. / 1.e-5 - 1., 1. / Smoothing.Radius[ismooth]);
+  return pf_set_collapse_model(pf_context, 1, cosmo, Smoothing.Nsmooth, D_in);
 }
 
 /* growth multipliers of compute_derivative for ScaleDep.order = 1..4 (src/fmax-pfft.c:344-364) at `redshift`:
@@ -600,7 +633,8 @@ static int check_CTtable_header(void) { /* :1235-1296, ELL_CLASSIC */
   int fail = 0, dummy = 0;
   double fdummy = 0;
   if (fread(&dummy, sizeof(int), 1, CTtableFilePointer) != 1) return 1;
-  if (dummy != 1) { printf("ERROR: CT table not constructed for ELL_CLASSIC, %d\n", dummy); fail = 1; }
+  if (!PF_ELL_SNG && dummy != 1) { printf("ERROR: CT table not constructed for ELL_CLASSIC, %d\n", dummy); fail = 1; }
+  if (PF_ELL_SNG && dummy != 3) { printf("ERROR: CT table not constructed for ELL_SNG and standard gravity, %d\n", dummy); fail = 1; }
   if (fread(&fdummy, sizeof(double), 1, CTtableFilePointer) != 1) return 1;
   if (fabs(fdummy - params.Omega0) > 1.e-10) { printf("ERROR: CT table constructed for the wrong Omega0, %f in place of %f\n", fdummy, params.Omega0); fail = 1; }
   if (fread(&fdummy, sizeof(double), 1, CTtableFilePointer) != 1) return 1;
@@ -616,7 +650,7 @@ static int check_CTtable_header(void) { /* :1235-1296, ELL_CLASSIC */
   return fail;
 }
 static void write_CTtable_header(void) { /* :1300-1340 */
-  int dummy = 1;
+  int dummy = PF_ELL_SNG ? 3 : 1;
   fwrite(&dummy, sizeof(int), 1, CTtableFilePointer);
   fwrite(&params.Omega0, sizeof(double), 1, CTtableFilePointer);
   fwrite(&params.OmegaLambda, sizeof(double), 1, CTtableFilePointer);
@@ -660,6 +694,7 @@ int initialize_collapse_times(int ismooth, int onlycompute) {
   }
   /* compute the table of this radius: every task computes all of it on its GPU (0.25 M evaluations) instead of the
      reference's split over tasks + MPI_Allgatherv; task 0 writes the file */
+  if (!ismooth && pf_upload_collapse_model()) return 1;
   if (pf_ct_build(pf_context, ismooth, Smoothing.Variance[ismooth], pf_ct_host)) return 1;
   if (!ThisTask) {
     if (onlycompute) strcpy(fname, params.CTtableFile);

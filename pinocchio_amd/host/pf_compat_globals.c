@@ -28,3 +28,5 @@ static double *rvector_slots[1] = {0};
 pfft_complex **cvector_fft = cvector_slots;
 double **rvector_fft = rvector_slots;
 int pf_compat_tabulated_ct = 0;
+int pf_compat_ell_sng = 0;
+double (*pf_Hubble)(double) = 0;

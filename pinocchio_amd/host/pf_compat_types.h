@@ -109,6 +109,9 @@ extern double (*pf_GrowingMode_3LPT_2)(double z, double k);
    (src/def_splines.h:40-42) and applied per mode; pf_invgrow_knots_radius[ismooth] = SPLINE_INVGROW[ismooth] */
 /* non-zero: behave like a -DTABULATED_CT build (src/collapse_times.c:780-1231) */
 extern int pf_compat_tabulated_ct;
+/* non-zero: behave like a -DELL_SNG build (src/collapse_times.c:222-400); Hubble(z) in km/s/Mpc as src/cosmo.c:1691 */
+extern int pf_compat_ell_sng;
+extern double (*pf_Hubble)(double z);
 extern int pf_compat_scale_dependent;
 extern pf_spline_knots pf_invgrow_knots_radius[64];
 

@@ -26,8 +26,8 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(ORACLE_DIR, "pf_oracle.c")
-    stale = (not os.path.exists(SO)) or os.path.getmtime(SO) < os.path.getmtime(src)
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("pf_oracle.c", "pf_oracle.h", "pf_genic.c", "pf_sng.c")]
+    stale = (not os.path.exists(SO)) or os.path.getmtime(SO) < max(os.path.getmtime(f) for f in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "-B"])
     return SO
@@ -77,6 +77,11 @@ def lib():
         L.orc_ct_delta.argtypes = [C.c_void_p]
         L.orc_interpolate_collapse_time.restype = C.c_double
         L.orc_interpolate_collapse_time.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
+        L.orc_ell_sng.restype = C.c_double
+        L.orc_ell_sng.argtypes = [C.c_double] * 4 + [dp]
+        L.orc_ell_sng_F.restype = C.c_double
+        L.orc_ell_sng_F.argtypes = [C.c_double] * 4 + [dp]
+        L.orc_set_collapse_model.argtypes = [C.c_void_p, C.c_int, dp, C.c_int, dp]
         L.orc_select_sorted.restype = C.c_size_t
         L.orc_select_sorted.argtypes = [C.c_void_p, C.c_float, C.POINTER(C.c_uint), C.POINTER(C.c_float)]
         _lib = L
@@ -154,6 +159,12 @@ class Oracle:
     def displacements(self, compute_sources=True):
         rc = self.L.orc_compute_displacements(self.h, int(compute_sources))
         assert rc == 0
+
+    def set_collapse_model(self, model, cosmo=None, d_in=None):
+        """0: ELL_CLASSIC; 1: ELL_SNG with cosmo = (Omega0, OmegaLambda, OmegaRad, OmegaK), D_in per radius"""
+        cosmo = np.ascontiguousarray(cosmo if cosmo is not None else np.zeros(4), dtype=np.float64)
+        d_in = np.ascontiguousarray(d_in if d_in is not None else np.zeros(1), dtype=np.float64)
+        assert self.L.orc_set_collapse_model(self.h, model, _dp(cosmo), len(d_in), _dp(d_in)) == 0
 
     def set_tabulated_ct(self, variance):
         v = np.ascontiguousarray(variance, dtype=np.float64)

@@ -126,3 +126,22 @@ def test_tabulated_ct_header_matches_oracle_bitwise(emul):
     assert np.array_equal(delta, dv)
     want = np.array([o.interpolate_collapse_time(*l) for l in lam])
     assert np.array_equal(F, want)
+
+
+def test_ell_sng_header_matches_oracle_bitwise(emul):
+    """the RKF45 / step-control / accept-reject loop of pf_sng_core.h on the host against oracle/pf_sng.c (written
+    separately from the same GSL algorithm): identical collapse epochs, including 'no collapse' and the sentinel"""
+    rng = np.random.default_rng(21)
+    n = 400
+    d = rng.uniform(-3.0, 6.0, n); x = rng.uniform(0.0, 3.0, n); y = rng.uniform(0.0, 3.0, n)
+    lam = np.stack([(d + 2 * x + y) / 3.0, (d - x + y) / 3.0, (d - x - 2 * y) / 3.0], axis=1).copy()
+    lam[:5] = [[1.0, 1.0, 1.0], [0.0, 0.0, 0.0], [2.0, 2.0, -1.0], [-1.0, -1.0, -1.0], [1e-3, 1e-3, 1e-3]]
+    L = oracle_lib.lib()
+    emul.emul_ell_sng.argtypes = [dp, C.c_long, C.c_double, dp, dp]
+    for cosmo, din in ((np.array([1.0, 0.0, 0.0, 0.0]), 1e-5), (np.array([0.25, 0.75, 0.0, 0.0]), 1.28e-5),
+                       (np.array([0.3, 0.6, 0.0, 0.1]), 1.2e-5)):
+        got = np.empty(n)
+        emul.emul_ell_sng(_dp(lam), n, din, _dp(cosmo), _dp(got))
+        want = np.array([L.orc_ell_sng(l[0], l[1], l[2], din, _dp(cosmo)) for l in lam])
+        assert np.array_equal(got, want)
+        assert (want > 0).sum() > 100 and (want == 0).sum() > 20

@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SO = os.path.join(ROOT, "pinocchio_amd", "libpf_compat.so")
 
 GROWTH_FN = C.CFUNCTYPE(C.c_double, C.c_double, C.c_double)
+HUBBLE_FN = C.CFUNCTYPE(C.c_double, C.c_double)
 
 
 class Smoothing(C.Structure):
@@ -482,7 +483,30 @@ def test_tabulated_ct_build_through_the_reference_driver(lib, tmp_path):
         assert lib.compute_fft_plans() == 0
         assert lib.compute_fmax() == 0
         assert np.array_equal(check(), first)
+        # -DELL_SNG: the same flow with the table filled by the ODE model (type code 3 in the file header)
+        cosmo = np.array([0.25, 0.75, 0.0, 0.0])
+        d_in = np.array([float(g[0]) * 1.28e-5] * len(radii_mpc))
+        o.set_collapse_model(1, cosmo, d_in)
+        tv_o[:] = o.compute_fmax(radii_mpc / cell, do_lpt=True)
+        po = o.products()
+        hub = HUBBLE_FN(lambda z: 70.0 * float(np.sqrt(0.25 * (1 + z) ** 3 + 0.75)))
+        C.c_void_p.in_dll(lib, "pf_Hubble").value = C.cast(hub, C.c_void_p).value
+        gm = GROWTH_FN(lambda z, k: float(g[0]) * (1.28e-5 if z > 1000.0 else 1.0))   # GrowingMode(z(a = 1e-5), k) and at z = 0
+        C.c_void_p.in_dll(lib, "pf_GrowingMode").value = C.cast(gm, C.c_void_p).value
+        C.c_int.in_dll(lib, "pf_compat_ell_sng").value = 1
+        par.CTtableFile = b"none"
+        par.RunFlag = b"pfsng"
+        prod[:] = 0
+        tv[:] = 0
+        assert lib.compute_fft_plans() == 0
+        assert lib.compute_fmax() == 0
+        p = prod.view(oracle_lib.PRODUCT_DTYPE).reshape(n, n, n)
+        assert np.allclose(tv, tv_o, rtol=1e-12)
+        d = np.abs(p["Fmax"].astype(np.float64) - po["Fmax"])
+        assert np.mean(d > 1e-4 * np.maximum(1.0, po["Fmax"])) < 1e-3 and (po["Fmax"] >= 1.0).mean() > 0.05
+        assert np.frombuffer((tmp_path / "pinocchio.pfsng.CTtable.out").read_bytes()[:4], dtype=np.int32)[0] == 3
     finally:
         os.chdir(cwd)
         C.c_int.in_dll(lib, "pf_compat_tabulated_ct").value = 0
+        C.c_int.in_dll(lib, "pf_compat_ell_sng").value = 0
         par.CTtableFile = b"none"

@@ -4,6 +4,8 @@ and the whole field-level path vs the independent numpy restatement."""
 import json
 import os
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -314,3 +316,48 @@ def test_tabulated_ct_restatement_vs_scipy():
     o.set_tabulated_ct([])
     o.compute_fmax(radii, do_lpt=False)
     assert np.array_equal(o.products()["Fmax"], direct)
+
+
+def _sng_rhs(t, y, cosmo):
+    O0, OL, Or, Ok = cosmo
+    z = 1.0 / t - 1.0
+    E2 = (Or * (1 + z) ** 4 + O0 * (1 + z) ** 3 + Ok * (1 + z) ** 2 + OL) / (Or + O0 + Ok + OL)
+    om, ol = O0 * (1 + z) ** 3 / E2, OL / E2
+    la, lv, ld = y[0:3], y[3:6], y[6:9]
+    delta = ld.sum()
+    f = np.zeros(9)
+    for i in range(3):
+        s = 0.0
+        for j in range(3):
+            if i == j or la[i] == la[j]:
+                continue
+            s += (ld[j] - ld[i]) * ((1 - la[i]) ** 2 * (1 + lv[i]) - (1 - la[j]) ** 2 * (1 + lv[j])) / ((1 - la[i]) ** 2 - (1 - la[j]) ** 2)
+        f[i] = lv[i] * (la[i] - 1) / t
+        f[i + 3] = 0.5 * (lv[i] * (om - 2 * ol - 2) - 3 * om * ld[i] - 2 * lv[i] ** 2) / t
+        f[i + 6] = ((5 / 6 + ld[i]) * ((3 + lv.sum()) - (1 + delta) / (2.5 + delta) * lv.sum()) - (2.5 + delta) * (1 + lv[i]) + s) / t
+    return f
+
+
+def test_ell_sng_restatement_vs_scipy():
+    """ELL_SNG (row f-4; parity unpinned: no reference output of that build exists): the restated system + GSL-style
+    RKF45 loop against scipy's DOP853 at tight tolerance, and the textbook spherical-collapse threshold"""
+    from scipy.integrate import solve_ivp
+    L = oracle_lib.lib()
+    dp = C.POINTER(C.c_double)
+    eds, lcdm = np.array([1.0, 0.0, 0.0, 0.0]), np.array([0.25, 0.75, 0.0, 0.0])
+    # a sphere in Einstein-de Sitter collapses when the linear overdensity reaches 1.686
+    a = L.orc_ell_sng(1.0, 1.0, 1.0, 1e-5, eds.ctypes.data_as(dp))
+    assert abs(3.0 * a - 1.686) < 2e-3
+    ev = lambda t, y, c: y[0] - 0.99999
+    ev.terminal, ev.direction = True, 1
+    for cosmo, din in ((eds, 1e-5), (lcdm, 1.28e-5)):
+        for l in ([2.0, 1.0, 0.5], [1.5, 0.2, -0.4], [0.8, 0.7, 0.1], [3.0, -0.5, -1.0], [-0.2, -0.3, -0.5]):
+            y0 = np.array([x * din for x in l] + [x * din / (x * din - 1) for x in l] + [x * din for x in l])
+            sol = solve_ivp(_sng_rhs, (1e-5, 5.0), y0, method="DOP853", rtol=1e-10, atol=1e-12, args=(cosmo,), events=ev)
+            want = sol.t_events[0][0] if len(sol.t_events[0]) else 0.0
+            got = L.orc_ell_sng(l[0], l[1], l[2], din, cosmo.ctypes.data_as(dp))
+            # the reference returns the end of the first accepted step past the threshold, scaled by 1/lambda_a (its
+            # interpolation runs from the initial point): within one step, i.e. ~1e-4, of the true crossing
+            assert abs(got - want) <= 3e-4 * max(want, 1e-30) if want > 0 else got == 0.0, (cosmo, l, got, want)
+            f = L.orc_ell_sng_F(l[0], l[1], l[2], din, cosmo.ctypes.data_as(dp))
+            assert f == (1.0 / got if got > 0 else 0.0)
