@@ -165,6 +165,15 @@ def main():
                 traffic = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
+        valu = None  # issue-side view of a VALU-bound dominant kernel, from the committed counter passes
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_valu.json")) as fh:
+                pv = json.load(fh)
+            if pv["config"] == {"grid": n, "field_bytes": args.field_bytes} and dom["name"] in pv["kernels"]:
+                k = pv["kernels"][dom["name"]]
+                valu = {"insts_per_cell": k["valu_insts_per_cell"], "valu_utilisation": k["valu_utilisation"], "source": "profiles/r01_pmc_valu.json"}
+        except (OSError, KeyError, ValueError):
+            pass
         w = args.field_bytes
         out = {
             "metric": "grid-cells/sec for full Fmax sweep (all smoothing radii) + 3LPT, 1024^3 box"
@@ -179,7 +188,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "note": "collapse is fp64-VALU bound (~800 instructions per cell); its HBM stream is a consequence, see DESIGN.md section 6",
-                         "launches": dom["launches"], "avg_ms": dom["total_ms"] / dom["launches"],
+                         "valu": valu, "launches": dom["launches"], "avg_ms": dom["total_ms"] / dom["launches"],
                          "alg_bytes_per_launch": dom["alg_bytes"] / dom["launches"]},
             "path_roofline": {"contract_bytes_per_cell": alg_bytes_per_cell(ns, w, lpt),
                               "frac_of_hbm_peak": alg_bytes_per_cell(ns, w, lpt) * cells / (ms * 1e-3) / world / (HBM_PEAK_GBS * 1e9)},
