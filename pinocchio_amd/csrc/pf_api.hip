@@ -808,6 +808,7 @@ static int collapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], hipStream_
   if (spline_for(c, ismooth, &p.spline)) return 1;
   p.partials = c->partials; p.fast = c->fast_libm ? 1 : 0;
   p.wpe = getenv("PF_COLLAPSE_WPE") ? atoi(getenv("PF_COLLAPSE_WPE")) : 0;
+  p.no_lut = (getenv("PF_SPLINE_LUT") && !atoi(getenv("PF_SPLINE_LUT"))) ? 1 : 0;
   if (c->model == 1 && c->tab_ns == 0)
     return pf_fail(c->rank, "ELL_SNG is evaluated through the collapse-time table only: call pf_set_tabulated_ct (TABULATED_CT build)");
   if (c->tab_ns > 0) {  // TABULATED_CT build: the table of this radius is made right before its pass (src/fmax.c:103-106)

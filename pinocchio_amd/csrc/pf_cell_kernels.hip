@@ -32,6 +32,7 @@ template <typename F, bool FAST, bool TAB = false>
 __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
   __shared__ double sk[TAB ? PF_CT_NBINS_D : 5 * PF_MAX_KNOTS];
   __shared__ double red[2 * (PF_CELL_BLOCK / 64)];
+  __shared__ unsigned short slut[TAB ? 1 : PF_SPLINE_LUT_BINS];
   const int nk = p.spline.n;
   if (TAB) {
     for (int i = threadIdx.x; i < PF_CT_NBINS_D; i += blockDim.x) sk[i] = p.ct.delta[i];
@@ -45,6 +46,10 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
     }
   }
   __syncthreads();
+  if (!TAB) {  // interval-search start table over the knots now in LDS
+    for (int b = threadIdx.x; b < PF_SPLINE_LUT_BINS; b += blockDim.x) slut[b] = pf_spline_lut_entry(sk, nk, b);
+    __syncthreads();
+  }
   pf_ct_view tv;
   tv.delta = sk; tv.y = p.ct.y; tv.b = p.ct.b; tv.c = p.ct.c; tv.d = p.ct.d; tv.ampl = p.ct.ampl;
   pf_spline_view sv;
@@ -52,6 +57,7 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
   if (!TAB) { sv.y = sk + PF_MAX_KNOTS; sv.c = sk + 2 * PF_MAX_KNOTS; sv.b = sk + 3 * PF_MAX_KNOTS; sv.d = sk + 4 * PF_MAX_KNOTS; }
   else sv.y = sv.c = sv.b = sv.d = sk;
   sv.n = nk;
+  if (!TAB && !p.no_lut) { sv.lut = slut; sv.lut_inv_w = (double)PF_SPLINE_LUT_BINS / (sk[nk - 1] - sk[0]); }
 
   const F *__restrict__ h0 = (const F *)p.h[0], *__restrict__ h1 = (const F *)p.h[1],
           *__restrict__ h2 = (const F *)p.h[2], *__restrict__ h3 = (const F *)p.h[3],

@@ -42,7 +42,12 @@
 struct pf_spline_view {
   const double *x, *y, *c, *b, *d;
   int n;
+  // optional start index per bin of a uniform grid over [x[0], x[n-1]] (pf_spline_lut_build): the interval search then
+  // walks forward from there (0-2 steps for the growth table) instead of bisecting; the interval found is the same
+  const unsigned short *lut = nullptr;
+  double lut_inv_w = 0.0;
 };
+#define PF_SPLINE_LUT_BINS 1024
 
 PF_HD double pf_spline_eval(const pf_spline_view &s, double v) {
   const double *xa = s.x, *ya = s.y, *ca = s.c;
@@ -50,14 +55,34 @@ PF_HD double pf_spline_eval(const pf_spline_view &s, double v) {
   if (v < xa[0]) return ya[0] + (v - xa[0]) * (ya[1] - ya[0]) / (xa[1] - xa[0]);
   if (v > xa[last])
     return ya[last] + (v - xa[last]) * (ya[last] - ya[last - 1]) / (xa[last] - xa[last - 1]);
-  // gsl_interp_bsearch(xa, v, 0, n-1)
-  int ilo = 0, ihi = last;
+  // gsl_interp_bsearch(xa, v, 0, n-1): the largest i <= n-2 with xa[i] <= v
+  int ilo = 0;
+  if (s.lut) {
+    int bin = (int)((v - xa[0]) * s.lut_inv_w) - 1;  // one bin early: immune to the rounding of the bin index
+    bin = bin < 0 ? 0 : (bin > PF_SPLINE_LUT_BINS - 1 ? PF_SPLINE_LUT_BINS - 1 : bin);
+    ilo = s.lut[bin];
+    while (ilo + 1 < last && xa[ilo + 1] <= v) ilo++;
+  } else {
+    int ihi = last;
+    while (ihi > ilo + 1) {
+      int i = (ihi + ilo) >> 1;
+      if (xa[i] > v) ihi = i; else ilo = i;
+    }
+  }
+  const double delx = v - xa[ilo];
+  return ya[ilo] + delx * (s.b[ilo] + delx * (ca[ilo] + delx * s.d[ilo]));
+}
+
+// lut[bin] = largest i <= n-2 with x[i] <= x[0] + bin * w, w = (x[n-1] - x[0]) / PF_SPLINE_LUT_BINS; one entry per call
+PF_HD unsigned short pf_spline_lut_entry(const double *xa, int n, int bin) {
+  const double w = (xa[n - 1] - xa[0]) / (double)PF_SPLINE_LUT_BINS;
+  const double v = xa[0] + bin * w;
+  int ilo = 0, ihi = n - 1;
   while (ihi > ilo + 1) {
     int i = (ihi + ilo) >> 1;
     if (xa[i] > v) ihi = i; else ilo = i;
   }
-  const double delx = v - xa[ilo];
-  return ya[ilo] + delx * (s.b[ilo] + delx * (ca[ilo] + delx * s.d[ilo]));
+  return (unsigned short)ilo;
 }
 
 // host side of the above: b_i = dy/dx - dx (c_{i+1} + 2 c_i)/3, d_i = (c_{i+1} - c_i)/(3 dx)   (GSL coeff_calc)

@@ -53,3 +53,17 @@ extern "C" void emul_ell_sng(const double *lam, long count, double D_in, const d
   pf_sng_cosmo c{cosmo[0], cosmo[1], cosmo[2], cosmo[3]};
   for (long i = 0; i < count; i++) bc[i] = pf_ell_sng(lam[3 * i], lam[3 * i + 1], lam[3 * i + 2], D_in, c);
 }
+
+// spline evaluation through the interval-search start table (what k_collapse uses) -- must find the same interval
+extern "C" int emul_spline_lut(const double *sx, const double *sy, int nk, const double *v, long count, double *out) {
+  std::vector<double> c(nk), b(nk), dd(nk);
+  if (pf_spline_coeffs(sx, sy, nk, c.data())) return 1;
+  pf_spline_bd(sx, sy, c.data(), nk, b.data(), dd.data());
+  std::vector<unsigned short> lut(PF_SPLINE_LUT_BINS);
+  for (int i = 0; i < PF_SPLINE_LUT_BINS; i++) lut[i] = pf_spline_lut_entry(sx, nk, i);
+  pf_spline_view s{sx, sy, c.data(), b.data(), dd.data(), nk};
+  s.lut = lut.data();
+  s.lut_inv_w = (double)PF_SPLINE_LUT_BINS / (sx[nk - 1] - sx[0]);
+  for (long i = 0; i < count; i++) out[i] = pf_spline_eval(s, v[i]);
+  return 0;
+}

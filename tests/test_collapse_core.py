@@ -145,3 +145,22 @@ def test_ell_sng_header_matches_oracle_bitwise(emul):
         want = np.array([L.orc_ell_sng(l[0], l[1], l[2], din, _dp(cosmo)) for l in lam])
         assert np.array_equal(got, want)
         assert (want > 0).sum() > 100 and (want == 0).sum() > 20
+
+
+def test_spline_interval_table_finds_the_bisection_interval(emul):
+    """the start-index table of k_collapse's spline lookup against plain bisection: identical values at the knots,
+    next to them (one ulp either side), at bin edges and at random abscissae; uniform and very uneven knot sets"""
+    emul.emul_spline_lut.argtypes = [dp, dp, C.c_int, dp, C.c_long, dp]
+    rng = np.random.default_rng(2)
+    x1, y1 = synth.invgrow_table("lcdm")
+    x2 = np.cumsum(np.concatenate([[0.0], rng.uniform(1e-6, 1.0, 209) ** 4])) - 3.0   # spacings over 24 orders of magnitude
+    y2 = np.sin(x2)
+    for x, y in ((x1, y1), (x2, y2), (x1[:3], y1[:3])):
+        n = len(x)
+        edges = x[0] + (x[-1] - x[0]) / 1024.0 * np.arange(1025)
+        v = np.concatenate([x, np.nextafter(x, -np.inf), np.nextafter(x, np.inf), edges, np.nextafter(edges, -np.inf),
+                            rng.uniform(x[0] - 0.5, x[-1] + 0.5, 20000)])
+        a = np.empty(len(v)); b = np.empty(len(v))
+        assert emul.emul_spline(_dp(x), _dp(y), n, _dp(v), len(v), _dp(a)) == 0
+        assert emul.emul_spline_lut(_dp(x), _dp(y), n, _dp(v), len(v), _dp(b)) == 0
+        assert np.array_equal(a, b)
