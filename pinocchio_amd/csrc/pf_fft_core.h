@@ -37,6 +37,28 @@ template <int DIR, typename F> PF_HD pfc<F> pf_mul_i(pfc<F> a) {
   return DIR > 0 ? pf_mk<F>(-a.y, a.x) : pf_mk<F>(a.y, -a.x);
 }
 
+// streaming (non-temporal) access to once-touched field data; -DPF_NT selects it (experiment)
+#if defined(__HIPCC__)
+template <typename F> struct pf_vec2 { typedef F type __attribute__((ext_vector_type(2))); };
+template <typename F> __device__ __forceinline__ pfc<F> pf_ld_stream(const pfc<F> *p) {
+#ifdef PF_NT
+  const typename pf_vec2<F>::type v = __builtin_nontemporal_load(reinterpret_cast<const typename pf_vec2<F>::type *>(p));
+  return pf_mk<F>(v.x, v.y);
+#else
+  return *p;
+#endif
+}
+template <typename F> __device__ __forceinline__ void pf_st_stream(pfc<F> *p, pfc<F> v) {
+#ifdef PF_NT
+  typename pf_vec2<F>::type t;
+  t.x = v.x; t.y = v.y;
+  __builtin_nontemporal_store(t, reinterpret_cast<typename pf_vec2<F>::type *>(p));
+#else
+  *p = v;
+#endif
+}
+#endif
+
 constexpr int pf_ilog2(int n) { return n <= 1 ? 0 : 1 + pf_ilog2(n >> 1); }
 // stage plan for 8 points per thread: radix 8 as long as it fits, the remainder (2 or 4) last
 constexpr int pf_nstages(int n) { return (pf_ilog2(n) + 2) / 3; }

@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(T *N / 8) __attribute__((amdgpu_waves_per_eu(4
         const int e = tlj + m * NT;
         const int se = e > N / 2 ? e - N : e;
         const bool inband = se <= p.band_e && se >= -p.band_e;
-        src[m] = (valid && inband) ? in[pf_addr(p.ain, outer, e, colj)] : pf_mk<F>(0, 0);
+        src[m] = (valid && inband) ? pf_ld_stream(&in[pf_addr(p.ain, outer, e, colj)]) : pf_mk<F>(0, 0);
       }
       if (p.pre) {
         int so = outer + p.outer_offset;
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(T *N / 8) __attribute__((amdgpu_waves_per_eu(4
 #pragma unroll
       for (int m = 0; m < 8; m++) {
         const int e = tlj + m * NT;
-        out[pf_addr(p.aout, outer, e, colj)] = v[m];
+        pf_st_stream(&out[pf_addr(p.aout, outer, e, colj)], v[m]);
       }
     }
   }
@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(TL *(N / 16)) k_c2r_persistent(const PfC2RPara
       const int idx = tid + i * NTHR;
       const int ll = idx / (M + 1), k = idx % (M + 1);
       const long long row = line0 + ll;
-      nxt[i] = (idx < TL * (M + 1) && row < p.nlines && k <= p.band_k) ? in[row * p.in_pitch + k] : pf_mk<F>(0, 0);
+      nxt[i] = (idx < TL * (M + 1) && row < p.nlines && k <= p.band_k) ? pf_ld_stream(&in[row * p.in_pitch + k]) : pf_mk<F>(0, 0);
     }
   };
 
@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(TL *(N / 16)) k_c2r_persistent(const PfC2RPara
       } else {
         C *o = reinterpret_cast<C *>(reinterpret_cast<F *>(p.job[job].out) + row * p.out_pitch);
 #pragma unroll
-        for (int m = 0; m < 8; m++) o[tlj + m * NT] = pf_mk<F>(pf_norm_dc(v[m].x, norm, dcv), pf_norm_dc(v[m].y, norm, dcv));
+        for (int m = 0; m < 8; m++) pf_st_stream(&o[tlj + m * NT], pf_mk<F>(pf_norm_dc(v[m].x, norm, dcv), pf_norm_dc(v[m].y, norm, dcv)));
       }
     }
     if (pf_nstages(M) == 1) __syncthreads();  // no exchange barrier separates phase B's LDS reads from the next phase A
