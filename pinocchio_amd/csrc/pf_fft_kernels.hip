@@ -289,7 +289,10 @@ __global__ void __launch_bounds__(TL *(N / 16)) k_r2c(const PfR2CParams p) {
 
 // columns per workgroup of the strided passes: 128-byte row segments where LDS allows
 template <typename F, int N> struct PfTileCols {
-  static constexpr int lds_budget = 64 * 1024;
+#ifndef PF_TILE_LDS_KB
+#define PF_TILE_LDS_KB 64
+#endif
+  static constexpr int lds_budget = PF_TILE_LDS_KB * 1024;
   static constexpr int t0 = 128 / (2 * (int)sizeof(F));  // 8 (fp64) or 16 (fp32)
   static constexpr int fit = lds_budget / (N * 2 * (int)sizeof(F));
   static constexpr int thr = 8192 / N;  // T*N/8 <= 1024
@@ -305,6 +308,10 @@ static int launch_strided_n(const PfStridedParams &p, hipStream_t st) {
   const long long nwork = (long long)ntiles * p.nouter;
   dim3 grid((unsigned)(((nwork + 7) >> 3) << 3), 1, 1), block(T * N / 8, 1, 1);
   const size_t shm = (size_t)N * T * sizeof(pfc<F>);
+  if (shm > 64 * 1024) {
+    static bool raised = false;  // per instantiation
+    if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_strided<F, N, T, DIR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); raised = true; }
+  }
   hipLaunchKernelGGL((k_strided<F, N, T, DIR>), grid, block, shm, st, p, nwork, ntiles);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
