@@ -129,6 +129,15 @@ PF_HD void pf_sincos_third(double x, double &sn, double &cs) {
   cs = fma(z * z, pc, fma(-0.5, z, 1.0));
 }
 
+// x / Y for a constant Y, correctly rounded, in three operations (Markstein): with c = RN(1/Y), q0 = RN(x c),
+// the residual x - Y q0 is exact in an fma and q0 + residual c rounds to RN(x / Y) -- the same double the
+// reference's division produces, so the q^3 < r^2 sentinel test sees the reference's own q and r
+template <int Y> PF_HD double pf_div_const(double x) {
+  const double c = 1.0 / (double)Y;
+  const double q0 = x * c;
+  return fma(fma(-(double)Y, q0, x), c, q0);
+}
+
 template <bool FAST> PF_HD void pf_cos3(double t, double &c1, double &c2, double &c3) {
   const double inv_3 = 1.0 / 3.0;
   if (!FAST) {
@@ -189,8 +198,8 @@ template <bool FAST = false> PF_HD double pf_ell_classic(double l1, double l2, d
       const double a1_2 = a1 * a1;
       const double a2 = l1 * rden;
       const double a3 = -1.0 * rden;
-      const double q = FAST ? (a1_2 - 3. * a2) * (1. / 9.) : (a1_2 - 3. * a2) / 9.;
-      const double r = FAST ? (2. * a1_2 * a1 - 9. * a1 * a2 + 27. * a3) * (1. / 54.)
+      const double q = FAST ? pf_div_const<9>(a1_2 - 3. * a2) : (a1_2 - 3. * a2) / 9.;
+      const double r = FAST ? pf_div_const<54>(2. * a1_2 * a1 - 9. * a1 * a2 + 27. * a3)
                             : (2. * a1_2 * a1 - 9. * a1 * a2 + 27. * a3) / 54.;
       const double r_2_q_3 = r * r - q * q * q;
       if (r_2_q_3 > 0) {
@@ -235,12 +244,12 @@ template <bool FAST = false> PF_HD bool pf_ordered_eigenvalues(const double d[6]
   const double add0 = d[3] * d[3], add1 = d[4] * d[4], add2 = d[5] * d[5];
   mu2 -= add0 + add1 + add2;
   const double mu3 = d[0] * d[1] * d[2] + 2. * d[3] * d[4] * d[5] - d[0] * add2 - d[1] * add1 - d[2] * add0;
-  const double q = FAST ? (mu1_2 - 3.0 * mu2) * (1.0 / 9.0) : (mu1_2 - 3.0 * mu2) / 9.0;
+  const double q = FAST ? pf_div_const<9>(mu1_2 - 3.0 * mu2) : (mu1_2 - 3.0 * mu2) / 9.0;
   double x1, x2, x3;
   if (q == 0.) {
     x1 = d[0]; x2 = d[1]; x3 = d[2];
   } else {
-    const double r = FAST ? -(2. * mu1_2 * mu1 - 9.0 * mu1 * mu2 + 27.0 * mu3) * (1. / 54.)
+    const double r = FAST ? pf_div_const<54>(-(2. * mu1_2 * mu1 - 9.0 * mu1 * mu2 + 27.0 * mu3))
                           : -(2. * mu1_2 * mu1 - 9.0 * mu1 * mu2 + 27.0 * mu3) / 54.;
     if (q * q * q < r * r || q < 0.0) {
       lam[0] = lam[1] = lam[2] = 0.0;

@@ -67,3 +67,7 @@ extern "C" int emul_spline_lut(const double *sx, const double *sy, int nk, const
   for (long i = 0; i < count; i++) out[i] = pf_spline_eval(s, v[i]);
   return 0;
 }
+
+extern "C" void emul_div_const(const double *x, long count, double *q9, double *q54) {
+  for (long i = 0; i < count; i++) { q9[i] = pf_div_const<9>(x[i]); q54[i] = pf_div_const<54>(x[i]); }
+}

@@ -164,3 +164,16 @@ def test_spline_interval_table_finds_the_bisection_interval(emul):
         assert emul.emul_spline(_dp(x), _dp(y), n, _dp(v), len(v), _dp(a)) == 0
         assert emul.emul_spline_lut(_dp(x), _dp(y), n, _dp(v), len(v), _dp(b)) == 0
         assert np.array_equal(a, b)
+
+
+def test_division_by_constant_is_correctly_rounded(emul):
+    """pf_div_const (multiply + two fma) against the IEEE division it stands in for: identical doubles"""
+    emul.emul_div_const.argtypes = [dp, C.c_long, dp, dp]
+    rng = np.random.default_rng(9)
+    x = np.concatenate([rng.standard_normal(200000) * 10.0 ** rng.integers(-30, 30, 200000), [0.0, -0.0, 9.0, 54.0, 1e-310, 1.7e308],
+                        np.arange(1.0, 2000.0)])
+    a = np.empty(len(x)); b = np.empty(len(x))
+    emul.emul_div_const(_dp(x), len(x), _dp(a), _dp(b))
+    keep = np.abs(x) > 1e-290            # the residual trick needs x c and the residual to stay normal
+    assert np.array_equal(a[keep], (x / 9.0)[keep]) and np.array_equal(b[keep], (x / 54.0)[keep])
+    assert np.allclose(a[~keep], (x / 9.0)[~keep], rtol=1e-15, atol=1e-320)
