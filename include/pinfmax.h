@@ -33,7 +33,9 @@ typedef struct pf_ctx pf_ctx;
 
 /* grid_data / FFT decomposition (src/pinocchio.h:295-308, src/fmax-pfft.c:80-134) */
 typedef struct {
-  int64_t n;        /* GSglobal[_x_] = [_y_] = [_z_] : cubic grid, power of two, 16..2048 */
+  int64_t n;        /* GSglobal[_x_] = [_y_] = [_z_] : cubic grid.  Power of two in 16..2048: the hand-written transform
+                       passes (any nranks, fp64 or fp32 fields).  Any other even size in 4..4096: library (hipFFT)
+                       transforms, one rank and fp64 fields only (the reference accepts any GridSize) */
   int     rank;     /* ThisTask */
   int     nranks;   /* NTasks; x-slabs, nranks must divide n */
   int     device;   /* HIP device ordinal of this rank */

@@ -101,8 +101,26 @@ static double now_s(void) {
 
 /* ------------------------------------------------------------------ FFT -- */
 
-/* in-place radix-2 DIT on n interleaved complex values; sign=+1 -> e^{+i..} */
+/* in-place radix-2 DIT on n interleaved complex values; sign=+1 -> e^{+i..}.  Grid sizes that are not a power of two
+   (the reference takes any GridSize through FFTW; e.g. the 200^3 of INSTALLATION:101) go through the plain O(n^2) sum
+   with the same twiddle table -- test sizes only. */
 static void fft1d(double *a, int n, int sign, const double *tw, const int *brev) {
+  if (n & (n - 1)) {
+    double tmp[2 * n];
+    for (int k = 0; k < n; k++) {
+      double sr = 0.0, si = 0.0;
+      int idx = 0; /* (j * k) mod n */
+      for (int j = 0; j < n; j++) {
+        const double wr = tw[2 * idx], wi = sign * tw[2 * idx + 1];
+        sr += a[2 * j] * wr - a[2 * j + 1] * wi;
+        si += a[2 * j] * wi + a[2 * j + 1] * wr;
+        idx += k; if (idx >= n) idx -= n;
+      }
+      tmp[2 * k] = sr; tmp[2 * k + 1] = si;
+    }
+    memcpy(a, tmp, sizeof(double) * 2 * n);
+    return;
+  }
   for (int i = 0; i < n; i++) {
     int j = brev[i];
     if (j > i) {
@@ -847,7 +865,7 @@ int orc_fmax_pdf(orc_ctx *c, unsigned long long hist[ORC_NBINS]) {
 /* ----------------------------------------------------------- plumbing --- */
 
 orc_ctx *orc_create(int n, int nthreads) {
-  if (n < 4 || (n & (n - 1))) return NULL;
+  if (n < 4 || (n & 1)) return NULL; /* even sizes; powers of two use the radix-2 transform */
   orc_ctx *c = (orc_ctx *)calloc(1, sizeof(orc_ctx));
   c->n = n; c->nzh = n / 2 + 1;
 #ifdef _OPENMP

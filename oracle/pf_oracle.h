@@ -42,7 +42,7 @@ typedef struct {
 
 typedef struct orc_ctx orc_ctx;
 
-/* single rank, cubic grid n^3 (n power of two >= 4); nthreads<=0 -> omp default */
+/* single rank, cubic grid n^3 (n even >= 4; not a power of two: O(n^2) transforms, test sizes only); nthreads<=0 -> omp default */
 orc_ctx *orc_create(int n, int nthreads);
 void     orc_destroy(orc_ctx *c);
 

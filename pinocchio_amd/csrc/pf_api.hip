@@ -118,6 +118,10 @@ struct pf_ctx {
   PfCtDev ct;
   double *ct_block;    // delta | alpha | gamma | y | b | c | d
   bool have_density, have_hessian, have_sources, products_init;
+  // general path: grid sizes that are not a power of two (one rank, fp64) go through library transforms
+  bool general;
+  void *W;                  // scratch spectrum of the filter
+  void *fft_c2r, *fft_r2c;  // hipfft plans (Z2D, D2Z), bound at run time (pf_general_fft_*)
   bool vel_zero_pending;  // the Vel* columns are to read as zero (src/collapse_times.c:472-489) but have not been cleared yet
   int last_ns;
   pf_alltoall_fn a2a; void *a2a_user;
@@ -186,6 +190,7 @@ extern "C" void pf_layout_3lpt(pf_product_layout *l) {
 }
 
 static size_t ncell(const pf_ctx *c) { return (size_t)c->nxl * c->n * c->n; }
+static long long rpitch(const pf_ctx *c) { return c->general ? c->n : 2 * c->nzp; }  // reals per row of a real field
 static double spec_bytes_alg(const pf_ctx *c) { return (double)c->n * c->nyl * c->nzh * 2.0 * c->fb; }  // one half-spectrum field
 static double real_bytes_alg(const pf_ctx *c) { return (double)ncell(c) * c->fb; }
 
@@ -194,7 +199,14 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   *out = nullptr;
   const int rank = cfg->rank;
   const long long n = cfg->n;
-  if (n < 16 || n > 2048 || (n & (n - 1))) return pf_fail(rank, "pf_create: grid size %lld must be a power of two in [16, 2048]", n);
+  const bool pow2 = !(n & (n - 1));
+  const bool want_general = !pow2 || (getenv("PF_GENERAL") && atoi(getenv("PF_GENERAL")));
+  if (want_general) {
+    if (n < 4 || n > 4096 || (n & 1)) return pf_fail(rank, "pf_create: grid size %lld must be even, in [4, 4096]", n);
+    if (cfg->nranks != 1 || cfg->field_bytes != 8)
+      return pf_fail(rank, "pf_create: grid size %lld is not a power of two: the library-transform path takes one rank and fp64 fields "
+                           "(slab decomposition and fp32 fields need a power of two in [16, 2048])", n);
+  } else if (n < 16 || n > 2048) return pf_fail(rank, "pf_create: grid size %lld must be a power of two in [16, 2048] (or any even size on one rank)", n);
   if (cfg->nranks < 1 || n % cfg->nranks || cfg->rank < 0 || cfg->rank >= cfg->nranks)
     return pf_fail(rank, "pf_create: nranks %d must divide the grid size %lld (slab decomposition)", cfg->nranks, n);
   if (cfg->nranks & (cfg->nranks - 1)) return pf_fail(rank, "pf_create: nranks %d must be a power of two", cfg->nranks);
@@ -205,6 +217,8 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   if (cfg->device < 0 || cfg->device >= ndev) return pf_fail(rank, "pf_create: device %d out of range (%d devices)", cfg->device, ndev);
   pf_ctx *c = new pf_ctx();
   c->cfg = *cfg; c->rank = rank; c->P = cfg->nranks; c->n = (int)n; c->nzh = c->n / 2 + 1; c->nzp = c->n / 2 + 8;
+  c->general = want_general; c->fft_c2r = c->fft_r2c = nullptr; c->W = nullptr;
+  if (c->general) c->nzp = c->nzh;  // natural layout [n][n][n/2+1], the boundary layout itself
   c->nxl = c->n / c->P; c->nyl = c->n / c->P; c->fb = cfg->field_bytes; c->timing = (cfg->flags & PF_FLAG_TIMING) != 0;
   c->dev_bytes = 0; c->own_stream = true; c->stream = nullptr;
   c->a2a = nullptr; c->ared = nullptr; c->a2a_user = c->ared_user = nullptr; c->rccl = nullptr;
@@ -267,6 +281,12 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
     PFCHK(c, dev_alloc(c, (void **)&c->blockA2, 3 * c->field_bytes));
     PFCHK(c, dev_alloc(c, &c->recvA2, 3 * c->field_bytes));
   }
+  if (c->general) {
+    PFCHK(c, dev_alloc(c, &c->W, c->field_bytes));
+    c->fuse = c->overlap = false;
+    const int rc = pf_gfft_create(c->n, c->stream, &c->fft_c2r, &c->fft_r2c);
+    if (rc) return pf_fail(rank, "pf_create: hipFFT plans for %d^3 failed (%d): grid sizes that are not a power of two need libhipfft", c->n, rc);
+  }
   const size_t nc = ncell(c);
   PFCHK(c, dev_alloc(c, (void **)&c->fmax, nc * sizeof(float)));
   PFCHK(c, dev_alloc(c, (void **)&c->rmax, nc * sizeof(int)));
@@ -304,7 +324,8 @@ extern "C" int pf_destroy(pf_ctx *c) {
   hipFree(c->dk); hipFree(c->blockA); hipFree(c->recvA); hipFree(c->tw); hipFree(c->blockA2); hipFree(c->recvA2);
   for (int i = 0; i < 6; i++) { hipFree(c->B[i]); hipFree(c->B2[i]); }
   for (int i = 0; i < 3; i++) hipFree(c->S[i]);
-  hipFree(c->fmax); hipFree(c->rmax); hipFree(c->vel12); hipFree(c->partials); hipFree(c->scal); hipFree(c->hist); hipFree(c->spl); hipFree(c->gtab); hipFree(c->ct_block);
+  hipFree(c->fmax); hipFree(c->rmax); hipFree(c->vel12); hipFree(c->partials); hipFree(c->scal); hipFree(c->hist); hipFree(c->spl); hipFree(c->gtab); hipFree(c->ct_block); hipFree(c->W);
+  pf_gfft_destroy(c->fft_c2r); pf_gfft_destroy(c->fft_r2c);
   for (auto &e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   for (auto &e : c->phase_evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   for (auto e : c->evpool) hipEventDestroy(e);
@@ -467,6 +488,61 @@ static int pipelined(pf_ctx *c, int count, int nf, Pre pre, Dst dst, Post post) 
 }
 static void *recv_field(pf_ctx *c, int set, int f) { return (char *)(set ? c->recvA2 : c->recvA) + (size_t)f * c->field_bytes; }
 
+// ---------------------------------------------------------------------------------------------- general path ----
+// Grid sizes that are not a power of two (one rank, fp64): the reference's own structure -- one k-space filter and one
+// 3-D c2r per component (compute_derivative, src/fmax-pfft.c:255-441) -- with hipFFT transforms on the natural layouts
+// (spectrum [n][n][n/2+1] = the boundary layout, real fields [n][n][n]).  Per-cell kernels are the same as in the
+// fused path.  Unfused, so it moves ~2x the bytes of the power-of-two path; it exists for completeness of the drop-in.
+static int g_filter(pf_ctx *c, const void *in, void *out, int a, int b, double rs, int order, bool normalise) {
+  double growth = order ? c->growth[order - 1] : 1.0;
+  const int o = order - 1;
+  const bool tab = order && c->gt_n[o];
+  KTimer t(c, KS_MISC, 2.0 * spec_bytes_alg(c));
+  PFCHK(c, pf_launch_gen_filter(in, out, c->n, a, b, rs, growth, tab ? c->gtab + o * PF_KBIN_CAP : nullptr, tab ? c->gt_n[o] : 0,
+                                tab ? c->gt_logkmin[o] : 0.0, tab ? c->gt_dlogk[o] : 1.0, tab ? c->gt_sign[o] : 1.0,
+                                normalise ? 1.0 / ((double)c->n * c->n * c->n) : 1.0, c->stream));
+  return 0;
+}
+static int g_c2r(pf_ctx *c, void *spec, void *real) {
+  KTimer t(c, KS_ZPASS_PLAIN, spec_bytes_alg(c) + real_bytes_alg(c));
+  if (pf_gfft_c2r(c->fft_c2r, spec, real)) return pf_fail(c->rank, "hipfftExecZ2D failed");
+  return 0;
+}
+static int g_r2c(pf_ctx *c, void *real, void *spec) {
+  KTimer t(c, KS_R2C_Z, spec_bytes_alg(c) + real_bytes_alg(c));
+  if (pf_gfft_r2c(c->fft_r2c, real, spec)) return pf_fail(c->rank, "hipfftExecD2Z failed");
+  return 0;
+}
+static int g_hessian_of(pf_ctx *c, const void *spec, double rs, void *const out[6]) {
+  static const int pa[6] = {1, 2, 3, 1, 1, 2}, pb[6] = {1, 2, 3, 2, 3, 3};  // storage order 11,22,33,12,13,23 (src/LPT.c:36-44)
+  for (int i = 0; i < 6; i++) {
+    PFCHK(c, g_filter(c, spec, c->W, pa[i], pb[i], rs, 0, true));
+    PFCHK(c, g_c2r(c, c->W, out[i]));
+  }
+  return 0;
+}
+static int g_displacements_of(pf_ctx *c, int count, const void *const *specs, const int *orders, void *tmp) {
+  const size_t nc = ncell(c);
+  for (int j = 0; j < count; j++)
+    for (int ia = 1; ia <= 3; ia++) {
+      PFCHK(c, g_filter(c, specs[j], c->W, ia, 0, 0.0, orders[j] + 1, true));
+      PFCHK(c, g_c2r(c, c->W, tmp));
+      PFCHK(c, pf_launch_real_to_col((const double *)tmp, c->vel12 + (size_t)(3 * orders[j] + ia - 1) * nc, nc, c->stream));
+    }
+  return 0;
+}
+// real field in f (pitch n) -> its unnormalised spectrum in f
+static int g_forward_of(pf_ctx *c, void *f) {
+  PFCHK(c, g_r2c(c, f, c->W));
+  HIPCHK(c, hipMemcpyAsync(f, c->W, c->field_bytes, hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+// spectrum in f -> c2r / N^3 in f
+static int g_reverse_of(pf_ctx *c, void *f) {
+  PFCHK(c, g_filter(c, f, c->W, -1, -1, 0.0, 0, true));
+  return g_c2r(c, c->W, f);
+}
+
 // six second derivatives of `spec` (KY layout) at smoothing rs -> six real fields out[0..5] (R layout)
 // order 11,22,33,12,13,23 (src/LPT.c:36-44); compute_second_derivatives, src/fmax.c:225-258
 // Gaussian window exp(-k^2 rs^2/2) < prune_eps (2^-60) beyond |k| = sqrt(-2 ln eps)/rs: those modes are dropped
@@ -495,6 +571,7 @@ static int hess_yz(pf_ctx *c, const void *const R[3], const double *dc, void *co
   return 0;
 }
 static int hessian_of(pf_ctx *c, const void *spec, double rs, const double *dc, void *const out[6], bool xy_only = false) {
+  if (c->general) return g_hessian_of(c, spec, rs, out);
   const int band = hess_band(c, rs, xy_only);
   return pipelined(c, 1, 3,
                    [&](int, void *const *A) { return hess_x(c, spec, rs, A, band); },
@@ -507,6 +584,7 @@ static int hessian_of(pf_ctx *c, const void *spec, double rs, const double *dc, 
 // The growth multiplier of ScaleDep.order = orders[j] + 1 is a scalar (c->growth) or, with a k-binned table
 // installed (pf_set_growth_table), applied per mode by k_apply_growth into the spare send field first.
 static int displacements_of(pf_ctx *c, int count, const void *const *specs, const int *orders, void *const tmp[3]) {
+  if (c->general) return g_displacements_of(c, count, specs, orders, tmp[0]);
   const size_t nc = ncell(c);
   return pipelined(c, count, 2,
                    [&](int j, void *const *A) {
@@ -545,6 +623,10 @@ static int forward_r2c(pf_ctx *c, void *f) {
   return 0;
 }
 static int forward_many(pf_ctx *c, int count, void *const *fs) {
+  if (c->general) {
+    for (int i = 0; i < count; i++) PFCHK(c, g_forward_of(c, fs[i]));
+    return 0;
+  }
   if (c->P == 1) {  // y-pass in place, nothing to exchange
     for (int i = 0; i < count; i++) {
       void *f = fs[i];
@@ -572,6 +654,7 @@ static int forward_of(pf_ctx *c, void *f) { return forward_many(c, 1, &f); }
 
 // plain c2r of the spectrum in `f` (KY) -> real in `f` (R) times 1/N^3, in place (reverse_transform)
 static int reverse_of(pf_ctx *c, void *f) {
+  if (c->general) return g_reverse_of(c, f);
   const Job xj[1] = {{f, f, PF_MUL_ONE}};
   PFCHK(c, xpass(c, KS_XPASS_PLAIN, +1, 1, xj, 0, 0.0, 1.0, 1));
   const void *R = f;
@@ -642,8 +725,13 @@ extern "C" int pf_set_density(pf_ctx *c, const double *kd) {
 extern "C" int pf_synth_density(pf_ctx *c, uint64_t seed, double sigma0, double slope) {
   if (!c) return 1;
   // white noise (R layout) -> r2c -> shape -> normalise
-  PFCHK(c, pf_launch_white(c->fb, c->dk, (long long)c->nxl * c->n, (long long)c->rank * c->nxl * c->n, c->n, 2 * c->nzp, seed, c->stream));
-  PFCHK(c, forward_of(c, c->dk));
+  if (c->general) {  // real noise in a real field, library r2c into the spectrum
+    PFCHK(c, pf_launch_white(c->fb, c->B[0], (long long)c->n * c->n, 0, c->n, c->n, seed, c->stream));
+    PFCHK(c, g_r2c(c, c->B[0], c->dk));
+  } else {
+    PFCHK(c, pf_launch_white(c->fb, c->dk, (long long)c->nxl * c->n, (long long)c->rank * c->nxl * c->n, c->n, 2 * c->nzp, seed, c->stream));
+    PFCHK(c, forward_of(c, c->dk));
+  }
   PfShapeParams p; memset(&p, 0, sizeof(p));
   p.spec = c->dk; p.n = c->n; p.nzp = c->nzp; p.nyl = c->nyl; p.y0 = c->rank * c->nyl; p.slope = slope; p.scale = 1.0;
   p.partials = c->partials; p.nblocks = PF_NBLK; p.mode = 0; p.dscale = nullptr;
@@ -804,7 +892,7 @@ extern "C" int pf_second_derivatives(pf_ctx *c, double rs) {
 static int collapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], hipStream_t st, bool build_table = true) {
   PfCollapseParams p; memset(&p, 0, sizeof(p));
   for (int i = 0; i < 6; i++) p.h[i] = H[i];
-  p.pitch = 2 * c->nzp; p.nrows = (long long)c->nxl * c->n; p.n = c->n; p.fmax = c->fmax; p.rmax = c->rmax; p.ismooth = ismooth;
+  p.pitch = rpitch(c); p.nrows = (long long)c->nxl * c->n; p.n = c->n; p.fmax = c->fmax; p.rmax = c->rmax; p.ismooth = ismooth;
   if (spline_for(c, ismooth, &p.spline)) return 1;
   p.partials = c->partials; p.fast = c->fast_libm ? 1 : 0;
   p.wpe = getenv("PF_COLLAPSE_WPE") ? atoi(getenv("PF_COLLAPSE_WPE")) : 0;
@@ -929,7 +1017,17 @@ extern "C" int pf_sweep(pf_ctx *c, int ns, const double *radius_cells, double *t
     HIPCHK(c, hipEventRecord(c->ev_c[b], cst));
     return 0;
   };
-  if (pipelined(c, ns, 3, pre, [&](int, int set, int f) { return recv_field(c, set, f); }, post)) return 1;
+  if (c->general) {  // one filter + one library c2r per component, then the same collapse pass
+    for (int ismooth = 0; ismooth < ns; ismooth++) {
+      {
+        PhaseTimer pt(c, 0);
+        PFCHK(c, g_hessian_of(c, c->dk, radius_cells[ismooth], c->B));
+      }
+      PhaseTimer pt(c, 1);
+      if (collapse_enqueue(c, ismooth, c->B, c->stream)) return 1;
+      HIPCHK(c, hipEventRecord(c->ev_c[0], c->stream));
+    }
+  } else if (pipelined(c, ns, 3, pre, [&](int, int set, int f) { return recv_field(c, set, f); }, post)) return 1;
   // join; keep the R=0 Hessian (last radius) in B for the LPT sources
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_c[(ns - 1) & 1], 0));
   if (ns >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_c[(ns - 2) & 1], 0));
@@ -965,7 +1063,7 @@ extern "C" int pf_displacements(pf_ctx *c, int compute_sources, int recompute_sd
       if (!c->have_hessian) return pf_fail(c->rank, "pf_displacements: second derivatives at R=0 not in place");
       PfLptSrcParams sp; memset(&sp, 0, sizeof(sp));
       for (int i = 0; i < 6; i++) sp.h[i] = c->B[i];
-      sp.s2 = c->S[0]; sp.s3a = c->S[1]; sp.s3b = c->S[2]; sp.pitch = 2 * c->nzp; sp.nrows = (long long)c->nxl * c->n; sp.n = c->n;
+      sp.s2 = c->S[0]; sp.s3a = c->S[1]; sp.s3b = c->S[2]; sp.pitch = rpitch(c); sp.nrows = (long long)c->nxl * c->n; sp.n = c->n;
       sp.partials = c->partials;
       size_t nb = (ncell(c) + 255) / 256; if (nb > PF_NBLK) nb = PF_NBLK;
       sp.nblocks = (int)nb;
@@ -980,7 +1078,7 @@ extern "C" int pf_displacements(pf_ctx *c, int compute_sources, int recompute_sd
       PFCHK(c, hessian_of(c, c->S[0], 0.0, c->scal + SC_DC_S2, c->B2));
       PfLptAccParams ap; memset(&ap, 0, sizeof(ap));
       for (int i = 0; i < 6; i++) { ap.h[i] = c->B[i]; ap.phi2[i] = c->B2[i]; }
-      ap.s3b = c->S[2]; ap.pitch = 2 * c->nzp; ap.nrows = (long long)c->nxl * c->n; ap.n = c->n;
+      ap.s3b = c->S[2]; ap.pitch = rpitch(c); ap.nrows = (long long)c->nxl * c->n; ap.n = c->n;
       {
         KTimer t(c, KS_LPT_ACC, 14.0 * real_bytes_alg(c));
         PFCHK(c, pf_launch_lpt_accum(c->fb, ap, c->stream));
@@ -1101,7 +1199,7 @@ extern "C" int pf_get_second_derivative(pf_ctx *c, int i, double *host) {
   if (!c || !host || i < 0 || i > 5) return pf_fail(0, "pf_get_second_derivative: bad argument");
   if (!c->have_hessian) return pf_fail(c->rank, "pf_get_second_derivative: not computed");
   const long long nrows = (long long)c->nxl * c->n;
-  PFCHK(c, pf_launch_real_export(c->fb, c->B[i], (double *)staging(c), nrows, c->n, 2 * c->nzp, c->stream));
+  PFCHK(c, pf_launch_real_export(c->fb, c->B[i], (double *)staging(c), nrows, c->n, rpitch(c), c->stream));
   HIPCHK(c, hipMemcpyAsync(host, staging(c), (size_t)nrows * c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
@@ -1121,12 +1219,12 @@ extern "C" int pf_get_density(pf_ctx *c, double *host) {
 static int import_real(pf_ctx *c, const double *host, void *dst) {
   const long long nrows = (long long)c->nxl * c->n;
   HIPCHK(c, hipMemcpyAsync(staging(c), host, (size_t)nrows * c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  PFCHK(c, pf_launch_real_import(c->fb, (const double *)staging(c), dst, nrows, c->n, 2 * c->nzp, c->stream));
+  PFCHK(c, pf_launch_real_import(c->fb, (const double *)staging(c), dst, nrows, c->n, rpitch(c), c->stream));
   return 0;
 }
 static int export_real(pf_ctx *c, const void *src, double *host) {
   const long long nrows = (long long)c->nxl * c->n;
-  PFCHK(c, pf_launch_real_export(c->fb, src, (double *)staging(c), nrows, c->n, 2 * c->nzp, c->stream));
+  PFCHK(c, pf_launch_real_export(c->fb, src, (double *)staging(c), nrows, c->n, rpitch(c), c->stream));
   HIPCHK(c, hipMemcpyAsync(host, staging(c), (size_t)nrows * c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
@@ -1165,6 +1263,11 @@ extern "C" int pf_derivative(pf_ctx *c, const double *spec_host, int first_deriv
   if (a == 0 && b == 0) growth = -growth;     // greens_function: -1/k^2 (src/fmax-pfft.c:449-450)
   void *f = c->A[0];
   PFCHK(c, import_spec(c, spec_host, f));
+  if (c->general) {
+    PFCHK(c, g_filter(c, f, c->W, a, b, rs_cells, order, true));
+    PFCHK(c, g_c2r(c, c->W, f));
+    return export_real(c, f, real_host);
+  }
   PFCHK(c, dc_of_host_spec(c, spec_host, SC_DC_TMP));
   if (order && c->gt_n[order - 1]) {
     const int o = order - 1;

@@ -267,6 +267,63 @@ __global__ void __launch_bounds__(PF_CELL_BLOCK)
   }
 }
 
+// ---- general grid sizes (library-FFT path, pf_api.hip "general path") --------------------------------------------
+// compute_derivative's k-space loop (src/fmax-pfft.c:303-386) on the natural layout [n][n][n/2+1]:
+// out(k) = in(k) * G(k) * exp(-k^2 rs^2 / 2) * growth * norm with G = k_a k_b / k^2, k_a / k^2 (then the re/im swap),
+// -1/k^2 for (0,0), 1 for (-1,-1); the k = 0 mode only takes norm (and the swap).  norm = 1/N^3 is applied here
+// because the library c2r that follows is unnormalised (the reference scales after its c2r, :220-225).
+__global__ void __launch_bounds__(PF_CELL_BLOCK)
+    k_gen_filter(const pfc<double> *__restrict__ in, pfc<double> *__restrict__ out, int n, int a, int b, double rs, double growth,
+                 const double *__restrict__ T, int nk, double logkmin, double dlogk, double sign, double norm) {
+  const int nzh = n / 2 + 1;
+  const double knorm = 2. * PF_PI / (double)n;
+  const size_t total = (size_t)n * n * nzh;
+  const bool swap = (a == 0 && b > 0) || (a > 0 && b == 0);
+  double kmin = 0, kmax = 0;
+  if (nk) { kmin = pow(10., logkmin); kmax = pow(10., logkmin + (nk - 1) * dlogk); }
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int iz = (int)(i % nzh);
+    const size_t r = i / nzh;
+    int iy = (int)(r % n), ix = (int)(r / n);
+    if (ix > n / 2) ix -= n;
+    if (iy > n / 2) iy -= n;
+    const double kx = knorm * ix, ky = knorm * iy, kz = knorm * iz;
+    const double k2_0 = kx * kx, k2_1 = k2_0 + ky * ky;
+    const double k_squared = k2_1 + kz * kz;
+    double re = in[i].x, im = in[i].y;
+    if (k_squared != 0.) {
+      double g = growth;
+      if (nk) {  // InterpolateGrowth, |k| in rad/cell (k_apply_growth)
+        const double k = sqrt(k_squared);
+        double v;
+        if (k < kmin) v = T[0];
+        else if (k > kmax) v = T[nk - 1];
+        else {
+          double dk = (log10(k) - logkmin) / dlogk;
+          const int kk = (int)dk;
+          dk -= kk;
+          v = (kk >= nk - 1) ? T[nk - 1] : dk * T[kk + 1] + (1 - dk) * T[kk];
+        }
+        g = sign * pow(10., v);
+      }
+      const double comp[4] = {1.0, kx, ky, kz};
+      double green = 1.0;
+      if (a >= 0 && b >= 0) green = (a == 0 && b == 0) ? -comp[a] * comp[b] / k_squared : comp[a] * comp[b] / k_squared;
+      const double w = green * exp(-0.5 * k_squared * rs * rs) * g;
+      re *= w; im *= w;
+    }
+    if (swap) { const double t = im; im = re; re = -t; }
+    out[i] = pf_mk<double>(re * norm, im * norm);
+  }
+}
+// real field -> one fp32 column of the products (write_from_rvector_to_products, src/fmax-pfft.c:563-631)
+__global__ void __launch_bounds__(PF_CELL_BLOCK) k_real_to_col(const double *__restrict__ src, float *__restrict__ dst, size_t ncell) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncell; i += (size_t)gridDim.x * blockDim.x) dst[i] = (float)src[i];
+}
+__global__ void __launch_bounds__(PF_CELL_BLOCK) k_scale_real(double *__restrict__ f, size_t ncell, double s) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncell; i += (size_t)gridDim.x * blockDim.x) f[i] *= s;
+}
+
 // device SoA -> the caller's AoS product_data (src/pinocchio.h:233-259)
 __global__ void __launch_bounds__(PF_CELL_BLOCK)
     k_pack_products(const float *fmax, const int *rmax, const float *vel12, size_t ncell_total, size_t first, size_t count,
@@ -441,6 +498,20 @@ int pf_launch_apply_growth(int fb, const void *in, void *out, int n, int nyl, in
   const int g = pf_grid_for((size_t)n * nyl * nzh);
   if (fb == 8) hipLaunchKernelGGL(k_apply_growth<double>, dim3(g), dim3(PF_CELL_BLOCK), 0, st, (const pfc<double> *)in, (pfc<double> *)out, n, nyl, nzh, nzp, y0, T, nk, logkmin, dlogk, sign);
   else hipLaunchKernelGGL(k_apply_growth<float>, dim3(g), dim3(PF_CELL_BLOCK), 0, st, (const pfc<float> *)in, (pfc<float> *)out, n, nyl, nzh, nzp, y0, T, nk, logkmin, dlogk, sign);
+  return PF_CHECK_LAUNCH();
+}
+int pf_launch_gen_filter(const void *in, void *out, int n, int a, int b, double rs, double growth, const double *T, int nk, double logkmin,
+                         double dlogk, double sign, double norm, hipStream_t st) {
+  hipLaunchKernelGGL(k_gen_filter, dim3(pf_grid_for((size_t)n * n * (n / 2 + 1))), dim3(PF_CELL_BLOCK), 0, st, (const pfc<double> *)in,
+                     (pfc<double> *)out, n, a, b, rs, growth, T, nk, logkmin, dlogk, sign, norm);
+  return PF_CHECK_LAUNCH();
+}
+int pf_launch_real_to_col(const double *src, float *dst, size_t ncell, hipStream_t st) {
+  hipLaunchKernelGGL(k_real_to_col, dim3(pf_grid_for(ncell)), dim3(PF_CELL_BLOCK), 0, st, src, dst, ncell);
+  return PF_CHECK_LAUNCH();
+}
+int pf_launch_scale_real(double *f, size_t ncell, double s, hipStream_t st) {
+  hipLaunchKernelGGL(k_scale_real, dim3(pf_grid_for(ncell)), dim3(PF_CELL_BLOCK), 0, st, f, ncell, s);
   return PF_CHECK_LAUNCH();
 }
 int pf_launch_fmax_pdf(const float *fmax, size_t ncell, unsigned long long *hist, hipStream_t st) {

@@ -163,6 +163,16 @@ int pf_launch_spec_import(int field_bytes, const double *src, void *dst, long lo
 int pf_launch_spec_export(int field_bytes, const void *src, double *dst, long long nrows, int nzh, int nzp, hipStream_t st);
 int pf_launch_real_import(int field_bytes, const double *src, void *dst, long long nrows, int n, long long pitch, hipStream_t st);
 int pf_launch_real_export(int field_bytes, const void *src, double *dst, long long nrows, int n, long long pitch, hipStream_t st);
+// general grid sizes (library-FFT path)
+int pf_launch_gen_filter(const void *in, void *out, int n, int a, int b, double rs, double growth, const double *T, int nk, double logkmin,
+                         double dlogk, double sign, double norm, hipStream_t st);
+int pf_launch_real_to_col(const double *src, float *dst, size_t ncell, hipStream_t st);
+int pf_launch_scale_real(double *f, size_t ncell, double s, hipStream_t st);
+// pf_gfft.cpp: hipFFT plans (double precision, n^3, natural layouts: spectrum [n][n][n/2+1], real [n][n][n])
+int pf_gfft_create(int n, hipStream_t st, void **c2r, void **r2c);
+int pf_gfft_c2r(void *plan, void *spec, void *real);   // unnormalised, out of place; may destroy spec
+int pf_gfft_r2c(void *plan, void *real, void *spec);   // unnormalised, out of place
+void pf_gfft_destroy(void *plan);
 // pf_select_sort.hip
 int pf_select_sort_device(const float *fmax, size_t ncell, float flast, unsigned int **d_idx, float **d_f, size_t *count, hipStream_t st);
 int pf_launch_block_vec3(const float *vel12, size_t ncell, int o, size_t first, size_t count, float *out, hipStream_t st);

@@ -722,3 +722,89 @@ def test_edge_case_fields_vs_oracle(api, case, monkeypatch):
             assert np.max(np.abs(p[name].astype(np.float64) - po[name])) <= 4e-7 * amp + 1e-300, name
         if case == "zero":
             assert not p["Vel"].any() and np.all(p["Rmax"] == po["Rmax"]) and np.array_equal(p["Fmax"], po["Fmax"])
+
+
+@pytest.mark.parametrize("n", [24, 40])
+def test_general_grid_sizes_vs_oracle(api, n):
+    """grid sizes that are not a power of two (the reference takes any GridSize; 200^3 in INSTALLATION:101): the
+    library-transform path against the oracle (plain O(n^2) transforms at these sizes), full path + taps"""
+    import np_restatement as npr
+    dk = synth.make_density(n, seed=n)
+    dk[0, 0, 0] = 0.11 * n ** 3
+    x, y = synth.invgrow_table("lcdm")
+    g = synth.growth_multipliers()
+    radii = np.array([2.0, 1.0, 0.0])
+    o = oracle_lib.Oracle(n, 0)
+    o.set_density(dk); o.set_invgrow(x, y); o.set_growth(g)
+    tv_o = o.compute_fmax(radii, do_lpt=True)
+    po = o.products()
+    hes_o = o.second_derivatives(1.3)
+    with api.Fmax(n) as f:
+        f.set_density(dk); f.set_invgrow(x, y); f.set_growth(g)
+        tv = f.compute_fmax(radii, do_lpt=True)
+        p = f.products()
+        pdf = f.Fmax_PDF()
+        f.compute_second_derivatives(1.3)
+        hes = [f.second_derivative(i) for i in range(6)]
+        rng = np.random.default_rng(1)
+        real = rng.standard_normal((n, n, n))
+        spec = f.forward_transform(real)
+        back = f.reverse_transform(dk)
+        d30 = f.compute_derivative(dk, 3, 0, 0.7, 2)
+        assert np.array_equal(f.density(), dk)
+    assert np.allclose(tv, tv_o, rtol=1e-12) and int(pdf.sum()) == n ** 3
+    for a, b in zip(hes, hes_o):
+        assert np.max(np.abs(a - b)) <= 1e-12 * np.max(np.abs(b))
+    _fmax_close(p["Fmax"], po["Fmax"])
+    assert np.mean(p["Rmax"] != po["Rmax"]) < 1e-3
+    for name in ("Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+        assert np.max(np.abs(p[name].astype(np.float64) - po[name])) <= 4e-7 * np.max(np.abs(po[name])), name
+    want = np.fft.rfftn(real, axes=(0, 1, 2))
+    assert np.max(np.abs(spec - want)) < 1e-12 * np.max(np.abs(want))
+    want = np.fft.irfftn(dk, s=(n, n, n), axes=(0, 1, 2))
+    assert np.max(np.abs(back - want)) < 1e-12 * np.max(np.abs(want))
+    want = npr.derivative(dk, 0.7, 3, 0, g[1])
+    assert np.max(np.abs(d30 - want)) < 1e-12 * np.max(np.abs(want))
+
+
+def test_general_path_equals_fused_path_on_a_power_of_two(api, monkeypatch):
+    """PF_GENERAL=1 forces the library-transform path on a size the hand-written passes also cover: same products"""
+    n = 64
+    dk = synth.make_density(n, seed=6)
+    x, y = synth.invgrow_table("lcdm")
+    g = synth.growth_multipliers()
+    radii = np.array([4.0, 1.0, 0.0])
+    out = []
+    for general in ("0", "1"):
+        monkeypatch.setenv("PF_GENERAL", general)
+        with api.Fmax(n) as f:
+            f.set_density(dk); f.set_invgrow(x, y); f.set_growth(g)
+            tv = f.compute_fmax(radii, do_lpt=True)
+            out.append((tv, f.products()))
+    (tv0, p0), (tv1, p1) = out
+    assert np.allclose(tv0, tv1, rtol=1e-12)
+    _fmax_close(p1["Fmax"], p0["Fmax"])
+    assert np.mean(p1["Rmax"] != p0["Rmax"]) < 1e-3
+    for name in ("Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+        assert np.max(np.abs(p1[name].astype(np.float64) - p0[name])) <= 4e-7 * np.max(np.abs(p0[name])), name
+
+
+def test_reference_example_size_200(api):
+    """BASELINE config 1 (200^3, INSTALLATION:101-102) through the general path: size-independent properties and the
+    device IC generator at that size"""
+    n = 200
+    x, y = synth.invgrow_table("lcdm")
+    with api.Fmax(n) as f:
+        f.synth_density(synth.SEED, 2.5, -2.0)
+        f.set_invgrow(x, y); f.set_growth(synth.growth_multipliers())
+        tv = f.compute_fmax(np.array([8.0, 2.0, 0.0]), do_lpt=True)
+        assert abs(np.sqrt(tv[-1]) - 2.5) < 1e-9                     # sigma(R=0) = the k-space normalisation
+        assert tv[0] < tv[1] < tv[2]
+        pdf = f.Fmax_PDF()
+        assert int(pdf.sum()) == n ** 3
+        f.compute_second_derivatives(0.0)
+        h = [f.second_derivative(i) for i in range(3)]
+        back = f.reverse_transform(f.density())
+        assert np.max(np.abs(h[0] + h[1] + h[2] - back)) < 1e-10 * np.max(np.abs(back))   # Laplacian identity
+        p = f.products()
+        assert (p["Fmax"] >= 1.0).mean() > 0.2 and np.isfinite(p["Vel"]).all() and p["Vel_2LPT"].any()
