@@ -100,7 +100,7 @@ class Oracle:
         self.n = n
         self.h = self.L.orc_create(n, nthreads)
         if not self.h:
-            raise ValueError("orc_create failed (n must be a power of two >= 4)")
+            raise ValueError("orc_create failed (n must be even and >= 4)")
 
     def close(self):
         if self.h:

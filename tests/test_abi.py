@@ -46,10 +46,13 @@ def test_create_rejects_bad_configs_and_missing_gpu(lib, capfd):
     import torch
     L = lib.load()
     h = C.c_void_p()
-    for n, nranks in ((100, 1), (8, 1), (4096, 1), (64, 3)):
-        cfg = lib.Config(n=n, rank=0, nranks=nranks, device=0, field_bytes=8, flags=0)
+    # odd, too small, too large, rank count not dividing / not a power of two; sizes that are not a power of two are
+    # one-rank fp64 only (library-transform path)
+    for n, nranks, fb in ((101, 1, 8), (2, 1, 8), (8192, 1, 8), (64, 3, 8), (100, 2, 8), (100, 1, 4), (4096, 1, 4)):
+        cfg = lib.Config(n=n, rank=0, nranks=nranks, device=0, field_bytes=fb, flags=0)
         assert L.pf_create(C.byref(h), C.byref(cfg)) != 0
         assert not h.value
+        assert b"no HIP device" not in L.pf_last_error()
     cfg = lib.Config(n=64, rank=0, nranks=1, device=0, field_bytes=2, flags=0)
     assert L.pf_create(C.byref(h), C.byref(cfg)) != 0
     if not torch.cuda.is_available():

@@ -361,3 +361,28 @@ def test_ell_sng_restatement_vs_scipy():
             assert abs(got - want) <= 3e-4 * max(want, 1e-30) if want > 0 else got == 0.0, (cosmo, l, got, want)
             f = L.orc_ell_sng_F(l[0], l[1], l[2], din, cosmo.ctypes.data_as(dp))
             assert f == (1.0 / got if got > 0 else 0.0)
+
+
+@pytest.mark.parametrize("n", [12, 20])
+def test_grid_sizes_that_are_not_a_power_of_two(n):
+    """the oracle on 2^a 3^b 5^c sizes (plain O(n^2) transforms) against numpy/pocketfft: Hessians, sweep, displacements"""
+    rng = np.random.default_rng(n)
+    dk = np.fft.rfftn(rng.standard_normal((n, n, n)), axes=(0, 1, 2))
+    x, y = synth.invgrow_table("lcdm")
+    g = synth.growth_multipliers()
+    o = oracle_lib.Oracle(n, 2)
+    o.set_density(dk); o.set_invgrow(x, y); o.set_growth(g)
+    for a, b in zip(o.second_derivatives(1.3), npr.hessian(dk, 1.3)):
+        assert np.max(np.abs(a - b)) <= 1e-13 * np.max(np.abs(b))
+    radii = np.array([1.5, 0.0])
+    tv = o.compute_fmax(radii, do_lpt=True)
+    p = o.products()
+    f, r, tvn, hes = npr.sweep(dk, radii, npr.Spline(x, y))
+    assert np.allclose(tv, tvn, rtol=1e-12)
+    ulp = np.spacing(np.maximum(np.abs(f), 1.0).astype(np.float32)).astype(np.float64)
+    assert np.all(np.abs(p["Fmax"].astype(np.float64) - f) <= 2 * ulp) and np.mean(p["Rmax"] != r) < 1e-3
+    d = npr.lpt(dk, hes, g)
+    for name in ("Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+        assert np.max(np.abs(p[name].astype(np.float64) - d[name])) <= 4e-7 * np.max(np.abs(d[name]))
+    with pytest.raises(ValueError):
+        oracle_lib.Oracle(15, 1)
