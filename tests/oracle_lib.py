@@ -98,6 +98,8 @@ class Oracle:
     def __init__(self, n: int, nthreads: int = 0):
         self.L = lib()
         self.n = n
+        if nthreads <= 0:  # the slab loops have n iterations: more threads than n/4 only add fork/join cost (256-thread hosts)
+            nthreads = max(1, min(os.cpu_count() or 1, n // 4))
         self.h = self.L.orc_create(n, nthreads)
         if not self.h:
             raise ValueError("orc_create failed (n must be even and >= 4)")
