@@ -68,6 +68,9 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
     const long long row = i / p.n;
     const long long a = row * p.pitch + (i - row * p.n);
     double d[6] = {(double)h0[a], (double)h1[a], (double)h2[a], (double)h3[a], (double)h4[a], (double)h5[a]};
+    // products[].Fmax is float, compared after promotion (quirk Q2); init -10 / -1 at ismooth 0.  Loaded here, with the
+    // Hessian, so that its latency hides under the solve instead of sitting between the solve and the store.
+    const float fold = p.ismooth ? p.fmax[i] : -10.0f;
     const double delta = d[0] + d[1] + d[2];
     sum += delta;
     sum2 += delta * delta;
@@ -75,8 +78,6 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
     // TABULATED_CT: the same eigenvalues, then the table instead of ell() (src/collapse_times.c:749)
     const double Fnew = TAB ? (pf_ordered_eigenvalues<FAST>(d, lam) ? pf_interpolate_collapse_time(tv, lam[0], lam[1], lam[2]) : -10.0)
                             : pf_inverse_collapse_time<FAST>(d, sv, lam);
-    // products[].Fmax is float, compared after promotion (quirk Q2); init -10 / -1 at ismooth 0
-    const float fold = p.ismooth ? p.fmax[i] : -10.0f;
     if ((double)fold < Fnew) {
       p.fmax[i] = (float)Fnew;
       p.rmax[i] = p.ismooth;

@@ -288,3 +288,43 @@ def test_snapshot_blocks_and_selection_on_slabs(api):
         sel = np.flatnonzero(fm >= np.float32(1.0))
         order = sel[np.lexsort((sel, -fm[sel].astype(np.float64)))]
         assert len(idx) > 0 and np.array_equal(idx, order.astype(np.uint32)) and np.array_equal(fs, fm[order])
+
+
+def test_build_options_on_slabs(api):
+    """SCALE_DEPENDENT growth tables (k_apply_growth needs the slab's global ky), per-radius splines, and the
+    TABULATED_CT table (built by every rank for itself) on P ranks: bitwise the single-rank products"""
+    n, P = 32, 4
+    nxl = n // P
+    dk = synth.make_density(n, seed=19)
+    radii = np.array([2.0, 1.0, 0.0])
+    splines = [synth.invgrow_table("lcdm", omega0=om) for om in (0.25, 0.30, 0.35)]
+    g = synth.growth_multipliers()
+    j = np.arange(10)
+    tabs = [np.log10(abs(g[o]) * (1.0 + 0.04 * (o + 1) * j)) for o in range(4)]
+    signs = [1.0, 1.0, -1.0, 1.0]
+    var = np.array([0.9, 1.8, 6.0])
+
+    def run(f, sl):
+        f.set_density(dk[sl])
+        for i, (x, y) in enumerate(splines):
+            f.set_invgrow(x, y, ismooth=i)
+        for o in range(4):
+            f.set_growth_table(o + 1, tabs[o], sign=signs[o])
+        f.compute_fmax(radii, do_lpt=True)
+        a = f.products()
+        f.set_tabulated_ct(var)
+        f.sweep(radii)
+        b = f.products()
+        f.set_tabulated_ct([])
+        return a, b
+
+    with api.Fmax(n) as f1:
+        a1, b1 = run(f1, slice(0, n))
+    res = run_ranks(api, n, P, lambda f, r: run(f, slice(r * nxl, (r + 1) * nxl)))
+    assert np.mean(a1["Fmax"] != b1["Fmax"]) > 0.3          # the table really replaced the direct solve
+    for r in range(P):
+        sl = slice(r * nxl, (r + 1) * nxl)
+        a, b = res[r]
+        for name in ("Fmax", "Rmax", "Vel", "Vel_2LPT", "Vel_3LPT_1"):
+            assert np.array_equal(a[name], a1[name][sl]), name
+        assert np.array_equal(b["Fmax"], b1["Fmax"][sl]) and np.array_equal(b["Rmax"], b1["Rmax"][sl])
