@@ -94,6 +94,7 @@ struct pf_ctx {
   void *recvA2;
   hipEvent_t ev_x[2], ev_r[2];
   void *tw;
+  double *etab;        // [n] window of the transformed axis for the x-pass in flight (pf_launch_exp_table)
   float *fmax, *vel12;
   int *rmax;
   double *partials;    // 2 * PF_NBLK
@@ -296,6 +297,7 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   PFCHK(c, dev_alloc(c, (void **)&c->hist, PF_NBINS * sizeof(unsigned long long)));
   PFCHK(c, dev_alloc(c, (void **)&c->spl, (size_t)(PF_MAX_SMOOTH + 1) * 5 * PF_KNOT_CAP * sizeof(double)));
   PFCHK(c, dev_alloc(c, (void **)&c->gtab, 4 * PF_KBIN_CAP * sizeof(double)));
+  PFCHK(c, dev_alloc(c, (void **)&c->etab, (size_t)c->n * sizeof(double)));
   memset(c->gt_n, 0, sizeof(c->gt_n));
   c->tab_ns = 0; c->tab_ready = false; c->tab_ismooth = -1; c->ct_block = nullptr; c->model = 0; c->sng_ns = 0; memset(&c->ct, 0, sizeof(c->ct));
   HIPCHK(c, hipMemsetAsync(c->scal, 0, SC_COUNT * sizeof(double), c->stream));
@@ -324,7 +326,7 @@ extern "C" int pf_destroy(pf_ctx *c) {
   hipFree(c->dk); hipFree(c->blockA); hipFree(c->recvA); hipFree(c->tw); hipFree(c->blockA2); hipFree(c->recvA2);
   for (int i = 0; i < 6; i++) { hipFree(c->B[i]); hipFree(c->B2[i]); }
   for (int i = 0; i < 3; i++) hipFree(c->S[i]);
-  hipFree(c->fmax); hipFree(c->rmax); hipFree(c->vel12); hipFree(c->partials); hipFree(c->scal); hipFree(c->hist); hipFree(c->spl); hipFree(c->gtab); hipFree(c->ct_block); hipFree(c->W);
+  hipFree(c->fmax); hipFree(c->rmax); hipFree(c->vel12); hipFree(c->partials); hipFree(c->scal); hipFree(c->hist); hipFree(c->spl); hipFree(c->gtab); hipFree(c->etab); hipFree(c->ct_block); hipFree(c->W);
   pf_gfft_destroy(c->fft_c2r); pf_gfft_destroy(c->fft_r2c);
   for (auto &e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   for (auto &e : c->phase_evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -396,6 +398,8 @@ static int xpass(pf_ctx *c, int kind, int dir, int njobs, const Job *jobs, int p
   for (int j = 0; j < njobs; j++) { p.job[j].in = jobs[j].in; p.job[j].out = jobs[j].out; p.job[j].mul = jobs[j].mul; }
   p.ain = p.aout = addr_ky_x(c);
   p.ncols = c->nzh; p.nouter = c->nyl; p.pre = pre; p.outer_offset = c->rank * c->nyl; p.rs = rs; p.growth = growth; p.tw = c->tw;
+  p.etab = c->etab;
+  if (pre && rs != 0.0) PFCHK(c, pf_launch_exp_table(c->etab, c->n, rs, c->stream));  // stream order: after the previous x-pass
   p.band_e = p.band_outer = c->n;
   double frac_cols = 1.0, frac_in = 1.0, frac_outer = 1.0;
   if (band < c->n / 2) {  // pruned: in-band columns (kz, ky) only, in-band x read, all x written

@@ -76,12 +76,15 @@ __global__ void __launch_bounds__(T *N / 8) __attribute__((amdgpu_waves_per_eu(4
         if (so > N / 2) so -= N;
         const double ko = kf * so, kc = kf * colj;
         const double ko2kc2 = ko * ko + kc * kc;
+        // window of the two untransformed axes times the growth factor: one exp per thread (none without smoothing)
+        const double woc = (p.rs != 0.0 ? exp(-0.5 * ko2kc2 * p.rs * p.rs) : 1.0) * p.growth;
 #pragma unroll
         for (int m = 0; m < 8; m++) {
           const int e = tlj + m * NT;
           const double ke = kf * (e > N / 2 ? e - N : e);
           const double k2 = ke * ke + ko2kc2;
-          const double fac = (k2 != 0.0) ? exp(-0.5 * k2 * p.rs * p.rs) * p.growth / k2 : 0.0;
+          const double we = p.rs != 0.0 ? p.etab[e] : 1.0;
+          const double fac = (k2 != 0.0) ? we * woc / k2 : 0.0;
           src[m] = pf_scale(src[m], (F)fac);
         }
       }
@@ -283,6 +286,18 @@ __global__ void __launch_bounds__(TL *(N / 16)) k_r2c(const PfR2CParams p) {
       if (k == 0) out[M] = pf_mk<F>(zk.x - zk.y, (F)0);
     }
   }
+}
+
+// etab[e] = exp(-k_e^2 rs^2 / 2), k_e = 2 pi s(e) / n, s(e) the signed wavenumber of index e
+__global__ void k_exp_table(double *etab, int n, double rs) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const double ke = 2.0 * 3.14159265358979323846 / (double)n * (e > n / 2 ? e - n : e);
+  etab[e] = exp(-0.5 * ke * ke * rs * rs);
+}
+int pf_launch_exp_table(double *etab, int n, double rs, hipStream_t st) {
+  hipLaunchKernelGGL(k_exp_table, dim3((n + 255) / 256), dim3(256), 0, st, etab, n, rs);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 // ------------------------------------------------------------ dispatch ----

@@ -36,6 +36,9 @@ struct PfStridedParams {
   int pre;           // 1: multiply by exp(-k^2 rs^2/2) * growth / k^2 (0 at k = 0) on load
   int outer_offset;  // global index of outer = 0 (k-space y-slab start)
   double rs, growth;
+  // pre: the Gaussian window is separable, exp(-k^2 rs^2/2) = E(k_e) * exp(-(k_o^2 + k_c^2) rs^2/2): etab[e] = E of the
+  // transformed axis (n doubles, pf_launch_exp_table) leaves one exp per thread instead of eight; rs == 0 needs none
+  const double *etab;
   const void *tw;    // exp(+2 pi i j / n), n entries of complex F
   // pruned transform of a band-limited (Gaussian-smoothed) spectrum: wavenumbers |s| > band carry a
   // weight below 2^-60 and are treated as exact zeros.  band_e masks the loads along the transformed
@@ -45,6 +48,7 @@ struct PfStridedParams {
 
 // one x- or y-pass: for every job, out = FFT_e[ in * pre * mul ]  (dir = +1 inverse, -1 forward)
 int pf_launch_strided(int field_bytes, int n, int dir, const PfStridedParams &p, hipStream_t st);
+int pf_launch_exp_table(double *etab, int n, double rs, hipStream_t st);
 
 struct PfC2RJob {
   const void *in;   // complex rows
