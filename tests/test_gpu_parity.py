@@ -808,3 +808,28 @@ def test_reference_example_size_200(api):
         assert np.max(np.abs(h[0] + h[1] + h[2] - back)) < 1e-10 * np.max(np.abs(back))   # Laplacian identity
         p = f.products()
         assert (p["Fmax"] >= 1.0).mean() > 0.2 and np.isfinite(p["Vel"]).all() and p["Vel_2LPT"].any()
+
+
+def test_contexts_release_their_memory(api):
+    """create / run / destroy in a loop, both transform paths, with every lazily allocated piece in use: the device
+    memory in use returns to where it started (no leak across the reference's finalize_fft / compute_fft_plans cycles)"""
+    import torch
+    x, y = synth.invgrow_table("lcdm")
+
+    def cycle(n):
+        with api.Fmax(n) as f:
+            f.synth_density(synth.SEED, 2.5, -2.0)
+            f.set_invgrow(x, y)
+            f.set_tabulated_ct([1.0, 2.0])
+            f.compute_fmax(np.array([1.0, 0.0]), do_lpt=True)
+            f.select_sorted(1.0)
+            f.products()
+
+    cycle(64); cycle(48)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(10):
+        cycle(64); cycle(48)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert abs(free1 - free0) < 64 * 2 ** 20, (free0, free1)
