@@ -160,6 +160,11 @@ int pf_set_tabulated_ct(pf_ctx *ctx, int nsmooth, const double *variance);
    (250 000 integrations per radius on the device; per cell it would be ~10^9 of them): pf_sweep fails without
    pf_set_tabulated_ct.  Standard gravity only (no MOD_GRAV_FR force modification). */
 int pf_set_collapse_model(pf_ctx *ctx, int model, const double cosmo[4], int nsmooth, const double *D_in);
+/* -DMOD_GRAV_FR on top of ELL_SNG: the force in the velocity equations is enhanced by 1 + ForceModification(size, a, delta)
+   (src/collapse_times.c:271-273, 295-312), Hu-Sawicki f(R) with |f_R0| = fr0 (the FR0 of the build; 0 switches it off),
+   h_over_c = 100 / c[km/s] (src/cosmo.c:109), size[ismooth] = the ODE parameter of that radius: Smoothing.Radius[ismooth],
+   and Smoothing.Radius[ismooth-1] for the last one (:378-388). */
+int pf_set_modified_gravity(pf_ctx *ctx, double fr0, double h_over_c, int nsmooth, const double *size);
 int pf_ct_build(pf_ctx *ctx, int ismooth, double variance, double *table_host);
 int pf_ct_load(pf_ctx *ctx, int ismooth, double variance, const double *table_host);
 

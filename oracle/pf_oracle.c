@@ -64,7 +64,7 @@ struct orc_ctx {
   /* TABULATED_CT build (src/collapse_times.c:780-1231, BILINEAR_SPLINE flavour :40): per radius a table of ell() on
      a (delta, x, y) grid and one natural cubic spline in delta per (x, y) node */
   int model;                      /* 0 ELL_CLASSIC, 1 ELL_SNG (oracle/pf_sng.c) */
-  double sng_cosmo[4], sng_Din[ORC_MAX_SMOOTH];
+  double sng_cosmo[7], sng_Din[ORC_MAX_SMOOTH], sng_size[ORC_MAX_SMOOTH];
   int cur_ismooth;
   int tab_ns;
   double tab_var[ORC_MAX_SMOOTH]; /* Smoothing.Variance[] */
@@ -525,7 +525,12 @@ double orc_ell_classic(double l1, double l2, double l3) {
 
 /* collapse_times.c:404-415 (ELL_CLASSIC) */
 static double ell_fn(orc_ctx *c, double l1, double l2, double l3) {
-  if (c->model == 1) return orc_ell_sng_F(l1, l2, l3, c->sng_Din[c->cur_ismooth], c->sng_cosmo); /* #ifdef ELL_SNG, :416 */
+  if (c->model == 1) { /* #ifdef ELL_SNG, :416 */
+    double cosmo[7];
+    memcpy(cosmo, c->sng_cosmo, sizeof(cosmo));
+    cosmo[6] = c->sng_size[c->cur_ismooth];
+    return orc_ell_sng_F(l1, l2, l3, c->sng_Din[c->cur_ismooth], cosmo);
+  }
   double bc = orc_ell_classic(l1, l2, l3);
   if (bc > 0.0) return 1. + orc_inverse_growing_mode(c, bc);
   else return 0.0;
@@ -933,6 +938,12 @@ int orc_set_collapse_model(orc_ctx *c, int model, const double cosmo[4], int ns,
     memcpy(c->sng_cosmo, cosmo, sizeof(double) * 4);
     memcpy(c->sng_Din, D_in, sizeof(double) * ns);
   }
+  return 0;
+}
+int orc_set_modified_gravity(orc_ctx *c, double fr0, double h_over_c, int ns, const double *size) {
+  if (ns < 0 || ns > ORC_MAX_SMOOTH) return 1;
+  c->sng_cosmo[4] = fr0; c->sng_cosmo[5] = h_over_c;
+  if (ns) memcpy(c->sng_size, size, sizeof(double) * ns);
   return 0;
 }
 int orc_set_tabulated_ct(orc_ctx *c, int ns, const double *variance) {

@@ -107,11 +107,15 @@ const double *orc_ct_delta(orc_ctx *c);
 double orc_interpolate_collapse_time(orc_ctx *c, double l1, double l2, double l3);
 
 /* ELL_SNG collapse model (oracle/pf_sng.c; src/collapse_times.c:222-400): scale factor of collapse of the ellipsoid
-   (0: none, -1: integrator failure) and the F = 1/b_c of ell().  cosmo = {Omega0, OmegaLambda, OmegaRad, OmegaK};
+   (0: none, -1: integrator failure) and the F = 1/b_c of ell().  cosmo = {Omega0, OmegaLambda, OmegaRad, OmegaK,
+   FR0, H_over_c, size}: the last three are the MOD_GRAV_FR force modification (src/collapse_times.c:295-312), FR0 = 0
+   is standard gravity; orc_set_collapse_model takes the first four, orc_set_modified_gravity the rest (size per radius:
+   Smoothing.Radius[ismooth], the previous radius for the last one, :378-388);
    D_in = GrowingMode(z(a = 1e-5), k of the radius).  orc_set_collapse_model(1, ...) makes ell() use it (the table of a
    TABULATED_CT build is then filled with it); model 0 = ELL_CLASSIC. */
-double orc_ell_sng(double l1, double l2, double l3, double D_in, const double cosmo[4]);
-double orc_ell_sng_F(double l1, double l2, double l3, double D_in, const double cosmo[4]);
+double orc_ell_sng(double l1, double l2, double l3, double D_in, const double cosmo[7]);
+double orc_ell_sng_F(double l1, double l2, double l3, double D_in, const double cosmo[7]);
+int orc_set_modified_gravity(orc_ctx *c, double fr0, double h_over_c, int ns, const double *size);
 int orc_set_collapse_model(orc_ctx *c, int model, const double cosmo[4], int ns, const double *D_in);
 
 /* Fmax >= flast (src/distribute.c:695), indices by descending Fmax (src/fragment.c:484-503, 118-126; ties by index).

@@ -32,7 +32,22 @@ static double OmegaLambda(const double *cosmo, double z) {
   return cosmo[1] / (Ezv * Ezv);
 }
 
-/* sng_system, src/collapse_times.c:241-293 (standard gravity) */
+/* ForceModification, src/collapse_times.c:295-312 (MOD_GRAV_FR): Hu-Sawicki f(R) with |f_R0| = cosmo[4] (the FR0 of the
+   build), H_over_c = cosmo[5] (100 / c, src/cosmo.c:109), size = cosmo[6] (the smoothing radius handed to the ODE as
+   its parameter, :378-388) */
+static double ForceModification(const double *cosmo, double size, double a, double delta) {
+  const double FR0 = cosmo[4], H_over_c = cosmo[5];
+  double ff = 4. * cosmo[1] / cosmo[0];
+  double thickness = FR0 / cosmo[0] / pow(H_over_c * size, 2.0) *
+                     pow(a, 7.) * pow((1. + delta), -1. / 3.) *
+                     (pow((1.0 + ff) / (1.0 + ff * pow(a, 3.)), 2.0) -
+                      pow((1.0 + ff) / (1.0 + delta + ff * pow(a, 3.)), 2.0));
+  double F3 = (thickness * (3. + thickness * (-3. + thickness)));
+  if (F3 < 0.) F3 = 0.;
+  return (F3 < 1. ? F3 / 3. : 1. / 3);
+}
+
+/* sng_system, src/collapse_times.c:241-293; cosmo[4] != 0 selects the MOD_GRAV_FR branch (:271-273) */
 static int sng_system(double t, const double y[], double f[], const double *cosmo) {
   int i, j;
   double sum;
@@ -51,9 +66,14 @@ static int sng_system(double t, const double y[], double f[], const double *cosm
       }
     }
     f[i] = (y[i + 3] * (y[i] - 1.0)) / t;
-    f[i + 3] = (0.5 * (y[i + 3] * (omegam - 2.0 * omegal - 2.0)
-                       - 3.0 * omegam * y[i + 6]
-                       - 2.0 * y[i + 3] * y[i + 3])) / t;
+    if (cosmo[4] != 0.0)
+      f[i + 3] = (0.5 * (y[i + 3] * (omegam - 2.0 * omegal - 2.0)
+                         - 3.0 * omegam * y[i + 6] * (1. + ForceModification(cosmo, cosmo[6], t, delta))
+                         - 2.0 * y[i + 3] * y[i + 3])) / t;
+    else
+      f[i + 3] = (0.5 * (y[i + 3] * (omegam - 2.0 * omegal - 2.0)
+                         - 3.0 * omegam * y[i + 6]
+                         - 2.0 * y[i + 3] * y[i + 3])) / t;
     f[i + 6] = ((5. / 6. + y[i + 6]) *
                 ((3. + y[3] + y[4] + y[5]) - (1. + delta) / (2.5 + delta) * (y[3] + y[4] + y[5])) -
                 (2.5 + delta) * (1. + y[i + 3]) + sum) / t;
@@ -167,7 +187,7 @@ static int evolve_apply(evolve_state *e, double *t, double t1, double *h, double
 
 /* ell_sng, src/collapse_times.c:319-400.  D_in = GrowingMode(1/amin - 1, k of this radius), supplied by the caller.
    olda / oldlam are set once before the loop and never updated (kept as in the reference). */
-double orc_ell_sng(double l1, double l2, double l3, double D_in, const double cosmo[4]) {
+double orc_ell_sng(double l1, double l2, double l3, double D_in, const double cosmo[7]) {
   double hh = 1.e-6;
   double amin = 1.e-5, amax = 5.0;
   double mya = amin;
@@ -187,7 +207,7 @@ double orc_ell_sng(double l1, double l2, double l3, double D_in, const double co
 }
 
 /* ell(), ELL_SNG branch (src/collapse_times.c:416-426) */
-double orc_ell_sng_F(double l1, double l2, double l3, double D_in, const double cosmo[4]) {
+double orc_ell_sng_F(double l1, double l2, double l3, double D_in, const double cosmo[7]) {
   double bc = orc_ell_sng(l1, l2, l3, D_in, cosmo);
   if (bc > 0.0) return 1. / bc;
   return 0.0;

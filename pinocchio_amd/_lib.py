@@ -79,6 +79,7 @@ PROTOTYPES = {
     "pf_select_sorted": (C.c_int, [_vp, C.c_float, C.c_size_t, C.POINTER(C.c_uint), C.POINTER(C.c_float), C.POINTER(C.c_size_t)]),
     "pf_get_block": (C.c_int, [_vp, C.c_char_p, C.c_int, _vp]),
     "pf_set_collapse_model": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double)]),
+    "pf_set_modified_gravity": (C.c_int, [_vp, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double)]),
     "pf_set_tabulated_ct": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double)]),
     "pf_ct_build": (C.c_int, [_vp, C.c_int, C.c_double, C.POINTER(C.c_double)]),
     "pf_ct_load": (C.c_int, [_vp, C.c_int, C.c_double, C.POINTER(C.c_double)]),

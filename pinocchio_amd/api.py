@@ -115,6 +115,11 @@ class Fmax:
         self._chk(self.L.pf_set_collapse_model(self.h, model, _dp(cs) if cs is not None else None, len(di) if di is not None else 0,
                                                _dp(di) if di is not None else None))
 
+    def set_modified_gravity(self, fr0: float, h_over_c: float = 100.0 / 299792.458, size=None):
+        """MOD_GRAV_FR force modification inside the ELL_SNG system (src/collapse_times.c:295-312); fr0 = 0: off"""
+        sz = np.ascontiguousarray(size, dtype=np.float64) if size is not None else None
+        self._chk(self.L.pf_set_modified_gravity(self.h, fr0, h_over_c, len(sz) if sz is not None else 0, _dp(sz) if sz is not None else None))
+
     def set_tabulated_ct(self, variance):
         """TABULATED_CT build: Smoothing.Variance[] per radius ([] = direct solve), src/collapse_times.c:780-1231"""
         v = np.ascontiguousarray(variance, dtype=np.float64)

@@ -114,7 +114,7 @@ struct pf_ctx {
   bool tab_ready;
   int tab_ismooth;
   int model;           // 0 ELL_CLASSIC, 1 ELL_SNG (only through the collapse-time table)
-  double sng_cosmo[4], sng_Din[PF_MAX_SMOOTH];
+  double sng_cosmo[7], sng_Din[PF_MAX_SMOOTH], sng_size[PF_MAX_SMOOTH];
   int sng_ns;
   PfCtDev ct;
   double *ct_block;    // delta | alpha | gamma | y | b | c | d
@@ -299,7 +299,7 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   PFCHK(c, dev_alloc(c, (void **)&c->gtab, 4 * PF_KBIN_CAP * sizeof(double)));
   PFCHK(c, dev_alloc(c, (void **)&c->etab, (size_t)c->n * sizeof(double)));
   memset(c->gt_n, 0, sizeof(c->gt_n));
-  c->tab_ns = 0; c->tab_ready = false; c->tab_ismooth = -1; c->ct_block = nullptr; c->model = 0; c->sng_ns = 0; memset(&c->ct, 0, sizeof(c->ct));
+  c->tab_ns = 0; c->tab_ready = false; c->tab_ismooth = -1; c->ct_block = nullptr; c->model = 0; c->sng_ns = 0; memset(c->sng_cosmo, 0, sizeof(c->sng_cosmo)); memset(c->sng_size, 0, sizeof(c->sng_size)); memset(&c->ct, 0, sizeof(c->ct));
   HIPCHK(c, hipMemsetAsync(c->scal, 0, SC_COUNT * sizeof(double), c->stream));
   // twiddles exp(+2 pi i j / n), computed in long double on the host
   {
@@ -832,6 +832,7 @@ static int ct_build(pf_ctx *c, int ismooth, double variance, const double *table
   if (c->model == 1 && !table_host) {
     if (ismooth >= c->sng_ns) return pf_fail(c->rank, "collapse-time table: no ELL_SNG growth factor for radius %d (pf_set_collapse_model)", ismooth);
     memcpy(c->ct.sng_cosmo, c->sng_cosmo, sizeof(c->sng_cosmo));
+    c->ct.sng_cosmo[6] = c->sng_size[ismooth];
     c->ct.sng_Din = c->sng_Din[ismooth];
   }
   PfSplineDev sp; memset(&sp, 0, sizeof(sp));
@@ -854,6 +855,15 @@ extern "C" int pf_set_collapse_model(pf_ctx *c, int model, const double cosmo[4]
     c->sng_ns = nsmooth;
   }
   c->model = model; c->tab_ready = false;
+  return 0;
+}
+extern "C" int pf_set_modified_gravity(pf_ctx *c, double fr0, double h_over_c, int nsmooth, const double *size) {
+  if (!c) return 1;
+  if (nsmooth < 0 || nsmooth > PF_MAX_SMOOTH || (fr0 != 0.0 && (!size || nsmooth < 1 || !(h_over_c > 0.0))))
+    return pf_fail(c->rank, "pf_set_modified_gravity: f(R) needs H_over_c and the smoothing radius of every table");
+  c->sng_cosmo[4] = fr0; c->sng_cosmo[5] = h_over_c;
+  if (nsmooth && size) memcpy(c->sng_size, size, nsmooth * sizeof(double));
+  c->tab_ready = false;
   return 0;
 }
 extern "C" int pf_set_tabulated_ct(pf_ctx *c, int nsmooth, const double *variance) {

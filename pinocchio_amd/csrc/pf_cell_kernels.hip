@@ -129,6 +129,7 @@ __global__ void __launch_bounds__(64) k_ct_table_sng(PfCtDev ct) {
   const int total = PF_CT_NBINS_D * PF_CT_NBINS_XY * PF_CT_NBINS_XY;
   pf_sng_cosmo c;
   c.Omega0 = ct.sng_cosmo[0]; c.OmegaLambda = ct.sng_cosmo[1]; c.OmegaRad = ct.sng_cosmo[2]; c.OmegaK = ct.sng_cosmo[3];
+  c.FR0 = ct.sng_cosmo[4]; c.H_over_c = ct.sng_cosmo[5]; c.size = ct.sng_cosmo[6];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int id = i % PF_CT_NBINS_D;
     const int ix = (i / PF_CT_NBINS_D) % PF_CT_NBINS_XY;

@@ -25,7 +25,20 @@
 
 struct pf_sng_cosmo {
   double Omega0, OmegaLambda, OmegaRad, OmegaK;  // Hubble(z), src/cosmo.c:1691-1711 with params.simpleLambda
+  // MOD_GRAV_FR (src/collapse_times.c:295-312): |f_R0| of the build (0 = standard gravity), 100 / c (src/cosmo.c:109)
+  // and the smoothing radius the reference hands to the ODE system as its parameter (:378-388)
+  double FR0 = 0.0, H_over_c = 0.0, size = 0.0;
 };
+
+// ForceModification (src/collapse_times.c:295-312): Hu-Sawicki f(R) thin-shell enhancement of the force, in [0, 1/3]
+PF_HD double pf_sng_force_modification(const pf_sng_cosmo &c, double a, double delta) {
+  const double ff = 4. * c.OmegaLambda / c.Omega0;
+  const double thickness = c.FR0 / c.Omega0 / pow(c.H_over_c * c.size, 2.0) * pow(a, 7.) * pow((1. + delta), -1. / 3.) *
+                           (pow((1.0 + ff) / (1.0 + ff * pow(a, 3.)), 2.0) - pow((1.0 + ff) / (1.0 + delta + ff * pow(a, 3.)), 2.0));
+  double F3 = (thickness * (3. + thickness * (-3. + thickness)));
+  if (F3 < 0.) F3 = 0.;
+  return (F3 < 1. ? F3 / 3. : 1. / 3);
+}
 
 PF_HD double pf_sng_Esq(const pf_sng_cosmo &c, double z) {
   return c.OmegaRad * pow(1. + z, 4.) + c.Omega0 * pow(1. + z, 3.) + c.OmegaK * pow(1. + z, 2.) + c.OmegaLambda;
@@ -51,7 +64,11 @@ PF_HD void pf_sng_system(double t, const double y[9], double f[9], const pf_sng_
              ((1. - y[i]) * (1. - y[i]) - (1. - y[j]) * (1. - y[j]));
     }
     f[i] = (y[i + 3] * (y[i] - 1.0)) / t;
-    f[i + 3] = (0.5 * (y[i + 3] * (omegam - 2.0 * omegal - 2.0) - 3.0 * omegam * y[i + 6] - 2.0 * y[i + 3] * y[i + 3])) / t;
+    if (c.FR0 != 0.0)
+      f[i + 3] = (0.5 * (y[i + 3] * (omegam - 2.0 * omegal - 2.0) - 3.0 * omegam * y[i + 6] * (1. + pf_sng_force_modification(c, t, delta)) -
+                         2.0 * y[i + 3] * y[i + 3])) / t;
+    else
+      f[i + 3] = (0.5 * (y[i + 3] * (omegam - 2.0 * omegal - 2.0) - 3.0 * omegam * y[i + 6] - 2.0 * y[i + 3] * y[i + 3])) / t;
     f[i + 6] = ((5. / 6. + y[i + 6]) * ((3. + y[3] + y[4] + y[5]) - (1. + delta) / (2.5 + delta) * (y[3] + y[4] + y[5])) -
                 (2.5 + delta) * (1. + y[i + 3]) + sum) / t;
   }

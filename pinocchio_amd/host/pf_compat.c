@@ -90,6 +90,18 @@
 #define PF_ELL_SNG pf_compat_ell_sng
 #define PF_HUBBLE(z) pf_Hubble(z)
 #endif
+/* -DMOD_GRAV_FR -DFR0=...: the f(R) force modification inside the ELL_SNG system (src/collapse_times.c:295-312) */
+#if defined(PF_IN_PINOCCHIO_TREE)
+#ifdef MOD_GRAV_FR
+#define PF_FR0 ((double)FR0)
+#else
+#define PF_FR0 0.0
+#endif
+#define PF_H_OVER_C H_over_c
+#else
+#define PF_FR0 pf_compat_fr0
+#define PF_H_OVER_C (100. / 299792.458) /* src/cosmo.c:109 with SPEEDOFLIGHT in km/s */
+#endif
 #if !defined(PF_IN_PINOCCHIO_TREE) || defined(TABULATED_CT)
 #define PF_HAVE_CT 1
 int initialize_collapse_times(int ismooth, int onlycompute);
@@ -249,6 +261,12 @@ static int pf_upload_collapse_model(void) {
   if (fabs(cosmo[3]) < 1e-12) cosmo[3] = 0.0;
   for (ismooth = 0; ismooth < Smoothing.Nsmooth; ismooth++) /* GrowingMode(1/amin - 1, 1/Radius), :353-361 */
     D_in[ismooth] = PF_GM_K(1. / 1.e-5 - 1., 1. / Smoothing.Radius[ismooth]);
+  if (PF_FR0 != 0.0) { /* ode_param: the radius itself, the previous one for the last radius (:378-388) */
+    double size[64];
+    for (ismooth = 0; ismooth < Smoothing.Nsmooth; ismooth++)
+      size[ismooth] = Smoothing.Radius[ismooth < Smoothing.Nsmooth - 1 ? ismooth : (ismooth > 0 ? ismooth - 1 : 0)];
+    if (pf_set_modified_gravity(pf_context, PF_FR0, PF_H_OVER_C, Smoothing.Nsmooth, size)) return 1;
+  } else if (pf_set_modified_gravity(pf_context, 0.0, 0.0, 0, NULL)) return 1;
   return pf_set_collapse_model(pf_context, 1, cosmo, Smoothing.Nsmooth, D_in);
 }
 
@@ -634,7 +652,8 @@ static int check_CTtable_header(void) { /* :1235-1296, ELL_CLASSIC */
   double fdummy = 0;
   if (fread(&dummy, sizeof(int), 1, CTtableFilePointer) != 1) return 1;
   if (!PF_ELL_SNG && dummy != 1) { printf("ERROR: CT table not constructed for ELL_CLASSIC, %d\n", dummy); fail = 1; }
-  if (PF_ELL_SNG && dummy != 3) { printf("ERROR: CT table not constructed for ELL_SNG and standard gravity, %d\n", dummy); fail = 1; }
+  if (PF_ELL_SNG && PF_FR0 == 0.0 && dummy != 3) { printf("ERROR: CT table not constructed for ELL_SNG and standard gravity, %d\n", dummy); fail = 1; }
+  if (PF_ELL_SNG && PF_FR0 != 0.0 && dummy != 4) { printf("ERROR: CT table not constructed for ELL_SNG and MOD_GRAV_FR, %d\n", dummy); fail = 1; }
   if (fread(&fdummy, sizeof(double), 1, CTtableFilePointer) != 1) return 1;
   if (fabs(fdummy - params.Omega0) > 1.e-10) { printf("ERROR: CT table constructed for the wrong Omega0, %f in place of %f\n", fdummy, params.Omega0); fail = 1; }
   if (fread(&fdummy, sizeof(double), 1, CTtableFilePointer) != 1) return 1;
@@ -650,7 +669,7 @@ static int check_CTtable_header(void) { /* :1235-1296, ELL_CLASSIC */
   return fail;
 }
 static void write_CTtable_header(void) { /* :1300-1340 */
-  int dummy = PF_ELL_SNG ? 3 : 1;
+  int dummy = PF_ELL_SNG ? (PF_FR0 != 0.0 ? 4 : 3) : 1;
   fwrite(&dummy, sizeof(int), 1, CTtableFilePointer);
   fwrite(&params.Omega0, sizeof(double), 1, CTtableFilePointer);
   fwrite(&params.OmegaLambda, sizeof(double), 1, CTtableFilePointer);

@@ -30,3 +30,4 @@ double **rvector_fft = rvector_slots;
 int pf_compat_tabulated_ct = 0;
 int pf_compat_ell_sng = 0;
 double (*pf_Hubble)(double) = 0;
+double pf_compat_fr0 = 0.0;

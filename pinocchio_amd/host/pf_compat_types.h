@@ -112,6 +112,7 @@ extern int pf_compat_tabulated_ct;
 /* non-zero: behave like a -DELL_SNG build (src/collapse_times.c:222-400); Hubble(z) in km/s/Mpc as src/cosmo.c:1691 */
 extern int pf_compat_ell_sng;
 extern double (*pf_Hubble)(double z);
+extern double pf_compat_fr0; /* non-zero: -DMOD_GRAV_FR with this FR0 */
 extern int pf_compat_scale_dependent;
 extern pf_spline_knots pf_invgrow_knots_radius[64];
 

@@ -50,7 +50,7 @@ extern "C" int emul_ct(const double *table /*[50*50*100]*/, double ampl, const d
 // ELL_SNG model of the device header (pf_sng_core.h)
 #include "../../pinocchio_amd/csrc/pf_sng_core.h"
 extern "C" void emul_ell_sng(const double *lam, long count, double D_in, const double *cosmo, double *bc) {
-  pf_sng_cosmo c{cosmo[0], cosmo[1], cosmo[2], cosmo[3]};
+  pf_sng_cosmo c{cosmo[0], cosmo[1], cosmo[2], cosmo[3], cosmo[4], cosmo[5], cosmo[6]};
   for (long i = 0; i < count; i++) bc[i] = pf_ell_sng(lam[3 * i], lam[3 * i + 1], lam[3 * i + 2], D_in, c);
 }
 

@@ -82,6 +82,7 @@ def lib():
         L.orc_ell_sng_F.restype = C.c_double
         L.orc_ell_sng_F.argtypes = [C.c_double] * 4 + [dp]
         L.orc_set_collapse_model.argtypes = [C.c_void_p, C.c_int, dp, C.c_int, dp]
+        L.orc_set_modified_gravity.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int, dp]
         L.orc_select_sorted.restype = C.c_size_t
         L.orc_select_sorted.argtypes = [C.c_void_p, C.c_float, C.POINTER(C.c_uint), C.POINTER(C.c_float)]
         _lib = L
@@ -167,6 +168,10 @@ class Oracle:
         cosmo = np.ascontiguousarray(cosmo if cosmo is not None else np.zeros(4), dtype=np.float64)
         d_in = np.ascontiguousarray(d_in if d_in is not None else np.zeros(1), dtype=np.float64)
         assert self.L.orc_set_collapse_model(self.h, model, _dp(cosmo), len(d_in), _dp(d_in)) == 0
+
+    def set_modified_gravity(self, fr0, h_over_c=100.0 / 299792.458, size=None):
+        sz = np.ascontiguousarray(size if size is not None else np.zeros(1), dtype=np.float64)
+        assert self.L.orc_set_modified_gravity(self.h, fr0, h_over_c, len(sz), _dp(sz)) == 0
 
     def set_tabulated_ct(self, variance):
         v = np.ascontiguousarray(variance, dtype=np.float64)

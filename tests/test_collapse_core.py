@@ -138,8 +138,10 @@ def test_ell_sng_header_matches_oracle_bitwise(emul):
     lam[:5] = [[1.0, 1.0, 1.0], [0.0, 0.0, 0.0], [2.0, 2.0, -1.0], [-1.0, -1.0, -1.0], [1e-3, 1e-3, 1e-3]]
     L = oracle_lib.lib()
     emul.emul_ell_sng.argtypes = [dp, C.c_long, C.c_double, dp, dp]
-    for cosmo, din in ((np.array([1.0, 0.0, 0.0, 0.0]), 1e-5), (np.array([0.25, 0.75, 0.0, 0.0]), 1.28e-5),
-                       (np.array([0.3, 0.6, 0.0, 0.1]), 1.2e-5)):
+    hoc = 100.0 / 299792.458
+    # Omega0, OmegaLambda, OmegaRad, OmegaK, FR0, H_over_c, size: the last case is MOD_GRAV_FR (|f_R0| = 1e-5, R = 2 Mpc)
+    for cosmo, din in ((np.array([1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]), 1e-5), (np.array([0.25, 0.75, 0.0, 0.0, 0.0, 0.0, 0.0]), 1.28e-5),
+                       (np.array([0.3, 0.6, 0.0, 0.1, 0.0, 0.0, 0.0]), 1.2e-5), (np.array([0.25, 0.75, 0.0, 0.0, 1e-5, hoc, 2.0]), 1.28e-5)):
         got = np.empty(n)
         emul.emul_ell_sng(_dp(lam), n, din, _dp(cosmo), _dp(got))
         want = np.array([L.orc_ell_sng(l[0], l[1], l[2], din, _dp(cosmo)) for l in lam])

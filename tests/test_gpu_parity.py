@@ -658,6 +658,19 @@ def test_ell_sng_table_vs_oracle(api):
     d = np.abs(p["Fmax"].astype(np.float64) - po["Fmax"])
     assert np.mean(d > 1e-4 * np.maximum(1.0, po["Fmax"])) < 1e-3 and np.mean(p["Rmax"] != po["Rmax"]) < 5e-3
     assert (po["Fmax"] >= 1.0).mean() > 0.05
+    # MOD_GRAV_FR on top: the table of one radius with the f(R) force modification switched on
+    o.set_modified_gravity(1e-5, size=[2.0, 2.0])
+    tab_fr_o, _ = o.ct_build(1, var[1])
+    with api.Fmax(n) as f:
+        f.set_invgrow(x, y)
+        f.set_collapse_model(1, cosmo, d_in)
+        f.set_modified_gravity(1e-5, size=[2.0, 2.0])
+        tab_fr = f.ct_build(1, var[1])
+    nz = (tab_fr != 0) & (tab_fr_o != 0)
+    err = np.abs(tab_fr[nz] - tab_fr_o[nz]) / tab_fr_o[nz]
+    assert np.mean(err > 1e-9) < 0.05 and err.max() < 1e-4
+    both = nz & (tab_o != 0)
+    assert np.mean(tab_fr_o[both] >= tab_o[both]) > 0.99 and np.mean(tab_fr_o[both] > tab_o[both] * (1 + 1e-4)) > 0.2   # earlier collapse
 
 
 @pytest.mark.parametrize("case", ["zero", "dc_only", "single_mode", "one_radius", "huge_amplitude", "tiny_amplitude"])

@@ -319,7 +319,7 @@ def test_tabulated_ct_restatement_vs_scipy():
 
 
 def _sng_rhs(t, y, cosmo):
-    O0, OL, Or, Ok = cosmo
+    O0, OL, Or, Ok, fr0, hoc, size = cosmo
     z = 1.0 / t - 1.0
     E2 = (Or * (1 + z) ** 4 + O0 * (1 + z) ** 3 + Ok * (1 + z) ** 2 + OL) / (Or + O0 + Ok + OL)
     om, ol = O0 * (1 + z) ** 3 / E2, OL / E2
@@ -333,7 +333,13 @@ def _sng_rhs(t, y, cosmo):
                 continue
             s += (ld[j] - ld[i]) * ((1 - la[i]) ** 2 * (1 + lv[i]) - (1 - la[j]) ** 2 * (1 + lv[j])) / ((1 - la[i]) ** 2 - (1 - la[j]) ** 2)
         f[i] = lv[i] * (la[i] - 1) / t
-        f[i + 3] = 0.5 * (lv[i] * (om - 2 * ol - 2) - 3 * om * ld[i] - 2 * lv[i] ** 2) / t
+        fm = 0.0
+        if fr0:                                     # ForceModification, src/collapse_times.c:295-312
+            ff = 4.0 * OL / O0
+            th = fr0 / O0 / (hoc * size) ** 2 * t ** 7 * (1 + delta) ** (-1 / 3) * (((1 + ff) / (1 + ff * t ** 3)) ** 2 - ((1 + ff) / (1 + delta + ff * t ** 3)) ** 2)
+            f3 = max(th * (3 + th * (-3 + th)), 0.0)
+            fm = f3 / 3 if f3 < 1 else 1 / 3
+        f[i + 3] = 0.5 * (lv[i] * (om - 2 * ol - 2) - 3 * om * ld[i] * (1 + fm) - 2 * lv[i] ** 2) / t
         f[i + 6] = ((5 / 6 + ld[i]) * ((3 + lv.sum()) - (1 + delta) / (2.5 + delta) * lv.sum()) - (2.5 + delta) * (1 + lv[i]) + s) / t
     return f
 
@@ -344,13 +350,18 @@ def test_ell_sng_restatement_vs_scipy():
     from scipy.integrate import solve_ivp
     L = oracle_lib.lib()
     dp = C.POINTER(C.c_double)
-    eds, lcdm = np.array([1.0, 0.0, 0.0, 0.0]), np.array([0.25, 0.75, 0.0, 0.0])
+    eds, lcdm = np.array([1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]), np.array([0.25, 0.75, 0.0, 0.0, 0.0, 0.0, 0.0])
+    fofr = np.array([0.25, 0.75, 0.0, 0.0, 1e-5, 100.0 / 299792.458, 2.0])     # MOD_GRAV_FR, |f_R0| = 1e-5, R = 2 Mpc
     # a sphere in Einstein-de Sitter collapses when the linear overdensity reaches 1.686
     a = L.orc_ell_sng(1.0, 1.0, 1.0, 1e-5, eds.ctypes.data_as(dp))
     assert abs(3.0 * a - 1.686) < 2e-3
     ev = lambda t, y, c: y[0] - 0.99999
     ev.terminal, ev.direction = True, 1
-    for cosmo, din in ((eds, 1e-5), (lcdm, 1.28e-5)):
+    # the fifth force can only speed the collapse up
+    gr = L.orc_ell_sng(1.2, 0.6, 0.3, 1.28e-5, lcdm.ctypes.data_as(dp))
+    fr = L.orc_ell_sng(1.2, 0.6, 0.3, 1.28e-5, fofr.ctypes.data_as(dp))
+    assert 0.0 < fr < gr and (gr - fr) / gr > 1e-3
+    for cosmo, din in ((eds, 1e-5), (lcdm, 1.28e-5), (fofr, 1.28e-5)):
         for l in ([2.0, 1.0, 0.5], [1.5, 0.2, -0.4], [0.8, 0.7, 0.1], [3.0, -0.5, -1.0], [-0.2, -0.3, -0.5]):
             y0 = np.array([x * din for x in l] + [x * din / (x * din - 1) for x in l] + [x * din for x in l])
             sol = solve_ivp(_sng_rhs, (1e-5, 5.0), y0, method="DOP853", rtol=1e-10, atol=1e-12, args=(cosmo,), events=ev)
