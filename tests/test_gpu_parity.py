@@ -37,13 +37,14 @@ def api():
     return _api
 
 
-def _fmax_close(got, want):
+def _fmax_close(got, want, max_abs=2e-3):
     """returns the indices of the ill-conditioned outlier cells (normally none below 64^3)"""
     ulp = np.spacing(np.maximum(np.abs(want), 1.0).astype(np.float32)).astype(np.float64)
     d = np.abs(got.astype(np.float64) - want.astype(np.float64))
     bad = d > 2 * ulp
     assert bad.sum() <= max(1, int(2e-5 * d.size)), (int(bad.sum()), d.max(), np.argwhere(bad)[:3])  # never less than one cell
-    assert d.max() <= 2e-3, d.max()
+    if max_abs is not None:
+        assert d.max() <= max_abs, d.max()
     assert np.mean(d > 0) < 1e-3, np.mean(d > 0)
     return np.argwhere(bad)
 
@@ -846,3 +847,54 @@ def test_contexts_release_their_memory(api):
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert abs(free1 - free0) < 64 * 2 ** 20, (free0, free1)
+
+
+@pytest.mark.parametrize("n,ns,lpt", [(256, 5, False), (512, 3, True)])
+def test_baseline_config_sizes_vs_oracle(api, n, ns, lpt):
+    """BASELINE configs 2 and 3 at their own grid sizes (256^3 Fmax only, 512^3 with displacements), cell by cell
+    against the oracle run on the host cores of the GPU box"""
+    radii = synth.radii_ladder(12)[[0, 4, 8, 10, 11]][-ns:] * (n / 1024.0)
+    radii[-1] = 0.0
+    x, y = synth.invgrow_table("lcdm")
+    g = synth.growth_multipliers()
+    with api.Fmax(n) as f:
+        f.synth_density(synth.SEED, 2.5, -2.0)
+        f.set_invgrow(x, y); f.set_growth(g)
+        tv = f.compute_fmax(radii, do_lpt=lpt)
+        p = f.products()
+        dk = f.density()
+    o = oracle_lib.Oracle(n, 0)
+    o.set_density(dk); o.set_invgrow(x, y); o.set_growth(g)
+    tv_o = o.compute_fmax(radii, do_lpt=lpt)
+    po = o.products()
+    assert np.allclose(tv, tv_o, rtol=1e-12)
+    # with 10^7 - 10^8 cells a few sit orders of magnitude closer to the singular surface of the reference's cubic
+    # (den -> 0) than anything at 128^3: there F moves by O(0.1 - 1) under a 1e-15 change of the Hessian.  The count
+    # criterion stays; the far outliers must each be explained by the oracle's own solver on the GPU's Hessian.
+    outliers = _fmax_close(p["Fmax"], po["Fmax"], max_abs=None)
+    d = np.abs(p["Fmax"].astype(np.float64) - po["Fmax"])
+    far = [tuple(c) for c in outliers if d[tuple(c)] > 2e-3]
+    assert len(far) <= 64, len(far)
+    if far:
+        o8 = oracle_lib.Oracle(8, 1)
+        o8.set_invgrow(x, y)
+        rng = np.random.default_rng(1)
+        with api.Fmax(n) as f:
+            f.set_density(dk)
+            for ir in sorted(set(int(p["Rmax"][c]) for c in far)):
+                f.compute_second_derivatives(radii[ir])
+                hg = [f.second_derivative(i) for i in range(6)]
+                for c in far:
+                    if p["Rmax"][c] != ir:
+                        continue
+                    h = np.array([hh[c] for hh in hg])
+                    fo = o8.inverse_collapse_time(h)[0]
+                    spread = max(abs(o8.inverse_collapse_time(h * (1.0 + rng.uniform(-4.4e-16, 4.4e-16, 6)))[0] - fo) for _ in range(64))
+                    ulp = float(np.spacing(np.float32(max(abs(fo), 1.0))))
+                    assert abs(float(p["Fmax"][c]) - fo) <= max(8.0 * spread, 2.0 * ulp), (c, fo, p["Fmax"][c], spread)
+    assert np.mean(p["Rmax"] != po["Rmax"]) < 1e-3
+    for name in ("Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+        if lpt:
+            assert np.max(np.abs(p[name].astype(np.float64) - po[name])) <= 4e-7 * np.max(np.abs(po[name])), name
+        else:
+            assert not p[name].any() and not po[name].any()
