@@ -852,7 +852,8 @@ def test_contexts_release_their_memory(api):
 @pytest.mark.parametrize("n,ns,lpt", [(256, 5, False), (512, 3, True)])
 def test_baseline_config_sizes_vs_oracle(api, n, ns, lpt):
     """BASELINE configs 2 and 3 at their own grid sizes (256^3 Fmax only, 512^3 with displacements), cell by cell
-    against the oracle run on the host cores of the GPU box"""
+    against the oracle run on the host cores of the GPU box.  (Not at 1024^3: the oracle plus both product arrays need
+    several hundred GB of host memory there; the metric's own size is covered by the size-independent properties.)"""
     radii = synth.radii_ladder(12)[[0, 4, 8, 10, 11]][-ns:] * (n / 1024.0)
     radii[-1] = 0.0
     x, y = synth.invgrow_table("lcdm")
@@ -874,7 +875,7 @@ def test_baseline_config_sizes_vs_oracle(api, n, ns, lpt):
     outliers = _fmax_close(p["Fmax"], po["Fmax"], max_abs=None)
     d = np.abs(p["Fmax"].astype(np.float64) - po["Fmax"])
     far = [tuple(c) for c in outliers if d[tuple(c)] > 2e-3]
-    assert len(far) <= 64, len(far)
+    assert len(far) <= max(64, int(1e-6 * d.size)), len(far)
     if far:
         o8 = oracle_lib.Oracle(8, 1)
         o8.set_invgrow(x, y)
