@@ -827,8 +827,14 @@ def test_reference_example_size_200(api):
 def test_contexts_release_their_memory(api):
     """create / run / destroy in a loop, both transform paths, with every lazily allocated piece in use: the device
     memory in use returns to where it started (no leak across the reference's finalize_fft / compute_fft_plans cycles)"""
-    import torch
     x, y = synth.invgrow_table("lcdm")
+    hip = C.CDLL("libamdhip64.so")            # the runtime the library itself is linked to (already loaded)
+    hip.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+
+    def free_bytes():
+        fr, tot = C.c_size_t(), C.c_size_t()
+        assert hip.hipDeviceSynchronize() == 0 and hip.hipMemGetInfo(C.byref(fr), C.byref(tot)) == 0
+        return fr.value
 
     def cycle(n):
         with api.Fmax(n) as f:
@@ -840,12 +846,10 @@ def test_contexts_release_their_memory(api):
             f.products()
 
     cycle(64); cycle(48)
-    torch.cuda.synchronize()
-    free0 = torch.cuda.mem_get_info()[0]
+    free0 = free_bytes()
     for _ in range(10):
         cycle(64); cycle(48)
-    torch.cuda.synchronize()
-    free1 = torch.cuda.mem_get_info()[0]
+    free1 = free_bytes()
     assert abs(free1 - free0) < 64 * 2 ** 20, (free0, free1)
 
 
