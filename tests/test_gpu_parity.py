@@ -268,11 +268,11 @@ def test_fmax_only_skips_lpt_and_reentry(api):
     assert np.allclose(p2["Vel_3LPT_2"], 0.125 * p1["Vel_3LPT_2"], rtol=2e-7, atol=0)
 
 
-def test_fp32_field_path(api):
+@pytest.mark.parametrize("n", [64, 256])
+def test_fp32_field_path(api, n):
     """config 5: fp32 density/derivative fields, fp64 collapse solve.  Stated
     tolerance: Hessian rel-L2 <= 1e-5; |dFmax| <= 1e-3 on 99.9 % of cells with F >= 0.5."""
-    n = 64
-    radii = np.array([4.0, 2.0, 1.0, 0.0])
+    radii = np.array([4.0, 2.0, 1.0, 0.0]) * (n / 64.0) ** 0.5
     (tv, p, pdf, _), (tv_o, po, pdf_o, _) = _run_both(api, n, radii, field_bytes=4)
     assert np.allclose(tv, tv_o, rtol=1e-5)
     sel = po["Fmax"] >= 0.5
