@@ -105,30 +105,29 @@ inline void pf_spline_bd(const double *xa, const double *ya, const double *ca, i
 // Each differs from the reference call by about one ulp, like the device libm differs from glibc.
 // sin and cos on [0, pi/3] (t = acos(.) in [0, pi], so t/3 never leaves it): Taylor series in x^2, no range
 // reduction; truncation < 1e-19, rounding ~1 ulp.  The generic sincos costs 155 instructions on gfx950, this ~30.
+// Taylor coefficients of sin (odd, -1/19! ... -1/3!) then cos (even, 1/20! ... 1/4!).  On the device they sit in constant
+// memory and arrive through scalar loads: gfx950's VOP3 encodings take no 64-bit literal, so as inline constants each of
+// them costs two v_mov_b32 per cell once the SGPR file is full -- scalar loads issue beside the vector stream instead.
+#if defined(__HIP_DEVICE_COMPILE__)
+static __constant__ double pf_sc_coef[18] = {
+#else
+static const double pf_sc_coef[18] = {
+#endif
+    -8.2206352466243297e-18, 2.8114572543455206e-15,  -7.6471637318198164e-13, 1.6059043836821613e-10, -2.5052108385441720e-08,
+    2.7557319223985893e-06,  -1.9841269841269841e-04, 8.3333333333333332e-03,  -1.6666666666666666e-01,
+    4.1103176233121648e-19,  -1.5619206968586225e-16, 4.7794773323873853e-14,  -1.1470745597729725e-11, 2.0876756987868100e-09,
+    -2.7557319223985888e-07, 2.4801587301587302e-05,  -1.3888888888888889e-03, 4.1666666666666664e-02};
 PF_HD void pf_sincos_third(double x, double &sn, double &cs) {
   const double z = x * x;
-  double ps = -8.2206352466243297e-18;            // -1/19!
-  ps = fma(ps, z, 2.8114572543455206e-15);        //  1/17!
-  ps = fma(ps, z, -7.6471637318198164e-13);       // -1/15!
-  ps = fma(ps, z, 1.6059043836821613e-10);        //  1/13!
-  ps = fma(ps, z, -2.5052108385441720e-08);       // -1/11!
-  ps = fma(ps, z, 2.7557319223985893e-06);        //  1/9!
-  ps = fma(ps, z, -1.9841269841269841e-04);       // -1/7!
-  ps = fma(ps, z, 8.3333333333333332e-03);        //  1/5!
-  ps = fma(ps, z, -1.6666666666666666e-01);       // -1/3!
+  double ps = pf_sc_coef[0];
+#pragma unroll
+  for (int i = 1; i < 9; i++) ps = fma(ps, z, pf_sc_coef[i]);
   sn = fma(x * z, ps, x);
-  double pc = 4.1103176233121648e-19;             //  1/20!
-  pc = fma(pc, z, -1.5619206968586225e-16);       // -1/18!
-  pc = fma(pc, z, 4.7794773323873853e-14);        //  1/16!
-  pc = fma(pc, z, -1.1470745597729725e-11);       // -1/14!
-  pc = fma(pc, z, 2.0876756987868100e-09);        //  1/12!
-  pc = fma(pc, z, -2.7557319223985888e-07);       // -1/10!
-  pc = fma(pc, z, 2.4801587301587302e-05);        //  1/8!
-  pc = fma(pc, z, -1.3888888888888889e-03);       // -1/6!
-  pc = fma(pc, z, 4.1666666666666664e-02);        //  1/4!
+  double pc = pf_sc_coef[9];
+#pragma unroll
+  for (int i = 10; i < 18; i++) pc = fma(pc, z, pf_sc_coef[i]);
   cs = fma(z * z, pc, fma(-0.5, z, 1.0));
 }
-
 // x / Y for a constant Y, correctly rounded, in three operations (Markstein): with c = RN(1/Y), q0 = RN(x c),
 // the residual x - Y q0 is exact in an fma and q0 + residual c rounds to RN(x / Y) -- the same double the
 // reference's division produces, so the q^3 < r^2 sentinel test sees the reference's own q and r
