@@ -510,3 +510,73 @@ def test_tabulated_ct_build_through_the_reference_driver(lib, tmp_path):
         C.c_int.in_dll(lib, "pf_compat_tabulated_ct").value = 0
         C.c_int.in_dll(lib, "pf_compat_ell_sng").value = 0
         par.CTtableFile = b"none"
+
+
+@pytest.mark.gpu
+def test_reference_validation_run_through_the_adapter(lib, tmp_path):
+    """The reference's committed validation run (HMF_Validation/, tests/golden/hmf_validation_kat.json) driven the way
+    main() drives it, through the reference-named entry points only: initial conditions from seed + cosmology
+    (pf_compat_genic in place of GenIC_large), compute_fmax, and the pinocchio.<run>.FmaxPDF.out it writes -- compared
+    with the logged sigma per radius, the collapsed count and the committed histogram file"""
+    import json
+    import ic_oracle
+    with open(os.path.join(ROOT, "tests", "golden", "hmf_validation_kat.json")) as fh:
+        kat = json.load(fh)
+    kp = kat["params"]
+    n = kp["GridSize"]
+    box = kp["BoxSize_h100"] / kp["Hubble100"]
+    radii_mpc = np.array(kat["radii_Mpc"])
+    x, y = ic_oracle.growth_table_lcdm(kp["Omega0"])
+    g = synth.growth_multipliers()
+
+    grid = C.cast(C.c_void_p.in_dll(lib, "MyGrids"), C.POINTER(Grid)).contents
+    for i in range(3):
+        grid.GSglobal[i] = n
+    grid.Ntotal = n ** 3
+    grid.BoxSize = box
+    assert lib.set_one_grid(0) == 0
+    prod = np.zeros(n ** 3 * 56 + 64, dtype=np.uint8)
+    prod = prod[(-prod.ctypes.data) % 32:][:n ** 3 * 56]
+    C.c_void_p.in_dll(lib, "products").value = prod.ctypes.data
+    C.cast(C.c_void_p.in_dll(lib, "kdensity"), C.POINTER(C.c_void_p))[0] = None
+    sm = Smoothing.in_dll(lib, "Smoothing")
+    tv = np.zeros(len(radii_mpc)); var = np.array(kat["variance"])
+    sm.Nsmooth = len(radii_mpc)
+    sm.Radius = radii_mpc.ctypes.data_as(C.POINTER(C.c_double))
+    sm.Variance = var.ctypes.data_as(C.POINTER(C.c_double))
+    sm.TrueVariance = tv.ctypes.data_as(C.POINTER(C.c_double))
+    sd = ScaleDep.in_dll(lib, "ScaleDep")
+    sd.nseg = 1
+    sd.z[0] = 0.0
+    kn = Knots.in_dll(lib, "pf_invgrow_knots")
+    kn.size = len(x)
+    kn.x = x.ctypes.data_as(C.POINTER(C.c_double))
+    kn.y = y.ctypes.data_as(C.POINTER(C.c_double))
+    fns = [GROWTH_FN(lambda z, k, v=v: float(v)) for v in g]
+    for name, fn in zip(("pf_GrowingMode", "pf_GrowingMode_2LPT", "pf_GrowingMode_3LPT_1", "pf_GrowingMode_3LPT_2"), fns):
+        C.c_void_p.in_dll(lib, name).value = C.cast(fn, C.c_void_p).value
+    par = Params.in_dll(lib, "params")
+    par.RunFlag = b"test"
+    par.GridSize[0] = par.GridSize[1] = par.GridSize[2] = n
+    par.RandomSeed = kp["RandomSeed"]
+    par.Omega0, par.OmegaBaryon, par.Hubble100 = kp["Omega0"], kp["OmegaBaryon"], kp["Hubble100"]
+    par.Sigma8, par.PrimordialIndex, par.BoxSize_htrue = kp["Sigma8"], kp["PrimordialIndex"], box
+    par.CTtableFile = b"none"
+    for flag in ("pf_compat_scale_dependent", "pf_compat_tabulated_ct", "pf_compat_ell_sng"):
+        C.c_int.in_dll(lib, flag).value = 0
+
+    lib.pf_compat_genic.argtypes = [C.c_double]
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        assert lib.compute_fft_plans() == 0
+        assert lib.pf_compat_genic(kat["PkNorm"]) == 0
+        assert lib.compute_fmax() == 0
+        written = [int(l.split()[2]) for l in open("pinocchio.test.FmaxPDF.out") if not l.startswith("#")]
+    finally:
+        os.chdir(cwd)
+    assert np.all(np.abs(np.sqrt(tv) - np.array(kat["computed_sigma"])) <= 6e-5)        # the log prints 4 decimals
+    want = np.array(kat["FmaxPDF"], dtype=np.int64)
+    got = np.array(written, dtype=np.int64)
+    assert got.sum() == n ** 3 and abs(int(got[10:].sum()) - kat["collapsed"]) <= 5
+    assert np.abs(got - want).sum() <= 200
