@@ -383,17 +383,27 @@ int compute_fmax(void) {
   rs = (double *)malloc(sizeof(double) * Smoothing.Nsmooth);
   for (ismooth = 0; ismooth < Smoothing.Nsmooth; ismooth++) rs[ismooth] = Smoothing.Radius[ismooth] / MyGrids[0].CellSize;
   Rsmooth = rs[Smoothing.Nsmooth - 1];
-  if (PF_TABULATED) { /* src/fmax.c:66-150 radius by radius: derivatives, table of this radius, collapse times */
-    for (ismooth = 0; ismooth < Smoothing.Nsmooth; ismooth++) {
-      if (pf_second_derivatives(pf_context, rs[ismooth]) || initialize_collapse_times(ismooth, 0) ||
-          compute_collapse_times(ismooth) || reset_collapse_times(ismooth)) { free(rs); return 1; }
-    }
-  } else if (pf_sweep(pf_context, Smoothing.Nsmooth, rs, Smoothing.TrueVariance)) { free(rs); return 1; }
-  free(rs);
-  if (!ThisTask)
-    for (ismooth = 0; ismooth < Smoothing.Nsmooth; ismooth++)
-      printf("[%s] Completed, R=%6.3f, expected sigma: %7.4f, computed sigma: %7.4f\n", fdate(), Smoothing.Radius[ismooth],
-             Smoothing.Variance ? sqrt(Smoothing.Variance[ismooth]) : 0.0, sqrt(Smoothing.TrueVariance[ismooth]));
+  {
+    double cpusm = pf_wtime();
+    if (PF_TABULATED) { /* src/fmax.c:66-150 radius by radius: derivatives, table of this radius, collapse times */
+      for (ismooth = 0; ismooth < Smoothing.Nsmooth; ismooth++) {
+        if (pf_second_derivatives(pf_context, rs[ismooth]) || initialize_collapse_times(ismooth, 0) ||
+            compute_collapse_times(ismooth) || reset_collapse_times(ismooth)) { free(rs); return 1; }
+      }
+    } else if (pf_sweep(pf_context, Smoothing.Nsmooth, rs, Smoothing.TrueVariance)) { free(rs); return 1; }
+    free(rs);
+    /* the radii run back to back on the device: the log keeps the reference's two lines per radius (src/fmax.c:66-69,
+       141-145), with the sweep's wall time shared evenly */
+    cpusm = (pf_wtime() - cpusm) / Smoothing.Nsmooth;
+    if (!ThisTask)
+      for (ismooth = 0; ismooth < Smoothing.Nsmooth; ismooth++) {
+        const double sig = Smoothing.Variance ? sqrt(Smoothing.Variance[ismooth]) : 0.0;
+        printf("\n[%s] Starting smoothing radius %d of %d (R=%9.5f, sigma=%9.5f)\n", fdate(), ismooth + 1, Smoothing.Nsmooth,
+               Smoothing.Radius[ismooth], sig);
+        printf("[%s] Completed, R=%6.3f, expected sigma: %7.4f, computed sigma: %7.4f, cpu time = %f s\n", fdate(),
+               Smoothing.Radius[ismooth], sig, sqrt(Smoothing.TrueVariance[ismooth]), cpusm);
+      }
+  }
 
   /* COMPUTATION OF DISPLACEMENTS for the first (or only) redshift segment (src/fmax.c:160-169) */
   if (!ThisTask) printf("\n[%s] Computing displacements  for redshift %f\n", fdate(), ScaleDep.z[0]);
