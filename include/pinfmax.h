@@ -76,6 +76,13 @@ const char *pf_last_error(void);
 typedef int (*pf_alltoall_fn)(void *user, const void *sendbuf, void *recvbuf,
                               size_t bytes_per_peer, void *stream);
 int pf_set_exchange(pf_ctx *ctx, pf_alltoall_fn fn, void *user);
+/* Optional companion for band-limited spectra (smoothing radii whose Gaussian window is below 2^-60 beyond |k| = band):
+   of each of the P blocks only one row range carries data.  Rank r sends send_bytes bytes from
+   sendbuf + q*block_bytes + send_off to every rank q (nothing when send_bytes == 0) and receives recv_bytes[p] bytes into
+   recvbuf + p*block_bytes + recv_off[p] from every rank p.  Without it the full blocks go through pf_alltoall_fn. */
+typedef int (*pf_alltoallv_fn)(void *user, const void *sendbuf, void *recvbuf, size_t block_bytes, size_t send_off,
+                               size_t send_bytes, const size_t *recv_off, const size_t *recv_bytes, void *stream);
+int pf_set_exchange_rows(pf_ctx *ctx, pf_alltoallv_fn fn, void *user);
 int pf_rccl_unique_id(void *id128);                 /* rank 0: ncclGetUniqueId */
 int pf_init_rccl(pf_ctx *ctx, const void *id128);   /* all ranks: ncclCommInitRank */
 /* small reductions (MPI_Reduce/MPI_Bcast at src/collapse_times.c:656-667,

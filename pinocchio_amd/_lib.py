@@ -42,6 +42,8 @@ class KernelStat(C.Structure):
 
 
 ALLTOALL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t),
+                           C.POINTER(C.c_size_t), C.c_void_p)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
 
 # every symbol include/pinfmax.h declares: name -> (restype, argtypes)
@@ -53,6 +55,7 @@ PROTOTYPES = {
     "pf_destroy": (C.c_int, [_vp]),
     "pf_last_error": (C.c_char_p, []),
     "pf_set_exchange": (C.c_int, [_vp, ALLTOALL_FN, _vp]),
+    "pf_set_exchange_rows": (C.c_int, [_vp, ALLTOALLV_FN, _vp]),
     "pf_rccl_unique_id": (C.c_int, [_vp]),
     "pf_init_rccl": (C.c_int, [_vp, _vp]),
     "pf_set_allreduce": (C.c_int, [_vp, ALLREDUCE_FN, _vp]),

@@ -126,6 +126,7 @@ struct pf_ctx {
   bool vel_zero_pending;  // the Vel* columns are to read as zero (src/collapse_times.c:472-489) but have not been cleared yet
   int last_ns;
   pf_alltoall_fn a2a; void *a2a_user;
+  pf_alltoallv_fn a2av; void *a2av_user;  // optional: exchange of a row range of every block (pruned radii)
   pf_allreduce_fn ared; void *ared_user;
   void *rccl;          // ncclComm_t when pf_init_rccl was used
   // measurement
@@ -222,7 +223,7 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   if (c->general) c->nzp = c->nzh;  // natural layout [n][n][n/2+1], the boundary layout itself
   c->nxl = c->n / c->P; c->nyl = c->n / c->P; c->fb = cfg->field_bytes; c->timing = (cfg->flags & PF_FLAG_TIMING) != 0;
   c->dev_bytes = 0; c->own_stream = true; c->stream = nullptr;
-  c->a2a = nullptr; c->ared = nullptr; c->a2a_user = c->ared_user = nullptr; c->rccl = nullptr;
+  c->a2a = nullptr; c->a2av = nullptr; c->a2av_user = nullptr; c->ared = nullptr; c->a2a_user = c->ared_user = nullptr; c->rccl = nullptr;
   c->have_density = c->have_hessian = c->have_sources = c->products_init = false; c->last_ns = 0;
   c->vel_zero_pending = false;
   memset(c->ks_ms, 0, sizeof(c->ks_ms)); memset(c->ks_bytes, 0, sizeof(c->ks_bytes)); memset(c->ks_n, 0, sizeof(c->ks_n));
@@ -354,6 +355,7 @@ extern "C" int pf_synchronize(pf_ctx *c) {
 extern "C" size_t pf_device_bytes(pf_ctx *c) { return c ? c->dev_bytes : 0; }
 
 extern "C" int pf_set_exchange(pf_ctx *c, pf_alltoall_fn fn, void *user) { c->a2a = fn; c->a2a_user = user; return 0; }
+extern "C" int pf_set_exchange_rows(pf_ctx *c, pf_alltoallv_fn fn, void *user) { c->a2av = fn; c->a2av_user = user; return 0; }
 extern "C" int pf_set_allreduce(pf_ctx *c, pf_allreduce_fn fn, void *user) { c->ared = fn; c->ared_user = user; return 0; }
 extern "C" int pf_exchange_buffers(pf_ctx *c, void **sendbuf, void **recvbuf, size_t *bytes) {
   if (sendbuf) *sendbuf = c->blockA;
@@ -371,6 +373,36 @@ static int exchange(pf_ctx *c, const void *send, void *recv, hipStream_t st = nu
   if (c->a2a(c->a2a_user, send, recv, c->field_bytes / c->P, (void *)st)) return pf_fail(c->rank, "all-to-all failed");
   return 0;
 }
+// The same all-to-all for a band-limited (Gaussian-smoothed) spectrum: of every block only the slab rows whose ky lies
+// in the band carry data (the x-pass writes nothing else, the y-pass reads nothing else).  The blocks of the inverse
+// transforms are laid out [q][y_local][x_local][nzp], so the in-band rows of a rank are ONE contiguous piece at the
+// same offset in each of its P send blocks: rank p owns ky = p*nyl .. (p+1)*nyl - 1, in band if ky <= band or
+// ky >= n - band (one interval per rank once P >= 2, band < n/2).  Ranks without in-band rows send nothing.
+static void band_rows(const pf_ctx *c, int p, int band, int *lo, int *hi) {
+  const int y0 = p * c->nyl, y1 = y0 + c->nyl;  // global ky range of rank p
+  *lo = *hi = 0;
+  if (y0 <= band) { *lo = 0; *hi = (band + 1 < y1 ? band + 1 : y1) - y0; }
+  else if (y1 > c->n - band) { *lo = (c->n - band > y0 ? c->n - band : y0) - y0; *hi = c->nyl; }
+}
+static int exchange_band(pf_ctx *c, const void *send, void *recv, int band, hipStream_t st = nullptr) {
+  if (c->P == 1) return 0;
+  const bool rows_off = getenv("PF_EXCHANGE_ROWS") && !atoi(getenv("PF_EXCHANGE_ROWS"));  // 0: always whole blocks
+  if (band >= c->n / 2 || !c->a2av || rows_off) return exchange(c, send, recv, st);
+  if (!st) st = c->stream;
+  const size_t row_bytes = (size_t)c->nxl * c->nzp * 2 * c->fb, block_bytes = c->field_bytes / c->P;
+  std::vector<size_t> roff(c->P), rbytes(c->P);
+  size_t total = 0;
+  for (int p = 0; p < c->P; p++) {
+    int lo, hi;
+    band_rows(c, p, band, &lo, &hi);
+    roff[p] = (size_t)lo * row_bytes; rbytes[p] = (size_t)(hi - lo) * row_bytes;
+    total += rbytes[p];
+  }
+  KTimer t(c, KS_EXCHANGE, (double)total, st);
+  if (c->a2av(c->a2av_user, send, recv, block_bytes, roff[c->rank], rbytes[c->rank], roff.data(), rbytes.data(), (void *)st))
+    return pf_fail(c->rank, "all-to-all (row range) failed");
+  return 0;
+}
 static int allreduce_dev(pf_ctx *c, void *buf, size_t count, int is_u64) {
   if (c->P == 1) return 0;
   if (!c->ared) return pf_fail(c->rank, "no all-reduce installed for %d ranks (pf_set_allreduce / pf_init_rccl)", c->P);
@@ -386,17 +418,26 @@ static PfAddr addr_ky_x(const pf_ctx *c) {  // KY layout, e = x, outer = y_local
 static PfAddr addr_blocks_y(const pf_ctx *c) {  // P blocks [p][nxl][nyl][nzp], e = y = p*nyl + yl, outer = x_local
   PfAddr a; a.os = (long long)c->nyl * c->nzp; a.el_shift = ilog2i(c->nyl); a.ehs = (long long)c->nxl * c->nyl * c->nzp; a.els = c->nzp; return a;
 }
+// inverse transforms, P > 1: send / receive blocks with the slab row slowest, [q][y_local][x_local][nzp]
+static PfAddr addr_yblocks_x(const pf_ctx *c) {  // x-pass output: e = x = q*nxl + xl, outer = y_local
+  PfAddr a; a.os = (long long)c->nxl * c->nzp; a.el_shift = ilog2i(c->nxl); a.ehs = (long long)c->nyl * c->nxl * c->nzp; a.els = c->nzp; return a;
+}
+static PfAddr addr_yblocks_y(const pf_ctx *c) {  // y-pass input: e = y = p*nyl + yl, outer = x_local
+  PfAddr a; a.os = c->nzp; a.el_shift = ilog2i(c->nyl); a.ehs = (long long)c->nyl * c->nxl * c->nzp; a.els = (long long)c->nxl * c->nzp; return a;
+}
 static PfAddr addr_xs_y(const pf_ctx *c) {  // XS layout, e = y, outer = x_local
   PfAddr a; a.os = (long long)c->n * c->nzp; a.el_shift = ilog2i(c->n); a.ehs = 0; a.els = c->nzp; return a;
 }
 
 struct Job { const void *in; void *out; int mul; };
 
-static int xpass(pf_ctx *c, int kind, int dir, int njobs, const Job *jobs, int pre, double rs, double growth, int nin, int band = 1 << 30) {
+static int xpass(pf_ctx *c, int kind, int dir, int njobs, const Job *jobs, int pre, double rs, double growth, int nin, int band = 1 << 30,
+                 bool out_yblocks = false) {
   PfStridedParams p; memset(&p, 0, sizeof(p));
   p.njobs = njobs;
   for (int j = 0; j < njobs; j++) { p.job[j].in = jobs[j].in; p.job[j].out = jobs[j].out; p.job[j].mul = jobs[j].mul; }
   p.ain = p.aout = addr_ky_x(c);
+  if (out_yblocks && c->P > 1) p.aout = addr_yblocks_x(c);
   p.ncols = c->nzh; p.nouter = c->nyl; p.pre = pre; p.outer_offset = c->rank * c->nyl; p.rs = rs; p.growth = growth; p.tw = c->tw;
   p.etab = c->etab;
   if (pre && rs != 0.0) PFCHK(c, pf_launch_exp_table(c->etab, c->n, rs, c->stream));  // stream order: after the previous x-pass
@@ -412,11 +453,12 @@ static int xpass(pf_ctx *c, int kind, int dir, int njobs, const Job *jobs, int p
   return 0;
 }
 // in_blocks: input is the P received blocks (after an all-to-all) else XS; out_blocks likewise (forward direction)
-static int ypass(pf_ctx *c, int kind, int dir, int njobs, const Job *jobs, bool in_blocks, bool out_blocks, int nin, int band = 1 << 30) {
+static int ypass(pf_ctx *c, int kind, int dir, int njobs, const Job *jobs, bool in_blocks, bool out_blocks, int nin, int band = 1 << 30,
+                 bool in_yblocks = false) {
   PfStridedParams p; memset(&p, 0, sizeof(p));
   p.njobs = njobs;
   for (int j = 0; j < njobs; j++) { p.job[j].in = jobs[j].in; p.job[j].out = jobs[j].out; p.job[j].mul = jobs[j].mul; }
-  p.ain = in_blocks ? addr_blocks_y(c) : addr_xs_y(c);
+  p.ain = in_blocks ? ((in_yblocks && c->P > 1) ? addr_yblocks_y(c) : addr_blocks_y(c)) : addr_xs_y(c);
   p.aout = out_blocks ? addr_blocks_y(c) : addr_xs_y(c);
   p.ncols = c->nzh; p.nouter = c->nxl; p.pre = 0; p.outer_offset = 0; p.rs = 0; p.growth = 1; p.tw = c->tw;
   p.band_e = p.band_outer = c->n;
@@ -456,8 +498,9 @@ static int zpass_c2r(pf_ctx *c, int kind, int njobs, const ZJob *jobs, const dou
 // the wire time hides behind the y/z passes and the collapse solve of item i ("overlap transposes of
 // field i with passes of field i+-1").  Hazards: pre(i) reuses the send set of item i-2, whose exchange post(i-2)
 // waited for; exchange(i) overwrites the receive set of item i-2 after ev_x(i), recorded behind post(i-2).
-template <class Pre, class Dst, class Post>
-static int pipelined(pf_ctx *c, int count, int nf, Pre pre, Dst dst, Post post) {
+// band(i): the spectrum of item i is band-limited to |k| <= band (>= n/2: not): only the in-band slab rows travel
+template <class Pre, class Dst, class Post, class Band>
+static int pipelined_band(pf_ctx *c, int count, int nf, Pre pre, Dst dst, Post post, Band band) {
   void *A[2][3];
   const void *R[3];
   for (int f = 0; f < 3; f++) { A[0][f] = c->A[f]; A[1][f] = c->pipeline ? (void *)(c->blockA2 + f * c->field_bytes) : c->A[f]; }
@@ -466,7 +509,7 @@ static int pipelined(pf_ctx *c, int count, int nf, Pre pre, Dst dst, Post post) 
       if (pre(i, A[0])) return 1;
       for (int f = 0; f < nf; f++) {
         R[f] = A[0][f];
-        if (c->P > 1) { void *d = dst(i, 0, f); PFCHK(c, exchange(c, A[0][f], d)); R[f] = d; }
+        if (c->P > 1) { void *d = dst(i, 0, f); PFCHK(c, exchange_band(c, A[0][f], d, band(i))); R[f] = d; }
       }
       if (post(i, R)) return 1;
     }
@@ -477,7 +520,7 @@ static int pipelined(pf_ctx *c, int count, int nf, Pre pre, Dst dst, Post post) 
     if (pre(i, A[s])) return 1;
     HIPCHK(c, hipEventRecord(c->ev_x[s], c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->cstream, c->ev_x[s], 0));
-    for (int f = 0; f < nf; f++) PFCHK(c, exchange(c, A[s][f], dst(i, s, f), c->cstream));
+    for (int f = 0; f < nf; f++) PFCHK(c, exchange_band(c, A[s][f], dst(i, s, f), band(i), c->cstream));
     HIPCHK(c, hipEventRecord(c->ev_r[s], c->cstream));
     return 0;
   };
@@ -489,6 +532,10 @@ static int pipelined(pf_ctx *c, int count, int nf, Pre pre, Dst dst, Post post) 
     if (post(i, R)) return 1;
   }
   return 0;
+}
+template <class Pre, class Dst, class Post>
+static int pipelined(pf_ctx *c, int count, int nf, Pre pre, Dst dst, Post post) {
+  return pipelined_band(c, count, nf, pre, dst, post, [](int) { return 1 << 30; });
 }
 static void *recv_field(pf_ctx *c, int set, int f) { return (char *)(set ? c->recvA2 : c->recvA) + (size_t)f * c->field_bytes; }
 
@@ -562,12 +609,12 @@ static int hess_band(const pf_ctx *c, double rs, bool xy_only) {
 }
 static int hess_x(pf_ctx *c, const void *spec, double rs, void *const A[3], int band) {
   const Job xj[3] = {{spec, A[0], PF_MUL_ONE}, {spec, A[1], PF_MUL_K}, {spec, A[2], PF_MUL_K2}};
-  return xpass(c, KS_XPASS_HESS, +1, 3, xj, 1, rs, 1.0, 1, band);
+  return xpass(c, KS_XPASS_HESS, +1, 3, xj, 1, rs, 1.0, 1, band, true);
 }
 static int hess_yz(pf_ctx *c, const void *const R[3], const double *dc, void *const out[6], int band, bool xy_only) {
   const Job yj[6] = {{R[2], out[0], PF_MUL_ONE}, {R[1], out[3], PF_MUL_K}, {R[1], out[4], PF_MUL_ONE},
                      {R[0], out[1], PF_MUL_K2}, {R[0], out[5], PF_MUL_K},  {R[0], out[2], PF_MUL_ONE}};
-  PFCHK(c, ypass(c, KS_YPASS_HESS, +1, 6, yj, true, false, 3, band));
+  PFCHK(c, ypass(c, KS_YPASS_HESS, +1, 6, yj, true, false, 3, band, true));
   if (xy_only) { c->last_band = band; return 0; }
   const ZJob zj[6] = {{out[0], out[0], PF_MUL_ONE, 0}, {out[1], out[1], PF_MUL_ONE, 0}, {out[2], out[2], PF_MUL_K2, 0},
                       {out[3], out[3], PF_MUL_ONE, 0}, {out[4], out[4], PF_MUL_K, 0},   {out[5], out[5], PF_MUL_K, 0}};
@@ -577,10 +624,11 @@ static int hess_yz(pf_ctx *c, const void *const R[3], const double *dc, void *co
 static int hessian_of(pf_ctx *c, const void *spec, double rs, const double *dc, void *const out[6], bool xy_only = false) {
   if (c->general) return g_hessian_of(c, spec, rs, out);
   const int band = hess_band(c, rs, xy_only);
-  return pipelined(c, 1, 3,
-                   [&](int, void *const *A) { return hess_x(c, spec, rs, A, band); },
-                   [&](int, int set, int f) { return recv_field(c, set, f); },
-                   [&](int, const void *const *R) { return hess_yz(c, R, dc, out, band, xy_only); });
+  return pipelined_band(c, 1, 3,
+                        [&](int, void *const *A) { return hess_x(c, spec, rs, A, band); },
+                        [&](int, int set, int f) { return recv_field(c, set, f); },
+                        [&](int, const void *const *R) { return hess_yz(c, R, dc, out, band, xy_only); },
+                        [&](int) { return band; });
 }
 
 // three first derivatives (displacement components) of specs[j] times growths[j] -> vel12[3*orders[j] .. +2]
@@ -603,13 +651,13 @@ static int displacements_of(pf_ctx *c, int count, const void *const *specs, cons
                        growth = 1.0;
                      }
                      const Job xj[2] = {{spec, A[0], PF_MUL_ONE}, {spec, A[1], PF_MUL_IK}};
-                     return xpass(c, KS_XPASS_DISP, +1, 2, xj, 1, 0.0, growth, 1);
+                     return xpass(c, KS_XPASS_DISP, +1, 2, xj, 1, 0.0, growth, 1, 1 << 30, true);
                    },
                    [&](int, int set, int f) { return recv_field(c, set, f); },
                    [&](int j, const void *const *R) {
                      const int o = orders[j];
                      const Job yj[3] = {{R[1], tmp[0], PF_MUL_ONE}, {R[0], tmp[1], PF_MUL_IK}, {R[0], tmp[2], PF_MUL_ONE}};
-                     PFCHK(c, ypass(c, KS_YPASS_DISP, +1, 3, yj, true, false, 2));
+                     PFCHK(c, ypass(c, KS_YPASS_DISP, +1, 3, yj, true, false, 2, 1 << 30, true));
                      const ZJob zj[3] = {{tmp[0], c->vel12 + (size_t)(3 * o + 0) * nc, PF_MUL_ONE, 1},
                                          {tmp[1], c->vel12 + (size_t)(3 * o + 1) * nc, PF_MUL_ONE, 1},
                                          {tmp[2], c->vel12 + (size_t)(3 * o + 2) * nc, PF_MUL_IK, 1}};
@@ -1041,7 +1089,8 @@ extern "C" int pf_sweep(pf_ctx *c, int ns, const double *radius_cells, double *t
       if (collapse_enqueue(c, ismooth, c->B, c->stream)) return 1;
       HIPCHK(c, hipEventRecord(c->ev_c[0], c->stream));
     }
-  } else if (pipelined(c, ns, 3, pre, [&](int, int set, int f) { return recv_field(c, set, f); }, post)) return 1;
+  } else if (pipelined_band(c, ns, 3, pre, [&](int, int set, int f) { return recv_field(c, set, f); }, post,
+                            [&](int ismooth) { return hess_band(c, radius_cells[ismooth], xy_only); })) return 1;
   // join; keep the R=0 Hessian (last radius) in B for the LPT sources
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_c[(ns - 1) & 1], 0));
   if (ns >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_c[(ns - 2) & 1], 0));
@@ -1369,6 +1418,24 @@ extern "C" int pf_debug_exchange(pf_ctx *c, size_t bytes_per_peer) {
     for (size_t i = 0; i < nw; i++)
       if (h[p * nw + i] != (((unsigned long long)p << 48) | ((unsigned long long)c->rank << 40) | i))
         return pf_fail(c->rank, "pf_debug_exchange: wrong word from rank %d at %zu", p, i);
+  if (c->a2av) {  // the row-range form: every rank a different range, some empty
+    std::vector<size_t> off(c->P), len(c->P);
+    for (int p = 0; p < c->P; p++) { off[p] = 8 * (size_t)((p % 3) * 37); len[p] = 8 * (size_t)(((p + 1) % 4) * 129); if (off[p] + len[p] > bytes_per_peer) len[p] = 0; }
+    for (int q = 0; q < c->P; q++)
+      for (size_t i = 0; i < nw; i++) h[q * nw + i] = ((unsigned long long)c->rank << 48) | ((unsigned long long)q << 40) | i;
+    HIPCHK(c, hipMemcpyAsync(c->A[0], h.data(), h.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(recv, 0, h.size() * 8, c->stream));
+    if (c->a2av(c->a2av_user, c->A[0], recv, bytes_per_peer, off[c->rank], len[c->rank], off.data(), len.data(), (void *)c->stream))
+      return pf_fail(c->rank, "pf_debug_exchange: row-range all-to-all failed");
+    HIPCHK(c, hipMemcpyAsync(h.data(), recv, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int p = 0; p < c->P; p++)
+      for (size_t i = 0; i < nw; i++) {
+        const bool in = 8 * i >= off[p] && 8 * i < off[p] + len[p];
+        const unsigned long long want = in ? (((unsigned long long)p << 48) | ((unsigned long long)c->rank << 40) | i) : 0ull;
+        if (h[p * nw + i] != want) return pf_fail(c->rank, "pf_debug_exchange: row-range exchange, wrong word from rank %d at %zu", p, i);
+      }
+  }
   if (c->ared) {
     double v[2] = {1.0 + c->rank, 2.0};
     HIPCHK(c, hipMemcpyAsync(c->scal, v, sizeof(v), hipMemcpyHostToDevice, c->stream));

@@ -59,6 +59,25 @@ static int fabric_alltoall(void *user, const void *send, void *recv, size_t byte
   return f->error;
 }
 
+static int fabric_alltoallv(void *user, const void *send, void *recv, size_t block_bytes, size_t send_off, size_t send_bytes,
+                            const size_t *recv_off, const size_t *recv_bytes, void *stream) {
+  FabricLink *l = (FabricLink *)user;
+  pf_fabric *f = l->f;
+  hipStream_t st = (hipStream_t)stream;
+  (void)send_off; (void)send_bytes;  // every rank derives the same ranges; the puller uses its own copy of them
+  if (hipStreamSynchronize(st) != hipSuccess) f->error = 1;
+  f->send[l->rank] = send;
+  fabric_barrier(f);
+  for (int p = 0; p < f->P; p++)  // pull the row range of block `rank` of every peer that has one
+    if (recv_bytes[p] &&
+        hipMemcpyAsync((char *)recv + (size_t)p * block_bytes + recv_off[p], (const char *)f->send[p] + (size_t)l->rank * block_bytes + recv_off[p],
+                       recv_bytes[p], hipMemcpyDeviceToDevice, st) != hipSuccess)
+      f->error = 1;
+  if (hipStreamSynchronize(st) != hipSuccess) f->error = 1;
+  fabric_barrier(f);
+  return f->error;
+}
+
 static int fabric_allreduce(void *user, void *buf, size_t count, int is_u64, void *stream) {
   FabricLink *l = (FabricLink *)user;
   pf_fabric *f = l->f;
@@ -104,6 +123,7 @@ extern "C" int pf_fabric_attach(pf_fabric *f, pf_ctx *ctx) {
   if (pf_ctx_rank_size(ctx, &l->rank, &P) || P != f->P) { delete l; return 1; }
   l->f = f;
   pf_set_exchange(ctx, fabric_alltoall, l);
+  pf_set_exchange_rows(ctx, fabric_alltoallv, l);
   pf_set_allreduce(ctx, fabric_allreduce, l);
   return 0;
 }

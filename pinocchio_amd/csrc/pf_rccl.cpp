@@ -63,6 +63,17 @@ static int rccl_alltoall(void *user, const void *send, void *recv, size_t bytes,
   }
   return g_api.GroupEnd() ? 1 : 0;
 }
+// the same exchange restricted to one row range per block (band-limited spectra): variable message sizes, empty ones skipped
+static int rccl_alltoallv(void *user, const void *send, void *recv, size_t block_bytes, size_t send_off, size_t send_bytes,
+                          const size_t *recv_off, const size_t *recv_bytes, void *stream) {
+  RcclLink *l = (RcclLink *)user;
+  if (g_api.GroupStart()) return 1;
+  for (int q = 0; q < l->nranks; q++) {
+    if (send_bytes && g_api.Send((const char *)send + (size_t)q * block_bytes + send_off, send_bytes, ncclChar_, q, l->comm, stream)) return 1;
+    if (recv_bytes[q] && g_api.Recv((char *)recv + (size_t)q * block_bytes + recv_off[q], recv_bytes[q], ncclChar_, q, l->comm, stream)) return 1;
+  }
+  return g_api.GroupEnd() ? 1 : 0;
+}
 static int rccl_allreduce(void *user, void *buf, size_t count, int is_u64, void *stream) {
   RcclLink *l = (RcclLink *)user;
   return g_api.AllReduce(buf, buf, count, is_u64 ? ncclUint64_ : ncclDouble_, ncclSum_, l->comm, stream) ? 1 : 0;
@@ -91,6 +102,7 @@ extern "C" int pf_init_rccl(pf_ctx *ctx, const void *id128) {
     return 1;
   }
   pf_set_exchange(ctx, rccl_alltoall, l);
+  pf_set_exchange_rows(ctx, rccl_alltoallv, l);
   pf_set_allreduce(ctx, rccl_allreduce, l);
   return 0;
 }

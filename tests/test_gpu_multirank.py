@@ -13,12 +13,16 @@ from pinocchio_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def run_ranks(api, n, P, body, field_bytes=8):
+def run_ranks_timed(api, n, P, body, field_bytes=8):
+    return run_ranks(api, n, P, body, field_bytes, timing=True)
+
+
+def run_ranks(api, n, P, body, field_bytes=8, timing=False):
     from pinocchio_amd import _lib
     L = _lib.load()
     fab = L.pf_fabric_create(P)
     assert fab
-    ctxs = [api.Fmax(n, rank=r, nranks=P, field_bytes=field_bytes) for r in range(P)]
+    ctxs = [api.Fmax(n, rank=r, nranks=P, field_bytes=field_bytes, timing=timing) for r in range(P)]
     for c in ctxs:
         assert L.pf_fabric_attach(fab, c.h) == 0
     out, err = [None] * P, [None] * P
@@ -328,3 +332,43 @@ def test_build_options_on_slabs(api):
         for name in ("Fmax", "Rmax", "Vel", "Vel_2LPT", "Vel_3LPT_1"):
             assert np.array_equal(a[name], a1[name][sl]), name
         assert np.array_equal(b["Fmax"], b1["Fmax"][sl]) and np.array_equal(b["Rmax"], b1["Rmax"][sl])
+
+
+@pytest.mark.parametrize("P,pipeline", [(2, 1), (4, 1), (8, 0), (16, 1)])
+def test_band_limited_radii_exchange_only_their_rows(api, P, pipeline, monkeypatch):
+    """smoothing radii whose window is below 2^-60 beyond |k| = band: only the in-band slab rows of each block go
+    through the all-to-all (pf_alltoallv_fn); same products bit for bit as one rank, and as whole-block exchanges,
+    with fewer bytes on the wire"""
+    n = 64
+    nxl = n // P
+    monkeypatch.setenv("PF_PIPELINE", str(pipeline))
+    dk = synth.make_density(n, seed=23)
+    radii = np.array([8.0, 6.0, 4.0, 3.2, 1.0, 0.0])           # bands 12, 16, 24, 30, none, none of 32
+    x, y = synth.invgrow_table("lcdm")
+    g = synth.growth_multipliers()
+
+    def body(f, r):
+        f.set_density(dk[r * nxl:(r + 1) * nxl])
+        f.set_invgrow(x, y); f.set_growth(g)
+        f.reset_kernel_stats()
+        tv = f.compute_fmax(radii, do_lpt=True)
+        ex = [k for k in f.kernel_stats() if k["name"] == "exchange"]
+        return tv, f.products(), (ex[0]["alg_bytes"] if ex else 0.0)
+
+    with api.Fmax(n) as f1:
+        f1.set_density(dk); f1.set_invgrow(x, y); f1.set_growth(g)
+        tv1 = f1.compute_fmax(radii, do_lpt=True)
+        p1 = f1.products()
+    out = {}
+    for rows in ("1", "0"):
+        monkeypatch.setenv("PF_EXCHANGE_ROWS", rows)
+        out[rows] = run_ranks_timed(api, n, P, body)
+    for r in range(P):
+        sl = slice(r * nxl, (r + 1) * nxl)
+        for rows in ("1", "0"):
+            tv, p, nbytes = out[rows][r]
+            assert np.allclose(tv, tv1, rtol=1e-13)
+            for name in ("Fmax", "Rmax", "Vel", "Vel_2LPT", "Vel_3LPT_1"):
+                assert np.array_equal(p[name], p1[name][sl]), (rows, name)
+    sent = {rows: sum(o[2] for o in out[rows]) for rows in ("1", "0")}
+    assert 0.0 < sent["1"] < 0.9 * sent["0"], sent      # 4 of 6 radii pruned to 39-95 % of their rows, LPT exchanges whole
