@@ -4,7 +4,8 @@ all-to-all and the small all-reduces of one rank's context.
 kind="rccl":  the library's own exchange (csrc/pf_rccl.cpp: grouped
               ncclSend/ncclRecv over xGMI); torch.distributed only broadcasts
               the 128-byte ncclUniqueId.
-kind="torch": every exchange is a torch.distributed all_to_all_single on
+kind="torch": every exchange is a torch.distributed all_to_all_single (all_to_all with
+              per-sender sizes for the row-range form of the band-limited radii) on
               tensors that alias the library's device buffers (backend "nccl"
               = RCCL on ROCm), enqueued on the library's stream.
 
@@ -53,6 +54,20 @@ def install_exchange(f, dist, torch, kind: str = "rccl"):
             print("exchange callback failed:", e, flush=True)
             return 1
 
+    def _a2av(user, send, recv, block_bytes, send_off, send_bytes, recv_off, recv_bytes, stream):
+        # row-range form (band-limited radii): per-sender sizes, empty messages allowed
+        try:
+            s = torch.as_tensor(_DevMem(send, block_bytes * world), device="cuda")
+            r = torch.as_tensor(_DevMem(recv, block_bytes * world), device="cuda")
+            ins = [s[q * block_bytes + send_off:q * block_bytes + send_off + send_bytes] for q in range(world)]
+            outs = [r[p * block_bytes + recv_off[p]:p * block_bytes + recv_off[p] + recv_bytes[p]] for p in range(world)]
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+                dist.all_to_all(outs, ins)
+            return 0
+        except Exception as e:  # noqa: BLE001
+            print("row-range exchange callback failed:", e, flush=True)
+            return 1
+
     def _ared(user, buf, count, is_u64, stream):
         try:
             if is_u64:
@@ -68,6 +83,8 @@ def install_exchange(f, dist, torch, kind: str = "rccl"):
 
     cb1 = _lib.ALLTOALL_FN(_a2a)
     cb2 = _lib.ALLREDUCE_FN(_ared)
+    cb3 = _lib.ALLTOALLV_FN(_a2av)
     f._chk(L.pf_set_exchange(f.h, cb1, None))
+    f._chk(L.pf_set_exchange_rows(f.h, cb3, None))
     f._chk(L.pf_set_allreduce(f.h, cb2, None))
-    return (cb1, cb2)
+    return (cb1, cb2, cb3)
