@@ -378,6 +378,13 @@ static int exchange(pf_ctx *c, const void *send, void *recv, hipStream_t st = nu
 // transforms are laid out [q][y_local][x_local][nzp], so the in-band rows of a rank are ONE contiguous piece at the
 // same offset in each of its P send blocks: rank p owns ky = p*nyl .. (p+1)*nyl - 1, in band if ky <= band or
 // ky >= n - band (one interval per rank once P >= 2, band < n/2).  Ranks without in-band rows send nothing.
+// ... and of those rows only the in-band kz columns: the blocks of a pruned item use the compact row pitch below
+// (a multiple of 8 complex = 128 bytes) instead of nzp, in the x-pass output, the exchange and the y-pass input alike
+static int band_zpitch(const pf_ctx *c, int band) {
+  if (c->P == 1 || band >= c->n / 2) return c->nzp;
+  const int zp = (band + 1 + 7) & ~7;
+  return zp < c->nzp ? zp : c->nzp;
+}
 static void band_rows(const pf_ctx *c, int p, int band, int *lo, int *hi) {
   const int y0 = p * c->nyl, y1 = y0 + c->nyl;  // global ky range of rank p
   *lo = *hi = 0;
@@ -389,7 +396,7 @@ static int exchange_band(pf_ctx *c, const void *send, void *recv, int band, hipS
   const bool rows_off = getenv("PF_EXCHANGE_ROWS") && !atoi(getenv("PF_EXCHANGE_ROWS"));  // 0: always whole blocks
   if (band >= c->n / 2 || !c->a2av || rows_off) return exchange(c, send, recv, st);
   if (!st) st = c->stream;
-  const size_t row_bytes = (size_t)c->nxl * c->nzp * 2 * c->fb, block_bytes = c->field_bytes / c->P;
+  const size_t row_bytes = (size_t)c->nxl * band_zpitch(c, band) * 2 * c->fb, block_bytes = c->field_bytes / c->P;
   std::vector<size_t> roff(c->P), rbytes(c->P);
   size_t total = 0;
   for (int p = 0; p < c->P; p++) {
@@ -419,11 +426,12 @@ static PfAddr addr_blocks_y(const pf_ctx *c) {  // P blocks [p][nxl][nyl][nzp], 
   PfAddr a; a.os = (long long)c->nyl * c->nzp; a.el_shift = ilog2i(c->nyl); a.ehs = (long long)c->nxl * c->nyl * c->nzp; a.els = c->nzp; return a;
 }
 // inverse transforms, P > 1: send / receive blocks with the slab row slowest, [q][y_local][x_local][nzp]
-static PfAddr addr_yblocks_x(const pf_ctx *c) {  // x-pass output: e = x = q*nxl + xl, outer = y_local
-  PfAddr a; a.os = (long long)c->nxl * c->nzp; a.el_shift = ilog2i(c->nxl); a.ehs = (long long)c->nyl * c->nxl * c->nzp; a.els = c->nzp; return a;
+// zp: row pitch inside the blocks (nzp, or the compact pitch of a band-limited item); the blocks keep their places
+static PfAddr addr_yblocks_x(const pf_ctx *c, int zp) {  // x-pass output: e = x = q*nxl + xl, outer = y_local
+  PfAddr a; a.os = (long long)c->nxl * zp; a.el_shift = ilog2i(c->nxl); a.ehs = (long long)c->nyl * c->nxl * c->nzp; a.els = zp; return a;
 }
-static PfAddr addr_yblocks_y(const pf_ctx *c) {  // y-pass input: e = y = p*nyl + yl, outer = x_local
-  PfAddr a; a.os = c->nzp; a.el_shift = ilog2i(c->nyl); a.ehs = (long long)c->nyl * c->nxl * c->nzp; a.els = (long long)c->nxl * c->nzp; return a;
+static PfAddr addr_yblocks_y(const pf_ctx *c, int zp) {  // y-pass input: e = y = p*nyl + yl, outer = x_local
+  PfAddr a; a.os = zp; a.el_shift = ilog2i(c->nyl); a.ehs = (long long)c->nyl * c->nxl * c->nzp; a.els = (long long)c->nxl * zp; return a;
 }
 static PfAddr addr_xs_y(const pf_ctx *c) {  // XS layout, e = y, outer = x_local
   PfAddr a; a.os = (long long)c->n * c->nzp; a.el_shift = ilog2i(c->n); a.ehs = 0; a.els = c->nzp; return a;
@@ -437,7 +445,7 @@ static int xpass(pf_ctx *c, int kind, int dir, int njobs, const Job *jobs, int p
   p.njobs = njobs;
   for (int j = 0; j < njobs; j++) { p.job[j].in = jobs[j].in; p.job[j].out = jobs[j].out; p.job[j].mul = jobs[j].mul; }
   p.ain = p.aout = addr_ky_x(c);
-  if (out_yblocks && c->P > 1) p.aout = addr_yblocks_x(c);
+  if (out_yblocks && c->P > 1) p.aout = addr_yblocks_x(c, band_zpitch(c, band));
   p.ncols = c->nzh; p.nouter = c->nyl; p.pre = pre; p.outer_offset = c->rank * c->nyl; p.rs = rs; p.growth = growth; p.tw = c->tw;
   p.etab = c->etab;
   if (pre && rs != 0.0) PFCHK(c, pf_launch_exp_table(c->etab, c->n, rs, c->stream));  // stream order: after the previous x-pass
@@ -458,7 +466,7 @@ static int ypass(pf_ctx *c, int kind, int dir, int njobs, const Job *jobs, bool 
   PfStridedParams p; memset(&p, 0, sizeof(p));
   p.njobs = njobs;
   for (int j = 0; j < njobs; j++) { p.job[j].in = jobs[j].in; p.job[j].out = jobs[j].out; p.job[j].mul = jobs[j].mul; }
-  p.ain = in_blocks ? ((in_yblocks && c->P > 1) ? addr_yblocks_y(c) : addr_blocks_y(c)) : addr_xs_y(c);
+  p.ain = in_blocks ? ((in_yblocks && c->P > 1) ? addr_yblocks_y(c, band_zpitch(c, band)) : addr_blocks_y(c)) : addr_xs_y(c);
   p.aout = out_blocks ? addr_blocks_y(c) : addr_xs_y(c);
   p.ncols = c->nzh; p.nouter = c->nxl; p.pre = 0; p.outer_offset = 0; p.rs = 0; p.growth = 1; p.tw = c->tw;
   p.band_e = p.band_outer = c->n;
