@@ -131,11 +131,12 @@ def test_synth_density_is_decomposition_independent(api):
         assert np.mean(d > 0) < 1e-3 and d.max() < 1e-3
 
 
-def test_fp32_fields_two_ranks(api):
-    n, P = 64, 2
+@pytest.mark.parametrize("P", [2, 8])
+def test_fp32_fields_on_slabs(api, P):
+    n = 64
     dk = synth.make_density(n, seed=5)
     x, y = synth.invgrow_table("lcdm")
-    radii = np.array([2.0, 0.0])
+    radii = np.array([7.0, 4.0, 2.0, 0.0])        # the first two are band-limited: in-band rows and columns only on the wire
     nxl = n // P
 
     def body(f, r):
