@@ -19,7 +19,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, rs, q):
+def _worker(rank, world, port, n, rs, q, prune=False):
     try:
         sys.path.insert(0, HERE)
         sys.path.insert(0, os.path.dirname(HERE))
@@ -34,7 +34,7 @@ def _worker(rank, world, port, n, rs, q):
         dk = synth.make_density(n, seed=23)
         dk[0, 0, 0] = 0.4 * n ** 3
         nxl = n // world
-        got = slab_model.hessian_slab(dist, torch, dk[rank * nxl:(rank + 1) * nxl], rs)
+        got = slab_model.hessian_slab(dist, torch, dk[rank * nxl:(rank + 1) * nxl], rs, prune=prune)
         o = oracle_lib.Oracle(n, 1)
         o.set_density(dk)
         want = o.second_derivatives(rs)
@@ -54,6 +54,30 @@ def test_slab_model_matches_oracle(world, n, rs):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, n, rs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, err in res:
+        assert isinstance(err, float), (rank, err)
+        assert err < 1e-12, (rank, err)
+
+
+@pytest.mark.parametrize("world,n,rs", [(2, 32, 6.0), (4, 32, 4.0)])
+def test_band_limited_exchange_model_matches_oracle(world, n, rs):
+    """the band-limited form of the exchange (in-band slab rows x in-band kz columns only, one interval of rows per
+    rank) on gloo: still the oracle's second derivatives, to the window weight that was dropped (< 2^-56 of the rms)"""
+    import slab_model
+    band = slab_model.hess_band(n, rs)
+    assert band < n // 2
+    rows = [slab_model.band_rows(n, world, p, band) for p in range(world)]
+    assert sum(hi - lo for lo, hi in rows) == 2 * band + 1          # every in-band ky exactly once
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, rs, q, True)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
