@@ -13,68 +13,96 @@
 
 #include <stddef.h>
 
-#define NBINS 210      /* src/pinocchio.h:65 */
-#define LBLENGTH 400   /* :57 */
-#define SBLENGTH 100   /* :58 */
-#define MAXOUTPUTS 100 /* :62 */
-#define ALIGN 32
-#define _x_ 0
-#define _y_ 1
-#define _z_ 2
+/* sizes and axis names the adapter uses (src/pinocchio.h:56-65, 84-85) */
+enum { NBINS = 210, LBLENGTH = 400, SBLENGTH = 100, MAXOUTPUTS = 100, ALIGN = 32 };
+enum { _x_ = 0, _y_ = 1, _z_ = 2 };
 
 typedef float PRODFLOAT; /* :219-225, no DOUBLE_PRECISION_PRODUCTS */
 
-typedef struct /* src/pinocchio.h:233-259 */
+/* One mirror per reference struct: same member names, types and order (the adapter source compiles against either),
+   one member per line with the field's role on the path. */
+typedef struct product_data_mirror /* src/pinocchio.h:233-259, -DTWO_LPT -DTHREE_LPT */
 {
-  int Rmax;
-  PRODFLOAT Fmax, Vel[3];
-  PRODFLOAT Vel_2LPT[3];
-  PRODFLOAT Vel_3LPT_1[3], Vel_3LPT_2[3];
+  int       Rmax;           /* index of the smoothing radius that gave Fmax */
+  PRODFLOAT Fmax;           /* 1 + z of collapse */
+  PRODFLOAT Vel[3];         /* Zel'dovich displacement */
+  PRODFLOAT Vel_2LPT[3];    /* 2LPT */
+  PRODFLOAT Vel_3LPT_1[3];  /* 3LPT, first term */
+  PRODFLOAT Vel_3LPT_2[3];  /* 3LPT, second term */
 #ifdef RECOMPUTE_DISPLACEMENTS /* the reference's default Makefile flags: 104-byte record */
-  PRODFLOAT Vel_prev[3];
-  PRODFLOAT Vel_2LPT_prev[3];
-  PRODFLOAT Vel_3LPT_1_prev[3], Vel_3LPT_2_prev[3];
+  PRODFLOAT Vel_prev[3];        /* the four above at the previous redshift segment, */
+  PRODFLOAT Vel_2LPT_prev[3];   /* filled by fragment.c's shift_all_displacements */
+  PRODFLOAT Vel_3LPT_1_prev[3];
+  PRODFLOAT Vel_3LPT_2_prev[3];
 #endif
-} product_data __attribute__((aligned(ALIGN)));
+} product_data __attribute__((aligned(32))); /* on the typedef, as in the reference: aligns objects, does not pad the record */
 
-typedef struct /* :284-292 */
+typedef struct smoothing_data_mirror /* :284-292 */
 {
-  int Nsmooth;
-  double *Radius, *Variance, *TrueVariance;
+  int     Nsmooth;        /* number of smoothing radii */
+  double *Radius;         /* Mpc */
+  double *Variance;       /* expected, from P(k) */
+  double *TrueVariance;   /* measured on the grid: written by the path */
 } smoothing_data;
 
-typedef struct /* :295-308, without the pfft plans */
+typedef struct grid_data_mirror /* :295-308, without the pfft plans */
 {
-  unsigned int total_local_size, total_local_size_fft;
-  unsigned int off, ParticlesPerTask;
-  ptrdiff_t GSglobal[3];
-  ptrdiff_t GSlocal[3];
-  ptrdiff_t GSstart[3];
-  ptrdiff_t GSlocal_k[3];
-  ptrdiff_t GSstart_k[3];
-  double lower_k_cutoff, upper_k_cutoff, norm, BoxSize, CellSize;
+  unsigned int       total_local_size;      /* real cells of this task */
+  unsigned int       total_local_size_fft;  /* doubles of the half-spectrum of this task */
+  unsigned int       off;
+  unsigned int       ParticlesPerTask;
+  ptrdiff_t          GSglobal[3];
+  ptrdiff_t          GSlocal[3];
+  ptrdiff_t          GSstart[3];
+  ptrdiff_t          GSlocal_k[3];
+  ptrdiff_t          GSstart_k[3];
+  double             lower_k_cutoff;
+  double             upper_k_cutoff;
+  double             norm;                  /* 1 / Ntotal */
+  double             BoxSize;
+  double             CellSize;
   unsigned long long Ntotal;
 } grid_data;
 
-typedef struct /* :536-542 */
+typedef struct ScaleDep_data_mirror /* :536-542 */
 {
-  int nseg, myseg, no_interp, order;
-  double z[MAXOUTPUTS], D[MAXOUTPUTS], D2[MAXOUTPUTS], D31[MAXOUTPUTS], D32[MAXOUTPUTS];
+  int    nseg;
+  int    myseg;
+  int    no_interp;
+  int    order;            /* which growth multiplier compute_derivative applies: 0 none, 1..4 */
+  double z[100];           /* MAXOUTPUTS redshift segments */
+  double D[100];
+  double D2[100];
+  double D31[100];
+  double D32[100];
   double redshift;
 } ScaleDep_data;
 
-typedef struct /* :368-378, the accumulators the path fills */
+typedef struct cputime_data_mirror /* :368-378, the accumulators the path fills */
 {
-  double fft, coll, lpt, fmax, io, deriv, mem_transf;
+  double fft;
+  double coll;
+  double lpt;
+  double fmax;
+  double io;
+  double deriv;
+  double mem_transf;
 } cputime_data;
 
-typedef struct /* the tags of param_data (:311-352) the path uses */
+typedef struct param_data_mirror /* the tags of param_data (:311-352) the path uses; stand-alone order */
 {
-  char RunFlag[SBLENGTH], DumpDir[SBLENGTH];
-  int GridSize[3], RandomSeed;
-  double Omega0, OmegaBaryon, Hubble100, Sigma8, PrimordialIndex, BoxSize_htrue; /* read by pf_compat_genic only */
-  double OmegaLambda;        /* with Omega0 and Hubble100 in the header of the collapse-time table file */
-  char CTtableFile[LBLENGTH]; /* "none": compute the tables (TABULATED_CT build) */
+  char   RunFlag[100];
+  char   DumpDir[100];
+  int    GridSize[3];
+  int    RandomSeed;
+  double Omega0;              /* the next six: read by pf_compat_genic only */
+  double OmegaBaryon;
+  double Hubble100;
+  double Sigma8;
+  double PrimordialIndex;
+  double BoxSize_htrue;
+  double OmegaLambda;         /* with Omega0 and Hubble100 in the header of the collapse-time table file */
+  char   CTtableFile[400];    /* "none": compute the tables (TABULATED_CT build) */
 } param_data;
 
 /* gsl_spline as far as my_spline_eval dereferences it (src/cosmo.c:2016-2027) */
