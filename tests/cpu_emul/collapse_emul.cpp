@@ -71,3 +71,11 @@ extern "C" int emul_spline_lut(const double *sx, const double *sy, int nk, const
 extern "C" void emul_div_const(const double *x, long count, double *q9, double *q54) {
   for (long i = 0; i < count; i++) { q9[i] = pf_div_const<9>(x[i]); q54[i] = pf_div_const<54>(x[i]); }
 }
+
+extern "C" void emul_log10(const double *x, long count, double *out) {
+  for (long i = 0; i < count; i++) out[i] = pf_log10_pos(x[i]);
+}
+
+extern "C" void emul_acos(const double *x, long count, double *out) {
+  for (long i = 0; i < count; i++) out[i] = pf_acos_series(x[i]);
+}

@@ -179,3 +179,41 @@ def test_division_by_constant_is_correctly_rounded(emul):
     keep = np.abs(x) > 1e-290            # the residual trick needs x c and the residual to stay normal
     assert np.array_equal(a[keep], (x / 9.0)[keep]) and np.array_equal(b[keep], (x / 54.0)[keep])
     assert np.allclose(a[~keep], (x / 9.0)[~keep], rtol=1e-15, atol=1e-320)
+
+
+def test_log10_of_the_fast_flavour(emul):
+    """pf_log10_pos against the correctly rounded value (numpy longdouble): within 2 ulp over the whole positive range,
+    relative to log10 itself also next to x = 1 where the result passes through zero"""
+    emul.emul_log10.argtypes = [dp, C.c_long, dp]
+    rng = np.random.default_rng(4)
+    x = np.concatenate([10.0 ** rng.uniform(-300, 300, 200000), 10.0 ** rng.uniform(-5, 2, 400000), 1.0 + rng.uniform(-1e-3, 1e-3, 100000),
+                        1.0 + rng.uniform(-1e-9, 1e-9, 1000), [1.0, 2.0, 0.5, 10.0, 0.1, 0.70710678118654752, 1.4142135623730951, 1e-5, 5.0]])
+    got = np.empty(len(x))
+    emul.emul_log10(_dp(x), len(x), _dp(got))
+    want = (np.log(x.astype(np.longdouble)) / np.log(np.longdouble(10))).astype(np.float64)
+    ulp = np.spacing(np.abs(want))
+    bad = np.abs(got - want) > 2 * ulp
+    assert not bad.any(), (x[bad][:5], got[bad][:5], want[bad][:5])
+    assert got[len(x) - 9] == 0.0          # log10(1)
+
+
+def test_acos_of_the_fast_flavour(emul):
+    """pf_acos_series against the correctly rounded value (mpmath, 40 digits): within 2 ulp on [-1, 1], dense next to the
+    branch points +-1/2 and the end points; NaN outside"""
+    import mpmath as mp
+    mp.mp.dps = 40
+    emul.emul_acos.argtypes = [dp, C.c_long, dp]
+    rng = np.random.default_rng(8)
+    x = np.concatenate([rng.uniform(-1, 1, 20000), 1.0 - 10.0 ** rng.uniform(-16, 0, 5000), -1.0 + 10.0 ** rng.uniform(-16, 0, 5000),
+                        0.5 + rng.uniform(-1e-6, 1e-6, 2000), -0.5 + rng.uniform(-1e-6, 1e-6, 2000), 10.0 ** rng.uniform(-300, -1, 2000),
+                        [0.0, 1.0, -1.0, 0.5, -0.5, np.nextafter(1.0, 0.0), np.nextafter(-1.0, 0.0)]])
+    x = np.clip(x, -1.0, 1.0)
+    got = np.empty(len(x))
+    emul.emul_acos(_dp(x), len(x), _dp(got))
+    want = np.array([float(mp.acos(mp.mpf(float(v)))) for v in x])
+    ulp = np.spacing(np.maximum(np.abs(want), 1e-300))
+    bad = np.abs(got - want) > 2 * ulp
+    assert not bad.any(), (x[bad][:5], got[bad][:5], want[bad][:5])
+    out = np.empty(3)
+    emul.emul_acos(_dp(np.array([1.0000001, -1.5, np.nan])), 3, _dp(out))
+    assert np.all(np.isnan(out))
