@@ -86,6 +86,7 @@ PROTOTYPES = {
     "pf_set_tabulated_ct": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double)]),
     "pf_ct_build": (C.c_int, [_vp, C.c_int, C.c_double, C.POINTER(C.c_double)]),
     "pf_ct_load": (C.c_int, [_vp, C.c_int, C.c_double, C.POINTER(C.c_double)]),
+    "pf_debug_math": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_double)]),
     "pf_update_products": (C.c_int, [_vp, _vp, C.POINTER(ProductLayout)]),
     "pf_set_growth_table": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_double, C.c_double, C.c_double]),
     "pf_get_second_derivative": (C.c_int, [_vp, C.c_int, _dp]),

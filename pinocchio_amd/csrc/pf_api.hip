@@ -1371,6 +1371,20 @@ extern "C" int pf_collapse_cells(pf_ctx *c, int ismooth, const double *d, size_t
   return 0;
 }
 
+// test tap: elementary functions of the solver's fast flavour on the device, which = 0 a/b, 1 sqrt a, 2 acos a, 3 log10 a,
+// 4 sin (b != 0) or cos (b == 0) of a in [0, pi/3], 5 a^0.333333333333333, 6 a/9
+extern "C" int pf_debug_math(pf_ctx *c, int which, const double *a, const double *b, size_t count, double *out) {
+  if (!c || !a || !b || !out) return 1;
+  if (count * 3 * sizeof(double) > 2 * c->field_bytes) return pf_fail(c->rank, "pf_debug_math: %zu values exceed the staging area", count);
+  double *da = (double *)staging(c), *db = da + count, *dout = db + count;
+  HIPCHK(c, hipMemcpyAsync(da, a, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(db, b, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  PFCHK(c, pf_launch_debug_math(which, da, db, count, dout, c->stream));
+  HIPCHK(c, hipMemcpyAsync(out, dout, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 // ------------------------------------------------------------- measurement --
 extern "C" int pf_get_cputime(pf_ctx *c, pf_cputime *t) {
   if (!c || !t) return 1;

@@ -178,6 +178,28 @@ __global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse_cells(const double *
   }
 }
 
+// test tap: the elementary functions of the fast flavour evaluated on the device (pf_debug_math)
+__global__ void __launch_bounds__(PF_CELL_BLOCK) k_debug_math(int which, const double *a, const double *b, size_t count, double *out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    double r = 0.0;
+    switch (which) {
+      case 0: r = pf_div_fast(a[i], b[i]); break;
+      case 1: r = pf_sqrt_fast(a[i]); break;
+      case 2: r = pf_acos_series(a[i]); break;
+      case 3: r = pf_log10_pos(a[i]); break;
+      case 4: { double sn, cs; pf_sincos_third(a[i], sn, cs); r = b[i] != 0.0 ? sn : cs; } break;
+      case 5: r = pf_pow_third<true>(a[i]); break;
+      case 6: r = pf_div_const<9>(a[i]); break;
+      default: break;
+    }
+    out[i] = r;
+  }
+}
+int pf_launch_debug_math(int which, const double *a, const double *b, size_t count, double *out, hipStream_t st) {
+  hipLaunchKernelGGL(k_debug_math, dim3(256), dim3(PF_CELL_BLOCK), 0, st, which, a, b, count, out);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 // K7 (src/LPT.c:64-93)
 template <typename F>
 __global__ void __launch_bounds__(PF_CELL_BLOCK) k_lpt_sources(const PfLptSrcParams p) {

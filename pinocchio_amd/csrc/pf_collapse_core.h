@@ -128,6 +128,37 @@ PF_HD void pf_sincos_third(double x, double &sn, double &cs) {
   for (int i = 10; i < 18; i++) pc = fma(pc, z, pf_sc_coef[i]);
   cs = fma(z * z, pc, fma(-0.5, z, 1.0));
 }
+// Division and square root of the fast flavour on the device: the hardware seeds (v_rcp_f64, v_rsq_f64) refined by
+// Newton / Goldschmidt steps and one final residual correction -- 8 and 13 operations instead of the 12 and 22 of the
+// IEEE expansions, which spend the difference on operand scaling for the subnormal and overflow ranges.  The arguments
+// here are the cubic's coefficients and discriminants (normal range; zero handled); the result is the correctly rounded
+// one except for rare 1-ulp cases.  The host build (tests) and the exact flavour keep the plain operators.
+PF_HD double pf_div_fast(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(b);
+  r = fma(fma(-b, r, 1.0), r, r);
+  r = fma(fma(-b, r, 1.0), r, r);
+  const double q = a * r;
+  return fma(fma(-b, q, a), r, q);
+#else
+  return a / b;
+#endif
+}
+PF_HD double pf_sqrt_fast(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (!(x > 0.0)) return x == 0.0 ? x : sqrt(x);  // zero, negative and NaN as the library
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  return fma(fma(-g, g, x), h, g);
+#else
+  return sqrt(x);
+#endif
+}
+
 // x / Y for a constant Y, correctly rounded, in three operations (Markstein): with c = RN(1/Y), q0 = RN(x c),
 // the residual x - Y q0 is exact in an fma and q0 + residual c rounds to RN(x / Y) -- the same double the
 // reference's division produces, so the q^3 < r^2 sentinel test sees the reference's own q and r
@@ -154,11 +185,12 @@ template <bool FAST> PF_HD void pf_cos3(double t, double &c1, double &c2, double
 }
 template <bool FAST> PF_HD double pf_pow_third(double x) {
   if (!FAST) return pow(x, 0.333333333333333);
-  // x^(1/3 - d) = cbrt(x) exp(-d ln x), d = 3.33e-16: ln x is needed to ~1e-2 only
+  // x^(1/3 - d) = cbrt(x) exp(-d ln x); d = 1/3 - (the double nearest to 0.333333333333333) = 3.5157e-16, so ln x is
+  // needed to ~1e-2 only
   int e;
   const double m = frexp(x, &e);
   const double lnx = 0.6931471805599453 * (double)e + (double)logf((float)m);
-  return cbrt(x) * (1.0 - 3.3306690738754696e-16 * lnx);
+  return cbrt(x) * (1.0 - 3.515706244646329e-16 * lnx);
 }
 template <bool FAST> PF_HD double pf_pow10(double y) {
   if (!FAST) return pow(10., y);
@@ -173,7 +205,7 @@ PF_HD double pf_acos_series(double x) {
   const double a = fabs(x);
   const bool big = a >= 0.5;
   const double z = big ? 0.5 * (1.0 - a) : a * a;
-  const double s = big ? sqrt(z) : a;
+  const double s = big ? pf_sqrt_fast(z) : a;
   double r = 2.87578513674215663e-02;
   r = fma(r, z, -1.48518870712472037e-02);
   r = fma(r, z, 1.74008794426940214e-02);
@@ -201,7 +233,7 @@ PF_HD double pf_log10_pos(double x) {
   double m = frexp(x, &e);                        // m in [0.5, 1)
   if (m < 0.70710678118654752440) { m += m; e -= 1; }
   const double f = m - 1.0;
-  const double s = f / (2.0 + f);
+  const double s = pf_div_fast(f, 2.0 + f);
   const double z = s * s;
   const double w = z * z;
   const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
@@ -242,7 +274,7 @@ template <bool FAST = false> PF_HD double pf_ell_classic(double l1, double l2, d
         }
       }
     } else {
-      const double rden = 1.0 / den;
+      const double rden = FAST ? pf_div_fast(1.0, den) : 1.0 / den;
       const double a1 = FAST ? 3. * l1 * (del - l1) * (1. / 14.) * rden : 3. * l1 * (del - l1) / 14. * rden;
       const double a1_2 = a1 * a1;
       const double a2 = l1 * rden;
@@ -253,15 +285,15 @@ template <bool FAST = false> PF_HD double pf_ell_classic(double l1, double l2, d
       const double r_2_q_3 = r * r - q * q * q;
       if (r_2_q_3 > 0) {
         const double fabs_r = fabs(r);
-        const double sq = pf_pow_third<FAST>(sqrt(r_2_q_3) + fabs_r);
+        const double sq = pf_pow_third<FAST>((FAST ? pf_sqrt_fast(r_2_q_3) : sqrt(r_2_q_3)) + fabs_r);
         // fabs(r)/r is +-1 for every finite non-zero r (and NaN at r = 0, kept)
-        ell = FAST ? -(r != 0. ? copysign(1.0, r) : fabs_r / r) * (sq + q / sq) - a1 * (1.0 / 3)
+        ell = FAST ? -(r != 0. ? copysign(1.0, r) : fabs_r / r) * (sq + pf_div_fast(q, sq)) - a1 * (1.0 / 3)
                    : -fabs_r / r * (sq + q / sq) - a1 / 3.;
         if (ell < 0.) ell = -.1;
       } else {
-        const double sq = 2 * sqrt(q);
+        const double sq = 2 * (FAST ? pf_sqrt_fast(q) : sqrt(q));
         const double inv_3 = 1.0 / 3;
-        const double t = FAST ? pf_acos_series(2 * r / (q * sq)) : acos(2 * r / q / sq);
+        const double t = FAST ? pf_acos_series(pf_div_fast(2 * r, q * sq)) : acos(2 * r / q / sq);
         double c1, c2, c3;
         pf_cos3<FAST>(t, c1, c2, c3);
         double s1 = -sq * c1 - a1 * inv_3;
@@ -277,7 +309,7 @@ template <bool FAST = false> PF_HD double pf_ell_classic(double l1, double l2, d
     }
   }
   if (del > 0. && ell > 0.) {
-    const double inv_del = 1.0 / del;
+    const double inv_del = FAST ? pf_div_fast(1.0, del) : 1.0 / del;
     ell += -.364 * inv_del * exp(-6.5 * (l1 - l2) * inv_del - 2.8 * (l2 - l3) * inv_del);
   }
   return ell;
@@ -304,8 +336,8 @@ template <bool FAST = false> PF_HD bool pf_ordered_eigenvalues(const double d[6]
       lam[0] = lam[1] = lam[2] = 0.0;
       return false;
     }
-    const double sq = 2 * sqrt(q);
-    const double t = FAST ? pf_acos_series(2 * r / (q * sq)) : acos(2 * r / q / sq);
+    const double sq = 2 * (FAST ? pf_sqrt_fast(q) : sqrt(q));
+    const double t = FAST ? pf_acos_series(pf_div_fast(2 * r, q * sq)) : acos(2 * r / q / sq);
     const double inv_3 = 1.0 / 3.0;
     double c1, c2, c3;
     pf_cos3<FAST>(t, c1, c2, c3);

@@ -177,6 +177,7 @@ int pf_gfft_create(int n, hipStream_t st, void **c2r, void **r2c);
 int pf_gfft_c2r(void *plan, void *spec, void *real);   // unnormalised, out of place; may destroy spec
 int pf_gfft_r2c(void *plan, void *real, void *spec);   // unnormalised, out of place
 void pf_gfft_destroy(void *plan);
+int pf_launch_debug_math(int which, const double *a, const double *b, size_t count, double *out, hipStream_t st);
 // pf_select_sort.hip
 int pf_select_sort_device(const float *fmax, size_t ncell, float flast, unsigned int **d_idx, float **d_f, size_t *count, hipStream_t st);
 int pf_launch_block_vec3(const float *vel12, size_t ncell, int o, size_t first, size_t count, float *out, hipStream_t st);

@@ -903,3 +903,46 @@ def test_baseline_config_sizes_vs_oracle(api, n, ns, lpt):
             assert np.max(np.abs(p[name].astype(np.float64) - po[name])) <= 4e-7 * np.max(np.abs(po[name])), name
         else:
             assert not p[name].any() and not po[name].any()
+
+
+def test_fast_flavour_elementary_functions_on_the_device(api):
+    """the solver's default arithmetic, function by function, on the device against correctly rounded values (numpy
+    longdouble / mpmath): hardware-seeded division and square root, series acos and log10, sin/cos on [0, pi/3],
+    x^0.333333333333333 and x/9"""
+    import mpmath as mp
+    mp.mp.dps = 40
+    rng = np.random.default_rng(17)
+    ld = np.longdouble
+
+    def run(f, which, a, b=None):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b if b is not None else np.ones_like(a), dtype=np.float64)
+        out = np.empty_like(a)
+        dp = C.POINTER(C.c_double)
+        f._chk(f.L.pf_debug_math(f.h, which, a.ctypes.data_as(dp), b.ctypes.data_as(dp), len(a), out.ctypes.data_as(dp)))
+        return out
+
+    def ulps(got, want):
+        want = np.asarray(want, dtype=np.float64)
+        return np.abs(got - want) / np.spacing(np.maximum(np.abs(want), 1e-300))
+
+    n = 200000
+    with api.Fmax(64) as f:
+        a = rng.standard_normal(n) * 10.0 ** rng.integers(-100, 100, n)
+        b = rng.standard_normal(n) * 10.0 ** rng.integers(-100, 100, n)
+        assert ulps(run(f, 0, a, b), (a.astype(ld) / b.astype(ld))).max() <= 1.0
+        x = np.abs(a)
+        assert ulps(run(f, 1, x), np.sqrt(x.astype(ld))).max() <= 1.0
+        assert run(f, 1, np.array([0.0]))[0] == 0.0 and np.isnan(run(f, 1, np.array([-1.0]))[0])
+        xa = np.concatenate([rng.uniform(-1, 1, 30000), 1.0 - 10.0 ** rng.uniform(-16, 0, 5000), -1.0 + 10.0 ** rng.uniform(-16, 0, 5000), [1.0, -1.0, 0.5, -0.5, 0.0]])
+        xa = np.clip(xa, -1.0, 1.0)
+        want = np.array([float(mp.acos(mp.mpf(float(v)))) for v in xa])
+        assert ulps(run(f, 2, xa), want).max() <= 2.0
+        xl = np.concatenate([10.0 ** rng.uniform(-300, 300, 50000), 10.0 ** rng.uniform(-5, 2, 100000), 1.0 + rng.uniform(-1e-3, 1e-3, 20000)])
+        assert ulps(run(f, 3, xl), np.log(xl.astype(ld)) / np.log(ld(10))).max() <= 2.0
+        th = rng.uniform(0.0, np.pi / 3, 50000)
+        assert ulps(run(f, 4, th, np.ones_like(th)), np.sin(th.astype(ld))).max() <= 2.0
+        assert ulps(run(f, 4, th, np.zeros_like(th)), np.cos(th.astype(ld))).max() <= 2.0
+        xp = 10.0 ** rng.uniform(-30, 30, 50000)
+        assert ulps(run(f, 5, xp), xp.astype(ld) ** ld(0.333333333333333)).max() <= 2.0
+        assert np.array_equal(run(f, 6, a), a / 9.0)
