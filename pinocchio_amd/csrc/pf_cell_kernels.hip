@@ -190,6 +190,8 @@ __global__ void __launch_bounds__(PF_CELL_BLOCK) k_debug_math(int which, const d
       case 4: { double sn, cs; pf_sincos_third(a[i], sn, cs); r = b[i] != 0.0 ? sn : cs; } break;
       case 5: r = pf_pow_third<true>(a[i]); break;
       case 6: r = pf_div_const<9>(a[i]); break;
+      case 7: r = pf_exp_series(a[i]); break;
+      case 8: r = pf_exp10_series(a[i]); break;
       default: break;
     }
     out[i] = r;

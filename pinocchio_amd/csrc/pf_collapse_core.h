@@ -117,6 +117,18 @@ static const double pf_sc_coef[18] = {
     2.7557319223985893e-06,  -1.9841269841269841e-04, 8.3333333333333332e-03,  -1.6666666666666666e-01,
     4.1103176233121648e-19,  -1.5619206968586225e-16, 4.7794773323873853e-14,  -1.1470745597729725e-11, 2.0876756987868100e-09,
     -2.7557319223985888e-07, 2.4801587301587302e-05,  -1.3888888888888889e-03, 4.1666666666666664e-02};
+// One Horner step r z + c as ONE v_fma_f64.  Left to itself the compiler selects the two-address v_fmac_f64 and, because
+// the coefficient is loop invariant and lives on in its VGPR pair, pays a v_mov_b64 copy in front of every step (60 of
+// the 1154 vector instructions of the collapse kernel).  Same operation, same rounding: results do not change.
+PF_HD double pf_horner(double r, double z, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(r), "v"(z), "v"(c));
+  return d;
+#else
+  return fma(r, z, c);
+#endif
+}
 PF_HD void pf_sincos_third(double x, double &sn, double &cs) {
   const double z = x * x;
   double ps = pf_sc_coef[0];
@@ -192,9 +204,44 @@ template <bool FAST> PF_HD double pf_pow_third(double x) {
   const double lnx = 0.6931471805599453 * (double)e + (double)logf((float)m);
   return cbrt(x) * (1.0 - 3.515706244646329e-16 * lnx);
 }
+// exp and 10^y of the fast flavour in 20 and 21 operations (the library calls cost 42 and 44 on gfx950, half of them
+// moves of their coefficients): k = rint(x log2 e), r = x - k ln2 in two steps (fdlibm's split of ln 2), e^r by one
+// degree-11 polynomial on |r| <= ln2 / 2 (1 + r + r^2 g(r), g a Chebyshev fit in 60-digit arithmetic, relative error
+// 1.6e-17 with the coefficients rounded to double), scaled by 2^k.  Within 1 ulp of the correctly rounded value
+// (tests/test_collapse_core.py).  The argument is clamped to the range where the result is finite and non-zero plus one
+// step, so overflow and underflow come out of the scaling as inf and 0; a NaN argument (not reachable from the callers:
+// ordered eigenvalues over a positive trace, a spline value) would give 0.
+PF_HD double pf_exp_reduced(double r) {
+  double p = 2.51003854955103203e-08;
+  p = pf_horner(p, r, 2.76200884454097462e-07);
+  p = pf_horner(p, r, 2.75572684599970641e-06);
+  p = pf_horner(p, r, 2.48015212959543761e-05);
+  p = pf_horner(p, r, 1.98412698630536177e-04);
+  p = pf_horner(p, r, 1.38888889172137167e-03);
+  p = pf_horner(p, r, 8.33333333333006153e-03);
+  p = pf_horner(p, r, 4.16666666666241289e-02);
+  p = pf_horner(p, r, 1.66666666666666685e-01);
+  p = pf_horner(p, r, 5.00000000000000111e-01);
+  p = fma(p, r, 1.0);
+  return fma(p, r, 1.0);
+}
+PF_HD double pf_exp_series(double x) {
+  x = fmin(fmax(x, -746.0), 710.0);  // e^-746 = 0 and e^710 = inf in double: k stays a small integer for every x
+  const double kd = rint(x * 1.44269504088896338700e+00);
+  double r = fma(kd, -6.93147180369123816490e-01, x);
+  r = fma(kd, -1.90821492927058770002e-10, r);
+  return ldexp(pf_exp_reduced(r), (int)kd);
+}
+PF_HD double pf_exp10_series(double y) {
+  y = fmin(fmax(y, -324.0), 309.0);
+  const double kd = rint(y * 3.32192809488736218171e+00);
+  double r = fma(kd, -3.01029995663611771306e-01, y);  // fdlibm's split of log10 2: k hi is exact for |k| < 2^13
+  r = fma(kd, -3.69423907715893078616e-13, r);
+  return ldexp(pf_exp_reduced(r * 2.30258509299404590109e+00), (int)kd);
+}
 template <bool FAST> PF_HD double pf_pow10(double y) {
   if (!FAST) return pow(10., y);
-  return exp10(y);
+  return pf_exp10_series(y);
 }
 
 // acos in ~55 operations (the library call costs 93 on gfx950), the classical reduction of fdlibm's e_acos.c with the
@@ -207,18 +254,18 @@ PF_HD double pf_acos_series(double x) {
   const double z = big ? 0.5 * (1.0 - a) : a * a;
   const double s = big ? pf_sqrt_fast(z) : a;
   double r = 2.87578513674215663e-02;
-  r = fma(r, z, -1.48518870712472037e-02);
-  r = fma(r, z, 1.74008794426940214e-02);
-  r = fma(r, z, 5.45750671864035815e-03);
-  r = fma(r, z, 1.03228143501857793e-02);
-  r = fma(r, z, 1.14791774151849057e-02);
-  r = fma(r, z, 1.39712129735529329e-02);
-  r = fma(r, z, 1.73523927208699726e-02);
-  r = fma(r, z, 2.23721729421498886e-02);
-  r = fma(r, z, 3.03819441385312465e-02);
-  r = fma(r, z, 4.46428571463554288e-02);
-  r = fma(r, z, 7.49999999999843292e-02);
-  r = fma(r, z, 1.66666666666666685e-01);
+  r = pf_horner(r, z, -1.48518870712472037e-02);
+  r = pf_horner(r, z, 1.74008794426940214e-02);
+  r = pf_horner(r, z, 5.45750671864035815e-03);
+  r = pf_horner(r, z, 1.03228143501857793e-02);
+  r = pf_horner(r, z, 1.14791774151849057e-02);
+  r = pf_horner(r, z, 1.39712129735529329e-02);
+  r = pf_horner(r, z, 1.73523927208699726e-02);
+  r = pf_horner(r, z, 2.23721729421498886e-02);
+  r = pf_horner(r, z, 3.03819441385312465e-02);
+  r = pf_horner(r, z, 4.46428571463554288e-02);
+  r = pf_horner(r, z, 7.49999999999843292e-02);
+  r = pf_horner(r, z, 1.66666666666666685e-01);
   const double as = fma(s * z, r, s);  // asin(s)
   if (!big) return (1.57079632679489655800e+00 - copysign(as, x)) + 6.12323399573676603587e-17;
   return x > 0.0 ? 2.0 * as : (3.14159265358979311600e+00 - 2.0 * as) + 1.22464679914735320717e-16;
@@ -248,7 +295,7 @@ PF_HD double pf_log10_pos(double x) {
 }
 
 template <bool FAST = false> PF_HD double pf_inverse_growing_mode(const pf_spline_view &s, double D) {
-  if (FAST) return exp10(-pf_spline_eval(s, pf_log10_pos(D))) - 1.;
+  if (FAST) return pf_exp10_series(-pf_spline_eval(s, pf_log10_pos(D))) - 1.;
   return 1. / pf_pow10<FAST>(pf_spline_eval(s, log10(D))) - 1.;
 }
 
@@ -310,7 +357,8 @@ template <bool FAST = false> PF_HD double pf_ell_classic(double l1, double l2, d
   }
   if (del > 0. && ell > 0.) {
     const double inv_del = FAST ? pf_div_fast(1.0, del) : 1.0 / del;
-    ell += -.364 * inv_del * exp(-6.5 * (l1 - l2) * inv_del - 2.8 * (l2 - l3) * inv_del);
+    const double arg = -6.5 * (l1 - l2) * inv_del - 2.8 * (l2 - l3) * inv_del;
+    ell += -.364 * inv_del * (FAST ? pf_exp_series(arg) : exp(arg));
   }
   return ell;
 }

@@ -217,3 +217,36 @@ def test_acos_of_the_fast_flavour(emul):
     out = np.empty(3)
     emul.emul_acos(_dp(np.array([1.0000001, -1.5, np.nan])), 3, _dp(out))
     assert np.all(np.isnan(out))
+
+
+def test_exp_and_exp10_of_the_fast_flavour(emul):
+    """pf_exp_series / pf_exp10_series against the correctly rounded values (mpmath, 40 digits): within 1 ulp over the
+    ranges the solver uses and over the whole finite range; exact at 0 and at integer powers of ten; inf / 0 beyond"""
+    import mpmath as mp
+    mp.mp.dps = 40
+    emul.emul_exp.argtypes = [dp, C.c_long, dp, dp]
+    rng = np.random.default_rng(21)
+    x = np.concatenate([rng.uniform(-40, 0.5, 20000), rng.uniform(-3.5, 3.5, 20000), rng.uniform(-300, 300, 5000),
+                        rng.uniform(-1e-3, 1e-3, 2000), 10.0 ** rng.uniform(-300, -3, 1000), -10.0 ** rng.uniform(-300, -3, 1000),
+                        0.5 * np.log(2.0) * (2 * np.arange(-20, 21) + 1), [0.0, -0.0, 1.0, -1.0]])
+    e = np.empty(len(x)); e10 = np.empty(len(x))
+    emul.emul_exp(_dp(x), len(x), _dp(e), _dp(e10))
+    want = np.array([float(mp.exp(mp.mpf(float(v)))) for v in x])
+    want10 = np.array([float(mp.power(10, mp.mpf(float(v)))) for v in x])
+    ok = (want > 1e-300) & np.isfinite(want)
+    ok10 = (want10 > 1e-300) & np.isfinite(want10)
+    assert (np.abs(e - want)[ok] <= np.spacing(want[ok])).all()
+    assert (np.abs(e10 - want10)[ok10] <= np.spacing(want10[ok10])).all()
+    k = np.arange(-300.0, 301.0)
+    p10 = np.empty(len(k))
+    emul.emul_exp(_dp(k), len(k), _dp(np.empty(len(k))), _dp(p10))
+    exact = np.array([float(mp.power(10, int(v))) for v in k])
+    assert (np.abs(p10 - exact) <= np.spacing(exact)).all()
+    print("10^k exact for", int(np.sum(p10 == exact)), "of", len(k), "integers; |k| <= 22:", bool(np.array_equal(p10[278:323], exact[278:323])))
+    edge = np.array([0.0, -746.0, -1e10, -np.inf, 710.0, 1e10, np.inf, -324.0, 309.0])
+    a = np.empty(len(edge)); b = np.empty(len(edge))
+    emul.emul_exp(_dp(edge), len(edge), _dp(a), _dp(b))
+    assert a[0] == 1.0 and b[0] == 1.0
+    assert np.all(a[1:4] == 0.0) and np.all(np.isinf(a[4:7]))
+    assert np.all(b[[1, 2, 3, 7]] == 0.0) and np.all(np.isinf(b[[4, 5, 6, 8]]))
+

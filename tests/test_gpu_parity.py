@@ -946,3 +946,11 @@ def test_fast_flavour_elementary_functions_on_the_device(api):
         xp = 10.0 ** rng.uniform(-30, 30, 50000)
         assert ulps(run(f, 5, xp), xp.astype(ld) ** ld(0.333333333333333)).max() <= 2.0
         assert np.array_equal(run(f, 6, a), a / 9.0)
+        xe = np.concatenate([rng.uniform(-40, 0.5, 20000), rng.uniform(-3.5, 3.5, 20000), rng.uniform(-300, 300, 5000), [0.0, 1.0, -1.0]])
+        want = np.array([float(mp.exp(mp.mpf(float(v)))) for v in xe])
+        want10 = np.array([float(mp.power(10, mp.mpf(float(v)))) for v in xe])
+        ok, ok10 = (want > 1e-300) & np.isfinite(want), (want10 > 1e-300) & np.isfinite(want10)
+        assert ulps(run(f, 7, xe)[ok], want[ok]).max() <= 1.0
+        assert ulps(run(f, 8, xe)[ok10], want10[ok10]).max() <= 1.0
+        edge = np.array([-746.0, -1e10, -np.inf, 710.0, np.inf])
+        assert np.array_equal(run(f, 7, edge), [0.0, 0.0, 0.0, np.inf, np.inf])
