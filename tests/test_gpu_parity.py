@@ -331,6 +331,41 @@ def test_properties_at_scale(api, n):
         assert rmax.min() >= 0 and rmax.max() <= 2
 
 
+def test_properties_on_the_box_of_the_metric(api):
+    """1024^3 fp64 (BASELINE.json's box, 226 GB on the device): what can be checked without the oracle and without the
+    60 GB of host products -- normalisation, monotone variances, the histogram, determinism of a repeated sweep, the
+    running maximum over the radii cell by cell (single FMAX / RMAX blocks, 4.3 GB each), and linearity"""
+    n = 1024
+    x, y = synth.invgrow_table("lcdm")
+    radii = synth.radii_ladder(12)[[2, 8, 11]]          # one band-limited radius, one full, R = 0
+    with api.Fmax(n) as f:
+        f.synth_density(synth.SEED, 2.5, -2.0)
+        f.set_invgrow(x, y)
+        tv1 = f.sweep(radii[:1])
+        fm1 = f.block("FMAX")
+        tv = f.sweep(radii)
+        assert tv[0] == tv1[0]
+        assert np.sqrt(tv[-1]) == pytest.approx(2.5, rel=1e-10) and tv[0] < tv[1] < tv[2]
+        pdf = f.Fmax_PDF()
+        assert int(pdf.sum()) == n ** 3
+        fm3 = f.block("FMAX")
+        rm3 = f.block("RMAX")
+        assert np.isfinite(fm3).all() and (fm3 >= fm1).all()       # running maximum
+        moved = rm3 > 0
+        assert rm3.min() >= -1 and rm3.max() == 2 and int((rm3 < 0).sum()) <= 100    # -1: the eigen-solver sentinel, rare
+        assert fm3[rm3 >= 0].min() >= 0.0
+        # a cell moves when the new F exceeds the stored float as doubles (quirk Q2): the float it stores may be the same one
+        assert np.array_equal(fm3[~moved], fm1[~moved]) and float(np.mean(fm3[moved] > fm1[moved])) > 0.999
+        del fm1, moved
+        tv_again = f.sweep(radii)
+        assert np.array_equal(tv_again, tv) and np.array_equal(f.block("FMAX"), fm3) and np.array_equal(f.block("RMAX"), rm3)
+        collapsed = int((fm3 >= 1.0).sum())
+        assert 0.3 * n ** 3 < collapsed < 0.7 * n ** 3   # sigma = 2.5: about half of the cells collapse by z = 0
+        del fm3, rm3
+        f.synth_density(synth.SEED, 5.0, -2.0)           # the same modes, twice the amplitude
+        assert f.sweep(radii[1:]) == pytest.approx(4.0 * tv[1:], rel=1e-12)
+
+
 def test_pruned_transform_equals_full_transform(api, monkeypatch):
     """Smoothed radii use a pruned FFT: modes whose Gaussian weight is < 2^-60 are not transformed.
     Against the full transform (PF_PRUNE_EPS=0) the Hessian changes by less than its own rounding."""
