@@ -171,7 +171,9 @@ def main():
                 pv = json.load(fh)
             if pv["config"] == {"grid": n, "field_bytes": args.field_bytes} and dom["name"] in pv["kernels"]:
                 k = pv["kernels"][dom["name"]]
-                valu = {"insts_per_cell": k["valu_insts_per_cell"], "valu_utilisation": k["valu_utilisation"], "source": "profiles/r01_pmc_valu.json"}
+                valu = {"insts_per_cell": k["valu_insts_per_cell"], "valu_utilisation": k["valu_utilisation"],
+                        "engine_clock_GHz": k.get("engine_clock_GHz_measured"), "valu_utilisation_at_measured_clock": k.get("valu_utilisation_at_measured_clock"),
+                        "source": "profiles/r01_pmc_valu.json"}
         except (OSError, KeyError, ValueError):
             pass
         w = args.field_bytes
