@@ -235,7 +235,8 @@ int pf_reverse_transform(pf_ctx *ctx, const double *spec_host, double *real_host
 int pf_derivative(pf_ctx *ctx, const double *spec_host, int first_derivative, int second_derivative, double rs_cells,
                   int order, double *real_host);
 /* test tap: the elementary functions the solver's default arithmetic uses on the device, which =
-   0 a/b, 1 sqrt(a), 2 acos(a), 3 log10(a), 4 sin (b != 0) or cos (b == 0) of a in [0, pi/3], 5 a^0.333333333333333, 6 a/9 */
+   0 a/b, 1 sqrt(a), 2 acos(a), 3 log10(a), 4 sin (b != 0) or cos (b == 0) of a in [0, pi/3], 5 a^0.333333333333333, 6 a/9,
+   7 exp(a), 8 10^a, 9 / 10 the raw hardware seeds v_rcp_f64(a) / v_rsq_f64(a) */
 int pf_debug_math(pf_ctx *ctx, int which, const double *a, const double *b, size_t count, double *out);
 /* per-cell solver on a list of Hessians d[6*count] -> F[count] (tests of
    inverse_collapse_time, src/collapse_times.c:679-776), ismooth selects the spline */

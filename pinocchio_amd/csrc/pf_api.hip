@@ -1372,7 +1372,7 @@ extern "C" int pf_collapse_cells(pf_ctx *c, int ismooth, const double *d, size_t
 }
 
 // test tap: elementary functions of the solver's fast flavour on the device, which = 0 a/b, 1 sqrt a, 2 acos a, 3 log10 a,
-// 4 sin (b != 0) or cos (b == 0) of a in [0, pi/3], 5 a^0.333333333333333, 6 a/9, 7 exp a, 8 10^a
+// 4 sin (b != 0) or cos (b == 0) of a in [0, pi/3], 5 a^0.333333333333333, 6 a/9, 7 exp a, 8 10^a, 9 / 10 the hardware seeds rcp a / rsq a
 extern "C" int pf_debug_math(pf_ctx *c, int which, const double *a, const double *b, size_t count, double *out) {
   if (!c || !a || !b || !out) return 1;
   if (count * 3 * sizeof(double) > 2 * c->field_bytes) return pf_fail(c->rank, "pf_debug_math: %zu values exceed the staging area", count);

@@ -198,6 +198,8 @@ __global__ void __launch_bounds__(PF_CELL_BLOCK) k_debug_math(int which, const d
       case 6: r = pf_div_const<9>(a[i]); break;
       case 7: r = pf_exp_series(a[i]); break;
       case 8: r = pf_exp10_series(a[i]); break;
+      case 9: r = __builtin_amdgcn_rcp(a[i]); break;
+      case 10: r = __builtin_amdgcn_rsq(a[i]); break;
       default: break;
     }
     out[i] = r;

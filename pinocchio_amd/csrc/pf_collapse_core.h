@@ -141,17 +141,16 @@ PF_HD void pf_sincos_third(double x, double &sn, double &cs) {
   cs = fma(z * z, pc, fma(-0.5, z, 1.0));
 }
 // Division and square root of the fast flavour on the device: the hardware seeds (v_rcp_f64, v_rsq_f64) refined by
-// Newton / Goldschmidt steps and one final residual correction -- 8 and 13 operations instead of the 12 and 22 of the
-// IEEE expansions, which spend the difference on operand scaling for the subnormal and overflow ranges.  The arguments
+// one Newton / Goldschmidt step and one final residual correction -- 6 and 10 operations instead of the 12 and 22 of the
+// IEEE expansions, which spend the difference on a second step and on operand scaling for the subnormal and overflow ranges.  The arguments
 // here are the cubic's coefficients and discriminants (normal range; zero handled); the result is the correctly rounded
 // one except for rare 1-ulp cases.  The host build (tests) and the exact flavour keep the plain operators.
 PF_HD double pf_div_fast(double a, double b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  double r = __builtin_amdgcn_rcp(b);
-  r = fma(fma(-b, r, 1.0), r, r);
-  r = fma(fma(-b, r, 1.0), r, r);
+  double r = __builtin_amdgcn_rcp(b);      // 2^-24.4 (measured, scratch/seedacc.py)
+  r = fma(fma(-b, r, 1.0), r, r);          // 2^-48.8
   const double q = a * r;
-  return fma(fma(-b, q, a), r, q);
+  return fma(fma(-b, q, a), r, q);         // exact residual times r: a second Newton step on r changes no result
 #else
   return a / b;
 #endif
@@ -159,12 +158,10 @@ PF_HD double pf_div_fast(double a, double b) {
 PF_HD double pf_sqrt_fast(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if (!(x > 0.0)) return x == 0.0 ? x : sqrt(x);  // zero, negative and NaN as the library
-  const double y = __builtin_amdgcn_rsq(x);
+  const double y = __builtin_amdgcn_rsq(x);  // 2^-24.2
   double g = x * y, h = 0.5 * y;
-  double r = fma(-h, g, 0.5);
-  g = fma(g, r, g); h = fma(h, r, h);
-  r = fma(-h, g, 0.5);
-  g = fma(g, r, g); h = fma(h, r, h);
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);        // 2^-47.8
   return fma(fma(-g, g, x), h, g);
 #else
   return sqrt(x);
@@ -349,8 +346,8 @@ template <bool FAST = false> PF_HD double pf_ell_classic(double l1, double l2, d
         if (s1 < 0.) s1 = 1.e10;
         if (s2 < 0.) s2 = 1.e10;
         if (s3 < 0.) s3 = 1.e10;
-        ell = (s1 < s2 ? s1 : s2);
-        ell = (s3 < ell ? s3 : ell);
+        ell = FAST ? fmin(fmin(s1, s2), s3) : (s1 < s2 ? s1 : s2);
+        if (!FAST) ell = (s3 < ell ? s3 : ell);
         if (ell == 1.e10) ell = -.1;
       }
     }
@@ -394,8 +391,10 @@ template <bool FAST = false> PF_HD bool pf_ordered_eigenvalues(const double d[6]
     x3 = -sq * c3 + mu1 * inv_3;
   }
   // ord(): hi, lo by comparisons, middle arithmetically
-  double hi = (x1 > x2 ? x1 : x2); hi = (hi > x3 ? hi : x3);
-  double lo = (x1 < x2 ? x1 : x2); lo = (lo < x3 ? lo : x3);
+  // (fast flavour: v_max_f64 / v_min_f64 instead of compare + two selects each; the same values except for the sign of
+  // a zero and for NaN, which is NaN in all three roots or in none)
+  double hi = FAST ? fmax(fmax(x1, x2), x3) : (x1 > x2 ? x1 : x2); if (!FAST) hi = (hi > x3 ? hi : x3);
+  double lo = FAST ? fmin(fmin(x1, x2), x3) : (x1 < x2 ? x1 : x2); if (!FAST) lo = (lo < x3 ? lo : x3);
   const double mid = x1 + x2 + x3 - lo - hi;
   lam[0] = hi; lam[1] = mid; lam[2] = lo;
   return true;

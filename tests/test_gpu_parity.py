@@ -969,6 +969,9 @@ def test_fast_flavour_elementary_functions_on_the_device(api):
         x = np.abs(a)
         assert ulps(run(f, 1, x), np.sqrt(x.astype(ld))).max() <= 1.0
         assert run(f, 1, np.array([0.0]))[0] == 0.0 and np.isnan(run(f, 1, np.array([-1.0]))[0])
+        # the hardware seeds behind them: one refinement step is enough only while they are good to better than 2^-22
+        assert np.max(np.abs(run(f, 9, x).astype(ld) * x.astype(ld) - 1)) < 2.0 ** -22
+        assert np.max(np.abs(run(f, 10, x).astype(ld) ** 2 * x.astype(ld) - 1)) < 2.0 ** -21
         xa = np.concatenate([rng.uniform(-1, 1, 30000), 1.0 - 10.0 ** rng.uniform(-16, 0, 5000), -1.0 + 10.0 ** rng.uniform(-16, 0, 5000), [1.0, -1.0, 0.5, -0.5, 0.0]])
         xa = np.clip(xa, -1.0, 1.0)
         want = np.array([float(mp.acos(mp.mpf(float(v)))) for v in xa])
