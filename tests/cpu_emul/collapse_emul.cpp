@@ -80,6 +80,10 @@ extern "C" void emul_acos(const double *x, long count, double *out) {
   for (long i = 0; i < count; i++) out[i] = pf_acos_series(x[i]);
 }
 
+extern "C" void emul_pow_third(const double *x, long count, double *out) {
+  for (long i = 0; i < count; i++) out[i] = pf_pow_third<true>(x[i]);
+}
+
 extern "C" void emul_exp(const double *x, long count, double *e, double *e10) {
   for (long i = 0; i < count; i++) { e[i] = pf_exp_series(x[i]); e10[i] = pf_exp10_series(x[i]); }
 }

@@ -250,3 +250,26 @@ def test_exp_and_exp10_of_the_fast_flavour(emul):
     assert np.all(a[1:4] == 0.0) and np.all(np.isinf(a[4:7]))
     assert np.all(b[[1, 2, 3, 7]] == 0.0) and np.all(np.isinf(b[[4, 5, 6, 8]]))
 
+
+
+def test_pow_third_of_the_fast_flavour(emul):
+    """pf_pow_third = cbrt(x) (1 - d ln x) with ln x from the exponent and a quadratic in the mantissa: the factor beside
+    the cube root against x^-d in 40 digits (d = 1/3 - 0.333333333333333, the reference's exponent is not 1/3), over 60
+    decades.  The cube root itself is the library's (glibc's here, off by up to 3 ulp; the device library's on the GPU,
+    where test_fast_flavour_elementary_functions_on_the_device holds the product to 2 ulp of x^0.333333333333333)."""
+    import mpmath as mp
+    mp.mp.dps = 40
+    emul.emul_pow_third.argtypes = [dp, C.c_long, dp]
+    libm = C.CDLL("libm.so.6")
+    libm.cbrt.restype = C.c_double
+    libm.cbrt.argtypes = [C.c_double]
+    rng = np.random.default_rng(31)
+    x = np.concatenate([10.0 ** rng.uniform(-30, 30, 30000), rng.uniform(0.5, 2.0, 5000), 2.0 ** np.arange(-60.0, 61.0)])
+    got = np.empty(len(x))
+    emul.emul_pow_third(_dp(x), len(x), _dp(got))
+    d = mp.mpf(1) / 3 - mp.mpf(0.333333333333333)
+    cb = np.array([libm.cbrt(float(v)) for v in x])
+    factor = np.array([float(mp.mpf(float(g)) / mp.mpf(float(c)) - 1) for g, c in zip(got, cb)])
+    want = np.array([float(mp.power(mp.mpf(float(v)), -d) - 1) for v in x])
+    assert np.max(np.abs(factor - want)) <= 2.3e-16        # one rounding of the factor, one of the product
+    assert np.max(np.abs(want)) > 2e-14                     # and the factor is not 1: 2.4e-14 at 1e30
