@@ -296,68 +296,91 @@ template <bool FAST = false> PF_HD double pf_inverse_growing_mode(const pf_splin
   return 1. / pf_pow10<FAST>(pf_spline_eval(s, log10(D))) - 1.;
 }
 
-template <bool FAST = false> PF_HD double pf_ell_classic(double l1, double l2, double l3) {
-  double ell;
+// ell_classic (src/collapse_times.c:291-402) in four pieces, so that a kernel can run the two expensive branches of the
+// cubic on cells regrouped by branch (k_collapse_grouped); pf_ell_classic below is their plain composition.
+struct pf_cubic { double a1, q, r, disc; };  // x^3 + a1 x^2 + a2 x + a3 reduced: q, r and disc = r^2 - q^3
+// everything up to the branch on the discriminant.  Returns 0: ell is final (the degenerate branches), 1: one real root
+// (disc > 0), 2: three real roots
+template <bool FAST = false> PF_HD int pf_ell_setup(double l1, double l2, double l3, double &ell, pf_cubic &c) {
   const double del = l1 + l2 + l3;
   const double det = l1 * l2 * l3;
   if (fabs(l1) < PF_SMALL) {
     ell = -0.1;
-  } else {
-    const double den = FAST ? det * (1. / 126.) + 5. * l1 * del * (del - l1) * (1. / 84.)
-                            : det / 126. + 5. * l1 * del * (del - l1) / 84.;
-    if (fabs(den) < PF_SMALL) {
-      if (fabs(del - l1) < PF_SMALL) {
-        ell = (l1 > 0.0) ? 1. / l1 : -.1;
-      } else {
-        const double dis = 7. * l1 * (l1 + 6. * del);
-        if (dis < 0.0) {
-          ell = -.1;
-        } else {
-          ell = (7. * l1 - sqrt(dis)) / (3. * l1 * (l1 - del));
-          if (ell < 0.) ell = -.1;
-        }
-      }
+    return 0;
+  }
+  const double den = FAST ? det * (1. / 126.) + 5. * l1 * del * (del - l1) * (1. / 84.)
+                          : det / 126. + 5. * l1 * del * (del - l1) / 84.;
+  if (fabs(den) < PF_SMALL) {
+    if (fabs(del - l1) < PF_SMALL) {
+      ell = (l1 > 0.0) ? 1. / l1 : -.1;
     } else {
-      const double rden = FAST ? pf_div_fast(1.0, den) : 1.0 / den;
-      const double a1 = FAST ? 3. * l1 * (del - l1) * (1. / 14.) * rden : 3. * l1 * (del - l1) / 14. * rden;
-      const double a1_2 = a1 * a1;
-      const double a2 = l1 * rden;
-      const double a3 = -1.0 * rden;
-      const double q = FAST ? pf_div_const<9>(a1_2 - 3. * a2) : (a1_2 - 3. * a2) / 9.;
-      const double r = FAST ? pf_div_const<54>(2. * a1_2 * a1 - 9. * a1 * a2 + 27. * a3)
-                            : (2. * a1_2 * a1 - 9. * a1 * a2 + 27. * a3) / 54.;
-      const double r_2_q_3 = r * r - q * q * q;
-      if (r_2_q_3 > 0) {
-        const double fabs_r = fabs(r);
-        const double sq = pf_pow_third<FAST>((FAST ? pf_sqrt_fast(r_2_q_3) : sqrt(r_2_q_3)) + fabs_r);
-        // fabs(r)/r is +-1 for every finite non-zero r (and NaN at r = 0, kept)
-        ell = FAST ? -(r != 0. ? copysign(1.0, r) : fabs_r / r) * (sq + pf_div_fast(q, sq)) - a1 * (1.0 / 3)
-                   : -fabs_r / r * (sq + q / sq) - a1 / 3.;
-        if (ell < 0.) ell = -.1;
+      const double dis = 7. * l1 * (l1 + 6. * del);
+      if (dis < 0.0) {
+        ell = -.1;
       } else {
-        const double sq = 2 * (FAST ? pf_sqrt_fast(q) : sqrt(q));
-        const double inv_3 = 1.0 / 3;
-        const double t = FAST ? pf_acos_series(pf_div_fast(2 * r, q * sq)) : acos(2 * r / q / sq);
-        double c1, c2, c3;
-        pf_cos3<FAST>(t, c1, c2, c3);
-        double s1 = -sq * c1 - a1 * inv_3;
-        double s2 = -sq * c2 - a1 * inv_3;
-        double s3 = -sq * c3 - a1 * inv_3;
-        if (s1 < 0.) s1 = 1.e10;
-        if (s2 < 0.) s2 = 1.e10;
-        if (s3 < 0.) s3 = 1.e10;
-        ell = FAST ? fmin(fmin(s1, s2), s3) : (s1 < s2 ? s1 : s2);
-        if (!FAST) ell = (s3 < ell ? s3 : ell);
-        if (ell == 1.e10) ell = -.1;
+        ell = (7. * l1 - sqrt(dis)) / (3. * l1 * (l1 - del));
+        if (ell < 0.) ell = -.1;
       }
     }
+    return 0;
   }
+  const double rden = FAST ? pf_div_fast(1.0, den) : 1.0 / den;
+  const double a1 = FAST ? 3. * l1 * (del - l1) * (1. / 14.) * rden : 3. * l1 * (del - l1) / 14. * rden;
+  const double a1_2 = a1 * a1;
+  const double a2 = l1 * rden;
+  const double a3 = -1.0 * rden;
+  c.a1 = a1;
+  c.q = FAST ? pf_div_const<9>(a1_2 - 3. * a2) : (a1_2 - 3. * a2) / 9.;
+  c.r = FAST ? pf_div_const<54>(2. * a1_2 * a1 - 9. * a1 * a2 + 27. * a3)
+             : (2. * a1_2 * a1 - 9. * a1 * a2 + 27. * a3) / 54.;
+  c.disc = c.r * c.r - c.q * c.q * c.q;
+  return c.disc > 0 ? 1 : 2;
+}
+template <bool FAST = false> PF_HD double pf_ell_one_root(const pf_cubic &c) {
+  const double a1 = c.a1, q = c.q, r = c.r, r_2_q_3 = c.disc;
+  const double fabs_r = fabs(r);
+  const double sq = pf_pow_third<FAST>((FAST ? pf_sqrt_fast(r_2_q_3) : sqrt(r_2_q_3)) + fabs_r);
+  // fabs(r)/r is +-1 for every finite non-zero r (and NaN at r = 0, kept)
+  double ell = FAST ? -(r != 0. ? copysign(1.0, r) : fabs_r / r) * (sq + pf_div_fast(q, sq)) - a1 * (1.0 / 3)
+                    : -fabs_r / r * (sq + q / sq) - a1 / 3.;
+  if (ell < 0.) ell = -.1;
+  return ell;
+}
+template <bool FAST = false> PF_HD double pf_ell_three_roots(const pf_cubic &c) {
+  const double a1 = c.a1, q = c.q, r = c.r;
+  const double sq = 2 * (FAST ? pf_sqrt_fast(q) : sqrt(q));
+  const double inv_3 = 1.0 / 3;
+  const double t = FAST ? pf_acos_series(pf_div_fast(2 * r, q * sq)) : acos(2 * r / q / sq);
+  double c1, c2, c3;
+  pf_cos3<FAST>(t, c1, c2, c3);
+  double s1 = -sq * c1 - a1 * inv_3;
+  double s2 = -sq * c2 - a1 * inv_3;
+  double s3 = -sq * c3 - a1 * inv_3;
+  if (s1 < 0.) s1 = 1.e10;
+  if (s2 < 0.) s2 = 1.e10;
+  if (s3 < 0.) s3 = 1.e10;
+  double ell = FAST ? fmin(fmin(s1, s2), s3) : (s1 < s2 ? s1 : s2);
+  if (!FAST) ell = (s3 < ell ? s3 : ell);
+  if (ell == 1.e10) ell = -.1;
+  return ell;
+}
+// the correction of the collapsing ellipsoids (:395-400)
+template <bool FAST = false> PF_HD double pf_ell_finish(double ell, double l1, double l2, double l3) {
+  const double del = l1 + l2 + l3;
   if (del > 0. && ell > 0.) {
     const double inv_del = FAST ? pf_div_fast(1.0, del) : 1.0 / del;
     const double arg = -6.5 * (l1 - l2) * inv_del - 2.8 * (l2 - l3) * inv_del;
     ell += -.364 * inv_del * (FAST ? pf_exp_series(arg) : exp(arg));
   }
   return ell;
+}
+template <bool FAST = false> PF_HD double pf_ell_classic(double l1, double l2, double l3) {
+  double ell = 0.0;
+  pf_cubic c;
+  const int kind = pf_ell_setup<FAST>(l1, l2, l3, ell, c);
+  if (kind == 1) ell = pf_ell_one_root<FAST>(c);
+  else if (kind == 2) ell = pf_ell_three_roots<FAST>(c);
+  return pf_ell_finish<FAST>(ell, l1, l2, l3);
 }
 
 // Eigenvalues of the symmetric tensor d = {11,22,33,12,13,23} by the trigonometric formula, ordered by ord()

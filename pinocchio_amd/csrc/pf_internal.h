@@ -105,6 +105,7 @@ struct PfCollapseParams {
   int fast;             // 1: sincos/cbrt/exp10 forms of the transcendental hot spots (pf_collapse_core.h)
   int wpe;              // occupancy experiment: 0 default, 4 / 5 = register-capped builds
   int no_lut;           // 1: plain bisection in the spline lookup (PF_SPLINE_LUT=0)
+  int grouped;          // 1: k_collapse_grouped (cells regrouped by the branch of the cubic; fast flavour, direct solve)
   int tabulated;        // 1: F from the collapse-time table `ct` (TABULATED_CT build) instead of the direct solve
   PfCtDev ct;
 };

@@ -366,6 +366,28 @@ def test_properties_on_the_box_of_the_metric(api):
         assert f.sweep(radii[1:]) == pytest.approx(4.0 * tv[1:], rel=1e-12)
 
 
+@pytest.mark.parametrize("n,fb", [(16, 8), (40, 8), (64, 8), (128, 8), (64, 4)])
+def test_grouped_collapse_kernel_equals_plain_kernel(api, n, fb, monkeypatch):
+    """k_collapse_grouped (PF_COLLAPSE_GROUPED=1, an experiment: the cells of a workgroup regrouped by the branch of the cubic
+    through LDS) against k_collapse (the default): the same operations per cell, so Fmax and Rmax bit for bit; the variances differ
+    by the order of their partial sums only.  Sizes with partly filled last blocks and rows shorter than a wave included."""
+    dk = synth.make_density(n, seed=7 + n)
+    x, y = synth.invgrow_table("lcdm")
+    radii = np.array([3.0, 1.2, 0.0])
+    out = {}
+    for g in ("0", "1"):
+        monkeypatch.setenv("PF_COLLAPSE_GROUPED", g)
+        with api.Fmax(n, field_bytes=fb) as f:
+            f.set_density(dk)
+            f.set_invgrow(x, y)
+            tv = f.sweep(radii)
+            out[g] = (tv, f.block("FMAX"), f.block("RMAX"), f.Fmax_PDF())
+    assert np.allclose(out["0"][0], out["1"][0], rtol=1e-13)
+    assert np.array_equal(out["0"][1], out["1"][1]) and np.array_equal(out["0"][2], out["1"][2])
+    assert np.array_equal(out["0"][3], out["1"][3])
+    assert (out["1"][2] > 0).any() and (out["1"][1] > 1.0).any()
+
+
 def test_pruned_transform_equals_full_transform(api, monkeypatch):
     """Smoothed radii use a pruned FFT: modes whose Gaussian weight is < 2^-60 are not transformed.
     Against the full transform (PF_PRUNE_EPS=0) the Hessian changes by less than its own rounding."""
