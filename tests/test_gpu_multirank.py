@@ -57,7 +57,7 @@ def api():
     return _api
 
 
-@pytest.mark.parametrize("n,P,pipeline", [(32, 2, 1), (64, 4, 1), (64, 8, 1), (64, 4, 0), (16, 16, 1), (32, 16, 0)])
+@pytest.mark.parametrize("n,P,pipeline", [(32, 2, 1), (64, 4, 1), (64, 8, 1), (64, 4, 0), (16, 16, 1), (32, 16, 0), (256, 8, 1)])
 def test_slab_ranks_match_single_rank(api, n, P, pipeline, monkeypatch):
     # pipeline = 1 (default): double-buffered exchange on the communication stream, the all-to-all of transform i+1
     # issued before the y/z passes of transform i; 0: one buffer set, everything on one stream
