@@ -58,12 +58,12 @@ extern "C" const char *pf_last_error(void) { return g_err; }
 enum {
   KS_XPASS_HESS = 0, KS_YPASS_HESS, KS_ZPASS_HESS, KS_COLLAPSE, KS_LPT_SRC, KS_LPT_ACC, KS_R2C_Z, KS_YPASS_FWD,
   KS_XPASS_FWD, KS_XPASS_DISP, KS_YPASS_DISP, KS_ZPASS_DISP, KS_XPASS_PLAIN, KS_YPASS_PLAIN, KS_ZPASS_PLAIN,
-  KS_EXCHANGE, KS_MISC, KS_ZCOLLAPSE, KS_COUNT
+  KS_EXCHANGE, KS_MISC, KS_ZCOLLAPSE, KS_ZPASS_INV, KS_COLLAPSE_INV, KS_COUNT
 };
 static const char *ks_names[KS_COUNT] = {
     "xpass_hess_1to3", "ypass_hess_3to6", "zpass_c2r_hess_6", "collapse", "lpt_sources", "lpt_accum", "zpass_r2c",
     "ypass_fwd", "xpass_fwd", "xpass_disp_1to2", "ypass_disp_2to3", "zpass_c2r_disp_3", "xpass_plain", "ypass_plain",
-    "zpass_c2r_plain", "exchange", "misc", "zpass_collapse_fused"};
+    "zpass_c2r_plain", "exchange", "misc", "zpass_collapse_fused", "zpass_c2r_hess_6to3inv", "collapse_inv"};
 
 struct EvPair { int kind; hipEvent_t a, b; double bytes; };
 
@@ -481,7 +481,7 @@ static int ypass(pf_ctx *c, int kind, int dir, int njobs, const Job *jobs, bool 
   return 0;
 }
 struct ZJob { const void *in; void *out; int mul; int f32; };
-static int zpass_c2r(pf_ctx *c, int kind, int njobs, const ZJob *jobs, const double *dc, int band = 1 << 30) {
+static int zpass_c2r(pf_ctx *c, int kind, int njobs, const ZJob *jobs, const double *dc, int band = 1 << 30, bool invariants = false) {
   PfC2RParams p; memset(&p, 0, sizeof(p));
   p.njobs = njobs;
   double outb = 0;
@@ -494,6 +494,11 @@ static int zpass_c2r(pf_ctx *c, int kind, int njobs, const ZJob *jobs, const dou
   p.band_k = c->n;
   double frac_in = 1.0;
   if (band < c->n / 2) { p.band_k = band; frac_in = (double)(band + 1) / c->nzh; }
+  if (invariants) {  // six components in, the three invariants of the tensor out (fields 0..2)
+    KTimer t(c, KS_ZPASS_INV, njobs * frac_in * spec_bytes_alg(c) + 3.0 * real_bytes_alg(c));
+    PFCHK(c, pf_launch_c2r_invariants(c->n, p, c->stream));
+    return 0;
+  }
   KTimer t(c, kind, njobs * frac_in * spec_bytes_alg(c) + outb);
   PFCHK(c, pf_launch_c2r(c->fb, c->n, p, c->stream));
   return 0;
@@ -619,14 +624,14 @@ static int hess_x(pf_ctx *c, const void *spec, double rs, void *const A[3], int 
   const Job xj[3] = {{spec, A[0], PF_MUL_ONE}, {spec, A[1], PF_MUL_K}, {spec, A[2], PF_MUL_K2}};
   return xpass(c, KS_XPASS_HESS, +1, 3, xj, 1, rs, 1.0, 1, band, true);
 }
-static int hess_yz(pf_ctx *c, const void *const R[3], const double *dc, void *const out[6], int band, bool xy_only) {
+static int hess_yz(pf_ctx *c, const void *const R[3], const double *dc, void *const out[6], int band, bool xy_only, bool invariants = false) {
   const Job yj[6] = {{R[2], out[0], PF_MUL_ONE}, {R[1], out[3], PF_MUL_K}, {R[1], out[4], PF_MUL_ONE},
                      {R[0], out[1], PF_MUL_K2}, {R[0], out[5], PF_MUL_K},  {R[0], out[2], PF_MUL_ONE}};
   PFCHK(c, ypass(c, KS_YPASS_HESS, +1, 6, yj, true, false, 3, band, true));
   if (xy_only) { c->last_band = band; return 0; }
   const ZJob zj[6] = {{out[0], out[0], PF_MUL_ONE, 0}, {out[1], out[1], PF_MUL_ONE, 0}, {out[2], out[2], PF_MUL_K2, 0},
                       {out[3], out[3], PF_MUL_ONE, 0}, {out[4], out[4], PF_MUL_K, 0},   {out[5], out[5], PF_MUL_K, 0}};
-  PFCHK(c, zpass_c2r(c, KS_ZPASS_HESS, 6, zj, dc, band));
+  PFCHK(c, zpass_c2r(c, KS_ZPASS_HESS, 6, zj, dc, band, invariants));
   return 0;
 }
 static int hessian_of(pf_ctx *c, const void *spec, double rs, const double *dc, void *const out[6], bool xy_only = false) {
@@ -959,7 +964,7 @@ extern "C" int pf_second_derivatives(pf_ctx *c, double rs) {
   return 0;
 }
 
-static int collapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], hipStream_t st, bool build_table = true) {
+static int collapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], hipStream_t st, bool build_table = true, bool invariants = false) {
   PfCollapseParams p; memset(&p, 0, sizeof(p));
   for (int i = 0; i < 6; i++) p.h[i] = H[i];
   p.pitch = rpitch(c); p.nrows = (long long)c->nxl * c->n; p.n = c->n; p.fmax = c->fmax; p.rmax = c->rmax; p.ismooth = ismooth;
@@ -982,7 +987,7 @@ static int collapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], hipStream_
   // experiment (PF_COLLAPSE_GROUPED=1): cells regrouped by the branch of the cubic, 512-thread blocks, two resident per CU.
   // Bit-identical Fmax / Rmax, but 25.4 ms per launch at 1024^3 against the 23.0 ms of the plain kernel
   const int grouped_env = getenv("PF_COLLAPSE_GROUPED") ? atoi(getenv("PF_COLLAPSE_GROUPED")) : 0;
-  if (grouped_env && p.fast && !p.tabulated && !p.wpe) {
+  if (grouped_env && p.fast && !p.tabulated && !p.wpe && !invariants) {
     p.grouped = 1;
     int per_cu = 4;
     if (const char *e = getenv("PF_COLLAPSE_GROUPED_WG_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
@@ -990,8 +995,9 @@ static int collapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], hipStream_
     if (nb > PF_NBLK) nb = PF_NBLK;
     p.nblocks = (int)nb;
   }
+  if (invariants) p.invariants = 1;
   {
-    KTimer t(c, KS_COLLAPSE, (double)ncell(c) * (6.0 * c->fb + 16.0), st);
+    KTimer t(c, invariants ? KS_COLLAPSE_INV : KS_COLLAPSE, (double)ncell(c) * ((invariants ? 3.0 : 6.0) * c->fb + 16.0), st);
     PFCHK(c, pf_launch_collapse(c->fb, p, st));
   }
   PFCHK(c, pf_launch_final_sum(c->partials, p.nblocks, c->scal + SC_VAR0 + 2 * ismooth, st));
@@ -1074,6 +1080,8 @@ extern "C" int pf_sweep(pf_ctx *c, int ns, const double *radius_cells, double *t
   HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_h[0], 0));
   PFCHK(c, products_reset(c, c->overlap ? c->stream2 : c->stream));
   const bool xy_only = c->fuse;
+  const bool invariants_ok = c->fb == 8 && !c->fuse && !c->general && c->tab_ns == 0 && !getenv("PF_COLLAPSE_WPE") &&
+                             !(getenv("PF_INVARIANTS") && !atoi(getenv("PF_INVARIANTS")));
   auto pre = [&](int ismooth, void *const *A) {
     PhaseTimer pt(c, 0);
     return hess_x(c, c->dk, radius_cells[ismooth], A, hess_band(c, radius_cells[ismooth], xy_only));
@@ -1082,9 +1090,12 @@ extern "C" int pf_sweep(pf_ctx *c, int ns, const double *radius_cells, double *t
     const int b = c->overlap ? (ismooth & 1) : 0;
     void **H = b ? c->B2 : c->B;
     if (c->overlap && ismooth >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_c[b], 0));
+    // every radius but the last (its Hessian stays in B for the LPT sources): the z-pass stores the three invariants of the
+    // tensor instead of its six components and the solve starts from them (PF_INVARIANTS=0: six components throughout)
+    const bool inv = invariants_ok && ismooth < ns - 1;
     {
       PhaseTimer pt(c, 0);
-      PFCHK(c, hess_yz(c, R, c->scal + SC_DC_DK, H, hess_band(c, radius_cells[ismooth], xy_only), xy_only));
+      PFCHK(c, hess_yz(c, R, c->scal + SC_DC_DK, H, hess_band(c, radius_cells[ismooth], xy_only), xy_only, inv));
     }
     HIPCHK(c, hipEventRecord(c->ev_h[b], c->stream));
     if (c->overlap) HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_h[b], 0));
@@ -1093,7 +1104,7 @@ extern "C" int pf_sweep(pf_ctx *c, int ns, const double *radius_cells, double *t
       PhaseTimer pt(c, 1, cst);
       if (c->fuse) {
         if (zcollapse_enqueue(c, ismooth, H, c->scal + SC_DC_DK, ismooth == ns - 1, cst)) return 1;
-      } else if (collapse_enqueue(c, ismooth, H, cst)) return 1;
+      } else if (collapse_enqueue(c, ismooth, H, cst, true, inv)) return 1;
     }
     HIPCHK(c, hipEventRecord(c->ev_c[b], cst));
     return 0;
@@ -1405,7 +1416,7 @@ extern "C" int pf_get_cputime(pf_ctx *c, pf_cputime *t) {
   resolve_events(c);
   double fft = 0;
   for (int k = 0; k < KS_COUNT; k++)
-    if (k != KS_COLLAPSE && k != KS_LPT_SRC && k != KS_LPT_ACC && k != KS_MISC) fft += 1e-3 * c->ks_ms[k];
+    if (k != KS_COLLAPSE && k != KS_COLLAPSE_INV && k != KS_LPT_SRC && k != KS_LPT_ACC && k != KS_MISC) fft += 1e-3 * c->ks_ms[k];
   t->fft = fft;
   return 0;
 }

@@ -28,7 +28,8 @@ __device__ __forceinline__ void pf_block_sum2(double &a, double &b, double *sh /
 }
 
 // K6: one thread per cell, grid-stride.  fp64 math whatever the field precision.
-template <typename F, bool FAST, bool TAB = false>
+// INV: h[0..2] hold the invariants mu1, mu2, mu3 of the tensor (written by k_c2r_invariants) instead of its components
+template <typename F, bool FAST, bool TAB = false, bool INV = false>
 __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
   __shared__ double sk[TAB ? PF_CT_NBINS_D : 5 * PF_MAX_KNOTS];
   __shared__ double red[2 * (PF_CELL_BLOCK / 64)];
@@ -73,17 +74,26 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
   for (long long i = i0; i < ncell; i += stride, row += srow, col += scol) {
     if (col >= p.n) { col -= p.n; row++; }
     const long long a = (long long)row * p.pitch + col;
-    double d[6] = {(double)h0[a], (double)h1[a], (double)h2[a], (double)h3[a], (double)h4[a], (double)h5[a]};
+    double d[6];
+    d[0] = (double)h0[a]; d[1] = (double)h1[a]; d[2] = (double)h2[a];
+    if (!INV) { d[3] = (double)h3[a]; d[4] = (double)h4[a]; d[5] = (double)h5[a]; }
     // products[].Fmax is float, compared after promotion (quirk Q2); init -10 / -1 at ismooth 0.  Loaded here, with the
     // Hessian, so that its latency hides under the solve instead of sitting between the solve and the store.
     const float fold = p.ismooth ? p.fmax[i] : -10.0f;
-    const double delta = d[0] + d[1] + d[2];
+    const double delta = INV ? d[0] : d[0] + d[1] + d[2];
     sum += delta;
     sum2 += delta * delta;
     double lam[3];
+    bool have_lam;
+    if (INV) {
+      const double third = d[0] * (1.0 / 3.0);  // an exactly isotropic tensor: its diagonal is not stored
+      const double diag[3] = {third, third, third};
+      have_lam = pf_eigen_from_invariants<FAST>(d[0], d[1], d[2], diag, lam);
+    } else {
+      have_lam = pf_ordered_eigenvalues<FAST>(d, lam);
+    }
     // TABULATED_CT: the same eigenvalues, then the table instead of ell() (src/collapse_times.c:749)
-    const double Fnew = TAB ? (pf_ordered_eigenvalues<FAST>(d, lam) ? pf_interpolate_collapse_time(tv, lam[0], lam[1], lam[2]) : -10.0)
-                            : pf_inverse_collapse_time<FAST>(d, sv, lam);
+    const double Fnew = !have_lam ? -10.0 : TAB ? pf_interpolate_collapse_time(tv, lam[0], lam[1], lam[2]) : pf_ell<FAST>(sv, lam[0], lam[1], lam[2]);
     if ((double)fold < Fnew) {
       p.fmax[i] = (float)Fnew;
       p.rmax[i] = p.ismooth;
@@ -109,6 +119,9 @@ __global__ void __launch_bounds__(PF_CELL_BLOCK) __attribute__((amdgpu_waves_per
 
 template <typename F, bool FAST>
 __global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse_tab(const PfCollapseParams p) { pf_collapse_body<F, FAST, true>(p); }
+// the solve on the three invariants per cell that k_c2r_invariants leaves in h[0..2] (fp64 fields)
+template <bool FAST>
+__global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse_inv(const PfCollapseParams p) { pf_collapse_body<double, FAST, false, true>(p); }
 
 // K6 with the cells of a workgroup regrouped by the branch of the cubic.  Two thirds of the cells have a one-root cubic
 // (square root, cube root: ~66 instructions), one third a three-root one (acos, sincos: ~116), and no wave of 64
@@ -599,6 +612,12 @@ int pf_launch_collapse(int fb, const PfCollapseParams &p, hipStream_t st) {
       if (p.fast) hipLaunchKernelGGL((k_collapse_tab<float, true>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
       else hipLaunchKernelGGL((k_collapse_tab<float, false>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
     }
+    return PF_CHECK_LAUNCH();
+  }
+  if (p.invariants) {
+    if (fb != 8 || p.tabulated) return 2;
+    if (p.fast) hipLaunchKernelGGL((k_collapse_inv<true>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
+    else hipLaunchKernelGGL((k_collapse_inv<false>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
     return PF_CHECK_LAUNCH();
   }
   if (p.grouped) {

@@ -385,18 +385,27 @@ template <bool FAST = false> PF_HD double pf_ell_classic(double l1, double l2, d
 
 // Eigenvalues of the symmetric tensor d = {11,22,33,12,13,23} by the trigonometric formula, ordered by ord()
 // (src/collapse_times.c:679-745).  Returns false for the -10 sentinel branch (q^3 < r^2 or q < 0).
-template <bool FAST = false> PF_HD bool pf_ordered_eigenvalues(const double d[6], double lam[3]) {
-  const double mu1 = d[0] + d[1] + d[2];
+// ... in two pieces: the three invariants of the tensor, and everything after them.  The invariants are all the solve
+// needs, so the z-pass of the sweep can store them (3 fields) instead of the six components (k_c2r_invariants); only an
+// exactly isotropic tensor (q == 0) takes its eigenvalues from the diagonal itself, `diag`.
+PF_HD void pf_invariants(const double d[6], double &mu1, double &mu2, double &mu3) {
+#if defined(__clang__)
+#pragma clang fp contract(off)  // also when included from a translation unit built with contraction on (the z-pass)
+#endif
+  mu1 = d[0] + d[1] + d[2];
   const double mu1_2 = mu1 * mu1;
-  double mu2 = 0.5 * mu1_2;
+  mu2 = 0.5 * mu1_2;
   mu2 -= 0.5 * (d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
   const double add0 = d[3] * d[3], add1 = d[4] * d[4], add2 = d[5] * d[5];
   mu2 -= add0 + add1 + add2;
-  const double mu3 = d[0] * d[1] * d[2] + 2. * d[3] * d[4] * d[5] - d[0] * add2 - d[1] * add1 - d[2] * add0;
+  mu3 = d[0] * d[1] * d[2] + 2. * d[3] * d[4] * d[5] - d[0] * add2 - d[1] * add1 - d[2] * add0;
+}
+template <bool FAST = false> PF_HD bool pf_eigen_from_invariants(double mu1, double mu2, double mu3, const double diag[3], double lam[3]) {
+  const double mu1_2 = mu1 * mu1;
   const double q = FAST ? pf_div_const<9>(mu1_2 - 3.0 * mu2) : (mu1_2 - 3.0 * mu2) / 9.0;
   double x1, x2, x3;
   if (q == 0.) {
-    x1 = d[0]; x2 = d[1]; x3 = d[2];
+    x1 = diag[0]; x2 = diag[1]; x3 = diag[2];
   } else {
     const double r = FAST ? pf_div_const<54>(-(2. * mu1_2 * mu1 - 9.0 * mu1 * mu2 + 27.0 * mu3))
                           : -(2. * mu1_2 * mu1 - 9.0 * mu1 * mu2 + 27.0 * mu3) / 54.;
@@ -421,6 +430,11 @@ template <bool FAST = false> PF_HD bool pf_ordered_eigenvalues(const double d[6]
   const double mid = x1 + x2 + x3 - lo - hi;
   lam[0] = hi; lam[1] = mid; lam[2] = lo;
   return true;
+}
+template <bool FAST = false> PF_HD bool pf_ordered_eigenvalues(const double d[6], double lam[3]) {
+  double mu1, mu2, mu3;
+  pf_invariants(d, mu1, mu2, mu3);
+  return pf_eigen_from_invariants<FAST>(mu1, mu2, mu3, d, lam);
 }
 
 // ell (src/collapse_times.c:404-427, ELL_CLASSIC): F = 1 + z_collapse, or 0 when the ellipsoid never collapses

@@ -20,6 +20,7 @@
 #include "pf_fft_core.h"
 
 #include "pf_fft_stages.h"
+#include "pf_collapse_core.h"  // pf_invariants
 
 __device__ __forceinline__ long long pf_addr(const PfAddr &a, int outer, int e, int col) {
   return (long long)outer * a.os + (long long)(e >> a.el_shift) * a.ehs + (long long)(e & ((1 << a.el_shift) - 1)) * a.els + col;
@@ -251,6 +252,99 @@ __global__ void __launch_bounds__(TL *(N / 16)) k_c2r_persistent(const PfC2RPara
   }
 }
 
+// The z-pass of the sweep, six components of one row per workgroup: line l of the tile is row `R` of component l, and
+// after the six transforms the workgroup reduces each cell's tensor to its three invariants mu1, mu2, mu3 -- all the
+// collapse solve reads (pf_eigen_from_invariants) -- and stores three real rows instead of six (into the first three
+// fields, in place: every input of row R is in registers or LDS before the first store).  Per radius the pass writes
+// 26 GB instead of 52 and the solve reads 26 instead of 52.  The component values are formed by the same expression as in
+// k_c2r (pf_norm_dc) and the invariants by the solve's own pf_invariants (no contraction): Fmax, Rmax and the variances
+// come out bit for bit as with the six-field path.  fp64 fields.
+template <int N>
+__global__ void __launch_bounds__(6 * (N / 16)) k_c2r_invariants(const PfC2RParams p, long long nrows) {
+  using F = double;
+  using C = pfc<F>;
+  constexpr int M = N / 2, NT = M / 8, TL = 6;
+  constexpr int LPL = (M + 1 > M + M / 8) ? M + 1 : M + M / 8;
+  constexpr int NTHR = TL * NT;
+  static_assert((size_t)LPL * sizeof(C) >= (size_t)N * sizeof(F), "a line's LDS holds its real row");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  C *lds = reinterpret_cast<C *>(smem);
+  const int tid = threadIdx.x;
+  const int l = tid / NT, tl = tid % NT;
+  const C *__restrict__ tw = reinterpret_cast<const C *>(p.tw);
+  const F kf = (F)(2.0 * 3.14159265358979323846 / (double)N);
+  const F norm = (F)p.norm;
+  const F dcv = p.dc ? (F)(*p.dc) : (F)0;
+  // this thread's component: input rows and kz factor
+  const C *in = reinterpret_cast<const C *>(p.job[0].in);
+  int mul = p.job[0].mul;
+#pragma unroll
+  for (int j = 1; j < TL; j++)
+    if (l == j) { in = reinterpret_cast<const C *>(p.job[j].in); mul = p.job[j].mul; }
+  F *__restrict__ o1 = reinterpret_cast<F *>(p.job[0].out), *__restrict__ o2 = reinterpret_cast<F *>(p.job[1].out),
+    *__restrict__ o3 = reinterpret_cast<F *>(p.job[2].out);
+
+  // a line is touched by its own threads only until the reduction: while those sit in one wave (N <= 1024) the LDS
+  // queue keeps their accesses in order and no workgroup barrier is needed
+  auto line_sync = [&]() { if (NT > 64) __syncthreads(); };
+  C nxt[9];
+  auto fetch = [&](long long R) {
+    const C *__restrict__ row = in + R * p.in_pitch;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int k = tl + m * NT;
+      nxt[m] = (k <= p.band_k) ? pf_ld_stream(&row[k]) : pf_mk<F>(0, 0);
+    }
+    nxt[8] = (tl == 0 && M <= p.band_k) ? pf_ld_stream(&row[M]) : pf_mk<F>(0, 0);
+  };
+
+  long long R = blockIdx.x;
+  if (R < nrows) fetch(R);
+#pragma unroll 1
+  for (; R < nrows; R += gridDim.x) {
+    int tlj = tl, lj = l, tidj = tid;
+    asm volatile("" : "+v"(tlj), "+v"(lj), "+v"(tidj));  // keep the index math inside the loop (see k_strided)
+    C *L = lds + lj * LPL;
+    // phase A: the prefetched row of this component -> its LDS line
+#pragma unroll
+    for (int m = 0; m < 8; m++) L[tlj + m * NT] = nxt[m];
+    if (tlj == 0) L[M] = nxt[8];
+    line_sync();
+    // phase B: kz factor + Hermitian fold into the half-length complex line
+    C v[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int e = tlj + m * NT;
+      v[m] = pf_zfold<F>(L[e], L[M - e], e, M, mul, kf, tw[e]);
+    }
+    line_sync();
+    if (R + gridDim.x < nrows) fetch(R + gridDim.x);  // in flight during the stages and the reduction below
+    PfStages<F, M, +1, 2>::run(
+        v, tlj, tw, [&](int pos, C val) { L[pf_lpad(pos)] = val; }, [&](int pos) { return L[pf_lpad(pos)]; });
+    line_sync();  // every thread of the line is done with the exchange area
+    // the real row of this component, in order, into its line
+    C *H = L;
+#pragma unroll
+    for (int m = 0; m < 8; m++) H[tlj + m * NT] = pf_mk<F>(pf_norm_dc(v[m].x, norm, dcv), pf_norm_dc(v[m].y, norm, dcv));
+    __syncthreads();
+    // per cell: six components -> three invariants; two neighbouring cells per thread (16-byte LDS reads and stores)
+    for (int c = 2 * tidj; c < N; c += 2 * NTHR) {
+      double2 h[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) h[k] = *reinterpret_cast<const double2 *>(reinterpret_cast<const F *>(lds + k * LPL) + c);
+      const double da[6] = {h[0].x, h[1].x, h[2].x, h[3].x, h[4].x, h[5].x}, db[6] = {h[0].y, h[1].y, h[2].y, h[3].y, h[4].y, h[5].y};
+      double a1, a2, a3, b1, b2, b3;
+      pf_invariants(da, a1, a2, a3);
+      pf_invariants(db, b1, b2, b3);
+      const long long a = R * p.out_pitch + c;
+      *reinterpret_cast<double2 *>(o1 + a) = make_double2(a1, b1);
+      *reinterpret_cast<double2 *>(o2 + a) = make_double2(a2, b2);
+      *reinterpret_cast<double2 *>(o3 + a) = make_double2(a3, b3);
+    }
+    __syncthreads();  // the lines are rewritten by the next phase A
+  }
+}
+
 template <typename F, int N, int TL>
 __global__ void __launch_bounds__(TL *(N / 16)) k_r2c(const PfR2CParams p) {
   using C = pfc<F>;
@@ -356,6 +450,22 @@ static int launch_c2r_n(const PfC2RParams &p, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+template <int N>
+static int launch_c2r_invariants_n(const PfC2RParams &p, hipStream_t st) {
+  constexpr int M = N / 2, NT = M / 8;
+  constexpr int LPL = (M + 1 > M + M / 8) ? M + 1 : M + M / 8;
+  static int ncu = 0;
+  if (!ncu) { hipDeviceProp_t prop; int dev = 0; hipGetDevice(&dev); hipGetDeviceProperties(&prop, dev); ncu = prop.multiProcessorCount; }
+  // two workgroups fit per CU; 32 per CU in the grid evens out the tail (measured 6: 254, 8: 248, 16: 241, 32: 235-237,
+  // 64: 236 ms per step of eleven launches at 1024^3)
+  static const int per_cu = getenv("PF_ZPASS_INV_WG_PER_CU") ? atoi(getenv("PF_ZPASS_INV_WG_PER_CU")) : 32;
+  long long g = (long long)ncu * (per_cu > 0 ? per_cu : 32);
+  if (g > p.nlines) g = p.nlines;
+  const size_t shm = (size_t)6 * LPL * sizeof(pfc<double>);
+  hipLaunchKernelGGL((k_c2r_invariants<N>), dim3((unsigned)g), dim3(6 * NT), shm, st, p, p.nlines);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 template <typename F, int N>
 static int launch_r2c_n(const PfR2CParams &p, hipStream_t st) {
   constexpr int M = N / 2, NT = M / 8;
@@ -415,6 +525,13 @@ int pf_launch_c2r(int fb, int n, const PfC2RParams &p, hipStream_t st) {
     PF_SWITCH_N(n, CALL)
 #undef CALL
   }
+}
+
+int pf_launch_c2r_invariants(int n, const PfC2RParams &p, hipStream_t st) {
+  if (p.njobs != 6) return 2;
+#define CALL(NN) launch_c2r_invariants_n<NN>(p, st)
+  PF_SWITCH_N(n, CALL)
+#undef CALL
 }
 
 int pf_launch_r2c(int fb, int n, const PfR2CParams &p, hipStream_t st) {

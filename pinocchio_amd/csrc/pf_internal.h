@@ -69,6 +69,8 @@ struct PfC2RParams {
   int band_k;           // input columns kz > band_k are zero (pruned), not read
 };
 int pf_launch_c2r(int field_bytes, int n, const PfC2RParams &p, hipStream_t st);
+// six components (njobs == 6, fp64) -> the three invariants of the tensor into job[0..2].out (pf_fft_kernels.hip)
+int pf_launch_c2r_invariants(int n, const PfC2RParams &p, hipStream_t st);
 
 struct PfR2CParams {
   const void *in;       // real rows, pitch in_pitch reals
@@ -105,6 +107,7 @@ struct PfCollapseParams {
   int fast;             // 1: sincos/cbrt/exp10 forms of the transcendental hot spots (pf_collapse_core.h)
   int wpe;              // occupancy experiment: 0 default, 4 / 5 = register-capped builds
   int no_lut;           // 1: plain bisection in the spline lookup (PF_SPLINE_LUT=0)
+  int invariants;       // 1: h[0..2] hold mu1, mu2, mu3 (k_c2r_invariants), h[3..5] unused
   int grouped;          // 1: k_collapse_grouped (cells regrouped by the branch of the cubic; fast flavour, direct solve)
   int tabulated;        // 1: F from the collapse-time table `ct` (TABULATED_CT build) instead of the direct solve
   PfCtDev ct;

@@ -388,6 +388,32 @@ def test_grouped_collapse_kernel_equals_plain_kernel(api, n, fb, monkeypatch):
     assert (out["1"][2] > 0).any() and (out["1"][1] > 1.0).any()
 
 
+@pytest.mark.parametrize("n", [16, 64, 128, 256])
+def test_invariant_zpass_equals_six_component_path(api, n, monkeypatch):
+    """Default sweep: for every radius but the last the z-pass stores the three invariants of the tensor (k_c2r_invariants)
+    and the solve starts from them; PF_INVARIANTS=0 keeps six components throughout.  The component values and the
+    invariants are formed by the same operations in both, so TrueVariance, Fmax, Rmax, the histogram and (from the last
+    radius's Hessian, which both keep) the displacements agree bit for bit.  Band-limited radii included."""
+    dk = synth.make_density(n, seed=3 + n)
+    dk[0, 0, 0] = 0.37 * n ** 3        # a DC mode: added to every component after the transform
+    x, y = synth.invgrow_table("lcdm")
+    radii = np.array([n / 16.0, n / 40.0, 1.5, 0.6, 0.0])
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PF_INVARIANTS", mode)
+        with api.Fmax(n) as f:
+            f.set_density(dk)
+            f.set_invgrow(x, y)
+            f.set_growth(synth.growth_multipliers())
+            tv = f.compute_fmax(radii, do_lpt=True)
+            out[mode] = (tv, f.products(), f.Fmax_PDF())
+    assert np.array_equal(out["0"][0], out["1"][0])
+    for name in ("Fmax", "Rmax", "Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+        assert np.array_equal(out["0"][1][name], out["1"][1][name]), name
+    assert np.array_equal(out["0"][2], out["1"][2])
+    assert (out["1"][1]["Rmax"] > 0).any() and (out["1"][1]["Rmax"] < 4).any()
+
+
 def test_pruned_transform_equals_full_transform(api, monkeypatch):
     """Smoothed radii use a pruned FFT: modes whose Gaussian weight is < 2^-60 are not transformed.
     Against the full transform (PF_PRUNE_EPS=0) the Hessian changes by less than its own rounding."""
