@@ -189,7 +189,7 @@ def main():
                        "device_GB": f.device_bytes / 1e9, "sigma_R0": float(np.sqrt(tv[-1]))},
             "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "note": "collapse is fp64-VALU bound (~570 instructions per cell); its HBM stream is a consequence, see DESIGN.md section 6",
+                         "note": "the collapse solve is fp64-VALU bound (~480 instructions per cell from the invariants, ~570 from six components); its HBM stream is a consequence, see DESIGN.md section 6",
                          "valu": valu, "launches": dom["launches"], "avg_ms": dom["total_ms"] / dom["launches"],
                          "alg_bytes_per_launch": dom["alg_bytes"] / dom["launches"]},
             "path_roofline": {"contract_bytes_per_cell": alg_bytes_per_cell(ns, w, lpt),

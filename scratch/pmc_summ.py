@@ -8,5 +8,5 @@ for tag in sys.argv[1:]:
         acc[k][row['Counter_Name']] += float(row['Counter_Value'])
     print('==', tag)
     for k, d in acc.items():
-        if any(x in k for x in ('k_strided','k_c2r','k_collapse')):
+        if any(x in k for x in ('k_strided','k_c2r','k_collapse')):  # k_c2r_invariants, k_collapse_inv included
             print(k, {c: '%.4g' % v for c, v in d.items()})
