@@ -231,9 +231,11 @@ __global__ void __launch_bounds__(TL *(N / 16)) k_c2r_persistent(const PfC2RPara
       const int e = tlj + m * NT;
       v[m] = pf_zfold<F>(L[e], L[M - e], e, M, mul, kf, tw[e]);
     }
-    __syncthreads();
+    // from here to the end of the stages a line belongs to its own NT threads: one wave for N <= 1024, whose LDS accesses
+    // stay in order without workgroup barriers (four of them per tile at N = 1024)
+    if (NT <= 64) __builtin_amdgcn_wave_barrier(); else __syncthreads();
     if (t + gridDim.x < ntiles) fetch(t + gridDim.x);  // in flight during the stages and the stores below
-    PfStages<F, M, +1, 2>::run(
+    PfStages<F, M, +1, 2, 0, (NT <= 64)>::run(
         v, tlj, tw, [&](int pos, C val) { L[pf_lpad(pos)] = val; }, [&](int pos) { return L[pf_lpad(pos)]; });
     const long long row = (t / p.njobs) * TL + lj;
     if (row < p.nlines) {
@@ -248,7 +250,8 @@ __global__ void __launch_bounds__(TL *(N / 16)) k_c2r_persistent(const PfC2RPara
         for (int m = 0; m < 8; m++) pf_st_stream(&o[tlj + m * NT], pf_mk<F>(pf_norm_dc(v[m].x, norm, dcv), pf_norm_dc(v[m].y, norm, dcv)));
       }
     }
-    if (pf_nstages(M) == 1) __syncthreads();  // no exchange barrier separates phase B's LDS reads from the next phase A
+    // the next phase A rewrites every line: all waves must be done with theirs
+    if (NT <= 64 || pf_nstages(M) == 1) __syncthreads();
   }
 }
 
@@ -286,7 +289,7 @@ __global__ void __launch_bounds__(6 * (N / 16)) k_c2r_invariants(const PfC2RPara
 
   // a line is touched by its own threads only until the reduction: while those sit in one wave (N <= 1024) the LDS
   // queue keeps their accesses in order and no workgroup barrier is needed
-  auto line_sync = [&]() { if (NT > 64) __syncthreads(); };
+  auto line_sync = [&]() { if (NT > 64) __syncthreads(); else __builtin_amdgcn_wave_barrier(); };
   C nxt[9];
   auto fetch = [&](long long R) {
     const C *__restrict__ row = in + R * p.in_pitch;
@@ -319,7 +322,7 @@ __global__ void __launch_bounds__(6 * (N / 16)) k_c2r_invariants(const PfC2RPara
     }
     line_sync();
     if (R + gridDim.x < nrows) fetch(R + gridDim.x);  // in flight during the stages and the reduction below
-    PfStages<F, M, +1, 2>::run(
+    PfStages<F, M, +1, 2, 0, (NT <= 64)>::run(
         v, tlj, tw, [&](int pos, C val) { L[pf_lpad(pos)] = val; }, [&](int pos) { return L[pf_lpad(pos)]; });
     line_sync();  // every thread of the line is done with the exchange area
     // the real row of this component, in order, into its line

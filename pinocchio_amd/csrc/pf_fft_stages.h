@@ -2,20 +2,23 @@
 #pragma once
 #include "pf_fft_core.h"
 
-template <typename F, int N, int DIR, int TWS, int S = 0>
+// WAVE_LOCAL: the N / 8 threads of a transform sit in one wave and exchange through LDS words nobody else touches: the
+// LDS queue serves a wave's accesses in order, so the exchange needs no workgroup barrier
+template <typename F, int N, int DIR, int TWS, int S = 0, bool WAVE_LOCAL = false>
 struct PfStages {
   template <typename WR, typename RD>
   static __device__ __forceinline__ void run(pfc<F> (&v)[8], int tl, const pfc<F> *__restrict__ tw, WR wr, RD rd) {
+    static_assert(!WAVE_LOCAL || N / 8 <= 64, "a wave-local transform has at most 64 threads");
     pf_stage<F, N, S, DIR, TWS>(v, tl, tw);
     if constexpr (S + 1 < pf_nstages(N)) {
       constexpr int NT = N / 8;
 #pragma unroll
       for (int m = 0; m < 8; m++) wr(pf_stage_pos<N, S>(tl, m), v[m]);
-      __syncthreads();
+      if constexpr (WAVE_LOCAL) __builtin_amdgcn_wave_barrier(); else __syncthreads();
 #pragma unroll
       for (int m = 0; m < 8; m++) v[m] = rd(tl + m * NT);
-      __syncthreads();
-      PfStages<F, N, DIR, TWS, S + 1>::run(v, tl, tw, wr, rd);
+      if constexpr (WAVE_LOCAL) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+      PfStages<F, N, DIR, TWS, S + 1, WAVE_LOCAL>::run(v, tl, tw, wr, rd);
     }
   }
 };
