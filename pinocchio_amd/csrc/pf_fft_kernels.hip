@@ -459,6 +459,8 @@ static int launch_c2r_invariants_n(const PfC2RParams &p, hipStream_t st) {
   constexpr int LPL = (M + 1 > M + M / 8) ? M + 1 : M + M / 8;
   static int ncu = 0;
   if (!ncu) { hipDeviceProp_t prop; int dev = 0; hipGetDevice(&dev); hipGetDeviceProperties(&prop, dev); ncu = prop.multiProcessorCount; }
+  // (a second row of prefetch per workgroup -- 159 VGPRs, still two workgroups per CU -- made the pass slower: 222-227 ms
+  // against 190-194 ms per step; more rows in flight on six fields at once cost more in DRAM locality than they hide)
   // two workgroups fit per CU; 32 per CU in the grid evens out the tail (measured 6: 254, 8: 248, 16: 241, 32: 235-237,
   // 64: 236 ms per step of eleven launches at 1024^3)
   static const int per_cu = getenv("PF_ZPASS_INV_WG_PER_CU") ? atoi(getenv("PF_ZPASS_INV_WG_PER_CU")) : 32;
