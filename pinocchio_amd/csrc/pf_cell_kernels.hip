@@ -109,8 +109,9 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
   }
 }
 
+// (four waves per SIMD = four 256-thread workgroups per CU, which the grid of 8 per CU is sized for: at most 128 VGPRs)
 template <typename F, bool FAST>
-__global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse(const PfCollapseParams p) { pf_collapse_body<F, FAST>(p); }
+__global__ void __launch_bounds__(PF_CELL_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) k_collapse(const PfCollapseParams p) { pf_collapse_body<F, FAST>(p); }
 // occupancy experiments (PF_COLLAPSE_WPE): the same body under a register cap
 template <typename F, bool FAST>
 __global__ void __launch_bounds__(PF_CELL_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) k_collapse_w4(const PfCollapseParams p) { pf_collapse_body<F, FAST>(p); }
@@ -121,7 +122,7 @@ template <typename F, bool FAST>
 __global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse_tab(const PfCollapseParams p) { pf_collapse_body<F, FAST, true>(p); }
 // the solve on the three invariants per cell that k_c2r_invariants leaves in h[0..2] (fp64 fields)
 template <bool FAST>
-__global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse_inv(const PfCollapseParams p) { pf_collapse_body<double, FAST, false, true>(p); }
+__global__ void __launch_bounds__(PF_CELL_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) k_collapse_inv(const PfCollapseParams p) { pf_collapse_body<double, FAST, false, true>(p); }
 
 // K6 with the cells of a workgroup regrouped by the branch of the cubic.  Two thirds of the cells have a one-root cubic
 // (square root, cube root: ~66 instructions), one third a three-root one (acos, sincos: ~116), and no wave of 64
