@@ -58,12 +58,12 @@ extern "C" const char *pf_last_error(void) { return g_err; }
 enum {
   KS_XPASS_HESS = 0, KS_YPASS_HESS, KS_ZPASS_HESS, KS_COLLAPSE, KS_LPT_SRC, KS_LPT_ACC, KS_R2C_Z, KS_YPASS_FWD,
   KS_XPASS_FWD, KS_XPASS_DISP, KS_YPASS_DISP, KS_ZPASS_DISP, KS_XPASS_PLAIN, KS_YPASS_PLAIN, KS_ZPASS_PLAIN,
-  KS_EXCHANGE, KS_MISC, KS_ZCOLLAPSE, KS_ZPASS_INV, KS_COLLAPSE_INV, KS_COUNT
+  KS_EXCHANGE, KS_MISC, KS_ZCOLLAPSE, KS_ZPASS_INV, KS_COLLAPSE_INV, KS_ZPASS_LPT3B, KS_COUNT
 };
 static const char *ks_names[KS_COUNT] = {
     "xpass_hess_1to3", "ypass_hess_3to6", "zpass_c2r_hess_6", "collapse", "lpt_sources", "lpt_accum", "zpass_r2c",
     "ypass_fwd", "xpass_fwd", "xpass_disp_1to2", "ypass_disp_2to3", "zpass_c2r_disp_3", "xpass_plain", "ypass_plain",
-    "zpass_c2r_plain", "exchange", "misc", "zpass_collapse_fused", "zpass_c2r_hess_6to3inv", "collapse_inv"};
+    "zpass_c2r_plain", "exchange", "misc", "zpass_collapse_fused", "zpass_c2r_hess_6to3inv", "collapse_inv", "zpass_c2r_hess_6_lpt3b"};
 
 struct EvPair { int kind; hipEvent_t a, b; double bytes; };
 
@@ -481,7 +481,8 @@ static int ypass(pf_ctx *c, int kind, int dir, int njobs, const Job *jobs, bool 
   return 0;
 }
 struct ZJob { const void *in; void *out; int mul; int f32; };
-static int zpass_c2r(pf_ctx *c, int kind, int njobs, const ZJob *jobs, const double *dc, int band = 1 << 30, bool invariants = false) {
+static int zpass_c2r(pf_ctx *c, int kind, int njobs, const ZJob *jobs, const double *dc, int band = 1 << 30, bool invariants = false,
+                     void *acc = nullptr) {
   PfC2RParams p; memset(&p, 0, sizeof(p));
   p.njobs = njobs;
   double outb = 0;
@@ -494,6 +495,12 @@ static int zpass_c2r(pf_ctx *c, int kind, int njobs, const ZJob *jobs, const dou
   p.band_k = c->n;
   double frac_in = 1.0;
   if (band < c->n / 2) { p.band_k = band; frac_in = (double)(band + 1) / c->nzh; }
+  if (acc) {  // six components in, none out: acc -= 2 phi2_ab h_ab with the first-order Hessian h in jobs[].out (src/LPT.c:134-137)
+    p.acc = acc;
+    KTimer t(c, KS_ZPASS_LPT3B, njobs * frac_in * spec_bytes_alg(c) + 8.0 * real_bytes_alg(c));
+    PFCHK(c, pf_launch_c2r_invariants(c->n, p, c->stream, 1));
+    return 0;
+  }
   if (invariants) {  // six components in, the three invariants of the tensor out (fields 0..2)
     KTimer t(c, KS_ZPASS_INV, njobs * frac_in * spec_bytes_alg(c) + 3.0 * real_bytes_alg(c));
     PFCHK(c, pf_launch_c2r_invariants(c->n, p, c->stream));
@@ -624,23 +631,31 @@ static int hess_x(pf_ctx *c, const void *spec, double rs, void *const A[3], int 
   const Job xj[3] = {{spec, A[0], PF_MUL_ONE}, {spec, A[1], PF_MUL_K}, {spec, A[2], PF_MUL_K2}};
   return xpass(c, KS_XPASS_HESS, +1, 3, xj, 1, rs, 1.0, 1, band, true);
 }
-static int hess_yz(pf_ctx *c, const void *const R[3], const double *dc, void *const out[6], int band, bool xy_only, bool invariants = false) {
+static int hess_yz(pf_ctx *c, const void *const R[3], const double *dc, void *const out[6], int band, bool xy_only, bool invariants = false,
+                   void *acc = nullptr, void *const *hfirst = nullptr) {
   const Job yj[6] = {{R[2], out[0], PF_MUL_ONE}, {R[1], out[3], PF_MUL_K}, {R[1], out[4], PF_MUL_ONE},
                      {R[0], out[1], PF_MUL_K2}, {R[0], out[5], PF_MUL_K},  {R[0], out[2], PF_MUL_ONE}};
   PFCHK(c, ypass(c, KS_YPASS_HESS, +1, 6, yj, true, false, 3, band, true));
   if (xy_only) { c->last_band = band; return 0; }
   const ZJob zj[6] = {{out[0], out[0], PF_MUL_ONE, 0}, {out[1], out[1], PF_MUL_ONE, 0}, {out[2], out[2], PF_MUL_K2, 0},
                       {out[3], out[3], PF_MUL_ONE, 0}, {out[4], out[4], PF_MUL_K, 0},   {out[5], out[5], PF_MUL_K, 0}};
+  if (acc) {  // the z-pass contracts the six rows with the first-order Hessian `hfirst` into `acc` and stores nothing else
+    ZJob cj[6];
+    for (int i = 0; i < 6; i++) { cj[i] = zj[i]; cj[i].out = hfirst[i]; }
+    PFCHK(c, zpass_c2r(c, KS_ZPASS_HESS, 6, cj, dc, band, false, acc));
+    return 0;
+  }
   PFCHK(c, zpass_c2r(c, KS_ZPASS_HESS, 6, zj, dc, band, invariants));
   return 0;
 }
-static int hessian_of(pf_ctx *c, const void *spec, double rs, const double *dc, void *const out[6], bool xy_only = false) {
+static int hessian_of(pf_ctx *c, const void *spec, double rs, const double *dc, void *const out[6], bool xy_only = false,
+                      void *acc = nullptr, void *const *hfirst = nullptr) {
   if (c->general) return g_hessian_of(c, spec, rs, out);
   const int band = hess_band(c, rs, xy_only);
   return pipelined_band(c, 1, 3,
                         [&](int, void *const *A) { return hess_x(c, spec, rs, A, band); },
                         [&](int, int set, int f) { return recv_field(c, set, f); },
-                        [&](int, const void *const *R) { return hess_yz(c, R, dc, out, band, xy_only); },
+                        [&](int, const void *const *R) { return hess_yz(c, R, dc, out, band, xy_only, false, acc, hfirst); },
                         [&](int) { return band; });
 }
 
@@ -1168,11 +1183,17 @@ extern "C" int pf_displacements(pf_ctx *c, int compute_sources, int recompute_sd
       PFCHK(c, pf_launch_sum1(c->partials, sp.nblocks, 1.0 / ((double)c->n * c->n * c->n), c->scal + SC_DC_S2, c->stream));
       PFCHK(c, allreduce_dev(c, c->scal + SC_DC_S2, 1, 0));
       PFCHK(c, forward_of(c, c->S[0]));
-      PFCHK(c, hessian_of(c, c->S[0], 0.0, c->scal + SC_DC_S2, c->B2));
-      PfLptAccParams ap; memset(&ap, 0, sizeof(ap));
-      for (int i = 0; i < 6; i++) { ap.h[i] = c->B[i]; ap.phi2[i] = c->B2[i]; }
-      ap.s3b = c->S[2]; ap.pitch = rpitch(c); ap.nrows = (long long)c->nxl * c->n; ap.n = c->n;
-      {
+      // Hessian of the 2LPT potential contracted with the first-order one into the 3LPT(b) source (src/LPT.c:112-137).  fp64
+      // fields: the z-pass does the contraction while it holds a row's six components (nothing of that Hessian is stored;
+      // PF_LPT_FUSE=0: six fields out, then k_lpt_accum); same operations per cell either way
+      const bool fuse3b = c->fb == 8 && !c->general && !(getenv("PF_LPT_FUSE") && !atoi(getenv("PF_LPT_FUSE")));
+      if (fuse3b) {
+        PFCHK(c, hessian_of(c, c->S[0], 0.0, c->scal + SC_DC_S2, c->B2, false, c->S[2], c->B));
+      } else {
+        PFCHK(c, hessian_of(c, c->S[0], 0.0, c->scal + SC_DC_S2, c->B2));
+        PfLptAccParams ap; memset(&ap, 0, sizeof(ap));
+        for (int i = 0; i < 6; i++) { ap.h[i] = c->B[i]; ap.phi2[i] = c->B2[i]; }
+        ap.s3b = c->S[2]; ap.pitch = rpitch(c); ap.nrows = (long long)c->nxl * c->n; ap.n = c->n;
         KTimer t(c, KS_LPT_ACC, 14.0 * real_bytes_alg(c));
         PFCHK(c, pf_launch_lpt_accum(c->fb, ap, c->stream));
       }

@@ -378,16 +378,10 @@ __global__ void __launch_bounds__(PF_CELL_BLOCK) k_lpt_accum(const PfLptAccParam
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < ncell; i += (long long)gridDim.x * blockDim.x) {
     const long long row = i / p.n;
     const long long a = row * p.pitch + (i - row * p.n);
-    double s = s3b[a];
-    // reference order of (ia,ib): 11,12,13,22,23,33 -> storage index 0,3,4,1,5,2
-    const int order[6] = {0, 3, 4, 1, 5, 2};
+    double ph[6], hh[6];
 #pragma unroll
-    for (int j = 0; j < 6; j++) {
-      const int c = order[j];
-      const double f = 2.0 * (c < 3 ? 1.0 : 2.0);
-      s -= f * (double)((const F *)p.phi2[c])[a] * (double)((const F *)p.h[c])[a];
-    }
-    s3b[a] = (F)s;
+    for (int c = 0; c < 6; c++) { ph[c] = (double)((const F *)p.phi2[c])[a]; hh[c] = (double)((const F *)p.h[c])[a]; }
+    s3b[a] = (F)pf_lpt3b_accumulate((double)s3b[a], ph, hh);
   }
 }
 

@@ -385,6 +385,25 @@ template <bool FAST = false> PF_HD double pf_ell_classic(double l1, double l2, d
 
 // Eigenvalues of the symmetric tensor d = {11,22,33,12,13,23} by the trigonometric formula, ordered by ord()
 // (src/collapse_times.c:679-745).  Returns false for the -10 sentinel branch (q^3 < r^2 or q < 0).
+// 3LPT(b) source accumulation of one cell (src/LPT.c:134-137): s -= 2 phi2_ab h_ab over the six components in the
+// reference's order 11,12,13,22,23,33 (storage index 0,3,4,1,5,2), off-diagonal ones twice.  One definition for
+// k_lpt_accum and for the z-pass that forms it on the fly (k_c2r_invariants, MODE 1); never contracted.
+PF_HD double pf_lpt3b_accumulate(double s, const double phi2[6], const double h[6]) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  const int order[6] = {0, 3, 4, 1, 5, 2};
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int j = 0; j < 6; j++) {
+    const int c = order[j];
+    const double f = 2.0 * (c < 3 ? 1.0 : 2.0);
+    s -= f * phi2[c] * h[c];
+  }
+  return s;
+}
+
 // ... in two pieces: the three invariants of the tensor, and everything after them.  The invariants are all the solve
 // needs, so the z-pass of the sweep can store them (3 fields) instead of the six components (k_c2r_invariants); only an
 // exactly isotropic tensor (q == 0) takes its eigenvalues from the diagonal itself, `diag`.

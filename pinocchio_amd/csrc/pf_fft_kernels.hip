@@ -262,7 +262,10 @@ __global__ void __launch_bounds__(TL *(N / 16)) k_c2r_persistent(const PfC2RPara
 // 26 GB instead of 52 and the solve reads 26 instead of 52.  The component values are formed by the same expression as in
 // k_c2r (pf_norm_dc) and the invariants by the solve's own pf_invariants (no contraction): Fmax, Rmax and the variances
 // come out bit for bit as with the six-field path.  fp64 fields.
-template <int N>
+// MODE 1 (the Hessian of the 2LPT potential, src/LPT.c:112-137): the six rows are not stored at all; each cell's 3LPT(b)
+// source is updated in place from them and the six components of the first-order Hessian (read from job[c].out):
+// p.acc -= 2 phi2_ab h_ab, by the same pf_lpt3b_accumulate as k_lpt_accum.
+template <int N, int MODE = 0>
 __global__ void __launch_bounds__(6 * (N / 16)) k_c2r_invariants(const PfC2RParams p, long long nrows) {
   using F = double;
   using C = pfc<F>;
@@ -336,13 +339,25 @@ __global__ void __launch_bounds__(6 * (N / 16)) k_c2r_invariants(const PfC2RPara
 #pragma unroll
       for (int k = 0; k < 6; k++) h[k] = *reinterpret_cast<const double2 *>(reinterpret_cast<const F *>(lds + k * LPL) + c);
       const double da[6] = {h[0].x, h[1].x, h[2].x, h[3].x, h[4].x, h[5].x}, db[6] = {h[0].y, h[1].y, h[2].y, h[3].y, h[4].y, h[5].y};
-      double a1, a2, a3, b1, b2, b3;
-      pf_invariants(da, a1, a2, a3);
-      pf_invariants(db, b1, b2, b3);
       const long long a = R * p.out_pitch + c;
-      *reinterpret_cast<double2 *>(o1 + a) = make_double2(a1, b1);
-      *reinterpret_cast<double2 *>(o2 + a) = make_double2(a2, b2);
-      *reinterpret_cast<double2 *>(o3 + a) = make_double2(a3, b3);
+      if (MODE == 0) {
+        double a1, a2, a3, b1, b2, b3;
+        pf_invariants(da, a1, a2, a3);
+        pf_invariants(db, b1, b2, b3);
+        *reinterpret_cast<double2 *>(o1 + a) = make_double2(a1, b1);
+        *reinterpret_cast<double2 *>(o2 + a) = make_double2(a2, b2);
+        *reinterpret_cast<double2 *>(o3 + a) = make_double2(a3, b3);
+      } else {
+        double ha[6], hb[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          const double2 g = *reinterpret_cast<const double2 *>(reinterpret_cast<const F *>(p.job[k].out) + a);
+          ha[k] = g.x; hb[k] = g.y;
+        }
+        double2 *acc = reinterpret_cast<double2 *>(reinterpret_cast<F *>(p.acc) + a);
+        const double2 s = *acc;
+        *acc = make_double2(pf_lpt3b_accumulate(s.x, da, ha), pf_lpt3b_accumulate(s.y, db, hb));
+      }
     }
     __syncthreads();  // the lines are rewritten by the next phase A
   }
@@ -454,7 +469,7 @@ static int launch_c2r_n(const PfC2RParams &p, hipStream_t st) {
 }
 
 template <int N>
-static int launch_c2r_invariants_n(const PfC2RParams &p, hipStream_t st) {
+static int launch_c2r_invariants_n(const PfC2RParams &p, hipStream_t st, int mode) {
   constexpr int M = N / 2, NT = M / 8;
   constexpr int LPL = (M + 1 > M + M / 8) ? M + 1 : M + M / 8;
   static int ncu = 0;
@@ -467,7 +482,8 @@ static int launch_c2r_invariants_n(const PfC2RParams &p, hipStream_t st) {
   long long g = (long long)ncu * (per_cu > 0 ? per_cu : 32);
   if (g > p.nlines) g = p.nlines;
   const size_t shm = (size_t)6 * LPL * sizeof(pfc<double>);
-  hipLaunchKernelGGL((k_c2r_invariants<N>), dim3((unsigned)g), dim3(6 * NT), shm, st, p, p.nlines);
+  if (mode == 1) hipLaunchKernelGGL((k_c2r_invariants<N, 1>), dim3((unsigned)g), dim3(6 * NT), shm, st, p, p.nlines);
+  else hipLaunchKernelGGL((k_c2r_invariants<N, 0>), dim3((unsigned)g), dim3(6 * NT), shm, st, p, p.nlines);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
@@ -532,9 +548,9 @@ int pf_launch_c2r(int fb, int n, const PfC2RParams &p, hipStream_t st) {
   }
 }
 
-int pf_launch_c2r_invariants(int n, const PfC2RParams &p, hipStream_t st) {
-  if (p.njobs != 6) return 2;
-#define CALL(NN) launch_c2r_invariants_n<NN>(p, st)
+int pf_launch_c2r_invariants(int n, const PfC2RParams &p, hipStream_t st, int mode) {
+  if (p.njobs != 6 || (mode == 1 && !p.acc)) return 2;
+#define CALL(NN) launch_c2r_invariants_n<NN>(p, st, mode)
   PF_SWITCH_N(n, CALL)
 #undef CALL
 }

@@ -67,10 +67,12 @@ struct PfC2RParams {
   const double *dc;     // device scalar added after normalisation (DC mode of 2nd derivatives), or null
   const void *tw;       // exp(+2 pi i j / n)
   int band_k;           // input columns kz > band_k are zero (pruned), not read
+  void *acc;            // k_c2r_invariants MODE 1: the real field updated in place (3LPT(b) source); job[c].out = first-order Hessian
 };
 int pf_launch_c2r(int field_bytes, int n, const PfC2RParams &p, hipStream_t st);
 // six components (njobs == 6, fp64) -> the three invariants of the tensor into job[0..2].out (pf_fft_kernels.hip)
-int pf_launch_c2r_invariants(int n, const PfC2RParams &p, hipStream_t st);
+// mode 1: nothing stored, p.acc -= 2 phi2_ab h_ab with h_ab read from job[c].out (the 3LPT(b) source, src/LPT.c:134-137)
+int pf_launch_c2r_invariants(int n, const PfC2RParams &p, hipStream_t st, int mode = 0);
 
 struct PfR2CParams {
   const void *in;       // real rows, pitch in_pitch reals

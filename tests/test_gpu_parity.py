@@ -414,6 +414,29 @@ def test_invariant_zpass_equals_six_component_path(api, n, monkeypatch):
     assert (out["1"][1]["Rmax"] > 0).any() and (out["1"][1]["Rmax"] < 4).any()
 
 
+@pytest.mark.parametrize("n", [16, 64, 256])
+def test_fused_3lpt_source_equals_separate_kernels(api, n, monkeypatch):
+    """Default: the z-pass of the 2LPT potential's Hessian contracts its six components with the first-order Hessian into the
+    3LPT(b) source on the fly (k_c2r_invariants, MODE 1) and stores none of them; PF_LPT_FUSE=0 stores six fields and runs
+    k_lpt_accum.  One per-cell function serves both: every product column bit for bit."""
+    dk = synth.make_density(n, seed=11 + n)
+    dk[0, 0, 0] = -0.2 * n ** 3
+    x, y = synth.invgrow_table("lcdm")
+    radii = np.array([2.0, 0.0])
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PF_LPT_FUSE", mode)
+        with api.Fmax(n) as f:
+            f.set_density(dk)
+            f.set_invgrow(x, y)
+            f.set_growth(synth.growth_multipliers())
+            f.compute_fmax(radii, do_lpt=True)
+            out[mode] = f.products()
+    for name in ("Fmax", "Rmax", "Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+        assert np.array_equal(out["0"][name], out["1"][name]), name
+    assert np.abs(out["1"]["Vel_3LPT_2"]).max() > 0
+
+
 def test_pruned_transform_equals_full_transform(api, monkeypatch):
     """Smoothed radii use a pruned FFT: modes whose Gaussian weight is < 2^-60 are not transformed.
     Against the full transform (PF_PRUNE_EPS=0) the Hessian changes by less than its own rounding."""
