@@ -80,6 +80,18 @@ extern "C" void emul_acos(const double *x, long count, double *out) {
   for (long i = 0; i < count; i++) out[i] = pf_acos_series(x[i]);
 }
 
+// the per-cell reductions the z-pass kernels share with the cell kernels
+extern "C" void emul_invariants(const double *d6, long count, double *mu3, double *lam3, int *ok) {
+  for (long i = 0; i < count; i++) {
+    pf_invariants(d6 + 6 * i, mu3[3 * i], mu3[3 * i + 1], mu3[3 * i + 2]);
+    const double third = mu3[3 * i] * (1.0 / 3.0), diag[3] = {third, third, third};
+    ok[i] = pf_eigen_from_invariants<false>(mu3[3 * i], mu3[3 * i + 1], mu3[3 * i + 2], diag, lam3 + 3 * i) ? 1 : 0;
+  }
+}
+extern "C" void emul_lpt3b(const double *s, const double *phi2, const double *h, long count, double *out) {
+  for (long i = 0; i < count; i++) out[i] = pf_lpt3b_accumulate(s[i], phi2 + 6 * i, h + 6 * i);
+}
+
 extern "C" void emul_pow_third(const double *x, long count, double *out) {
   for (long i = 0; i < count; i++) out[i] = pf_pow_third<true>(x[i]);
 }

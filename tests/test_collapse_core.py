@@ -273,3 +273,39 @@ def test_pow_third_of_the_fast_flavour(emul):
     want = np.array([float(mp.power(mp.mpf(float(v)), -d) - 1) for v in x])
     assert np.max(np.abs(factor - want)) <= 2.3e-16        # one rounding of the factor, one of the product
     assert np.max(np.abs(want)) > 2e-14                     # and the factor is not 1: 2.4e-14 at 1e30
+
+
+def test_invariants_and_lpt_contraction_of_the_zpass(emul):
+    """pf_invariants + pf_eigen_from_invariants (what k_c2r_invariants stores and k_collapse_inv starts from) give the
+    eigenvalues of pf_ordered_eigenvalues bit for bit (same operations), and those are the eigenvalues of the tensor
+    (numpy); pf_lpt3b_accumulate is s - 2 sum_ab phi2_ab h_ab in the reference's order of the components."""
+    iv = C.POINTER(C.c_int)
+    emul.emul_invariants.argtypes = [dp, C.c_long, dp, dp, iv]
+    emul.emul_lpt3b.argtypes = [dp, dp, dp, C.c_long, dp]
+    rng = np.random.default_rng(77)
+    n = 20000
+    d = rng.standard_normal((n, 6)) * 10.0 ** rng.integers(-3, 3, (n, 1))
+    mu = np.empty((n, 3)); lam = np.empty((n, 3)); ok = np.empty(n, dtype=np.int32)
+    emul.emul_invariants(_dp(d), n, _dp(mu), _dp(lam), ok.ctypes.data_as(iv))
+    T = np.zeros((n, 3, 3))
+    T[:, 0, 0], T[:, 1, 1], T[:, 2, 2], T[:, 0, 1], T[:, 0, 2], T[:, 1, 2] = d.T
+    T[:, 1, 0], T[:, 2, 0], T[:, 2, 1] = T[:, 0, 1], T[:, 0, 2], T[:, 1, 2]
+    assert np.allclose(mu[:, 0], np.trace(T, axis1=1, axis2=2), rtol=1e-13, atol=0)
+    assert np.allclose(mu[:, 2], np.linalg.det(T), rtol=1e-9, atol=1e-12 * np.abs(d).max(axis=1) ** 3)
+    good = ok == 1
+    assert good.mean() > 0.99
+    ref = np.linalg.eigvalsh(T)[:, ::-1]
+    scale = np.abs(ref).max(axis=1, keepdims=True)
+    assert np.max(np.abs(lam[good] - ref[good]) / scale[good]) < 1e-7     # the trigonometric formula near double roots
+    assert np.median(np.abs(lam[good] - ref[good]) / scale[good]) < 1e-15
+    s = rng.standard_normal(n); ph = rng.standard_normal((n, 6)); h = rng.standard_normal((n, 6))
+    out = np.empty(n)
+    emul.emul_lpt3b(_dp(s), _dp(ph), _dp(h), n, _dp(out))
+    w = np.array([2.0, 2.0, 2.0, 4.0, 4.0, 4.0])
+    assert np.allclose(out, s - (w * ph * h).sum(axis=1), rtol=1e-13, atol=1e-13)
+    # operation order of the reference: 11,12,13,22,23,33, each term 2 (or 4) * phi2 * h, subtracted one by one
+    want = s.copy()
+    for c in (0, 3, 4, 1, 5, 2):
+        want -= (2.0 if c < 3 else 4.0) * ph[:, c] * h[:, c]
+    assert np.array_equal(out, want)
+
