@@ -1095,7 +1095,8 @@ extern "C" int pf_sweep(pf_ctx *c, int ns, const double *radius_cells, double *t
   HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_h[0], 0));
   PFCHK(c, products_reset(c, c->overlap ? c->stream2 : c->stream));
   const bool xy_only = c->fuse;
-  const bool invariants_ok = c->fb == 8 && !c->fuse && !c->general && c->tab_ns == 0 && !getenv("PF_COLLAPSE_WPE") &&
+  // (n <= 1024: the six-line workgroup of a 2048-point row would need 110 KB of dynamic LDS, a size this build never launches)
+  const bool invariants_ok = c->fb == 8 && c->n <= 1024 && !c->fuse && !c->general && c->tab_ns == 0 && !getenv("PF_COLLAPSE_WPE") &&
                              !(getenv("PF_INVARIANTS") && !atoi(getenv("PF_INVARIANTS")));
   auto pre = [&](int ismooth, void *const *A) {
     PhaseTimer pt(c, 0);
@@ -1186,7 +1187,7 @@ extern "C" int pf_displacements(pf_ctx *c, int compute_sources, int recompute_sd
       // Hessian of the 2LPT potential contracted with the first-order one into the 3LPT(b) source (src/LPT.c:112-137).  fp64
       // fields: the z-pass does the contraction while it holds a row's six components (nothing of that Hessian is stored;
       // PF_LPT_FUSE=0: six fields out, then k_lpt_accum); same operations per cell either way
-      const bool fuse3b = c->fb == 8 && !c->general && !(getenv("PF_LPT_FUSE") && !atoi(getenv("PF_LPT_FUSE")));
+      const bool fuse3b = c->fb == 8 && c->n <= 1024 && !c->general && !(getenv("PF_LPT_FUSE") && !atoi(getenv("PF_LPT_FUSE")));
       if (fuse3b) {
         PFCHK(c, hessian_of(c, c->S[0], 0.0, c->scal + SC_DC_S2, c->B2, false, c->S[2], c->B));
       } else {

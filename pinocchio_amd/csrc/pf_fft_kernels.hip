@@ -549,7 +549,7 @@ int pf_launch_c2r(int fb, int n, const PfC2RParams &p, hipStream_t st) {
 }
 
 int pf_launch_c2r_invariants(int n, const PfC2RParams &p, hipStream_t st, int mode) {
-  if (p.njobs != 6 || (mode == 1 && !p.acc)) return 2;
+  if (p.njobs != 6 || (mode == 1 && !p.acc) || n > 1024) return 2;
 #define CALL(NN) launch_c2r_invariants_n<NN>(p, st, mode)
   PF_SWITCH_N(n, CALL)
 #undef CALL
