@@ -230,6 +230,46 @@ def evaluate(f, n, cells):
     return out
 
 
+# ---- SCALE_DEPENDENT build: growth per mode (src/cosmo.c:1728-1755 InterpolateGrowth, :1789-1819 GrowingMode*) ----
+# compute_derivative hands |k| in rad/cell to GrowingMode*(z, k) (src/fmax-pfft.c:339-364): the multiplier of mode m is
+#   sign * 10^( (1 - w) T[kk] + w T[kk+1] ),  t = (log10 k - LOGKMIN) / DELTALOGK, kk = (int) t, w = t - kk,
+#   T[0] below kmin = 10^LOGKMIN, T[nk-1] above kmax = 10^(LOGKMIN + (nk-1) DELTALOGK);  k = 2 pi |m| / N.
+# T = the log10-growth of each k-bin at the redshift of the call (what the spline of each bin returns).  The displacement
+# tables above scale mode by mode: coefficient(m) = coefficient at unit growth * multiplier(|m|).  Evaluated here in 40 digits.
+SD = dict(logkmin=Fr(-1), dlogk=Fr(1, 4), sign=[1, 1, -1, 1],
+          T=[[Fr(-1, 20), Fr(-1, 10), Fr(-1, 5), Fr(-3, 10), Fr(-9, 20), Fr(-3, 5)],
+             [Fr(-2, 5), Fr(-9, 20), Fr(-1, 2), Fr(-3, 5), Fr(-7, 10), Fr(-9, 10)],
+             [Fr(-1), Fr(-19, 20), Fr(-9, 10), Fr(-4, 5), Fr(-3, 4), Fr(-7, 10)],
+             [Fr(-9, 10), Fr(-1), Fr(-11, 10), Fr(-6, 5), Fr(-5, 4), Fr(-13, 10)]])
+
+
+def growth_of_mode(order, m2, n):
+    T = [mpmath.mpf(t.numerator) / t.denominator for t in SD["T"][order]]
+    nk = len(T)
+    lkmin = mpmath.mpf(SD["logkmin"].numerator) / SD["logkmin"].denominator
+    dlk = mpmath.mpf(SD["dlogk"].numerator) / SD["dlogk"].denominator
+    k = 2 * mpmath.pi * mpmath.sqrt(m2) / n
+    if k < mpmath.power(10, lkmin):
+        v = T[0]
+    elif k > mpmath.power(10, lkmin + (nk - 1) * dlk):
+        v = T[nk - 1]
+    else:
+        t = (mpmath.log10(k) - lkmin) / dlk
+        kk = int(mpmath.floor(t))
+        w = t - kk
+        assert 1e-9 < w < 1 - 1e-9 and kk + 1 < nk, "a mode on a bin edge would hang on the last bit of log10"
+        v = w * T[kk + 1] + (1 - w) * T[kk]
+    return SD["sign"][order] * mpmath.power(10, v)
+
+
+def scale_dependent_section(r):
+    m2s = sorted({m[0] ** 2 + m[1] ** 2 + m[2] ** 2 for fs in r["vel"].values() for f in fs for m in f})
+    gk = {}
+    for n in (16, 32, 64):
+        gk[str(n)] = [{str(m2): float(growth_of_mode(o, m2, n)) for m2 in m2s} for o in range(4)]
+    return dict(logkmin=str(SD["logkmin"]), dlogk=str(SD["dlogk"]), sign=SD["sign"], T=[[str(t) for t in row] for row in SD["T"]], gk=gk)
+
+
 CASES = [
     # three waves in general position, no mean; growth multipliers of the EdS normalisation (src/cosmo.c:250-257, sign of
     # the 3LPT_1 term from GrowingMode_3LPT_1, src/cosmo.c:1810)
@@ -274,7 +314,8 @@ def main():
             waves=[[list(m), str(a), str(b)] for m, a, b in case["waves"]], max_mode=mmax,
             delta=table_json(r["delta"]), d=[table_json(f) for f in r["d"]], s2=table_json(r["s2"]), s3a=table_json(r["s3a"]),
             s3b=table_json(r["s3b"]), phi2=[table_json(f) for f in r["phi2"]],
-            vel={k: [table_json(f) for f in fs] for k, fs in r["vel"].items()}, sample=sample))
+            vel={k: [table_json(f) for f in fs] for k, fs in r["vel"].items()}, sample=sample,
+            scale_dependent=scale_dependent_section(r)))
         print(case["name"], "modes:", len(r["delta"]), len(r["s2"]), len(r["s3a"]), len(r["s3b"]), "max |m_i|", mmax)
     with open(os.path.join(HERE, "lpt_analytic.json"), "w") as f:
         json.dump(out, f, separators=(",", ":"))

@@ -116,3 +116,28 @@ def fp32_close(got_f32, want_f64, extra_abs=0.0):
     err = np.abs(got_f32.astype(np.float64) - want_f64) - extra_abs
     off = (got_f32 != want32) & (np.abs(got_f32.astype(np.float64) - want32.astype(np.float64)) > extra_abs)  # (zero crossings aside)
     return float(np.max(err / ulp)), float(np.mean(off))
+
+
+def scale_dependent_expected(c, n, x0=0, nx=None):
+    """Vel* of a SCALE_DEPENDENT build: every mode of the unit-growth displacement tables times the multiplier of its |k|
+    (generator's 40-digit values of InterpolateGrowth / GrowingMode*, src/cosmo.c:1728-1819, at k = 2 pi |m| / n rad/cell)"""
+    sd = c["scale_dependent"]
+    gk = sd["gk"][str(n)]
+    fac = n / (2 * np.pi)
+    out = {}
+    for o, k in enumerate(VEL_NAMES):
+        g_rat = Fraction(c["growth"][o])
+        comps = []
+        for t in c["vel"][k]:
+            scaled = []
+            for m, re, im in t:
+                w = gk[o][str(m[0] ** 2 + m[1] ** 2 + m[2] ** 2)]
+                scaled.append([m, Fraction(re) / g_rat * Fraction(w), Fraction(im) / g_rat * Fraction(w)])
+            comps.append(fac * evaluate(scaled, n, x0, nx))
+        out[k] = np.stack(comps, axis=-1)
+    return out
+
+
+def scale_dependent_tables(c):
+    sd = c["scale_dependent"]
+    return dict(T=[np.array([_f(t) for t in row]) for row in sd["T"]], logkmin=_f(sd["logkmin"]), dlogk=_f(sd["dlogk"]), sign=sd["sign"])

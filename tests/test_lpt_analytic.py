@@ -61,6 +61,33 @@ def test_oracle_vs_closed_form(name, n):
     _check_fields(name, n, d, kv, o.products())
 
 
+def _check_scale_dependent(name, n, prod, x0=0, nx=None):
+    c = la.case(name)
+    e = la.scale_dependent_expected(c, n, x0, nx)
+    for k in la.VEL_NAMES:
+        amp = np.max(np.abs(e[k]))
+        # the multiplier goes through log10 and pow(10., .) in the reference's own arithmetic: ~1e-15 relative per mode
+        ulps, frac = la.fp32_close(prod[k], e[k], extra_abs=2e-14 * amp)
+        assert ulps <= 1.0, (name, n, k, ulps)
+        assert frac <= 1e-3, (name, n, k, frac)
+
+
+@pytest.mark.parametrize("name", ["three_waves", "axis_waves"])
+@pytest.mark.parametrize("n", [16, 32])
+def test_oracle_scale_dependent_growth_vs_closed_form(name, n):
+    """row f-3: k-dependent growth multipliers per mode (SCALE_DEPENDENT build), modes below kmin, inside the table and above kmax"""
+    c = la.case(name)
+    sd = la.scale_dependent_tables(c)
+    o = oracle_lib.Oracle(n, 2)
+    o.set_density(la.density_spectrum(c, n))
+    x, y = synth.invgrow_table("eds")
+    o.set_invgrow(x, y)
+    for order in range(4):
+        o.set_growth_table(order + 1, sd["T"][order], sd["logkmin"], sd["dlogk"], float(sd["sign"][order]))
+    o.compute_fmax(np.array([0.0]), do_lpt=True)
+    _check_scale_dependent(name, n, o.products())
+
+
 # ---------------------------------------------------------------------------------------------------- GPU ----
 @pytest.fixture(scope="module")
 def api():
@@ -205,3 +232,32 @@ def test_lpt_identities_at_scale(api, n):
         for a, b in ((0, 1), (0, 2), (1, 2)):
             assert rms((kk[a] * v[b] - kk[b] * v[a])[ok]) <= 2e-6 * amp, (name, "curl", a, b)
         assert abs(v[0][0, 0, 0]) <= 1e-6 * amp * n ** 1.5                  # the mean displacement is zero
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["three_waves", "axis_waves"])
+@pytest.mark.parametrize("n,nranks", [(16, 1), (32, 1), (64, 1), (32, 2)])
+def test_hip_scale_dependent_growth_vs_closed_form(api, name, n, nranks):
+    """row f-3 on the device: pf_set_growth_table + k_apply_growth against the per-mode closed form"""
+    import test_gpu_multirank as mr
+    c = la.case(name)
+    sd = la.scale_dependent_tables(c)
+    x, y = synth.invgrow_table("eds")
+    dk = la.density_spectrum(c, n)
+    nxl = n // nranks
+
+    def body(f, r):
+        f.set_density(dk[r * nxl:(r + 1) * nxl])
+        f.set_invgrow(x, y)
+        for order in range(4):
+            f.set_growth_table(order + 1, sd["T"][order], sd["logkmin"], sd["dlogk"], float(sd["sign"][order]))
+        f.compute_fmax(np.array([0.0]), do_lpt=True)
+        return f.products()
+
+    if nranks == 1:
+        with api.Fmax(n) as f:
+            _check_scale_dependent(name, n, body(f, 0))
+    else:
+        res = mr.run_ranks(api, n, nranks, body)
+        for r in range(nranks):
+            _check_scale_dependent(name, n, res[r], x0=r * nxl, nx=nxl)
