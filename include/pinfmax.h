@@ -83,8 +83,12 @@ int pf_set_exchange(pf_ctx *ctx, pf_alltoall_fn fn, void *user);
 typedef int (*pf_alltoallv_fn)(void *user, const void *sendbuf, void *recvbuf, size_t block_bytes, size_t send_off,
                                size_t send_bytes, const size_t *recv_off, const size_t *recv_bytes, void *stream);
 int pf_set_exchange_rows(pf_ctx *ctx, pf_alltoallv_fn fn, void *user);
+int pf_rccl_available(void);                        /* 1 when librccl can be bound in this process (host side only: no
+                                                       communicator, no collective -- what the ranks vote on before any of them
+                                                       enters ncclCommInitRank) */
 int pf_rccl_unique_id(void *id128);                 /* rank 0: ncclGetUniqueId */
-int pf_init_rccl(pf_ctx *ctx, const void *id128);   /* all ranks: ncclCommInitRank */
+int pf_init_rccl(pf_ctx *ctx, const void *id128);   /* all ranks: ncclCommInitRank; the context owns the communicator */
+int pf_release_rccl(pf_ctx *ctx);                   /* ncclCommDestroy + callbacks cleared (also done by pf_destroy) */
 /* small reductions (MPI_Reduce/MPI_Bcast at src/collapse_times.c:656-667,
    src/fmax.c:527): sum `count` doubles / uint64 in place over all ranks */
 typedef int (*pf_allreduce_fn)(void *user, void *buf, size_t count, int is_u64, void *stream);
@@ -238,6 +242,21 @@ int pf_derivative(pf_ctx *ctx, const double *spec_host, int first_derivative, in
    0 a/b, 1 sqrt(a), 2 acos(a), 3 log10(a), 4 sin (b != 0) or cos (b == 0) of a in [0, pi/3], 5 a^0.333333333333333, 6 a/9,
    7 exp(a), 8 10^a, 9 / 10 the raw hardware seeds v_rcp_f64(a) / v_rsq_f64(a) */
 int pf_debug_math(pf_ctx *ctx, int which, const double *a, const double *b, size_t count, double *out);
+/* test tap without a context: ONE pass kernel on a batch of lines, host in / host out in fp64 (converted to field_bytes on
+   the way); every instantiation of the hand-written transforms -- N = 2048 of BASELINE config 5 included, whose box does
+   not fit one GPU -- can so be compared line by line with an independent transform (tests/test_gpu_lines.py).
+   pass 0 / 1: the strided x / y pass, inverse / forward, complex [nouter][n][ncols] in and out, with the k-space factor
+   `mul` (0 one, 1 k, 2 k^2, 3 i k) along the transformed axis, loads beyond |wavenumber| > band treated as zeros, and with
+   pre != 0 the first-pass filter exp(-k^2 rs^2 / 2) growth / k^2 of compute_derivative (src/fmax-pfft.c:366-373);
+   pass 2: z-pass c2r, complex [nouter][n/2+1] -> real [nouter][n], unnormalised (reverse_transform without its 1/N^3);
+   pass 3: z-pass r2c, real [nouter][n] -> complex [nouter][n/2+1] (forward_transform);
+   pass 4: the six-rows-to-three-invariants z-pass of the sweep, complex [6][nouter][n/2+1] -> real [3][nouter][n], followed by
+           one more double: 1.0 when a cell raised the q == 0 flag (see pf_debug_invariant_reruns). */
+int pf_debug_lines(int field_bytes, int n, int pass, int mul, int band, int nouter, int ncols, int pre, double rs,
+                   double growth, int outer_offset, const double *in, double *out);
+/* how many sweeps of this context were repeated with six components per cell because the invariant z-pass met a tensor
+   with q == 0 that is not exactly isotropic (the reference's "already diagonal" branch, src/collapse_times.c:722-727) */
+int pf_debug_invariant_reruns(pf_ctx *ctx);
 /* per-cell solver on a list of Hessians d[6*count] -> F[count] (tests of
    inverse_collapse_time, src/collapse_times.c:679-776), ismooth selects the spline */
 int pf_collapse_cells(pf_ctx *ctx, int ismooth, const double *d, size_t count, double *F);

@@ -56,6 +56,8 @@ PROTOTYPES = {
     "pf_last_error": (C.c_char_p, []),
     "pf_set_exchange": (C.c_int, [_vp, ALLTOALL_FN, _vp]),
     "pf_set_exchange_rows": (C.c_int, [_vp, ALLTOALLV_FN, _vp]),
+    "pf_rccl_available": (C.c_int, []),
+    "pf_release_rccl": (C.c_int, [_vp]),
     "pf_rccl_unique_id": (C.c_int, [_vp]),
     "pf_init_rccl": (C.c_int, [_vp, _vp]),
     "pf_set_allreduce": (C.c_int, [_vp, ALLREDUCE_FN, _vp]),
@@ -87,6 +89,8 @@ PROTOTYPES = {
     "pf_ct_build": (C.c_int, [_vp, C.c_int, C.c_double, C.POINTER(C.c_double)]),
     "pf_ct_load": (C.c_int, [_vp, C.c_int, C.c_double, C.POINTER(C.c_double)]),
     "pf_debug_math": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_double)]),
+    "pf_debug_lines": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, _dp, _dp]),
+    "pf_debug_invariant_reruns": (C.c_int, [_vp]),
     "pf_update_products": (C.c_int, [_vp, _vp, C.POINTER(ProductLayout)]),
     "pf_set_growth_table": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_double, C.c_double, C.c_double]),
     "pf_get_second_derivative": (C.c_int, [_vp, C.c_int, _dp]),

@@ -29,6 +29,8 @@
 #include "pf_collapse_core.h"
 #include "pf_internal.h"
 
+extern "C" void pf_rccl_release(void *link);  // pf_rccl.cpp
+
 // ------------------------------------------------------------------ errors --
 static thread_local char g_err[512] = "";
 static int pf_fail(int task, const char *fmt, ...) {
@@ -54,6 +56,12 @@ extern "C" const char *pf_last_error(void) { return g_err; }
     if (r__) return pf_fail((ctx)->rank, "%s failed (%d) (%s:%d)", #call, r__, __FILE__, __LINE__); \
   } while (0)
 
+#define PFCHK0(call)                                                                       \
+  do {                                                                                     \
+    int r__ = (call);                                                                      \
+    if (r__) return pf_fail(0, "%s failed (%d) (%s:%d)", #call, r__, __FILE__, __LINE__);  \
+  } while (0)
+
 // ----------------------------------------------------------------- context --
 enum {
   KS_XPASS_HESS = 0, KS_YPASS_HESS, KS_ZPASS_HESS, KS_COLLAPSE, KS_LPT_SRC, KS_LPT_ACC, KS_R2C_Z, KS_YPASS_FWD,
@@ -73,12 +81,12 @@ struct pf_ctx {
   pf_config cfg;
   int n, nzh, nzp, P, rank, nxl, nyl, fb;
   bool timing;
-  hipStream_t stream;   // FFT passes and everything else
-  hipStream_t stream2;  // collapse solve of radius i, overlapped with the passes of radius i+1 (pf_sweep)
-  hipEvent_t ev_h[2], ev_c[2];
+  hipStream_t stream;   // every kernel of the path; the exchanges of a pipelined multi-rank run go to cstream
   int collapse_blocks;
-  bool overlap, fuse, fast_libm;
-  int ncu, fused_wg_per_cu, fused_skew_ns, last_band;
+  bool fast_libm;
+  int ncu, dev;
+  int inv_reruns;       // sweeps repeated with six components because the invariant z-pass met a q == 0 cell (pf_sweep)
+  PfTuning tune;        // run-time switches, read from the environment once, in pf_create
   double prune_eps;
   bool own_stream;
   size_t field_bytes;  // one spectrum-sized field
@@ -141,7 +149,7 @@ struct pf_ctx {
 #define PF_NBLK 2048
 #define PF_KNOT_CAP 512
 #define PF_KBIN_CAP 32
-enum { SC_SUM = 0, SC_SUM2 = 1, SC_DC_DK = 2, SC_DC_S2 = 3, SC_POWER = 4, SC_DSCALE = 5, SC_DC_TMP = 6, SC_VAR0 = 8 /* 2 per radius */, SC_COUNT = 8 + 2 * PF_MAX_SMOOTH };
+enum { SC_SUM = 0, SC_SUM2 = 1, SC_DC_DK = 2, SC_DC_S2 = 3, SC_POWER = 4, SC_DSCALE = 5, SC_DC_TMP = 6, SC_INV_FLAG = 7 /* raised by the invariant z-pass, see pf_sweep; adjacent to SC_VAR0: one all-reduce */, SC_VAR0 = 8 /* 2 per radius */, SC_COUNT = 8 + 2 * PF_MAX_SMOOTH };
 
 static hipEvent_t ev_get(pf_ctx *c) {
   if (!c->evpool.empty()) { hipEvent_t e = c->evpool.back(); c->evpool.pop_back(); return e; }
@@ -163,7 +171,6 @@ struct PhaseTimer {
 };
 static void resolve_events(pf_ctx *c) {
   hipStreamSynchronize(c->stream);
-  hipStreamSynchronize(c->stream2);
   hipStreamSynchronize(c->cstream);
   for (auto &e : c->evs) {
     float ms = 0; hipEventElapsedTime(&ms, e.a, e.b);
@@ -187,6 +194,18 @@ static int dev_alloc(pf_ctx *c, void **p, size_t bytes) {
   return 0;
 }
 
+// twiddles exp(+2 pi i j / n), computed in long double on the host, exact on the axes
+static void host_twiddles(int n, int fb, std::vector<char> &h) {
+  h.resize((size_t)n * 2 * fb);
+  for (int j = 0; j < n; j++) {
+    long double a = 2.0L * 3.14159265358979323846264338327950288L * (long double)j / (long double)n;
+    double re = (double)cosl(a), im = (double)sinl(a);
+    if (j == 0) { re = 1; im = 0; } else if (4 * j == n) { re = 0; im = 1; } else if (2 * j == n) { re = -1; im = 0; } else if (4 * j == 3 * n) { re = 0; im = -1; }
+    if (fb == 8) { ((double *)h.data())[2 * j] = re; ((double *)h.data())[2 * j + 1] = im; }
+    else { ((float *)h.data())[2 * j] = (float)re; ((float *)h.data())[2 * j + 1] = (float)im; }
+  }
+}
+
 extern "C" void pf_layout_3lpt(pf_product_layout *l) {
   l->stride = 56; l->off_Rmax = 0; l->off_Fmax = 4; l->off_Vel = 8; l->off_Vel_2LPT = 20; l->off_Vel_3LPT_1 = 32; l->off_Vel_3LPT_2 = 44;
 }
@@ -196,13 +215,92 @@ static long long rpitch(const pf_ctx *c) { return c->general ? c->n : 2 * c->nzp
 static double spec_bytes_alg(const pf_ctx *c) { return (double)c->n * c->nyl * c->nzh * 2.0 * c->fb; }  // one half-spectrum field
 static double real_bytes_alg(const pf_ctx *c) { return (double)ncell(c) * c->fb; }
 
+static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+// The run-time switches of DESIGN.md section 6: read here, once per context, never on a launch path.
+static void read_tuning(PfTuning *t) {
+  t->zpass_persist = env_int("PF_ZPASS_PERSIST", 24);
+  t->zpass_inv_wg_per_cu = env_int("PF_ZPASS_INV_WG_PER_CU", 32);
+  if (t->zpass_inv_wg_per_cu <= 0) t->zpass_inv_wg_per_cu = 32;
+  t->spline_lut = env_int("PF_SPLINE_LUT", 1) != 0;
+  t->exchange_rows = env_int("PF_EXCHANGE_ROWS", 1) != 0;
+  t->invariants = env_int("PF_INVARIANTS", 1) != 0;
+  t->lpt_fuse = env_int("PF_LPT_FUSE", 1) != 0;
+  t->collapse_wg_per_cu = env_int("PF_COLLAPSE_WG_PER_CU", 8);
+  if (t->collapse_wg_per_cu <= 0) t->collapse_wg_per_cu = 8;
+  t->general = env_int("PF_GENERAL", 0) != 0;
+  t->pipeline = env_int("PF_PIPELINE", 1) != 0;
+  t->exact_libm = env_int("PF_EXACT_LIBM", 0) != 0;
+  t->prune_eps = 8.673617379884035e-19;  // 2^-60; PF_PRUNE_EPS=0 transforms every mode
+  if (const char *e = getenv("PF_PRUNE_EPS")) t->prune_eps = atof(e);
+}
+
+static int create_body(pf_ctx *c, const pf_config *cfg) {
+  const int rank = cfg->rank;
+  HIPCHK(c, hipSetDevice(cfg->device));
+  HIPCHK(c, hipStreamCreate(&c->stream));
+  HIPCHK(c, hipStreamCreate(&c->cstream));
+  for (int i = 0; i < 2; i++) {
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_x[i], hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_r[i], hipEventDisableTiming));
+  }
+  {
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, cfg->device));
+    // Default: the sincos / cbrt / exp10 forms of the solver's transcendental hot spots (pf_collapse_core.h), 25 %
+    // fewer fp64 instructions.  PF_EXACT_LIBM=1: the reference's own calls (cos x3, pow, pow), bit-comparable with the CPU.
+    c->fast_libm = !c->tune.exact_libm;
+    c->ncu = prop.multiProcessorCount;
+    c->prune_eps = c->tune.prune_eps;
+    // four 256-thread workgroups of the solve fit per CU (128 VGPRs); 8 per CU in the grid evens out the tail
+    c->collapse_blocks = prop.multiProcessorCount * c->tune.collapse_wg_per_cu;
+    if (c->collapse_blocks > PF_NBLK) c->collapse_blocks = PF_NBLK;
+  }
+  c->field_bytes = (size_t)c->n * c->nyl * c->nzp * 2 * c->fb;
+  PFCHK(c, dev_alloc(c, &c->dk, c->field_bytes));
+  PFCHK(c, dev_alloc(c, (void **)&c->blockA, 3 * c->field_bytes));
+  for (int i = 0; i < 3; i++) c->A[i] = c->blockA + i * c->field_bytes;
+  for (int i = 0; i < 6; i++) PFCHK(c, dev_alloc(c, &c->B[i], c->field_bytes));
+  for (int i = 0; i < 3; i++) PFCHK(c, dev_alloc(c, &c->S[i], c->field_bytes));
+  if (c->P > 1) PFCHK(c, dev_alloc(c, &c->recvA, 3 * c->field_bytes));
+  if (c->pipeline) {
+    PFCHK(c, dev_alloc(c, (void **)&c->blockA2, 3 * c->field_bytes));
+    PFCHK(c, dev_alloc(c, &c->recvA2, 3 * c->field_bytes));
+  }
+  if (c->general) {
+    PFCHK(c, dev_alloc(c, &c->W, c->field_bytes));
+    const int rc = pf_gfft_create(c->n, c->stream, &c->fft_c2r, &c->fft_r2c);
+    if (rc) return pf_fail(rank, "pf_create: hipFFT plans for %d^3 failed (%d): grid sizes that are not a power of two need libhipfft", c->n, rc);
+  }
+  const size_t nc = ncell(c);
+  PFCHK(c, dev_alloc(c, (void **)&c->fmax, nc * sizeof(float)));
+  PFCHK(c, dev_alloc(c, (void **)&c->rmax, nc * sizeof(int)));
+  PFCHK(c, dev_alloc(c, (void **)&c->vel12, 12 * nc * sizeof(float)));
+  PFCHK(c, dev_alloc(c, (void **)&c->partials, 2 * PF_NBLK * sizeof(double)));
+  PFCHK(c, dev_alloc(c, (void **)&c->scal, SC_COUNT * sizeof(double)));
+  PFCHK(c, dev_alloc(c, (void **)&c->hist, PF_NBINS * sizeof(unsigned long long)));
+  PFCHK(c, dev_alloc(c, (void **)&c->spl, (size_t)(PF_MAX_SMOOTH + 1) * 5 * PF_KNOT_CAP * sizeof(double)));
+  PFCHK(c, dev_alloc(c, (void **)&c->gtab, 4 * PF_KBIN_CAP * sizeof(double)));
+  PFCHK(c, dev_alloc(c, (void **)&c->etab, (size_t)c->n * sizeof(double)));
+  HIPCHK(c, hipMemsetAsync(c->scal, 0, SC_COUNT * sizeof(double), c->stream));
+  {
+    std::vector<char> h;
+    host_twiddles(c->n, c->fb, h);
+    PFCHK(c, dev_alloc(c, &c->tw, h.size()));
+    HIPCHK(c, hipMemcpy(c->tw, h.data(), h.size(), hipMemcpyHostToDevice));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   if (!out || !cfg) return pf_fail(0, "pf_create: null argument");
   *out = nullptr;
   const int rank = cfg->rank;
   const long long n = cfg->n;
   const bool pow2 = !(n & (n - 1));
-  const bool want_general = !pow2 || (getenv("PF_GENERAL") && atoi(getenv("PF_GENERAL")));
+  PfTuning tune;
+  read_tuning(&tune);
+  const bool want_general = !pow2 || tune.general;
   if (want_general) {
     if (n < 4 || n > 4096 || (n & 1)) return pf_fail(rank, "pf_create: grid size %lld must be even, in [4, 4096]", n);
     if (cfg->nranks != 1 || cfg->field_bytes != 8)
@@ -219,6 +317,7 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   if (cfg->device < 0 || cfg->device >= ndev) return pf_fail(rank, "pf_create: device %d out of range (%d devices)", cfg->device, ndev);
   pf_ctx *c = new pf_ctx();
   c->cfg = *cfg; c->rank = rank; c->P = cfg->nranks; c->n = (int)n; c->nzh = c->n / 2 + 1; c->nzp = c->n / 2 + 8;
+  c->tune = tune; c->dev = cfg->device; c->inv_reruns = 0;
   c->general = want_general; c->fft_c2r = c->fft_r2c = nullptr; c->W = nullptr;
   if (c->general) c->nzp = c->nzh;  // natural layout [n][n][n/2+1], the boundary layout itself
   c->nxl = c->n / c->P; c->nyl = c->n / c->P; c->fb = cfg->field_bytes; c->timing = (cfg->flags & PF_FLAG_TIMING) != 0;
@@ -232,98 +331,29 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   for (int i = 0; i < 6; i++) { c->B[i] = nullptr; c->B2[i] = nullptr; }
   c->blockA = nullptr; c->dk = nullptr; c->recvA = nullptr; c->tw = nullptr;
   c->blockA2 = nullptr; c->recvA2 = nullptr; c->cstream = nullptr;
-  c->pipeline = c->P > 1 && !(getenv("PF_PIPELINE") && !atoi(getenv("PF_PIPELINE")));
+  c->fmax = nullptr; c->rmax = nullptr; c->vel12 = nullptr; c->partials = nullptr; c->scal = nullptr; c->hist = nullptr; c->spl = nullptr;
+  c->gtab = nullptr; c->etab = nullptr; c->ct_block = nullptr;
+  for (int i = 0; i < 2; i++) c->ev_x[i] = c->ev_r[i] = nullptr;
+  c->pipeline = c->P > 1 && tune.pipeline;
   for (int i = 0; i < 3; i++) { c->A[i] = nullptr; c->S[i] = nullptr; }
-
-  HIPCHK(c, hipSetDevice(cfg->device));
-  HIPCHK(c, hipStreamCreate(&c->stream));
-  HIPCHK(c, hipStreamCreate(&c->stream2));
-  HIPCHK(c, hipStreamCreate(&c->cstream));
-  for (int i = 0; i < 2; i++) {
-    HIPCHK(c, hipEventCreateWithFlags(&c->ev_h[i], hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&c->ev_c[i], hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&c->ev_x[i], hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&c->ev_r[i], hipEventDisableTiming));
-  }
-  {
-    // the collapse solve is fp64-ALU bound and runs beside the HBM-bound passes of the next radius:
-    // 2 workgroups (of 4 waves) per CU leave VGPRs for one pass workgroup per CU
-    hipDeviceProp_t prop;
-    HIPCHK(c, hipGetDeviceProperties(&prop, cfg->device));
-    // Experiments kept behind switches (measured on MI355X at 1024^3, see DESIGN.md "What did not pay"):
-    // PF_OVERLAP=1: collapse of radius i on a second stream beside the passes of radius i+1 -- no gain, each kernel
-    //   loses in occupancy what the pair wins in overlap.
-    // PF_FUSE=1: z-pass fused with the solve in one persistent kernel -- slower (86 vs 74 ms per radius): the solve is
-    //   fp64-ALU bound, so the row transforms' instructions are exposed instead of hidden under HBM time.
-    c->overlap = getenv("PF_OVERLAP") && atoi(getenv("PF_OVERLAP"));
-    c->fuse = getenv("PF_FUSE") && atoi(getenv("PF_FUSE"));
-    // Default: the sincos / cbrt / exp10 forms of the solver's transcendental hot spots (pf_collapse_core.h), 25 %
-    // fewer fp64 instructions.  PF_EXACT_LIBM=1: the reference's own calls (cos x3, pow, pow), bit-comparable with the CPU.
-    c->fast_libm = !(getenv("PF_EXACT_LIBM") && atoi(getenv("PF_EXACT_LIBM")));
-    c->ncu = prop.multiProcessorCount;
-    c->prune_eps = 8.673617379884035e-19;  // 2^-60; PF_PRUNE_EPS=0 transforms every mode
-    if (const char *e = getenv("PF_PRUNE_EPS")) c->prune_eps = atof(e);
-    c->last_band = 1 << 30;
-    c->fused_wg_per_cu = 3;
-    c->fused_skew_ns = 12000;
-    if (const char *e = getenv("PF_FUSED_WG_PER_CU")) c->fused_wg_per_cu = atoi(e) > 0 ? atoi(e) : 3;
-    int per_cu = c->overlap ? 2 : 8;
-    if (const char *e = getenv("PF_COLLAPSE_WG_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
-    c->collapse_blocks = prop.multiProcessorCount * per_cu;
-    if (c->collapse_blocks > PF_NBLK) c->collapse_blocks = PF_NBLK;
-  }
-  c->field_bytes = (size_t)c->n * c->nyl * c->nzp * 2 * c->fb;
-  PFCHK(c, dev_alloc(c, &c->dk, c->field_bytes));
-  PFCHK(c, dev_alloc(c, (void **)&c->blockA, 3 * c->field_bytes));
-  for (int i = 0; i < 3; i++) c->A[i] = c->blockA + i * c->field_bytes;
-  for (int i = 0; i < 6; i++) PFCHK(c, dev_alloc(c, &c->B[i], c->field_bytes));
-  for (int i = 0; i < 3; i++) PFCHK(c, dev_alloc(c, &c->S[i], c->field_bytes));
-  if (c->P > 1) PFCHK(c, dev_alloc(c, &c->recvA, 3 * c->field_bytes));
-  if (c->pipeline) {
-    PFCHK(c, dev_alloc(c, (void **)&c->blockA2, 3 * c->field_bytes));
-    PFCHK(c, dev_alloc(c, &c->recvA2, 3 * c->field_bytes));
-  }
-  if (c->general) {
-    PFCHK(c, dev_alloc(c, &c->W, c->field_bytes));
-    c->fuse = c->overlap = false;
-    const int rc = pf_gfft_create(c->n, c->stream, &c->fft_c2r, &c->fft_r2c);
-    if (rc) return pf_fail(rank, "pf_create: hipFFT plans for %d^3 failed (%d): grid sizes that are not a power of two need libhipfft", c->n, rc);
-  }
-  const size_t nc = ncell(c);
-  PFCHK(c, dev_alloc(c, (void **)&c->fmax, nc * sizeof(float)));
-  PFCHK(c, dev_alloc(c, (void **)&c->rmax, nc * sizeof(int)));
-  PFCHK(c, dev_alloc(c, (void **)&c->vel12, 12 * nc * sizeof(float)));
-  PFCHK(c, dev_alloc(c, (void **)&c->partials, 2 * PF_NBLK * sizeof(double)));
-  PFCHK(c, dev_alloc(c, (void **)&c->scal, SC_COUNT * sizeof(double)));
-  PFCHK(c, dev_alloc(c, (void **)&c->hist, PF_NBINS * sizeof(unsigned long long)));
-  PFCHK(c, dev_alloc(c, (void **)&c->spl, (size_t)(PF_MAX_SMOOTH + 1) * 5 * PF_KNOT_CAP * sizeof(double)));
-  PFCHK(c, dev_alloc(c, (void **)&c->gtab, 4 * PF_KBIN_CAP * sizeof(double)));
-  PFCHK(c, dev_alloc(c, (void **)&c->etab, (size_t)c->n * sizeof(double)));
   memset(c->gt_n, 0, sizeof(c->gt_n));
-  c->tab_ns = 0; c->tab_ready = false; c->tab_ismooth = -1; c->ct_block = nullptr; c->model = 0; c->sng_ns = 0; memset(c->sng_cosmo, 0, sizeof(c->sng_cosmo)); memset(c->sng_size, 0, sizeof(c->sng_size)); memset(&c->ct, 0, sizeof(c->ct));
-  HIPCHK(c, hipMemsetAsync(c->scal, 0, SC_COUNT * sizeof(double), c->stream));
-  // twiddles exp(+2 pi i j / n), computed in long double on the host
-  {
-    std::vector<char> h((size_t)c->n * 2 * c->fb);
-    for (int j = 0; j < c->n; j++) {
-      long double a = 2.0L * 3.14159265358979323846264338327950288L * (long double)j / (long double)c->n;
-      double re = (double)cosl(a), im = (double)sinl(a);
-      if (j == 0) { re = 1; im = 0; } else if (4 * j == c->n) { re = 0; im = 1; } else if (2 * j == c->n) { re = -1; im = 0; } else if (4 * j == 3 * c->n) { re = 0; im = -1; }
-      if (c->fb == 8) { ((double *)h.data())[2 * j] = re; ((double *)h.data())[2 * j + 1] = im; }
-      else { ((float *)h.data())[2 * j] = (float)re; ((float *)h.data())[2 * j + 1] = (float)im; }
-    }
-    PFCHK(c, dev_alloc(c, &c->tw, h.size()));
-    HIPCHK(c, hipMemcpy(c->tw, h.data(), h.size(), hipMemcpyHostToDevice));
+  c->tab_ns = 0; c->tab_ready = false; c->tab_ismooth = -1; c->model = 0; c->sng_ns = 0; memset(c->sng_cosmo, 0, sizeof(c->sng_cosmo)); memset(c->sng_size, 0, sizeof(c->sng_size)); memset(&c->ct, 0, sizeof(c->ct));
+  const int rc = create_body(c, cfg);
+  if (rc) {  // nothing of a half-built context stays behind (13 fields of 8.7 GB each at 1024^3)
+    std::string msg = g_err;
+    pf_destroy(c);
+    snprintf(g_err, sizeof(g_err), "%s", msg.c_str());
+    return rc;
   }
-  HIPCHK(c, hipStreamSynchronize(c->stream));
   *out = c;
   return 0;
 }
 
 extern "C" int pf_destroy(pf_ctx *c) {
   if (!c) return 0;
-  hipStreamSynchronize(c->stream);
-  hipStreamSynchronize(c->stream2); hipStreamSynchronize(c->cstream);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->cstream) hipStreamSynchronize(c->cstream);
+  pf_rccl_release(c->rccl); c->rccl = nullptr;
   hipFree(c->dk); hipFree(c->blockA); hipFree(c->recvA); hipFree(c->tw); hipFree(c->blockA2); hipFree(c->recvA2);
   for (int i = 0; i < 6; i++) { hipFree(c->B[i]); hipFree(c->B2[i]); }
   for (int i = 0; i < 3; i++) hipFree(c->S[i]);
@@ -332,10 +362,9 @@ extern "C" int pf_destroy(pf_ctx *c) {
   for (auto &e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   for (auto &e : c->phase_evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   for (auto e : c->evpool) hipEventDestroy(e);
-  if (c->own_stream) hipStreamDestroy(c->stream);
-  hipStreamDestroy(c->stream2);
-  hipStreamDestroy(c->cstream);
-  for (int i = 0; i < 2; i++) { hipEventDestroy(c->ev_h[i]); hipEventDestroy(c->ev_c[i]); hipEventDestroy(c->ev_x[i]); hipEventDestroy(c->ev_r[i]); }
+  if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+  if (c->cstream) hipStreamDestroy(c->cstream);
+  for (int i = 0; i < 2; i++) { if (c->ev_x[i]) hipEventDestroy(c->ev_x[i]); if (c->ev_r[i]) hipEventDestroy(c->ev_r[i]); }
   delete c;
   return 0;
 }
@@ -349,7 +378,7 @@ extern "C" int pf_set_stream(pf_ctx *c, void *stream) {
 }
 extern "C" void *pf_get_stream(pf_ctx *c) { return c ? (void *)c->stream : nullptr; }
 extern "C" int pf_synchronize(pf_ctx *c) {
-  HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2)); HIPCHK(c, hipStreamSynchronize(c->cstream));
+  HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->cstream));
   return 0;
 }
 extern "C" size_t pf_device_bytes(pf_ctx *c) { return c ? c->dev_bytes : 0; }
@@ -393,8 +422,7 @@ static void band_rows(const pf_ctx *c, int p, int band, int *lo, int *hi) {
 }
 static int exchange_band(pf_ctx *c, const void *send, void *recv, int band, hipStream_t st = nullptr) {
   if (c->P == 1) return 0;
-  const bool rows_off = getenv("PF_EXCHANGE_ROWS") && !atoi(getenv("PF_EXCHANGE_ROWS"));  // 0: always whole blocks
-  if (band >= c->n / 2 || !c->a2av || rows_off) return exchange(c, send, recv, st);
+  if (band >= c->n / 2 || !c->a2av || !c->tune.exchange_rows) return exchange(c, send, recv, st);  // PF_EXCHANGE_ROWS=0: always whole blocks
   if (!st) st = c->stream;
   const size_t row_bytes = (size_t)c->nxl * band_zpitch(c, band) * 2 * c->fb, block_bytes = c->field_bytes / c->P;
   std::vector<size_t> roff(c->P), rbytes(c->P);
@@ -447,7 +475,7 @@ static int xpass(pf_ctx *c, int kind, int dir, int njobs, const Job *jobs, int p
   p.ain = p.aout = addr_ky_x(c);
   if (out_yblocks && c->P > 1) p.aout = addr_yblocks_x(c, band_zpitch(c, band));
   p.ncols = c->nzh; p.nouter = c->nyl; p.pre = pre; p.outer_offset = c->rank * c->nyl; p.rs = rs; p.growth = growth; p.tw = c->tw;
-  p.etab = c->etab;
+  p.etab = c->etab; p.dev = c->dev;
   if (pre && rs != 0.0) PFCHK(c, pf_launch_exp_table(c->etab, c->n, rs, c->stream));  // stream order: after the previous x-pass
   p.band_e = p.band_outer = c->n;
   double frac_cols = 1.0, frac_in = 1.0, frac_outer = 1.0;
@@ -468,7 +496,7 @@ static int ypass(pf_ctx *c, int kind, int dir, int njobs, const Job *jobs, bool 
   for (int j = 0; j < njobs; j++) { p.job[j].in = jobs[j].in; p.job[j].out = jobs[j].out; p.job[j].mul = jobs[j].mul; }
   p.ain = in_blocks ? ((in_yblocks && c->P > 1) ? addr_yblocks_y(c, band_zpitch(c, band)) : addr_blocks_y(c)) : addr_xs_y(c);
   p.aout = out_blocks ? addr_blocks_y(c) : addr_xs_y(c);
-  p.ncols = c->nzh; p.nouter = c->nxl; p.pre = 0; p.outer_offset = 0; p.rs = 0; p.growth = 1; p.tw = c->tw;
+  p.ncols = c->nzh; p.nouter = c->nxl; p.pre = 0; p.outer_offset = 0; p.rs = 0; p.growth = 1; p.tw = c->tw; p.dev = c->dev;
   p.band_e = p.band_outer = c->n;
   double frac_cols = 1.0, frac_in = 1.0;
   if (band < c->n / 2) {  // pruned: kz columns in band, in-band ky read, all y written, every x
@@ -495,6 +523,8 @@ static int zpass_c2r(pf_ctx *c, int kind, int njobs, const ZJob *jobs, const dou
   p.band_k = c->n;
   double frac_in = 1.0;
   if (band < c->n / 2) { p.band_k = band; frac_in = (double)(band + 1) / c->nzh; }
+  p.ncu = c->ncu; p.dev = c->dev; p.persist_per_cu = c->tune.zpass_persist; p.inv_per_cu = c->tune.zpass_inv_wg_per_cu;
+  p.flag = c->scal + SC_INV_FLAG;
   if (acc) {  // six components in, none out: acc -= 2 phi2_ab h_ab with the first-order Hessian h in jobs[].out (src/LPT.c:134-137)
     p.acc = acc;
     KTimer t(c, KS_ZPASS_LPT3B, njobs * frac_in * spec_bytes_alg(c) + 8.0 * real_bytes_alg(c));
@@ -618,9 +648,9 @@ static int g_reverse_of(pf_ctx *c, void *f) {
 // order 11,22,33,12,13,23 (src/LPT.c:36-44); compute_second_derivatives, src/fmax.c:225-258
 // Gaussian window exp(-k^2 rs^2/2) < prune_eps (2^-60) beyond |k| = sqrt(-2 ln eps)/rs: those modes are dropped
 // (pruned FFT).  Their total contribution is < 2^-56 of the unsmoothed rms: below the rounding of the transform.
-static int hess_band(const pf_ctx *c, double rs, bool xy_only) {
+static int hess_band(const pf_ctx *c, double rs) {
   int band = 1 << 30;
-  if (rs > 0.0 && c->prune_eps > 0.0 && !xy_only) {  // (the experimental fused z-pass reads full rows)
+  if (rs > 0.0 && c->prune_eps > 0.0) {
     const double kc = sqrt(-2.0 * log(c->prune_eps)) / rs;
     const double kb = kc * c->n / (2.0 * 3.14159265358979323846);
     if (kb < c->n / 2 - 1) band = (int)kb + 1;
@@ -631,12 +661,11 @@ static int hess_x(pf_ctx *c, const void *spec, double rs, void *const A[3], int 
   const Job xj[3] = {{spec, A[0], PF_MUL_ONE}, {spec, A[1], PF_MUL_K}, {spec, A[2], PF_MUL_K2}};
   return xpass(c, KS_XPASS_HESS, +1, 3, xj, 1, rs, 1.0, 1, band, true);
 }
-static int hess_yz(pf_ctx *c, const void *const R[3], const double *dc, void *const out[6], int band, bool xy_only, bool invariants = false,
+static int hess_yz(pf_ctx *c, const void *const R[3], const double *dc, void *const out[6], int band, bool invariants = false,
                    void *acc = nullptr, void *const *hfirst = nullptr) {
   const Job yj[6] = {{R[2], out[0], PF_MUL_ONE}, {R[1], out[3], PF_MUL_K}, {R[1], out[4], PF_MUL_ONE},
                      {R[0], out[1], PF_MUL_K2}, {R[0], out[5], PF_MUL_K},  {R[0], out[2], PF_MUL_ONE}};
   PFCHK(c, ypass(c, KS_YPASS_HESS, +1, 6, yj, true, false, 3, band, true));
-  if (xy_only) { c->last_band = band; return 0; }
   const ZJob zj[6] = {{out[0], out[0], PF_MUL_ONE, 0}, {out[1], out[1], PF_MUL_ONE, 0}, {out[2], out[2], PF_MUL_K2, 0},
                       {out[3], out[3], PF_MUL_ONE, 0}, {out[4], out[4], PF_MUL_K, 0},   {out[5], out[5], PF_MUL_K, 0}};
   if (acc) {  // the z-pass contracts the six rows with the first-order Hessian `hfirst` into `acc` and stores nothing else
@@ -648,14 +677,14 @@ static int hess_yz(pf_ctx *c, const void *const R[3], const double *dc, void *co
   PFCHK(c, zpass_c2r(c, KS_ZPASS_HESS, 6, zj, dc, band, invariants));
   return 0;
 }
-static int hessian_of(pf_ctx *c, const void *spec, double rs, const double *dc, void *const out[6], bool xy_only = false,
+static int hessian_of(pf_ctx *c, const void *spec, double rs, const double *dc, void *const out[6],
                       void *acc = nullptr, void *const *hfirst = nullptr) {
   if (c->general) return g_hessian_of(c, spec, rs, out);
-  const int band = hess_band(c, rs, xy_only);
+  const int band = hess_band(c, rs);
   return pipelined_band(c, 1, 3,
                         [&](int, void *const *A) { return hess_x(c, spec, rs, A, band); },
                         [&](int, int set, int f) { return recv_field(c, set, f); },
-                        [&](int, const void *const *R) { return hess_yz(c, R, dc, out, band, xy_only, false, acc, hfirst); },
+                        [&](int, const void *const *R) { return hess_yz(c, R, dc, out, band, false, acc, hfirst); },
                         [&](int) { return band; });
 }
 
@@ -985,8 +1014,7 @@ static int collapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], hipStream_
   p.pitch = rpitch(c); p.nrows = (long long)c->nxl * c->n; p.n = c->n; p.fmax = c->fmax; p.rmax = c->rmax; p.ismooth = ismooth;
   if (spline_for(c, ismooth, &p.spline)) return 1;
   p.partials = c->partials; p.fast = c->fast_libm ? 1 : 0;
-  p.wpe = getenv("PF_COLLAPSE_WPE") ? atoi(getenv("PF_COLLAPSE_WPE")) : 0;
-  p.no_lut = (getenv("PF_SPLINE_LUT") && !atoi(getenv("PF_SPLINE_LUT"))) ? 1 : 0;
+  p.no_lut = c->tune.spline_lut ? 0 : 1;
   if (c->model == 1 && c->tab_ns == 0)
     return pf_fail(c->rank, "ELL_SNG is evaluated through the collapse-time table only: call pf_set_tabulated_ct (TABULATED_CT build)");
   if (c->tab_ns > 0) {  // TABULATED_CT build: the table of this radius is made right before its pass (src/fmax.c:103-106)
@@ -999,17 +1027,6 @@ static int collapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], hipStream_
   }
   size_t nb = (ncell(c) + 255) / 256; if (nb > (size_t)c->collapse_blocks) nb = c->collapse_blocks;
   p.nblocks = (int)nb;
-  // experiment (PF_COLLAPSE_GROUPED=1): cells regrouped by the branch of the cubic, 512-thread blocks, two resident per CU.
-  // Bit-identical Fmax / Rmax, but 25.4 ms per launch at 1024^3 against the 23.0 ms of the plain kernel
-  const int grouped_env = getenv("PF_COLLAPSE_GROUPED") ? atoi(getenv("PF_COLLAPSE_GROUPED")) : 0;
-  if (grouped_env && p.fast && !p.tabulated && !p.wpe && !invariants) {
-    p.grouped = 1;
-    int per_cu = 4;
-    if (const char *e = getenv("PF_COLLAPSE_GROUPED_WG_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
-    nb = (ncell(c) + 511) / 512; if (nb > (size_t)c->ncu * per_cu) nb = (size_t)c->ncu * per_cu;
-    if (nb > PF_NBLK) nb = PF_NBLK;
-    p.nblocks = (int)nb;
-  }
   if (invariants) p.invariants = 1;
   {
     KTimer t(c, invariants ? KS_COLLAPSE_INV : KS_COLLAPSE, (double)ncell(c) * ((invariants ? 3.0 : 6.0) * c->fb + 16.0), st);
@@ -1019,35 +1036,11 @@ static int collapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], hipStream_
   return 0;
 }
 
-// z-pass of the six components fused with the collapse solve (pf_fused_kernels.hip); H holds the y-pass output
-static int zcollapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], const double *dc, bool write_h, hipStream_t st) {
-  PfFusedParams p; memset(&p, 0, sizeof(p));
-  const int mul[6] = {PF_MUL_ONE, PF_MUL_ONE, PF_MUL_K2, PF_MUL_ONE, PF_MUL_K, PF_MUL_K};
-  for (int i = 0; i < 6; i++) { p.in[i] = H[i]; p.out[i] = H[i]; p.mul[i] = mul[i]; }
-  p.write_h = write_h ? 1 : 0;
-  p.nlines = (long long)c->nxl * c->n; p.in_pitch = c->nzp; p.out_pitch = 2 * c->nzp;
-  p.norm = 1.0 / ((double)c->n * c->n * c->n); p.dc = dc; p.tw = c->tw;
-  p.fmax = c->fmax; p.rmax = c->rmax; p.ismooth = ismooth;
-  if (spline_for(c, ismooth, &p.spline)) return 1;
-  p.partials = c->partials; p.max_blocks = PF_NBLK;
-  p.debug_skip = getenv("PF_FUSED_DEBUG_SKIP") ? atoi(getenv("PF_FUSED_DEBUG_SKIP")) : 0;
-  p.skew_ns = getenv("PF_FUSED_SKEW_NS") ? atoi(getenv("PF_FUSED_SKEW_NS")) : c->fused_skew_ns;
-  p.ncu = c->ncu;
-  int nb = 0;
-  {
-    KTimer t(c, KS_ZCOLLAPSE, 6.0 * spec_bytes_alg(c) + (double)ncell(c) * 16.0 + (write_h ? 6.0 * real_bytes_alg(c) : 0.0), st);
-    PFCHK(c, pf_launch_zcollapse(c->fb, c->n, p, c->fused_wg_per_cu, c->ncu, st, &nb));
-  }
-  PFCHK(c, pf_launch_final_sum(c->partials, nb, c->scal + SC_VAR0 + 2 * ismooth, st));
-  return 0;
-}
-
 // compute_collapse_times at ismooth = 0 resets the products (src/collapse_times.c:461-492: Fmax = -10, Rmax = -1, every
 // Vel = 0).  The collapse kernel of the first radius writes Fmax/Rmax of every cell itself; the 48 bytes per cell of
 // velocities are cleared only if somebody reads them before pf_displacements has rewritten all twelve columns.
-static int products_reset(pf_ctx *c, hipStream_t st) {
-  if (c->fuse) { PFCHK(c, pf_launch_fill_products(c->fmax, c->rmax, c->vel12, ncell(c), st)); c->vel_zero_pending = false; }
-  else c->vel_zero_pending = true;
+static int products_reset(pf_ctx *c) {
+  c->vel_zero_pending = true;
   c->products_init = true;
   return 0;
 }
@@ -1064,7 +1057,7 @@ extern "C" int pf_collapse_times(pf_ctx *c, int ismooth, double *tv) {
   if (!c->have_hessian) return pf_fail(c->rank, "pf_collapse_times: second derivatives not computed");
   if (ismooth < 0 || ismooth >= PF_MAX_SMOOTH) return pf_fail(c->rank, "pf_collapse_times: ismooth %d out of range", ismooth);
   if (ismooth == 0) {  // src/collapse_times.c:461-492
-    PFCHK(c, products_reset(c, c->stream));
+    PFCHK(c, products_reset(c));
   } else if (!c->products_init)
     return pf_fail(c->rank, "pf_collapse_times: products not initialised (ismooth 0 must come first)");
   {
@@ -1080,50 +1073,26 @@ extern "C" int pf_collapse_times(pf_ctx *c, int ismooth, double *tv) {
   return 0;
 }
 
-extern "C" int pf_sweep(pf_ctx *c, int ns, const double *radius_cells, double *true_variance) {
-  if (!c || !radius_cells) return pf_fail(0, "pf_sweep: null argument");
-  if (ns < 1 || ns > PF_MAX_SMOOTH) return pf_fail(c->rank, "pf_sweep: Nsmooth %d not in [1, %d]", ns, PF_MAX_SMOOTH);
-  if (!c->have_density) return pf_fail(c->rank, "pf_sweep: density not set");
-  if (c->overlap)
-    for (int i = 0; i < 6; i++)
-      if (!c->B2[i]) PFCHK(c, dev_alloc(c, &c->B2[i], c->field_bytes));
+static int sweep_body(pf_ctx *c, int ns, const double *radius_cells, double *true_variance, bool six_components) {
   PhaseTimer ft(c, 4);
-  // Two Hessian buffers (B, B2) and two streams: the collapse solve of radius i (fp64-ALU bound,
-  // stream2) runs beside the FFT passes of radius i+1 (HBM bound, stream).  The Fmax/Rmax running
-  // max stays in radius order because every collapse launch is on stream2.
-  HIPCHK(c, hipEventRecord(c->ev_h[0], c->stream));
-  HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_h[0], 0));
-  PFCHK(c, products_reset(c, c->overlap ? c->stream2 : c->stream));
-  const bool xy_only = c->fuse;
+  PFCHK(c, products_reset(c));
   // (n <= 1024: the six-line workgroup of a 2048-point row would need 110 KB of dynamic LDS, a size this build never launches)
-  const bool invariants_ok = c->fb == 8 && c->n <= 1024 && !c->fuse && !c->general && c->tab_ns == 0 && !getenv("PF_COLLAPSE_WPE") &&
-                             !(getenv("PF_INVARIANTS") && !atoi(getenv("PF_INVARIANTS")));
+  const bool invariants_ok = c->fb == 8 && c->n <= 1024 && !c->general && c->tab_ns == 0 && c->tune.invariants && !six_components;
+  HIPCHK(c, hipMemsetAsync(c->scal + SC_INV_FLAG, 0, sizeof(double), c->stream));
   auto pre = [&](int ismooth, void *const *A) {
     PhaseTimer pt(c, 0);
-    return hess_x(c, c->dk, radius_cells[ismooth], A, hess_band(c, radius_cells[ismooth], xy_only));
+    return hess_x(c, c->dk, radius_cells[ismooth], A, hess_band(c, radius_cells[ismooth]));
   };
   auto post = [&](int ismooth, const void *const *R) {
-    const int b = c->overlap ? (ismooth & 1) : 0;
-    void **H = b ? c->B2 : c->B;
-    if (c->overlap && ismooth >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_c[b], 0));
     // every radius but the last (its Hessian stays in B for the LPT sources): the z-pass stores the three invariants of the
     // tensor instead of its six components and the solve starts from them (PF_INVARIANTS=0: six components throughout)
     const bool inv = invariants_ok && ismooth < ns - 1;
     {
       PhaseTimer pt(c, 0);
-      PFCHK(c, hess_yz(c, R, c->scal + SC_DC_DK, H, hess_band(c, radius_cells[ismooth], xy_only), xy_only, inv));
+      PFCHK(c, hess_yz(c, R, c->scal + SC_DC_DK, c->B, hess_band(c, radius_cells[ismooth]), inv));
     }
-    HIPCHK(c, hipEventRecord(c->ev_h[b], c->stream));
-    if (c->overlap) HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_h[b], 0));
-    hipStream_t cst = c->overlap ? c->stream2 : c->stream;
-    {
-      PhaseTimer pt(c, 1, cst);
-      if (c->fuse) {
-        if (zcollapse_enqueue(c, ismooth, H, c->scal + SC_DC_DK, ismooth == ns - 1, cst)) return 1;
-      } else if (collapse_enqueue(c, ismooth, H, cst, true, inv)) return 1;
-    }
-    HIPCHK(c, hipEventRecord(c->ev_c[b], cst));
-    return 0;
+    PhaseTimer pt(c, 1);
+    return collapse_enqueue(c, ismooth, c->B, c->stream, true, inv);
   };
   if (c->general) {  // one filter + one library c2r per component, then the same collapse pass
     for (int ismooth = 0; ismooth < ns; ismooth++) {
@@ -1133,24 +1102,34 @@ extern "C" int pf_sweep(pf_ctx *c, int ns, const double *radius_cells, double *t
       }
       PhaseTimer pt(c, 1);
       if (collapse_enqueue(c, ismooth, c->B, c->stream)) return 1;
-      HIPCHK(c, hipEventRecord(c->ev_c[0], c->stream));
     }
   } else if (pipelined_band(c, ns, 3, pre, [&](int, int set, int f) { return recv_field(c, set, f); }, post,
-                            [&](int ismooth) { return hess_band(c, radius_cells[ismooth], xy_only); })) return 1;
-  // join; keep the R=0 Hessian (last radius) in B for the LPT sources
-  HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_c[(ns - 1) & 1], 0));
-  if (ns >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_c[(ns - 2) & 1], 0));
-  if (c->overlap && ((ns - 1) & 1))
-    for (int i = 0; i < 6; i++) { void *t = c->B[i]; c->B[i] = c->B2[i]; c->B2[i] = t; }
+                            [&](int ismooth) { return hess_band(c, radius_cells[ismooth]); })) return 1;
+  // the R=0 Hessian (last radius) stays in B for the LPT sources
   c->have_hessian = true; c->last_ns = ns;
-  PFCHK(c, allreduce_dev(c, c->scal + SC_VAR0, 2 * (size_t)ns, 0));
-  std::vector<double> s(2 * ns);
-  HIPCHK(c, hipMemcpyAsync(s.data(), c->scal + SC_VAR0, 2 * ns * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  PFCHK(c, allreduce_dev(c, c->scal + SC_INV_FLAG, 1 + 2 * (size_t)ns, 0));
+  std::vector<double> s(1 + 2 * ns);
+  HIPCHK(c, hipMemcpyAsync(s.data(), c->scal + SC_INV_FLAG, s.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (true_variance)
-    for (int i = 0; i < ns; i++) true_variance[i] = s[2 * i + 1] / ((double)c->n * c->n * c->n);
-  return 0;
+    for (int i = 0; i < ns; i++) true_variance[i] = s[1 + 2 * i + 1] / ((double)c->n * c->n * c->n);
+  return s[0] != 0.0 ? 2 : 0;
 }
+
+extern "C" int pf_sweep(pf_ctx *c, int ns, const double *radius_cells, double *true_variance) {
+  if (!c || !radius_cells) return pf_fail(0, "pf_sweep: null argument");
+  if (ns < 1 || ns > PF_MAX_SMOOTH) return pf_fail(c->rank, "pf_sweep: Nsmooth %d not in [1, %d]", ns, PF_MAX_SMOOTH);
+  if (!c->have_density) return pf_fail(c->rank, "pf_sweep: density not set");
+  int rc = sweep_body(c, ns, radius_cells, true_variance, false);
+  // rc 2: on some rank a cell's tensor had q = (mu1^2 - 3 mu2) / 9 == 0 in floating point without being exactly isotropic.
+  // The reference then takes the tensor's own diagonal as the eigenvalues (src/collapse_times.c:722-727), which the three
+  // invariants do not determine: the sweep is repeated with six components per cell.  (A Gaussian field never gets there --
+  // five independent combinations would have to vanish to 1e-8 at once -- and the exactly isotropic tensors of an empty
+  // field do not raise the flag; the flag is summed over the ranks with the variances, so all of them repeat together.)
+  if (rc == 2) { c->inv_reruns++; rc = sweep_body(c, ns, radius_cells, true_variance, true); }
+  return rc;
+}
+extern "C" int pf_debug_invariant_reruns(pf_ctx *c) { return c ? c->inv_reruns : -1; }
 
 extern "C" int pf_displacements(pf_ctx *c, int compute_sources, int recompute_sd) {
   if (!c) return 1;
@@ -1187,9 +1166,9 @@ extern "C" int pf_displacements(pf_ctx *c, int compute_sources, int recompute_sd
       // Hessian of the 2LPT potential contracted with the first-order one into the 3LPT(b) source (src/LPT.c:112-137).  fp64
       // fields: the z-pass does the contraction while it holds a row's six components (nothing of that Hessian is stored;
       // PF_LPT_FUSE=0: six fields out, then k_lpt_accum); same operations per cell either way
-      const bool fuse3b = c->fb == 8 && c->n <= 1024 && !c->general && !(getenv("PF_LPT_FUSE") && !atoi(getenv("PF_LPT_FUSE")));
+      const bool fuse3b = c->fb == 8 && c->n <= 1024 && !c->general && c->tune.lpt_fuse;
       if (fuse3b) {
-        PFCHK(c, hessian_of(c, c->S[0], 0.0, c->scal + SC_DC_S2, c->B2, false, c->S[2], c->B));
+        PFCHK(c, hessian_of(c, c->S[0], 0.0, c->scal + SC_DC_S2, c->B2, c->S[2], c->B));
       } else {
         PFCHK(c, hessian_of(c, c->S[0], 0.0, c->scal + SC_DC_S2, c->B2));
         PfLptAccParams ap; memset(&ap, 0, sizeof(ap));
@@ -1514,7 +1493,116 @@ extern "C" int pf_debug_exchange(pf_ctx *c, size_t bytes_per_peer) {
   return 0;
 }
 
+// Test tap without a context: one of the three pass kernels on a batch of lines, host in and host out (fp64 on the host,
+// converted to the field type on the way).  It exists so that every instantiation -- in particular N = 2048 (BASELINE
+// config 5), whose 3-D box does not fit one GPU -- can be compared with an independent transform line by line.
+//   pass 0 / 1: k_strided inverse (+1) / forward (-1): in, out complex [nouter][n][ncols]; `mul`, `band` (loads with
+//               |wavenumber| > band are zeros; >= n/2: none), pre / rs / growth / outer_offset as in the x-pass
+//   pass 2: z-pass c2r (k_c2r_persistent, or k_c2r with PF_ZPASS_PERSIST=0): in complex [nouter][n/2+1], out real [nouter][n],
+//           unnormalised, `mul` in kz, columns kz > band not read
+//   pass 3: k_r2c: in real [nouter][n], out complex [nouter][n/2+1]
+//   pass 4: k_c2r_invariants (n <= 1024): in complex [6][nouter][n/2+1], out real [3][nouter][n] = mu1, mu2, mu3 of the six rows
+extern "C" int pf_debug_lines(int field_bytes, int n, int pass, int mul, int band, int nouter, int ncols, int pre, double rs,
+                              double growth, int outer_offset, const double *in, double *out) {
+  double *flag_out = (pass == 4 && out) ? out + (size_t)3 * nouter * n : nullptr;  // pass 4: one more double after the rows, the q == 0 flag
+  if (!in || !out || nouter < 1 || (field_bytes != 8 && field_bytes != 4) || n < 16 || n > 2048 || (n & (n - 1)) || pass < 0 || pass > 4)
+    return pf_fail(0, "pf_debug_lines: bad argument");
+  if (pass == 4 && (field_bytes != 8 || n > 1024)) return pf_fail(0, "pf_debug_lines: the invariant z-pass takes fp64 rows of at most 1024 points");
+  const int fb = field_bytes, nzh = n / 2 + 1;
+  pf_ctx *nc = nullptr;  // for the error macros
+  size_t n_in, n_out;    // scalars of type F
+  if (pass <= 1) { if (ncols < 1) return pf_fail(0, "pf_debug_lines: ncols"); n_in = n_out = (size_t)nouter * n * ncols * 2; }
+  else if (pass == 2) { n_in = (size_t)nouter * nzh * 2; n_out = (size_t)nouter * n; }
+  else if (pass == 3) { n_in = (size_t)nouter * n; n_out = (size_t)nouter * nzh * 2; }
+  else { n_in = (size_t)6 * nouter * nzh * 2; n_out = (size_t)3 * nouter * n; }
+  // pass 3 runs in place like forward_r2c: the buffer must hold the longer of the two rows
+  const size_t n_in_alloc = pass == 3 ? (n_in > n_out ? n_in : n_out) : n_in;
+  void *d_in = nullptr, *d_out = nullptr, *d_tw = nullptr; double *d_etab = nullptr, *d_flag = nullptr;
+  PfTuning tune;
+  read_tuning(&tune);
+  int dev = 0, ncu = 0;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return pf_fail(0, "pf_debug_lines: no HIP device");
+    ncu = prop.multiProcessorCount;
+  }
+  std::vector<char> tw;
+  host_twiddles(n, fb, tw);
+  int rc = 0;
+  auto body = [&]() -> int {
+    HIPCHK(nc, hipMalloc(&d_in, n_in_alloc * fb));
+    HIPCHK(nc, hipMalloc(&d_out, n_out * fb));
+    HIPCHK(nc, hipMalloc(&d_tw, tw.size()));
+    HIPCHK(nc, hipMalloc((void **)&d_etab, (size_t)n * sizeof(double)));
+    HIPCHK(nc, hipMalloc((void **)&d_flag, sizeof(double)));
+    HIPCHK(nc, hipMemset(d_flag, 0, sizeof(double)));
+    HIPCHK(nc, hipMemcpy(d_tw, tw.data(), tw.size(), hipMemcpyHostToDevice));
+    if (fb == 8) HIPCHK(nc, hipMemcpy(d_in, in, n_in * 8, hipMemcpyHostToDevice));
+    else {
+      std::vector<float> h(n_in);
+      for (size_t i = 0; i < n_in; i++) h[i] = (float)in[i];
+      HIPCHK(nc, hipMemcpy(d_in, h.data(), n_in * 4, hipMemcpyHostToDevice));
+    }
+    HIPCHK(nc, hipMemset(d_out, 0, n_out * fb));
+    if (pass <= 1) {
+      PfStridedParams p; memset(&p, 0, sizeof(p));
+      p.njobs = 1; p.job[0].in = d_in; p.job[0].out = d_out; p.job[0].mul = mul;
+      p.ain.os = (long long)n * ncols; p.ain.el_shift = ilog2i(n); p.ain.ehs = 0; p.ain.els = ncols; p.aout = p.ain;
+      p.ncols = ncols; p.nouter = nouter; p.pre = pre; p.outer_offset = outer_offset; p.rs = rs; p.growth = growth; p.tw = d_tw; p.etab = d_etab;
+      p.band_e = p.band_outer = n; p.dev = dev;
+      if (band < n / 2) p.band_e = band;
+      if (pre && rs != 0.0) PFCHK0(pf_launch_exp_table(d_etab, n, rs, nullptr));
+      PFCHK0(pf_launch_strided(fb, n, pass == 0 ? +1 : -1, p, nullptr));
+    } else if (pass == 2 || pass == 4) {
+      PfC2RParams p; memset(&p, 0, sizeof(p));
+      p.njobs = pass == 2 ? 1 : 6;
+      static const int mul6[6] = {PF_MUL_ONE, PF_MUL_ONE, PF_MUL_K2, PF_MUL_ONE, PF_MUL_K, PF_MUL_K};
+      for (int j = 0; j < p.njobs; j++) {
+        p.job[j].in = (char *)d_in + (size_t)j * nouter * nzh * 2 * fb;
+        p.job[j].out = pass == 2 ? d_out : (char *)d_out + (size_t)(j % 3) * nouter * n * fb;
+        p.job[j].mul = pass == 2 ? mul : mul6[j]; p.job[j].out_f32 = 0;
+      }
+      p.nlines = nouter; p.in_pitch = nzh; p.out_pitch = n; p.norm = 1.0; p.dc = nullptr; p.tw = d_tw; p.band_k = band < n / 2 ? band : n;
+      p.ncu = ncu; p.dev = dev; p.persist_per_cu = tune.zpass_persist; p.inv_per_cu = tune.zpass_inv_wg_per_cu; p.flag = d_flag;
+      if (pass == 2) PFCHK0(pf_launch_c2r(fb, n, p, nullptr));
+      else PFCHK0(pf_launch_c2r_invariants(n, p, nullptr, 0));
+    } else {
+      PfR2CParams p; p.in = d_in; p.out = d_out; p.nlines = nouter; p.in_pitch = n; p.out_pitch = nzh; p.tw = d_tw;
+      PFCHK0(pf_launch_r2c(fb, n, p, nullptr));
+    }
+    HIPCHK(nc, hipDeviceSynchronize());
+    if (pass == 4 && flag_out) HIPCHK(nc, hipMemcpy(flag_out, d_flag, sizeof(double), hipMemcpyDeviceToHost));
+    if (fb == 8) HIPCHK(nc, hipMemcpy(out, d_out, n_out * 8, hipMemcpyDeviceToHost));
+    else {
+      std::vector<float> h(n_out);
+      HIPCHK(nc, hipMemcpy(h.data(), d_out, n_out * 4, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < n_out; i++) out[i] = (double)h[i];
+    }
+    return 0;
+  };
+  rc = body();
+  hipFree(d_in); hipFree(d_out); hipFree(d_tw); hipFree(d_etab); hipFree(d_flag);
+  return rc;
+}
+
 // used by pf_rccl.cpp
+extern "C" int pf_ctx_set_rccl(pf_ctx *c, void *link) {
+  if (!c) return 1;
+  pf_rccl_release(c->rccl);
+  c->rccl = link;
+  return 0;
+}
+// drops the built-in RCCL exchange (communicator destroyed, callbacks cleared): a caller that falls back to another
+// exchange kind after pf_init_rccl leaves nothing of the first one behind
+extern "C" int pf_release_rccl(pf_ctx *c) {
+  if (!c) return 1;
+  if (c->rccl) {
+    hipStreamSynchronize(c->stream); hipStreamSynchronize(c->cstream);
+    pf_rccl_release(c->rccl); c->rccl = nullptr;
+    c->a2a = nullptr; c->a2av = nullptr; c->ared = nullptr; c->a2a_user = c->a2av_user = c->ared_user = nullptr;
+  }
+  return 0;
+}
 extern "C" int pf_ctx_rank_size(pf_ctx *c, int *rank, int *nranks) {
   if (!c) return 1;
   *rank = c->rank; *nranks = c->P;

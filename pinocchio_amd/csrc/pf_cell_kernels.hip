@@ -112,137 +112,11 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
 // (four waves per SIMD = four 256-thread workgroups per CU, which the grid of 8 per CU is sized for: at most 128 VGPRs)
 template <typename F, bool FAST>
 __global__ void __launch_bounds__(PF_CELL_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) k_collapse(const PfCollapseParams p) { pf_collapse_body<F, FAST>(p); }
-// occupancy experiments (PF_COLLAPSE_WPE): the same body under a register cap
-template <typename F, bool FAST>
-__global__ void __launch_bounds__(PF_CELL_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) k_collapse_w4(const PfCollapseParams p) { pf_collapse_body<F, FAST>(p); }
-template <typename F, bool FAST>
-__global__ void __launch_bounds__(PF_CELL_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) k_collapse_w5(const PfCollapseParams p) { pf_collapse_body<F, FAST>(p); }
-
 template <typename F, bool FAST>
 __global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse_tab(const PfCollapseParams p) { pf_collapse_body<F, FAST, true>(p); }
 // the solve on the three invariants per cell that k_c2r_invariants leaves in h[0..2] (fp64 fields)
 template <bool FAST>
 __global__ void __launch_bounds__(PF_CELL_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) k_collapse_inv(const PfCollapseParams p) { pf_collapse_body<double, FAST, false, true>(p); }
-
-// K6 with the cells of a workgroup regrouped by the branch of the cubic.  Two thirds of the cells have a one-root cubic
-// (square root, cube root: ~66 instructions), one third a three-root one (acos, sincos: ~116), and no wave of 64
-// neighbouring cells is uniform, so in k_collapse every wave pays both.  Here a workgroup of 512 cells does the part
-// that is the same for all (Hessian -> eigenvalues -> coefficients of the cubic), then sorts the cubics through LDS -- one-root
-// ones from the front of a 512-entry list, three-root ones from the back --, solves entry t in thread t (at most two of
-// the eight waves see both kinds), hands the root back to the cell's thread and finishes there (correction, inverse
-// growth, running maximum).  Same operations per cell as k_collapse: Fmax and Rmax are bit-identical; the variance
-// partials are summed over 512-thread blocks instead of 256-thread ones.  Fast flavour, direct solve only.
-// Measured (1024^3, same box): 25.4 ms per launch against 23.0 ms for k_collapse -- the three barriers couple the eight
-// waves of a block, which then waits for its slowest SIMD (the one holding the mixed wave: ~250 instruction slots against
-// an average of ~165), and ranks, prefix sums and the LDS round trip cost ~50 instructions per cell.  Kept as an
-// experiment (PF_COLLAPSE_GROUPED=1), not the default.
-// Every __syncthreads below is reached by every thread: the cell loop runs on the block's base index.
-#define PF_GROUP_BLOCK 512
-template <typename F>
-__global__ void __launch_bounds__(PF_GROUP_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) k_collapse_grouped(const PfCollapseParams p) {
-  constexpr int NB = PF_GROUP_BLOCK, NW = NB / 64;
-  __shared__ double sk[5 * PF_MAX_KNOTS];
-  __shared__ double red[2 * NW];
-  __shared__ unsigned short slut[PF_SPLINE_LUT_BINS];
-  __shared__ double e_a1[NB], e_q[NB], e_r[NB], e_disc[NB];  // the cubics, regrouped
-  __shared__ double ell_of[NB];                               // the root, per cell (= per thread)
-  __shared__ unsigned short e_src[NB];                        // thread a regrouped entry came from
-  __shared__ int wcnt[2][NW];                                 // per wave: one-root, three-root cells
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nk = p.spline.n;
-  for (int i = tid; i < nk; i += NB) {
-    sk[i] = p.spline.x[i];
-    sk[PF_MAX_KNOTS + i] = p.spline.y[i];
-    sk[2 * PF_MAX_KNOTS + i] = p.spline.c[i];
-    sk[3 * PF_MAX_KNOTS + i] = p.spline.b[i];
-    sk[4 * PF_MAX_KNOTS + i] = p.spline.d[i];
-  }
-  __syncthreads();
-  for (int b = tid; b < PF_SPLINE_LUT_BINS; b += NB) slut[b] = pf_spline_lut_entry(sk, nk, b);
-  __syncthreads();
-  pf_spline_view sv;
-  sv.x = sk; sv.y = sk + PF_MAX_KNOTS; sv.c = sk + 2 * PF_MAX_KNOTS; sv.b = sk + 3 * PF_MAX_KNOTS; sv.d = sk + 4 * PF_MAX_KNOTS;
-  sv.n = nk;
-  if (!p.no_lut) { sv.lut = slut; sv.lut_inv_w = (double)PF_SPLINE_LUT_BINS / (sk[nk - 1] - sk[0]); }
-
-  const F *__restrict__ h0 = (const F *)p.h[0], *__restrict__ h1 = (const F *)p.h[1],
-          *__restrict__ h2 = (const F *)p.h[2], *__restrict__ h3 = (const F *)p.h[3],
-          *__restrict__ h4 = (const F *)p.h[4], *__restrict__ h5 = (const F *)p.h[5];
-  const long long ncell = p.nrows * p.n;
-  double sum = 0.0, sum2 = 0.0;
-  const long long stride = (long long)gridDim.x * NB;
-  const int srow = (int)(stride / p.n), scol = (int)(stride - (long long)srow * p.n);
-  const long long i0 = (long long)blockIdx.x * NB + tid;
-  int row = (int)(i0 / p.n), col = (int)(i0 - (long long)row * p.n);
-  for (long long base = (long long)blockIdx.x * NB; base < ncell; base += stride, row += srow, col += scol) {
-    if (col >= p.n) { col -= p.n; row++; }
-    const long long i = base + tid;
-    const bool active = i < ncell;
-    // ---- per cell: Hessian -> ordered eigenvalues -> the cubic -------------------------------------------------------
-    double lam[3] = {0.0, 0.0, 0.0}, ell = 0.0;
-    float fold = -10.0f;
-    bool ok = false;
-    int kind = 0;
-    pf_cubic cub; cub.a1 = cub.q = cub.r = cub.disc = 0.0;
-    if (active) {
-      const long long a = (long long)row * p.pitch + col;
-      double d[6] = {(double)h0[a], (double)h1[a], (double)h2[a], (double)h3[a], (double)h4[a], (double)h5[a]};
-      if (p.ismooth) fold = p.fmax[i];
-      const double delta = d[0] + d[1] + d[2];
-      sum += delta;
-      sum2 += delta * delta;
-      ok = pf_ordered_eigenvalues<true>(d, lam);
-      if (ok) kind = pf_ell_setup<true>(lam[0], lam[1], lam[2], ell, cub);
-    }
-    // ---- regroup: rank of this cell among the one-root / three-root cells of the block ---------------------------------
-    const unsigned long long m1 = __builtin_amdgcn_ballot_w64(kind == 1), m3 = __builtin_amdgcn_ballot_w64(kind == 2);
-    if (lane == 0) { wcnt[0][wave] = __popcll(m1); wcnt[1][wave] = __popcll(m3); }
-    __syncthreads();
-    int off1 = 0, off3 = 0, n1 = 0, n3 = 0;
-#pragma unroll
-    for (int w = 0; w < NW; w++) {
-      const int c1 = wcnt[0][w], c3 = wcnt[1][w];
-      if (w < wave) { off1 += c1; off3 += c3; }
-      n1 += c1; n3 += c3;
-    }
-    if (kind) {
-      const unsigned long long m = kind == 1 ? m1 : m3;
-      const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-      const int pos = kind == 1 ? off1 + rank : NB - 1 - (off3 + rank);
-      e_a1[pos] = cub.a1; e_q[pos] = cub.q; e_r[pos] = cub.r; e_disc[pos] = cub.disc;
-      e_src[pos] = (unsigned short)tid;
-    }
-    __syncthreads();
-    // ---- solve entry `tid`: one-root cubics in [0, n1), three-root ones in [NB - n3, NB) -------------------------------
-    if (tid < n1 || tid >= NB - n3) {
-      pf_cubic e; e.a1 = e_a1[tid]; e.q = e_q[tid]; e.r = e_r[tid]; e.disc = e_disc[tid];
-      const double root = tid < n1 ? pf_ell_one_root<true>(e) : pf_ell_three_roots<true>(e);
-      ell_of[e_src[tid]] = root;
-    }
-    __syncthreads();
-    // ---- back in the cell's thread: correction, inverse growth, running maximum ----------------------------------------
-    if (active) {
-      double Fnew = -10.0;
-      if (ok) {
-        if (kind) ell = ell_of[tid];
-        const double bc = pf_ell_finish<true>(ell, lam[0], lam[1], lam[2]);
-        Fnew = bc > 0.0 ? 1. + pf_inverse_growing_mode<true>(sv, bc) : 0.0;
-      }
-      if ((double)fold < Fnew) {
-        p.fmax[i] = (float)Fnew;
-        p.rmax[i] = p.ismooth;
-      } else if (!p.ismooth) {
-        p.fmax[i] = -10.0f;
-        p.rmax[i] = -1;
-      }
-    }
-  }
-  pf_block_sum2(sum, sum2, red);
-  if (tid == 0) {
-    p.partials[2 * blockIdx.x] = sum;
-    p.partials[2 * blockIdx.x + 1] = sum2;
-  }
-}
 
 // initialize_collapse_times (src/collapse_times.c:956-972): CT_table[i] = ell(ismooth, l1, l2, l3) on the
 // (delta, x, y) grid, i = id + 100 * (ix + 50 * iy)
@@ -615,13 +489,6 @@ int pf_launch_collapse(int fb, const PfCollapseParams &p, hipStream_t st) {
     else hipLaunchKernelGGL((k_collapse_inv<false>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
     return PF_CHECK_LAUNCH();
   }
-  if (p.grouped) {
-    if (fb == 8) hipLaunchKernelGGL((k_collapse_grouped<double>), dim3(p.nblocks), dim3(PF_GROUP_BLOCK), 0, st, p);
-    else hipLaunchKernelGGL((k_collapse_grouped<float>), dim3(p.nblocks), dim3(PF_GROUP_BLOCK), 0, st, p);
-    return PF_CHECK_LAUNCH();
-  }
-  if (fb == 8 && p.fast && p.wpe == 4) { hipLaunchKernelGGL((k_collapse_w4<double, true>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p); return PF_CHECK_LAUNCH(); }
-  if (fb == 8 && p.fast && p.wpe == 5) { hipLaunchKernelGGL((k_collapse_w5<double, true>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p); return PF_CHECK_LAUNCH(); }
   if (fb == 8) {
     if (p.fast) hipLaunchKernelGGL((k_collapse<double, true>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
     else hipLaunchKernelGGL((k_collapse<double, false>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);

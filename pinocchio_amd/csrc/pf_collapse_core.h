@@ -419,6 +419,17 @@ PF_HD void pf_invariants(const double d[6], double &mu1, double &mu2, double &mu
   mu2 -= add0 + add1 + add2;
   mu3 = d[0] * d[1] * d[2] + 2. * d[3] * d[4] * d[5] - d[0] * add2 - d[1] * add1 - d[2] * add0;
 }
+// q of pf_eigen_from_invariants is zero (or so small that the division by nine flushes it) although the diagonal is not
+// exactly (mu1/3, mu1/3, mu1/3) -- the one case in which the three invariants do not carry what the solve reads
+PF_HD bool pf_invariants_lose_diagonal(const double d[6], double mu1, double mu2) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  const double x = mu1 * mu1 - 3.0 * mu2;
+  if (!(x == 0.0 || (x < 1e-290 && x > -1e-290))) return false;
+  const double third = mu1 * (1.0 / 3.0);
+  return !(d[0] == third && d[1] == third && d[2] == third);
+}
 template <bool FAST = false> PF_HD bool pf_eigen_from_invariants(double mu1, double mu2, double mu3, const double diag[3], double lam[3]) {
   const double mu1_2 = mu1 * mu1;
   const double q = FAST ? pf_div_const<9>(mu1_2 - 3.0 * mu2) : (mu1_2 - 3.0 * mu2) / 9.0;
@@ -610,3 +621,9 @@ inline int pf_spline_coeffs(const double *xa, const double *ya, int n, double *c
   delete[] g;
   return 0;
 }
+
+// The translation units built with -ffp-contract=on (the transform kernels) get their default back for the code that
+// follows this header, whatever the include order (the Makefile defines PF_FP_CONTRACT_ON for them).
+#if defined(__clang__) && defined(PF_FP_CONTRACT_ON)
+#pragma clang fp contract(on)
+#endif

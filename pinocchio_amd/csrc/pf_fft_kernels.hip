@@ -14,8 +14,6 @@
 //
 // A strided launch carries several (input, multiplier, output) jobs grouped by
 // input: a workgroup reads its tile once and transforms it for every job on it.
-#include <stdlib.h>
-
 #include "pf_internal.h"
 #include "pf_fft_core.h"
 
@@ -233,7 +231,7 @@ __global__ void __launch_bounds__(TL *(N / 16)) k_c2r_persistent(const PfC2RPara
     }
     // from here to the end of the stages a line belongs to its own NT threads: one wave for N <= 1024, whose LDS accesses
     // stay in order without workgroup barriers (four of them per tile at N = 1024)
-    if (NT <= 64) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+    if (NT <= 64) pf_wave_sync(); else __syncthreads();
     if (t + gridDim.x < ntiles) fetch(t + gridDim.x);  // in flight during the stages and the stores below
     PfStages<F, M, +1, 2, 0, (NT <= 64)>::run(
         v, tlj, tw, [&](int pos, C val) { L[pf_lpad(pos)] = val; }, [&](int pos) { return L[pf_lpad(pos)]; });
@@ -292,7 +290,7 @@ __global__ void __launch_bounds__(6 * (N / 16)) k_c2r_invariants(const PfC2RPara
 
   // a line is touched by its own threads only until the reduction: while those sit in one wave (N <= 1024) the LDS
   // queue keeps their accesses in order and no workgroup barrier is needed
-  auto line_sync = [&]() { if (NT > 64) __syncthreads(); else __builtin_amdgcn_wave_barrier(); };
+  auto line_sync = [&]() { if (NT > 64) __syncthreads(); else pf_wave_sync(); };
   C nxt[9];
   auto fetch = [&](long long R) {
     const C *__restrict__ row = in + R * p.in_pitch;
@@ -344,6 +342,9 @@ __global__ void __launch_bounds__(6 * (N / 16)) k_c2r_invariants(const PfC2RPara
         double a1, a2, a3, b1, b2, b3;
         pf_invariants(da, a1, a2, a3);
         pf_invariants(db, b1, b2, b3);
+        // the solve's q == 0 case takes the tensor's own diagonal (src/collapse_times.c:722-727), which is not stored: it
+        // will use mu1/3 three times.  The same unless the tensor is exactly that; otherwise the sweep is repeated (pf_sweep)
+        if (pf_invariants_lose_diagonal(da, a1, a2) || pf_invariants_lose_diagonal(db, b1, b2)) *p.flag = 1.0;
         *reinterpret_cast<double2 *>(o1 + a) = make_double2(a1, b1);
         *reinterpret_cast<double2 *>(o2 + a) = make_double2(a2, b2);
         *reinterpret_cast<double2 *>(o3 + a) = make_double2(a3, b3);
@@ -436,8 +437,9 @@ static int launch_strided_n(const PfStridedParams &p, hipStream_t st) {
   dim3 grid((unsigned)(((nwork + 7) >> 3) << 3), 1, 1), block(T * N / 8, 1, 1);
   const size_t shm = (size_t)N * T * sizeof(pfc<F>);
   if (shm > 64 * 1024) {
-    static bool raised = false;  // per instantiation
-    if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_strided<F, N, T, DIR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); raised = true; }
+    static bool raised[PF_MAX_DEVICES] = {};  // per instantiation and device
+    const int d = p.dev >= 0 && p.dev < PF_MAX_DEVICES ? p.dev : 0;
+    if (!raised[d]) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_strided<F, N, T, DIR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); raised[d] = true; }
   }
   hipLaunchKernelGGL((k_strided<F, N, T, DIR>), grid, block, shm, st, p, nwork, ntiles);
   return hipGetLastError() == hipSuccess ? 0 : 1;
@@ -454,12 +456,10 @@ static int launch_c2r_n(const PfC2RParams &p, hipStream_t st) {
   // Workgroups that walk over tiles with the next tile prefetched in registers: 21.5 -> 18.4 ms per six-field launch at
   // 1024^3 (4.8 -> 5.6 TB/s algorithmic).  3 fit per CU (140 VGPRs); 24 per CU = 8 rounds of ~256 tiles each evens out
   // the tail (measured 3: 19.1, 6: 18.9, 12: 18.6, 24: 18.4 ms).  PF_ZPASS_PERSIST=0 selects the one-shot kernel.
-  static const int persist = getenv("PF_ZPASS_PERSIST") ? atoi(getenv("PF_ZPASS_PERSIST")) : 24;
-  if (persist > 0 && N >= 64) {
-    static int ncu = 0;
-    if (!ncu) { hipDeviceProp_t prop; int dev = 0; hipGetDevice(&dev); hipGetDeviceProperties(&prop, dev); ncu = prop.multiProcessorCount; }
+  const int persist = p.persist_per_cu;
+  if (persist > 0 && N >= 64 && p.ncu > 0) {
     const long long ntiles = nblk * p.njobs;
-    long long g = (long long)ncu * persist;
+    long long g = (long long)p.ncu * persist;
     if (g > ntiles) g = ntiles;
     hipLaunchKernelGGL((k_c2r_persistent<F, N, TL>), dim3((unsigned)g), block, shm, st, p, ntiles);
     return hipGetLastError() == hipSuccess ? 0 : 1;
@@ -472,14 +472,11 @@ template <int N>
 static int launch_c2r_invariants_n(const PfC2RParams &p, hipStream_t st, int mode) {
   constexpr int M = N / 2, NT = M / 8;
   constexpr int LPL = (M + 1 > M + M / 8) ? M + 1 : M + M / 8;
-  static int ncu = 0;
-  if (!ncu) { hipDeviceProp_t prop; int dev = 0; hipGetDevice(&dev); hipGetDeviceProperties(&prop, dev); ncu = prop.multiProcessorCount; }
   // (a second row of prefetch per workgroup -- 159 VGPRs, still two workgroups per CU -- made the pass slower: 222-227 ms
   // against 190-194 ms per step; more rows in flight on six fields at once cost more in DRAM locality than they hide)
   // two workgroups fit per CU; 32 per CU in the grid evens out the tail (measured 6: 254, 8: 248, 16: 241, 32: 235-237,
   // 64: 236 ms per step of eleven launches at 1024^3)
-  static const int per_cu = getenv("PF_ZPASS_INV_WG_PER_CU") ? atoi(getenv("PF_ZPASS_INV_WG_PER_CU")) : 32;
-  long long g = (long long)ncu * (per_cu > 0 ? per_cu : 32);
+  long long g = (long long)(p.ncu > 0 ? p.ncu : 256) * (p.inv_per_cu > 0 ? p.inv_per_cu : 32);
   if (g > p.nlines) g = p.nlines;
   const size_t shm = (size_t)6 * LPL * sizeof(pfc<double>);
   if (mode == 1) hipLaunchKernelGGL((k_c2r_invariants<N, 1>), dim3((unsigned)g), dim3(6 * NT), shm, st, p, p.nlines);
@@ -549,7 +546,7 @@ int pf_launch_c2r(int fb, int n, const PfC2RParams &p, hipStream_t st) {
 }
 
 int pf_launch_c2r_invariants(int n, const PfC2RParams &p, hipStream_t st, int mode) {
-  if (p.njobs != 6 || (mode == 1 && !p.acc) || n > 1024) return 2;
+  if (p.njobs != 6 || (mode == 1 && !p.acc) || (mode == 0 && !p.flag) || n > 1024) return 2;
 #define CALL(NN) launch_c2r_invariants_n<NN>(p, st, mode)
   PF_SWITCH_N(n, CALL)
 #undef CALL

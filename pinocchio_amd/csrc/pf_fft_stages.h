@@ -2,6 +2,15 @@
 #pragma once
 #include "pf_fft_core.h"
 
+// Exchange through LDS between the lanes of ONE wave: the LDS queue serves a wave's accesses in order, so no instruction is
+// needed -- but the compiler must neither move LDS accesses across this point nor assume other lanes' words unchanged: a
+// release / acquire fence pair at wavefront scope around the scheduling barrier says exactly that and emits nothing.
+__device__ __forceinline__ void pf_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // WAVE_LOCAL: the N / 8 threads of a transform sit in one wave and exchange through LDS words nobody else touches: the
 // LDS queue serves a wave's accesses in order, so the exchange needs no workgroup barrier
 template <typename F, int N, int DIR, int TWS, int S = 0, bool WAVE_LOCAL = false>
@@ -14,10 +23,10 @@ struct PfStages {
       constexpr int NT = N / 8;
 #pragma unroll
       for (int m = 0; m < 8; m++) wr(pf_stage_pos<N, S>(tl, m), v[m]);
-      if constexpr (WAVE_LOCAL) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+      if constexpr (WAVE_LOCAL) pf_wave_sync(); else __syncthreads();
 #pragma unroll
       for (int m = 0; m < 8; m++) v[m] = rd(tl + m * NT);
-      if constexpr (WAVE_LOCAL) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+      if constexpr (WAVE_LOCAL) pf_wave_sync(); else __syncthreads();
       PfStages<F, N, DIR, TWS, S + 1, WAVE_LOCAL>::run(v, tl, tw, wr, rd);
     }
   }

@@ -7,6 +7,17 @@
 #include "../../include/pinfmax.h"
 
 #define PF_MAX_JOBS 6
+#define PF_MAX_DEVICES 64
+
+// run-time switches, read from the environment once per context in pf_create (pf_api.hip: read_tuning);
+// launch paths see only this struct
+struct PfTuning {
+  int zpass_persist;        // PF_ZPASS_PERSIST: workgroups per CU of the persistent z-pass, 0 = one-shot workgroups
+  int zpass_inv_wg_per_cu;  // PF_ZPASS_INV_WG_PER_CU
+  int collapse_wg_per_cu;   // PF_COLLAPSE_WG_PER_CU
+  bool spline_lut, exchange_rows, invariants, lpt_fuse, general, pipeline, exact_libm;
+  double prune_eps;
+};
 
 // multiplier applied along the transformed axis before the 1-D transform
 // (k = 2 pi s / N, s the signed wavenumber of src/fmax-pfft.c:306-339)
@@ -44,6 +55,7 @@ struct PfStridedParams {
   // weight below 2^-60 and are treated as exact zeros.  band_e masks the loads along the transformed
   // axis, band_outer skips whole workgroups; columns are pruned by ncols.  band >= n/2 disables.
   int band_e, band_outer;
+  int dev;           // device the launch goes to (the LDS-size attribute of an instantiation is raised once per device)
 };
 
 // one x- or y-pass: for every job, out = FFT_e[ in * pre * mul ]  (dir = +1 inverse, -1 forward)
@@ -68,6 +80,10 @@ struct PfC2RParams {
   const void *tw;       // exp(+2 pi i j / n)
   int band_k;           // input columns kz > band_k are zero (pruned), not read
   void *acc;            // k_c2r_invariants MODE 1: the real field updated in place (3LPT(b) source); job[c].out = first-order Hessian
+  double *flag;         // k_c2r_invariants MODE 0: set to 1 when a cell has q == 0 without being exactly isotropic (pf_sweep repeats)
+  int ncu, dev;         // CUs of the device, device index
+  int persist_per_cu;   // workgroups per CU of the persistent z-pass (0: one-shot kernel)
+  int inv_per_cu;       // workgroups per CU of the invariant z-pass
 };
 int pf_launch_c2r(int field_bytes, int n, const PfC2RParams &p, hipStream_t st);
 // six components (njobs == 6, fp64) -> the three invariants of the tensor into job[0..2].out (pf_fft_kernels.hip)
@@ -107,10 +123,8 @@ struct PfCollapseParams {
   double *partials;     // [2*nblocks]: sum delta, sum delta^2 per block
   int nblocks;
   int fast;             // 1: sincos/cbrt/exp10 forms of the transcendental hot spots (pf_collapse_core.h)
-  int wpe;              // occupancy experiment: 0 default, 4 / 5 = register-capped builds
   int no_lut;           // 1: plain bisection in the spline lookup (PF_SPLINE_LUT=0)
   int invariants;       // 1: h[0..2] hold mu1, mu2, mu3 (k_c2r_invariants), h[3..5] unused
-  int grouped;          // 1: k_collapse_grouped (cells regrouped by the branch of the cubic; fast flavour, direct solve)
   int tabulated;        // 1: F from the collapse-time table `ct` (TABULATED_CT build) instead of the direct solve
   PfCtDev ct;
 };
@@ -118,28 +132,6 @@ int pf_launch_ct_build(const PfSplineDev &sp, const PfCtDev &ct, int fast, int c
 int pf_launch_collapse(int field_bytes, const PfCollapseParams &p, hipStream_t st);
 int pf_launch_final_sum(const double *partials, int nblocks, double *out2, hipStream_t st);
 int pf_launch_collapse_cells(const double *d, size_t count, PfSplineDev s, double *F, int fast, hipStream_t st);
-
-// fused z-pass + collapse (pf_fused_kernels.hip)
-struct PfFusedParams {
-  const void *in[6];    // six complex fields after the y-pass (XS layout)
-  int mul[6];           // kz factor per component
-  void *out[6];         // real rows written when write_h (may alias in)
-  int write_h;
-  long long nlines, in_pitch, out_pitch;
-  double norm;
-  const double *dc;
-  const void *tw;
-  float *fmax;
-  int *rmax;
-  int ismooth;
-  PfSplineDev spline;
-  double *partials;     // [2*nblocks]
-  int max_blocks;
-  int debug_skip;       // timing experiments only: 1 = skip the solve, 2 = skip the row transforms
-  int skew_ns, ncu;     // start-up stagger between the workgroups that share a CU
-};
-int pf_launch_zcollapse(int field_bytes, int n, const PfFusedParams &p, int blocks_per_cu, int ncu, hipStream_t st,
-                        int *nblocks_out);
 
 struct PfLptSrcParams {
   const void *h[6];

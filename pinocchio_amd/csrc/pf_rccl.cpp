@@ -54,30 +54,38 @@ static int load_rccl() {
 
 struct RcclLink { ncclComm_t comm; int rank, nranks; };
 
+// (a group that was opened is always closed, also when a call inside it fails: an open group would swallow every later
+//  RCCL call of the process, the fallback exchange's included)
 static int rccl_alltoall(void *user, const void *send, void *recv, size_t bytes, void *stream) {
   RcclLink *l = (RcclLink *)user;
   if (g_api.GroupStart()) return 1;
-  for (int q = 0; q < l->nranks; q++) {
-    if (g_api.Send((const char *)send + (size_t)q * bytes, bytes, ncclChar_, q, l->comm, stream)) return 1;
-    if (g_api.Recv((char *)recv + (size_t)q * bytes, bytes, ncclChar_, q, l->comm, stream)) return 1;
+  int bad = 0;
+  for (int q = 0; q < l->nranks && !bad; q++) {
+    bad |= g_api.Send((const char *)send + (size_t)q * bytes, bytes, ncclChar_, q, l->comm, stream) != 0;
+    if (!bad) bad |= g_api.Recv((char *)recv + (size_t)q * bytes, bytes, ncclChar_, q, l->comm, stream) != 0;
   }
-  return g_api.GroupEnd() ? 1 : 0;
+  return (g_api.GroupEnd() != 0) | bad;
 }
 // the same exchange restricted to one row range per block (band-limited spectra): variable message sizes, empty ones skipped
 static int rccl_alltoallv(void *user, const void *send, void *recv, size_t block_bytes, size_t send_off, size_t send_bytes,
                           const size_t *recv_off, const size_t *recv_bytes, void *stream) {
   RcclLink *l = (RcclLink *)user;
   if (g_api.GroupStart()) return 1;
-  for (int q = 0; q < l->nranks; q++) {
-    if (send_bytes && g_api.Send((const char *)send + (size_t)q * block_bytes + send_off, send_bytes, ncclChar_, q, l->comm, stream)) return 1;
-    if (recv_bytes[q] && g_api.Recv((char *)recv + (size_t)q * block_bytes + recv_off[q], recv_bytes[q], ncclChar_, q, l->comm, stream)) return 1;
+  int bad = 0;
+  for (int q = 0; q < l->nranks && !bad; q++) {
+    if (send_bytes) bad |= g_api.Send((const char *)send + (size_t)q * block_bytes + send_off, send_bytes, ncclChar_, q, l->comm, stream) != 0;
+    if (!bad && recv_bytes[q]) bad |= g_api.Recv((char *)recv + (size_t)q * block_bytes + recv_off[q], recv_bytes[q], ncclChar_, q, l->comm, stream) != 0;
   }
-  return g_api.GroupEnd() ? 1 : 0;
+  return (g_api.GroupEnd() != 0) | bad;
 }
 static int rccl_allreduce(void *user, void *buf, size_t count, int is_u64, void *stream) {
   RcclLink *l = (RcclLink *)user;
   return g_api.AllReduce(buf, buf, count, is_u64 ? ncclUint64_ : ncclDouble_, ncclSum_, l->comm, stream) ? 1 : 0;
 }
+
+// host-side only: can this process bind RCCL at all?  No collective, no communicator -- safe to call before the ranks
+// vote on the exchange kind (a rank that cannot must say so BEFORE its peers block inside ncclCommInitRank)
+extern "C" int pf_rccl_available(void) { return load_rccl() ? 0 : 1; }
 
 extern "C" int pf_rccl_unique_id(void *id128) {
   if (!id128 || load_rccl()) return 1;
@@ -87,13 +95,21 @@ extern "C" int pf_rccl_unique_id(void *id128) {
   return 0;
 }
 
-// rank/nranks come from the context's own configuration
+// rank/nranks come from the context's own configuration; the context owns the link (pf_destroy / pf_release_rccl)
 extern "C" int pf_ctx_rank_size(pf_ctx *ctx, int *rank, int *nranks);
+extern "C" int pf_ctx_set_rccl(pf_ctx *ctx, void *link);
+
+extern "C" void pf_rccl_release(void *link) {
+  RcclLink *l = (RcclLink *)link;
+  if (!l) return;
+  if (g_api.h && l->comm) g_api.CommDestroy(l->comm);
+  delete l;
+}
 
 extern "C" int pf_init_rccl(pf_ctx *ctx, const void *id128) {
   if (!ctx || !id128 || load_rccl()) return 1;
   RcclLink *l = new RcclLink();
-  if (pf_ctx_rank_size(ctx, &l->rank, &l->nranks)) return 1;
+  if (pf_ctx_rank_size(ctx, &l->rank, &l->nranks)) { delete l; return 1; }
   ncclUniqueId id;
   memcpy(&id, id128, sizeof(id));
   if (g_api.CommInitRank(&l->comm, l->nranks, id, l->rank)) {
@@ -104,5 +120,6 @@ extern "C" int pf_init_rccl(pf_ctx *ctx, const void *id128) {
   pf_set_exchange(ctx, rccl_alltoall, l);
   pf_set_exchange_rows(ctx, rccl_alltoallv, l);
   pf_set_allreduce(ctx, rccl_allreduce, l);
+  pf_ctx_set_rccl(ctx, l);
   return 0;
 }

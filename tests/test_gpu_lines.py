@@ -1,0 +1,168 @@
+"""Every instantiation of the hand-written 1-D passes, line by line against numpy's pocketfft (an independent transform):
+the strided x/y pass (k_strided), the z-pass c2r (k_c2r / k_c2r_persistent), the forward z-pass (k_r2c) and the six-row
+invariant z-pass (k_c2r_invariants), fp64 and fp32 fields, with and without band pruning and with the k-space factors of
+compute_derivative (src/fmax-pfft.c:306-397).  N = 2048 is the row length of BASELINE config 5 (2048^3 on eight GPUs): its
+box does not fit one GPU, its kernels do -- pf_debug_lines runs them on a batch of lines without a context."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [16, 64, 256, 1024, 2048]
+
+
+@pytest.fixture(scope="module")
+def L():
+    from pinocchio_amd import _lib
+    return _lib.load()
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def run(L, fb, n, pas, inp, out_shape, mul=0, band=1 << 30, nouter=1, ncols=1, pre=0, rs=0.0, growth=1.0, outer_offset=0):
+    inp = np.ascontiguousarray(inp)
+    out = np.zeros(out_shape, dtype=np.complex128 if pas in (0, 1, 3) else np.float64)
+    rc = L.pf_debug_lines(fb, n, pas, mul, band, nouter, ncols, pre, rs, growth, outer_offset,
+                          _dp(inp.view(np.float64)), _dp(out.view(np.float64)))
+    assert rc == 0, L.pf_last_error()
+    return out
+
+
+def run_invariants(L, n, x, rows):
+    """pass 4: six spectra rows -> (mu1, mu2, mu3) rows, plus the q == 0 flag"""
+    x = np.ascontiguousarray(x)
+    out = np.zeros(3 * rows * n + 1)
+    rc = L.pf_debug_lines(8, n, 4, 0, 1 << 30, rows, 1, 0, 0.0, 1.0, 0, _dp(x.view(np.float64)), _dp(out))
+    assert rc == 0, L.pf_last_error()
+    return out[:-1].reshape(3, rows, n), out[-1]
+
+
+def signed(n):
+    e = np.arange(n)
+    return np.where(e > n // 2, e - n, e).astype(np.float64)  # Nyquist stays +n/2 (src/fmax-pfft.c:306-339)
+
+
+def kfactor(mul, k):
+    return {0: np.ones_like(k) + 0j, 1: k + 0j, 2: k * k + 0j, 3: 1j * k}[mul]
+
+
+def tol(fb, n):
+    return (2e-15 if fb == 8 else 1e-6) * np.log2(n)
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("fb", [8, 4])
+def test_strided_pass_lines(L, n, fb):
+    rng = np.random.default_rng(n + fb)
+    nouter, ncols = 3, 21  # not a multiple of the tile width: the last tile is ragged
+    x = rng.standard_normal((nouter, n, ncols)) + 1j * rng.standard_normal((nouter, n, ncols))
+    k = 2 * np.pi / n * signed(n)
+    for mul in (0, 1, 2, 3):
+        got = run(L, fb, n, 0, x, x.shape, mul=mul, nouter=nouter, ncols=ncols)
+        want = np.fft.ifft(x * kfactor(mul, k)[None, :, None], axis=1) * n
+        assert np.max(np.abs(got - want)) <= tol(fb, n) * np.max(np.abs(want)), (n, fb, mul)
+    got = run(L, fb, n, 1, x, x.shape, nouter=nouter, ncols=ncols)
+    want = np.fft.fft(x, axis=1)
+    assert np.max(np.abs(got - want)) <= tol(fb, n) * np.max(np.abs(want)), (n, fb, "forward")
+    # band-limited loads: wavenumbers beyond the band are exact zeros of the input
+    band = n // 5
+    xb = x * (np.abs(signed(n)) <= band)[None, :, None]
+    got = run(L, fb, n, 0, x, x.shape, mul=2, band=band, nouter=nouter, ncols=ncols)
+    want = np.fft.ifft(xb * kfactor(2, k)[None, :, None], axis=1) * n
+    assert np.max(np.abs(got - want)) <= tol(fb, n) * np.max(np.abs(want)), (n, fb, "band")
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("fb", [8, 4])
+def test_first_pass_filter_on_lines(L, n, fb):
+    """the x-pass of the sweep: window, 1/k^2, growth and the factor of its own axis fused into the load"""
+    rng = np.random.default_rng(3 * n + fb)
+    nouter, ncols, off = 4, 9, n - 2  # outer rows n-2, n-1, 0, 1 (mod n) around k_outer = 0: the k = 0 mode sits in row 2
+    x = rng.standard_normal((nouter, n, ncols)) + 1j * rng.standard_normal((nouter, n, ncols))
+    ke = 2 * np.pi / n * signed(n)
+    so = (np.arange(nouter) + off)
+    so = np.where(so > n // 2, so - n, so).astype(np.float64)
+    ko = 2 * np.pi / n * so
+    kc = 2 * np.pi / n * np.arange(ncols)
+    k2 = ko[:, None, None] ** 2 + ke[None, :, None] ** 2 + kc[None, None, :] ** 2
+    for rs, g, mul in ((0.0, 1.0, 0), (2.5, 0.37, 2), (0.0, -0.111, 3)):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            f = np.where(k2 > 0, np.exp(-0.5 * k2 * rs * rs) * g / k2, 0.0)
+        got = run(L, fb, n, 0, x, x.shape, mul=mul, nouter=nouter, ncols=ncols, pre=1, rs=rs, growth=g, outer_offset=off)
+        want = np.fft.ifft(x * f * kfactor(mul, ke)[None, :, None], axis=1) * n
+        assert np.max(np.abs(got - want)) <= 4 * tol(fb, n) * np.max(np.abs(want)), (n, fb, rs, mul)
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("fb", [8, 4])
+@pytest.mark.parametrize("persist", ["24", "0"])
+def test_zpass_c2r_lines(L, n, fb, persist, monkeypatch):
+    monkeypatch.setenv("PF_ZPASS_PERSIST", persist)  # 0: the one-shot kernel k_c2r (switches are read at every call of the tap)
+    rng = np.random.default_rng(5 * n + fb)
+    rows, h = 37, n // 2 + 1
+    x = rng.standard_normal((rows, h)) + 1j * rng.standard_normal((rows, h))
+    kz = 2 * np.pi / n * np.arange(h)
+    for mul in (0, 1, 2, 3):
+        got = run(L, fb, n, 2, x, (rows, n), mul=mul, nouter=rows)
+        want = np.fft.irfft(x * kfactor(mul, kz)[None, :], n=n, axis=1) * n
+        assert np.max(np.abs(got - want)) <= tol(fb, n) * np.max(np.abs(want)), (n, fb, mul)
+    band = n // 7
+    got = run(L, fb, n, 2, x, (rows, n), mul=1, band=band, nouter=rows)
+    want = np.fft.irfft(x * (np.arange(h) <= band) * kz, n=n, axis=1) * n
+    assert np.max(np.abs(got - want)) <= tol(fb, n) * np.max(np.abs(want)), (n, fb, "band")
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("fb", [8, 4])
+def test_zpass_r2c_lines(L, n, fb):
+    rng = np.random.default_rng(7 * n + fb)
+    rows = 29
+    x = rng.standard_normal((rows, n))
+    got = run(L, fb, n, 3, x, (rows, n // 2 + 1), nouter=rows)
+    want = np.fft.rfft(x, axis=1)
+    assert np.max(np.abs(got - want)) <= tol(fb, n) * np.max(np.abs(want)), (n, fb)
+
+
+@pytest.mark.parametrize("n", [16, 64, 256, 1024])
+def test_invariant_zpass_lines(L, n):
+    """six rows in, the three invariants of each cell's tensor out (what the solve of every radius but the last reads)"""
+    rng = np.random.default_rng(11 * n)
+    rows, h = 23, n // 2 + 1
+    x = rng.standard_normal((6, rows, h)) + 1j * rng.standard_normal((6, rows, h))
+    kz = 2 * np.pi / n * np.arange(h)
+    mul6 = (0, 0, 2, 0, 1, 1)
+    d = [np.fft.irfft(x[j] * kfactor(mul6[j], kz)[None, :], n=n, axis=1) * n for j in range(6)]
+    got, flag = run_invariants(L, n, x, rows)
+    assert flag == 0.0
+    mu1 = d[0] + d[1] + d[2]
+    mu2 = 0.5 * mu1 * mu1 - 0.5 * (d[0] ** 2 + d[1] ** 2 + d[2] ** 2) - (d[3] ** 2 + d[4] ** 2 + d[5] ** 2)
+    mu3 = d[0] * d[1] * d[2] + 2 * d[3] * d[4] * d[5] - d[0] * d[5] ** 2 - d[1] * d[4] ** 2 - d[2] * d[3] ** 2
+    amp = max(np.max(np.abs(v)) for v in d)
+    for gi, wi, p in ((got[0], mu1, 1), (got[1], mu2, 2), (got[2], mu3, 3)):
+        assert np.max(np.abs(gi - wi)) <= 8 * tol(8, n) * amp ** p, (n, p)
+
+
+def test_invariant_zpass_flags_tensors_it_cannot_serve(L):
+    """q == 0 in floating point: the reference takes the tensor's own diagonal (src/collapse_times.c:722-727).  Constant rows
+    (only the k = 0 column set) make every cell of a row the same tensor."""
+    n, rows = 64, 4
+    h = n // 2 + 1
+
+    def flag_of(d):
+        x = np.zeros((6, rows, h), dtype=np.complex128)
+        for j in range(6):
+            x[j, :, 0] = d[j]  # c2r of a k = 0 mode alone, unnormalised: the constant d[j]
+        got, flag = run_invariants(L, n, x, rows)
+        assert np.all(got[0] == (d[0] + d[1]) + d[2])
+        return flag
+
+    assert flag_of([0.0] * 6) == 0.0                                        # exactly isotropic (the empty field): mu1/3 IS the diagonal
+    assert flag_of([0.75, 0.75, 0.75, 0, 0, 0]) == 0.0                       # exactly isotropic, 3 * 0.75 / 3 exact
+    assert flag_of([1.0, 1.0 + 2.0 ** -30, 1.0, 0, 0, 0]) == 1.0             # anisotropy below sqrt(eps): q rounds to zero
+    assert flag_of([1.0, 1.0, 1.0, 2.0 ** -30, 0, 0]) == 1.0                 # the same through an off-diagonal component
+    assert flag_of([1e-170, 2e-170, -1e-170, 1e-171, 0, 0]) == 1.0           # squares underflow
+    assert flag_of([1.0, 1.1, 0.9, 0.01, 0.0, 0.0]) == 0.0                   # an ordinary tensor

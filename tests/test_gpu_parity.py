@@ -366,28 +366,6 @@ def test_properties_on_the_box_of_the_metric(api):
         assert f.sweep(radii[1:]) == pytest.approx(4.0 * tv[1:], rel=1e-12)
 
 
-@pytest.mark.parametrize("n,fb", [(16, 8), (40, 8), (64, 8), (128, 8), (64, 4)])
-def test_grouped_collapse_kernel_equals_plain_kernel(api, n, fb, monkeypatch):
-    """k_collapse_grouped (PF_COLLAPSE_GROUPED=1, an experiment: the cells of a workgroup regrouped by the branch of the cubic
-    through LDS) against k_collapse (the default): the same operations per cell, so Fmax and Rmax bit for bit; the variances differ
-    by the order of their partial sums only.  Sizes with partly filled last blocks and rows shorter than a wave included."""
-    dk = synth.make_density(n, seed=7 + n)
-    x, y = synth.invgrow_table("lcdm")
-    radii = np.array([3.0, 1.2, 0.0])
-    out = {}
-    for g in ("0", "1"):
-        monkeypatch.setenv("PF_COLLAPSE_GROUPED", g)
-        with api.Fmax(n, field_bytes=fb) as f:
-            f.set_density(dk)
-            f.set_invgrow(x, y)
-            tv = f.sweep(radii)
-            out[g] = (tv, f.block("FMAX"), f.block("RMAX"), f.Fmax_PDF())
-    assert np.allclose(out["0"][0], out["1"][0], rtol=1e-13)
-    assert np.array_equal(out["0"][1], out["1"][1]) and np.array_equal(out["0"][2], out["1"][2])
-    assert np.array_equal(out["0"][3], out["1"][3])
-    assert (out["1"][2] > 0).any() and (out["1"][1] > 1.0).any()
-
-
 @pytest.mark.parametrize("n", [16, 64, 128, 256])
 def test_invariant_zpass_equals_six_component_path(api, n, monkeypatch):
     """Default sweep: for every radius but the last the z-pass stores the three invariants of the tensor (k_c2r_invariants)
@@ -780,14 +758,16 @@ def test_ell_sng_table_vs_oracle(api):
     assert np.mean(tab_fr_o[both] >= tab_o[both]) > 0.99 and np.mean(tab_fr_o[both] > tab_o[both] * (1 + 1e-4)) > 0.2   # earlier collapse
 
 
-@pytest.mark.parametrize("case", ["zero", "dc_only", "single_mode", "one_radius", "huge_amplitude", "tiny_amplitude"])
+@pytest.mark.parametrize("case", ["zero", "dc_only", "single_mode", "one_radius", "huge_amplitude", "tiny_amplitude", "underflow_amplitude"])
 def test_edge_case_fields_vs_oracle(api, case, monkeypatch):
     """degenerate inputs the solver's branch ladder exists for (src/collapse_times.c:114-221, 679-776): an empty field
     (q == 0, |l1| < 1e-20), a field that is only its k = 0 mode (untouched by the filter, src/fmax-pfft.c:368: all six
     components equal, eigenvalues (3h, 0, 0)), a single plane wave (two zero eigenvalues) -- both exactly on
     q^3 == r^2, where the -10 sentinel, a NaN from acos(1 + eps) or a value comes out depending on the last bit --,
-    one smoothing radius, and amplitudes far outside the inverse-growth table (linear extrapolation of my_spline_eval,
-    src/cosmo.c:2016-2027)"""
+    one smoothing radius, amplitudes far outside the inverse-growth table (linear extrapolation of my_spline_eval,
+    src/cosmo.c:2016-2027), and an amplitude whose squares underflow: q == 0 with a tensor that is not isotropic, the
+    reference's "already diagonal" branch (src/collapse_times.c:722-727), which the invariant z-pass cannot serve and
+    answers by repeating the sweep with six components"""
     n = 16
     x, y = synth.invgrow_table("lcdm")
     g = synth.growth_multipliers()
@@ -805,6 +785,8 @@ def test_edge_case_fields_vs_oracle(api, case, monkeypatch):
         dk = synth.make_density(n, seed=2) * 1e6
     elif case == "tiny_amplitude":
         dk = synth.make_density(n, seed=2) * 1e-12
+    elif case == "underflow_amplitude":
+        dk = synth.make_density(n, seed=2) * 1e-165
     o = oracle_lib.Oracle(n, 1)
     o.set_density(dk); o.set_invgrow(x, y); o.set_growth(g)
     tv_o = o.compute_fmax(radii, do_lpt=True)
@@ -817,6 +799,10 @@ def test_edge_case_fields_vs_oracle(api, case, monkeypatch):
             tv = f.compute_fmax(radii, do_lpt=True)
             p = f.products()
             pdf = f.Fmax_PDF()
+            reruns = f.L.pf_debug_invariant_reruns(f.h)
+        assert reruns == (1 if case == "underflow_amplitude" else 0), (case, reruns)
+        if case == "underflow_amplitude":
+            assert np.array_equal(p["Fmax"], po["Fmax"]) and np.array_equal(p["Rmax"], po["Rmax"])
         assert np.allclose(tv, tv_o, rtol=1e-12, atol=1e-300)
         assert int(pdf.sum()) == n ** 3
         fo, fg = po["Fmax"].astype(np.float64), p["Fmax"].astype(np.float64)
