@@ -147,21 +147,23 @@ def test_invariant_zpass_lines(L, n):
 
 
 def test_invariant_zpass_flags_tensors_it_cannot_serve(L):
-    """q == 0 in floating point: the reference takes the tensor's own diagonal (src/collapse_times.c:722-727).  Constant rows
-    (only the k = 0 column set) make every cell of a row the same tensor."""
+    """q == 0 in floating point: the reference takes the tensor's own diagonal (src/collapse_times.c:722-727).  Rows holding
+    one kz = 1 mode make every cell of a row the same tensor d times cos(2 pi z / n)."""
     n, rows = 64, 4
     h = n // 2 + 1
+    kz = 2 * np.pi / n
+    fac = (1.0, 1.0, kz * kz, 1.0, kz, kz)  # the kz factors of the six components
 
     def flag_of(d):
         x = np.zeros((6, rows, h), dtype=np.complex128)
         for j in range(6):
-            x[j, :, 0] = d[j]  # c2r of a k = 0 mode alone, unnormalised: the constant d[j]
+            x[j, :, 1] = d[j] / (2.0 * fac[j])
         got, flag = run_invariants(L, n, x, rows)
-        assert np.all(got[0] == (d[0] + d[1]) + d[2])
+        want = ((d[0] + d[1]) + d[2]) * np.cos(kz * np.arange(n))
+        assert np.max(np.abs(got[0] - want[None, :])) <= 1e-14 * max(abs(v) for v in d) if any(d) else not got.any()
         return flag
 
     assert flag_of([0.0] * 6) == 0.0                                        # exactly isotropic (the empty field): mu1/3 IS the diagonal
-    assert flag_of([0.75, 0.75, 0.75, 0, 0, 0]) == 0.0                       # exactly isotropic, 3 * 0.75 / 3 exact
     assert flag_of([1.0, 1.0 + 2.0 ** -30, 1.0, 0, 0, 0]) == 1.0             # anisotropy below sqrt(eps): q rounds to zero
     assert flag_of([1.0, 1.0, 1.0, 2.0 ** -30, 0, 0]) == 1.0                 # the same through an off-diagonal component
     assert flag_of([1e-170, 2e-170, -1e-170, 1e-171, 0, 0]) == 1.0           # squares underflow
