@@ -100,6 +100,9 @@ typedef struct pf_fabric pf_fabric;
 pf_fabric *pf_fabric_create(int nranks);
 void pf_fabric_destroy(pf_fabric *f);
 int pf_fabric_attach(pf_fabric *f, pf_ctx *ctx);
+/* test knob: every all-to-all first idles its stream for that long, so that the copies land late and anything the
+   pipelined exchange fails to wait for reads stale data */
+int pf_fabric_set_delay(pf_fabric *f, int microseconds);
 /* self-test of the installed exchange (pattern through the all-to-all and the all-reduce), any nranks >= 1 */
 int pf_debug_exchange(pf_ctx *ctx, size_t bytes_per_peer);
 /* device pointers + size (bytes) of the exchange buffers, so that a host

@@ -64,6 +64,7 @@ PROTOTYPES = {
     "pf_fabric_create": (_vp, [C.c_int]),
     "pf_fabric_destroy": (None, [_vp]),
     "pf_fabric_attach": (C.c_int, [_vp, _vp]),
+    "pf_fabric_set_delay": (C.c_int, [_vp, C.c_int]),
     "pf_debug_exchange": (C.c_int, [_vp, C.c_size_t]),
     "pf_exchange_buffers": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "pf_set_stream": (C.c_int, [_vp, _vp]),

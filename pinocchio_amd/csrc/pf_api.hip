@@ -230,6 +230,10 @@ static void read_tuning(PfTuning *t) {
   t->general = env_int("PF_GENERAL", 0) != 0;
   t->pipeline = env_int("PF_PIPELINE", 1) != 0;
   t->exact_libm = env_int("PF_EXACT_LIBM", 0) != 0;
+  // fault injection for the tests of the exchange pipeline (tests/test_gpu_multirank.py): "recv" drops the wait of the
+  // compute stream for the exchange it is about to consume, "send" the wait of the exchange for the x-pass that fills its blocks
+  const char *fault = getenv("PF_DEBUG_PIPELINE_FAULT");
+  t->debug_fault = !fault ? 0 : !strcmp(fault, "recv") ? 1 : !strcmp(fault, "send") ? 2 : 0;
   t->prune_eps = 8.673617379884035e-19;  // 2^-60; PF_PRUNE_EPS=0 transforms every mode
   if (const char *e = getenv("PF_PRUNE_EPS")) t->prune_eps = atof(e);
 }
@@ -569,7 +573,7 @@ static int pipelined_band(pf_ctx *c, int count, int nf, Pre pre, Dst dst, Post p
     const int s = i & 1;
     if (pre(i, A[s])) return 1;
     HIPCHK(c, hipEventRecord(c->ev_x[s], c->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->cstream, c->ev_x[s], 0));
+    if (c->tune.debug_fault != 2) HIPCHK(c, hipStreamWaitEvent(c->cstream, c->ev_x[s], 0));
     for (int f = 0; f < nf; f++) PFCHK(c, exchange_band(c, A[s][f], dst(i, s, f), band(i), c->cstream));
     HIPCHK(c, hipEventRecord(c->ev_r[s], c->cstream));
     return 0;
@@ -577,7 +581,7 @@ static int pipelined_band(pf_ctx *c, int count, int nf, Pre pre, Dst dst, Post p
   if (issue(0)) return 1;
   for (int i = 0; i < count; i++) {
     if (i + 1 < count && issue(i + 1)) return 1;
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_r[i & 1], 0));
+    if (c->tune.debug_fault != 1) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_r[i & 1], 0));
     for (int f = 0; f < nf; f++) R[f] = dst(i, i & 1, f);
     if (post(i, R)) return 1;
   }

@@ -17,6 +17,7 @@ struct PfTuning {
   int collapse_wg_per_cu;   // PF_COLLAPSE_WG_PER_CU
   bool spline_lut, exchange_rows, invariants, lpt_fuse, general, pipeline, exact_libm;
   double prune_eps;
+  int debug_fault;          // PF_DEBUG_PIPELINE_FAULT (tests only): 1 / 2 = one wait of the exchange pipeline left out
 };
 
 // multiplier applied along the transformed axis before the 1-D transform

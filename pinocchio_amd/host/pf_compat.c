@@ -125,17 +125,19 @@ static double pf_wtime(void) {
   return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
-/* src/fmax.c:261-289 */
+/* The reference's time stamp (src/fmax.c:261-289 rearranges ctime()): "Www Mmm dd yyyy hh:mm:ss", 24 characters, day of
+   the month blank padded, English names whatever the locale.  Built from the broken-down local time. */
 char *fdate(void) {
-  time_t current_time;
-  char *string;
-  int n;
-  current_time = time(NULL);
-  string = ctime(&current_time);
-  for (n = 0; n < 10; n++) *(date_string + n) = *(string + n);
-  for (n = 10; n < 15; n++) *(date_string + n) = *(string + n + 9);
-  for (n = 10; n < 19; n++) *(date_string + n + 5) = *(string + n);
-  *(date_string + 24) = '\0';
+  static const char day_name[7][4] = {"Sun", "Mon", "Tue", "Wed", "Thu", "Fri", "Sat"};
+  static const char month_name[12][4] = {"Jan", "Feb", "Mar", "Apr", "May", "Jun", "Jul", "Aug", "Sep", "Oct", "Nov", "Dec"};
+  const time_t now = time(NULL);
+  struct tm t;
+  char stamp[64]; /* room for any int the compiler can imagine in the fields; 24 characters are used */
+  localtime_r(&now, &t);
+  snprintf(stamp, sizeof(stamp), "%s %s %2d %4d %02d:%02d:%02d", day_name[t.tm_wday % 7], month_name[t.tm_mon % 12], t.tm_mday,
+           1900 + t.tm_year, t.tm_hour, t.tm_min, t.tm_sec);
+  memcpy(date_string, stamp, 24);
+  date_string[24] = '\0';
   return date_string;
 }
 
@@ -147,10 +149,21 @@ int set_one_grid(int ThisGrid) {
     printf("ERROR on task %d: the GPU path needs a cubic grid\n", ThisTask);
     return 1;
   }
-  if (n % NTasks) {
+  if (n % NTasks) { /* PFFT would hand out ragged slabs; the device transposes equal blocks */
     printf("ERROR on task %d: NTasks=%d must divide GridSize=%ld (slab decomposition)\n", ThisTask, NTasks, (long)n);
     return 1;
   }
+  if (params.use_transposed_fft) { /* src/fmax-pfft.c:271-281: k-space would be stored [y, x, z] */
+    printf("ERROR on task %d: UseTransposedFFT is not supported by the GPU path (k-space stays in x, y, z order)\n", ThisTask);
+    return 1;
+  }
+#ifdef PF_IN_PINOCCHIO_TREE
+  if (internal.tasks_subdivision_dim > 1) { /* src/initialization.c:1317-1325: pencils / volumes */
+    printf("ERROR on task %d: the GPU path decomposes the box in slabs (one task per GPU): tasks_subdivision_dim = %d\n", ThisTask,
+           internal.tasks_subdivision_dim);
+    return 1;
+  }
+#endif
   G->norm = (double)1.0 / ((double)G->Ntotal);
   G->CellSize = (double)G->BoxSize / G->GSglobal[_x_];
   G->GSlocal[_x_] = n / NTasks; G->GSlocal[_y_] = n; G->GSlocal[_z_] = n;
@@ -426,20 +439,23 @@ int compute_fmax(void) {
   return 0;
 }
 
-/* src/fmax.c:509-550 */
+/* bin of the Fmax histogram: tenths of F, everything below 0 in the first and everything from NBINS/10 on in the last bin
+   (the definition behind pinocchio.*.FmaxPDF.out, src/fmax.c:517-525) */
+static int pf_pdf_bin(float F) {
+  const int b = (int)(F * 10.);
+  return b < 0 ? 0 : b >= NBINS ? NBINS - 1 : b;
+}
+
+/* Fmax_PDF (src/fmax.c:509-550): the histogram comes from the device (already summed over the ranks) or, when the products
+   only exist on the host (after read_dumps), from this rank's records; rank 0 writes the reference's ASCII file */
 int Fmax_PDF(void) {
-  unsigned long long counter[NBINS], coll;
-  int i;
+  unsigned long long counter[NBINS];
   if (pf_context) {
-    if (pf_fmax_pdf(pf_context, counter)) return 1; /* already summed over ranks */
-  } else { /* products only on the host (after read_dumps): the reference's own loop */
-    for (i = 0; i < NBINS; i++) counter[i] = 0;
-    for (i = 0; i < (int)MyGrids[0].total_local_size; i++) {
-      int xF = (int)(products[i].Fmax * 10.);
-      if (xF < 0) xF = 0;
-      if (xF >= NBINS) xF = NBINS - 1;
-      counter[xF]++;
-    }
+    if (pf_fmax_pdf(pf_context, counter)) return 1;
+  } else {
+    const product_data *p = products, *end = products + MyGrids[0].total_local_size;
+    memset(counter, 0, sizeof(counter));
+    for (; p != end; p++) counter[pf_pdf_bin(p->Fmax)]++;
 #ifdef PF_IN_PINOCCHIO_TREE
     {
       unsigned long long mine[NBINS];
@@ -450,107 +466,107 @@ int Fmax_PDF(void) {
   }
   if (!ThisTask) {
     char filename[LBLENGTH];
+    unsigned long long collapsed = 0;
     FILE *file;
-    coll = 0;
-    for (i = 10; i < NBINS; i++) coll += counter[i];
-    printf("[%s] Number of collapsed particles to z=0: %llu\n", fdate(), coll);
+    int b;
+    for (b = 10; b < NBINS; b++) collapsed += counter[b]; /* F >= 1: collapsed by z = 0 */
+    printf("[%s] Number of collapsed particles to z=0: %llu\n", fdate(), collapsed);
     sprintf(filename, "pinocchio.%s.FmaxPDF.out", params.RunFlag);
     file = fopen(filename, "w");
     if (!file) { printf("ERROR on task %d: could not open file %s\n", ThisTask, filename); return 1; }
-    fprintf(file, "# Fmax PDF over %llu particles\n", MyGrids[0].Ntotal);
-    fprintf(file, "# 1-2: F interval\n");
-    fprintf(file, "# 3: number of particles in that interval\n");
-    fprintf(file, "#\n");
-    for (i = 0; i < NBINS; i++)
-      fprintf(file, " %6.1f   %6.1f  %llu\n", (double)i / 10., (i == NBINS - 1 ? 999.0 : (double)(i + 1) / 10.), counter[i]);
+    fprintf(file, "# Fmax PDF over %llu particles\n# 1-2: F interval\n# 3: number of particles in that interval\n#\n", MyGrids[0].Ntotal);
+    for (b = 0; b < NBINS; b++)
+      fprintf(file, " %6.1f   %6.1f  %llu\n", (double)b / 10., b + 1 < NBINS ? (double)(b + 1) / 10. : 999.0, counter[b]);
     fclose(file);
   }
   return 0;
 }
 
-/* src/fmax.c:372-426 */
-int dump_products(void) {
-  struct stat dr;
-  FILE *file;
+/* ---- dump / restore of the products (src/fmax.c:372-506): DumpDir/summary (four "%d   # label" lines), DumpDir/TrueVariance
+   (Nsmooth doubles), DumpDir/Task.<rank> (this rank's product_data records); formats as in the reference ---- */
+struct pf_summary_line { const char *label; int value; };
+static int pf_summary_fill(struct pf_summary_line line[4]) {
+  line[0].label = "NTasks";                  line[0].value = NTasks;
+  line[1].label = "random seed";             line[1].value = params.RandomSeed;
+  line[2].label = "grid size";               line[2].value = params.GridSize[0];
+  line[3].label = "length of product_data";  line[3].value = (int)sizeof(product_data);
+  return 4;
+}
+/* what a mismatch of line i is called in the reference's message */
+static const char *const pf_summary_what[4] = {"number of tasks", "random seed", "grid size", "length of product_data"};
+
+/* one binary file of the dump directory, written or read whole; 0 on success */
+static int pf_dump_blob(const char *name, void *data, size_t size, size_t count, int writing, int task_in_message) {
   char fname[LBLENGTH];
-  if (!ThisTask) {
-    if (stat(params.DumpDir, &dr)) {
-      printf("Creating directory %s\n", params.DumpDir);
-      if (mkdir(params.DumpDir, 0755)) {
-        printf("ERROR IN CREATING DIRECTORY %s (task 0)\n", params.DumpDir);
-        return 1;
-      }
-    }
-    sprintf(fname, "%ssummary", params.DumpDir);
-    file = fopen(fname, "w");
-    fprintf(file, "%d   # NTasks\n", NTasks);
-    fprintf(file, "%d   # random seed\n", params.RandomSeed);
-    fprintf(file, "%d   # grid size\n", params.GridSize[0]);
-    fprintf(file, "%d   # length of product_data\n", (int)sizeof(product_data));
-    fclose(file);
-    sprintf(fname, "%sTrueVariance", params.DumpDir);
-    file = fopen(fname, "wb");
-    fwrite(Smoothing.TrueVariance, sizeof(double), Smoothing.Nsmooth, file);
-    fclose(file);
-  }
-#ifdef PF_IN_PINOCCHIO_TREE
-  MPI_Barrier(MPI_COMM_WORLD);
-#endif
-  sprintf(fname, "%sTask.%d", params.DumpDir, ThisTask);
-  file = fopen(fname, "wb");
-  if (file == 0x0) {
-    printf("ERROR on Task %d: could not open file %s\n", ThisTask, fname);
+  FILE *file;
+  size_t done;
+  snprintf(fname, sizeof(fname), "%s%s", params.DumpDir, name);
+  file = fopen(fname, writing ? "wb" : "rb");
+  if (!file) {
+    if (task_in_message) printf("ERROR on Task %d: could not open file %s\n", ThisTask, fname);
+    else printf("ERROR on Task 0: could not open file %s\n", fname);
     return 1;
   }
-  fwrite(products, sizeof(product_data), MyGrids[0].total_local_size, file);
+  done = writing ? fwrite(data, size, count, file) : fread(data, size, count, file);
   fclose(file);
-  return 0;
+  return done != count;
 }
 
-/* src/fmax.c:429-506 */
-int read_dumps(void) {
-  FILE *file;
-  char fname[LBLENGTH], buf[SBLENGTH];
-  int myNTasks, myRandomSeed, myGridSize, myPDlength;
+int dump_products(void) {
+  char name[64];
   if (!ThisTask) {
-    int error = 0;
-    sprintf(fname, "%ssummary", params.DumpDir);
+    struct pf_summary_line line[4];
+    struct stat dr;
+    char fname[LBLENGTH];
+    FILE *file;
+    int i;
+    const int nl = pf_summary_fill(line);
+    if (stat(params.DumpDir, &dr)) {
+      printf("Creating directory %s\n", params.DumpDir);
+      if (mkdir(params.DumpDir, 0755)) { printf("ERROR IN CREATING DIRECTORY %s (task 0)\n", params.DumpDir); return 1; }
+    }
+    snprintf(fname, sizeof(fname), "%ssummary", params.DumpDir);
+    file = fopen(fname, "w");
+    if (!file) { printf("ERROR on Task 0: could not open file %s\n", fname); return 1; }
+    for (i = 0; i < nl; i++) fprintf(file, "%d   # %s\n", line[i].value, line[i].label);
+    fclose(file);
+    if (pf_dump_blob("TrueVariance", Smoothing.TrueVariance, sizeof(double), Smoothing.Nsmooth, 1, 0)) return 1;
+  }
+#ifdef PF_IN_PINOCCHIO_TREE
+  MPI_Barrier(MPI_COMM_WORLD); /* the directory exists before the other ranks write into it */
+#endif
+  snprintf(name, sizeof(name), "Task.%d", ThisTask);
+  return pf_dump_blob(name, products, sizeof(product_data), MyGrids[0].total_local_size, 1, 1);
+}
+
+int read_dumps(void) {
+  char name[64];
+  if (!ThisTask) {
+    struct pf_summary_line line[4];
+    char fname[LBLENGTH], buf[SBLENGTH];
+    FILE *file;
+    int i, mismatches = 0;
+    const int nl = pf_summary_fill(line);
+    snprintf(fname, sizeof(fname), "%ssummary", params.DumpDir);
     file = fopen(fname, "r");
-    if (file == 0x0) {
-      printf("ERROR on Task 0: could not open file %s\n", fname);
-      return 1;
+    if (!file) { printf("ERROR on Task 0: could not open file %s\n", fname); return 1; }
+    for (i = 0; i < nl; i++) {
+      int found = 0;
+      if (!fgets(buf, SBLENGTH, file) || sscanf(buf, "%d", &found) != 1 || found != line[i].value) {
+        /* the run that wrote the dump is named first, this one second */
+        printf("ERROR: the %s in %s does not match - %d vs %d\n", pf_summary_what[i], fname, found, line[i].value);
+        mismatches++;
+      }
     }
-    (void)!fgets(buf, SBLENGTH, file); sscanf(buf, "%d", &myNTasks);
-    (void)!fgets(buf, SBLENGTH, file); sscanf(buf, "%d", &myRandomSeed);
-    (void)!fgets(buf, SBLENGTH, file); sscanf(buf, "%d", &myGridSize);
-    (void)!fgets(buf, SBLENGTH, file); sscanf(buf, "%d", &myPDlength);
     fclose(file);
-    if (NTasks != myNTasks) { printf("ERROR: the number of tasks in %s does not match - %d vs %d\n", fname, myNTasks, NTasks); error++; }
-    if (params.RandomSeed != myRandomSeed) { printf("ERROR: the random seed in %s does not match - %d vs %d\n", fname, myRandomSeed, params.RandomSeed); error++; }
-    if (params.GridSize[0] != myGridSize) { printf("ERROR: the grid size in %s does not match - %d vs %d\n", fname, myGridSize, params.GridSize[0]); error++; }
-    if (myPDlength != (int)sizeof(product_data)) { printf("ERROR: the length of product_data in %s does not match - %d vs %d\n", fname, myPDlength, (int)sizeof(product_data)); error++; }
-    if (error) return 1;
-    sprintf(fname, "%sTrueVariance", params.DumpDir);
-    file = fopen(fname, "rb");
-    if (file == 0x0) {
-      printf("ERROR on Task 0: could not open file %s\n", fname);
-      return 1;
-    }
-    if (fread(Smoothing.TrueVariance, sizeof(double), Smoothing.Nsmooth, file) != (size_t)Smoothing.Nsmooth) return 1;
-    fclose(file);
+    if (mismatches) return 1;
+    if (pf_dump_blob("TrueVariance", Smoothing.TrueVariance, sizeof(double), Smoothing.Nsmooth, 0, 0)) return 1;
   }
 #ifdef PF_IN_PINOCCHIO_TREE
   MPI_Bcast(Smoothing.TrueVariance, Smoothing.Nsmooth, MPI_DOUBLE, 0, MPI_COMM_WORLD);
 #endif
-  sprintf(fname, "%sTask.%d", params.DumpDir, ThisTask);
-  file = fopen(fname, "rb");
-  if (file == 0x0) {
-    printf("ERROR on Task %d: could not open file %s\n", ThisTask, fname);
-    return 1;
-  }
-  if (fread(products, sizeof(product_data), MyGrids[0].total_local_size, file) != MyGrids[0].total_local_size) return 1;
-  fclose(file);
-  return 0;
+  snprintf(name, sizeof(name), "Task.%d", ThisTask);
+  return pf_dump_blob(name, products, sizeof(product_data), MyGrids[0].total_local_size, 0, 1);
 }
 
 /* ------------------------------------------------------------------------------------------------------------

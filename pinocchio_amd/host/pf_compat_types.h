@@ -103,6 +103,7 @@ typedef struct param_data_mirror /* the tags of param_data (:311-352) the path u
   double BoxSize_htrue;
   double OmegaLambda;         /* with Omega0 and Hubble100 in the header of the collapse-time table file */
   char   CTtableFile[400];    /* "none": compute the tables (TABULATED_CT build) */
+  int    use_transposed_fft;  /* UseTransposedFFT: the path keeps k-space in x, y, z order and refuses anything else */
 } param_data;
 
 /* gsl_spline as far as my_spline_eval dereferences it (src/cosmo.c:2016-2027) */

@@ -41,7 +41,13 @@ class Params(C.Structure):
     _fields_ = [("RunFlag", C.c_char * 100), ("DumpDir", C.c_char * 100), ("GridSize", C.c_int * 3), ("RandomSeed", C.c_int),
                 ("Omega0", C.c_double), ("OmegaBaryon", C.c_double), ("Hubble100", C.c_double), ("Sigma8", C.c_double),
                 ("PrimordialIndex", C.c_double), ("BoxSize_htrue", C.c_double), ("OmegaLambda", C.c_double),
-                ("CTtableFile", C.c_char * 400)]
+                ("CTtableFile", C.c_char * 400), ("use_transposed_fft", C.c_int)]
+
+
+def c_output(capfd):
+    """what the C side printed since the last call (its stdio buffer is flushed first)"""
+    C.CDLL(None).fflush(None)
+    return capfd.readouterr().out
 
 
 class Knots(C.Structure):
@@ -73,6 +79,126 @@ def test_reference_symbols_and_geometry(lib):
     assert grid.norm == 1.0 / n ** 3 and grid.CellSize == 2.0
     lib.fdate.restype = C.c_char_p
     assert len(lib.fdate()) == 24
+
+
+def test_fdate_is_the_references_rearranged_ctime(lib):
+    """src/fmax.c:261-289: characters 0-9 of ctime(), then its year, then its time of day"""
+    import time
+    lib.fdate.restype = C.c_char_p
+    libc = C.CDLL(None)
+    libc.ctime.restype = C.c_char_p
+    for _ in range(3):
+        t0 = int(time.time())
+        got = lib.fdate().decode()
+        t1 = int(time.time())
+        want = []
+        for t in range(t0, t1 + 1):
+            s = libc.ctime(C.byref(C.c_long(t))).decode()          # "Www Mmm dd hh:mm:ss yyyy\n"
+            want.append(s[:10] + s[19:24] + s[10:19])
+        assert got in want, (got, want)
+
+
+def test_geometry_refuses_what_the_path_does_not_do(lib, capfd):
+    """ragged slabs, non-cubic grids and UseTransposedFFT (src/fmax-pfft.c:92, 271-281) fail loudly, in the reference's format"""
+    grid = C.cast(C.c_void_p.in_dll(lib, "MyGrids"), C.POINTER(Grid)).contents
+    par = Params.in_dll(lib, "params")
+    ntasks = C.c_int.in_dll(lib, "NTasks")
+    n = 64
+    for i in range(3):
+        grid.GSglobal[i] = n
+    grid.Ntotal = n ** 3
+    grid.BoxSize = 128.0
+    try:
+        par.use_transposed_fft = 1
+        assert lib.set_one_grid(0) == 1
+        assert "ERROR on task 0: UseTransposedFFT" in c_output(capfd)
+        par.use_transposed_fft = 0
+        ntasks.value = 3
+        assert lib.set_one_grid(0) == 1
+        assert "ERROR on task 0: NTasks=3 must divide GridSize=64" in c_output(capfd)
+        ntasks.value = 1
+        grid.GSglobal[1] = 32
+        assert lib.set_one_grid(0) == 1
+        assert "ERROR on task 0" in c_output(capfd)
+    finally:
+        par.use_transposed_fft = 0
+        ntasks.value = 1
+        grid.GSglobal[1] = n
+    assert lib.set_one_grid(0) == 0
+
+
+def test_dump_and_read_products_round_trip_and_formats(lib, tmp_path, capfd):
+    """dump_products / read_dumps (src/fmax.c:372-506) need no device: byte formats of the three files, the round trip, and
+    the reference's messages when the dump belongs to another run"""
+    n = 8
+    grid = C.cast(C.c_void_p.in_dll(lib, "MyGrids"), C.POINTER(Grid)).contents
+    for i in range(3):
+        grid.GSglobal[i] = n
+    grid.Ntotal = n ** 3
+    grid.BoxSize = 16.0
+    assert lib.set_one_grid(0) == 0
+    par = Params.in_dll(lib, "params")
+    par.DumpDir = (str(tmp_path) + "/dump/").encode()
+    par.RandomSeed = 486604
+    for i in range(3):
+        par.GridSize[i] = n
+    rng = np.random.default_rng(1)
+    raw = np.zeros(n ** 3 * 56 + 64, dtype=np.uint8)
+    prod = raw[(-raw.ctypes.data) % 32:][:n ** 3 * 56]
+    prod[:] = rng.integers(0, 256, prod.size, dtype=np.uint8)
+    C.c_void_p.in_dll(lib, "products").value = prod.ctypes.data
+    sm = Smoothing.in_dll(lib, "Smoothing")
+    tv = np.array([0.25, 1.5, 6.25])
+    sm.Nsmooth = 3
+    sm.TrueVariance = tv.ctypes.data_as(C.POINTER(C.c_double))
+    assert lib.dump_products() == 0
+    d = tmp_path / "dump"
+    assert (d / "summary").read_text() == "1   # NTasks\n486604   # random seed\n8   # grid size\n56   # length of product_data\n"
+    assert (d / "TrueVariance").read_bytes() == tv.tobytes()
+    assert (d / "Task.0").read_bytes() == prod.tobytes()
+    want = prod.copy()
+    prod[:] = 0
+    tv[:] = 0
+    assert lib.read_dumps() == 0
+    assert np.array_equal(prod, want) and list(tv) == [0.25, 1.5, 6.25]
+    c_output(capfd)
+    par.RandomSeed = 7
+    assert lib.read_dumps() == 1
+    out = c_output(capfd)
+    assert "ERROR: the random seed in %ssummary does not match - 486604 vs 7" % par.DumpDir.decode() in out
+    par.RandomSeed = 486604
+    # Fmax_PDF from host products only (no device context): the reference's own loop and file
+    rec = np.frombuffer(prod, dtype=np.dtype([("Rmax", "<i4"), ("Fmax", "<f4"), ("rest", "V48")]))
+    fm = rng.uniform(-11.0, 25.0, n ** 3).astype(np.float32)
+    np.frombuffer(prod, dtype=np.uint8).reshape(-1, 56)[:, 4:8] = fm.view(np.uint8).reshape(-1, 4)
+    par.RunFlag = b"hostpdf"
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        assert lib.Fmax_PDF() == 0
+        lines = open("pinocchio.hostpdf.FmaxPDF.out").read().splitlines()
+    finally:
+        os.chdir(cwd)
+    assert lines[0] == "# Fmax PDF over %d particles" % n ** 3 and lines[1:4] == ["# 1-2: F interval", "# 3: number of particles in that interval", "#"]
+    bins = np.clip((fm.astype(np.float32) * np.float64(10.0)).astype(np.int64), 0, 209)  # (int)(float * 10.) in double, truncation
+    counts = np.bincount(bins, minlength=210)
+    assert len(lines) == 4 + 210
+    for b in (0, 1, 57, 208, 209):
+        assert lines[4 + b] == " %6.1f   %6.1f  %d" % (b / 10.0, 999.0 if b == 209 else (b + 1) / 10.0, counts[b])
+    assert rec.shape == (n ** 3,)
+
+
+@pytest.mark.parametrize("flags", [[], ["-DSCALE_DEPENDENT"], ["-DTABULATED_CT"], ["-DTABULATED_CT", "-DELL_SNG"],
+                                   ["-DTABULATED_CT", "-DELL_SNG", "-DMOD_GRAV_FR", "-DFR0=1e-5"],
+                                   ["-DRECOMPUTE_DISPLACEMENTS", "-DSCALE_DEPENDENT"]])
+def test_in_tree_build_of_the_adapter_type_checks(flags):
+    """INTEGRATION.md's recipe compiles pf_compat.c with -DPF_IN_PINOCCHIO_TREE against the reference's pinocchio.h; MPI, GSL
+    and PFFT are not in this image, so the #ifdef branches are type-checked (-fsyntax-only) against declaration-only
+    headers (tests/intree_decls/: test infrastructure, no definitions, pins nothing)"""
+    cmd = ["gcc", "-std=gnu99", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter", "-DPF_IN_PINOCCHIO_TREE", *flags,
+           "-I" + os.path.join(ROOT, "tests", "intree_decls"), os.path.join(ROOT, "pinocchio_amd", "host", "pf_compat.c")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
 
 
 @pytest.mark.gpu

@@ -17,11 +17,13 @@ def run_ranks_timed(api, n, P, body, field_bytes=8):
     return run_ranks(api, n, P, body, field_bytes, timing=True)
 
 
-def run_ranks(api, n, P, body, field_bytes=8, timing=False):
+def run_ranks(api, n, P, body, field_bytes=8, timing=False, delay_us=0):
     from pinocchio_amd import _lib
     L = _lib.load()
     fab = L.pf_fabric_create(P)
     assert fab
+    if delay_us:
+        assert L.pf_fabric_set_delay(fab, delay_us) == 0
     ctxs = [api.Fmax(n, rank=r, nranks=P, field_bytes=field_bytes, timing=timing) for r in range(P)]
     for c in ctxs:
         assert L.pf_fabric_attach(fab, c.h) == 0
@@ -373,3 +375,67 @@ def test_band_limited_radii_exchange_only_their_rows(api, P, pipeline, monkeypat
                 assert np.array_equal(p[name], p1[name][sl]), (rows, name)
     sent = {rows: sum(o[2] for o in out[rows]) for rows in ("1", "0")}
     assert 0.0 < sent["1"] < 0.8 * sent["0"], sent      # 4 of 6 radii keep 39-95 % of their rows and 41-97 % of their columns, LPT exchanges whole
+
+
+@pytest.mark.parametrize("P,delay_us,fb", [(2, 4000, 8), (4, 2000, 8), (8, 1000, 8), (4, 2000, 4)])
+def test_pipelined_exchange_with_late_communication(api, P, delay_us, fb):
+    """The fabric's all-to-all is asynchronous on the device (events, no stream synchronisation), so the exchange of
+    transform i+1 really runs on the communication stream beside the y/z passes and the solve of transform i.  Here every
+    exchange first idles its stream for milliseconds -- longer than all the kernels of a radius at this size -- so the
+    compute stream runs far ahead: whatever the pipeline of pf_api.hip fails to wait for (receive set not yet filled,
+    send set overwritten before it was pulled, receive set overwritten while the y-pass still reads it) changes the
+    results, which must stay bitwise those of one rank.  Sweep (3 fields per item, band-limited and full radii, odd count)
+    and the displacement pipelines (2 fields, 1 field per item)."""
+    n = 64
+    nxl = n // P
+    dk = synth.make_density(n, seed=29)
+    radii = np.array([8.0, 4.0, 3.2, 1.0, 0.0])
+    x, y = synth.invgrow_table("lcdm")
+    g = synth.growth_multipliers()
+
+    def body(f, r):
+        f.set_density(dk[r * nxl:(r + 1) * nxl])
+        f.set_invgrow(x, y); f.set_growth(g)
+        tv = f.compute_fmax(radii, do_lpt=True)
+        tv2 = f.compute_fmax(radii[1:], do_lpt=True)       # a second run: buffer sets start from the other parity
+        return tv, tv2, f.products()
+
+    with api.Fmax(n, field_bytes=fb) as f1:
+        f1.set_density(dk); f1.set_invgrow(x, y); f1.set_growth(g)
+        tv1 = f1.compute_fmax(radii, do_lpt=True)
+        tv1b = f1.compute_fmax(radii[1:], do_lpt=True)
+        p1 = f1.products()
+    res = run_ranks(api, n, P, body, field_bytes=fb, delay_us=delay_us)
+    for r in range(P):
+        tv, tv2, p = res[r]
+        sl = slice(r * nxl, (r + 1) * nxl)
+        assert np.allclose(tv, tv1, rtol=1e-13) and np.allclose(tv2, tv1b, rtol=1e-13)
+        for name in ("Fmax", "Rmax", "Vel", "Vel_2LPT", "Vel_3LPT_1"):
+            assert np.array_equal(p[name], p1[name][sl]), (r, name)
+        a, b = p["Vel_3LPT_2"].astype(np.float64), p1["Vel_3LPT_2"][sl].astype(np.float64)
+        assert np.max(np.abs(a - b)) <= 2e-7 * np.max(np.abs(b))
+
+
+@pytest.mark.parametrize("fault", ["recv", "send"])
+def test_late_communication_exposes_a_missing_wait(api, fault, monkeypatch):
+    """the same set-up with one wait of the pipeline taken out on purpose (PF_DEBUG_PIPELINE_FAULT, read in pf_create): the
+    results must change -- the test above can see what it is there to see"""
+    n, P = 64, 4
+    nxl = n // P
+    dk = synth.make_density(n, seed=29)
+    radii = np.array([8.0, 4.0, 3.2, 1.0, 0.0])
+    x, y = synth.invgrow_table("lcdm")
+
+    def body(f, r):
+        f.set_density(dk[r * nxl:(r + 1) * nxl])
+        f.set_invgrow(x, y)
+        f.sweep(radii)
+        return f.products()["Fmax"]
+
+    with api.Fmax(n) as f1:
+        f1.set_density(dk); f1.set_invgrow(x, y)
+        f1.sweep(radii)
+        fm1 = f1.products()["Fmax"]
+    monkeypatch.setenv("PF_DEBUG_PIPELINE_FAULT", fault)
+    res = run_ranks(api, n, P, body, delay_us=2000)
+    assert any(not np.array_equal(res[r], fm1[r * nxl:(r + 1) * nxl]) for r in range(P))
