@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(PKG, "libpinfmax_hip.so")
+# PINFMAX_LIB: another build of the same library (A/B measurements of a kernel variant, csrc/Makefile VARIANT=...)
+SO = os.environ.get("PINFMAX_LIB") or os.path.join(PKG, "libpinfmax_hip.so")
 NBINS = 210
 MAX_SMOOTH = 64
 
