@@ -12,11 +12,23 @@ times each) then pf_displacements (2LPT/3LPT sources + 12 displacement fields).
 Workload at every N: the 1024^3 fp64 box the metric is quoted on (fits one
 GPU: ~226 GB), sharded in x-slabs over the ranks -> strong scaling.  Rank 0
 prints ONE JSON line.
+
+What the line carries beyond the contract fields:
+  roofline           the dominant kernel BY SYMBOL (what `rocprofv3 --stats` lists first): all launch classes that run the
+                     same kernel function are summed; achieved = algorithmic bytes / HIP-event time of those launches
+  roofline_by_class  the same for the single most expensive launch class (the fp64-VALU-bound collapse solve, whose byte
+                     rate is a consequence, with its issue-side counters)
+  path_roofline      whole step: the survey's contract bytes (6600 B per cell) AND the bytes this design really moves
+  kernels            per launch class: launches, ms per step, algorithmic GB/s, symbol
+  exchange           (N > 1) kind negotiated, bytes per step per rank, time on the communication stream
+  exact_libm         (N = 1) step time with PF_EXACT_LIBM=1 (the reference's own libm calls in the solve), informational
+  cpu_baseline       (N = 1) the CPU oracle on all host threads, on a bounded sample of the workload
+Counter-derived fields (`traffic`, `valu`) come from committed rocprofv3 passes (profiles/r02_*.json) and are emitted only
+when those passes were made on the very kernel sources this run loads (hash of pinocchio_amd/csrc); otherwise null.
 """
 from __future__ import annotations
 
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -27,14 +39,45 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-from pinocchio_amd import api, synth  # noqa: E402
+from pinocchio_amd import _lib, api, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+PROFILE_ROUND = "r02"
 
 
 def alg_bytes_per_cell(ns: int, w: int, lpt: bool) -> float:
     """SURVEY.md section 8d contract figure: Ns*(49W+16) + 207W + 48"""
     return ns * (49 * w + 16) + ((207 * w + 48) if lpt else 0)
+
+
+def symbol_of(cls: str, n: int, fb: int, fast: bool = True) -> str:
+    """kernel function behind a launch class, spelled as rocprofv3 prints it (csrc/pf_fft_kernels.hip dispatch tables)"""
+    F = "double" if fb == 8 else "float"
+    t = max(1, min(128 // (2 * fb), (64 * 1024) // (n * 2 * fb), 8192 // n))      # PfTileCols
+    nt = n // 16
+    tl = 1 if nt >= 256 else 256 // nt
+    b = "true" if fast else "false"
+    if cls in ("xpass_hess_1to3", "ypass_hess_3to6", "xpass_disp_1to2", "ypass_disp_2to3", "xpass_plain", "ypass_plain"):
+        return f"k_strided<{F}, {n}, {t}, 1>"
+    if cls in ("xpass_fwd", "ypass_fwd"):
+        return f"k_strided<{F}, {n}, {t}, -1>"
+    if cls in ("zpass_c2r_hess_6", "zpass_c2r_disp_3", "zpass_c2r_plain"):
+        return f"k_c2r_persistent<{F}, {n}, {tl}>"
+    return {"zpass_c2r_hess_6to3inv": f"k_c2r_invariants<{n}, 0>", "zpass_c2r_hess_6_lpt3b": f"k_c2r_invariants<{n}, 1>",
+            "collapse": f"k_collapse<{F}, {b}>", "collapse_inv": f"k_collapse_inv<{b}>", "lpt_sources": f"k_lpt_sources<{F}>",
+            "lpt_accum": f"k_lpt_accum<{F}>", "zpass_r2c": f"k_r2c<{F}, {n}, {tl}>"}.get(cls, cls)
+
+
+def committed_counters(kind: str, n: int, fb: int):
+    """profiles/r02_pmc_<kind>.json if it was measured on the kernel sources loaded now, else None"""
+    try:
+        with open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_{kind}.json")) as fh:
+            d = json.load(fh)
+        if d.get("kernel_source_sha") == _lib.source_sha() and d.get("config") == {"grid": n, "field_bytes": fb}:
+            return d
+    except (OSError, ValueError):
+        pass
+    return None
 
 
 def cpu_baseline(n: int, ns: int, lpt: bool) -> dict:
@@ -44,7 +87,7 @@ def cpu_baseline(n: int, ns: int, lpt: bool) -> dict:
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)  # the slab loops of an n=256 grid do not scale past ~n/4 threads
+    threads = max(1, min(cores, n // 2))  # all hardware threads; the slab loops have n iterations
     dk = synth.philox_density(n, synth.SEED, 2.5, -2.0)
     x, y = synth.invgrow_table("lcdm")
     o = oracle_lib.Oracle(n, threads)
@@ -58,7 +101,7 @@ def cpu_baseline(n: int, ns: int, lpt: bool) -> dict:
     tm = o.timers()
     return {"value": n ** 3 / dt, "unit": "grid-cells/s", "cores": threads, "kind": "port",
             "sample": f"{n}^3 box, {ns} radii{' + 3LPT' if lpt else ''}, same synthetic spectrum, {dt:.2f} s "
-                      f"(fft {tm['fft']:.2f} s, collapse {tm['coll']:.2f} s, lpt {tm['lpt']:.2f} s); host has {cores} hardware threads"}
+                      f"(fft {tm['fft']:.2f} s, collapse {tm['coll']:.2f} s, lpt {tm['lpt']:.2f} s); host has {cores} hardware threads, {threads} used"}
 
 
 def main():
@@ -70,7 +113,8 @@ def main():
     ap.add_argument("--ns", type=int, default=12, help="number of smoothing radii")
     ap.add_argument("--field-bytes", type=int, default=8, choices=(4, 8))
     ap.add_argument("--no-lpt", action="store_true", help="Fmax-only (BASELINE config 2)")
-    ap.add_argument("--cpu-n", type=int, default=256, help="grid side of the CPU-baseline sample (0: skip)")
+    ap.add_argument("--cpu-n", type=int, default=512, help="grid side of the CPU-baseline sample (0: skip)")
+    ap.add_argument("--exact-steps", type=int, default=1, help="steps of the PF_EXACT_LIBM=1 informational run (0: skip)")
     ap.add_argument("--exchange", default="rccl", choices=("rccl", "torch"))
     args = ap.parse_args()
 
@@ -91,27 +135,22 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     f = api.Fmax(n, rank=rank, nranks=world, device=local_rank, field_bytes=args.field_bytes, timing=True)
-    keep = []
+    keep = None
     exchange_kind = None
     if world > 1:
         from pinocchio_amd import dist as pfdist
-        # built-in RCCL exchange first; if it cannot be set up or fails its self-test on this node, the same
-        # collectives go through torch.distributed (also RCCL) on tensors aliasing the library's buffers
-        kinds = [args.exchange] + [k for k in ("rccl", "torch") if k != args.exchange]
-        for kind in kinds:
-            ok = 1
-            try:
-                keep.append(pfdist.install_exchange(f, dist, torch, kind=kind))
-                ok = f.L.pf_debug_exchange(f.h, 1 << 20)
-            except Exception as e:  # noqa: BLE001
-                print(f"[rank {rank}] exchange '{kind}' unavailable: {e}", file=sys.stderr, flush=True)
-            t = torch.tensor([ok], dtype=torch.int32, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            if int(t.item()) == 0:
-                exchange_kind = kind
-                break
-        if exchange_kind is None:
-            raise SystemExit("no working multi-GPU exchange")
+        # built-in RCCL exchange first; if some rank cannot bind it, set it up or pass its self-test, the same collectives go
+        # through torch.distributed (also RCCL) on tensors aliasing the library's buffers.  Collective and vote-guarded: no
+        # rank is left inside a communicator set-up (pinocchio_amd/dist.py).  A failure here exits non-zero; nothing re-execs.
+        try:
+            exchange_kind, keep = pfdist.negotiate_exchange(f, dist, torch, preferred=args.exchange, device="cuda")
+        except RuntimeError as e:
+            print(f"[rank {rank}] {e}", file=sys.stderr, flush=True)
+            f.close()
+            dist.destroy_process_group()
+            raise SystemExit(3)
+        if rank == 0:
+            print(f"[bench] {world} ranks, all-to-all via '{exchange_kind}'", file=sys.stderr, flush=True)
 
     f.synth_density(synth.SEED, 2.5, -2.0)
     x, y = synth.invgrow_table("lcdm")
@@ -119,14 +158,14 @@ def main():
     f.set_growth(synth.growth_multipliers())
     radii = synth.radii_ladder(ns)
 
-    def step():
-        tv = f.sweep(radii)
+    def step(ctx):
+        tv = ctx.sweep(radii)
         if lpt:
-            f.compute_displacements(1, 0)
+            ctx.compute_displacements(1, 0)
         return tv
 
-    def fence():
-        f.synchronize()
+    def fence(ctx):
+        ctx.synchronize()
         if world > 1:
             torch.cuda.synchronize()
             dist.barrier()
@@ -134,14 +173,14 @@ def main():
 
     tv = None
     for _ in range(args.warmup):
-        tv = step()
+        tv = step(f)
     f.reset_kernel_stats()
     f.reset_cputime()
-    fence()
+    fence(f)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        tv = step()
-    fence()
+        tv = step(f)
+    fence(f)
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -149,34 +188,72 @@ def main():
         dt = float(t.item())
     stats = f.kernel_stats()
     cput = f.cputime()
+    device_gb = f.device_bytes / 1e9
+    reruns = f.L.pf_debug_invariant_reruns(f.h)
+    f.close()
+    del keep
+
+    exact = None
+    if world == 1 and args.exact_steps > 0:
+        # the same step with the reference's own libm calls in the solve (bit-comparable with the CPU): what the default
+        # arithmetic (series forms, hardware-seeded division: each within ~1 ulp of those calls) buys
+        os.environ["PF_EXACT_LIBM"] = "1"
+        try:
+            with api.Fmax(n, field_bytes=args.field_bytes) as fx:
+                fx.synth_density(synth.SEED, 2.5, -2.0)
+                fx.set_invgrow(x, y)
+                fx.set_growth(synth.growth_multipliers())
+                step(fx)
+                fx.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.exact_steps):
+                    step(fx)
+                fx.synchronize()
+                exact = {"ms_per_step": 1e3 * (time.perf_counter() - t1) / args.exact_steps, "steps": args.exact_steps,
+                         "note": "PF_EXACT_LIBM=1: cos x3, pow, pow, log10, acos, exp and IEEE division / sqrt as the reference calls them"}
+        finally:
+            del os.environ["PF_EXACT_LIBM"]
 
     if rank == 0:
         ms = 1e3 * dt / args.steps
         cells = float(n) ** 3
         value = cells * args.steps / dt
-        dom = max((s for s in stats if s["name"] != "exchange"), key=lambda s: s["total_ms"])
-        ach = dom["alg_bytes"] / (dom["total_ms"] * 1e-3) / 1e9
-        traffic = None  # HBM bytes per launch from the PMC counters (rocprofv3 passes, profiles/*_pmc_traffic.json)
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-                pmc = json.load(fh)
-            if pmc["config"] == {"grid": n, "field_bytes": args.field_bytes} and dom["name"] in pmc["kernels"]:
-                k = pmc["kernels"][dom["name"]]
-                traffic = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
-        valu = None  # issue-side view of a VALU-bound dominant kernel, from the committed counter passes
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_valu.json")) as fh:
-                pv = json.load(fh)
-            if pv["config"] == {"grid": n, "field_bytes": args.field_bytes} and dom["name"] in pv["kernels"]:
-                k = pv["kernels"][dom["name"]]
-                valu = {"insts_per_cell": k["valu_insts_per_cell"], "valu_utilisation": k["valu_utilisation"],
-                        "engine_clock_GHz": k.get("engine_clock_GHz_measured"), "valu_utilisation_at_measured_clock": k.get("valu_utilisation_at_measured_clock"),
-                        "source": "profiles/r01_pmc_valu.json"}
-        except (OSError, KeyError, ValueError):
-            pass
         w = args.field_bytes
+        kern = [s for s in stats if s["name"] != "exchange"]
+        for s in kern:
+            s["symbol"] = symbol_of(s["name"], n, w)
+
+        def roof(group, label):
+            tms = sum(s["total_ms"] for s in group)
+            byt = sum(s["alg_bytes"] for s in group)
+            nl = sum(s["launches"] for s in group)
+            ach = byt / (tms * 1e-3) / 1e9
+            return {"bound": "hbm", "kernel": label, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": None, "launches": nl, "avg_ms": tms / nl, "alg_bytes_per_launch": byt / nl,
+                    "ms_per_step": tms / args.steps, "share_of_gpu_time": tms / sum(s["total_ms"] for s in kern),
+                    "classes": [s["name"] for s in group]}
+
+        by_symbol = {}
+        for s in kern:
+            by_symbol.setdefault(s["symbol"], []).append(s)
+        dom_sym = max(by_symbol, key=lambda k: sum(s["total_ms"] for s in by_symbol[k]))
+        roofline = roof(by_symbol[dom_sym], dom_sym)
+        dom_cls = max(kern, key=lambda s: s["total_ms"])
+        roofline_cls = roof([dom_cls], dom_cls["symbol"])
+        roofline_cls["class"] = dom_cls["name"]
+        # HBM bytes per launch from the PMC counters of the same command (profiles/tools/collect.sh), only if measured on these sources
+        pmc = committed_counters("traffic", n, w)
+        for r in (roofline, roofline_cls):
+            if pmc and r["kernel"] in pmc["kernels"]:
+                k = pmc["kernels"][r["kernel"]]
+                r["traffic"] = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
+                r["traffic_source"] = f"profiles/{PROFILE_ROUND}_pmc_traffic.json"
+        pv = committed_counters("valu", n, w)
+        if pv and roofline_cls["kernel"] in pv["kernels"]:
+            roofline_cls["valu"] = dict(pv["kernels"][roofline_cls["kernel"]], source=f"profiles/{PROFILE_ROUND}_pmc_valu.json")
+        if dom_cls["name"].startswith("collapse"):
+            roofline_cls["note"] = "the collapse solve is fp64-VALU bound; its HBM stream is a consequence, see DESIGN.md section 6"
+        design_bytes = sum(s["alg_bytes"] for s in kern) / args.steps
         out = {
             "metric": "grid-cells/sec for full Fmax sweep (all smoothing radii) + 3LPT, 1024^3 box"
                       if (n == 1024 and lpt) else f"grid-cells/sec, Fmax sweep{' + 3LPT' if lpt else ''}, {n}^3 box",
@@ -186,22 +263,33 @@ def main():
             "config": {"workload": f"{n}^3 box, {ns} smoothing radii, Fmax sweep{' + 2LPT/3LPT displacements' if lpt else ' only'}, "
                                    f"{'fp64' if w == 8 else 'fp32-field'} path, Philox white noise with P(k)~k^-2, sigma(R=0)=2.5",
                        "grid": n, "nsmooth": ns, "lpt": lpt, "parallelism": f"x-slabs over {world} GPU(s)" + (f", all-to-all via {exchange_kind}" if exchange_kind else ""),
-                       "device_GB": f.device_bytes / 1e9, "sigma_R0": float(np.sqrt(tv[-1]))},
-            "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "note": "the collapse solve is fp64-VALU bound (~480 instructions per cell from the invariants, ~570 from six components); its HBM stream is a consequence, see DESIGN.md section 6",
-                         "valu": valu, "launches": dom["launches"], "avg_ms": dom["total_ms"] / dom["launches"],
-                         "alg_bytes_per_launch": dom["alg_bytes"] / dom["launches"]},
+                       "device_GB": device_gb, "sigma_R0": float(np.sqrt(tv[-1])), "kernel_source_sha": _lib.source_sha(),
+                       "invariant_reruns": reruns},
+            "roofline": roofline,
+            "roofline_by_class": roofline_cls,
             "path_roofline": {"contract_bytes_per_cell": alg_bytes_per_cell(ns, w, lpt),
-                              "frac_of_hbm_peak": alg_bytes_per_cell(ns, w, lpt) * cells / (ms * 1e-3) / world / (HBM_PEAK_GBS * 1e9)},
-            "kernels": [{"name": s["name"], "launches": s["launches"], "ms_per_step": s["total_ms"] / args.steps,
-                         "GBps": s["alg_bytes"] / max(s["total_ms"], 1e-9) / 1e6} for s in stats],
+                              "frac_of_hbm_peak_contract": alg_bytes_per_cell(ns, w, lpt) * cells / (ms * 1e-3) / world / (HBM_PEAK_GBS * 1e9),
+                              "design_bytes_per_step_per_gpu": design_bytes,
+                              "design_bytes_per_cell": design_bytes * world / cells,
+                              "frac_of_hbm_peak_design": design_bytes / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9),
+                              "note": "contract: the survey's 6600 B per cell for the reference's structure; design: the bytes the shared-pass kernels really move (sum of the per-launch algorithmic bytes)"},
+            "kernels": [{"name": s["name"], "symbol": s["symbol"], "launches": s["launches"], "ms_per_step": s["total_ms"] / args.steps,
+                         "GBps": s["alg_bytes"] / max(s["total_ms"], 1e-9) / 1e6} for s in kern],
             "phases_s_per_step": {k: v / args.steps for k, v in cput.items()},
         }
+        ex = [s for s in stats if s["name"] == "exchange"]
+        if world > 1:
+            e = ex[0] if ex else {"launches": 0, "total_ms": 0.0, "alg_bytes": 0.0}
+            out["exchange"] = {"kind": exchange_kind, "calls_per_step": e["launches"] / args.steps, "GB_per_step_per_rank": e["alg_bytes"] / args.steps / 1e9,
+                               "ms_per_step_on_comm_stream": e["total_ms"] / args.steps,
+                               "GBps_per_rank": e["alg_bytes"] / max(e["total_ms"], 1e-9) / 1e6,
+                               "compute_ms_per_step": sum(s["total_ms"] for s in kern) / args.steps,
+                               "note": "rank 0's HIP events around its all-to-alls on the communication stream; they run beside the compute stream (DESIGN.md section 5): step time well below compute + exchange means the overlap works"}
+        if exact:
+            out["exact_libm"] = exact
         if world == 1 and args.cpu_n:
             out["cpu_baseline"] = cpu_baseline(args.cpu_n, ns, lpt)
         print(json.dumps(out))
-    f.close()
     if world > 1:
         dist.destroy_process_group()
 

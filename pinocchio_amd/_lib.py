@@ -112,6 +112,20 @@ PROTOTYPES = {
 _lib = None
 
 
+def source_sha() -> str:
+    """16 hex digits identifying the kernel sources next to this file (csrc/*.hip, *.h, *.cpp): stamps counter profiles, so
+    that numbers measured on other kernels are never attached to a run (bench.py, profiles/tools/summarise.py)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip")) + glob.glob(os.path.join(PKG, "csrc", "*.h")) +
+                       glob.glob(os.path.join(PKG, "csrc", "*.cpp"))):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def load():
     """Load the HIP library; raises (never falls back) when it is missing."""
     global _lib

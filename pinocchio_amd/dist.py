@@ -1,19 +1,23 @@
-"""Multi-GPU plumbing for a Python host harness (bench.py): installs the slab
-all-to-all and the small all-reduces of one rank's context.
+"""Multi-GPU plumbing for a Python host harness (bench.py): chooses and installs the slab all-to-all and the small
+all-reduces of one rank's context.
 
-kind="rccl":  the library's own exchange (csrc/pf_rccl.cpp: grouped
-              ncclSend/ncclRecv over xGMI); torch.distributed only broadcasts
-              the 128-byte ncclUniqueId.
-kind="torch": every exchange is a torch.distributed all_to_all_single (all_to_all with
-              per-sender sizes for the row-range form of the band-limited radii) on
-              tensors that alias the library's device buffers (backend "nccl"
-              = RCCL on ROCm), enqueued on the library's stream.
+kind="rccl":  the library's own exchange (csrc/pf_rccl.cpp: grouped ncclSend/ncclRecv over xGMI); torch.distributed only
+              broadcasts the 128-byte ncclUniqueId.
+kind="torch": every exchange is a torch.distributed all_to_all_single (all_to_all with per-sender sizes for the row-range
+              form of the band-limited radii) on tensors that alias the library's device buffers (backend "nccl" = RCCL
+              on ROCm), enqueued on the library's stream.
+
+`negotiate_exchange` is collective and cannot hang on a one-sided failure: before any rank enters a communicator set-up
+or a data collective of a kind, ALL ranks vote on a purely local check; after each collective step they vote on its
+outcome; a kind that loses a vote is released everywhere (communicator destroyed) before the next one is tried.  The
+votes themselves go through the process group that brought the ranks up (it works, or the job would not have started).
 
 PyTorch is plumbing here (process group, streams), not the compute path.
 """
 from __future__ import annotations
 
 import ctypes as C
+import sys
 
 from . import _lib
 
@@ -26,65 +30,152 @@ class _DevMem:
                                          "version": 3}
 
 
-def install_exchange(f, dist, torch, kind: str = "rccl"):
-    """f: api.Fmax.  Returns an object that must be kept alive as long as f is used."""
-    L = f.L
-    if kind == "rccl":
+def _vote(dist, torch, ok: bool, device) -> bool:
+    """True only if every rank says ok"""
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
+class RcclKind:
+    """the library's built-in exchange"""
+    name = "rccl"
+
+    def __init__(self, f, dist, torch, device):
+        self.f, self.dist, self.torch, self.device = f, dist, torch, device
+        self.keep = None
+
+    def can_bind(self) -> bool:  # host side only: dlopen + symbols
+        return bool(self.f.L.pf_rccl_available())
+
+    def setup(self) -> bool:
+        L, dist, torch = self.f.L, self.dist, self.torch
         idbuf = (C.c_ubyte * 128)()
+        have_id = True
         if dist.get_rank() == 0:
-            f._chk(L.pf_rccl_unique_id(C.cast(idbuf, C.c_void_p)))
-        t = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8, device="cuda")
+            have_id = L.pf_rccl_unique_id(C.cast(idbuf, C.c_void_p)) == 0
+        # every rank learns whether rank 0 has an id BEFORE anybody calls ncclCommInitRank
+        if not _vote(dist, torch, have_id, self.device):
+            return False
+        t = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8, device=self.device)
         dist.broadcast(t, src=0)
-        raw = bytes(t.cpu().tolist())
-        idbuf = (C.c_ubyte * 128).from_buffer_copy(raw)
-        f._chk(L.pf_init_rccl(f.h, C.cast(idbuf, C.c_void_p)))
-        return idbuf
+        idbuf = (C.c_ubyte * 128).from_buffer_copy(bytes(t.cpu().tolist()))
+        self.keep = idbuf
+        return L.pf_init_rccl(self.f.h, C.cast(idbuf, C.c_void_p)) == 0
 
-    world = dist.get_world_size()
+    def release(self):
+        self.f.L.pf_release_rccl(self.f.h)
+        self.keep = None
 
-    def _a2a(user, send, recv, bytes_per_peer, stream):
+
+class TorchKind:
+    """torch.distributed collectives on tensors aliasing the library's buffers"""
+    name = "torch"
+
+    def __init__(self, f, dist, torch, device):
+        self.f, self.dist, self.torch, self.device = f, dist, torch, device
+        self.keep = None
+
+    def can_bind(self) -> bool:
+        return True
+
+    def setup(self) -> bool:
+        f, dist, torch = self.f, self.dist, self.torch
+        world = dist.get_world_size()
+
+        def _a2a(user, send, recv, bytes_per_peer, stream):
+            try:
+                nbytes = bytes_per_peer * world
+                s = torch.as_tensor(_DevMem(send, nbytes), device="cuda")
+                r = torch.as_tensor(_DevMem(recv, nbytes), device="cuda")
+                with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+                    dist.all_to_all_single(r, s)
+                return 0
+            except Exception as e:  # noqa: BLE001 -- surfaces as "all-to-all failed" in the library
+                print("exchange callback failed:", e, flush=True)
+                return 1
+
+        def _a2av(user, send, recv, block_bytes, send_off, send_bytes, recv_off, recv_bytes, stream):
+            # row-range form (band-limited radii): per-sender sizes, empty messages allowed
+            try:
+                s = torch.as_tensor(_DevMem(send, block_bytes * world), device="cuda")
+                r = torch.as_tensor(_DevMem(recv, block_bytes * world), device="cuda")
+                ins = [s[q * block_bytes + send_off:q * block_bytes + send_off + send_bytes] for q in range(world)]
+                outs = [r[p * block_bytes + recv_off[p]:p * block_bytes + recv_off[p] + recv_bytes[p]] for p in range(world)]
+                with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+                    dist.all_to_all(outs, ins)
+                return 0
+            except Exception as e:  # noqa: BLE001
+                print("row-range exchange callback failed:", e, flush=True)
+                return 1
+
+        def _ared(user, buf, count, is_u64, stream):
+            try:
+                t = torch.as_tensor(_DevMem(buf, count * 8, "<i8" if is_u64 else "<f8", 8), device="cuda")
+                with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+                    dist.all_reduce(t)
+                return 0
+            except Exception as e:  # noqa: BLE001
+                print("all-reduce callback failed:", e, flush=True)
+                return 1
+
+        cb1, cb2, cb3 = _lib.ALLTOALL_FN(_a2a), _lib.ALLREDUCE_FN(_ared), _lib.ALLTOALLV_FN(_a2av)
+        self.keep = (cb1, cb2, cb3)
+        L = f.L
+        return L.pf_set_exchange(f.h, cb1, None) == 0 and L.pf_set_exchange_rows(f.h, cb3, None) == 0 and \
+            L.pf_set_allreduce(f.h, cb2, None) == 0
+
+    def release(self):
+        self.keep = None
+
+
+KINDS = {"rccl": RcclKind, "torch": TorchKind}
+
+
+def negotiate_exchange(f, dist, torch, preferred: str = "rccl", device="cuda", kinds=None, selftest_bytes: int = 1 << 20, log=None):
+    """Collective over the process group.  Tries `preferred`, then the other kinds, and returns (name, keep-alive object)
+    of the first one every rank could bind, set up and self-test (pf_debug_exchange: all-to-all, row-range all-to-all and
+    all-reduce with a known pattern); raises RuntimeError on every rank if none works.  `kinds`: name -> class, for tests."""
+    kinds = kinds or KINDS
+    order = [preferred] + [k for k in kinds if k != preferred]
+    log = log or (lambda msg: print(msg, file=sys.stderr, flush=True))
+    rank = dist.get_rank()
+    for name in order:
+        k = kinds[name](f, dist, torch, device)
         try:
-            nbytes = bytes_per_peer * world
-            s = torch.as_tensor(_DevMem(send, nbytes), device="cuda")
-            r = torch.as_tensor(_DevMem(recv, nbytes), device="cuda")
-            with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
-                dist.all_to_all_single(r, s)
-            return 0
-        except Exception as e:  # noqa: BLE001 -- surfaces as "all-to-all failed" in the library
-            print("exchange callback failed:", e, flush=True)
-            return 1
-
-    def _a2av(user, send, recv, block_bytes, send_off, send_bytes, recv_off, recv_bytes, stream):
-        # row-range form (band-limited radii): per-sender sizes, empty messages allowed
-        try:
-            s = torch.as_tensor(_DevMem(send, block_bytes * world), device="cuda")
-            r = torch.as_tensor(_DevMem(recv, block_bytes * world), device="cuda")
-            ins = [s[q * block_bytes + send_off:q * block_bytes + send_off + send_bytes] for q in range(world)]
-            outs = [r[p * block_bytes + recv_off[p]:p * block_bytes + recv_off[p] + recv_bytes[p]] for p in range(world)]
-            with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
-                dist.all_to_all(outs, ins)
-            return 0
+            local = bool(k.can_bind())
         except Exception as e:  # noqa: BLE001
-            print("row-range exchange callback failed:", e, flush=True)
-            return 1
-
-    def _ared(user, buf, count, is_u64, stream):
+            log(f"[rank {rank}] exchange '{name}': local check raised {e!r}")
+            local = False
+        if not _vote(dist, torch, local, device):       # nobody has touched a communicator of this kind yet
+            log(f"[rank {rank}] exchange '{name}' cannot be bound on every rank (here: {local})")
+            continue
         try:
-            if is_u64:
-                t = torch.as_tensor(_DevMem(buf, count * 8, "<i8", 8), device="cuda")
-            else:
-                t = torch.as_tensor(_DevMem(buf, count * 8, "<f8", 8), device="cuda")
-            with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
-                dist.all_reduce(t)
-            return 0
+            ok = bool(k.setup())
         except Exception as e:  # noqa: BLE001
-            print("all-reduce callback failed:", e, flush=True)
-            return 1
+            log(f"[rank {rank}] exchange '{name}': set-up raised {e!r}")
+            ok = False
+        if _vote(dist, torch, ok, device):
+            try:
+                ok = f.L.pf_debug_exchange(f.h, selftest_bytes) == 0
+            except Exception as e:  # noqa: BLE001
+                log(f"[rank {rank}] exchange '{name}': self-test raised {e!r}")
+                ok = False
+            if _vote(dist, torch, ok, device):
+                return name, k
+            log(f"[rank {rank}] exchange '{name}' failed its self-test on some rank (here: {ok})")
+        else:
+            log(f"[rank {rank}] exchange '{name}' could not be set up on every rank (here: {ok})")
+        try:
+            k.release()
+        except Exception as e:  # noqa: BLE001
+            log(f"[rank {rank}] exchange '{name}': release raised {e!r}")
+    raise RuntimeError("no working multi-GPU exchange")
 
-    cb1 = _lib.ALLTOALL_FN(_a2a)
-    cb2 = _lib.ALLREDUCE_FN(_ared)
-    cb3 = _lib.ALLTOALLV_FN(_a2av)
-    f._chk(L.pf_set_exchange(f.h, cb1, None))
-    f._chk(L.pf_set_exchange_rows(f.h, cb3, None))
-    f._chk(L.pf_set_allreduce(f.h, cb2, None))
-    return (cb1, cb2, cb3)
+
+def install_exchange(f, dist, torch, kind: str = "rccl"):
+    """one kind, no negotiation (tests of a single kind on a one-rank group); returns the keep-alive object"""
+    k = KINDS[kind](f, dist, torch, "cuda")
+    if not k.can_bind() or not k.setup():
+        raise RuntimeError(f"exchange '{kind}' unavailable")
+    return k

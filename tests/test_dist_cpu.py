@@ -86,3 +86,99 @@ def test_band_limited_exchange_model_matches_oracle(world, n, rs):
     for rank, err in res:
         assert isinstance(err, float), (rank, err)
         assert err < 1e-12, (rank, err)
+
+
+# ---- the product's exchange negotiation (pinocchio_amd/dist.py) under a real 2-process gloo group ----
+def _negotiate_worker(rank, world, port, scenario, q):
+    try:
+        sys.path.insert(0, os.path.dirname(HERE))
+        import torch
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from pinocchio_amd import dist as pfdist
+
+        calls = []
+
+        class FakeLib:
+            def __init__(self):
+                self.installed = None
+
+            def pf_debug_exchange(self, h, nbytes):
+                calls.append(("selftest", self.installed))
+                bad = scenario.get("selftest_fails", {}).get(self.installed, ())
+                return 1 if rank in bad else 0
+
+        class FakeCtx:
+            L = FakeLib()
+            h = None
+
+        def make(name):
+            class Kind:
+                def __init__(self, f, dist_, torch_, device):
+                    self.f = f
+
+                def can_bind(self):
+                    calls.append(("can_bind", name))
+                    if rank in scenario.get("bind_raises", {}).get(name, ()):
+                        raise OSError("cannot load librccl")
+                    return rank not in scenario.get("cannot_bind", {}).get(name, ())
+
+                def setup(self):
+                    calls.append(("setup", name))
+                    # a set-up that contains a collective: must only be entered when every rank enters it
+                    t = torch.tensor([rank])
+                    dist.broadcast(t, src=0)
+                    self.f.L.installed = name
+                    return rank not in scenario.get("setup_fails", {}).get(name, ())
+
+                def release(self):
+                    calls.append(("release", name))
+                    self.f.L.installed = None
+            Kind.name = name
+            return Kind
+
+        kinds = {"rccl": make("rccl"), "torch": make("torch")}
+        f = FakeCtx()
+        try:
+            name, _ = pfdist.negotiate_exchange(f, dist, torch, preferred="rccl", device="cpu", kinds=kinds, log=lambda m: None)
+        except RuntimeError:
+            name = None
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, name, calls))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, repr(e), []))
+
+
+@pytest.mark.parametrize("scenario,chosen", [
+    ({}, "rccl"),
+    ({"cannot_bind": {"rccl": (1,)}}, "torch"),           # one rank cannot dlopen RCCL: nobody enters its set-up
+    ({"bind_raises": {"rccl": (0,)}}, "torch"),
+    ({"setup_fails": {"rccl": (0,)}}, "torch"),           # ncclCommInitRank fails on one rank: released on all, then torch
+    ({"selftest_fails": {"rccl": (1,)}}, "torch"),        # wrong words on one rank only
+    ({"selftest_fails": {"rccl": (1,), "torch": (0,)}}, None),
+])
+def test_exchange_negotiation_never_leaves_a_rank_behind(scenario, chosen):
+    """bench.py --gpus N: every rank must reach the same decision, through the same number of collectives, whatever
+    fails and wherever (a one-sided failure used to leave the other ranks inside a collective)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 2
+    procs = [ctx.Process(target=_negotiate_worker, args=(r, world, port, scenario, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [chosen] * world, res
+    c0, c1 = res[0][2], res[1][2]
+    assert c0 == c1, (c0, c1)                      # the same steps in the same order on both ranks
+    if scenario.get("cannot_bind") or scenario.get("bind_raises"):
+        assert ("setup", "rccl") not in c0         # the vote came first
+    if scenario.get("setup_fails") or scenario.get("selftest_fails"):
+        assert ("release", "rccl") in c0           # nothing of the failed kind stays behind
