@@ -143,44 +143,38 @@ static void fft1d(double *a, int n, int sign, const double *tw, const int *brev)
   }
 }
 
-/* complex transforms along x and y of a half-spectrum array [n][n][nzh] */
+/* complex transforms along x and y of a half-spectrum array [n][n][nzh].  The lines are strided (nzh, n*nzh complex);
+   ORC_FFT_BLOCK neighbouring kz columns are gathered together so that every cache line fetched is used whole.  Each
+   line still goes through the same fft1d: results do not depend on the blocking. */
+#define ORC_FFT_BLOCK 8
+static void fft_strided_lines(const orc_ctx *c, double *base, size_t stride, int ncols, int sign, double *lines) {
+  const int n = c->n;
+  for (int e = 0; e < n; e++) {
+    const double *src = base + 2 * (size_t)e * stride;
+    for (int j = 0; j < ncols; j++) { lines[2 * ((size_t)j * n + e)] = src[2 * j]; lines[2 * ((size_t)j * n + e) + 1] = src[2 * j + 1]; }
+  }
+  for (int j = 0; j < ncols; j++) fft1d(lines + 2 * (size_t)j * n, n, sign, c->tw, c->brev);
+  for (int e = 0; e < n; e++) {
+    double *dst = base + 2 * (size_t)e * stride;
+    for (int j = 0; j < ncols; j++) { dst[2 * j] = lines[2 * ((size_t)j * n + e)]; dst[2 * j + 1] = lines[2 * ((size_t)j * n + e) + 1]; }
+  }
+}
 static void fft_xy(orc_ctx *c, double *spec, int sign) {
   const int n = c->n, nzh = c->nzh;
-  /* y lines: fixed (x,kz), stride nzh */
 #pragma omp parallel num_threads(c->nthreads)
   {
-    double *line = (double *)malloc(sizeof(double) * 2 * n);
+    double *lines = (double *)malloc(sizeof(double) * 2 * n * ORC_FFT_BLOCK);
+    /* y lines: fixed (x,kz), stride nzh */
 #pragma omp for schedule(static)
     for (int x = 0; x < n; x++)
-      for (int kz = 0; kz < nzh; kz++) {
-        double *base = spec + 2 * ((size_t)x * n * nzh + kz);
-        for (int y = 0; y < n; y++) {
-          line[2 * y] = base[2 * (size_t)y * nzh];
-          line[2 * y + 1] = base[2 * (size_t)y * nzh + 1];
-        }
-        fft1d(line, n, sign, c->tw, c->brev);
-        for (int y = 0; y < n; y++) {
-          base[2 * (size_t)y * nzh] = line[2 * y];
-          base[2 * (size_t)y * nzh + 1] = line[2 * y + 1];
-        }
-      }
+      for (int kz = 0; kz < nzh; kz += ORC_FFT_BLOCK)
+        fft_strided_lines(c, spec + 2 * ((size_t)x * n * nzh + kz), (size_t)nzh, nzh - kz < ORC_FFT_BLOCK ? nzh - kz : ORC_FFT_BLOCK, sign, lines);
     /* x lines: fixed (y,kz), stride n*nzh */
 #pragma omp for schedule(static)
     for (int y = 0; y < n; y++)
-      for (int kz = 0; kz < nzh; kz++) {
-        double *base = spec + 2 * ((size_t)y * nzh + kz);
-        const size_t st = (size_t)n * nzh;
-        for (int x = 0; x < n; x++) {
-          line[2 * x] = base[2 * x * st];
-          line[2 * x + 1] = base[2 * x * st + 1];
-        }
-        fft1d(line, n, sign, c->tw, c->brev);
-        for (int x = 0; x < n; x++) {
-          base[2 * x * st] = line[2 * x];
-          base[2 * x * st + 1] = line[2 * x + 1];
-        }
-      }
-    free(line);
+      for (int kz = 0; kz < nzh; kz += ORC_FFT_BLOCK)
+        fft_strided_lines(c, spec + 2 * ((size_t)y * nzh + kz), (size_t)n * nzh, nzh - kz < ORC_FFT_BLOCK ? nzh - kz : ORC_FFT_BLOCK, sign, lines);
+    free(lines);
   }
 }
 
