@@ -228,6 +228,7 @@ static void read_tuning(PfTuning *t) {
   t->collapse_wg_per_cu = env_int("PF_COLLAPSE_WG_PER_CU", 8);
   if (t->collapse_wg_per_cu <= 0) t->collapse_wg_per_cu = 8;
   t->general = env_int("PF_GENERAL", 0) != 0;
+
   t->pipeline = env_int("PF_PIPELINE", 1) != 0;
   t->exact_libm = env_int("PF_EXACT_LIBM", 0) != 0;
   // fault injection for the tests of the exchange pipeline (tests/test_gpu_multirank.py): "recv" drops the wait of the
@@ -414,7 +415,7 @@ static int exchange(pf_ctx *c, const void *send, void *recv, hipStream_t st = nu
 // ... and of those rows only the in-band kz columns: the blocks of a pruned item use the compact row pitch below
 // (a multiple of 8 complex = 128 bytes) instead of nzp, in the x-pass output, the exchange and the y-pass input alike
 static int band_zpitch(const pf_ctx *c, int band) {
-  if (c->P == 1 || band >= c->n / 2) return c->nzp;
+  if (band >= c->n / 2) return c->nzp;
   const int zp = (band + 1 + 7) & ~7;
   return zp < c->nzp ? zp : c->nzp;
 }
@@ -457,7 +458,11 @@ static PfAddr addr_ky_x(const pf_ctx *c) {  // KY layout, e = x, outer = y_local
 static PfAddr addr_blocks_y(const pf_ctx *c) {  // P blocks [p][nxl][nyl][nzp], e = y = p*nyl + yl, outer = x_local
   PfAddr a; a.os = (long long)c->nyl * c->nzp; a.el_shift = ilog2i(c->nyl); a.ehs = (long long)c->nxl * c->nyl * c->nzp; a.els = c->nzp; return a;
 }
-// inverse transforms, P > 1: send / receive blocks with the slab row slowest, [q][y_local][x_local][nzp]
+// inverse transforms: the x-pass outputs are laid out with the slab row slowest, [q][y_local][x_local][nzp] -- the send /
+// receive blocks of a multi-rank run, and for one rank simply [y][x][nzp]: the x-pass then writes its 1024 segments of a
+// tile at a stride of one row (8.3 KB) instead of one x-plane (8.5 MB = 65 * 2^17 bytes, an address pattern the memory
+// channels do not like: 7.7 -> 6.1 ms per Hessian x-pass at 1024^3), the y-pass reads at the plane stride instead
+// (unchanged within the box-to-box spread).
 // zp: row pitch inside the blocks (nzp, or the compact pitch of a band-limited item); the blocks keep their places
 static PfAddr addr_yblocks_x(const pf_ctx *c, int zp) {  // x-pass output: e = x = q*nxl + xl, outer = y_local
   PfAddr a; a.os = (long long)c->nxl * zp; a.el_shift = ilog2i(c->nxl); a.ehs = (long long)c->nyl * c->nxl * c->nzp; a.els = zp; return a;
@@ -477,7 +482,7 @@ static int xpass(pf_ctx *c, int kind, int dir, int njobs, const Job *jobs, int p
   p.njobs = njobs;
   for (int j = 0; j < njobs; j++) { p.job[j].in = jobs[j].in; p.job[j].out = jobs[j].out; p.job[j].mul = jobs[j].mul; }
   p.ain = p.aout = addr_ky_x(c);
-  if (out_yblocks && c->P > 1) p.aout = addr_yblocks_x(c, band_zpitch(c, band));
+  if (out_yblocks) p.aout = addr_yblocks_x(c, band_zpitch(c, band));
   p.ncols = c->nzh; p.nouter = c->nyl; p.pre = pre; p.outer_offset = c->rank * c->nyl; p.rs = rs; p.growth = growth; p.tw = c->tw;
   p.etab = c->etab; p.dev = c->dev;
   if (pre && rs != 0.0) PFCHK(c, pf_launch_exp_table(c->etab, c->n, rs, c->stream));  // stream order: after the previous x-pass
@@ -498,7 +503,7 @@ static int ypass(pf_ctx *c, int kind, int dir, int njobs, const Job *jobs, bool 
   PfStridedParams p; memset(&p, 0, sizeof(p));
   p.njobs = njobs;
   for (int j = 0; j < njobs; j++) { p.job[j].in = jobs[j].in; p.job[j].out = jobs[j].out; p.job[j].mul = jobs[j].mul; }
-  p.ain = in_blocks ? ((in_yblocks && c->P > 1) ? addr_yblocks_y(c, band_zpitch(c, band)) : addr_blocks_y(c)) : addr_xs_y(c);
+  p.ain = in_blocks ? (in_yblocks ? addr_yblocks_y(c, band_zpitch(c, band)) : addr_blocks_y(c)) : addr_xs_y(c);
   p.aout = out_blocks ? addr_blocks_y(c) : addr_xs_y(c);
   p.ncols = c->nzh; p.nouter = c->nxl; p.pre = 0; p.outer_offset = 0; p.rs = 0; p.growth = 1; p.tw = c->tw; p.dev = c->dev;
   p.band_e = p.band_outer = c->n;
