@@ -558,6 +558,11 @@ static int zpass_c2r(pf_ctx *c, int kind, int njobs, const ZJob *jobs, const dou
 // field i with passes of field i+-1").  Hazards: pre(i) reuses the send set of item i-2, whose exchange post(i-2)
 // waited for; exchange(i) overwrites the receive set of item i-2 after ev_x(i), recorded behind post(i-2).
 // band(i): the spectrum of item i is band-limited to |k| <= band (>= n/2: not): only the in-band slab rows travel
+// (fault injection of the tests only: holds the compute stream back so that an exchange that does not wait starts too early)
+__global__ void k_debug_idle(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
 template <class Pre, class Dst, class Post, class Band>
 static int pipelined_band(pf_ctx *c, int count, int nf, Pre pre, Dst dst, Post post, Band band) {
   void *A[2][3];
@@ -576,6 +581,7 @@ static int pipelined_band(pf_ctx *c, int count, int nf, Pre pre, Dst dst, Post p
   }
   auto issue = [&](int i) -> int {
     const int s = i & 1;
+    if (c->tune.debug_fault == 2) hipLaunchKernelGGL(k_debug_idle, dim3(1), dim3(1), 0, c->stream, 200000LL);  // 2 ms at 100 MHz
     if (pre(i, A[s])) return 1;
     HIPCHK(c, hipEventRecord(c->ev_x[s], c->stream));
     if (c->tune.debug_fault != 2) HIPCHK(c, hipStreamWaitEvent(c->cstream, c->ev_x[s], 0));

@@ -416,12 +416,13 @@ def test_pipelined_exchange_with_late_communication(api, P, delay_us, fb):
         assert np.max(np.abs(a - b)) <= 2e-7 * np.max(np.abs(b))
 
 
-@pytest.mark.parametrize("fault,n,P,delay_us", [("recv", 64, 4, 2000), ("send", 256, 2, 0)])
+@pytest.mark.parametrize("fault,n,P,delay_us", [("recv", 64, 4, 2000), ("send", 64, 4, 0)])
 def test_late_communication_exposes_a_missing_wait(api, fault, n, P, delay_us, monkeypatch):
     """the same set-up with one wait of the pipeline taken out on purpose (PF_DEBUG_PIPELINE_FAULT, read in pf_create): the
     results must change -- the test above can see what it is there to see.  "recv": the compute stream does not wait for
     the exchange it consumes (exposed by a late communication stream); "send": the exchange does not wait for the x-pass
-    that fills its blocks (exposed by a grid large enough for the x-pass to still run when the copies start)"""
+    that fills its blocks (the injected fault also holds the compute stream back by 2 ms before every x-pass, so the copies
+    are certain to start first)"""
     nxl = n // P
     dk = synth.make_density(n, seed=29)
     radii = np.array([8.0, 4.0, 3.2, 1.0, 0.0])
