@@ -101,20 +101,41 @@ template <int N, int S> PF_HD int pf_stage_pos(int tl, int m) {
   return (jb - k) * R + k + t * NS;
 }
 
-// stage S on the 8 registers of thread tl.  tw[j] = exp(+2 pi i j / (N*TWS)).
-template <typename F, int N, int S, int DIR, int TWS>
-PF_HD void pf_stage(pfc<F> (&v)[8], int tl, const pfc<F> *__restrict__ tw) {
+// Twiddles of stage S: one table value w^1 per butterfly of the thread (Q = 8/R of them; none in stage 0, where NS = 1).
+// They depend on the thread's place in the line only -- not on the line, the job or the row -- so a kernel may fetch them
+// wherever their latency is hidden (before the LDS exchange that precedes the stage, or once outside its loop over rows).
+constexpr int pf_stage_ntw(int n, int s) { return pf_ns(n, s) > 1 ? 8 / pf_radix(n, s) : 0; }
+constexpr int pf_ntw_before(int n, int s) { return s == 0 ? 0 : pf_ntw_before(n, s - 1) + pf_stage_ntw(n, s - 1); }
+constexpr int pf_ntw_total(int n) { return pf_ntw_before(n, pf_nstages(n)); }
+
+// tw[j] = exp(+2 pi i j / (N*TWS))
+// (arrays by reference and compile-time offsets: the values must stay in registers -- through a pointer the compiler puts
+//  them in scratch memory, and a scratch reload waits on the same in-order counter as every global load before it)
+template <typename F, int N, int S, int DIR, int TWS, int OFF = 0, int NW>
+PF_HD void pf_stage_twiddles(int tl, const pfc<F> *__restrict__ tw, pfc<F> (&w)[NW]) {
   constexpr int R = pf_radix(N, S), NS = pf_ns(N, S), Q = 8 / R, NT = N / 8;
   constexpr int TWM = (N / (NS * R)) * TWS;
+  if (NS > 1) {
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      const int jb = tl + q * NT;
+      const int k = jb & (NS - 1);
+      w[OFF + q] = tw[k * TWM];
+      if (DIR < 0) w[OFF + q].y = -w[OFF + q].y;
+    }
+  }
+}
+
+// stage S on the 8 registers of a thread, with its twiddles w[0..Q-1] in hand
+template <typename F, int N, int S, int DIR, int OFF = 0, int NW>
+PF_HD void pf_stage_apply(pfc<F> (&v)[8], const pfc<F> (&w)[NW]) {
+  constexpr int R = pf_radix(N, S), NS = pf_ns(N, S), Q = 8 / R;
 #pragma unroll
   for (int q = 0; q < Q; q++) {
-    const int jb = tl + q * NT;
-    const int k = jb & (NS - 1);
     if (NS > 1) {
-      // one table load per butterfly: w^2..w^(R-1) by products of depth <= 3 (error <= ~4 ulp, far inside the
+      // one table value per butterfly: w^2..w^(R-1) by products of depth <= 3 (error <= ~4 ulp, far inside the
       // transform's own rounding) instead of R-1 dependent L1 loads
-      pfc<F> w1 = tw[k * TWM];
-      if (DIR < 0) w1.y = -w1.y;
+      const pfc<F> w1 = w[OFF + q];
       v[q + 1 * Q] = pf_cmul(v[q + 1 * Q], w1);
       if (R >= 4) {
         const pfc<F> w2 = pf_cmul(w1, w1), w3 = pf_cmul(w2, w1);
@@ -137,6 +158,14 @@ PF_HD void pf_stage(pfc<F> (&v)[8], int tl, const pfc<F> *__restrict__ tw) {
       pf_bfly2<DIR>(v[q], v[q + Q]);
     }
   }
+}
+
+// stage S with its twiddles fetched on the spot
+template <typename F, int N, int S, int DIR, int TWS>
+PF_HD void pf_stage(pfc<F> (&v)[8], int tl, const pfc<F> *__restrict__ tw) {
+  pfc<F> w[8 / pf_radix(N, S)];
+  pf_stage_twiddles<F, N, S, DIR, TWS>(tl, tw, w);
+  pf_stage_apply<F, N, S, DIR>(v, w);
 }
 
 // LDS padding for contiguous-line kernels: breaks the stride-8 write pattern of stage 0

@@ -12,26 +12,36 @@ __device__ __forceinline__ void pf_wave_sync() {
 }
 
 // WAVE_LOCAL: the N / 8 threads of a transform sit in one wave and exchange through LDS words nobody else touches: the
-// LDS queue serves a wave's accesses in order, so the exchange needs no workgroup barrier
+// LDS queue serves a wave's accesses in order, so the exchange needs no workgroup barrier.
+// Twiddles: the table values of stage S+1 are requested BEFORE the LDS exchange that follows stage S, so their L1 latency
+// passes during the exchange instead of after it (x-pass 6.4 -> 6.0 ms per Hessian launch at 1024^3; fetching them once
+// outside the row loop of the invariant z-pass, 160 VGPRs, changed nothing there: profiles/r02_experiments.md).
 template <typename F, int N, int DIR, int TWS, int S = 0, bool WAVE_LOCAL = false>
 struct PfStages {
   template <typename WR, typename RD>
+  static __device__ __forceinline__ void exchange(pfc<F> (&v)[8], int tl, WR wr, RD rd) {
+    constexpr int NT = N / 8;
+#pragma unroll
+    for (int m = 0; m < 8; m++) wr(pf_stage_pos<N, S>(tl, m), v[m]);
+    if constexpr (WAVE_LOCAL) pf_wave_sync(); else __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 8; m++) v[m] = rd(tl + m * NT);
+    if constexpr (WAVE_LOCAL) pf_wave_sync(); else __syncthreads();
+  }
+  // entry (S = 0): stage 0 has no twiddles
+  template <typename WR, typename RD>
   static __device__ __forceinline__ void run(pfc<F> (&v)[8], int tl, const pfc<F> *__restrict__ tw, WR wr, RD rd) {
     static_assert(!WAVE_LOCAL || N / 8 <= 64, "a wave-local transform has at most 64 threads");
-    pf_stage<F, N, S, DIR, TWS>(v, tl, tw);
+    if constexpr (S == 0) pf_stage<F, N, 0, DIR, TWS>(v, tl, tw);
     if constexpr (S + 1 < pf_nstages(N)) {
-      constexpr int NT = N / 8;
-#pragma unroll
-      for (int m = 0; m < 8; m++) wr(pf_stage_pos<N, S>(tl, m), v[m]);
-      if constexpr (WAVE_LOCAL) pf_wave_sync(); else __syncthreads();
-#pragma unroll
-      for (int m = 0; m < 8; m++) v[m] = rd(tl + m * NT);
-      if constexpr (WAVE_LOCAL) pf_wave_sync(); else __syncthreads();
+      pfc<F> w[8 / pf_radix(N, S + 1)];
+      pf_stage_twiddles<F, N, S + 1, DIR, TWS>(tl, tw, w);
+      exchange(v, tl, wr, rd);
+      pf_stage_apply<F, N, S + 1, DIR>(v, w);
       PfStages<F, N, DIR, TWS, S + 1, WAVE_LOCAL>::run(v, tl, tw, wr, rd);
     }
   }
 };
-
 
 // 1/N^3 normalisation plus the DC mode, one definition for every z-pass so that they round alike
 template <typename F> __device__ __forceinline__ F pf_norm_dc(F v, F norm, F dc) { return v * norm + dc; }
