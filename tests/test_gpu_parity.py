@@ -284,6 +284,37 @@ def test_fp32_field_path(api, n):
     assert np.abs(pdf.astype(np.int64) - pdf_o.astype(np.int64)).sum() <= 2e-3 * n ** 3
 
 
+def test_fp32_fields_on_the_largest_box_one_gpu_holds(api):
+    """BASELINE config 5's arithmetic (fp32 density / derivative fields, fp64 collapse solve, the six-component kernels that a
+    2048^3 run takes) end to end at the largest size whose fp32 path fits one GPU, 1024^3 -- against the fp64-field run of the
+    same modes: variances to fp32 accuracy, Fmax within the stated tolerance of the fp32 path, plus the properties that need no
+    second run.  (The 2048-point kernels themselves: tests/test_gpu_lines.py.)"""
+    n = 1024
+    x, y = synth.invgrow_table("lcdm")
+    radii = synth.radii_ladder(12)[[2, 8, 11]]          # one band-limited radius, one full, R = 0
+    with api.Fmax(n) as f:
+        f.synth_density(synth.SEED, 2.5, -2.0)
+        f.set_invgrow(x, y)
+        tv64 = f.sweep(radii)
+        fm64 = f.block("FMAX")
+    with api.Fmax(n, field_bytes=4) as f:
+        f.synth_density(synth.SEED, 2.5, -2.0)
+        f.set_invgrow(x, y)
+        tv = f.sweep(radii)
+        pdf = f.Fmax_PDF()
+        fm = f.block("FMAX")
+        rm = f.block("RMAX")
+        assert f.device_bytes < 150e9
+    assert np.allclose(tv, tv64, rtol=2e-5) and tv[0] < tv[1] < tv[2]
+    assert np.sqrt(tv[-1]) == pytest.approx(2.5, rel=1e-5)
+    assert int(pdf.sum()) == n ** 3 and np.isfinite(fm).all()
+    assert rm.min() >= -1 and rm.max() == 2
+    sel = fm64 >= 0.5
+    d = np.abs(fm[sel].astype(np.float64) - fm64[sel].astype(np.float64))
+    assert np.mean(d <= 1e-3) > 0.999, float(np.mean(d <= 1e-3))
+    assert abs(float((fm >= 1.0).mean()) - float((fm64 >= 1.0).mean())) < 1e-4   # collapsed fraction
+
+
 def test_synth_density_matches_numpy_mirror(api):
     n = 32
     with api.Fmax(n) as f:
