@@ -52,6 +52,18 @@ __global__ void __launch_bounds__(T *N / 8) __attribute__((amdgpu_waves_per_eu(4
   }
 
   C src[8], v[8];
+  // a tile of input `in` into src: issued as early as src is free, consumed at the top of the job that uses it
+  auto load_tile = [&](const void *inp, int tlj, int colj) {
+    const C *__restrict__ in = reinterpret_cast<const C *>(inp);
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int e = tlj + m * NT;
+      const int se = e > N / 2 ? e - N : e;
+      const bool inband = se <= p.band_e && se >= -p.band_e;
+      src[m] = (valid && inband) ? pf_ld_stream(&in[pf_addr(p.ain, outer, e, colj)]) : pf_mk<F>(0, 0);
+    }
+  };
+  load_tile(p.job[0].in, tl, col);
 #pragma unroll 1
   for (int j = 0; j < p.njobs; j++) {
     // Everything below is loop invariant except the job; left to LICM the compiler hoists every
@@ -61,31 +73,21 @@ __global__ void __launch_bounds__(T *N / 8) __attribute__((amdgpu_waves_per_eu(4
     asm volatile("" : "+v"(tlj), "+v"(cj));
     const int colj = tile * T + cj;
     // jobs are grouped by input: a tile is read from HBM once and transformed for every job that uses it
-    if (j == 0 || p.job[j].in != p.job[j - 1].in) {
-      const C *__restrict__ in = reinterpret_cast<const C *>(p.job[j].in);
+    if (p.pre && (j == 0 || p.job[j].in != p.job[j - 1].in)) {
+      int so = outer + p.outer_offset;
+      if (so > N / 2) so -= N;
+      const double ko = kf * so, kc = kf * colj;
+      const double ko2kc2 = ko * ko + kc * kc;
+      // window of the two untransformed axes times the growth factor: one exp per thread (none without smoothing)
+      const double woc = (p.rs != 0.0 ? exp(-0.5 * ko2kc2 * p.rs * p.rs) : 1.0) * p.growth;
 #pragma unroll
       for (int m = 0; m < 8; m++) {
         const int e = tlj + m * NT;
-        const int se = e > N / 2 ? e - N : e;
-        const bool inband = se <= p.band_e && se >= -p.band_e;
-        src[m] = (valid && inband) ? pf_ld_stream(&in[pf_addr(p.ain, outer, e, colj)]) : pf_mk<F>(0, 0);
-      }
-      if (p.pre) {
-        int so = outer + p.outer_offset;
-        if (so > N / 2) so -= N;
-        const double ko = kf * so, kc = kf * colj;
-        const double ko2kc2 = ko * ko + kc * kc;
-        // window of the two untransformed axes times the growth factor: one exp per thread (none without smoothing)
-        const double woc = (p.rs != 0.0 ? exp(-0.5 * ko2kc2 * p.rs * p.rs) : 1.0) * p.growth;
-#pragma unroll
-        for (int m = 0; m < 8; m++) {
-          const int e = tlj + m * NT;
-          const double ke = kf * (e > N / 2 ? e - N : e);
-          const double k2 = ke * ke + ko2kc2;
-          const double we = p.rs != 0.0 ? p.etab[e] : 1.0;
-          const double fac = (k2 != 0.0) ? we * woc / k2 : 0.0;
-          src[m] = pf_scale(src[m], (F)fac);
-        }
+        const double ke = kf * (e > N / 2 ? e - N : e);
+        const double k2 = ke * ke + ko2kc2;
+        const double we = p.rs != 0.0 ? p.etab[e] : 1.0;
+        const double fac = (k2 != 0.0) ? we * woc / k2 : 0.0;
+        src[m] = pf_scale(src[m], (F)fac);
       }
     }
     const int mul = p.job[j].mul;
@@ -99,6 +101,8 @@ __global__ void __launch_bounds__(T *N / 8) __attribute__((amdgpu_waves_per_eu(4
       else if (mul == PF_MUL_IK) x = pf_mul_i<+1>(pf_scale(x, ke));
       v[m] = x;
     }
+    // src is free once the last job on this input has taken its copy: the next input's tile travels during the stages
+    if (j + 1 < p.njobs && p.job[j + 1].in != p.job[j].in) load_tile(p.job[j + 1].in, tlj, colj);
     PfStages<F, N, DIR, 1>::run(
         v, tlj, tw, [&](int pos, C val) { lds[pos * T + cj] = val; }, [&](int pos) { return lds[pos * T + cj]; });
     if (valid) {
