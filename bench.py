@@ -138,10 +138,17 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # one process per GPU: LOCAL_RANK names the device, unless the launcher already narrowed the visible devices to one
+        ndev = torch.cuda.device_count()
+        if ndev < 1:
+            raise SystemExit("no GPU visible")
+        device = local_rank % ndev
+        torch.cuda.set_device(device)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+    else:
+        device = 0
 
-    f = api.Fmax(n, rank=rank, nranks=world, device=local_rank, field_bytes=args.field_bytes, timing=True)
+    f = api.Fmax(n, rank=rank, nranks=world, device=device, field_bytes=args.field_bytes, timing=True)
     keep = None
     exchange_kind = None
     if world > 1:
