@@ -191,6 +191,16 @@ for kind in ("torch", "rccl"):
         keep = pfdist.install_exchange(f, dist, torch, kind=kind)
         assert f.L.pf_debug_exchange(f.h, 1 << 20) == 0, kind
         del keep
+# what bench.py --gpus N does: vote-guarded negotiation on the NCCL (= RCCL) process group, either preference
+for pref in ("rccl", "torch"):
+    with api.Fmax(64) as f:
+        name, keep = pfdist.negotiate_exchange(f, dist, torch, preferred=pref, device="cuda")
+        assert name == pref, (name, pref)
+        assert f.L.pf_debug_exchange(f.h, 1 << 16) == 0
+        if name == "rccl":
+            assert f.L.pf_release_rccl(f.h) == 0      # communicator destroyed, callbacks cleared
+            assert f.L.pf_debug_exchange(f.h, 1 << 16) != 0
+        del keep
 dist.destroy_process_group()
 print("TORCH_OK")
 """
