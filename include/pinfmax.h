@@ -133,6 +133,8 @@ typedef struct {
   double BoxSize_true_Mpc;
   double PkNorm;
   unsigned int RandomSeed;
+  int FixedIC;    /* params.FixedIC: "non-random modules of the Fourier modes", no Rayleigh factor -log(ampl) (src/GenIC.c:375) */
+  int PairedIC;   /* params.PairedIC: every phase shifted by pi (src/GenIC.c:371) */
 } pf_genic_params;
 int pf_pk_norm(const pf_genic_params *p, double sigma8, double *pknorm);
 int pf_genic_density(pf_ctx *ctx, const pf_genic_params *p);

@@ -183,7 +183,13 @@ double orc_powerspec_EH(double k, const orc_cosmo *p) { return pow(k, p->Primord
 /* GenIC_large for ONE task owning the whole grid, non-transposed layout.
    seed[jj*n + ii] = seed of the (ii, jj) column (spiral order, built by the caller).
    kdensity out: [n][n][n/2+1][2], already multiplied by n^3 (src/GenIC.c:430-445). */
+int orc_genic_ic(int n, double box, const unsigned int *seed, double pknorm, const orc_cosmo *cosmo, int FixedIC, int PairedIC, double *kdensity);
 int orc_genic(int n, double box, const unsigned int *seed, double pknorm, const orc_cosmo *cosmo, double *kdensity) {
+  return orc_genic_ic(n, box, seed, pknorm, cosmo, 0, 0, kdensity);
+}
+/* the same with the two run-time options of src/GenIC.c:370-376: PairedIC adds pi to every phase, FixedIC leaves the Rayleigh
+   factor -log(ampl) out ("non-random modules of the Fourier modes") */
+int orc_genic_ic(int n, double box, const unsigned int *seed, double pknorm, const orc_cosmo *cosmo, int FixedIC, int PairedIC, double *kdensity) {
   const int Nmesh = n, Nsample = n, Nmesh_2 = n / 2, Nmesh_odd = n % 2;
   const int nzh = n / 2 + 1;
   const double Box = box;
@@ -236,7 +242,8 @@ int orc_genic(int n, double box, const unsigned int *seed, double pknorm, const 
             do ampl = ranlxd_uniform(&k0_generator); while (ampl == 0);
           }
         }
-        p_of_k *= -log(ampl); /* !FixedIC */
+        if (PairedIC) phase += ORC_PI;
+        if (!FixedIC) p_of_k *= -log(ampl);
         double delta = fac * sqrt(p_of_k);
         size_t addr = 2 * (((size_t)i * n + addr_j) * nzh + k);
         kdensity[addr] = delta * cos(phase);

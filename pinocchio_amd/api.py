@@ -82,10 +82,10 @@ class Fmax:
         self._chk(self.L.pf_synth_density(self.h, C.c_uint64(seed), sigma0, slope))
 
     def genic_density(self, seed: int, box_true_mpc: float, omega0: float, omega_baryon: float, hubble100: float,
-                      primordial_index: float, sigma8: float = 0.0, pknorm: float = 0.0) -> float:
+                      primordial_index: float, sigma8: float = 0.0, pknorm: float = 0.0, fixed: bool = False, paired: bool = False) -> float:
         """GenIC_large (src/GenIC.c:73) on the device.  Give PkNorm, or sigma8 to have it computed
         (normalize_PowerSpectrum, src/cosmo.c:1058).  Returns the PkNorm used."""
-        p = _lib.GenicParams(omega0, omega_baryon, hubble100, primordial_index, box_true_mpc, pknorm, seed)
+        p = _lib.GenicParams(omega0, omega_baryon, hubble100, primordial_index, box_true_mpc, pknorm, seed, int(fixed), int(paired))
         if pknorm <= 0.0:
             v = C.c_double()
             self._chk(self.L.pf_pk_norm(C.byref(p), sigma8, C.byref(v)))

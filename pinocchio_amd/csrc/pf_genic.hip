@@ -184,6 +184,7 @@ struct GenicArgs {
   int n, nzp, nyl, y0;
   double box, fac, pknorm, n3;
   EHConst eh;
+  bool fixed, paired;        // params.FixedIC, params.PairedIC
 };
 
 template <typename F>
@@ -224,7 +225,8 @@ __global__ void __launch_bounds__(64) k_genic(const GenicArgs a) {
         do ampl = pfg_ranlxd_uniform(k0); while (ampl == 0);
       }
     }
-    p_of_k *= -log(ampl);
+    if (a.paired) phase += PFG_PI;      // src/GenIC.c:371
+    if (!a.fixed) p_of_k *= -log(ampl);  // src/GenIC.c:375
     const double delta = a.fac * sqrt(p_of_k);
     row[2 * kk] = (F)(delta * cos(phase) * a.n3);
     row[2 * kk + 1] = (F)(sign * delta * sin(phase) * a.n3);
@@ -267,6 +269,7 @@ int pf_genic_launch(int fb, void *dk, int n, int nzp, int nyl, int y0, const pf_
   GenicArgs a;
   a.dk = dk; a.seed = dseed; a.n = n; a.nzp = nzp; a.nyl = nyl; a.y0 = y0;
   a.box = p->BoxSize_true_Mpc; a.fac = pow(1. / a.box, 1.5); a.pknorm = p->PkNorm; a.n3 = pow((double)n, 3.0);
+  a.fixed = p->FixedIC != 0; a.paired = p->PairedIC != 0;
   eh_constants(p, &a.eh);
   const long long ncol = (long long)n * nyl;
   const unsigned blocks = (unsigned)((ncol + 63) / 64);

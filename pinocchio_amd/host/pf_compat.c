@@ -227,6 +227,7 @@ int pf_compat_genic(double PkNorm) {
   g.Omega0 = params.Omega0; g.OmegaBaryon = params.OmegaBaryon; g.Hubble100 = params.Hubble100;
   g.PrimordialIndex = params.PrimordialIndex; g.BoxSize_true_Mpc = params.BoxSize_htrue;
   g.RandomSeed = (unsigned int)params.RandomSeed;
+  g.FixedIC = params.FixedIC; g.PairedIC = params.PairedIC; /* src/GenIC.c:371-376 */
   g.PkNorm = PkNorm;
   if (PkNorm <= 0.0 && pf_pk_norm(&g, params.Sigma8, &g.PkNorm)) return 1;
   if (!ThisTask) printf("[%s] Generating the linear density field on the device, PkNorm=%g\n", fdate(), g.PkNorm);

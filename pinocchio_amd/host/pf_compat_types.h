@@ -104,6 +104,8 @@ typedef struct param_data_mirror /* the tags of param_data (:311-352) the path u
   double OmegaLambda;         /* with Omega0 and Hubble100 in the header of the collapse-time table file */
   char   CTtableFile[400];    /* "none": compute the tables (TABULATED_CT build) */
   int    use_transposed_fft;  /* UseTransposedFFT: the path keeps k-space in x, y, z order and refuses anything else */
+  int    FixedIC;             /* GenIC options (src/GenIC.c:371-376), read by pf_compat_genic */
+  int    PairedIC;
 } param_data;
 
 /* gsl_spline as far as my_spline_eval dereferences it (src/cosmo.c:2016-2027) */

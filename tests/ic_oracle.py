@@ -21,6 +21,7 @@ def _lib():
     L.orc_powerspec_EH.restype = C.c_double
     L.orc_powerspec_EH.argtypes = [C.c_double, C.POINTER(Cosmo)]
     L.orc_genic.argtypes = [C.c_int, C.c_double, C.POINTER(C.c_uint), C.c_double, C.POINTER(Cosmo), C.POINTER(C.c_double)]
+    L.orc_genic_ic.argtypes = [C.c_int, C.c_double, C.POINTER(C.c_uint), C.c_double, C.POINTER(Cosmo), C.c_int, C.c_int, C.POINTER(C.c_double)]
     return L
 
 
@@ -62,13 +63,14 @@ def pk_norm(p, sigma8: float) -> float:
     return sigma8 ** 2 / val
 
 
-def genic(n: int, box_true_mpc: float, seed: int, pknorm: float, p) -> np.ndarray:
+def genic(n: int, box_true_mpc: float, seed: int, pknorm: float, p, fixed: bool = False, paired: bool = False) -> np.ndarray:
+    """fixed / paired: params.FixedIC / params.PairedIC (src/GenIC.c:370-376)"""
     L = _lib()
     cos = Cosmo(p["Omega0"], p["OmegaBaryon"], p["Hubble100"], p["PrimordialIndex"])
     st = seed_table(n, seed)
     out = np.zeros((n, n, n // 2 + 1), dtype=np.complex128)
-    rc = L.orc_genic(n, box_true_mpc, st.ctypes.data_as(C.POINTER(C.c_uint)), pknorm, C.byref(cos),
-                     out.view(np.float64).ctypes.data_as(C.POINTER(C.c_double)))
+    rc = L.orc_genic_ic(n, box_true_mpc, st.ctypes.data_as(C.POINTER(C.c_uint)), pknorm, C.byref(cos), int(fixed), int(paired),
+                        out.view(np.float64).ctypes.data_as(C.POINTER(C.c_double)))
     assert rc == 0
     return out
 

@@ -58,7 +58,7 @@ typedef struct /* src/pinocchio.h:311-352, the tags the adapter reads */
 {
   double Omega0, OmegaLambda, OmegaBaryon, Hubble100, Sigma8, PrimordialIndex, BoxSize_htrue, k_for_GM;
   char RunFlag[SBLENGTH], DumpDir[SBLENGTH], CTtableFile[LBLENGTH];
-  int GridSize[3], RandomSeed, use_transposed_fft;
+  int GridSize[3], RandomSeed, use_transposed_fft, FixedIC, PairedIC;
 } param_data;
 extern param_data params;
 

@@ -41,7 +41,7 @@ class Params(C.Structure):
     _fields_ = [("RunFlag", C.c_char * 100), ("DumpDir", C.c_char * 100), ("GridSize", C.c_int * 3), ("RandomSeed", C.c_int),
                 ("Omega0", C.c_double), ("OmegaBaryon", C.c_double), ("Hubble100", C.c_double), ("Sigma8", C.c_double),
                 ("PrimordialIndex", C.c_double), ("BoxSize_htrue", C.c_double), ("OmegaLambda", C.c_double),
-                ("CTtableFile", C.c_char * 400), ("use_transposed_fft", C.c_int)]
+                ("CTtableFile", C.c_char * 400), ("use_transposed_fft", C.c_int), ("FixedIC", C.c_int), ("PairedIC", C.c_int)]
 
 
 def c_output(capfd):
