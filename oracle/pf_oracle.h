@@ -94,8 +94,10 @@ void orc_timers(orc_ctx *c, double t[5]);
 #ifdef __cplusplus
 }
 #endif
-/* PARITY UNPINNED for the two build options below (SCALE_DEPENDENT additions above, TABULATED_CT here): the reference
-   commits no output produced with them; these restatements are checked against numpy / scipy only.
+/* The build options below (SCALE_DEPENDENT additions above, TABULATED_CT, ELL_SNG, MOD_GRAV_FR) are pinned end to end by the
+   runs the reference commits under tests/only_HMF_tests (SCALE_DEP_LCDM, MOD_GRAV_and_SCALE_DEP: sigma per radius, collapsed
+   count, Fmax histogram; tests/test_hmf256_kat.py, fixtures tests/golden/{hmf256,mg256}_kat.json); TABULATED_CT tables of
+   ELL_CLASSIC and ELL_SNG without f(R) have no run of their own and share that code.
    TABULATED_CT build (row f-4; src/collapse_times.c:780-1231 with the BILINEAR_SPLINE interpolation of :40):
    orc_set_tabulated_ct(ns, Smoothing.Variance[]) makes every following collapse-time pass build the table of ell()
    for its radius (100 x 50 x 50 nodes in (delta, x, y) / sqrt(variance)) and interpolate in it; ns = 0 returns to the

@@ -261,7 +261,7 @@ def test_select_sorted_is_the_fragmentation_order():
 
 
 def test_tabulated_ct_restatement_vs_scipy():
-    """TABULATED_CT (row f-4; no reference output exists for it, so this restatement is pinned only by construction):
+    """TABULATED_CT (row f-4; pinned end to end by the reference's f(R) run in test_hmf256_kat.py; here unit by unit):
     the delta sampling, the table of ell() and the bilinear-of-splines interpolation against scipy's natural spline"""
     from scipy.interpolate import CubicSpline
     n = 16
@@ -345,7 +345,7 @@ def _sng_rhs(t, y, cosmo):
 
 
 def test_ell_sng_restatement_vs_scipy():
-    """ELL_SNG (row f-4; parity unpinned: no reference output of that build exists): the restated system + GSL-style
+    """ELL_SNG (row f-4; pinned end to end by the reference's f(R) run in test_hmf256_kat.py): the restated system + GSL-style
     RKF45 loop against scipy's DOP853 at tight tolerance, and the textbook spherical-collapse threshold"""
     from scipy.integrate import solve_ivp
     L = oracle_lib.lib()
