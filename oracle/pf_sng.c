@@ -6,8 +6,10 @@
  * GSL (2.7.1 in the reference's validation build, HMF_Validation/VALIDATION_log.txt:3) is not vendored in the
  * reference and not present in this image.  The three pieces the call site uses are restated from GSL's published
  * algorithm: ode-initval2/rkf45.c (step), ode-initval2/cstd.c (gsl_odeiv2_control_standard_new, hadjust) and
- * ode-initval2/evolve.c (gsl_odeiv2_evolve_apply).  PARITY UNPINNED: the reference commits no output of an ELL_SNG
- * build; this file is checked against scipy's integrators at the integrator's own tolerance (tests/test_oracle.py).
+ * ode-initval2/evolve.c (gsl_odeiv2_evolve_apply).  Pinned end to end by the one ELL_SNG run the reference commits with its
+ * outputs (tests/only_HMF_tests/MOD_GRAV_and_SCALE_DEP: 256^3, TABULATED_CT + MOD_GRAV_FR; collapsed count to 8 cells of
+ * 16.7 M and the Fmax histogram, tests/test_hmf256_kat.py) and checked against scipy's integrators at the integrator's own
+ * tolerance (tests/test_oracle.py).
  */
 #include <float.h>
 #include <math.h>
