@@ -121,7 +121,7 @@ struct pf_ctx {
   double tab_var[PF_MAX_SMOOTH];
   bool tab_ready;
   int tab_ismooth;
-  int model;           // 0 ELL_CLASSIC, 1 ELL_SNG (only through the collapse-time table)
+  int model;           // 0 ELL_CLASSIC, 1 ELL_SNG (fills the collapse-time table of a TABULATED_CT build; per cell without one)
   double sng_cosmo[7], sng_Din[PF_MAX_SMOOTH], sng_size[PF_MAX_SMOOTH];
   int sng_ns;
   PfCtDev ct;
@@ -1030,8 +1030,14 @@ static int collapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], hipStream_
   if (spline_for(c, ismooth, &p.spline)) return 1;
   p.partials = c->partials; p.fast = c->fast_libm ? 1 : 0;
   p.no_lut = c->tune.spline_lut ? 0 : 1;
-  if (c->model == 1 && c->tab_ns == 0)
-    return pf_fail(c->rank, "ELL_SNG is evaluated through the collapse-time table only: call pf_set_tabulated_ct (TABULATED_CT build)");
+  if (c->model == 1 && c->tab_ns == 0) {  // ELL_SNG without TABULATED_CT: every cell integrates its own ellipsoid
+    if (invariants) return pf_fail(c->rank, "ELL_SNG per cell reads the six components");
+    if (ismooth >= c->sng_ns) return pf_fail(c->rank, "ELL_SNG: no growth factor for radius %d (pf_set_collapse_model)", ismooth);
+    memcpy(p.ct.sng_cosmo, c->sng_cosmo, sizeof(c->sng_cosmo));
+    p.ct.sng_cosmo[6] = c->sng_size[ismooth];
+    p.ct.sng_Din = c->sng_Din[ismooth];
+    p.sng = 1;
+  }
   if (c->tab_ns > 0) {  // TABULATED_CT build: the table of this radius is made right before its pass (src/fmax.c:103-106)
     if (build_table) {
       if (ismooth >= c->tab_ns) return pf_fail(c->rank, "collapse-time table: no variance for radius %d (pf_set_tabulated_ct)", ismooth);
@@ -1092,7 +1098,7 @@ static int sweep_body(pf_ctx *c, int ns, const double *radius_cells, double *tru
   PhaseTimer ft(c, 4);
   PFCHK(c, products_reset(c));
   // (n <= 1024: the six-line workgroup of a 2048-point row would need 110 KB of dynamic LDS, a size this build never launches)
-  const bool invariants_ok = c->fb == 8 && c->n <= 1024 && !c->general && c->tab_ns == 0 && c->tune.invariants && !six_components;
+  const bool invariants_ok = c->fb == 8 && c->n <= 1024 && !c->general && c->tab_ns == 0 && c->model == 0 && c->tune.invariants && !six_components;
   HIPCHK(c, hipMemsetAsync(c->scal + SC_INV_FLAG, 0, sizeof(double), c->stream));
   auto pre = [&](int ismooth, void *const *A) {
     PhaseTimer pt(c, 0);

@@ -29,7 +29,9 @@ __device__ __forceinline__ void pf_block_sum2(double &a, double &b, double *sh /
 
 // K6: one thread per cell, grid-stride.  fp64 math whatever the field precision.
 // INV: h[0..2] hold the invariants mu1, mu2, mu3 of the tensor (written by k_c2r_invariants) instead of its components
-template <typename F, bool FAST, bool TAB = false, bool INV = false>
+// SNG: ell() of an ELL_SNG build without TABULATED_CT (src/collapse_times.c:416-426): the ellipsoid of every cell is
+// integrated on its own (pf_sng_core.h)
+template <typename F, bool FAST, bool TAB = false, bool INV = false, bool SNG = false>
 __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
   __shared__ double sk[TAB ? PF_CT_NBINS_D : 5 * PF_MAX_KNOTS];
   __shared__ double red[2 * (PF_CELL_BLOCK / 64)];
@@ -58,6 +60,11 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
   if (!TAB) { sv.y = sk + PF_MAX_KNOTS; sv.c = sk + 2 * PF_MAX_KNOTS; sv.b = sk + 3 * PF_MAX_KNOTS; sv.d = sk + 4 * PF_MAX_KNOTS; }
   else sv.y = sv.c = sv.b = sv.d = sk;
   sv.n = nk;
+  pf_sng_cosmo sc;
+  if (SNG) {
+    sc.Omega0 = p.ct.sng_cosmo[0]; sc.OmegaLambda = p.ct.sng_cosmo[1]; sc.OmegaRad = p.ct.sng_cosmo[2]; sc.OmegaK = p.ct.sng_cosmo[3];
+    sc.FR0 = p.ct.sng_cosmo[4]; sc.H_over_c = p.ct.sng_cosmo[5]; sc.size = p.ct.sng_cosmo[6];
+  }
   if (!TAB && !p.no_lut) { sv.lut = slut; sv.lut_inv_w = (double)PF_SPLINE_LUT_BINS / (sk[nk - 1] - sk[0]); }
 
   const F *__restrict__ h0 = (const F *)p.h[0], *__restrict__ h1 = (const F *)p.h[1],
@@ -93,7 +100,10 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
       have_lam = pf_ordered_eigenvalues<FAST>(d, lam);
     }
     // TABULATED_CT: the same eigenvalues, then the table instead of ell() (src/collapse_times.c:749)
-    const double Fnew = !have_lam ? -10.0 : TAB ? pf_interpolate_collapse_time(tv, lam[0], lam[1], lam[2]) : pf_ell<FAST>(sv, lam[0], lam[1], lam[2]);
+    const double Fnew = !have_lam ? -10.0
+                        : TAB   ? pf_interpolate_collapse_time(tv, lam[0], lam[1], lam[2])
+                        : SNG   ? pf_ell_sng_F(lam[0], lam[1], lam[2], p.ct.sng_Din, sc)
+                                : pf_ell<FAST>(sv, lam[0], lam[1], lam[2]);
     if ((double)fold < Fnew) {
       p.fmax[i] = (float)Fnew;
       p.rmax[i] = p.ismooth;
@@ -114,6 +124,9 @@ template <typename F, bool FAST>
 __global__ void __launch_bounds__(PF_CELL_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) k_collapse(const PfCollapseParams p) { pf_collapse_body<F, FAST>(p); }
 template <typename F, bool FAST>
 __global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse_tab(const PfCollapseParams p) { pf_collapse_body<F, FAST, true>(p); }
+// ELL_SNG per cell: thousands of dependent steps per thread, lanes of a wave finish at different times -- small workgroups
+template <typename F, bool FAST>
+__global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse_sng(const PfCollapseParams p) { pf_collapse_body<F, FAST, false, false, true>(p); }
 // the solve on the three invariants per cell that k_c2r_invariants leaves in h[0..2] (fp64 fields)
 template <bool FAST>
 __global__ void __launch_bounds__(PF_CELL_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) k_collapse_inv(const PfCollapseParams p) { pf_collapse_body<double, FAST, false, true>(p); }
@@ -480,6 +493,17 @@ int pf_launch_collapse(int fb, const PfCollapseParams &p, hipStream_t st) {
     } else {
       if (p.fast) hipLaunchKernelGGL((k_collapse_tab<float, true>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
       else hipLaunchKernelGGL((k_collapse_tab<float, false>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
+    }
+    return PF_CHECK_LAUNCH();
+  }
+  if (p.sng) {
+    if (p.invariants) return 2;
+    if (fb == 8) {
+      if (p.fast) hipLaunchKernelGGL((k_collapse_sng<double, true>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
+      else hipLaunchKernelGGL((k_collapse_sng<double, false>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
+    } else {
+      if (p.fast) hipLaunchKernelGGL((k_collapse_sng<float, true>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
+      else hipLaunchKernelGGL((k_collapse_sng<float, false>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
     }
     return PF_CHECK_LAUNCH();
   }

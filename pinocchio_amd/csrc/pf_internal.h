@@ -127,6 +127,7 @@ struct PfCollapseParams {
   int no_lut;           // 1: plain bisection in the spline lookup (PF_SPLINE_LUT=0)
   int invariants;       // 1: h[0..2] hold mu1, mu2, mu3 (k_c2r_invariants), h[3..5] unused
   int tabulated;        // 1: F from the collapse-time table `ct` (TABULATED_CT build) instead of the direct solve
+  int sng;              // 1: ELL_SNG without a table -- one RKF45 integration per cell, cosmology and D_in in ct.sng_*
   PfCtDev ct;
 };
 int pf_launch_ct_build(const PfSplineDev &sp, const PfCtDev &ct, int fast, int compute_table, hipStream_t st);

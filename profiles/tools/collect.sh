@@ -1,18 +1,17 @@
 #!/bin/bash
 # Round artefacts in one gpurun call (run from the repo root ON THE GPU BOX):
 #   profiles/tools/collect.sh r02
-# 1. smoke()  2. default bench line  3. rocprofv3 --kernel-trace --stats of a bench command  4. counter passes of one bench
+# 1. smoke()  2. rocprofv3 --kernel-trace --stats of a bench command  3. counter passes of one bench
 # step, each in its own run with --kernel-trace only (gpurun refuses --pmc together with other trace domains):
 # FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU SQ_WAVES | SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES | GRBM_GUI_ACTIVE
-# 5. profiles/tools/summarise.py -> gpurun_out/<round>_*.json / .csv, to be copied into profiles/ and committed.
+# 4. profiles/tools/summarise.py -> gpurun_out/<round>_*.json / .csv, to be copied into profiles/ and committed
+# 5. the default bench line (python3 bench.py), which then carries the counters of step 3.
 # The profiled program is `python3 bench.py ...` directly after `--` (no env / bash -c hop: the profiler has initialised the GPU).
 tag=${1:-r02}
 R=$PWD
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-timeout 1500 python3 bench.py > gpurun_out/${tag}_bench_default.json 2> gpurun_out/${tag}_bench_default.err
-tail -c 400 gpurun_out/${tag}_bench_default.json; echo
 rm -rf gpurun_out/prof_${tag} gpurun_out/pmc_${tag}_*
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag} -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-n 0 --exact-steps 0 \
@@ -29,3 +28,8 @@ pmc busy SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES
 pmc clk GRBM_GUI_ACTIVE
 cd $R
 python3 profiles/tools/summarise.py $tag
+# the default bench line last, with the counter summaries of THIS box and THESE kernel sources in place (bench.py attaches
+# roofline.traffic / valu only from profiles stamped with the sources it runs)
+cp gpurun_out/${tag}_pmc_traffic.json gpurun_out/${tag}_pmc_valu.json gpurun_out/${tag}_kernel_stats.csv profiles/
+timeout 1500 python3 bench.py > gpurun_out/${tag}_bench_default.json 2> gpurun_out/${tag}_bench_default.err
+tail -c 400 gpurun_out/${tag}_bench_default.json; echo

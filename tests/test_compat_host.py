@@ -188,7 +188,7 @@ def test_dump_and_read_products_round_trip_and_formats(lib, tmp_path, capfd):
     assert rec.shape == (n ** 3,)
 
 
-@pytest.mark.parametrize("flags", [[], ["-DSCALE_DEPENDENT"], ["-DTABULATED_CT"], ["-DTABULATED_CT", "-DELL_SNG"],
+@pytest.mark.parametrize("flags", [[], ["-DSCALE_DEPENDENT"], ["-DTABULATED_CT"], ["-DELL_SNG"], ["-DTABULATED_CT", "-DELL_SNG"],
                                    ["-DTABULATED_CT", "-DELL_SNG", "-DMOD_GRAV_FR", "-DFR0=1e-5"],
                                    ["-DRECOMPUTE_DISPLACEMENTS", "-DSCALE_DEPENDENT"]])
 def test_in_tree_build_of_the_adapter_type_checks(flags):
