@@ -65,6 +65,7 @@ def symbol_of(cls: str, n: int, fb: int, fast: bool = True) -> str:
         return f"k_c2r_persistent<{F}, {n}, {tl}>"
     return {"zpass_c2r_hess_6to3inv": f"k_c2r_invariants<{n}, 0>", "zpass_c2r_hess_6_lpt3b": f"k_c2r_invariants<{n}, 1>",
             "collapse": f"k_collapse<{F}, {b}>", "collapse_inv": f"k_collapse_inv<{b}>", "lpt_sources": f"k_lpt_sources<{F}>",
+            "collapse_lpt_sources": f"k_collapse_src<{F}, {b}>",
             "lpt_accum": f"k_lpt_accum<{F}>", "zpass_r2c": f"k_r2c<{F}, {n}, {tl}>"}.get(cls, cls)
 
 
@@ -173,10 +174,7 @@ def main():
     radii = synth.radii_ladder(ns)
 
     def step(ctx):
-        tv = ctx.sweep(radii)
-        if lpt:
-            ctx.compute_displacements(1, 0)
-        return tv
+        return ctx.compute_fmax(radii, do_lpt=lpt)   # the sweep, then compute_displacements(1, 0) as src/fmax.c:36-190
 
     def fence(ctx):
         ctx.synchronize()

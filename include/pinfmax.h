@@ -189,6 +189,12 @@ int pf_ct_load(pf_ctx *ctx, int ismooth, double variance, const double *table_ho
    Rsmooth = Radius/CellSize, src/fmax.c:233) second derivatives + collapse
    times; Smoothing.TrueVariance[0..ns-1] out (src/collapse_times.c:670). */
 int pf_sweep(pf_ctx *ctx, int ns, const double *radius_cells, double *true_variance);
+/* compute_fmax goes straight from the last radius to compute_displacements(1, 0, z) (src/fmax.c:150-163): with on != 0 the
+   collapse pass of the last radius of every following pf_sweep also writes the 2LPT / 3LPT sources of src/LPT.c:64-93
+   from the six components it holds, and the next pf_displacements(1, 0) starts from them instead of reading the six
+   fields again (same arithmetic, same sums: results do not change).  Off by default: a sweep that is not followed by
+   the displacements would write three fields for nothing. */
+int pf_set_sources_in_sweep(pf_ctx *ctx, int on);
 /* compute_second_derivatives (src/fmax.c:225-258): six Hessian fields at one radius */
 int pf_second_derivatives(pf_ctx *ctx, double radius_cells);
 /* compute_collapse_times (src/collapse_times.c:431-673) on the resident Hessian */

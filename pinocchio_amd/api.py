@@ -146,7 +146,11 @@ class Fmax:
 
     def compute_fmax(self, radii_cells, do_lpt: bool = True) -> np.ndarray:
         """compute_fmax (src/fmax.c:36-190): sweep, then compute_displacements(1,0,z)"""
-        tv = self.sweep(radii_cells)
+        self._chk(self.L.pf_set_sources_in_sweep(self.h, 1 if do_lpt else 0))
+        try:
+            tv = self.sweep(radii_cells)
+        finally:
+            self.L.pf_set_sources_in_sweep(self.h, 0)
         if do_lpt:
             self.compute_displacements(1, 0)
         return tv

@@ -66,12 +66,13 @@ extern "C" const char *pf_last_error(void) { return g_err; }
 enum {
   KS_XPASS_HESS = 0, KS_YPASS_HESS, KS_ZPASS_HESS, KS_COLLAPSE, KS_LPT_SRC, KS_LPT_ACC, KS_R2C_Z, KS_YPASS_FWD,
   KS_XPASS_FWD, KS_XPASS_DISP, KS_YPASS_DISP, KS_ZPASS_DISP, KS_XPASS_PLAIN, KS_YPASS_PLAIN, KS_ZPASS_PLAIN,
-  KS_EXCHANGE, KS_MISC, KS_ZCOLLAPSE, KS_ZPASS_INV, KS_COLLAPSE_INV, KS_ZPASS_LPT3B, KS_COUNT
+  KS_EXCHANGE, KS_MISC, KS_ZCOLLAPSE, KS_ZPASS_INV, KS_COLLAPSE_INV, KS_ZPASS_LPT3B, KS_COLLAPSE_SRC, KS_COUNT
 };
 static const char *ks_names[KS_COUNT] = {
     "xpass_hess_1to3", "ypass_hess_3to6", "zpass_c2r_hess_6", "collapse", "lpt_sources", "lpt_accum", "zpass_r2c",
     "ypass_fwd", "xpass_fwd", "xpass_disp_1to2", "ypass_disp_2to3", "zpass_c2r_disp_3", "xpass_plain", "ypass_plain",
-    "zpass_c2r_plain", "exchange", "misc", "zpass_collapse_fused", "zpass_c2r_hess_6to3inv", "collapse_inv", "zpass_c2r_hess_6_lpt3b"};
+    "zpass_c2r_plain", "exchange", "misc", "zpass_collapse_fused", "zpass_c2r_hess_6to3inv", "collapse_inv", "zpass_c2r_hess_6_lpt3b",
+    "collapse_lpt_sources"};
 
 struct EvPair { int kind; hipEvent_t a, b; double bytes; };
 
@@ -127,6 +128,10 @@ struct pf_ctx {
   PfCtDev ct;
   double *ct_block;    // delta | alpha | gamma | y | b | c | d
   bool have_density, have_hessian, have_sources, products_init;
+  // pf_set_sources_in_sweep: the solve of a sweep's last radius also writes the LPT sources (S[0..2], real space) and the
+  // sum of S2; sources_fresh says they are what pf_displacements(1, 0) would compute from the Hessian in B
+  bool sweep_sources, sources_fresh;
+  double *partials_src;  // PF_NBLK
   // general path: grid sizes that are not a power of two (one rank, fp64) go through library transforms
   bool general;
   void *W;                  // scratch spectrum of the filter
@@ -281,6 +286,7 @@ static int create_body(pf_ctx *c, const pf_config *cfg) {
   PFCHK(c, dev_alloc(c, (void **)&c->rmax, nc * sizeof(int)));
   PFCHK(c, dev_alloc(c, (void **)&c->vel12, 12 * nc * sizeof(float)));
   PFCHK(c, dev_alloc(c, (void **)&c->partials, 2 * PF_NBLK * sizeof(double)));
+  PFCHK(c, dev_alloc(c, (void **)&c->partials_src, PF_NBLK * sizeof(double)));
   PFCHK(c, dev_alloc(c, (void **)&c->scal, SC_COUNT * sizeof(double)));
   PFCHK(c, dev_alloc(c, (void **)&c->hist, PF_NBINS * sizeof(unsigned long long)));
   PFCHK(c, dev_alloc(c, (void **)&c->spl, (size_t)(PF_MAX_SMOOTH + 1) * 5 * PF_KNOT_CAP * sizeof(double)));
@@ -329,6 +335,7 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   c->dev_bytes = 0; c->own_stream = true; c->stream = nullptr;
   c->a2a = nullptr; c->a2av = nullptr; c->a2av_user = nullptr; c->ared = nullptr; c->a2a_user = c->ared_user = nullptr; c->rccl = nullptr;
   c->have_density = c->have_hessian = c->have_sources = c->products_init = false; c->last_ns = 0;
+  c->sweep_sources = c->sources_fresh = false; c->partials_src = nullptr;
   c->vel_zero_pending = false;
   memset(c->ks_ms, 0, sizeof(c->ks_ms)); memset(c->ks_bytes, 0, sizeof(c->ks_bytes)); memset(c->ks_n, 0, sizeof(c->ks_n));
   memset(&c->cpu, 0, sizeof(c->cpu)); memset(c->spl_set, 0, sizeof(c->spl_set)); memset(c->spl_n, 0, sizeof(c->spl_n));
@@ -362,7 +369,7 @@ extern "C" int pf_destroy(pf_ctx *c) {
   hipFree(c->dk); hipFree(c->blockA); hipFree(c->recvA); hipFree(c->tw); hipFree(c->blockA2); hipFree(c->recvA2);
   for (int i = 0; i < 6; i++) { hipFree(c->B[i]); hipFree(c->B2[i]); }
   for (int i = 0; i < 3; i++) hipFree(c->S[i]);
-  hipFree(c->fmax); hipFree(c->rmax); hipFree(c->vel12); hipFree(c->partials); hipFree(c->scal); hipFree(c->hist); hipFree(c->spl); hipFree(c->gtab); hipFree(c->etab); hipFree(c->ct_block); hipFree(c->W);
+  hipFree(c->fmax); hipFree(c->rmax); hipFree(c->vel12); hipFree(c->partials); hipFree(c->partials_src); hipFree(c->scal); hipFree(c->hist); hipFree(c->spl); hipFree(c->gtab); hipFree(c->etab); hipFree(c->ct_block); hipFree(c->W);
   pf_gfft_destroy(c->fft_c2r); pf_gfft_destroy(c->fft_r2c);
   for (auto &e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   for (auto &e : c->phase_evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -842,7 +849,7 @@ extern "C" int pf_set_density(pf_ctx *c, const double *kd) {
   // boundary layout: this rank's x-slab [nxl][n][nzh] (non-transposed PFFT output, src/fmax-pfft.c:366)
   PFCHK(c, import_spec(c, kd, c->dk));
   PFCHK(c, dc_of_host_spec(c, kd, SC_DC_DK));
-  c->have_density = true; c->have_hessian = false; c->have_sources = false;
+  c->have_density = true; c->have_hessian = false; c->have_sources = false; c->sources_fresh = false;
   return 0;
 }
 
@@ -867,7 +874,7 @@ extern "C" int pf_synth_density(pf_ctx *c, uint64_t seed, double sigma0, double 
   PFCHK(c, pf_launch_shape(c->fb, p, c->stream));
   HIPCHK(c, hipMemsetAsync(c->scal + SC_DC_DK, 0, sizeof(double), c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->have_density = true; c->have_hessian = false; c->have_sources = false;
+  c->have_density = true; c->have_hessian = false; c->have_sources = false; c->sources_fresh = false;
   return 0;
 }
 
@@ -883,7 +890,7 @@ extern "C" int pf_genic_density(pf_ctx *c, const pf_genic_params *p) {
   HIPCHK(c, hipMemsetAsync(c->scal + SC_DC_DK, 0, sizeof(double), c->stream));  // the DC mode is left at zero
   HIPCHK(c, hipStreamSynchronize(c->stream));
   hipFree(dseed);
-  c->have_density = true; c->have_hessian = false; c->have_sources = false;
+  c->have_density = true; c->have_hessian = false; c->have_sources = false; c->sources_fresh = false;
   return 0;
 }
 
@@ -1019,11 +1026,12 @@ extern "C" int pf_second_derivatives(pf_ctx *c, double rs) {
   if (!c->have_density) return pf_fail(c->rank, "pf_second_derivatives: density not set");
   PhaseTimer pt(c, 0);
   PFCHK(c, hessian_of(c, c->dk, rs, c->scal + SC_DC_DK, c->B));
-  c->have_hessian = true;
+  c->have_hessian = true; c->sources_fresh = false;
   return 0;
 }
 
-static int collapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], hipStream_t st, bool build_table = true, bool invariants = false) {
+static int collapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], hipStream_t st, bool build_table = true, bool invariants = false,
+                            bool sources = false) {
   PfCollapseParams p; memset(&p, 0, sizeof(p));
   for (int i = 0; i < 6; i++) p.h[i] = H[i];
   p.pitch = rpitch(c); p.nrows = (long long)c->nxl * c->n; p.n = c->n; p.fmax = c->fmax; p.rmax = c->rmax; p.ismooth = ismooth;
@@ -1049,11 +1057,21 @@ static int collapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], hipStream_
   size_t nb = (ncell(c) + 255) / 256; if (nb > (size_t)c->collapse_blocks) nb = c->collapse_blocks;
   p.nblocks = (int)nb;
   if (invariants) p.invariants = 1;
+  sources = sources && !invariants && !p.tabulated && !p.sng;
+  if (sources) {  // K7 in the same pass (the grid is k_lpt_sources' own: identical partial sums of S2)
+    p.sources = 1; p.src[0] = c->S[0]; p.src[1] = c->S[1]; p.src[2] = c->S[2]; p.src_partials = c->partials_src;
+    c->have_sources = false;  // S now holds real-space sources, not the resident LPT spectra
+  }
   {
-    KTimer t(c, invariants ? KS_COLLAPSE_INV : KS_COLLAPSE, (double)ncell(c) * ((invariants ? 3.0 : 6.0) * c->fb + 16.0), st);
+    KTimer t(c, sources ? KS_COLLAPSE_SRC : invariants ? KS_COLLAPSE_INV : KS_COLLAPSE,
+             (double)ncell(c) * ((invariants ? 3.0 : sources ? 9.0 : 6.0) * c->fb + 16.0), st);
     PFCHK(c, pf_launch_collapse(c->fb, p, st));
   }
   PFCHK(c, pf_launch_final_sum(c->partials, p.nblocks, c->scal + SC_VAR0 + 2 * ismooth, st));
+  if (sources) {
+    PFCHK(c, pf_launch_sum1(c->partials_src, p.nblocks, 1.0 / ((double)c->n * c->n * c->n), c->scal + SC_DC_S2, st));
+    c->sources_fresh = true;
+  }
   return 0;
 }
 
@@ -1097,6 +1115,7 @@ extern "C" int pf_collapse_times(pf_ctx *c, int ismooth, double *tv) {
 static int sweep_body(pf_ctx *c, int ns, const double *radius_cells, double *true_variance, bool six_components) {
   PhaseTimer ft(c, 4);
   PFCHK(c, products_reset(c));
+  c->sources_fresh = false;
   // (n <= 1024: the six-line workgroup of a 2048-point row would need 110 KB of dynamic LDS, a size this build never launches)
   const bool invariants_ok = c->fb == 8 && c->n <= 1024 && !c->general && c->tab_ns == 0 && c->model == 0 && c->tune.invariants && !six_components;
   HIPCHK(c, hipMemsetAsync(c->scal + SC_INV_FLAG, 0, sizeof(double), c->stream));
@@ -1113,7 +1132,7 @@ static int sweep_body(pf_ctx *c, int ns, const double *radius_cells, double *tru
       PFCHK(c, hess_yz(c, R, c->scal + SC_DC_DK, c->B, hess_band(c, radius_cells[ismooth]), inv));
     }
     PhaseTimer pt(c, 1);
-    return collapse_enqueue(c, ismooth, c->B, c->stream, true, inv);
+    return collapse_enqueue(c, ismooth, c->B, c->stream, true, inv, c->sweep_sources && ismooth == ns - 1);
   };
   if (c->general) {  // one filter + one library c2r per component, then the same collapse pass
     for (int ismooth = 0; ismooth < ns; ismooth++) {
@@ -1122,7 +1141,7 @@ static int sweep_body(pf_ctx *c, int ns, const double *radius_cells, double *tru
         PFCHK(c, g_hessian_of(c, c->dk, radius_cells[ismooth], c->B));
       }
       PhaseTimer pt(c, 1);
-      if (collapse_enqueue(c, ismooth, c->B, c->stream)) return 1;
+      if (collapse_enqueue(c, ismooth, c->B, c->stream, true, false, c->sweep_sources && ismooth == ns - 1)) return 1;
     }
   } else if (pipelined_band(c, ns, 3, pre, [&](int, int set, int f) { return recv_field(c, set, f); }, post,
                             [&](int ismooth) { return hess_band(c, radius_cells[ismooth]); })) return 1;
@@ -1151,6 +1170,11 @@ extern "C" int pf_sweep(pf_ctx *c, int ns, const double *radius_cells, double *t
   return rc;
 }
 extern "C" int pf_debug_invariant_reruns(pf_ctx *c) { return c ? c->inv_reruns : -1; }
+extern "C" int pf_set_sources_in_sweep(pf_ctx *c, int on) {
+  if (!c) return 1;
+  c->sweep_sources = on != 0;
+  return 0;
+}
 
 extern "C" int pf_displacements(pf_ctx *c, int compute_sources, int recompute_sd) {
   if (!c) return 1;
@@ -1164,12 +1188,13 @@ extern "C" int pf_displacements(pf_ctx *c, int compute_sources, int recompute_sd
   if (recompute_sd) {  // src/fmax.c:301-318
     PhaseTimer pt(c, 0);
     PFCHK(c, hessian_of(c, c->dk, 0.0, c->scal + SC_DC_DK, c->B));
-    c->have_hessian = true;
+    c->have_hessian = true; c->sources_fresh = false;
   }
   {
     PhaseTimer pt(c, 2);
     if (compute_sources) {  // src/LPT.c:46-175
       if (!c->have_hessian) return pf_fail(c->rank, "pf_displacements: second derivatives at R=0 not in place");
+      if (!c->sources_fresh) {  // (else: the sweep's last solve has left S2, S3a, the S3b start and the sum of S2)
       PfLptSrcParams sp; memset(&sp, 0, sizeof(sp));
       for (int i = 0; i < 6; i++) sp.h[i] = c->B[i];
       sp.s2 = c->S[0]; sp.s3a = c->S[1]; sp.s3b = c->S[2]; sp.pitch = rpitch(c); sp.nrows = (long long)c->nxl * c->n; sp.n = c->n;
@@ -1182,6 +1207,8 @@ extern "C" int pf_displacements(pf_ctx *c, int compute_sources, int recompute_sd
       }
       // DC of the 2LPT source spectrum = sum of S2; it passes the k-filter untouched (k^2 = 0)
       PFCHK(c, pf_launch_sum1(c->partials, sp.nblocks, 1.0 / ((double)c->n * c->n * c->n), c->scal + SC_DC_S2, c->stream));
+      }
+      c->sources_fresh = false;  // S[0] is transformed in place below
       PFCHK(c, allreduce_dev(c, c->scal + SC_DC_S2, 1, 0));
       PFCHK(c, forward_of(c, c->S[0]));
       // Hessian of the 2LPT potential contracted with the first-order one into the 3LPT(b) source (src/LPT.c:112-137).  fp64
@@ -1438,7 +1465,7 @@ extern "C" int pf_get_cputime(pf_ctx *c, pf_cputime *t) {
   resolve_events(c);
   double fft = 0;
   for (int k = 0; k < KS_COUNT; k++)
-    if (k != KS_COLLAPSE && k != KS_COLLAPSE_INV && k != KS_LPT_SRC && k != KS_LPT_ACC && k != KS_MISC) fft += 1e-3 * c->ks_ms[k];
+    if (k != KS_COLLAPSE && k != KS_COLLAPSE_INV && k != KS_COLLAPSE_SRC && k != KS_LPT_SRC && k != KS_LPT_ACC && k != KS_MISC) fft += 1e-3 * c->ks_ms[k];
   t->fft = fft;
   return 0;
 }

@@ -31,7 +31,16 @@ __device__ __forceinline__ void pf_block_sum2(double &a, double &b, double *sh /
 // INV: h[0..2] hold the invariants mu1, mu2, mu3 of the tensor (written by k_c2r_invariants) instead of its components
 // SNG: ell() of an ELL_SNG build without TABULATED_CT (src/collapse_times.c:416-426): the ellipsoid of every cell is
 // integrated on its own (pf_sng_core.h)
-template <typename F, bool FAST, bool TAB = false, bool INV = false, bool SNG = false>
+// K7 (src/LPT.c:64-93): the 2LPT source and the two 3LPT sources that need only the first-order Hessian, from one
+// cell's six components {11,22,33,12,13,23}; one definition for k_lpt_sources and for the solve that forms them in passing
+PF_HD void pf_lpt_sources_cell(const double d[6], double &src2, double &src31, double &src32) {
+  src2 = d[0] * d[1] + d[0] * d[2] + d[1] * d[2] - d[3] * d[3] - d[4] * d[4] - d[5] * d[5];
+  src31 = 3.0 * (d[0] * (d[1] * d[2] - d[5] * d[5]) - d[3] * (d[3] * d[2] - d[4] * d[5]) + d[4] * (d[3] * d[5] - d[4] * d[1]));
+  src32 = 2.0 * (d[0] + d[1] + d[2]) * src2;
+}
+// SRC: the pass of the last radius of a sweep that is followed by compute_LPT_displacements -- the cell's six components are
+// in registers anyway, so its three LPT sources are written here and k_lpt_sources (six more field reads) is not run
+template <typename F, bool FAST, bool TAB = false, bool INV = false, bool SNG = false, bool SRC = false>
 __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
   __shared__ double sk[TAB ? PF_CT_NBINS_D : 5 * PF_MAX_KNOTS];
   __shared__ double red[2 * (PF_CELL_BLOCK / 64)];
@@ -71,7 +80,8 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
           *__restrict__ h2 = (const F *)p.h[2], *__restrict__ h3 = (const F *)p.h[3],
           *__restrict__ h4 = (const F *)p.h[4], *__restrict__ h5 = (const F *)p.h[5];
   const long long ncell = p.nrows * p.n;
-  double sum = 0.0, sum2 = 0.0;
+  double sum = 0.0, sum2 = 0.0, sum_src = 0.0;
+  F *__restrict__ s2 = (F *)p.src[0], *__restrict__ s3a = (F *)p.src[1], *__restrict__ s3b = (F *)p.src[2];
   // grid-stride walk over the cells with (row, column) carried along: one 64-bit division per thread instead of one per
   // cell (the division and the address arithmetic behind it were 36 of the ~650 vector instructions a cell costs)
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -87,6 +97,14 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
     // products[].Fmax is float, compared after promotion (quirk Q2); init -10 / -1 at ismooth 0.  Loaded here, with the
     // Hessian, so that its latency hides under the solve instead of sitting between the solve and the store.
     const float fold = p.ismooth ? p.fmax[i] : -10.0f;
+    if (SRC) {
+      double src2, src31, src32;
+      pf_lpt_sources_cell(d, src2, src31, src32);
+      s2[a] = (F)src2;
+      s3a[a] = (F)src31;
+      s3b[a] = (F)src32;
+      sum_src += (double)(F)src2;
+    }
     const double delta = INV ? d[0] : d[0] + d[1] + d[2];
     sum += delta;
     sum2 += delta * delta;
@@ -117,6 +135,12 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
     p.partials[2 * blockIdx.x] = sum;
     p.partials[2 * blockIdx.x + 1] = sum2;
   }
+  if (SRC) {  // the same grid and walk as k_lpt_sources: the same partial sums
+    double dummy = 0.0;
+    __syncthreads();
+    pf_block_sum2(sum_src, dummy, red);
+    if (threadIdx.x == 0) p.src_partials[blockIdx.x] = sum_src;
+  }
 }
 
 // (four waves per SIMD = four 256-thread workgroups per CU, which the grid of 8 per CU is sized for: at most 128 VGPRs)
@@ -124,6 +148,8 @@ template <typename F, bool FAST>
 __global__ void __launch_bounds__(PF_CELL_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) k_collapse(const PfCollapseParams p) { pf_collapse_body<F, FAST>(p); }
 template <typename F, bool FAST>
 __global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse_tab(const PfCollapseParams p) { pf_collapse_body<F, FAST, true>(p); }
+template <typename F, bool FAST>
+__global__ void __launch_bounds__(PF_CELL_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) k_collapse_src(const PfCollapseParams p) { pf_collapse_body<F, FAST, false, false, false, true>(p); }
 // ELL_SNG per cell: thousands of dependent steps per thread, lanes of a wave finish at different times -- small workgroups
 template <typename F, bool FAST>
 __global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse_sng(const PfCollapseParams p) { pf_collapse_body<F, FAST, false, false, true>(p); }
@@ -244,10 +270,9 @@ __global__ void __launch_bounds__(PF_CELL_BLOCK) k_lpt_sources(const PfLptSrcPar
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < ncell; i += (long long)gridDim.x * blockDim.x) {
     const long long row = i / p.n;
     const long long a = row * p.pitch + (i - row * p.n);
-    const double d0 = h0[a], d1 = h1[a], d2 = h2[a], d3 = h3[a], d4 = h4[a], d5 = h5[a];
-    const double src2 = d0 * d1 + d0 * d2 + d1 * d2 - d3 * d3 - d4 * d4 - d5 * d5;
-    const double src31 = 3.0 * (d0 * (d1 * d2 - d5 * d5) - d3 * (d3 * d2 - d4 * d5) + d4 * (d3 * d5 - d4 * d1));
-    const double src32 = 2.0 * (d0 + d1 + d2) * src2;
+    const double d[6] = {(double)h0[a], (double)h1[a], (double)h2[a], (double)h3[a], (double)h4[a], (double)h5[a]};
+    double src2, src31, src32;
+    pf_lpt_sources_cell(d, src2, src31, src32);
     s2[a] = (F)src2;
     s3a[a] = (F)src31;
     s3b[a] = (F)src32;
@@ -493,6 +518,17 @@ int pf_launch_collapse(int fb, const PfCollapseParams &p, hipStream_t st) {
     } else {
       if (p.fast) hipLaunchKernelGGL((k_collapse_tab<float, true>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
       else hipLaunchKernelGGL((k_collapse_tab<float, false>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
+    }
+    return PF_CHECK_LAUNCH();
+  }
+  if (p.sources) {
+    if (p.invariants || p.tabulated || p.sng) return 2;
+    if (fb == 8) {
+      if (p.fast) hipLaunchKernelGGL((k_collapse_src<double, true>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
+      else hipLaunchKernelGGL((k_collapse_src<double, false>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
+    } else {
+      if (p.fast) hipLaunchKernelGGL((k_collapse_src<float, true>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
+      else hipLaunchKernelGGL((k_collapse_src<float, false>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
     }
     return PF_CHECK_LAUNCH();
   }

@@ -128,6 +128,11 @@ struct PfCollapseParams {
   int invariants;       // 1: h[0..2] hold mu1, mu2, mu3 (k_c2r_invariants), h[3..5] unused
   int tabulated;        // 1: F from the collapse-time table `ct` (TABULATED_CT build) instead of the direct solve
   int sng;              // 1: ELL_SNG without a table -- one RKF45 integration per cell, cosmology and D_in in ct.sng_*
+  // sources: the same pass also forms the 2LPT / 3LPT sources of the cell from the six components it holds (what
+  // k_lpt_sources computes, src/LPT.c:64-93) -- fields of type F in src[0..2], per-block sums of S2 in src_partials
+  int sources;
+  void *src[3];
+  double *src_partials;
   PfCtDev ct;
 };
 int pf_launch_ct_build(const PfSplineDev &sp, const PfCtDev &ct, int fast, int compute_table, hipStream_t st);

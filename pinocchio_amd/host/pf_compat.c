@@ -404,7 +404,11 @@ int compute_fmax(void) {
         if (pf_second_derivatives(pf_context, rs[ismooth]) || initialize_collapse_times(ismooth, 0) ||
             compute_collapse_times(ismooth) || reset_collapse_times(ismooth)) { free(rs); return 1; }
       }
-    } else if (pf_sweep(pf_context, Smoothing.Nsmooth, rs, Smoothing.TrueVariance)) { free(rs); return 1; }
+    } else { /* compute_displacements(1, 0, z) follows at once (src/fmax.c:150-163): the last radius leaves the LPT sources */
+      int rc = pf_set_sources_in_sweep(pf_context, 1) || pf_sweep(pf_context, Smoothing.Nsmooth, rs, Smoothing.TrueVariance);
+      pf_set_sources_in_sweep(pf_context, 0);
+      if (rc) { free(rs); return 1; }
+    }
     free(rs);
     /* the radii run back to back on the device: the log keeps the reference's two lines per radius (src/fmax.c:66-69,
        141-145), with the sweep's wall time shared evenly */

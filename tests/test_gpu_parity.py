@@ -446,6 +446,48 @@ def test_fused_3lpt_source_equals_separate_kernels(api, n, monkeypatch):
     assert np.abs(out["1"]["Vel_3LPT_2"]).max() > 0
 
 
+@pytest.mark.parametrize("fb", [8, 4])
+@pytest.mark.parametrize("n", [16, 64, 256])
+def test_sources_formed_by_the_last_solve_equal_the_separate_kernel(api, n, fb):
+    """compute_fmax (sweep + compute_displacements(1, 0) back to back, src/fmax.c:150-163): the collapse pass of the last radius
+    also writes the three LPT sources of src/LPT.c:64-93 from the six components it holds (k_collapse_src) and
+    k_lpt_sources is not run; sweep() and compute_displacements(1, 0) called apart run the separate kernel.  One per-cell
+    function, the same grid and walk for the sum of S2: the LPT spectra and every product column bit for bit.  Afterwards the
+    separate kernel must still serve a second compute_displacements(1, 0) and one after new second derivatives."""
+    dk = synth.make_density(n, seed=21 + n)
+    dk[0, 0, 0] = 0.1 * n ** 3
+    x, y = synth.invgrow_table("lcdm")
+    radii = np.array([2.0, 0.7, 0.0])
+    out = {}
+    for mode in ("apart", "together"):
+        with api.Fmax(n, field_bytes=fb, timing=True) as f:
+            f.set_density(dk)
+            f.set_invgrow(x, y)
+            f.set_growth(synth.growth_multipliers())
+            f.reset_kernel_stats()
+            if mode == "apart":
+                tv = f.sweep(radii)
+                f.compute_displacements(1, 0)
+            else:
+                tv = f.compute_fmax(radii, do_lpt=True)
+            classes = {k["name"] for k in f.kernel_stats()}
+            assert ("collapse_lpt_sources" in classes) == (mode == "together") and ("lpt_sources" in classes) == (mode == "apart"), classes
+            out[mode] = (tv, f.products(), [f.kvector(w) for w in (0, 1, 2)])
+            if mode == "together":
+                f.compute_displacements(1, 0)              # again: the sources are gone (transformed in place), the kernel runs
+                again = f.products()
+                f.compute_second_derivatives(0.0)
+                f.compute_displacements(1, 0)
+                after = f.products()
+    assert np.array_equal(out["apart"][0], out["together"][0])
+    for name in ("Fmax", "Rmax", "Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+        assert np.array_equal(out["apart"][1][name], out["together"][1][name]), name
+        assert np.array_equal(out["apart"][1][name], again[name]) and np.array_equal(out["apart"][1][name], after[name]), name
+    for a, b in zip(out["apart"][2], out["together"][2]):
+        assert np.array_equal(a, b)
+    assert np.abs(out["together"][1]["Vel_2LPT"]).max() > 0
+
+
 def test_pruned_transform_equals_full_transform(api, monkeypatch):
     """Smoothed radii use a pruned FFT: modes whose Gaussian weight is < 2^-60 are not transformed.
     Against the full transform (PF_PRUNE_EPS=0) the Hessian changes by less than its own rounding."""
