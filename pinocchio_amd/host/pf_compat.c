@@ -113,6 +113,7 @@ int reset_collapse_times(int ismooth);
 
 static pf_ctx *pf_context = NULL;
 static int pf_density_on_device = 0; /* set by pf_compat_genic: kdensity[0] is not uploaded */
+static int pf_inputs_on_device = 0;  /* the context holds the density and the inverse-growth spline(s) (pf_upload_inputs) */
 static int pf_device_of_rank = -1; /* -1: rank % visible devices */
 
 /* lets a launcher pin ranks to devices before compute_fft_plans (e.g. from SLURM_LOCALID) */
@@ -211,6 +212,7 @@ int finalize_fft(void) {
     pf_destroy(pf_context);
     pf_context = NULL;
     pf_density_on_device = 0;
+    pf_inputs_on_device = 0;
   }
 #endif
   return 0;
@@ -255,6 +257,7 @@ static int pf_upload_inputs(void) {
                          (int)pf_invgrow_knots_radius[ismooth].size)) return 1;
   } else if (pf_set_invgrow(pf_context, -1, PF_KNOTS_X, PF_KNOTS_Y, PF_KNOTS_N)) return 1;
 #endif
+  pf_inputs_on_device = 1;
   return 0;
 }
 
@@ -358,7 +361,9 @@ int Fmax_PDF(void);
 int compute_displacements(int compute_sources, int recompute_sd, double redshift) {
   double cputmp = pf_wtime();
   if (!ThisTask) printf("\n[%s] Computing LPT displacements\n", fdate());
-  if (!pf_context && pf_upload_inputs()) return 1;
+  /* "pinocchio.x parameterfile 3" (src/pinocchio.c:172-187) comes here straight from the initialisation: plans made, nothing
+     uploaded yet */
+  if ((!pf_context || !pf_inputs_on_device) && pf_upload_inputs()) return 1;
   ScaleDep.redshift = redshift;
   if (pf_upload_growth(redshift)) return 1;
   if (pf_displacements(pf_context, compute_sources, recompute_sd)) return 1;

@@ -282,6 +282,68 @@ def test_compute_fmax_like_the_reference_driver(lib, tmp_path):
 
 
 @pytest.mark.gpu
+def test_lpt_snapshot_mode_goes_straight_to_the_displacements(lib, tmp_path):
+    """"pinocchio.x parameterfile 3" (src/pinocchio.c:172-200, the N-body initial-condition mode of
+    tests/Readme_Pinocchio_tests_V5_1.txt): after the initialisation (plans made) the driver calls
+    compute_displacements(1, 1, outputs.z[0]) -- second derivatives at R = 0 recomputed, sources, twelve displacement fields --
+    and hands the host `products` to write_LPT_snapshot; compute_fmax never runs.  Against the oracle's
+    compute_second_derivatives(0) + compute_LPT_displacements + first derivatives."""
+    n = 32
+    dk = np.ascontiguousarray(synth.make_density(n, seed=77))
+    g = np.array([0.61, -0.21, 0.017, -0.043])      # growth multipliers at the snapshot's redshift
+    x, y = synth.invgrow_table("lcdm")
+    assert lib.finalize_fft() == 0                   # whatever an earlier test left behind
+    grid = C.cast(C.c_void_p.in_dll(lib, "MyGrids"), C.POINTER(Grid)).contents
+    for i in range(3):
+        grid.GSglobal[i] = n
+    grid.Ntotal = n ** 3
+    grid.BoxSize = n * 2.0
+    assert lib.set_one_grid(0) == 0
+    prod = np.zeros(n ** 3 * 56 + 64, dtype=np.uint8)
+    prod = prod[(-prod.ctypes.data) % 32:][:n ** 3 * 56]
+    C.c_void_p.in_dll(lib, "products").value = prod.ctypes.data
+    kd = C.cast(C.c_void_p.in_dll(lib, "kdensity"), C.POINTER(C.c_void_p))
+    kd[0] = dk.ctypes.data
+    sm = Smoothing.in_dll(lib, "Smoothing")
+    radii = np.array([2.0, 0.0]); tv = np.zeros(2); var = np.ones(2)
+    sm.Nsmooth = 2
+    sm.Radius = radii.ctypes.data_as(C.POINTER(C.c_double))
+    sm.Variance = var.ctypes.data_as(C.POINTER(C.c_double))
+    sm.TrueVariance = tv.ctypes.data_as(C.POINTER(C.c_double))
+    kn = Knots.in_dll(lib, "pf_invgrow_knots")
+    kn.size = len(x)
+    kn.x = x.ctypes.data_as(C.POINTER(C.c_double))
+    kn.y = y.ctypes.data_as(C.POINTER(C.c_double))
+    fns = [GROWTH_FN(lambda z, k, v=v: float(v) if z == 49.0 else float("nan")) for v in g]
+    for name, fn in zip(("pf_GrowingMode", "pf_GrowingMode_2LPT", "pf_GrowingMode_3LPT_1", "pf_GrowingMode_3LPT_2"), fns):
+        C.c_void_p.in_dll(lib, name).value = C.cast(fn, C.c_void_p).value
+    par = Params.in_dll(lib, "params")
+    par.RunFlag = b"pfsnap"
+    par.GridSize[0] = par.GridSize[1] = par.GridSize[2] = n
+    C.c_int.in_dll(lib, "pf_compat_scale_dependent").value = 0
+    C.c_int.in_dll(lib, "pf_compat_tabulated_ct").value = 0
+    C.c_int.in_dll(lib, "pf_compat_ell_sng").value = 0
+    lib.compute_displacements.argtypes = [C.c_int, C.c_int, C.c_double]
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        assert lib.compute_fft_plans() == 0          # initialization() -> set_grids -> compute_fft_plans
+        assert lib.compute_displacements(1, 1, 49.0) == 0
+        assert lib.finalize_fft() == 0
+    finally:
+        os.chdir(cwd)
+    p = prod.view(oracle_lib.PRODUCT_DTYPE).reshape(n, n, n)
+    o = oracle_lib.Oracle(n, 0)
+    o.set_density(dk); o.set_invgrow(x, y); o.set_growth(g)
+    o.second_derivatives(0.0)
+    o.displacements(compute_sources=True)
+    po = o.products()
+    for name in ("Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+        amp = np.max(np.abs(po[name]))
+        assert amp > 0 and np.max(np.abs(p[name].astype(np.float64) - po[name])) <= 4e-7 * amp, name
+
+
+@pytest.mark.gpu
 def test_genic_on_device_through_the_reference_driver(lib, tmp_path):
     """GenIC_large replaced by pf_compat_genic: no kdensity[0] on the host at all; same sigma and Fmax as the oracle
     fed with the restated generator's field"""
