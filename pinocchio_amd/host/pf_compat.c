@@ -719,7 +719,8 @@ static void write_CTtable_header(void) { /* :1300-1340 */
 int initialize_collapse_times(int ismooth, int onlycompute) {
   int fail = 0, dummy;
   char fname[LBLENGTH];
-  if (!pf_context && pf_upload_inputs()) return 1;
+  /* also the first call of "pinocchio.x parameterfile 1" (src/pinocchio.c:100-131): plans made, nothing uploaded yet */
+  if ((!pf_context || !pf_inputs_on_device) && pf_upload_inputs()) return 1;
   if (!pf_ct_host) pf_ct_host = (double *)malloc(sizeof(double) * PF_CT_NCOMP);
   if (!ismooth && !ThisTask)
     printf("[%s] Grid for interpolating collapse times: CT_NBINS_D=%d, CT_NBINS_XY=%d\n", fdate(), PF_CT_NBINS_D, PF_CT_NBINS_XY);

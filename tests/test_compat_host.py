@@ -671,6 +671,16 @@ def test_tabulated_ct_build_through_the_reference_driver(lib, tmp_path):
         assert lib.compute_fft_plans() == 0
         assert lib.compute_fmax() == 0
         assert np.array_equal(check(), first)
+        # "pinocchio.x parameterfile 1" (src/pinocchio.c:100-131): straight from the initialisation, only the tables of all
+        # radii, written to params.CTtableFile itself
+        only = tmp_path / "only.CTtable"
+        par.CTtableFile = str(only).encode()
+        lib.initialize_collapse_times.argtypes = [C.c_int, C.c_int]
+        assert lib.finalize_fft() == 0 and lib.compute_fft_plans() == 0
+        for i in range(len(radii_mpc)):
+            assert lib.initialize_collapse_times(i, 1) == 0
+        assert lib.finalize_fft() == 0
+        assert only.read_bytes() == raw
         # -DELL_SNG: the same flow with the table filled by the ODE model (type code 3 in the file header)
         cosmo = np.array([0.25, 0.75, 0.0, 0.0])
         d_in = np.array([float(g[0]) * 1.28e-5] * len(radii_mpc))
