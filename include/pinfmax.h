@@ -172,9 +172,10 @@ int pf_set_tabulated_ct(pf_ctx *ctx, int nsmooth, const double *variance);
    nine-equation system of Nadkarni-Ghosh & Singhal (2016) -- the step, error control and accept/reject logic of
    gsl_odeiv2_step_rkf45 / control_standard_new(1e-6, 1e-6, 1, 1) / evolve_apply -- with
    cosmo = {Omega0, OmegaLambda, OmegaRad, OmegaK} for OmegaMatter(z) / OmegaLambda(z) (src/cosmo.c:1675-1718) and
-   D_in[ismooth] = GrowingMode(1/1e-5 - 1, k of the radius) (:353-361).  ELL_SNG exists only together with the table
-   (250 000 integrations per radius on the device; per cell it would be ~10^9 of them): pf_sweep fails without
-   pf_set_tabulated_ct.  Standard gravity only (no MOD_GRAV_FR force modification). */
+   D_in[ismooth] = GrowingMode(1/1e-5 - 1, k of the radius) (:353-361).  With pf_set_tabulated_ct the model fills the
+   table (250 000 integrations per radius); without it -- a reference build with -DELL_SNG and no -DTABULATED_CT -- every
+   cell integrates its own ellipsoid in the collapse pass (k_collapse_sng: correct, and ~10^3 times the work of the table
+   at 1024^3).  pf_set_modified_gravity adds the MOD_GRAV_FR force modification. */
 int pf_set_collapse_model(pf_ctx *ctx, int model, const double cosmo[4], int nsmooth, const double *D_in);
 /* -DMOD_GRAV_FR on top of ELL_SNG: the force in the velocity equations is enhanced by 1 + ForceModification(size, a, delta)
    (src/collapse_times.c:271-273, 295-312), Hu-Sawicki f(R) with |f_R0| = fr0 (the FR0 of the build; 0 switches it off),
@@ -189,6 +190,12 @@ int pf_ct_load(pf_ctx *ctx, int ismooth, double variance, const double *table_ho
    Rsmooth = Radius/CellSize, src/fmax.c:233) second derivatives + collapse
    times; Smoothing.TrueVariance[0..ns-1] out (src/collapse_times.c:670). */
 int pf_sweep(pf_ctx *ctx, int ns, const double *radius_cells, double *true_variance);
+/* The reference chooses the order of the displacements at compile time (src/Makefile: -DTWO_LPT, -DTHREE_LPT;
+   src/fmax.c:300-336, src/LPT.c:30, 78, 113, 214).  order 3 (default): both; 2: -DTWO_LPT alone -- the 2LPT source and its
+   displacement, no 3LPT sources, no Hessian of the 2LPT potential; 1: neither -- Zel'dovich displacements only, no second
+   derivatives on re-entry.  Columns of orders that are not computed are zero (their fields do not exist in such a build's
+   product_data: give them negative offsets in pf_product_layout). */
+int pf_set_lpt_order(pf_ctx *ctx, int order);
 /* compute_fmax goes straight from the last radius to compute_displacements(1, 0, z) (src/fmax.c:150-163): with on != 0 the
    collapse pass of the last radius of every following pf_sweep also writes the 2LPT / 3LPT sources of src/LPT.c:64-93
    from the six components it holds, and the next pf_displacements(1, 0) starts from them instead of reading the six

@@ -163,6 +163,10 @@ class Fmax:
         self._chk(self.L.pf_collapse_times(self.h, ismooth, C.byref(tv)))
         return tv.value
 
+    def set_lpt_order(self, order: int):
+        """3: -DTWO_LPT -DTHREE_LPT (default); 2: -DTWO_LPT only; 1: Zel'dovich displacements only"""
+        self._chk(self.L.pf_set_lpt_order(self.h, int(order)))
+
     def compute_displacements(self, compute_sources: int = 1, recompute_sd: int = 0):
         self._chk(self.L.pf_displacements(self.h, int(compute_sources), int(recompute_sd)))
 

@@ -128,9 +128,11 @@ struct pf_ctx {
   PfCtDev ct;
   double *ct_block;    // delta | alpha | gamma | y | b | c | d
   bool have_density, have_hessian, have_sources, products_init;
+  int sources_order;  // LPT order the resident source spectra were made for
   // pf_set_sources_in_sweep: the solve of a sweep's last radius also writes the LPT sources (S[0..2], real space) and the
   // sum of S2; sources_fresh says they are what pf_displacements(1, 0) would compute from the Hessian in B
   bool sweep_sources, sources_fresh;
+  int lpt_order;  // 3: -DTWO_LPT -DTHREE_LPT (default), 2: -DTWO_LPT only, 1: Zel'dovich only (pf_set_lpt_order)
   double *partials_src;  // PF_NBLK
   // general path: grid sizes that are not a power of two (one rank, fp64) go through library transforms
   bool general;
@@ -335,7 +337,7 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   c->dev_bytes = 0; c->own_stream = true; c->stream = nullptr;
   c->a2a = nullptr; c->a2av = nullptr; c->a2av_user = nullptr; c->ared = nullptr; c->a2a_user = c->ared_user = nullptr; c->rccl = nullptr;
   c->have_density = c->have_hessian = c->have_sources = c->products_init = false; c->last_ns = 0;
-  c->sweep_sources = c->sources_fresh = false; c->partials_src = nullptr;
+  c->sweep_sources = c->sources_fresh = false; c->partials_src = nullptr; c->lpt_order = 3;
   c->vel_zero_pending = false;
   memset(c->ks_ms, 0, sizeof(c->ks_ms)); memset(c->ks_bytes, 0, sizeof(c->ks_bytes)); memset(c->ks_n, 0, sizeof(c->ks_n));
   memset(&c->cpu, 0, sizeof(c->cpu)); memset(c->spl_set, 0, sizeof(c->spl_set)); memset(c->spl_n, 0, sizeof(c->spl_n));
@@ -1057,7 +1059,7 @@ static int collapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], hipStream_
   size_t nb = (ncell(c) + 255) / 256; if (nb > (size_t)c->collapse_blocks) nb = c->collapse_blocks;
   p.nblocks = (int)nb;
   if (invariants) p.invariants = 1;
-  sources = sources && !invariants && !p.tabulated && !p.sng;
+  sources = sources && c->lpt_order >= 2 && !invariants && !p.tabulated && !p.sng;
   if (sources) {  // K7 in the same pass (the grid is k_lpt_sources' own: identical partial sums of S2)
     p.sources = 1; p.src[0] = c->S[0]; p.src[1] = c->S[1]; p.src[2] = c->S[2]; p.src_partials = c->partials_src;
     c->have_sources = false;  // S now holds real-space sources, not the resident LPT spectra
@@ -1170,6 +1172,12 @@ extern "C" int pf_sweep(pf_ctx *c, int ns, const double *radius_cells, double *t
   return rc;
 }
 extern "C" int pf_debug_invariant_reruns(pf_ctx *c) { return c ? c->inv_reruns : -1; }
+extern "C" int pf_set_lpt_order(pf_ctx *c, int order) {
+  if (!c) return 1;
+  if (order < 1 || order > 3) return pf_fail(c->rank, "pf_set_lpt_order: order %d (1 Zel'dovich, 2 -DTWO_LPT, 3 -DTHREE_LPT)", order);
+  c->lpt_order = order;
+  return 0;
+}
 extern "C" int pf_set_sources_in_sweep(pf_ctx *c, int on) {
   if (!c) return 1;
   c->sweep_sources = on != 0;
@@ -1185,14 +1193,14 @@ extern "C" int pf_displacements(pf_ctx *c, int compute_sources, int recompute_sd
     PFCHK(c, pf_launch_fill_products(c->fmax, c->rmax, c->vel12, ncell(c), c->stream));
     c->products_init = true;
   }
-  if (recompute_sd) {  // src/fmax.c:301-318
+  if (recompute_sd && c->lpt_order >= 2) {  // src/fmax.c:301-318 (inside #ifdef TWO_LPT)
     PhaseTimer pt(c, 0);
     PFCHK(c, hessian_of(c, c->dk, 0.0, c->scal + SC_DC_DK, c->B));
     c->have_hessian = true; c->sources_fresh = false;
   }
   {
     PhaseTimer pt(c, 2);
-    if (compute_sources) {  // src/LPT.c:46-175
+    if (compute_sources && c->lpt_order >= 2) {  // src/LPT.c:46-175 (#ifdef TWO_LPT)
       if (!c->have_hessian) return pf_fail(c->rank, "pf_displacements: second derivatives at R=0 not in place");
       if (!c->sources_fresh) {  // (else: the sweep's last solve has left S2, S3a, the S3b start and the sum of S2)
       PfLptSrcParams sp; memset(&sp, 0, sizeof(sp));
@@ -1215,7 +1223,8 @@ extern "C" int pf_displacements(pf_ctx *c, int compute_sources, int recompute_sd
       // fields: the z-pass does the contraction while it holds a row's six components (nothing of that Hessian is stored;
       // PF_LPT_FUSE=0: six fields out, then k_lpt_accum); same operations per cell either way
       const bool fuse3b = c->fb == 8 && c->n <= 1024 && !c->general && c->tune.lpt_fuse;
-      if (fuse3b) {
+      if (c->lpt_order < 3) {  // no THREE_LPT (src/LPT.c:78-92, 113-175): the 2LPT source alone
+      } else if (fuse3b) {
         PFCHK(c, hessian_of(c, c->S[0], 0.0, c->scal + SC_DC_S2, c->B2, c->S[2], c->B));
       } else {
         PFCHK(c, hessian_of(c, c->S[0], 0.0, c->scal + SC_DC_S2, c->B2));
@@ -1226,16 +1235,25 @@ extern "C" int pf_displacements(pf_ctx *c, int compute_sources, int recompute_sd
         PFCHK(c, pf_launch_lpt_accum(c->fb, ap, c->stream));
       }
       void *const s12[2] = {c->S[1], c->S[2]};
-      PFCHK(c, forward_many(c, 2, s12));
-      c->have_sources = true;
-    } else if (!c->have_sources)
+      if (c->lpt_order >= 3) PFCHK(c, forward_many(c, 2, s12));
+      c->have_sources = true; c->sources_order = c->lpt_order;
+    } else if (c->lpt_order >= 2 && (!c->have_sources || c->sources_order < c->lpt_order))
       return pf_fail(c->rank, "pf_displacements: LPT sources not resident (call with compute_sources = 1 first)");
     // ScaleDep.order = 2, 3, 4 (src/LPT.c:181-184, 219-221, 226-228), then Zel'dovich (src/fmax.c:342-345); one
     // pipeline so that with P > 1 each exchange runs beside the y/z passes of the previous field
     void *tmp[3] = {c->B2[0], c->B2[1], c->B2[2]};
-    const void *const specs[4] = {c->S[0], c->S[1], c->S[2], c->dk};
-    const int orders[4] = {1, 2, 3, 0};
-    PFCHK(c, displacements_of(c, 4, specs, orders, tmp));
+    // (a build without THREE_LPT / TWO_LPT has no such fields in product_data: their columns here are zero)
+    const void *specs[4];
+    int orders[4], count = 0;
+    if (c->lpt_order >= 2) { specs[count] = c->S[0]; orders[count++] = 1; }
+    if (c->lpt_order >= 3) { specs[count] = c->S[1]; orders[count++] = 2; specs[count] = c->S[2]; orders[count++] = 3; }
+    specs[count] = c->dk; orders[count++] = 0;
+    PFCHK(c, displacements_of(c, count, specs, orders, tmp));
+    if (c->lpt_order < 3) {
+      const size_t nc = ncell(c);
+      const int k0 = c->lpt_order == 2 ? 6 : 3;  // columns 3 o .. 3 o + 2 of order o: 0 Zel'dovich, 1 2LPT, 2 3LPT(a), 3 3LPT(b)
+      HIPCHK(c, hipMemsetAsync(c->vel12 + (size_t)k0 * nc, 0, (size_t)(12 - k0) * nc * sizeof(float), c->stream));
+    }
     c->vel_zero_pending = false;  // all twelve columns rewritten
   }
   return 0;

@@ -111,6 +111,18 @@ int reset_collapse_times(int ismooth);
 #define reset_collapse_times(a) 0
 #endif
 
+/* order of the displacements: the reference's -DTWO_LPT / -DTHREE_LPT (src/pinocchio.h:158-160: THREE_LPT implies TWO_LPT);
+   the stand-alone build has the full record and takes the order from pf_compat_lpt_order */
+#if defined(PF_IN_PINOCCHIO_TREE) && defined(THREE_LPT)
+#define PF_LPT_ORDER 3
+#elif defined(PF_IN_PINOCCHIO_TREE) && defined(TWO_LPT)
+#define PF_LPT_ORDER 2
+#elif defined(PF_IN_PINOCCHIO_TREE)
+#define PF_LPT_ORDER 1
+#else
+#define PF_LPT_ORDER pf_compat_lpt_order
+#endif
+
 static pf_ctx *pf_context = NULL;
 static int pf_density_on_device = 0; /* set by pf_compat_genic: kdensity[0] is not uploaded */
 static int pf_inputs_on_device = 0;  /* the context holds the density and the inverse-growth spline(s) (pf_upload_inputs) */
@@ -189,6 +201,7 @@ int compute_fft_plans(void) {
   cfg.flags = PF_FLAG_TIMING; /* cputime.fft like the reference (src/fmax-pfft.c:195-199) */
   if (pf_context) return 0;
   if (pf_create(&pf_context, &cfg)) return 1;
+  if (pf_set_lpt_order(pf_context, PF_LPT_ORDER)) return 1;
 #if defined(PF_IN_PINOCCHIO_TREE)
   if (NTasks > 1) { /* one rank per GPU: RCCL all-to-all replaces the MPI_Alltoall inside pfft_execute */
     char id[128];
@@ -330,16 +343,28 @@ static void pf_collect_cputime(void) {
 
 static int pf_inside_compute_fmax = 0;
 
+/* the displacement fields this build's product_data has (src/pinocchio.h:237-243) */
+static void pf_velocity_offsets(pf_product_layout *lay) {
+  lay->off_Vel = (int)offsetof(product_data, Vel);
+  lay->off_Vel_2LPT = lay->off_Vel_3LPT_1 = lay->off_Vel_3LPT_2 = -1;
+#if !defined(PF_IN_PINOCCHIO_TREE) || defined(TWO_LPT) || defined(THREE_LPT)
+  if (PF_LPT_ORDER >= 2) lay->off_Vel_2LPT = (int)offsetof(product_data, Vel_2LPT);
+#endif
+#if !defined(PF_IN_PINOCCHIO_TREE) || defined(THREE_LPT)
+  if (PF_LPT_ORDER >= 3) {
+    lay->off_Vel_3LPT_1 = (int)offsetof(product_data, Vel_3LPT_1);
+    lay->off_Vel_3LPT_2 = (int)offsetof(product_data, Vel_3LPT_2);
+  }
+#endif
+}
+
 /* re-entrant compute_displacements (src/fragment.c:398-410): only the Vel* fields of the host records change */
 static int pf_download_velocities(void) {
   pf_product_layout lay;
   lay.stride = sizeof(product_data);
   lay.off_Rmax = -1;
   lay.off_Fmax = -1;
-  lay.off_Vel = (int)offsetof(product_data, Vel);
-  lay.off_Vel_2LPT = (int)offsetof(product_data, Vel_2LPT);
-  lay.off_Vel_3LPT_1 = (int)offsetof(product_data, Vel_3LPT_1);
-  lay.off_Vel_3LPT_2 = (int)offsetof(product_data, Vel_3LPT_2);
+  pf_velocity_offsets(&lay);
   return pf_update_products(pf_context, products, &lay);
 }
 
@@ -348,10 +373,7 @@ static int pf_download_products(void) {
   lay.stride = sizeof(product_data);
   lay.off_Rmax = (int)offsetof(product_data, Rmax);
   lay.off_Fmax = (int)offsetof(product_data, Fmax);
-  lay.off_Vel = (int)offsetof(product_data, Vel);
-  lay.off_Vel_2LPT = (int)offsetof(product_data, Vel_2LPT);
-  lay.off_Vel_3LPT_1 = (int)offsetof(product_data, Vel_3LPT_1);
-  lay.off_Vel_3LPT_2 = (int)offsetof(product_data, Vel_3LPT_2);
+  pf_velocity_offsets(&lay);
   return pf_get_products(pf_context, products, &lay);
 }
 
@@ -410,7 +432,7 @@ int compute_fmax(void) {
             compute_collapse_times(ismooth) || reset_collapse_times(ismooth)) { free(rs); return 1; }
       }
     } else { /* compute_displacements(1, 0, z) follows at once (src/fmax.c:150-163): the last radius leaves the LPT sources */
-      int rc = pf_set_sources_in_sweep(pf_context, 1) || pf_sweep(pf_context, Smoothing.Nsmooth, rs, Smoothing.TrueVariance);
+      int rc = pf_set_sources_in_sweep(pf_context, PF_LPT_ORDER >= 2) || pf_sweep(pf_context, Smoothing.Nsmooth, rs, Smoothing.TrueVariance);
       pf_set_sources_in_sweep(pf_context, 0);
       if (rc) { free(rs); return 1; }
     }
@@ -631,9 +653,13 @@ void write_from_rvector_to_products(int ThisGrid, int ia, int order) {
   const double *r = rvector_fft[ThisGrid];
   switch (order) {
     case 1: for (index = 0; index < nloc; index++) products[index].Vel[ia] = r[index]; break;
+#if !defined(PF_IN_PINOCCHIO_TREE) || defined(TWO_LPT) || defined(THREE_LPT)
     case 2: for (index = 0; index < nloc; index++) products[index].Vel_2LPT[ia] = r[index]; break;
+#endif
+#if !defined(PF_IN_PINOCCHIO_TREE) || defined(THREE_LPT)
     case 3: for (index = 0; index < nloc; index++) products[index].Vel_3LPT_1[ia] = r[index]; break;
     case 4: for (index = 0; index < nloc; index++) products[index].Vel_3LPT_2[ia] = r[index]; break;
+#endif
     default: break;
   }
 }

@@ -27,6 +27,7 @@ static pfft_complex *cvector_slots[1] = {0};
 static double *rvector_slots[1] = {0};
 pfft_complex **cvector_fft = cvector_slots;
 double **rvector_fft = rvector_slots;
+int pf_compat_lpt_order = 3;    /* stand-alone build: 3 = -DTWO_LPT -DTHREE_LPT, 2 = -DTWO_LPT, 1 = neither */
 int pf_compat_tabulated_ct = 0;
 int pf_compat_ell_sng = 0;
 double (*pf_Hubble)(double) = 0;

@@ -26,14 +26,23 @@ typedef struct product_data_mirror /* src/pinocchio.h:233-259, -DTWO_LPT -DTHREE
   int       Rmax;           /* index of the smoothing radius that gave Fmax */
   PRODFLOAT Fmax;           /* 1 + z of collapse */
   PRODFLOAT Vel[3];         /* Zel'dovich displacement */
+  /* (the type-check of the in-tree branches, tests/intree_decls/, drops the fields a build without TWO_LPT / THREE_LPT lacks) */
+#if !defined(PF_IN_PINOCCHIO_TREE) || defined(TWO_LPT) || defined(THREE_LPT)
   PRODFLOAT Vel_2LPT[3];    /* 2LPT */
+#endif
+#if !defined(PF_IN_PINOCCHIO_TREE) || defined(THREE_LPT)
   PRODFLOAT Vel_3LPT_1[3];  /* 3LPT, first term */
   PRODFLOAT Vel_3LPT_2[3];  /* 3LPT, second term */
+#endif
 #ifdef RECOMPUTE_DISPLACEMENTS /* the reference's default Makefile flags: 104-byte record */
   PRODFLOAT Vel_prev[3];        /* the four above at the previous redshift segment, */
+#if !defined(PF_IN_PINOCCHIO_TREE) || defined(TWO_LPT) || defined(THREE_LPT)
   PRODFLOAT Vel_2LPT_prev[3];   /* filled by fragment.c's shift_all_displacements */
+#endif
+#if !defined(PF_IN_PINOCCHIO_TREE) || defined(THREE_LPT)
   PRODFLOAT Vel_3LPT_1_prev[3];
   PRODFLOAT Vel_3LPT_2_prev[3];
+#endif
 #endif
 } product_data __attribute__((aligned(32))); /* on the typedef, as in the reference: aligns objects, does not pad the record */
 
@@ -139,6 +148,7 @@ extern double (*pf_GrowingMode_3LPT_2)(double z, double k);
 /* non-zero: behave like a -DSCALE_DEPENDENT build -- the growth functions above are sampled at the NkBINS k-bins
    (src/def_splines.h:40-42) and applied per mode; pf_invgrow_knots_radius[ismooth] = SPLINE_INVGROW[ismooth] */
 /* non-zero: behave like a -DTABULATED_CT build (src/collapse_times.c:780-1231) */
+extern int pf_compat_lpt_order;    /* 3 (default), 2, 1: the -DTWO_LPT / -DTHREE_LPT choice of a stand-alone run */
 extern int pf_compat_tabulated_ct;
 /* non-zero: behave like a -DELL_SNG build (src/collapse_times.c:222-400); Hubble(z) in km/s/Mpc as src/cosmo.c:1691 */
 extern int pf_compat_ell_sng;

@@ -188,9 +188,14 @@ def test_dump_and_read_products_round_trip_and_formats(lib, tmp_path, capfd):
     assert rec.shape == (n ** 3,)
 
 
-@pytest.mark.parametrize("flags", [[], ["-DSCALE_DEPENDENT"], ["-DTABULATED_CT"], ["-DELL_SNG"], ["-DTABULATED_CT", "-DELL_SNG"],
-                                   ["-DTABULATED_CT", "-DELL_SNG", "-DMOD_GRAV_FR", "-DFR0=1e-5"],
-                                   ["-DRECOMPUTE_DISPLACEMENTS", "-DSCALE_DEPENDENT"]])
+LPT3 = ["-DTWO_LPT", "-DTHREE_LPT"]          # the reference Makefile's defaults (src/Makefile:46-47)
+
+
+@pytest.mark.parametrize("flags", [LPT3, LPT3 + ["-DSCALE_DEPENDENT"], LPT3 + ["-DTABULATED_CT"], LPT3 + ["-DELL_SNG"],
+                                   LPT3 + ["-DTABULATED_CT", "-DELL_SNG"],
+                                   LPT3 + ["-DTABULATED_CT", "-DELL_SNG", "-DMOD_GRAV_FR", "-DFR0=1e-5"],
+                                   LPT3 + ["-DRECOMPUTE_DISPLACEMENTS", "-DSCALE_DEPENDENT"],
+                                   ["-DTWO_LPT"], ["-DTWO_LPT", "-DRECOMPUTE_DISPLACEMENTS"], [], ["-DTHREE_LPT"]])
 def test_in_tree_build_of_the_adapter_type_checks(flags):
     """INTEGRATION.md's recipe compiles pf_compat.c with -DPF_IN_PINOCCHIO_TREE against the reference's pinocchio.h; MPI, GSL
     and PFFT are not in this image, so the #ifdef branches are type-checked (-fsyntax-only) against declaration-only

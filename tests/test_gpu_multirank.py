@@ -108,6 +108,34 @@ def test_slab_ranks_match_single_rank(api, n, P, pipeline, monkeypatch):
         assert np.max(np.abs(a - b)) <= 2e-7 * np.max(np.abs(b))
 
 
+@pytest.mark.parametrize("order", [2, 1])
+def test_lower_lpt_orders_on_slabs(api, order):
+    """pf_set_lpt_order (a build without -DTHREE_LPT / -DTWO_LPT) with the exchange pipeline: fewer fields go through it"""
+    n, P = 32, 2
+    dk = synth.make_density(n, seed=6)
+    x, y = synth.invgrow_table("lcdm")
+    g = synth.growth_multipliers()
+    radii = np.array([1.5, 0.0])
+    nxl = n // P
+
+    def body(f, r):
+        f.set_density(dk[r * nxl:(r + 1) * nxl])
+        f.set_invgrow(x, y); f.set_growth(g); f.set_lpt_order(order)
+        f.compute_fmax(radii, do_lpt=True)
+        return f.products()
+
+    with api.Fmax(n) as f1:
+        f1.set_density(dk); f1.set_invgrow(x, y); f1.set_growth(g); f1.set_lpt_order(order)
+        f1.compute_fmax(radii, do_lpt=True)
+        p1 = f1.products()
+    res = run_ranks(api, n, P, body)
+    for r in range(P):
+        sl = slice(r * nxl, (r + 1) * nxl)
+        for name in ("Fmax", "Rmax", "Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+            assert np.array_equal(res[r][name], p1[name][sl]), (r, name)
+    assert np.abs(p1["Vel"]).max() > 0 and (np.abs(p1["Vel_2LPT"]).max() > 0) == (order == 2) and not p1["Vel_3LPT_1"].any()
+
+
 def test_synth_density_is_decomposition_independent(api):
     n, P = 64, 4
     x, y = synth.invgrow_table("lcdm")

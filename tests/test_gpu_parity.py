@@ -488,6 +488,48 @@ def test_sources_formed_by_the_last_solve_equal_the_separate_kernel(api, n, fb):
     assert np.abs(out["together"][1]["Vel_2LPT"]).max() > 0
 
 
+def test_lower_lpt_orders_of_a_build_without_three_lpt_or_two_lpt(api):
+    """The reference picks the order of the displacements at compile time (-DTWO_LPT, -DTHREE_LPT: src/fmax.c:300-336,
+    src/LPT.c:30, 78, 113, 214).  pf_set_lpt_order(2): the 2LPT source and its displacement only -- Vel and Vel_2LPT bit for
+    bit those of the full run, no Hessian of the 2LPT potential, no 3LPT passes; (1): Zel'dovich only, no second
+    derivatives on re-entry.  The columns of the orders left out are zero.  Fmax / Rmax do not depend on it."""
+    n = 32
+    dk = synth.make_density(n, seed=5)
+    x, y = synth.invgrow_table("lcdm")
+    radii = np.array([1.5, 0.0])
+
+    def run(order, entry):
+        with api.Fmax(n, timing=True) as f:
+            f.set_density(dk)
+            return body(f, order, entry)
+
+    def body(f, order, entry):
+        f.set_invgrow(x, y)
+        f.set_growth(synth.growth_multipliers())
+        f.set_lpt_order(order)
+        f.reset_kernel_stats()
+        if entry == "compute_fmax":
+            f.compute_fmax(radii, do_lpt=True)
+        else:                                           # pinocchio.x parameterfile 3: compute_displacements(1, 1, z)
+            f.compute_displacements(1, 1)
+        return f.products(), {k["name"] for k in f.kernel_stats()}
+
+    for entry in ("compute_fmax", "snapshot"):
+        full, _ = run(3, entry)
+        two, cls2 = run(2, entry)
+        one, cls1 = run(1, entry)
+        for name in ("Fmax", "Rmax", "Vel"):
+            assert np.array_equal(full[name], two[name]) and np.array_equal(full[name], one[name]), (entry, name)
+        assert np.array_equal(full["Vel_2LPT"], two["Vel_2LPT"]) and np.abs(two["Vel_2LPT"]).max() > 0
+        assert not one["Vel_2LPT"].any()
+        for name in ("Vel_3LPT_1", "Vel_3LPT_2"):
+            assert np.abs(full[name]).max() > 0 and not two[name].any() and not one[name].any(), (entry, name)
+        assert "zpass_c2r_hess_6_lpt3b" not in cls2 and "lpt_accum" not in cls2
+        assert not (cls1 & {"lpt_sources", "collapse_lpt_sources", "zpass_r2c", "xpass_fwd"})
+        if entry == "snapshot":
+            assert "xpass_hess_1to3" in cls2 and "xpass_hess_1to3" not in cls1
+
+
 def test_pruned_transform_equals_full_transform(api, monkeypatch):
     """Smoothed radii use a pruned FFT: modes whose Gaussian weight is < 2^-60 are not transformed.
     Against the full transform (PF_PRUNE_EPS=0) the Hessian changes by less than its own rounding."""
