@@ -167,6 +167,11 @@ int pf_set_growth_table(pf_ctx *ctx, int order, const double *log10_growth, int 
    pf_ct_load installs a table read from such a file (params.CTtableFile) instead of computing it.
    A following pf_collapse_times(ismooth) uses the table in place. */
 int pf_set_tabulated_ct(pf_ctx *ctx, int nsmooth, const double *variance);
+/* How the collapse pass reads the table (interpolate_collapse_time, src/collapse_times.c:1139-1231): 0 = BILINEAR_SPLINE, the
+   source's own define (default); 1 = a build with -DTRILINEAR (eight table entries, no splines); 2 = -DALL_SPLINE (sixteen
+   node splines, then gsl_spline2d's bicubic on the 4 x 4 grid around the cell) -- the three options of
+   tests/Readme_Pinocchio_tests_V5_1.txt.  The table and its file are the same for all three. */
+int pf_set_ct_interpolation(pf_ctx *ctx, int flavour);
 /* What fills the table: model 0 = ELL_CLASSIC (ell_classic + InverseGrowingMode, src/collapse_times.c:114-221, 404-415);
    model 1 = ELL_SNG (src/collapse_times.c:222-400, 416-426): per node one adaptive RKF45 integration of the
    nine-equation system of Nadkarni-Ghosh & Singhal (2016) -- the step, error control and accept/reject logic of

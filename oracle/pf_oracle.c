@@ -67,6 +67,7 @@ struct orc_ctx {
   double sng_cosmo[7], sng_Din[ORC_MAX_SMOOTH], sng_size[ORC_MAX_SMOOTH];
   int cur_ismooth;
   int tab_ns;
+  int ct_flavour;                 /* 0 BILINEAR_SPLINE (the source's define), 1 TRILINEAR, 2 ALL_SPLINE */
   double tab_var[ORC_MAX_SMOOTH]; /* Smoothing.Variance[] */
   double tab_ampl;                /* sqrt(Smoothing.Variance[ismooth]) of the table in place */
   double *ct_table, *ct_c, *ct_delta;
@@ -593,7 +594,95 @@ static int ct_initialize(orc_ctx *c, int ismooth) {
   return 0;
 }
 
-/* interpolate_collapse_time, BILINEAR_SPLINE (collapse_times.c:1110-1126, 1219-1231) */
+/* GSL interpolation/cspline.c cspline_eval_deriv (what gsl_spline_eval_deriv calls) on explicit arrays */
+static double gsl_spline_eval_deriv_arrays(const double *xa, const double *ya, const double *ca, int nk, double x) {
+  size_t ilo = 0, ihi = (size_t)nk - 1;
+  while (ihi > ilo + 1) {
+    size_t i = (ihi + ilo) / 2;
+    if (xa[i] > x) ihi = i; else ilo = i;
+  }
+  const size_t index = ilo;
+  const double dx = xa[index + 1] - xa[index];
+  const double dy = ya[index + 1] - ya[index];
+  const double delx = x - xa[index];
+  const double c_i = ca[index], c_ip1 = ca[index + 1];
+  const double b_i = (dy / dx) - dx * (c_ip1 + 2.0 * c_i) / 3.0;
+  const double d_i = (c_ip1 - c_i) / (3.0 * dx);
+  return b_i + delx * (2.0 * c_i + 3.0 * d_i * delx);
+}
+
+/* GSL 2.7.1 interp2d/bicubic.c (not vendored; restated): bicubic_init -- the partial derivatives zx, zy, zxy at the
+   nodes from natural cubic splines along the rows and columns -- and bicubic_eval -- the bicubic Hermite patch of the
+   cell that holds (x, y).  za[j * 4 + i] = z(xa[i], ya[j]) as in IDX2D.  gsl_spline2d_eval refuses points outside the
+   grid (GSL_EDOM, which aborts under the default handler); here the edge cell's patch is evaluated, as
+   gsl_spline2d_eval_extrap does. */
+static double gsl_bicubic_4x4(const double xa[4], const double ya[4], const double za[16], double x, double y) {
+  double zx[16], zy[16], zxy[16], u[4], v[4], sc[4];
+  for (int j = 0; j < 4; j++) { /* zx: a spline in x through every row */
+    for (int i = 0; i < 4; i++) { u[i] = xa[i]; v[i] = za[j * 4 + i]; }
+    natural_cspline(u, v, 4, sc);
+    for (int i = 0; i < 4; i++) zx[j * 4 + i] = gsl_spline_eval_deriv_arrays(u, v, sc, 4, xa[i]);
+  }
+  for (int i = 0; i < 4; i++) { /* zy: a spline in y through every column */
+    for (int j = 0; j < 4; j++) { u[j] = ya[j]; v[j] = za[j * 4 + i]; }
+    natural_cspline(u, v, 4, sc);
+    for (int j = 0; j < 4; j++) zy[j * 4 + i] = gsl_spline_eval_deriv_arrays(u, v, sc, 4, ya[j]);
+  }
+  for (int j = 0; j < 4; j++) { /* zxy: a spline in x through every row of zy */
+    for (int i = 0; i < 4; i++) { u[i] = xa[i]; v[i] = zy[j * 4 + i]; }
+    natural_cspline(u, v, 4, sc);
+    for (int i = 0; i < 4; i++) zxy[j * 4 + i] = gsl_spline_eval_deriv_arrays(u, v, sc, 4, xa[i]);
+  }
+  size_t xi = 0, yi = 0; /* gsl_interp_bsearch over the whole grid */
+  { size_t lo = 0, hi = 3; while (hi > lo + 1) { size_t i = (hi + lo) / 2; if (xa[i] > x) hi = i; else lo = i; } xi = lo; }
+  { size_t lo = 0, hi = 3; while (hi > lo + 1) { size_t i = (hi + lo) / 2; if (ya[i] > y) hi = i; else lo = i; } yi = lo; }
+#define IDX(i, j) ((j) * 4 + (i))
+  const double xmin = xa[xi], xmax = xa[xi + 1], ymin = ya[yi], ymax = ya[yi + 1];
+  const double zminmin = za[IDX(xi, yi)], zminmax = za[IDX(xi, yi + 1)], zmaxmin = za[IDX(xi + 1, yi)], zmaxmax = za[IDX(xi + 1, yi + 1)];
+  const double dx = xmax - xmin, dy = ymax - ymin;
+  const double t = (x - xmin) / dx, uu = (y - ymin) / dy;
+  const double dt = 1. / dx, du = 1. / dy;
+  const double zxminmin = zx[IDX(xi, yi)] / dt, zxminmax = zx[IDX(xi, yi + 1)] / dt, zxmaxmin = zx[IDX(xi + 1, yi)] / dt, zxmaxmax = zx[IDX(xi + 1, yi + 1)] / dt;
+  const double zyminmin = zy[IDX(xi, yi)] / du, zyminmax = zy[IDX(xi, yi + 1)] / du, zymaxmin = zy[IDX(xi + 1, yi)] / du, zymaxmax = zy[IDX(xi + 1, yi + 1)] / du;
+  const double zxyminmin = zxy[IDX(xi, yi)] / (dt * du), zxyminmax = zxy[IDX(xi, yi + 1)] / (dt * du), zxymaxmin = zxy[IDX(xi + 1, yi)] / (dt * du),
+               zxymaxmax = zxy[IDX(xi + 1, yi + 1)] / (dt * du);
+#undef IDX
+  const double t0 = 1, t1 = t, t2 = t * t, t3 = t * t2, u0 = 1, u1 = uu, u2 = uu * uu, u3 = uu * u2;
+  double z = 0, w;
+  w = zminmin; z += w * t0 * u0;
+  w = zyminmin; z += w * t0 * u1;
+  w = -3 * zminmin + 3 * zminmax - 2 * zyminmin - zyminmax; z += w * t0 * u2;
+  w = 2 * zminmin - 2 * zminmax + zyminmin + zyminmax; z += w * t0 * u3;
+  w = zxminmin; z += w * t1 * u0;
+  w = zxyminmin; z += w * t1 * u1;
+  w = -3 * zxminmin + 3 * zxminmax - 2 * zxyminmin - zxyminmax; z += w * t1 * u2;
+  w = 2 * zxminmin - 2 * zxminmax + zxyminmin + zxyminmax; z += w * t1 * u3;
+  w = -3 * zminmin + 3 * zmaxmin - 2 * zxminmin - zxmaxmin; z += w * t2 * u0;
+  w = -3 * zyminmin + 3 * zymaxmin - 2 * zxyminmin - zxymaxmin; z += w * t2 * u1;
+  w = 9 * zminmin - 9 * zmaxmin + 9 * zmaxmax - 9 * zminmax + 6 * zxminmin + 3 * zxmaxmin - 3 * zxmaxmax - 6 * zxminmax + 6 * zyminmin - 6 * zymaxmin -
+      3 * zymaxmax + 3 * zyminmax + 4 * zxyminmin + 2 * zxymaxmin + zxymaxmax + 2 * zxyminmax;
+  z += w * t2 * u2;
+  w = -6 * zminmin + 6 * zmaxmin - 6 * zmaxmax + 6 * zminmax - 4 * zxminmin - 2 * zxmaxmin + 2 * zxmaxmax + 4 * zxminmax - 3 * zyminmin + 3 * zymaxmin +
+      3 * zymaxmax - 3 * zyminmax - 2 * zxyminmin - zxymaxmin - zxymaxmax - 2 * zxyminmax;
+  z += w * t2 * u3;
+  w = 2 * zminmin - 2 * zmaxmin + zxminmin + zxmaxmin; z += w * t3 * u0;
+  w = 2 * zyminmin - 2 * zymaxmin + zxyminmin + zxymaxmin; z += w * t3 * u1;
+  w = -6 * zminmin + 6 * zmaxmin - 6 * zmaxmax + 6 * zminmax - 3 * zxminmin - 3 * zxmaxmin + 3 * zxmaxmax + 3 * zxminmax - 4 * zyminmin + 4 * zymaxmin +
+      2 * zymaxmax - 2 * zyminmax - 2 * zxyminmin - 2 * zxymaxmin - zxymaxmax - zxyminmax;
+  z += w * t3 * u2;
+  w = 4 * zminmin - 4 * zmaxmin + 4 * zmaxmax - 4 * zminmax + 2 * zxminmin + 2 * zxmaxmin - 2 * zxmaxmax - 2 * zxminmax + 2 * zyminmin - 2 * zymaxmin -
+      2 * zymaxmax + 2 * zyminmax + zxyminmin + zxymaxmin + zxymaxmax + zxyminmax;
+  z += w * t3 * u3;
+  return z;
+}
+
+/* interpolate_collapse_time (collapse_times.c:1139-1231).  The source defines BILINEAR_SPLINE; -DTRILINEAR or -DALL_SPLINE in
+   the Makefile's OPTIONS (tests/Readme_Pinocchio_tests_V5_1.txt) put their own return in front of it. */
+int orc_set_ct_interpolation(orc_ctx *c, int flavour) {
+  if (flavour < 0 || flavour > 2) return 1;
+  c->ct_flavour = flavour;
+  return 0;
+}
 double orc_interpolate_collapse_time(orc_ctx *c, double l1, double l2, double l3) {
   const double bin_x = CT_RANGE_X / (double)(CT_NBINS_XY);
   double ampl = c->tab_ampl;
@@ -604,10 +693,44 @@ double orc_interpolate_collapse_time(orc_ctx *c, double l1, double l2, double l3
   int iy = (int)(y / bin_x);
   ix = (ix >= CT_NBINS_XY - 1) ? CT_NBINS_XY - 2 : (ix < 0) ? 0 : ix;
   iy = (iy >= CT_NBINS_XY - 1) ? CT_NBINS_XY - 2 : (iy < 0) ? 0 : iy;
-  double dx = x / bin_x - ix;
-  double dy = y / bin_x - iy;
 #define CT_SPL(I, J) my_spline_eval_arrays(c->ct_delta, c->ct_table + (size_t)(I) * CT_NBINS_D + (size_t)(J) * CT_NBINS_D * CT_NBINS_XY, \
                                            c->ct_c + (size_t)(I) * CT_NBINS_D + (size_t)(J) * CT_NBINS_D * CT_NBINS_XY, CT_NBINS_D, d)
+  if (c->ct_flavour == 2) { /* #ifdef ALL_SPLINE, :1153-1185: bicubic on the 4x4 nodes around the cell */
+    double xls[4], yls[4], zls[16];
+    int ixstart = (ix == 0) ? 0 : (ix >= CT_NBINS_XY - 2) ? CT_NBINS_XY - 4 : ix - 1;
+    int iystart = (iy == 0) ? 0 : (iy >= CT_NBINS_XY - 2) ? CT_NBINS_XY - 4 : iy - 1;
+    for (int ixx = 0; ixx < 4; ixx++) {
+      xls[ixx] = (ixx + ixstart) * bin_x;
+      yls[ixx] = (ixx + iystart) * bin_x;
+    }
+    for (int ixx = 0; ixx < 4; ixx++)
+      for (int iyy = 0; iyy < 4; iyy++) zls[ixx + iyy * 4] = CT_SPL(ixx + ixstart, iyy + iystart);
+    return gsl_bicubic_4x4(xls, yls, zls, x, y);
+  }
+  if (c->ct_flavour == 1) { /* #ifdef TRILINEAR, :1189-1216 */
+    const double *dv = c->ct_delta, *T = c->ct_table;
+    int id;
+    if (d <= dv[0]) id = 0;
+    else if (d >= dv[CT_NBINS_D - 1]) id = CT_NBINS_D - 2;
+    else { /* bsearch with compare_search (:1129-1135): dv[id] <= d < dv[id + 1] */
+      int lo = 0, hi = CT_NBINS_D - 1;
+      while (hi > lo + 1) { int m = (hi + lo) / 2; if (dv[m] > d) hi = m; else lo = m; }
+      id = lo;
+    }
+    double dd = (d - dv[id]) / (dv[id + 1] - dv[id]);
+    double dx = x / bin_x - ix;
+    double dy = y / bin_x - iy;
+    return (((1. - dd) * (1. - dx) * (1. - dy) * T[id + (ix) * CT_NBINS_D + (iy) * CT_NBINS_D * CT_NBINS_XY]) +
+            ((dd) * (1. - dx) * (1. - dy) * T[(id + 1) + (ix) * CT_NBINS_D + (iy) * CT_NBINS_D * CT_NBINS_XY]) +
+            ((1. - dd) * (dx) * (1. - dy) * T[id + (ix + 1) * CT_NBINS_D + (iy) * CT_NBINS_D * CT_NBINS_XY]) +
+            ((dd) * (dx) * (1. - dy) * T[(id + 1) + (ix + 1) * CT_NBINS_D + (iy) * CT_NBINS_D * CT_NBINS_XY]) +
+            ((1. - dd) * (1. - dx) * (dy) * T[id + (ix) * CT_NBINS_D + (iy + 1) * CT_NBINS_D * CT_NBINS_XY]) +
+            ((dd) * (1. - dx) * (dy) * T[(id + 1) + (ix) * CT_NBINS_D + (iy + 1) * CT_NBINS_D * CT_NBINS_XY]) +
+            ((1. - dd) * (dx) * (dy) * T[id + (ix + 1) * CT_NBINS_D + (iy + 1) * CT_NBINS_D * CT_NBINS_XY]) +
+            ((dd) * (dx) * (dy) * T[(id + 1) + (ix + 1) * CT_NBINS_D + (iy + 1) * CT_NBINS_D * CT_NBINS_XY]));
+  }
+  double dx = x / bin_x - ix;
+  double dy = y / bin_x - iy;
   return ((1. - dx) * (1. - dy) * CT_SPL(ix, iy) +
           (dx) * (1. - dy) * CT_SPL(ix + 1, iy) +
           (1. - dx) * (dy) * CT_SPL(ix, iy + 1) +

@@ -107,6 +107,10 @@ int orc_ct_build(orc_ctx *c, int ismooth, double variance);
 const double *orc_ct_table(orc_ctx *c);
 const double *orc_ct_delta(orc_ctx *c);
 double orc_interpolate_collapse_time(orc_ctx *c, double l1, double l2, double l3);
+/* the interpolation of a -DTRILINEAR (1) or -DALL_SPLINE (2) build (src/collapse_times.c:1153-1216; gsl_spline2d's bicubic
+   restated from GSL 2.7.1 interp2d/bicubic.c); 0 = BILINEAR_SPLINE, the source's own define.  No run of the reference with
+   either is committed: PARITY UNPINNED for these two (checked against an independent numpy construction). */
+int orc_set_ct_interpolation(orc_ctx *c, int flavour);
 
 /* ELL_SNG collapse model (oracle/pf_sng.c; src/collapse_times.c:222-400): scale factor of collapse of the ellipsoid
    (0: none, -1: integrator failure) and the F = 1/b_c of ell().  cosmo = {Omega0, OmegaLambda, OmegaRad, OmegaK,

@@ -163,6 +163,10 @@ class Fmax:
         self._chk(self.L.pf_collapse_times(self.h, ismooth, C.byref(tv)))
         return tv.value
 
+    def set_ct_interpolation(self, flavour: int):
+        """0 BILINEAR_SPLINE (default), 1 -DTRILINEAR, 2 -DALL_SPLINE"""
+        self._chk(self.L.pf_set_ct_interpolation(self.h, int(flavour)))
+
     def set_lpt_order(self, order: int):
         """3: -DTWO_LPT -DTHREE_LPT (default); 2: -DTWO_LPT only; 1: Zel'dovich displacements only"""
         self._chk(self.L.pf_set_lpt_order(self.h, int(order)))

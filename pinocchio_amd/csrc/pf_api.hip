@@ -132,6 +132,7 @@ struct pf_ctx {
   // pf_set_sources_in_sweep: the solve of a sweep's last radius also writes the LPT sources (S[0..2], real space) and the
   // sum of S2; sources_fresh says they are what pf_displacements(1, 0) would compute from the Hessian in B
   bool sweep_sources, sources_fresh;
+  int ct_flavour; // table interpolation of the build: 0 BILINEAR_SPLINE, 1 TRILINEAR, 2 ALL_SPLINE (pf_set_ct_interpolation)
   int lpt_order;  // 3: -DTWO_LPT -DTHREE_LPT (default), 2: -DTWO_LPT only, 1: Zel'dovich only (pf_set_lpt_order)
   double *partials_src;  // PF_NBLK
   // general path: grid sizes that are not a power of two (one rank, fp64) go through library transforms
@@ -337,7 +338,7 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   c->dev_bytes = 0; c->own_stream = true; c->stream = nullptr;
   c->a2a = nullptr; c->a2av = nullptr; c->a2av_user = nullptr; c->ared = nullptr; c->a2a_user = c->ared_user = nullptr; c->rccl = nullptr;
   c->have_density = c->have_hessian = c->have_sources = c->products_init = false; c->last_ns = 0;
-  c->sweep_sources = c->sources_fresh = false; c->partials_src = nullptr; c->lpt_order = 3;
+  c->sweep_sources = c->sources_fresh = false; c->partials_src = nullptr; c->lpt_order = 3; c->ct_flavour = 0;
   c->vel_zero_pending = false;
   memset(c->ks_ms, 0, sizeof(c->ks_ms)); memset(c->ks_bytes, 0, sizeof(c->ks_bytes)); memset(c->ks_n, 0, sizeof(c->ks_n));
   memset(&c->cpu, 0, sizeof(c->cpu)); memset(c->spl_set, 0, sizeof(c->spl_set)); memset(c->spl_n, 0, sizeof(c->spl_n));
@@ -957,7 +958,7 @@ static int ct_build(pf_ctx *c, int ismooth, double variance, const double *table
   if (!(variance > 0.0)) return pf_fail(c->rank, "collapse-time table: Smoothing.Variance[%d] = %g must be positive", ismooth, variance);
   PFCHK(c, ct_alloc(c));
   c->ct.ampl = sqrt(variance);
-  c->ct.model = c->model;
+  c->ct.model = c->model; c->ct.flavour = c->ct_flavour;
   if (c->model == 1 && !table_host) {
     if (ismooth >= c->sng_ns) return pf_fail(c->rank, "collapse-time table: no ELL_SNG growth factor for radius %d (pf_set_collapse_model)", ismooth);
     memcpy(c->ct.sng_cosmo, c->sng_cosmo, sizeof(c->sng_cosmo));
@@ -1054,7 +1055,7 @@ static int collapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], hipStream_
       if (ct_build(c, ismooth, c->tab_var[ismooth], nullptr, st)) return 1;
     } else if (!c->tab_ready)
       return pf_fail(c->rank, "collapse-time table not built (pf_ct_build / pf_ct_load)");
-    p.tabulated = 1; p.ct = c->ct;
+    p.tabulated = 1; p.ct = c->ct; p.ct.flavour = c->ct_flavour;
   }
   size_t nb = (ncell(c) + 255) / 256; if (nb > (size_t)c->collapse_blocks) nb = c->collapse_blocks;
   p.nblocks = (int)nb;
@@ -1172,6 +1173,12 @@ extern "C" int pf_sweep(pf_ctx *c, int ns, const double *radius_cells, double *t
   return rc;
 }
 extern "C" int pf_debug_invariant_reruns(pf_ctx *c) { return c ? c->inv_reruns : -1; }
+extern "C" int pf_set_ct_interpolation(pf_ctx *c, int flavour) {
+  if (!c) return 1;
+  if (flavour < 0 || flavour > 2) return pf_fail(c->rank, "pf_set_ct_interpolation: flavour %d (0 BILINEAR_SPLINE, 1 TRILINEAR, 2 ALL_SPLINE)", flavour);
+  c->ct_flavour = flavour;
+  return 0;
+}
 extern "C" int pf_set_lpt_order(pf_ctx *c, int order) {
   if (!c) return 1;
   if (order < 1 || order > 3) return pf_fail(c->rank, "pf_set_lpt_order: order %d (1 Zel'dovich, 2 -DTWO_LPT, 3 -DTHREE_LPT)", order);

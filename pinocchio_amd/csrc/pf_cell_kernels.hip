@@ -40,7 +40,7 @@ PF_HD void pf_lpt_sources_cell(const double d[6], double &src2, double &src31, d
 }
 // SRC: the pass of the last radius of a sweep that is followed by compute_LPT_displacements -- the cell's six components are
 // in registers anyway, so its three LPT sources are written here and k_lpt_sources (six more field reads) is not run
-template <typename F, bool FAST, bool TAB = false, bool INV = false, bool SNG = false, bool SRC = false>
+template <typename F, bool FAST, bool TAB = false, bool INV = false, bool SNG = false, bool SRC = false, int FLAV = 0>
 __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
   __shared__ double sk[TAB ? PF_CT_NBINS_D : 5 * PF_MAX_KNOTS];
   __shared__ double red[2 * (PF_CELL_BLOCK / 64)];
@@ -119,7 +119,7 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
     }
     // TABULATED_CT: the same eigenvalues, then the table instead of ell() (src/collapse_times.c:749)
     const double Fnew = !have_lam ? -10.0
-                        : TAB   ? pf_interpolate_collapse_time(tv, lam[0], lam[1], lam[2])
+                        : TAB   ? pf_interpolate_collapse_time_as<FLAV>(tv, lam[0], lam[1], lam[2])
                         : SNG   ? pf_ell_sng_F(lam[0], lam[1], lam[2], p.ct.sng_Din, sc)
                                 : pf_ell<FAST>(sv, lam[0], lam[1], lam[2]);
     if ((double)fold < Fnew) {
@@ -146,8 +146,16 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
 // (four waves per SIMD = four 256-thread workgroups per CU, which the grid of 8 per CU is sized for: at most 128 VGPRs)
 template <typename F, bool FAST>
 __global__ void __launch_bounds__(PF_CELL_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) k_collapse(const PfCollapseParams p) { pf_collapse_body<F, FAST>(p); }
-template <typename F, bool FAST>
-__global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse_tab(const PfCollapseParams p) { pf_collapse_body<F, FAST, true>(p); }
+// FLAV: the table interpolation of the build (0 BILINEAR_SPLINE, 1 -DTRILINEAR, 2 -DALL_SPLINE)
+template <typename F, bool FAST, int FLAV>
+__global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse_tab(const PfCollapseParams p) { pf_collapse_body<F, FAST, true, false, false, false, FLAV>(p); }
+template <typename F, bool FAST> static void pf_launch_collapse_tab(const PfCollapseParams &p, hipStream_t st) {
+  switch (p.ct.flavour) {
+    case 1: hipLaunchKernelGGL((k_collapse_tab<F, FAST, 1>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p); break;
+    case 2: hipLaunchKernelGGL((k_collapse_tab<F, FAST, 2>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p); break;
+    default: hipLaunchKernelGGL((k_collapse_tab<F, FAST, 0>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p); break;
+  }
+}
 template <typename F, bool FAST>
 __global__ void __launch_bounds__(PF_CELL_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) k_collapse_src(const PfCollapseParams p) { pf_collapse_body<F, FAST, false, false, false, true>(p); }
 // ELL_SNG per cell: thousands of dependent steps per thread, lanes of a wave finish at different times -- small workgroups
@@ -513,11 +521,11 @@ int pf_launch_collapse(int fb, const PfCollapseParams &p, hipStream_t st) {
   if (p.spline.n > PF_MAX_KNOTS) return 2;
   if (p.tabulated) {
     if (fb == 8) {
-      if (p.fast) hipLaunchKernelGGL((k_collapse_tab<double, true>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
-      else hipLaunchKernelGGL((k_collapse_tab<double, false>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
+      if (p.fast) pf_launch_collapse_tab<double, true>(p, st);
+      else pf_launch_collapse_tab<double, false>(p, st);
     } else {
-      if (p.fast) hipLaunchKernelGGL((k_collapse_tab<float, true>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
-      else hipLaunchKernelGGL((k_collapse_tab<float, false>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
+      if (p.fast) pf_launch_collapse_tab<float, true>(p, st);
+      else pf_launch_collapse_tab<float, false>(p, st);
     }
     return PF_CHECK_LAUNCH();
   }

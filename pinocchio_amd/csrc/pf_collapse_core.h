@@ -532,6 +532,144 @@ PF_HD double pf_interpolate_collapse_time(const pf_ct_view &t, double l1, double
   return ((1. - dx) * (1. - dy) * s[0] + (dx) * (1. - dy) * s[1] + (1. - dx) * (dy) * s[2] + (dx) * (dy) * s[3]);
 }
 
+// ---- the other two interpolation flavours the reference offers (tests/Readme_Pinocchio_tests_V5_1.txt): -DTRILINEAR and
+// -DALL_SPLINE put their own return in front of the BILINEAR_SPLINE one (src/collapse_times.c:1153-1216)
+enum { PF_CT_BILINEAR_SPLINE = 0, PF_CT_TRILINEAR = 1, PF_CT_ALL_SPLINE = 2 };
+// my_spline_eval of the node spline (ix, iy) at d
+PF_HD double pf_ct_node_eval(const pf_ct_view &t, int ix, int iy, double d) {
+  const double *xa = t.delta;
+  const int last = PF_CT_NBINS_D - 1;
+  const int node = (ix + iy * PF_CT_NBINS_XY) * PF_CT_NBINS_D;
+  const double *ya = t.y + node;
+  if (d < xa[0]) return ya[0] + (d - xa[0]) * (ya[1] - ya[0]) / (xa[1] - xa[0]);
+  if (d > xa[last]) return ya[last] + (d - xa[last]) * (ya[last] - ya[last - 1]) / (xa[last] - xa[last - 1]);
+  int ilo = 0, ihi = last;
+  while (ihi > ilo + 1) {
+    const int i = (ihi + ilo) >> 1;
+    if (xa[i] > d) ihi = i; else ilo = i;
+  }
+  const double delx = d - xa[ilo];
+  return ya[ilo] + delx * (t.b[node + ilo] + delx * (t.c[node + ilo] + delx * t.d[node + ilo]));
+}
+// TRILINEAR (:1189-1216): the eight table entries around (d, x, y), no splines
+PF_HD double pf_interpolate_trilinear(const pf_ct_view &t, double d, double x, double y, int ix, int iy) {
+  const double bin_x = PF_CT_RANGE_X / (double)(PF_CT_NBINS_XY);
+  const double *dv = t.delta, *T = t.y;
+  int id;
+  if (d <= dv[0]) id = 0;
+  else if (d >= dv[PF_CT_NBINS_D - 1]) id = PF_CT_NBINS_D - 2;
+  else {  // bsearch with compare_search (:1129-1135): dv[id] <= d < dv[id + 1]
+    int lo = 0, hi = PF_CT_NBINS_D - 1;
+    while (hi > lo + 1) { const int m = (hi + lo) >> 1; if (dv[m] > d) hi = m; else lo = m; }
+    id = lo;
+  }
+  const double dd = (d - dv[id]) / (dv[id + 1] - dv[id]);
+  const double dx = x / bin_x - ix;
+  const double dy = y / bin_x - iy;
+  const int D = PF_CT_NBINS_D, DX = PF_CT_NBINS_D * PF_CT_NBINS_XY;
+  return (((1. - dd) * (1. - dx) * (1. - dy) * T[id + (ix)*D + (iy)*DX]) + ((dd) * (1. - dx) * (1. - dy) * T[(id + 1) + (ix)*D + (iy)*DX]) +
+          ((1. - dd) * (dx) * (1. - dy) * T[id + (ix + 1) * D + (iy)*DX]) + ((dd) * (dx) * (1. - dy) * T[(id + 1) + (ix + 1) * D + (iy)*DX]) +
+          ((1. - dd) * (1. - dx) * (dy)*T[id + (ix)*D + (iy + 1) * DX]) + ((dd) * (1. - dx) * (dy)*T[(id + 1) + (ix)*D + (iy + 1) * DX]) +
+          ((1. - dd) * (dx) * (dy)*T[id + (ix + 1) * D + (iy + 1) * DX]) + ((dd) * (dx) * (dy)*T[(id + 1) + (ix + 1) * D + (iy + 1) * DX]));
+}
+// derivative at its four knots of the natural cubic spline through (xa, ya): GSL's cspline_init for size 4 (a 2 x 2
+// symmetric system, solve_tridiag's LDL^t with its order of operations) and cspline_eval_deriv at each knot
+PF_HD void pf_cspline4_node_derivs(const double xa[4], const double ya[4], double dz[4]) {
+  const double h0 = xa[1] - xa[0], h1 = xa[2] - xa[1], h2 = xa[3] - xa[2];
+  const double y0 = ya[1] - ya[0], y1 = ya[2] - ya[1], y2 = ya[3] - ya[2];
+  const double r0 = (h0 != 0.0) ? 1.0 / h0 : 0.0, r1 = (h1 != 0.0) ? 1.0 / h1 : 0.0, r2 = (h2 != 0.0) ? 1.0 / h2 : 0.0;
+  const double diag0 = 2.0 * (h1 + h0), diag1 = 2.0 * (h2 + h1);
+  const double g0 = 3.0 * (y1 * r1 - y0 * r0), g1 = 3.0 * (y2 * r2 - y1 * r1);
+  const double alpha0 = diag0, gamma0 = h1 / alpha0, alpha1 = diag1 - h1 * gamma0;
+  const double z1 = g1 - gamma0 * g0;
+  const double cc0 = g0 / alpha0, cc1 = z1 / alpha1;
+  const double c[4] = {0.0, cc0 - gamma0 * cc1, cc1, 0.0};
+  const double h[3] = {h0, h1, h2}, dy[3] = {y0, y1, y2};
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int i = 0; i < 3; i++) dz[i] = (dy[i] / h[i]) - h[i] * (c[i + 1] + 2.0 * c[i]) / 3.0;  // delx = 0: b_i itself
+  const double b2 = dz[2], d2 = (c[3] - c[2]) / (3.0 * h2);
+  dz[3] = b2 + h2 * (2.0 * c[2] + 3.0 * d2 * h2);  // the last knot belongs to the last interval (gsl_interp_bsearch)
+}
+// ALL_SPLINE (:1153-1185): the sixteen node splines around the cell evaluated at d, then gsl_spline2d's bicubic on that
+// 4 x 4 grid (GSL 2.7.1 interp2d/bicubic.c restated: bicubic_init's zx, zy, zxy from natural splines along rows and
+// columns, bicubic_eval's Hermite patch).  Beyond the grid gsl_spline2d_eval raises GSL_EDOM (the reference aborts);
+// here the edge cell's patch is evaluated, as gsl_spline2d_eval_extrap does.
+PF_HD double pf_interpolate_all_spline(const pf_ct_view &t, double d, double x, double y, int ix, int iy) {
+  const double bin_x = PF_CT_RANGE_X / (double)(PF_CT_NBINS_XY);
+  const int ixstart = (ix == 0) ? 0 : (ix >= PF_CT_NBINS_XY - 2) ? PF_CT_NBINS_XY - 4 : ix - 1;
+  const int iystart = (iy == 0) ? 0 : (iy >= PF_CT_NBINS_XY - 2) ? PF_CT_NBINS_XY - 4 : iy - 1;
+  double xa[4], ya[4], za[16], zx[16], zy[16], zxy[16], u[4], dz[4];
+  for (int k = 0; k < 4; k++) { xa[k] = (k + ixstart) * bin_x; ya[k] = (k + iystart) * bin_x; }
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) za[j * 4 + i] = pf_ct_node_eval(t, i + ixstart, j + iystart, d);
+  for (int j = 0; j < 4; j++) {
+    pf_cspline4_node_derivs(xa, za + 4 * j, dz);
+    for (int i = 0; i < 4; i++) zx[j * 4 + i] = dz[i];
+  }
+  for (int i = 0; i < 4; i++) {
+    for (int j = 0; j < 4; j++) u[j] = za[j * 4 + i];
+    pf_cspline4_node_derivs(ya, u, dz);
+    for (int j = 0; j < 4; j++) zy[j * 4 + i] = dz[j];
+  }
+  for (int j = 0; j < 4; j++) {
+    pf_cspline4_node_derivs(xa, zy + 4 * j, dz);
+    for (int i = 0; i < 4; i++) zxy[j * 4 + i] = dz[i];
+  }
+  int xi = 0, yi = 0;
+  { int lo = 0, hi = 3; while (hi > lo + 1) { const int m = (hi + lo) >> 1; if (xa[m] > x) hi = m; else lo = m; } xi = lo; }
+  { int lo = 0, hi = 3; while (hi > lo + 1) { const int m = (hi + lo) >> 1; if (ya[m] > y) hi = m; else lo = m; } yi = lo; }
+  const int i00 = yi * 4 + xi, i01 = (yi + 1) * 4 + xi, i10 = yi * 4 + xi + 1, i11 = (yi + 1) * 4 + xi + 1;  // [x][y]: min/max
+  const double dx = xa[xi + 1] - xa[xi], dy = ya[yi + 1] - ya[yi];
+  const double tt = (x - xa[xi]) / dx, uu = (y - ya[yi]) / dy;
+  const double dt = 1. / dx, du = 1. / dy;
+  const double zminmin = za[i00], zminmax = za[i01], zmaxmin = za[i10], zmaxmax = za[i11];
+  const double zxminmin = zx[i00] / dt, zxminmax = zx[i01] / dt, zxmaxmin = zx[i10] / dt, zxmaxmax = zx[i11] / dt;
+  const double zyminmin = zy[i00] / du, zyminmax = zy[i01] / du, zymaxmin = zy[i10] / du, zymaxmax = zy[i11] / du;
+  const double zxyminmin = zxy[i00] / (dt * du), zxyminmax = zxy[i01] / (dt * du), zxymaxmin = zxy[i10] / (dt * du), zxymaxmax = zxy[i11] / (dt * du);
+  const double t0 = 1, t1 = tt, t2 = tt * tt, t3 = tt * t2, u0 = 1, u1 = uu, u2 = uu * uu, u3 = uu * u2;
+  double z = 0, w;
+  w = zminmin; z += w * t0 * u0;
+  w = zyminmin; z += w * t0 * u1;
+  w = -3 * zminmin + 3 * zminmax - 2 * zyminmin - zyminmax; z += w * t0 * u2;
+  w = 2 * zminmin - 2 * zminmax + zyminmin + zyminmax; z += w * t0 * u3;
+  w = zxminmin; z += w * t1 * u0;
+  w = zxyminmin; z += w * t1 * u1;
+  w = -3 * zxminmin + 3 * zxminmax - 2 * zxyminmin - zxyminmax; z += w * t1 * u2;
+  w = 2 * zxminmin - 2 * zxminmax + zxyminmin + zxyminmax; z += w * t1 * u3;
+  w = -3 * zminmin + 3 * zmaxmin - 2 * zxminmin - zxmaxmin; z += w * t2 * u0;
+  w = -3 * zyminmin + 3 * zymaxmin - 2 * zxyminmin - zxymaxmin; z += w * t2 * u1;
+  w = 9 * zminmin - 9 * zmaxmin + 9 * zmaxmax - 9 * zminmax + 6 * zxminmin + 3 * zxmaxmin - 3 * zxmaxmax - 6 * zxminmax + 6 * zyminmin - 6 * zymaxmin -
+      3 * zymaxmax + 3 * zyminmax + 4 * zxyminmin + 2 * zxymaxmin + zxymaxmax + 2 * zxyminmax;
+  z += w * t2 * u2;
+  w = -6 * zminmin + 6 * zmaxmin - 6 * zmaxmax + 6 * zminmax - 4 * zxminmin - 2 * zxmaxmin + 2 * zxmaxmax + 4 * zxminmax - 3 * zyminmin + 3 * zymaxmin +
+      3 * zymaxmax - 3 * zyminmax - 2 * zxyminmin - zxymaxmin - zxymaxmax - 2 * zxyminmax;
+  z += w * t2 * u3;
+  w = 2 * zminmin - 2 * zmaxmin + zxminmin + zxmaxmin; z += w * t3 * u0;
+  w = 2 * zyminmin - 2 * zymaxmin + zxyminmin + zxymaxmin; z += w * t3 * u1;
+  w = -6 * zminmin + 6 * zmaxmin - 6 * zmaxmax + 6 * zminmax - 3 * zxminmin - 3 * zxmaxmin + 3 * zxmaxmax + 3 * zxminmax - 4 * zyminmin + 4 * zymaxmin +
+      2 * zymaxmax - 2 * zyminmax - 2 * zxyminmin - 2 * zxymaxmin - zxymaxmax - zxyminmax;
+  z += w * t3 * u2;
+  w = 4 * zminmin - 4 * zmaxmin + 4 * zmaxmax - 4 * zminmax + 2 * zxminmin + 2 * zxmaxmin - 2 * zxmaxmax - 2 * zxminmax + 2 * zyminmin - 2 * zymaxmin -
+      2 * zymaxmax + 2 * zyminmax + zxyminmin + zxymaxmin + zxymaxmax + zxyminmax;
+  z += w * t3 * u3;
+  return z;
+}
+// interpolate_collapse_time of a build with flavour FLAV
+template <int FLAV> PF_HD double pf_interpolate_collapse_time_as(const pf_ct_view &t, double l1, double l2, double l3) {
+  if (FLAV == PF_CT_BILINEAR_SPLINE) return pf_interpolate_collapse_time(t, l1, l2, l3);
+  const double bin_x = PF_CT_RANGE_X / (double)(PF_CT_NBINS_XY);
+  const double d = (l1 + l2 + l3) / t.ampl;
+  const double x = (l1 - l2) / t.ampl;
+  const double y = (l2 - l3) / t.ampl;
+  int ix = (int)(x / bin_x);
+  int iy = (int)(y / bin_x);
+  ix = (ix >= PF_CT_NBINS_XY - 1) ? PF_CT_NBINS_XY - 2 : (ix < 0) ? 0 : ix;
+  iy = (iy >= PF_CT_NBINS_XY - 1) ? PF_CT_NBINS_XY - 2 : (iy < 0) ? 0 : iy;
+  return FLAV == PF_CT_TRILINEAR ? pf_interpolate_trilinear(t, d, x, y, ix, iy) : pf_interpolate_all_spline(t, d, x, y, ix, iy);
+}
+
 // GSL's cspline_init for one (x, y) node of the collapse-time table (gsl_spline_init, src/collapse_times.c:1037-1041):
 // right-hand side, forward and back substitution with the shared LDL^t factors (pf_ct_tridiag), then the b, d that
 // cspline_eval derives from c.  c doubles as the work array of the substitutions.

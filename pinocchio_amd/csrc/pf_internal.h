@@ -110,6 +110,7 @@ struct PfCtDev {
   const double *alpha, *gamma;     // [98] factors of the shared tridiagonal system
   double ampl;
   int model;                       // what fills the table: 0 ell_classic + InverseGrowingMode, 1 ell_sng (pf_sng_core.h)
+  int flavour;                     // how the solve reads it: 0 BILINEAR_SPLINE, 1 TRILINEAR, 2 ALL_SPLINE (pf_collapse_core.h)
   double sng_cosmo[7], sng_Din;    // ELL_SNG: Omega0, OmegaLambda, OmegaRad, OmegaK, FR0, H_over_c, size; GrowingMode at a = 1e-5 for this radius
 };
 struct PfCollapseParams {

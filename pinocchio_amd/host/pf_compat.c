@@ -123,6 +123,18 @@ int reset_collapse_times(int ismooth);
 #define PF_LPT_ORDER pf_compat_lpt_order
 #endif
 
+/* table interpolation of a TABULATED_CT build: -DTRILINEAR or -DALL_SPLINE in OPTIONS (tests/Readme_Pinocchio_tests_V5_1.txt)
+   take precedence over the BILINEAR_SPLINE the source defines (src/collapse_times.c:39-41, 1153-1231) */
+#if defined(PF_IN_PINOCCHIO_TREE) && defined(ALL_SPLINE)
+#define PF_CT_FLAVOUR 2
+#elif defined(PF_IN_PINOCCHIO_TREE) && defined(TRILINEAR)
+#define PF_CT_FLAVOUR 1
+#elif defined(PF_IN_PINOCCHIO_TREE)
+#define PF_CT_FLAVOUR 0
+#else
+#define PF_CT_FLAVOUR pf_compat_ct_interpolation
+#endif
+
 static pf_ctx *pf_context = NULL;
 static int pf_density_on_device = 0; /* set by pf_compat_genic: kdensity[0] is not uploaded */
 static int pf_inputs_on_device = 0;  /* the context holds the density and the inverse-growth spline(s) (pf_upload_inputs) */
@@ -202,6 +214,7 @@ int compute_fft_plans(void) {
   if (pf_context) return 0;
   if (pf_create(&pf_context, &cfg)) return 1;
   if (pf_set_lpt_order(pf_context, PF_LPT_ORDER)) return 1;
+  if (pf_set_ct_interpolation(pf_context, PF_CT_FLAVOUR)) return 1;
 #if defined(PF_IN_PINOCCHIO_TREE)
   if (NTasks > 1) { /* one rank per GPU: RCCL all-to-all replaces the MPI_Alltoall inside pfft_execute */
     char id[128];

@@ -29,6 +29,7 @@ pfft_complex **cvector_fft = cvector_slots;
 double **rvector_fft = rvector_slots;
 int pf_compat_lpt_order = 3;    /* stand-alone build: 3 = -DTWO_LPT -DTHREE_LPT, 2 = -DTWO_LPT, 1 = neither */
 int pf_compat_tabulated_ct = 0;
+int pf_compat_ct_interpolation = 0; /* 0 BILINEAR_SPLINE, 1 -DTRILINEAR, 2 -DALL_SPLINE */
 int pf_compat_ell_sng = 0;
 double (*pf_Hubble)(double) = 0;
 double pf_compat_fr0 = 0.0;

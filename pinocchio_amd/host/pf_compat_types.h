@@ -150,6 +150,7 @@ extern double (*pf_GrowingMode_3LPT_2)(double z, double k);
 /* non-zero: behave like a -DTABULATED_CT build (src/collapse_times.c:780-1231) */
 extern int pf_compat_lpt_order;    /* 3 (default), 2, 1: the -DTWO_LPT / -DTHREE_LPT choice of a stand-alone run */
 extern int pf_compat_tabulated_ct;
+extern int pf_compat_ct_interpolation;
 /* non-zero: behave like a -DELL_SNG build (src/collapse_times.c:222-400); Hubble(z) in km/s/Mpc as src/cosmo.c:1691 */
 extern int pf_compat_ell_sng;
 extern double (*pf_Hubble)(double z);

@@ -33,7 +33,7 @@ extern "C" int emul_spline(const double *sx, const double *sy, int nk, const dou
 
 // TABULATED_CT pieces of the header: delta sampling, shared tridiagonal factors, node splines, interpolation
 extern "C" int emul_ct(const double *table /*[50*50*100]*/, double ampl, const double *lam /*[3*count]*/, long count,
-                       double *delta_out /*[100]*/, double *F) {
+                       double *delta_out /*[100]*/, double *F, int flavour /* 0 BILINEAR_SPLINE, 1 TRILINEAR, 2 ALL_SPLINE */) {
   const int nd = PF_CT_NBINS_D, nn = PF_CT_NBINS_XY * PF_CT_NBINS_XY;
   std::vector<double> delta(nd), alpha(nd), gamma(nd), c((size_t)nn * nd), b((size_t)nn * nd), d((size_t)nn * nd);
   pf_ct_delta_vector(delta.data());
@@ -42,7 +42,12 @@ extern "C" int emul_ct(const double *table /*[50*50*100]*/, double ampl, const d
     pf_ct_node_spline(delta.data(), alpha.data(), gamma.data(), table + (size_t)node * nd, c.data() + (size_t)node * nd,
                       b.data() + (size_t)node * nd, d.data() + (size_t)node * nd);
   pf_ct_view t{delta.data(), table, b.data(), c.data(), d.data(), ampl};
-  for (long i = 0; i < count; i++) F[i] = pf_interpolate_collapse_time(t, lam[3 * i], lam[3 * i + 1], lam[3 * i + 2]);
+  for (long i = 0; i < count; i++) {
+    const double *l = lam + 3 * i;
+    F[i] = flavour == 1   ? pf_interpolate_collapse_time_as<PF_CT_TRILINEAR>(t, l[0], l[1], l[2])
+           : flavour == 2 ? pf_interpolate_collapse_time_as<PF_CT_ALL_SPLINE>(t, l[0], l[1], l[2])
+                          : pf_interpolate_collapse_time_as<PF_CT_BILINEAR_SPLINE>(t, l[0], l[1], l[2]);
+  }
   for (int i = 0; i < nd; i++) delta_out[i] = delta[i];
   return 0;
 }

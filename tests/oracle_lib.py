@@ -184,6 +184,11 @@ class Oracle:
         d = np.ctypeslib.as_array(self.L.orc_ct_delta(self.h), shape=(100,)).copy()
         return t, d
 
+    def set_ct_interpolation(self, flavour: int):
+        """0 BILINEAR_SPLINE (the source's define), 1 -DTRILINEAR, 2 -DALL_SPLINE"""
+        self.L.orc_set_ct_interpolation.argtypes = [C.c_void_p, C.c_int]
+        assert self.L.orc_set_ct_interpolation(self.h, int(flavour)) == 0
+
     def interpolate_collapse_time(self, l1, l2, l3):
         return self.L.orc_interpolate_collapse_time(self.h, l1, l2, l3)
 

@@ -121,11 +121,15 @@ def test_tabulated_ct_header_matches_oracle_bitwise(emul):
     yy = rng.uniform(0.0, 4.0, n)
     lam = np.stack([(d + 2 * xx + yy) / 3.0 * ampl, (d - xx + yy) / 3.0 * ampl, (d - xx - 2 * yy) / 3.0 * ampl], axis=1).copy()
     F = np.empty(n); delta = np.empty(100)
-    emul.emul_ct.argtypes = [dp, C.c_double, dp, C.c_long, dp, dp]
-    assert emul.emul_ct(_dp(np.ascontiguousarray(tab)), ampl, _dp(lam), n, _dp(delta), _dp(F)) == 0
-    assert np.array_equal(delta, dv)
-    want = np.array([o.interpolate_collapse_time(*l) for l in lam])
-    assert np.array_equal(F, want)
+    emul.emul_ct.argtypes = [dp, C.c_double, dp, C.c_long, dp, dp, C.c_int]
+    # 0: BILINEAR_SPLINE, the source's define; 1, 2: the -DTRILINEAR and -DALL_SPLINE flavours (:1153-1216; the 4 x 4 natural
+    # splines and the bicubic patch of gsl_spline2d in the header's closed form against the oracle's general-size restatement)
+    for flavour in (0, 1, 2):
+        assert emul.emul_ct(_dp(np.ascontiguousarray(tab)), ampl, _dp(lam), n, _dp(delta), _dp(F), flavour) == 0
+        assert np.array_equal(delta, dv)
+        o.set_ct_interpolation(flavour)
+        want = np.array([o.interpolate_collapse_time(*l) for l in lam])
+        assert np.array_equal(F, want), (flavour, np.abs(F - want).max())
 
 
 def test_ell_sng_header_matches_oracle_bitwise(emul):

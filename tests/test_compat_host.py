@@ -192,7 +192,8 @@ LPT3 = ["-DTWO_LPT", "-DTHREE_LPT"]          # the reference Makefile's defaults
 
 
 @pytest.mark.parametrize("flags", [LPT3, LPT3 + ["-DSCALE_DEPENDENT"], LPT3 + ["-DTABULATED_CT"], LPT3 + ["-DELL_SNG"],
-                                   LPT3 + ["-DTABULATED_CT", "-DELL_SNG"],
+                                   LPT3 + ["-DTABULATED_CT", "-DELL_SNG"], LPT3 + ["-DTABULATED_CT", "-DTRILINEAR"],
+                                   LPT3 + ["-DTABULATED_CT", "-DALL_SPLINE"],
                                    LPT3 + ["-DTABULATED_CT", "-DELL_SNG", "-DMOD_GRAV_FR", "-DFR0=1e-5"],
                                    LPT3 + ["-DRECOMPUTE_DISPLACEMENTS", "-DSCALE_DEPENDENT"],
                                    ["-DTWO_LPT"], ["-DTWO_LPT", "-DRECOMPUTE_DISPLACEMENTS"], [], ["-DTHREE_LPT"]])

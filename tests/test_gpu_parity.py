@@ -822,6 +822,44 @@ def test_tabulated_ct_build_vs_oracle(api):
     assert np.mean(p2["Rmax"] != po["Rmax"]) < 1e-3
 
 
+@pytest.mark.parametrize("flavour", [1, 2])
+def test_trilinear_and_all_spline_table_interpolation_vs_oracle(api, flavour):
+    """a build with -DTRILINEAR (1) or -DALL_SPLINE (2) in OPTIONS (src/collapse_times.c:1153-1216, the three choices of
+    tests/Readme_Pinocchio_tests_V5_1.txt): the same table, read with eight entries or with sixteen node splines and
+    gsl_spline2d's bicubic.  The oracle's table is loaded on both sides, so only the Hessian's rounding is left."""
+    n = 32
+    dk = synth.make_density(n, seed=45)
+    x, y = synth.invgrow_table("lcdm")
+    radii = np.array([2.0, 0.0])
+    o = oracle_lib.Oracle(n, 0)
+    o.set_density(dk); o.set_invgrow(x, y)
+    var = o.compute_fmax(radii, do_lpt=False)
+    o.set_tabulated_ct(var)
+    o.compute_fmax(radii, do_lpt=False)
+    p0 = o.products()                                   # BILINEAR_SPLINE
+    o.set_ct_interpolation(flavour)
+    tv_o = o.compute_fmax(radii, do_lpt=False)
+    po = o.products()
+    with api.Fmax(n) as f:
+        f.set_density(dk); f.set_invgrow(x, y)
+        f.set_ct_interpolation(flavour)
+        for i, r in enumerate(radii):
+            f.compute_second_derivatives(r)
+            t_i, _ = o.ct_build(i, var[i])
+            f.ct_load(i, var[i], t_i)
+            f.compute_collapse_times(i)
+        p = f.products()
+        f.set_tabulated_ct(var)                         # and the sweep building its own tables
+        tv = f.sweep(radii)
+        ps = f.products()
+    ulp = np.spacing(np.maximum(np.abs(po["Fmax"]), 1.0).astype(np.float32)).astype(np.float64)
+    assert np.mean(np.abs(p["Fmax"].astype(np.float64) - po["Fmax"]) > 2 * ulp) < 1e-4
+    assert np.mean(p["Rmax"] != po["Rmax"]) < 1e-3
+    assert np.allclose(tv, tv_o, rtol=1e-12)
+    _fmax_close(ps["Fmax"], po["Fmax"])
+    assert np.mean(po["Fmax"] != p0["Fmax"]) > 0.3       # not the default flavour's numbers
+
+
 def test_ell_sng_table_vs_oracle(api):
     """row f-4, ELL_SNG: per cell (a build without TABULATED_CT, src/collapse_times.c:416-426), then the collapse-time
     table filled by 250 000 adaptive RKF45 integrations on the device against the oracle's restatement
