@@ -44,6 +44,12 @@ typedef struct {
 } pf_config;
 
 #define PF_FLAG_TIMING 1  /* record per-kernel HIP-event timings (pf_kernel_stats) */
+/* a -DDOUBLE_PRECISION_PRODUCTS build (src/Makefile:68, src/pinocchio.h:219-225: PRODFLOAT double): Fmax and the Vel*
+   fields of product_data are doubles.  Fmax is then kept and compared in fp64 (no rounding of the running maximum to fp32
+   between radii, cf. src/collapse_times.c:587-590) and the displacements leave the z-pass as the doubles it computes.
+   fp64 fields only.  pf_get_products / pf_update_products write doubles at the layout's offsets; pf_select_sorted and
+   pf_get_block (fp32 by definition) refuse. */
+#define PF_FLAG_DOUBLE_PRODUCTS 2
 
 /* layout of the caller's product_data record (src/pinocchio.h:233-259).
    Offsets in bytes; a negative offset means "field absent".  pf_layout_3lpt()

@@ -32,12 +32,19 @@ extern "C" {
 
 #define ORC_NBINS 210 /* src/pinocchio.h:65 */
 
-/* src/pinocchio.h:233-259 with -DTWO_LPT -DTHREE_LPT, float products: 56 B */
+/* src/pinocchio.h:219-225: PRODFLOAT is float, or double in a -DDOUBLE_PRECISION_PRODUCTS build -- the same switch here
+   (oracle/Makefile builds both: libpf_oracle.so and libpf_oracle_dp.so) */
+#ifdef DOUBLE_PRECISION_PRODUCTS
+typedef double ORC_PRODFLOAT;
+#else
+typedef float ORC_PRODFLOAT;
+#endif
+/* src/pinocchio.h:233-259 with -DTWO_LPT -DTHREE_LPT: 56 B with float products, 112 B with double ones */
 typedef struct {
   int   Rmax;
-  float Fmax, Vel[3];
-  float Vel_2LPT[3];
-  float Vel_3LPT_1[3], Vel_3LPT_2[3];
+  ORC_PRODFLOAT Fmax, Vel[3];
+  ORC_PRODFLOAT Vel_2LPT[3];
+  ORC_PRODFLOAT Vel_3LPT_1[3], Vel_3LPT_2[3];
 } orc_product;
 
 typedef struct orc_ctx orc_ctx;

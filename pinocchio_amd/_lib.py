@@ -15,6 +15,7 @@ NBINS = 210
 MAX_SMOOTH = 64
 
 FLAG_TIMING = 1
+FLAG_DOUBLE_PRODUCTS = 2
 
 
 class Config(C.Structure):

@@ -16,6 +16,11 @@ from . import _lib
 PRODUCT_DTYPE = np.dtype(
     [("Rmax", "<i4"), ("Fmax", "<f4"), ("Vel", "<f4", 3), ("Vel_2LPT", "<f4", 3),
      ("Vel_3LPT_1", "<f4", 3), ("Vel_3LPT_2", "<f4", 3)], align=False)  # src/pinocchio.h:233-259, 56 B
+# the same record of a -DDOUBLE_PRECISION_PRODUCTS build (PRODFLOAT double, src/pinocchio.h:219-225): 112 B
+PRODUCT_DTYPE_DP = np.dtype(
+    {"names": ["Rmax", "Fmax", "Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"],
+     "formats": ["<i4", "<f8", ("<f8", 3), ("<f8", 3), ("<f8", 3), ("<f8", 3)],
+     "offsets": [0, 8, 16, 40, 64, 88], "itemsize": 112})
 
 
 class PinfmaxError(RuntimeError):
@@ -30,12 +35,13 @@ class Fmax:
     """One rank's context: an x-slab of an n^3 grid on one MI355X."""
 
     def __init__(self, n: int, rank: int = 0, nranks: int = 1, device: int = 0, field_bytes: int = 8,
-                 timing: bool = False):
+                 timing: bool = False, double_products: bool = False):
         self.L = _lib.load()
+        self.double_products = bool(double_products)
         self.n, self.rank, self.nranks = int(n), int(rank), int(nranks)
         self.nxl = self.n // self.nranks
         cfg = _lib.Config(n=n, rank=rank, nranks=nranks, device=device, field_bytes=field_bytes,
-                          flags=_lib.FLAG_TIMING if timing else 0)
+                          flags=(_lib.FLAG_TIMING if timing else 0) | (_lib.FLAG_DOUBLE_PRODUCTS if double_products else 0))
         h = C.c_void_p()
         self._chk(self.L.pf_create(C.byref(h), C.byref(cfg)))
         self.h = h
@@ -183,7 +189,12 @@ class Fmax:
     def products(self) -> np.ndarray:
         lay = _lib.ProductLayout()
         self.L.pf_layout_3lpt(C.byref(lay))
-        out = np.zeros((self.nxl, self.n, self.n), dtype=PRODUCT_DTYPE)
+        dtype = PRODUCT_DTYPE
+        if self.double_products:      # PRODFLOAT double: the natural alignment of the reference's struct (Fmax at byte 8)
+            dtype = PRODUCT_DTYPE_DP
+            lay.stride, lay.off_Rmax, lay.off_Fmax = 112, 0, 8
+            lay.off_Vel, lay.off_Vel_2LPT, lay.off_Vel_3LPT_1, lay.off_Vel_3LPT_2 = 16, 40, 64, 88
+        out = np.zeros((self.nxl, self.n, self.n), dtype=dtype)
         self._chk(self.L.pf_get_products(self.h, out.ctypes.data_as(C.c_void_p), C.byref(lay)))
         return out
 

@@ -104,7 +104,9 @@ struct pf_ctx {
   hipEvent_t ev_x[2], ev_r[2];
   void *tw;
   double *etab;        // [n] window of the transformed axis for the x-pass in flight (pf_launch_exp_table)
-  float *fmax, *vel12;
+  // products, SoA: Fmax and the twelve displacement columns as PRODFLOAT -- float, or double with PF_FLAG_DOUBLE_PRODUCTS (pb = 8)
+  void *fmax, *vel12;
+  int pb;
   int *rmax;
   double *partials;    // 2 * PF_NBLK
   double *scal;        // device scalars, see SC_*
@@ -285,9 +287,9 @@ static int create_body(pf_ctx *c, const pf_config *cfg) {
     if (rc) return pf_fail(rank, "pf_create: hipFFT plans for %d^3 failed (%d): grid sizes that are not a power of two need libhipfft", c->n, rc);
   }
   const size_t nc = ncell(c);
-  PFCHK(c, dev_alloc(c, (void **)&c->fmax, nc * sizeof(float)));
+  PFCHK(c, dev_alloc(c, (void **)&c->fmax, nc * (size_t)c->pb));
   PFCHK(c, dev_alloc(c, (void **)&c->rmax, nc * sizeof(int)));
-  PFCHK(c, dev_alloc(c, (void **)&c->vel12, 12 * nc * sizeof(float)));
+  PFCHK(c, dev_alloc(c, (void **)&c->vel12, 12 * nc * (size_t)c->pb));
   PFCHK(c, dev_alloc(c, (void **)&c->partials, 2 * PF_NBLK * sizeof(double)));
   PFCHK(c, dev_alloc(c, (void **)&c->partials_src, PF_NBLK * sizeof(double)));
   PFCHK(c, dev_alloc(c, (void **)&c->scal, SC_COUNT * sizeof(double)));
@@ -325,6 +327,8 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
     return pf_fail(rank, "pf_create: nranks %d must divide the grid size %lld (slab decomposition)", cfg->nranks, n);
   if (cfg->nranks & (cfg->nranks - 1)) return pf_fail(rank, "pf_create: nranks %d must be a power of two", cfg->nranks);
   if (cfg->field_bytes != 8 && cfg->field_bytes != 4) return pf_fail(rank, "pf_create: field_bytes must be 8 or 4");
+  if ((cfg->flags & PF_FLAG_DOUBLE_PRODUCTS) && cfg->field_bytes != 8)
+    return pf_fail(rank, "pf_create: PF_FLAG_DOUBLE_PRODUCTS (fp64 Fmax and displacements) needs fp64 fields");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return pf_fail(rank, "pf_create: no HIP device available (libpinfmax_hip has no CPU path)");
@@ -334,7 +338,7 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   c->tune = tune; c->dev = cfg->device; c->inv_reruns = 0;
   c->general = want_general; c->fft_c2r = c->fft_r2c = nullptr; c->W = nullptr;
   if (c->general) c->nzp = c->nzh;  // natural layout [n][n][n/2+1], the boundary layout itself
-  c->nxl = c->n / c->P; c->nyl = c->n / c->P; c->fb = cfg->field_bytes; c->timing = (cfg->flags & PF_FLAG_TIMING) != 0;
+  c->nxl = c->n / c->P; c->nyl = c->n / c->P; c->fb = cfg->field_bytes; c->timing = (cfg->flags & PF_FLAG_TIMING) != 0; c->pb = (cfg->flags & PF_FLAG_DOUBLE_PRODUCTS) ? 8 : 4;
   c->dev_bytes = 0; c->own_stream = true; c->stream = nullptr;
   c->a2a = nullptr; c->a2av = nullptr; c->a2av_user = nullptr; c->ared = nullptr; c->a2a_user = c->ared_user = nullptr; c->rccl = nullptr;
   c->have_density = c->have_hessian = c->have_sources = c->products_init = false; c->last_ns = 0;
@@ -647,13 +651,16 @@ static int g_hessian_of(pf_ctx *c, const void *spec, double rs, void *const out[
   }
   return 0;
 }
+// column k (0..11 = 3 * order + axis) of the SoA displacements
+static void *velcol(const pf_ctx *c, int k) { return (char *)c->vel12 + (size_t)k * ncell(c) * (size_t)c->pb; }
+
 static int g_displacements_of(pf_ctx *c, int count, const void *const *specs, const int *orders, void *tmp) {
   const size_t nc = ncell(c);
   for (int j = 0; j < count; j++)
     for (int ia = 1; ia <= 3; ia++) {
       PFCHK(c, g_filter(c, specs[j], c->W, ia, 0, 0.0, orders[j] + 1, true));
       PFCHK(c, g_c2r(c, c->W, tmp));
-      PFCHK(c, pf_launch_real_to_col((const double *)tmp, c->vel12 + (size_t)(3 * orders[j] + ia - 1) * nc, nc, c->stream));
+      PFCHK(c, pf_launch_real_to_col((const double *)tmp, velcol(c, 3 * orders[j] + ia - 1), nc, c->pb, c->stream));
     }
   return 0;
 }
@@ -740,9 +747,10 @@ static int displacements_of(pf_ctx *c, int count, const void *const *specs, cons
                      const int o = orders[j];
                      const Job yj[3] = {{R[1], tmp[0], PF_MUL_ONE}, {R[0], tmp[1], PF_MUL_IK}, {R[0], tmp[2], PF_MUL_ONE}};
                      PFCHK(c, ypass(c, KS_YPASS_DISP, +1, 3, yj, true, false, 2, 1 << 30, true));
-                     const ZJob zj[3] = {{tmp[0], c->vel12 + (size_t)(3 * o + 0) * nc, PF_MUL_ONE, 1},
-                                         {tmp[1], c->vel12 + (size_t)(3 * o + 1) * nc, PF_MUL_ONE, 1},
-                                         {tmp[2], c->vel12 + (size_t)(3 * o + 2) * nc, PF_MUL_IK, 1}};
+                     const int compact = c->pb == 8 ? 2 : 1;  // rows of pitch n: float, or the fields' own double
+                     const ZJob zj[3] = {{tmp[0], velcol(c, 3 * o + 0), PF_MUL_ONE, compact},
+                                         {tmp[1], velcol(c, 3 * o + 1), PF_MUL_ONE, compact},
+                                         {tmp[2], velcol(c, 3 * o + 2), PF_MUL_IK, compact}};
                      PFCHK(c, zpass_c2r(c, KS_ZPASS_DISP, 3, zj, nullptr));
                      return 0;
                    });
@@ -1037,7 +1045,7 @@ static int collapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], hipStream_
                             bool sources = false) {
   PfCollapseParams p; memset(&p, 0, sizeof(p));
   for (int i = 0; i < 6; i++) p.h[i] = H[i];
-  p.pitch = rpitch(c); p.nrows = (long long)c->nxl * c->n; p.n = c->n; p.fmax = c->fmax; p.rmax = c->rmax; p.ismooth = ismooth;
+  p.pitch = rpitch(c); p.nrows = (long long)c->nxl * c->n; p.n = c->n; p.fmax = c->fmax; p.prod_f64 = c->pb == 8; p.rmax = c->rmax; p.ismooth = ismooth;
   if (spline_for(c, ismooth, &p.spline)) return 1;
   p.partials = c->partials; p.fast = c->fast_libm ? 1 : 0;
   p.no_lut = c->tune.spline_lut ? 0 : 1;
@@ -1088,7 +1096,7 @@ static int products_reset(pf_ctx *c) {
 }
 static int velocities_ready(pf_ctx *c) {
   if (c->vel_zero_pending) {
-    HIPCHK(c, hipMemsetAsync(c->vel12, 0, 12 * ncell(c) * sizeof(float), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->vel12, 0, 12 * ncell(c) * (size_t)c->pb, c->stream));
     c->vel_zero_pending = false;
   }
   return 0;
@@ -1197,7 +1205,7 @@ extern "C" int pf_displacements(pf_ctx *c, int compute_sources, int recompute_sd
   for (int i = 0; i < 6; i++)
     if (!c->B2[i]) PFCHK(c, dev_alloc(c, &c->B2[i], c->field_bytes));
   if (!c->products_init) {
-    PFCHK(c, pf_launch_fill_products(c->fmax, c->rmax, c->vel12, ncell(c), c->stream));
+    PFCHK(c, pf_launch_fill_products(c->fmax, c->rmax, c->vel12, ncell(c), c->pb, c->stream));
     c->products_init = true;
   }
   if (recompute_sd && c->lpt_order >= 2) {  // src/fmax.c:301-318 (inside #ifdef TWO_LPT)
@@ -1259,7 +1267,7 @@ extern "C" int pf_displacements(pf_ctx *c, int compute_sources, int recompute_sd
     if (c->lpt_order < 3) {
       const size_t nc = ncell(c);
       const int k0 = c->lpt_order == 2 ? 6 : 3;  // columns 3 o .. 3 o + 2 of order o: 0 Zel'dovich, 1 2LPT, 2 3LPT(a), 3 3LPT(b)
-      HIPCHK(c, hipMemsetAsync(c->vel12 + (size_t)k0 * nc, 0, (size_t)(12 - k0) * nc * sizeof(float), c->stream));
+      HIPCHK(c, hipMemsetAsync(velcol(c, k0), 0, (size_t)(12 - k0) * nc * (size_t)c->pb, c->stream));
     }
     c->vel_zero_pending = false;  // all twelve columns rewritten
   }
@@ -1269,7 +1277,7 @@ extern "C" int pf_displacements(pf_ctx *c, int compute_sources, int recompute_sd
 extern "C" int pf_fmax_pdf(pf_ctx *c, unsigned long long hist[PF_NBINS]) {
   if (!c || !hist) return 1;
   HIPCHK(c, hipMemsetAsync(c->hist, 0, PF_NBINS * sizeof(unsigned long long), c->stream));
-  PFCHK(c, pf_launch_fmax_pdf(c->fmax, ncell(c), c->hist, c->stream));
+  PFCHK(c, pf_launch_fmax_pdf(c->fmax, ncell(c), c->hist, c->pb, c->stream));
   PFCHK(c, allreduce_dev(c, c->hist, PF_NBINS, 1));
   HIPCHK(c, hipMemcpyAsync(hist, c->hist, PF_NBINS * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1288,7 +1296,7 @@ extern "C" int pf_get_products(pf_ctx *c, void *host, const pf_product_layout *l
   for (size_t first = 0; first < nc; first += cap) {
     const size_t cnt = (nc - first < cap) ? nc - first : cap;
     HIPCHK(c, hipMemsetAsync(staging(c), 0, cnt * l->stride, c->stream));
-    PFCHK(c, pf_launch_pack_products(c->fmax, c->rmax, c->vel12, nc, first, cnt, staging(c), l->stride, l->off_Rmax, l->off_Fmax, ov, c->stream));
+    PFCHK(c, pf_launch_pack_products(c->pb, c->fmax, c->rmax, c->vel12, nc, first, cnt, staging(c), l->stride, l->off_Rmax, l->off_Fmax, ov, c->stream));
     HIPCHK(c, hipMemcpyAsync((char *)host + first * l->stride, staging(c), cnt * l->stride, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
@@ -1310,7 +1318,7 @@ extern "C" int pf_update_products(pf_ctx *c, void *host, const pf_product_layout
   for (size_t first = 0; first < nc; first += cap) {
     const size_t cnt = (nc - first < cap) ? nc - first : cap;
     HIPCHK(c, hipMemcpyAsync(staging(c), (const char *)host + first * l->stride, cnt * l->stride, hipMemcpyHostToDevice, c->stream));
-    PFCHK(c, pf_launch_pack_products(c->fmax, c->rmax, c->vel12, nc, first, cnt, staging(c), l->stride, l->off_Rmax, l->off_Fmax, ov, c->stream));
+    PFCHK(c, pf_launch_pack_products(c->pb, c->fmax, c->rmax, c->vel12, nc, first, cnt, staging(c), l->stride, l->off_Rmax, l->off_Fmax, ov, c->stream));
     HIPCHK(c, hipMemcpyAsync((char *)host + first * l->stride, staging(c), cnt * l->stride, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
@@ -1323,7 +1331,8 @@ extern "C" int pf_select_sorted(pf_ctx *c, float flast, size_t capacity, unsigne
   if (!c->products_init) return pf_fail(c->rank, "pf_select_sorted: products not computed");
   if (ncell(c) > 0xFFFFFFFFull) return pf_fail(c->rank, "pf_select_sorted: more than 2^32 cells on one rank");
   unsigned int *d_idx = nullptr; float *d_f = nullptr;
-  if (pf_select_sort_device(c->fmax, ncell(c), flast, &d_idx, &d_f, count, c->stream)) return pf_fail(c->rank, "pf_select_sorted: device sort failed (out of memory?)");
+  if (c->pb != 4) return pf_fail(c->rank, "pf_select_sorted: fp32 Fmax only (not with PF_FLAG_DOUBLE_PRODUCTS)");
+  if (pf_select_sort_device((const float *)c->fmax, ncell(c), flast, &d_idx, &d_f, count, c->stream)) return pf_fail(c->rank, "pf_select_sorted: device sort failed (out of memory?)");
   const size_t m = *count < capacity ? *count : capacity;
   if (m && cell_index) HIPCHK(c, hipMemcpyAsync(cell_index, d_idx, m * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
   if (m && fmax) HIPCHK(c, hipMemcpyAsync(fmax, d_f, m * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -1336,6 +1345,7 @@ extern "C" int pf_select_sorted(pf_ctx *c, float flast, size_t capacity, unsigne
 extern "C" int pf_get_block(pf_ctx *c, const char *name, int id_bytes, void *host) {
   if (!c || !name || !host) return pf_fail(0, "pf_get_block: null argument");
   if (!c->products_init) return pf_fail(c->rank, "pf_get_block: products not computed");
+  if (c->pb != 4) return pf_fail(c->rank, "pf_get_block: the fp32 snapshot blocks are served from fp32 products only (not with PF_FLAG_DOUBLE_PRODUCTS)");
   PFCHK(c, velocities_ready(c));
   const size_t nc = ncell(c);
   if (!strncmp(name, "FMAX", 4)) { HIPCHK(c, hipMemcpyAsync(host, c->fmax, nc * sizeof(float), hipMemcpyDeviceToHost, c->stream)); }
@@ -1353,7 +1363,7 @@ extern "C" int pf_get_block(pf_ctx *c, const char *name, int id_bytes, void *hos
     for (size_t first = 0; first < nc; first += cap) {
       const size_t cnt = (nc - first < cap) ? nc - first : cap;
       if (id) PFCHK(c, pf_launch_block_id(id_bytes, gfirst + first, cnt, staging(c), c->stream));
-      else PFCHK(c, pf_launch_block_vec3(c->vel12, nc, o, first, cnt, (float *)staging(c), c->stream));
+      else PFCHK(c, pf_launch_block_vec3((const float *)c->vel12, nc, o, first, cnt, (float *)staging(c), c->stream));
       HIPCHK(c, hipMemcpyAsync((char *)host + first * rec, staging(c), cnt * rec, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
     }

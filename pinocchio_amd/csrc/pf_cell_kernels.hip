@@ -2,6 +2,8 @@
 // solve with running max (src/collapse_times.c:431-673), LPT sources
 // (src/LPT.c:64-93, :134-137), products init/pack (src/collapse_times.c:461-492,
 // src/fmax-pfft.c:563-631), Fmax PDF (src/fmax.c:509-550), layout converters.
+#include <type_traits>
+
 #include "pf_internal.h"
 #include "pf_fft_core.h"
 #include "pf_collapse_core.h"
@@ -40,7 +42,8 @@ PF_HD void pf_lpt_sources_cell(const double d[6], double &src2, double &src31, d
 }
 // SRC: the pass of the last radius of a sweep that is followed by compute_LPT_displacements -- the cell's six components are
 // in registers anyway, so its three LPT sources are written here and k_lpt_sources (six more field reads) is not run
-template <typename F, bool FAST, bool TAB = false, bool INV = false, bool SNG = false, bool SRC = false, int FLAV = 0>
+// PR: PRODFLOAT, the type of products.Fmax (float; double in a -DDOUBLE_PRECISION_PRODUCTS build, src/pinocchio.h:219-225)
+template <typename F, bool FAST, bool TAB = false, bool INV = false, bool SNG = false, bool SRC = false, int FLAV = 0, typename PR = float>
 __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
   __shared__ double sk[TAB ? PF_CT_NBINS_D : 5 * PF_MAX_KNOTS];
   __shared__ double red[2 * (PF_CELL_BLOCK / 64)];
@@ -96,7 +99,8 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
     if (!INV) { d[3] = (double)h3[a]; d[4] = (double)h4[a]; d[5] = (double)h5[a]; }
     // products[].Fmax is float, compared after promotion (quirk Q2); init -10 / -1 at ismooth 0.  Loaded here, with the
     // Hessian, so that its latency hides under the solve instead of sitting between the solve and the store.
-    const float fold = p.ismooth ? p.fmax[i] : -10.0f;
+    PR *__restrict__ fmax = (PR *)p.fmax;
+    const PR fold = p.ismooth ? fmax[i] : (PR)-10.0f;
     if (SRC) {
       double src2, src31, src32;
       pf_lpt_sources_cell(d, src2, src31, src32);
@@ -123,10 +127,10 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
                         : SNG   ? pf_ell_sng_F(lam[0], lam[1], lam[2], p.ct.sng_Din, sc)
                                 : pf_ell<FAST>(sv, lam[0], lam[1], lam[2]);
     if ((double)fold < Fnew) {
-      p.fmax[i] = (float)Fnew;
+      fmax[i] = (PR)Fnew;
       p.rmax[i] = p.ismooth;
     } else if (!p.ismooth) {
-      p.fmax[i] = -10.0f;
+      fmax[i] = (PR)-10.0f;
       p.rmax[i] = -1;
     }
   }
@@ -144,26 +148,26 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
 }
 
 // (four waves per SIMD = four 256-thread workgroups per CU, which the grid of 8 per CU is sized for: at most 128 VGPRs)
-template <typename F, bool FAST>
-__global__ void __launch_bounds__(PF_CELL_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) k_collapse(const PfCollapseParams p) { pf_collapse_body<F, FAST>(p); }
+template <typename F, bool FAST, typename PR = float>
+__global__ void __launch_bounds__(PF_CELL_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) k_collapse(const PfCollapseParams p) { pf_collapse_body<F, FAST, false, false, false, false, 0, PR>(p); }
 // FLAV: the table interpolation of the build (0 BILINEAR_SPLINE, 1 -DTRILINEAR, 2 -DALL_SPLINE)
-template <typename F, bool FAST, int FLAV>
-__global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse_tab(const PfCollapseParams p) { pf_collapse_body<F, FAST, true, false, false, false, FLAV>(p); }
-template <typename F, bool FAST> static void pf_launch_collapse_tab(const PfCollapseParams &p, hipStream_t st) {
+template <typename F, bool FAST, int FLAV, typename PR = float>
+__global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse_tab(const PfCollapseParams p) { pf_collapse_body<F, FAST, true, false, false, false, FLAV, PR>(p); }
+template <typename F, bool FAST, typename PR> static void pf_launch_collapse_tab(const PfCollapseParams &p, hipStream_t st) {
   switch (p.ct.flavour) {
-    case 1: hipLaunchKernelGGL((k_collapse_tab<F, FAST, 1>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p); break;
-    case 2: hipLaunchKernelGGL((k_collapse_tab<F, FAST, 2>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p); break;
-    default: hipLaunchKernelGGL((k_collapse_tab<F, FAST, 0>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p); break;
+    case 1: hipLaunchKernelGGL((k_collapse_tab<F, FAST, 1, PR>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p); break;
+    case 2: hipLaunchKernelGGL((k_collapse_tab<F, FAST, 2, PR>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p); break;
+    default: hipLaunchKernelGGL((k_collapse_tab<F, FAST, 0, PR>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p); break;
   }
 }
-template <typename F, bool FAST>
-__global__ void __launch_bounds__(PF_CELL_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) k_collapse_src(const PfCollapseParams p) { pf_collapse_body<F, FAST, false, false, false, true>(p); }
+template <typename F, bool FAST, typename PR = float>
+__global__ void __launch_bounds__(PF_CELL_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) k_collapse_src(const PfCollapseParams p) { pf_collapse_body<F, FAST, false, false, false, true, 0, PR>(p); }
 // ELL_SNG per cell: thousands of dependent steps per thread, lanes of a wave finish at different times -- small workgroups
-template <typename F, bool FAST>
-__global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse_sng(const PfCollapseParams p) { pf_collapse_body<F, FAST, false, false, true>(p); }
+template <typename F, bool FAST, typename PR = float>
+__global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse_sng(const PfCollapseParams p) { pf_collapse_body<F, FAST, false, false, true, false, 0, PR>(p); }
 // the solve on the three invariants per cell that k_c2r_invariants leaves in h[0..2] (fp64 fields)
-template <bool FAST>
-__global__ void __launch_bounds__(PF_CELL_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) k_collapse_inv(const PfCollapseParams p) { pf_collapse_body<double, FAST, false, true>(p); }
+template <bool FAST, typename PR = float>
+__global__ void __launch_bounds__(PF_CELL_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) k_collapse_inv(const PfCollapseParams p) { pf_collapse_body<double, FAST, false, true, false, false, 0, PR>(p); }
 
 // initialize_collapse_times (src/collapse_times.c:956-972): CT_table[i] = ell(ismooth, l1, l2, l3) on the
 // (delta, x, y) grid, i = id + 100 * (ix + 50 * iy)
@@ -305,12 +309,13 @@ __global__ void __launch_bounds__(PF_CELL_BLOCK) k_lpt_accum(const PfLptAccParam
   }
 }
 
-__global__ void __launch_bounds__(PF_CELL_BLOCK) k_fill_products(float *fmax, int *rmax, float *vel12, size_t ncell) {
+template <typename PR>
+__global__ void __launch_bounds__(PF_CELL_BLOCK) k_fill_products(PR *fmax, int *rmax, PR *vel12, size_t ncell) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncell; i += (size_t)gridDim.x * blockDim.x) {
-    fmax[i] = -10.0f;
+    fmax[i] = (PR)-10.0f;
     rmax[i] = -1;
 #pragma unroll
-    for (int k = 0; k < 12; k++) vel12[(size_t)k * ncell + i] = 0.0f;
+    for (int k = 0; k < 12; k++) vel12[(size_t)k * ncell + i] = (PR)0;
   }
 }
 
@@ -399,27 +404,29 @@ __global__ void __launch_bounds__(PF_CELL_BLOCK)
   }
 }
 // real field -> one fp32 column of the products (write_from_rvector_to_products, src/fmax-pfft.c:563-631)
-__global__ void __launch_bounds__(PF_CELL_BLOCK) k_real_to_col(const double *__restrict__ src, float *__restrict__ dst, size_t ncell) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncell; i += (size_t)gridDim.x * blockDim.x) dst[i] = (float)src[i];
+template <typename PR>
+__global__ void __launch_bounds__(PF_CELL_BLOCK) k_real_to_col(const double *__restrict__ src, PR *__restrict__ dst, size_t ncell) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncell; i += (size_t)gridDim.x * blockDim.x) dst[i] = (PR)src[i];
 }
 __global__ void __launch_bounds__(PF_CELL_BLOCK) k_scale_real(double *__restrict__ f, size_t ncell, double s) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncell; i += (size_t)gridDim.x * blockDim.x) f[i] *= s;
 }
 
 // device SoA -> the caller's AoS product_data (src/pinocchio.h:233-259)
+template <typename PR>
 __global__ void __launch_bounds__(PF_CELL_BLOCK)
-    k_pack_products(const float *fmax, const int *rmax, const float *vel12, size_t ncell_total, size_t first, size_t count,
+    k_pack_products(const PR *fmax, const int *rmax, const PR *vel12, size_t ncell_total, size_t first, size_t count,
                     char *aos, size_t stride, int off_rmax, int off_fmax, int ov0, int ov1, int ov2, int ov3) {
   const int ov[4] = {ov0, ov1, ov2, ov3};
   for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += (size_t)gridDim.x * blockDim.x) {
     const size_t i = first + j;
     char *rec = aos + j * stride;
     if (off_rmax >= 0) *reinterpret_cast<int *>(rec + off_rmax) = rmax[i];
-    if (off_fmax >= 0) *reinterpret_cast<float *>(rec + off_fmax) = fmax[i];
+    if (off_fmax >= 0) *reinterpret_cast<PR *>(rec + off_fmax) = fmax[i];
 #pragma unroll
     for (int o = 0; o < 4; o++)
       if (ov[o] >= 0) {
-        float *v = reinterpret_cast<float *>(rec + ov[o]);
+        PR *v = reinterpret_cast<PR *>(rec + ov[o]);
         v[0] = vel12[(size_t)(3 * o + 0) * ncell_total + i];
         v[1] = vel12[(size_t)(3 * o + 1) * ncell_total + i];
         v[2] = vel12[(size_t)(3 * o + 2) * ncell_total + i];
@@ -428,7 +435,8 @@ __global__ void __launch_bounds__(PF_CELL_BLOCK)
 }
 
 // K11 (src/fmax.c:517-525)
-__global__ void __launch_bounds__(PF_CELL_BLOCK) k_fmax_pdf(const float *fmax, size_t ncell, unsigned long long *hist) {
+template <typename PR>
+__global__ void __launch_bounds__(PF_CELL_BLOCK) k_fmax_pdf(const PR *fmax, size_t ncell, unsigned long long *hist) {
   __shared__ unsigned int sh[210];
   for (int i = threadIdx.x; i < 210; i += blockDim.x) sh[i] = 0;
   __syncthreads();
@@ -517,54 +525,54 @@ int pf_launch_ct_build(const PfSplineDev &sp, const PfCtDev &ct, int fast, int c
   hipLaunchKernelGGL(k_ct_splines, dim3((PF_CT_NBINS_XY * PF_CT_NBINS_XY + PF_CELL_BLOCK - 1) / PF_CELL_BLOCK), dim3(PF_CELL_BLOCK), 0, st, ct);
   return PF_CHECK_LAUNCH();
 }
-int pf_launch_collapse(int fb, const PfCollapseParams &p, hipStream_t st) {
+// one kernel per (field type, libm flavour, variant, PRODFLOAT); double products exist with fp64 fields only
+template <typename PR> static int pf_launch_collapse_as(int fb, const PfCollapseParams &p, hipStream_t st) {
+  constexpr bool F32_FIELDS_TOO = std::is_same<PR, float>::value;
   if (p.spline.n > PF_MAX_KNOTS) return 2;
+  if (fb != 8 && !F32_FIELDS_TOO) return 2;
+  const dim3 g(p.nblocks), b(PF_CELL_BLOCK);
+#define PF_BY_FIELD_AND_LIBM(K)                                                            \
+  do {                                                                                     \
+    if (fb == 8) {                                                                         \
+      if (p.fast) hipLaunchKernelGGL((K<double, true, PR>), g, b, 0, st, p);               \
+      else hipLaunchKernelGGL((K<double, false, PR>), g, b, 0, st, p);                     \
+    } else if constexpr (F32_FIELDS_TOO) {                                                 \
+      if (p.fast) hipLaunchKernelGGL((K<float, true, PR>), g, b, 0, st, p);                \
+      else hipLaunchKernelGGL((K<float, false, PR>), g, b, 0, st, p);                      \
+    }                                                                                      \
+  } while (0)
   if (p.tabulated) {
     if (fb == 8) {
-      if (p.fast) pf_launch_collapse_tab<double, true>(p, st);
-      else pf_launch_collapse_tab<double, false>(p, st);
-    } else {
-      if (p.fast) pf_launch_collapse_tab<float, true>(p, st);
-      else pf_launch_collapse_tab<float, false>(p, st);
+      if (p.fast) pf_launch_collapse_tab<double, true, PR>(p, st);
+      else pf_launch_collapse_tab<double, false, PR>(p, st);
+    } else if constexpr (F32_FIELDS_TOO) {
+      if (p.fast) pf_launch_collapse_tab<float, true, PR>(p, st);
+      else pf_launch_collapse_tab<float, false, PR>(p, st);
     }
     return PF_CHECK_LAUNCH();
   }
   if (p.sources) {
     if (p.invariants || p.tabulated || p.sng) return 2;
-    if (fb == 8) {
-      if (p.fast) hipLaunchKernelGGL((k_collapse_src<double, true>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
-      else hipLaunchKernelGGL((k_collapse_src<double, false>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
-    } else {
-      if (p.fast) hipLaunchKernelGGL((k_collapse_src<float, true>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
-      else hipLaunchKernelGGL((k_collapse_src<float, false>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
-    }
+    PF_BY_FIELD_AND_LIBM(k_collapse_src);
     return PF_CHECK_LAUNCH();
   }
   if (p.sng) {
     if (p.invariants) return 2;
-    if (fb == 8) {
-      if (p.fast) hipLaunchKernelGGL((k_collapse_sng<double, true>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
-      else hipLaunchKernelGGL((k_collapse_sng<double, false>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
-    } else {
-      if (p.fast) hipLaunchKernelGGL((k_collapse_sng<float, true>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
-      else hipLaunchKernelGGL((k_collapse_sng<float, false>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
-    }
+    PF_BY_FIELD_AND_LIBM(k_collapse_sng);
     return PF_CHECK_LAUNCH();
   }
   if (p.invariants) {
     if (fb != 8 || p.tabulated) return 2;
-    if (p.fast) hipLaunchKernelGGL((k_collapse_inv<true>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
-    else hipLaunchKernelGGL((k_collapse_inv<false>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
+    if (p.fast) hipLaunchKernelGGL((k_collapse_inv<true, PR>), g, b, 0, st, p);
+    else hipLaunchKernelGGL((k_collapse_inv<false, PR>), g, b, 0, st, p);
     return PF_CHECK_LAUNCH();
   }
-  if (fb == 8) {
-    if (p.fast) hipLaunchKernelGGL((k_collapse<double, true>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
-    else hipLaunchKernelGGL((k_collapse<double, false>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
-  } else {
-    if (p.fast) hipLaunchKernelGGL((k_collapse<float, true>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
-    else hipLaunchKernelGGL((k_collapse<float, false>), dim3(p.nblocks), dim3(PF_CELL_BLOCK), 0, st, p);
-  }
+  PF_BY_FIELD_AND_LIBM(k_collapse);
+#undef PF_BY_FIELD_AND_LIBM
   return PF_CHECK_LAUNCH();
+}
+int pf_launch_collapse(int fb, const PfCollapseParams &p, hipStream_t st) {
+  return p.prod_f64 ? pf_launch_collapse_as<double>(fb, p, st) : pf_launch_collapse_as<float>(fb, p, st);
 }
 int pf_launch_final_sum(const double *partials, int nblocks, double *out2, hipStream_t st) {
   hipLaunchKernelGGL(k_final_sum2, dim3(1), dim3(64), 0, st, partials, nblocks, out2);
@@ -590,15 +598,22 @@ int pf_launch_lpt_accum(int fb, const PfLptAccParams &p, hipStream_t st) {
   else hipLaunchKernelGGL(k_lpt_accum<float>, dim3(g), dim3(PF_CELL_BLOCK), 0, st, p);
   return PF_CHECK_LAUNCH();
 }
-int pf_launch_fill_products(float *fmax, int *rmax, float *vel12, size_t ncell, hipStream_t st) {
-  hipLaunchKernelGGL(k_fill_products, dim3(pf_grid_for(ncell)), dim3(PF_CELL_BLOCK), 0, st, fmax, rmax, vel12, ncell);
+int pf_launch_fill_products(void *fmax, int *rmax, void *vel12, size_t ncell, int pb, hipStream_t st) {
+  const dim3 g(pf_grid_for(ncell)), b(PF_CELL_BLOCK);
+  if (pb == 8) hipLaunchKernelGGL(k_fill_products<double>, g, b, 0, st, (double *)fmax, rmax, (double *)vel12, ncell);
+  else hipLaunchKernelGGL(k_fill_products<float>, g, b, 0, st, (float *)fmax, rmax, (float *)vel12, ncell);
   return PF_CHECK_LAUNCH();
 }
-int pf_launch_pack_products(const float *fmax, const int *rmax, const float *vel12, size_t ncell_total, size_t first,
+int pf_launch_pack_products(int pb, const void *fmax, const int *rmax, const void *vel12, size_t ncell_total, size_t first,
                             size_t count, char *aos, size_t stride, int off_rmax, int off_fmax, const int ov[4],
                             hipStream_t st) {
-  hipLaunchKernelGGL(k_pack_products, dim3(pf_grid_for(count)), dim3(PF_CELL_BLOCK), 0, st, fmax, rmax, vel12,
-                     ncell_total, first, count, aos, stride, off_rmax, off_fmax, ov[0], ov[1], ov[2], ov[3]);
+  const dim3 g(pf_grid_for(count)), b(PF_CELL_BLOCK);
+  if (pb == 8)
+    hipLaunchKernelGGL(k_pack_products<double>, g, b, 0, st, (const double *)fmax, rmax, (const double *)vel12, ncell_total, first, count, aos,
+                       stride, off_rmax, off_fmax, ov[0], ov[1], ov[2], ov[3]);
+  else
+    hipLaunchKernelGGL(k_pack_products<float>, g, b, 0, st, (const float *)fmax, rmax, (const float *)vel12, ncell_total, first, count, aos,
+                       stride, off_rmax, off_fmax, ov[0], ov[1], ov[2], ov[3]);
   return PF_CHECK_LAUNCH();
 }
 int pf_launch_apply_growth(int fb, const void *in, void *out, int n, int nyl, int nzh, int nzp, int y0, const double *T, int nk,
@@ -614,16 +629,18 @@ int pf_launch_gen_filter(const void *in, void *out, int n, int a, int b, double 
                      (pfc<double> *)out, n, a, b, rs, growth, T, nk, logkmin, dlogk, sign, norm);
   return PF_CHECK_LAUNCH();
 }
-int pf_launch_real_to_col(const double *src, float *dst, size_t ncell, hipStream_t st) {
-  hipLaunchKernelGGL(k_real_to_col, dim3(pf_grid_for(ncell)), dim3(PF_CELL_BLOCK), 0, st, src, dst, ncell);
+int pf_launch_real_to_col(const double *src, void *dst, size_t ncell, int pb, hipStream_t st) {
+  if (pb == 8) hipLaunchKernelGGL(k_real_to_col<double>, dim3(pf_grid_for(ncell)), dim3(PF_CELL_BLOCK), 0, st, src, (double *)dst, ncell);
+  else hipLaunchKernelGGL(k_real_to_col<float>, dim3(pf_grid_for(ncell)), dim3(PF_CELL_BLOCK), 0, st, src, (float *)dst, ncell);
   return PF_CHECK_LAUNCH();
 }
 int pf_launch_scale_real(double *f, size_t ncell, double s, hipStream_t st) {
   hipLaunchKernelGGL(k_scale_real, dim3(pf_grid_for(ncell)), dim3(PF_CELL_BLOCK), 0, st, f, ncell, s);
   return PF_CHECK_LAUNCH();
 }
-int pf_launch_fmax_pdf(const float *fmax, size_t ncell, unsigned long long *hist, hipStream_t st) {
-  hipLaunchKernelGGL(k_fmax_pdf, dim3(pf_grid_for(ncell)), dim3(PF_CELL_BLOCK), 0, st, fmax, ncell, hist);
+int pf_launch_fmax_pdf(const void *fmax, size_t ncell, unsigned long long *hist, int pb, hipStream_t st) {
+  if (pb == 8) hipLaunchKernelGGL(k_fmax_pdf<double>, dim3(pf_grid_for(ncell)), dim3(PF_CELL_BLOCK), 0, st, (const double *)fmax, ncell, hist);
+  else hipLaunchKernelGGL(k_fmax_pdf<float>, dim3(pf_grid_for(ncell)), dim3(PF_CELL_BLOCK), 0, st, (const float *)fmax, ncell, hist);
   return PF_CHECK_LAUNCH();
 }
 int pf_launch_spec_import(int fb, const double *src, void *dst, long long nrows, int nzh, int nzp, hipStream_t st) {

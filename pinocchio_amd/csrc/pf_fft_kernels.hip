@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(TL *(N / 16)) k_c2r(const PfC2RParams p) {
   if (row < p.nlines) {
     const F norm = (F)p.norm;
     const F dcv = p.dc ? (F)(*p.dc) : (F)0;
-    if (p.job[job].out_f32) {
+    if (p.job[job].out_f32 == 1) {
       float2 *o = reinterpret_cast<float2 *>(reinterpret_cast<float *>(p.job[job].out) + row * (long long)N);
 #pragma unroll
       for (int m = 0; m < 8; m++) {
@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(TL *(N / 16)) k_c2r(const PfC2RParams p) {
         o[n2] = make_float2((float)pf_norm_dc(v[m].x, norm, dcv), (float)pf_norm_dc(v[m].y, norm, dcv));
       }
     } else {
-      C *o = reinterpret_cast<C *>(reinterpret_cast<F *>(p.job[job].out) + row * p.out_pitch);
+      C *o = reinterpret_cast<C *>(reinterpret_cast<F *>(p.job[job].out) + row * (p.job[job].out_f32 == 2 ? (long long)N : p.out_pitch));
 #pragma unroll
       for (int m = 0; m < 8; m++) {
         const int n2 = tl + m * NT;
@@ -241,13 +241,13 @@ __global__ void __launch_bounds__(TL *(N / 16)) k_c2r_persistent(const PfC2RPara
         v, tlj, tw, [&](int pos, C val) { L[pf_lpad(pos)] = val; }, [&](int pos) { return L[pf_lpad(pos)]; });
     const long long row = (t / p.njobs) * TL + lj;
     if (row < p.nlines) {
-      if (p.job[job].out_f32) {
+      if (p.job[job].out_f32 == 1) {
         float2 *o = reinterpret_cast<float2 *>(reinterpret_cast<float *>(p.job[job].out) + row * (long long)N);
 #pragma unroll
         for (int m = 0; m < 8; m++)
           o[tlj + m * NT] = make_float2((float)pf_norm_dc(v[m].x, norm, dcv), (float)pf_norm_dc(v[m].y, norm, dcv));
       } else {
-        C *o = reinterpret_cast<C *>(reinterpret_cast<F *>(p.job[job].out) + row * p.out_pitch);
+        C *o = reinterpret_cast<C *>(reinterpret_cast<F *>(p.job[job].out) + row * (p.job[job].out_f32 == 2 ? (long long)N : p.out_pitch));
 #pragma unroll
         for (int m = 0; m < 8; m++) pf_st_stream(&o[tlj + m * NT], pf_mk<F>(pf_norm_dc(v[m].x, norm, dcv), pf_norm_dc(v[m].y, norm, dcv)));
       }

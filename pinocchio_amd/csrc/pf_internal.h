@@ -65,7 +65,7 @@ int pf_launch_exp_table(double *etab, int n, double rs, hipStream_t st);
 
 struct PfC2RJob {
   const void *in;   // complex rows
-  void *out;        // real rows (type F, pitch out_pitch) or float rows (pitch n) when out_f32
+  void *out;        // real rows (type F, pitch out_pitch); out_f32 == 1: float rows of pitch n; == 2: rows of type F, pitch n
   int mul;          // multiplier in kz
   int out_f32;
 };
@@ -118,7 +118,8 @@ struct PfCollapseParams {
   long long pitch;
   long long nrows;      // nx_local * n
   int n;                // row length
-  float *fmax;
+  void *fmax;           // products.Fmax: float, or double when prod_f64 (-DDOUBLE_PRECISION_PRODUCTS, fp64 fields only)
+  int prod_f64;
   int *rmax;
   int ismooth;
   PfSplineDev spline;
@@ -160,13 +161,14 @@ struct PfLptAccParams {
 int pf_launch_lpt_accum(int field_bytes, const PfLptAccParams &p, hipStream_t st);
 
 int pf_launch_sum1(const double *partials, int nblocks, double scale, double *out, hipStream_t st);
-int pf_launch_fill_products(float *fmax, int *rmax, float *vel12, size_t ncell, hipStream_t st);
+// pb: bytes of a PRODFLOAT (4, or 8 for -DDOUBLE_PRECISION_PRODUCTS): the type of fmax[] and of the twelve vel12 columns
+int pf_launch_fill_products(void *fmax, int *rmax, void *vel12, size_t ncell, int pb, hipStream_t st);
 int pf_launch_apply_growth(int fb, const void *in, void *out, int n, int nyl, int nzh, int nzp, int y0, const double *T, int nk,
                            double logkmin, double dlogk, double sign, hipStream_t st);
-int pf_launch_pack_products(const float *fmax, const int *rmax, const float *vel12, size_t ncell_total,
+int pf_launch_pack_products(int pb, const void *fmax, const int *rmax, const void *vel12, size_t ncell_total,
                             size_t first, size_t count, char *aos, size_t stride, int off_rmax, int off_fmax,
                             const int off_vel[4], hipStream_t st);
-int pf_launch_fmax_pdf(const float *fmax, size_t ncell, unsigned long long *hist, hipStream_t st);
+int pf_launch_fmax_pdf(const void *fmax, size_t ncell, unsigned long long *hist, int pb, hipStream_t st);
 // copy + pitch/precision conversion of a half-spectrum between the boundary layout
 // (fp64, rows of nzh complex) and the internal one (F, rows of nzp complex)
 int pf_launch_spec_import(int field_bytes, const double *src, void *dst, long long nrows, int nzh, int nzp, hipStream_t st);
@@ -176,7 +178,7 @@ int pf_launch_real_export(int field_bytes, const void *src, double *dst, long lo
 // general grid sizes (library-FFT path)
 int pf_launch_gen_filter(const void *in, void *out, int n, int a, int b, double rs, double growth, const double *T, int nk, double logkmin,
                          double dlogk, double sign, double norm, hipStream_t st);
-int pf_launch_real_to_col(const double *src, float *dst, size_t ncell, hipStream_t st);
+int pf_launch_real_to_col(const double *src, void *dst, size_t ncell, int pb, hipStream_t st);
 int pf_launch_scale_real(double *f, size_t ncell, double s, hipStream_t st);
 // pf_gfft.cpp: hipFFT plans (double precision, n^3, natural layouts: spectrum [n][n][n/2+1], real [n][n][n])
 int pf_gfft_create(int n, hipStream_t st, void **c2r, void **r2c);

@@ -211,6 +211,9 @@ int compute_fft_plans(void) {
   cfg.device = pf_device_of_rank >= 0 ? pf_device_of_rank : 0;
   cfg.field_bytes = 8;
   cfg.flags = PF_FLAG_TIMING; /* cputime.fft like the reference (src/fmax-pfft.c:195-199) */
+#if defined(PF_IN_PINOCCHIO_TREE) && defined(DOUBLE_PRECISION_PRODUCTS)
+  cfg.flags |= PF_FLAG_DOUBLE_PRODUCTS; /* PRODFLOAT double (src/pinocchio.h:219-225): Fmax and Vel* stay fp64 on the device too */
+#endif
   if (pf_context) return 0;
   if (pf_create(&pf_context, &cfg)) return 1;
   if (pf_set_lpt_order(pf_context, PF_LPT_ORDER)) return 1;

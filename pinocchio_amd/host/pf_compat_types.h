@@ -17,7 +17,11 @@
 enum { NBINS = 210, LBLENGTH = 400, SBLENGTH = 100, MAXOUTPUTS = 100, ALIGN = 32 };
 enum { _x_ = 0, _y_ = 1, _z_ = 2 };
 
-typedef float PRODFLOAT; /* :219-225, no DOUBLE_PRECISION_PRODUCTS */
+#if defined(PF_IN_PINOCCHIO_TREE) && defined(DOUBLE_PRECISION_PRODUCTS) /* :219-225 (only the type-check of the in-tree branches gets here) */
+typedef double PRODFLOAT;
+#else
+typedef float PRODFLOAT;
+#endif
 
 /* One mirror per reference struct: same member names, types and order (the adapter source compiles against either),
    one member per line with the field's role on the path. */

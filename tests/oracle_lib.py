@@ -21,23 +21,31 @@ PRODUCT_DTYPE = np.dtype(
     [("Rmax", "<i4"), ("Fmax", "<f4"), ("Vel", "<f4", 3), ("Vel_2LPT", "<f4", 3),
      ("Vel_3LPT_1", "<f4", 3), ("Vel_3LPT_2", "<f4", 3)], align=False)
 assert PRODUCT_DTYPE.itemsize == 56
+# a -DDOUBLE_PRECISION_PRODUCTS build (PRODFLOAT double, src/pinocchio.h:219-225): natural alignment puts Fmax at byte 8
+PRODUCT_DTYPE_DP = np.dtype(
+    {"names": ["Rmax", "Fmax", "Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"],
+     "formats": ["<i4", "<f8", ("<f8", 3), ("<f8", 3), ("<f8", 3), ("<f8", 3)],
+     "offsets": [0, 8, 16, 40, 64, 88], "itemsize": 112})
+SO_DP = os.path.join(ORACLE_DIR, "libpf_oracle_dp.so")
 
 _lib = None
+_lib_dp = None
 
 
 def build(force: bool = False) -> str:
     srcs = [os.path.join(ORACLE_DIR, f) for f in ("pf_oracle.c", "pf_oracle.h", "pf_genic.c", "pf_sng.c")]
-    stale = (not os.path.exists(SO)) or os.path.getmtime(SO) < max(os.path.getmtime(f) for f in srcs)
+    stale = any((not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs) for so in (SO, SO_DP))
     if force or stale:
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "-B"])
     return SO
 
 
-def lib():
-    global _lib
-    if _lib is None:
+def lib(double_products: bool = False):
+    """the oracle, or its -DDOUBLE_PRECISION_PRODUCTS build"""
+    global _lib, _lib_dp
+    if (_lib_dp if double_products else _lib) is None:
         build()
-        L = C.CDLL(SO)
+        L = C.CDLL(SO_DP if double_products else SO)
         dp = C.POINTER(C.c_double)
         L.orc_create.restype = C.c_void_p
         L.orc_create.argtypes = [C.c_int, C.c_int]
@@ -85,8 +93,11 @@ def lib():
         L.orc_set_modified_gravity.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int, dp]
         L.orc_select_sorted.restype = C.c_size_t
         L.orc_select_sorted.argtypes = [C.c_void_p, C.c_float, C.POINTER(C.c_uint), C.POINTER(C.c_float)]
-        _lib = L
-    return _lib
+        if double_products:
+            _lib_dp = L
+        else:
+            _lib = L
+    return _lib_dp if double_products else _lib
 
 
 def _dp(a):
@@ -96,8 +107,9 @@ def _dp(a):
 class Oracle:
     """One oracle context on an n^3 grid."""
 
-    def __init__(self, n: int, nthreads: int = 0):
-        self.L = lib()
+    def __init__(self, n: int, nthreads: int = 0, double_products: bool = False):
+        self.L = lib(double_products)
+        self.product_dtype = PRODUCT_DTYPE_DP if double_products else PRODUCT_DTYPE
         self.n = n
         if nthreads <= 0:  # the slab loops have n iterations: more threads than n/4 only add fork/join cost (256-thread hosts)
             nthreads = max(1, min(os.cpu_count() or 1, n // 4))
@@ -201,8 +213,8 @@ class Oracle:
     def products(self) -> np.ndarray:
         n = self.n
         ptr = self.L.orc_products(self.h)
-        buf = (C.c_char * (PRODUCT_DTYPE.itemsize * n ** 3)).from_address(ptr)
-        return np.frombuffer(buf, dtype=PRODUCT_DTYPE).reshape(n, n, n).copy()
+        buf = (C.c_char * (self.product_dtype.itemsize * n ** 3)).from_address(ptr)
+        return np.frombuffer(buf, dtype=self.product_dtype).reshape(n, n, n).copy()
 
     def kvector(self, which: int) -> np.ndarray:
         n = self.n

@@ -196,7 +196,8 @@ LPT3 = ["-DTWO_LPT", "-DTHREE_LPT"]          # the reference Makefile's defaults
                                    LPT3 + ["-DTABULATED_CT", "-DALL_SPLINE"],
                                    LPT3 + ["-DTABULATED_CT", "-DELL_SNG", "-DMOD_GRAV_FR", "-DFR0=1e-5"],
                                    LPT3 + ["-DRECOMPUTE_DISPLACEMENTS", "-DSCALE_DEPENDENT"],
-                                   ["-DTWO_LPT"], ["-DTWO_LPT", "-DRECOMPUTE_DISPLACEMENTS"], [], ["-DTHREE_LPT"]])
+                                   ["-DTWO_LPT"], ["-DTWO_LPT", "-DRECOMPUTE_DISPLACEMENTS"], [], ["-DTHREE_LPT"],
+                                   LPT3 + ["-DDOUBLE_PRECISION_PRODUCTS", "-DRECOMPUTE_DISPLACEMENTS"]])
 def test_in_tree_build_of_the_adapter_type_checks(flags):
     """INTEGRATION.md's recipe compiles pf_compat.c with -DPF_IN_PINOCCHIO_TREE against the reference's pinocchio.h; MPI, GSL
     and PFFT are not in this image, so the #ifdef branches are type-checked (-fsyntax-only) against declaration-only

@@ -822,6 +822,47 @@ def test_tabulated_ct_build_vs_oracle(api):
     assert np.mean(p2["Rmax"] != po["Rmax"]) < 1e-3
 
 
+@pytest.mark.parametrize("n", [32, 64])
+def test_double_precision_products_build_vs_oracle(api, n):
+    """-DDOUBLE_PRECISION_PRODUCTS (src/Makefile:68; PRODFLOAT double, src/pinocchio.h:219-225): Fmax is kept and compared in
+    fp64 -- the running maximum is no longer rounded to fp32 between radii (src/collapse_times.c:587-590) -- and the Vel*
+    fields take the doubles the transforms produce.  PF_FLAG_DOUBLE_PRODUCTS against the oracle built with the same flag
+    (112-byte records); the sweep with invariants, the six-component route, the sources formed by the last solve."""
+    dk = synth.make_density(n, seed=61 + n)
+    dk[0, 0, 0] = 0.05 * n ** 3
+    x, y = synth.invgrow_table("lcdm")
+    g = synth.growth_multipliers()
+    radii = np.array([n / 16.0, 1.5, 0.7, 0.0])
+    o = oracle_lib.Oracle(n, 0, double_products=True)
+    o.set_density(dk); o.set_invgrow(x, y); o.set_growth(g)
+    tv_o = o.compute_fmax(radii, do_lpt=True)
+    po = o.products()
+    assert po.dtype.itemsize == 112 and po["Fmax"].dtype == np.float64
+    o32 = oracle_lib.Oracle(n, 0)
+    o32.set_density(dk); o32.set_invgrow(x, y); o32.set_growth(g)
+    o32.compute_fmax(radii, do_lpt=True)
+    p32 = o32.products()
+    with api.Fmax(n, double_products=True) as f:
+        f.set_density(dk); f.set_invgrow(x, y); f.set_growth(g)
+        tv = f.compute_fmax(radii, do_lpt=True)
+        p = f.products()
+        pdf = f.Fmax_PDF()
+        with pytest.raises(api.PinfmaxError):
+            f.select_sorted(1.0)                       # fp32 by definition
+    assert p.dtype.itemsize == 112 and np.allclose(tv, tv_o, rtol=1e-12)
+    # Fmax in fp64: the default libm flavour against glibc, as in the fp32 build but without the fp32 rounding on top
+    rel = np.abs(p["Fmax"] - po["Fmax"]) / np.maximum(1.0, np.abs(po["Fmax"]))
+    assert np.mean(rel > 1e-10) < 1e-3 and np.quantile(rel, 0.99) < 1e-12, (np.mean(rel > 1e-10), np.quantile(rel, 0.99))
+    assert np.mean(p["Rmax"] != po["Rmax"]) < 1e-3
+    assert np.abs(pdf.astype(np.int64) - o.fmax_pdf().astype(np.int64)).sum() <= 4
+    for name in ("Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+        amp = np.max(np.abs(po[name]))
+        assert amp > 0 and np.max(np.abs(p[name] - po[name])) <= 1e-12 * amp, name      # fp64 all the way: no 6e-8 floor
+    # and they are the fp32 build's numbers before rounding
+    assert np.max(np.abs(p["Vel"].astype(np.float32) - p32["Vel"])) <= np.spacing(np.float32(np.abs(p32["Vel"]).max()))
+    assert not np.array_equal(p["Fmax"].astype(np.float32).astype(np.float64), p["Fmax"])
+
+
 @pytest.mark.parametrize("flavour", [1, 2])
 def test_trilinear_and_all_spline_table_interpolation_vs_oracle(api, flavour):
     """a build with -DTRILINEAR (1) or -DALL_SPLINE (2) in OPTIONS (src/collapse_times.c:1153-1216, the three choices of

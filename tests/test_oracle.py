@@ -411,6 +411,31 @@ def test_trilinear_and_all_spline_table_interpolation_vs_independent_constructio
         assert np.median(np.abs(res[fl][both] - res[0][both]) / res[0][both]) < 5e-3 and not np.array_equal(res[fl], res[0])
 
 
+def test_double_precision_products_build_of_the_oracle():
+    """-DDOUBLE_PRECISION_PRODUCTS (PRODFLOAT double, src/pinocchio.h:219-225): the same restatement with the one typedef
+    changed.  Displacements: the float build's values are these rounded once; Fmax: without the fp32 rounding of the running
+    maximum (quirk Q2 has nothing left to act on) -- so Rmax may move where two radii give F within an fp32 ulp."""
+    n = 16
+    dk = synth.make_density(n, seed=33)
+    x, y = synth.invgrow_table("lcdm")
+    g = synth.growth_multipliers()
+    radii = np.array([2.0, 1.0, 0.0])
+    res = []
+    for dp in (False, True):
+        o = oracle_lib.Oracle(n, 2, double_products=dp)
+        o.set_density(dk); o.set_invgrow(x, y); o.set_growth(g)
+        tv = o.compute_fmax(radii, do_lpt=True)
+        res.append((tv, o.products(), o.fmax_pdf()))
+    (tv4, p4, h4), (tv8, p8, h8) = res
+    assert p4.dtype.itemsize == 56 and p8.dtype.itemsize == 112
+    assert np.array_equal(tv4, tv8)
+    for name in ("Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+        assert p8[name].dtype == np.float64 and np.array_equal(p8[name].astype(np.float32), p4[name]), name
+    assert np.array_equal(p8["Fmax"].astype(np.float32), p4["Fmax"]) or np.mean(p8["Fmax"].astype(np.float32) != p4["Fmax"]) < 1e-3
+    assert np.mean(p8["Rmax"] != p4["Rmax"]) < 1e-3 and np.abs(h4.astype(np.int64) - h8.astype(np.int64)).sum() <= 4
+    assert not np.array_equal(p8["Fmax"].astype(np.float32).astype(np.float64), p8["Fmax"])
+
+
 def _sng_rhs(t, y, cosmo):
     O0, OL, Or, Ok, fr0, hoc, size = cosmo
     z = 1.0 / t - 1.0
