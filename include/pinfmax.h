@@ -123,6 +123,13 @@ void *pf_get_stream(pf_ctx *ctx);
    fp64 [n/nranks][n][n/2+1][2], pre-multiplied by N^3 (src/GenIC.c:430-445).
    host pointer; uploaded (and converted to fp32 when field_bytes == 4). */
 int pf_set_density(pf_ctx *ctx, const double *kdensity_slab);
+/* params.use_transposed_fft (PFFT_TRANSPOSED_OUT on slabs, src/fmax-pfft.c:92, 271-281): with on != 0 every spectrum that
+   crosses this interface -- pf_set_density, pf_get_density, pf_get_kvector, pf_forward_transform (out),
+   pf_reverse_transform / pf_derivative (in) -- is this rank's KY-slab in the memory order [ky_local][kx][kz][2]
+   (ky_local = n/nranks rows starting at rank * n/nranks) instead of the kx-slab [kx_local][ky][kz][2].  The device
+   layout is a ky-slab anyway, so the regrouping all-to-all of the non-transposed boundary disappears.  Call it right
+   after pf_create; results do not depend on it. */
+int pf_set_transposed_spectra(pf_ctx *ctx, int on);
 /* synthetic delta(k) generated in HBM (bench / large property tests):
    Philox-4x32 white noise, P(k) ~ k^slope inside the Nyquist sphere, DC and
    Nyquist planes zero, sigma(R=0) = sigma0.  numpy mirror:

@@ -169,6 +169,10 @@ class Fmax:
         self._chk(self.L.pf_collapse_times(self.h, ismooth, C.byref(tv)))
         return tv.value
 
+    def set_transposed_spectra(self, on: bool):
+        """spectra cross the interface as [ky_local][kx][kz] (params.use_transposed_fft on slabs)"""
+        self._chk(self.L.pf_set_transposed_spectra(self.h, 1 if on else 0))
+
     def set_ct_interpolation(self, flavour: int):
         """0 BILINEAR_SPLINE (default), 1 -DTRILINEAR, 2 -DALL_SPLINE"""
         self._chk(self.L.pf_set_ct_interpolation(self.h, int(flavour)))

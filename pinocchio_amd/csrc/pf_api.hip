@@ -134,6 +134,7 @@ struct pf_ctx {
   // pf_set_sources_in_sweep: the solve of a sweep's last radius also writes the LPT sources (S[0..2], real space) and the
   // sum of S2; sources_fresh says they are what pf_displacements(1, 0) would compute from the Hessian in B
   bool sweep_sources, sources_fresh;
+  bool transposed; // spectra cross the boundary as [ky_local][kx][kz] (pf_set_transposed_spectra)
   int ct_flavour; // table interpolation of the build: 0 BILINEAR_SPLINE, 1 TRILINEAR, 2 ALL_SPLINE (pf_set_ct_interpolation)
   int lpt_order;  // 3: -DTWO_LPT -DTHREE_LPT (default), 2: -DTWO_LPT only, 1: Zel'dovich only (pf_set_lpt_order)
   double *partials_src;  // PF_NBLK
@@ -342,7 +343,7 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   c->dev_bytes = 0; c->own_stream = true; c->stream = nullptr;
   c->a2a = nullptr; c->a2av = nullptr; c->a2av_user = nullptr; c->ared = nullptr; c->a2a_user = c->ared_user = nullptr; c->rccl = nullptr;
   c->have_density = c->have_hessian = c->have_sources = c->products_init = false; c->last_ns = 0;
-  c->sweep_sources = c->sources_fresh = false; c->partials_src = nullptr; c->lpt_order = 3; c->ct_flavour = 0;
+  c->sweep_sources = c->sources_fresh = false; c->partials_src = nullptr; c->lpt_order = 3; c->ct_flavour = 0; c->transposed = false;
   c->vel_zero_pending = false;
   memset(c->ks_ms, 0, sizeof(c->ks_ms)); memset(c->ks_bytes, 0, sizeof(c->ks_bytes)); memset(c->ks_n, 0, sizeof(c->ks_n));
   memset(&c->cpu, 0, sizeof(c->cpu)); memset(c->spl_set, 0, sizeof(c->spl_set)); memset(c->spl_n, 0, sizeof(c->spl_n));
@@ -816,6 +817,11 @@ static char *staging(pf_ctx *c) { return (char *)c->A[1]; }  // 2 fields of scra
 static int import_spec(pf_ctx *c, const double *host, void *dst) {
   const long long nrows = (long long)c->nxl * c->n;
   HIPCHK(c, hipMemcpyAsync(staging(c), host, (size_t)nrows * c->nzh * 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (c->transposed) {  // the caller's slab is a ky-slab already: a local swap of the two leading indices, nothing to exchange
+    HIPCHK(c, hipMemsetAsync(dst, 0, c->field_bytes, c->stream));
+    PFCHK(c, pf_launch_spec_import_t(c->fb, (const double *)staging(c), dst, c->n, c->nyl, c->nzh, c->nzp, c->stream));
+    return 0;
+  }
   if (c->P == 1) {
     HIPCHK(c, hipMemsetAsync(dst, 0, c->field_bytes, c->stream));
     PFCHK(c, pf_launch_spec_import(c->fb, (const double *)staging(c), dst, nrows, c->nzh, c->nzp, c->stream));
@@ -831,6 +837,12 @@ static int import_spec(pf_ctx *c, const double *host, void *dst) {
 static int export_spec(pf_ctx *c, const void *spec, double *host) {
   const long long nrows = (long long)c->nxl * c->n;
   const void *rows = spec;
+  if (c->transposed) {
+    PFCHK(c, pf_launch_spec_export_t(c->fb, spec, (double *)staging(c), c->n, c->nyl, c->nzh, c->nzp, c->stream));
+    HIPCHK(c, hipMemcpyAsync(host, staging(c), (size_t)nrows * c->nzh * 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+  }
   if (c->P > 1) {  // KY has x slowest: the block for the owner of an x-slab is contiguous, no pack
     void *blocks = recv_field(c, 0, 1), *r = recv_field(c, 0, 2);
     PFCHK(c, exchange(c, spec, blocks));
@@ -1181,6 +1193,11 @@ extern "C" int pf_sweep(pf_ctx *c, int ns, const double *radius_cells, double *t
   return rc;
 }
 extern "C" int pf_debug_invariant_reruns(pf_ctx *c) { return c ? c->inv_reruns : -1; }
+extern "C" int pf_set_transposed_spectra(pf_ctx *c, int on) {
+  if (!c) return 1;
+  c->transposed = on != 0;
+  return 0;
+}
 extern "C" int pf_set_ct_interpolation(pf_ctx *c, int flavour) {
   if (!c) return 1;
   if (flavour < 0 || flavour > 2) return pf_fail(c->rank, "pf_set_ct_interpolation: flavour %d (0 BILINEAR_SPLINE, 1 TRILINEAR, 2 ALL_SPLINE)", flavour);

@@ -470,6 +470,28 @@ __global__ void k_spec_export(const F *src, double *dst, long long nrows, int nz
     dst[i] = (double)src[row * 2 * nzp + r];
   }
 }
+// the same for a caller whose k-space is PFFT_TRANSPOSED_OUT on slabs (params.use_transposed_fft, src/fmax-pfft.c:92,
+// 271-281): host order [ky_local][kx][kz] <-> device KY layout [kx][ky_local][kz] -- the two leading indices swap places
+template <typename F>
+__global__ void k_spec_import_t(const double *src, F *dst, int n, int nyl, int nzh, int nzp) {
+  const long long total = (long long)nyl * n * nzh * 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / (2 * nzh);
+    const long long r = i - row * 2 * nzh;
+    const long long yl = row / n, x = row - yl * n;
+    dst[(x * nyl + yl) * 2 * nzp + r] = (F)src[i];
+  }
+}
+template <typename F>
+__global__ void k_spec_export_t(const F *src, double *dst, int n, int nyl, int nzh, int nzp) {
+  const long long total = (long long)nyl * n * nzh * 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / (2 * nzh);
+    const long long r = i - row * 2 * nzh;
+    const long long yl = row / n, x = row - yl * n;
+    dst[i] = (double)src[(x * nyl + yl) * 2 * nzp + r];
+  }
+}
 template <typename F>
 __global__ void k_real_import(const double *src, F *dst, long long nrows, int n, long long pitch) {
   const long long total = nrows * n;
@@ -653,6 +675,18 @@ int pf_launch_spec_export(int fb, const void *src, double *dst, long long nrows,
   const int g = pf_grid_for((size_t)(nrows * nzh * 2));
   if (fb == 8) hipLaunchKernelGGL(k_spec_export<double>, dim3(g), dim3(PF_CELL_BLOCK), 0, st, (const double *)src, dst, nrows, nzh, nzp);
   else hipLaunchKernelGGL(k_spec_export<float>, dim3(g), dim3(PF_CELL_BLOCK), 0, st, (const float *)src, dst, nrows, nzh, nzp);
+  return PF_CHECK_LAUNCH();
+}
+int pf_launch_spec_import_t(int fb, const double *src, void *dst, int n, int nyl, int nzh, int nzp, hipStream_t st) {
+  const int g = pf_grid_for((size_t)nyl * n * nzh * 2);
+  if (fb == 8) hipLaunchKernelGGL(k_spec_import_t<double>, dim3(g), dim3(PF_CELL_BLOCK), 0, st, src, (double *)dst, n, nyl, nzh, nzp);
+  else hipLaunchKernelGGL(k_spec_import_t<float>, dim3(g), dim3(PF_CELL_BLOCK), 0, st, src, (float *)dst, n, nyl, nzh, nzp);
+  return PF_CHECK_LAUNCH();
+}
+int pf_launch_spec_export_t(int fb, const void *src, double *dst, int n, int nyl, int nzh, int nzp, hipStream_t st) {
+  const int g = pf_grid_for((size_t)nyl * n * nzh * 2);
+  if (fb == 8) hipLaunchKernelGGL(k_spec_export_t<double>, dim3(g), dim3(PF_CELL_BLOCK), 0, st, (const double *)src, dst, n, nyl, nzh, nzp);
+  else hipLaunchKernelGGL(k_spec_export_t<float>, dim3(g), dim3(PF_CELL_BLOCK), 0, st, (const float *)src, dst, n, nyl, nzh, nzp);
   return PF_CHECK_LAUNCH();
 }
 int pf_launch_real_import(int fb, const double *src, void *dst, long long nrows, int n, long long pitch, hipStream_t st) {

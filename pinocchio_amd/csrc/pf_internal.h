@@ -173,6 +173,8 @@ int pf_launch_fmax_pdf(const void *fmax, size_t ncell, unsigned long long *hist,
 // (fp64, rows of nzh complex) and the internal one (F, rows of nzp complex)
 int pf_launch_spec_import(int field_bytes, const double *src, void *dst, long long nrows, int nzh, int nzp, hipStream_t st);
 int pf_launch_spec_export(int field_bytes, const void *src, double *dst, long long nrows, int nzh, int nzp, hipStream_t st);
+int pf_launch_spec_import_t(int fb, const double *src, void *dst, int n, int nyl, int nzh, int nzp, hipStream_t st);
+int pf_launch_spec_export_t(int fb, const void *src, double *dst, int n, int nyl, int nzh, int nzp, hipStream_t st);
 int pf_launch_real_import(int field_bytes, const double *src, void *dst, long long nrows, int n, long long pitch, hipStream_t st);
 int pf_launch_real_export(int field_bytes, const void *src, double *dst, long long nrows, int n, long long pitch, hipStream_t st);
 // general grid sizes (library-FFT path)

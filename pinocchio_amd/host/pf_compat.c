@@ -178,10 +178,6 @@ int set_one_grid(int ThisGrid) {
     printf("ERROR on task %d: NTasks=%d must divide GridSize=%ld (slab decomposition)\n", ThisTask, NTasks, (long)n);
     return 1;
   }
-  if (params.use_transposed_fft) { /* src/fmax-pfft.c:271-281: k-space would be stored [y, x, z] */
-    printf("ERROR on task %d: UseTransposedFFT is not supported by the GPU path (k-space stays in x, y, z order)\n", ThisTask);
-    return 1;
-  }
 #ifdef PF_IN_PINOCCHIO_TREE
   if (internal.tasks_subdivision_dim > 1) { /* src/initialization.c:1317-1325: pencils / volumes */
     printf("ERROR on task %d: the GPU path decomposes the box in slabs (one task per GPU): tasks_subdivision_dim = %d\n", ThisTask,
@@ -195,7 +191,11 @@ int set_one_grid(int ThisGrid) {
   G->GSstart[_x_] = ThisTask * (n / NTasks); G->GSstart[_y_] = 0; G->GSstart[_z_] = 0;
   G->GSlocal_k[_x_] = n / NTasks; G->GSlocal_k[_y_] = n; G->GSlocal_k[_z_] = n / 2 + 1; /* non-transposed output */
   G->GSstart_k[_x_] = G->GSstart[_x_]; G->GSstart_k[_y_] = 0; G->GSstart_k[_z_] = 0;
-  G->total_local_size_fft = (unsigned int)(2 * G->GSlocal_k[_x_] * n * (n / 2 + 1));
+  if (params.use_transposed_fft) { /* PFFT_TRANSPOSED_OUT on slabs (src/fmax-pfft.c:92): k-space is a ky-slab, memory order [y, x, z] (:271-281) */
+    G->GSlocal_k[_x_] = n; G->GSlocal_k[_y_] = n / NTasks;
+    G->GSstart_k[_x_] = 0; G->GSstart_k[_y_] = ThisTask * (n / NTasks);
+  }
+  G->total_local_size_fft = (unsigned int)(2 * (n / NTasks) * n * (n / 2 + 1));
   G->total_local_size = (unsigned int)(G->GSlocal[_x_] * n * n);
   G->off = 0;
   return 0;
@@ -218,6 +218,7 @@ int compute_fft_plans(void) {
   if (pf_create(&pf_context, &cfg)) return 1;
   if (pf_set_lpt_order(pf_context, PF_LPT_ORDER)) return 1;
   if (pf_set_ct_interpolation(pf_context, PF_CT_FLAVOUR)) return 1;
+  if (pf_set_transposed_spectra(pf_context, params.use_transposed_fft)) return 1;
 #if defined(PF_IN_PINOCCHIO_TREE)
   if (NTasks > 1) { /* one rank per GPU: RCCL all-to-all replaces the MPI_Alltoall inside pfft_execute */
     char id[128];

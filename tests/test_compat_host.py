@@ -99,7 +99,8 @@ def test_fdate_is_the_references_rearranged_ctime(lib):
 
 
 def test_geometry_refuses_what_the_path_does_not_do(lib, capfd):
-    """ragged slabs, non-cubic grids and UseTransposedFFT (src/fmax-pfft.c:92, 271-281) fail loudly, in the reference's format"""
+    """ragged slabs and non-cubic grids fail loudly, in the reference's format; UseTransposedFFT (src/fmax-pfft.c:92, 271-281)
+    is a geometry: the k-space extents become those of a ky-slab"""
     grid = C.cast(C.c_void_p.in_dll(lib, "MyGrids"), C.POINTER(Grid)).contents
     par = Params.in_dll(lib, "params")
     ntasks = C.c_int.in_dll(lib, "NTasks")
@@ -110,8 +111,12 @@ def test_geometry_refuses_what_the_path_does_not_do(lib, capfd):
     grid.BoxSize = 128.0
     try:
         par.use_transposed_fft = 1
-        assert lib.set_one_grid(0) == 1
-        assert "ERROR on task 0: UseTransposedFFT" in c_output(capfd)
+        ntasks.value = 4
+        C.c_int.in_dll(lib, "ThisTask").value = 3
+        assert lib.set_one_grid(0) == 0
+        assert [grid.GSlocal_k[i] for i in range(3)] == [n, n // 4, n // 2 + 1] and [grid.GSstart_k[i] for i in range(3)] == [0, 3 * n // 4, 0]
+        assert [grid.GSlocal[i] for i in range(3)] == [n // 4, n, n] and grid.total_local_size_fft == 2 * (n // 4) * n * (n // 2 + 1)
+        C.c_int.in_dll(lib, "ThisTask").value = 0
         par.use_transposed_fft = 0
         ntasks.value = 3
         assert lib.set_one_grid(0) == 1
@@ -123,6 +128,7 @@ def test_geometry_refuses_what_the_path_does_not_do(lib, capfd):
     finally:
         par.use_transposed_fft = 0
         ntasks.value = 1
+        C.c_int.in_dll(lib, "ThisTask").value = 0
         grid.GSglobal[1] = n
     assert lib.set_one_grid(0) == 0
 
@@ -289,14 +295,17 @@ def test_compute_fmax_like_the_reference_driver(lib, tmp_path):
 
 
 @pytest.mark.gpu
-def test_lpt_snapshot_mode_goes_straight_to_the_displacements(lib, tmp_path):
+@pytest.mark.parametrize("transposed", [0, 1])
+def test_lpt_snapshot_mode_goes_straight_to_the_displacements(lib, tmp_path, transposed):
     """"pinocchio.x parameterfile 3" (src/pinocchio.c:172-200, the N-body initial-condition mode of
     tests/Readme_Pinocchio_tests_V5_1.txt): after the initialisation (plans made) the driver calls
     compute_displacements(1, 1, outputs.z[0]) -- second derivatives at R = 0 recomputed, sources, twelve displacement fields --
     and hands the host `products` to write_LPT_snapshot; compute_fmax never runs.  Against the oracle's
-    compute_second_derivatives(0) + compute_LPT_displacements + first derivatives."""
+    compute_second_derivatives(0) + compute_LPT_displacements + first derivatives.  transposed: UseTransposedFFT 1, the
+    setting for initial conditions that reproduce an N-GenIC / 2LPTic run (DOCUMENTATION:377) -- kdensity is stored [y, x, z]."""
     n = 32
     dk = np.ascontiguousarray(synth.make_density(n, seed=77))
+    kdens = np.ascontiguousarray(dk.transpose(1, 0, 2)) if transposed else dk
     g = np.array([0.61, -0.21, 0.017, -0.043])      # growth multipliers at the snapshot's redshift
     x, y = synth.invgrow_table("lcdm")
     assert lib.finalize_fft() == 0                   # whatever an earlier test left behind
@@ -305,12 +314,14 @@ def test_lpt_snapshot_mode_goes_straight_to_the_displacements(lib, tmp_path):
         grid.GSglobal[i] = n
     grid.Ntotal = n ** 3
     grid.BoxSize = n * 2.0
+    par = Params.in_dll(lib, "params")
+    par.use_transposed_fft = transposed
     assert lib.set_one_grid(0) == 0
     prod = np.zeros(n ** 3 * 56 + 64, dtype=np.uint8)
     prod = prod[(-prod.ctypes.data) % 32:][:n ** 3 * 56]
     C.c_void_p.in_dll(lib, "products").value = prod.ctypes.data
     kd = C.cast(C.c_void_p.in_dll(lib, "kdensity"), C.POINTER(C.c_void_p))
-    kd[0] = dk.ctypes.data
+    kd[0] = kdens.ctypes.data
     sm = Smoothing.in_dll(lib, "Smoothing")
     radii = np.array([2.0, 0.0]); tv = np.zeros(2); var = np.ones(2)
     sm.Nsmooth = 2
@@ -339,6 +350,7 @@ def test_lpt_snapshot_mode_goes_straight_to_the_displacements(lib, tmp_path):
         assert lib.finalize_fft() == 0
     finally:
         os.chdir(cwd)
+        par.use_transposed_fft = 0
     p = prod.view(oracle_lib.PRODUCT_DTYPE).reshape(n, n, n)
     o = oracle_lib.Oracle(n, 0)
     o.set_density(dk); o.set_invgrow(x, y); o.set_growth(g)

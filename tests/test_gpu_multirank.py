@@ -108,6 +108,54 @@ def test_slab_ranks_match_single_rank(api, n, P, pipeline, monkeypatch):
         assert np.max(np.abs(a - b)) <= 2e-7 * np.max(np.abs(b))
 
 
+@pytest.mark.parametrize("P", [1, 2, 4])
+def test_transposed_spectra_at_the_boundary(api, P):
+    """params.use_transposed_fft (PFFT_TRANSPOSED_OUT on slabs, src/fmax-pfft.c:92, 271-281): every spectrum crosses the
+    interface as this rank's ky-slab in [ky_local][kx][kz] order.  Same field in -> the very same products, source spectra
+    and transforms out (bit for bit: the device layout and every kernel are the same, only the import / export differ)."""
+    n = 32
+    dk = synth.make_density(n, seed=9)
+    dk[0, 0, 0] = 0.3 * n ** 3
+    x, y = synth.invgrow_table("lcdm")
+    g = synth.growth_multipliers()
+    radii = np.array([2.0, 0.0])
+    nl = n // P
+    dkt = np.ascontiguousarray(dk.transpose(1, 0, 2))                   # [ky][kx][kz]
+    rng = np.random.default_rng(4)
+    real = rng.standard_normal((n, n, n))
+
+    def body(f, r, transposed):
+        f.set_transposed_spectra(transposed)
+        sl = slice(r * nl, (r + 1) * nl)
+        f.set_density(dkt[sl] if transposed else dk[sl])
+        f.set_invgrow(x, y); f.set_growth(g)
+        tv = f.compute_fmax(radii, do_lpt=True)
+        kv = f.kvector(1)
+        spec = f.forward_transform(real[sl])
+        back = f.reverse_transform(dkt[sl] if transposed else dk[sl])
+        der = f.compute_derivative(dkt[sl] if transposed else dk[sl], 1, 2, 1.0, 0)
+        return tv, f.products(), f.density(), kv, spec, back, der
+
+    def run(transposed):
+        if P == 1:
+            with api.Fmax(n) as f:
+                return [body(f, 0, transposed)]
+        return run_ranks(api, n, P, lambda f, r: body(f, r, transposed))
+
+    plain, tr = run(False), run(True)
+    for r in range(P):
+        assert np.array_equal(plain[r][0], tr[r][0])
+        for name in ("Fmax", "Rmax", "Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+            assert np.array_equal(plain[r][1][name], tr[r][1][name]), (r, name)
+        assert np.array_equal(plain[r][5], tr[r][5]) and np.array_equal(plain[r][6], tr[r][6])
+    # spectra out: the transposed ones are the ky-slabs of the same global arrays
+    for k in (2, 3, 4):
+        whole = np.concatenate([plain[r][k] for r in range(P)], axis=0)                  # [kx][ky][kz]
+        whole_t = np.concatenate([tr[r][k] for r in range(P)], axis=0)                   # [ky][kx][kz]
+        assert np.array_equal(whole.transpose(1, 0, 2), whole_t), k
+    assert np.array_equal(np.concatenate([tr[r][2] for r in range(P)], axis=0), dkt)
+
+
 @pytest.mark.parametrize("order", [2, 1])
 def test_lower_lpt_orders_on_slabs(api, order):
     """pf_set_lpt_order (a build without -DTHREE_LPT / -DTWO_LPT) with the exchange pipeline: fewer fields go through it"""
