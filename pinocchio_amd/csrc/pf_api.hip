@@ -95,6 +95,12 @@ struct pf_ctx {
   char *blockA;        // A[0..2] contiguous (also host<->device staging through A[1..2])
   void *dk, *A[3], *B[6], *B2[6], *S[3];
   void *recvA;         // P > 1: 3 fields, all-to-all destination
+  // P > 1 (PF_REPLICATE_DK, default on): every rank also holds the WHOLE delta(k), [kx][ky][kz] with row pitch nzp.  The
+  // passes that start from delta(k) -- the second derivatives of every radius and the Zel'dovich displacements -- then
+  // transform every line on every rank and keep only their own x-slab: no all-to-all for 38 of the 50 field exchanges of
+  // a 12-radius step, at the price of an x-pass that does not shrink with P.  Gathered once per density (dk_full_valid).
+  void *dk_full;
+  bool replicate, dk_full_valid;
   // P > 1: second set of send/receive fields and a communication stream, so that the all-to-all of transform i+1
   // runs beside the y/z passes (and the collapse solve) of transform i (pipelined(), PF_PIPELINE=0 to disable)
   bool pipeline;
@@ -241,6 +247,7 @@ static void read_tuning(PfTuning *t) {
   t->general = env_int("PF_GENERAL", 0) != 0;
 
   t->pipeline = env_int("PF_PIPELINE", 1) != 0;
+  t->replicate = env_int("PF_REPLICATE_DK", 1) != 0;
   t->exact_libm = env_int("PF_EXACT_LIBM", 0) != 0;
   // fault injection for the tests of the exchange pipeline (tests/test_gpu_multirank.py): "recv" drops the wait of the
   // compute stream for the exchange it is about to consume, "send" the wait of the exchange for the x-pass that fills its blocks
@@ -278,6 +285,8 @@ static int create_body(pf_ctx *c, const pf_config *cfg) {
   for (int i = 0; i < 6; i++) PFCHK(c, dev_alloc(c, &c->B[i], c->field_bytes));
   for (int i = 0; i < 3; i++) PFCHK(c, dev_alloc(c, &c->S[i], c->field_bytes));
   if (c->P > 1) PFCHK(c, dev_alloc(c, &c->recvA, 3 * c->field_bytes));
+  c->replicate = c->P > 1 && !c->general && c->tune.replicate;
+  if (c->replicate) PFCHK(c, dev_alloc(c, &c->dk_full, (size_t)c->P * c->field_bytes));
   if (c->pipeline) {
     PFCHK(c, dev_alloc(c, (void **)&c->blockA2, 3 * c->field_bytes));
     PFCHK(c, dev_alloc(c, &c->recvA2, 3 * c->field_bytes));
@@ -350,7 +359,7 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   c->growth[0] = 1.0; c->growth[1] = 3. / 7.; c->growth[2] = -1. / 9.; c->growth[3] = 5. / 42.;
   for (int i = 0; i < 6; i++) { c->B[i] = nullptr; c->B2[i] = nullptr; }
   c->blockA = nullptr; c->dk = nullptr; c->recvA = nullptr; c->tw = nullptr;
-  c->blockA2 = nullptr; c->recvA2 = nullptr; c->cstream = nullptr;
+  c->blockA2 = nullptr; c->recvA2 = nullptr; c->cstream = nullptr; c->dk_full = nullptr; c->replicate = false; c->dk_full_valid = false;
   c->fmax = nullptr; c->rmax = nullptr; c->vel12 = nullptr; c->partials = nullptr; c->scal = nullptr; c->hist = nullptr; c->spl = nullptr;
   c->gtab = nullptr; c->etab = nullptr; c->ct_block = nullptr;
   for (int i = 0; i < 2; i++) c->ev_x[i] = c->ev_r[i] = nullptr;
@@ -374,7 +383,7 @@ extern "C" int pf_destroy(pf_ctx *c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->cstream) hipStreamSynchronize(c->cstream);
   pf_rccl_release(c->rccl); c->rccl = nullptr;
-  hipFree(c->dk); hipFree(c->blockA); hipFree(c->recvA); hipFree(c->tw); hipFree(c->blockA2); hipFree(c->recvA2);
+  hipFree(c->dk); hipFree(c->blockA); hipFree(c->recvA); hipFree(c->tw); hipFree(c->blockA2); hipFree(c->recvA2); hipFree(c->dk_full);
   for (int i = 0; i < 6; i++) { hipFree(c->B[i]); hipFree(c->B2[i]); }
   for (int i = 0; i < 3; i++) hipFree(c->S[i]);
   hipFree(c->fmax); hipFree(c->rmax); hipFree(c->vel12); hipFree(c->partials); hipFree(c->partials_src); hipFree(c->scal); hipFree(c->hist); hipFree(c->spl); hipFree(c->gtab); hipFree(c->etab); hipFree(c->ct_block); hipFree(c->W);
@@ -485,6 +494,17 @@ static PfAddr addr_yblocks_x(const pf_ctx *c, int zp) {  // x-pass output: e = x
 static PfAddr addr_yblocks_y(const pf_ctx *c, int zp) {  // y-pass input: e = y = p*nyl + yl, outer = x_local
   PfAddr a; a.os = zp; a.el_shift = ilog2i(c->nyl); a.ehs = (long long)c->nyl * c->nxl * c->nzp; a.els = (long long)c->nxl * zp; return a;
 }
+// replicated delta(k): the x-pass reads the whole spectrum [kx][ky][kz] (outer = global ky) ...
+static PfAddr addr_full_x(const pf_ctx *c) {
+  PfAddr a; a.os = c->nzp; a.el_shift = ilog2i(c->n); a.ehs = 0; a.els = (long long)c->n * c->nzp; return a;
+}
+// ... and writes this rank's x-slab of every line as [ky][x_local][zp]: what the y-pass then reads in place (e = ky)
+static PfAddr addr_local_x(const pf_ctx *c, int zp) {
+  PfAddr a; a.os = (long long)c->nxl * zp; a.el_shift = ilog2i(c->nxl); a.ehs = 0; a.els = zp; return a;
+}
+static PfAddr addr_local_y(const pf_ctx *c, int zp) {
+  PfAddr a; a.os = zp; a.el_shift = ilog2i(c->n); a.ehs = 0; a.els = (long long)c->nxl * zp; return a;
+}
 static PfAddr addr_xs_y(const pf_ctx *c) {  // XS layout, e = y, outer = x_local
   PfAddr a; a.os = (long long)c->n * c->nzp; a.el_shift = ilog2i(c->n); a.ehs = 0; a.els = c->nzp; return a;
 }
@@ -492,7 +512,7 @@ static PfAddr addr_xs_y(const pf_ctx *c) {  // XS layout, e = y, outer = x_local
 struct Job { const void *in; void *out; int mul; };
 
 static int xpass(pf_ctx *c, int kind, int dir, int njobs, const Job *jobs, int pre, double rs, double growth, int nin, int band = 1 << 30,
-                 bool out_yblocks = false) {
+                 bool out_yblocks = false, bool replicated = false) {
   PfStridedParams p; memset(&p, 0, sizeof(p));
   p.njobs = njobs;
   for (int j = 0; j < njobs; j++) { p.job[j].in = jobs[j].in; p.job[j].out = jobs[j].out; p.job[j].mul = jobs[j].mul; }
@@ -500,6 +520,10 @@ static int xpass(pf_ctx *c, int kind, int dir, int njobs, const Job *jobs, int p
   if (out_yblocks) p.aout = addr_yblocks_x(c, band_zpitch(c, band));
   p.ncols = c->nzh; p.nouter = c->nyl; p.pre = pre; p.outer_offset = c->rank * c->nyl; p.rs = rs; p.growth = growth; p.tw = c->tw;
   p.etab = c->etab; p.dev = c->dev;
+  if (replicated) {  // the input is the whole spectrum: every ky line, only this rank's x-slab of the result
+    p.ain = addr_full_x(c); p.aout = addr_local_x(c, band_zpitch(c, band));
+    p.nouter = c->n; p.outer_offset = 0; p.out_e0 = c->rank * c->nxl; p.out_ne = c->nxl;
+  }
   if (pre && rs != 0.0) PFCHK(c, pf_launch_exp_table(c->etab, c->n, rs, c->stream));  // stream order: after the previous x-pass
   p.band_e = p.band_outer = c->n;
   double frac_cols = 1.0, frac_in = 1.0, frac_outer = 1.0;
@@ -508,17 +532,19 @@ static int xpass(pf_ctx *c, int kind, int dir, int njobs, const Job *jobs, int p
     p.ncols = band + 1;
     frac_cols = (double)(band + 1) / c->nzh; frac_in = frac_outer = (double)(2 * band + 1) / c->n;
   }
-  KTimer t(c, kind, (nin * frac_in + njobs) * frac_cols * frac_outer * spec_bytes_alg(c));
+  // (replicated: the whole spectrum is read, P slabs; one slab per output is written)
+  KTimer t(c, kind, (nin * frac_in * (replicated ? c->P : 1) + njobs) * frac_cols * frac_outer * spec_bytes_alg(c));
   PFCHK(c, pf_launch_strided(c->fb, c->n, dir, p, c->stream));
   return 0;
 }
 // in_blocks: input is the P received blocks (after an all-to-all) else XS; out_blocks likewise (forward direction)
 static int ypass(pf_ctx *c, int kind, int dir, int njobs, const Job *jobs, bool in_blocks, bool out_blocks, int nin, int band = 1 << 30,
-                 bool in_yblocks = false) {
+                 bool in_yblocks = false, bool in_local = false) {
   PfStridedParams p; memset(&p, 0, sizeof(p));
   p.njobs = njobs;
   for (int j = 0; j < njobs; j++) { p.job[j].in = jobs[j].in; p.job[j].out = jobs[j].out; p.job[j].mul = jobs[j].mul; }
   p.ain = in_blocks ? (in_yblocks ? addr_yblocks_y(c, band_zpitch(c, band)) : addr_blocks_y(c)) : addr_xs_y(c);
+  if (in_local) p.ain = addr_local_y(c, band_zpitch(c, band));  // written in place by a replicated x-pass
   p.aout = out_blocks ? addr_blocks_y(c) : addr_xs_y(c);
   p.ncols = c->nzh; p.nouter = c->nxl; p.pre = 0; p.outer_offset = 0; p.rs = 0; p.growth = 1; p.tw = c->tw; p.dev = c->dev;
   p.band_e = p.band_outer = c->n;
@@ -579,9 +605,18 @@ __global__ void k_debug_idle(long long ticks) {
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 template <class Pre, class Dst, class Post, class Band>
-static int pipelined_band(pf_ctx *c, int count, int nf, Pre pre, Dst dst, Post post, Band band) {
+static int pipelined_band(pf_ctx *c, int count, int nf, Pre pre, Dst dst, Post post, Band band, bool local = false) {
   void *A[2][3];
   const void *R[3];
+  if (local) {  // replicated spectrum: pre writes this rank's slab straight into what post reads -- nothing travels
+    for (int i = 0; i < count; i++) {
+      void *D[3];
+      for (int f = 0; f < nf; f++) { D[f] = dst(i, 0, f); R[f] = D[f]; }
+      if (pre(i, D)) return 1;
+      if (post(i, R)) return 1;
+    }
+    return 0;
+  }
   for (int f = 0; f < 3; f++) { A[0][f] = c->A[f]; A[1][f] = c->pipeline ? (void *)(c->blockA2 + f * c->field_bytes) : c->A[f]; }
   if (c->P == 1 || !c->pipeline) {
     for (int i = 0; i < count; i++) {
@@ -690,15 +725,27 @@ static int hess_band(const pf_ctx *c, double rs) {
   }
   return band;
 }
-static int hess_x(pf_ctx *c, const void *spec, double rs, void *const A[3], int band) {
+static int hess_x(pf_ctx *c, const void *spec, double rs, void *const A[3], int band, bool replicated = false) {
   const Job xj[3] = {{spec, A[0], PF_MUL_ONE}, {spec, A[1], PF_MUL_K}, {spec, A[2], PF_MUL_K2}};
-  return xpass(c, KS_XPASS_HESS, +1, 3, xj, 1, rs, 1.0, 1, band, true);
+  return xpass(c, KS_XPASS_HESS, +1, 3, xj, 1, rs, 1.0, 1, band, true, replicated);
+}
+// gathers delta(k) of all ranks into dk_full, once per density: this rank's ky-slab goes to its place in a zeroed array
+// and an integer all-reduce adds the other ranks' zeros to it (exact for either field type; ~2 x 8.6 GB per rank at 1024^3)
+static int ensure_dk_full(pf_ctx *c) {
+  if (!c->replicate || c->dk_full_valid) return 0;
+  const size_t rows = (size_t)c->nyl * c->nzp * 2 * c->fb;  // the nyl rows this rank holds of one kx plane
+  HIPCHK(c, hipMemsetAsync(c->dk_full, 0, (size_t)c->P * c->field_bytes, c->stream));
+  HIPCHK(c, hipMemcpy2DAsync((char *)c->dk_full + (size_t)c->rank * rows, (size_t)c->P * rows, c->dk, rows, rows, (size_t)c->n,
+                             hipMemcpyDeviceToDevice, c->stream));
+  PFCHK(c, allreduce_dev(c, c->dk_full, (size_t)c->P * c->field_bytes / 8, 1));
+  c->dk_full_valid = true;
+  return 0;
 }
 static int hess_yz(pf_ctx *c, const void *const R[3], const double *dc, void *const out[6], int band, bool invariants = false,
-                   void *acc = nullptr, void *const *hfirst = nullptr) {
+                   void *acc = nullptr, void *const *hfirst = nullptr, bool in_local = false) {
   const Job yj[6] = {{R[2], out[0], PF_MUL_ONE}, {R[1], out[3], PF_MUL_K}, {R[1], out[4], PF_MUL_ONE},
                      {R[0], out[1], PF_MUL_K2}, {R[0], out[5], PF_MUL_K},  {R[0], out[2], PF_MUL_ONE}};
-  PFCHK(c, ypass(c, KS_YPASS_HESS, +1, 6, yj, true, false, 3, band, true));
+  PFCHK(c, ypass(c, KS_YPASS_HESS, +1, 6, yj, true, false, 3, band, true, in_local));
   const ZJob zj[6] = {{out[0], out[0], PF_MUL_ONE, 0}, {out[1], out[1], PF_MUL_ONE, 0}, {out[2], out[2], PF_MUL_K2, 0},
                       {out[3], out[3], PF_MUL_ONE, 0}, {out[4], out[4], PF_MUL_K, 0},   {out[5], out[5], PF_MUL_K, 0}};
   if (acc) {  // the z-pass contracts the six rows with the first-order Hessian `hfirst` into `acc` and stores nothing else
@@ -714,11 +761,13 @@ static int hessian_of(pf_ctx *c, const void *spec, double rs, const double *dc, 
                       void *acc = nullptr, void *const *hfirst = nullptr) {
   if (c->general) return g_hessian_of(c, spec, rs, out);
   const int band = hess_band(c, rs);
+  const bool rep = c->replicate && spec == c->dk;  // the LPT source spectra stay distributed: their transposes travel
+  if (rep) PFCHK(c, ensure_dk_full(c));
   return pipelined_band(c, 1, 3,
-                        [&](int, void *const *A) { return hess_x(c, spec, rs, A, band); },
+                        [&](int, void *const *A) { return hess_x(c, rep ? c->dk_full : spec, rs, A, band, rep); },
                         [&](int, int set, int f) { return recv_field(c, set, f); },
-                        [&](int, const void *const *R) { return hess_yz(c, R, dc, out, band, false, acc, hfirst); },
-                        [&](int) { return band; });
+                        [&](int, const void *const *R) { return hess_yz(c, R, dc, out, band, false, acc, hfirst, rep); },
+                        [&](int) { return band; }, rep);
 }
 
 // three first derivatives (displacement components) of specs[j] times growths[j] -> vel12[3*orders[j] .. +2]
@@ -727,11 +776,13 @@ static int hessian_of(pf_ctx *c, const void *spec, double rs, const double *dc, 
 // installed (pf_set_growth_table), applied per mode by k_apply_growth into the spare send field first.
 static int displacements_of(pf_ctx *c, int count, const void *const *specs, const int *orders, void *const tmp[3]) {
   if (c->general) return g_displacements_of(c, count, specs, orders, tmp[0]);
-  const size_t nc = ncell(c);
-  return pipelined(c, count, 2,
+  // items that start from delta(k) itself (the Zel'dovich term) use the replicated spectrum when there is one and no
+  // per-mode growth table has to be applied to it first: nothing travels for them.  They run after the others.
+  auto run = [&](int cnt, const void *const *sp, const int *ord, bool rep) -> int {
+    return pipelined_band(c, cnt, 2,
                    [&](int j, void *const *A) {
-                     const int o = orders[j];
-                     const void *spec = specs[j];
+                     const int o = ord[j];
+                     const void *spec = rep ? c->dk_full : sp[j];
                      double growth = c->growth[o];
                      if (c->gt_n[o]) {
                        KTimer t(c, KS_MISC, 2.0 * spec_bytes_alg(c));
@@ -741,20 +792,34 @@ static int displacements_of(pf_ctx *c, int count, const void *const *specs, cons
                        growth = 1.0;
                      }
                      const Job xj[2] = {{spec, A[0], PF_MUL_ONE}, {spec, A[1], PF_MUL_IK}};
-                     return xpass(c, KS_XPASS_DISP, +1, 2, xj, 1, 0.0, growth, 1, 1 << 30, true);
+                     return xpass(c, KS_XPASS_DISP, +1, 2, xj, 1, 0.0, growth, 1, 1 << 30, true, rep);
                    },
                    [&](int, int set, int f) { return recv_field(c, set, f); },
                    [&](int j, const void *const *R) {
-                     const int o = orders[j];
+                     const int o = ord[j];
                      const Job yj[3] = {{R[1], tmp[0], PF_MUL_ONE}, {R[0], tmp[1], PF_MUL_IK}, {R[0], tmp[2], PF_MUL_ONE}};
-                     PFCHK(c, ypass(c, KS_YPASS_DISP, +1, 3, yj, true, false, 2, 1 << 30, true));
+                     PFCHK(c, ypass(c, KS_YPASS_DISP, +1, 3, yj, true, false, 2, 1 << 30, true, rep));
                      const int compact = c->pb == 8 ? 2 : 1;  // rows of pitch n: float, or the fields' own double
                      const ZJob zj[3] = {{tmp[0], velcol(c, 3 * o + 0), PF_MUL_ONE, compact},
                                          {tmp[1], velcol(c, 3 * o + 1), PF_MUL_ONE, compact},
                                          {tmp[2], velcol(c, 3 * o + 2), PF_MUL_IK, compact}};
                      PFCHK(c, zpass_c2r(c, KS_ZPASS_DISP, 3, zj, nullptr));
                      return 0;
-                   });
+                   },
+                   [](int) { return 1 << 30; }, rep);
+  };
+  const void *far[4], *near_[4];
+  int far_o[4], near_o[4], nfar = 0, nnear = 0;
+  for (int j = 0; j < count; j++) {
+    if (c->replicate && specs[j] == c->dk && !c->gt_n[orders[j]]) { near_[nnear] = specs[j]; near_o[nnear++] = orders[j]; }
+    else { far[nfar] = specs[j]; far_o[nfar++] = orders[j]; }
+  }
+  if (nfar && run(nfar, far, far_o, false)) return 1;
+  if (nnear) {
+    PFCHK(c, ensure_dk_full(c));
+    if (run(nnear, near_, near_o, true)) return 1;
+  }
+  return 0;
 }
 
 // unnormalised r2c of the real fields fs[i] (R layout) -> spectra in place (KY layout)
@@ -872,7 +937,7 @@ extern "C" int pf_set_density(pf_ctx *c, const double *kd) {
   // boundary layout: this rank's x-slab [nxl][n][nzh] (non-transposed PFFT output, src/fmax-pfft.c:366)
   PFCHK(c, import_spec(c, kd, c->dk));
   PFCHK(c, dc_of_host_spec(c, kd, SC_DC_DK));
-  c->have_density = true; c->have_hessian = false; c->have_sources = false; c->sources_fresh = false;
+  c->have_density = true; c->have_hessian = false; c->have_sources = false; c->sources_fresh = false; c->dk_full_valid = false;
   return 0;
 }
 
@@ -897,7 +962,7 @@ extern "C" int pf_synth_density(pf_ctx *c, uint64_t seed, double sigma0, double 
   PFCHK(c, pf_launch_shape(c->fb, p, c->stream));
   HIPCHK(c, hipMemsetAsync(c->scal + SC_DC_DK, 0, sizeof(double), c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->have_density = true; c->have_hessian = false; c->have_sources = false; c->sources_fresh = false;
+  c->have_density = true; c->have_hessian = false; c->have_sources = false; c->sources_fresh = false; c->dk_full_valid = false;
   return 0;
 }
 
@@ -913,7 +978,7 @@ extern "C" int pf_genic_density(pf_ctx *c, const pf_genic_params *p) {
   HIPCHK(c, hipMemsetAsync(c->scal + SC_DC_DK, 0, sizeof(double), c->stream));  // the DC mode is left at zero
   HIPCHK(c, hipStreamSynchronize(c->stream));
   hipFree(dseed);
-  c->have_density = true; c->have_hessian = false; c->have_sources = false; c->sources_fresh = false;
+  c->have_density = true; c->have_hessian = false; c->have_sources = false; c->sources_fresh = false; c->dk_full_valid = false;
   return 0;
 }
 
@@ -1142,9 +1207,11 @@ static int sweep_body(pf_ctx *c, int ns, const double *radius_cells, double *tru
   // (n <= 1024: the six-line workgroup of a 2048-point row would need 110 KB of dynamic LDS, a size this build never launches)
   const bool invariants_ok = c->fb == 8 && c->n <= 1024 && !c->general && c->tab_ns == 0 && c->model == 0 && c->tune.invariants && !six_components;
   HIPCHK(c, hipMemsetAsync(c->scal + SC_INV_FLAG, 0, sizeof(double), c->stream));
+  const bool rep = c->replicate;
+  if (rep) PFCHK(c, ensure_dk_full(c));
   auto pre = [&](int ismooth, void *const *A) {
     PhaseTimer pt(c, 0);
-    return hess_x(c, c->dk, radius_cells[ismooth], A, hess_band(c, radius_cells[ismooth]));
+    return hess_x(c, rep ? c->dk_full : c->dk, radius_cells[ismooth], A, hess_band(c, radius_cells[ismooth]), rep);
   };
   auto post = [&](int ismooth, const void *const *R) {
     // every radius but the last (its Hessian stays in B for the LPT sources): the z-pass stores the three invariants of the
@@ -1152,7 +1219,7 @@ static int sweep_body(pf_ctx *c, int ns, const double *radius_cells, double *tru
     const bool inv = invariants_ok && ismooth < ns - 1;
     {
       PhaseTimer pt(c, 0);
-      PFCHK(c, hess_yz(c, R, c->scal + SC_DC_DK, c->B, hess_band(c, radius_cells[ismooth]), inv));
+      PFCHK(c, hess_yz(c, R, c->scal + SC_DC_DK, c->B, hess_band(c, radius_cells[ismooth]), inv, nullptr, nullptr, rep));
     }
     PhaseTimer pt(c, 1);
     return collapse_enqueue(c, ismooth, c->B, c->stream, true, inv, c->sweep_sources && ismooth == ns - 1);
@@ -1167,7 +1234,7 @@ static int sweep_body(pf_ctx *c, int ns, const double *radius_cells, double *tru
       if (collapse_enqueue(c, ismooth, c->B, c->stream, true, false, c->sweep_sources && ismooth == ns - 1)) return 1;
     }
   } else if (pipelined_band(c, ns, 3, pre, [&](int, int set, int f) { return recv_field(c, set, f); }, post,
-                            [&](int ismooth) { return hess_band(c, radius_cells[ismooth]); })) return 1;
+                            [&](int ismooth) { return hess_band(c, radius_cells[ismooth]); }, rep)) return 1;
   // the R=0 Hessian (last radius) stays in B for the LPT sources
   c->have_hessian = true; c->last_ns = ns;
   PFCHK(c, allreduce_dev(c, c->scal + SC_INV_FLAG, 1 + 2 * (size_t)ns, 0));

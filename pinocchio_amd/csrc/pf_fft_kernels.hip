@@ -107,10 +107,18 @@ __global__ void __launch_bounds__(T *N / 8) __attribute__((amdgpu_waves_per_eu(4
         v, tlj, tw, [&](int pos, C val) { lds[pos * T + cj] = val; }, [&](int pos) { return lds[pos * T + cj]; });
     if (valid) {
       C *__restrict__ out = reinterpret_cast<C *>(p.job[j].out);
+      if (p.out_ne > 0) {  // uniform: the slab of the transformed axis this rank keeps
 #pragma unroll
-      for (int m = 0; m < 8; m++) {
-        const int e = tlj + m * NT;
-        pf_st_stream(&out[pf_addr(p.aout, outer, e, colj)], v[m]);
+        for (int m = 0; m < 8; m++) {
+          const int e = tlj + m * NT;
+          if ((unsigned)(e - p.out_e0) < (unsigned)p.out_ne) pf_st_stream(&out[pf_addr(p.aout, outer, e, colj)], v[m]);
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          const int e = tlj + m * NT;
+          pf_st_stream(&out[pf_addr(p.aout, outer, e, colj)], v[m]);
+        }
       }
     }
   }

@@ -15,7 +15,7 @@ struct PfTuning {
   int zpass_persist;        // PF_ZPASS_PERSIST: workgroups per CU of the persistent z-pass, 0 = one-shot workgroups
   int zpass_inv_wg_per_cu;  // PF_ZPASS_INV_WG_PER_CU
   int collapse_wg_per_cu;   // PF_COLLAPSE_WG_PER_CU
-  bool spline_lut, exchange_rows, invariants, lpt_fuse, general, pipeline, exact_libm;
+  bool spline_lut, exchange_rows, invariants, lpt_fuse, general, pipeline, exact_libm, replicate;
   double prune_eps;
   int debug_fault;          // PF_DEBUG_PIPELINE_FAULT (tests only): 1 / 2 = one wait of the exchange pipeline left out
 };
@@ -57,6 +57,9 @@ struct PfStridedParams {
   // axis, band_outer skips whole workgroups; columns are pruned by ncols.  band >= n/2 disables.
   int band_e, band_outer;
   int dev;           // device the launch goes to (the LDS-size attribute of an instantiation is raised once per device)
+  // out_ne > 0: only the outputs e in [out_e0, out_e0 + out_ne) are stored (a rank that holds the whole spectrum and
+  // transforms every line, but keeps its own slab of the transformed axis: no exchange afterwards)
+  int out_e0, out_ne;
 };
 
 // one x- or y-pass: for every job, out = FFT_e[ in * pre * mul ]  (dir = +1 inverse, -1 forward)

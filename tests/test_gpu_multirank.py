@@ -59,8 +59,12 @@ def api():
     return _api
 
 
+@pytest.mark.parametrize("replicate", [1, 0])
 @pytest.mark.parametrize("n,P,pipeline", [(32, 2, 1), (64, 4, 1), (64, 8, 1), (64, 4, 0), (16, 16, 1), (32, 16, 0), (256, 8, 1)])
-def test_slab_ranks_match_single_rank(api, n, P, pipeline, monkeypatch):
+def test_slab_ranks_match_single_rank(api, n, P, pipeline, replicate, monkeypatch):
+    # replicate = 1 (default): every rank holds the whole delta(k) and the passes that start from it exchange nothing;
+    # 0: every transform goes through the all-to-all
+    monkeypatch.setenv("PF_REPLICATE_DK", str(replicate))
     # pipeline = 1 (default): double-buffered exchange on the communication stream, the all-to-all of transform i+1
     # issued before the y/z passes of transform i; 0: one buffer set, everything on one stream
     monkeypatch.setenv("PF_PIPELINE", str(pipeline))
@@ -106,6 +110,41 @@ def test_slab_ranks_match_single_rank(api, n, P, pipeline, monkeypatch):
         # the 3LPT(b) source carries the all-reduced mean of the 2LPT source: ulp-level differences allowed
         a, b = p["Vel_3LPT_2"].astype(np.float64), p1["Vel_3LPT_2"][sl].astype(np.float64)
         assert np.max(np.abs(a - b)) <= 2e-7 * np.max(np.abs(b))
+
+
+@pytest.mark.parametrize("fb", [8, 4])
+def test_replicated_spectrum_leaves_only_the_lpt_transposes(api, fb, monkeypatch):
+    """PF_REPLICATE_DK (default on with more than one rank): every rank gathers the whole delta(k) once (an integer all-reduce
+    of a zero-padded array: exact for fp64 and fp32 fields) and the second derivatives of every radius and the Zel'dovich
+    displacements start from it -- each rank transforms every x-line and keeps its own slab.  What still travels: the three
+    forward transforms of the LPT sources, the Hessian of the 2LPT potential (3 fields) and three displacement pairs:
+    12 of the 50 field exchanges of a 12-radius step (here 12 of 5 * 3 + 2 + 12 = 29).  Same results bit for bit."""
+    n, P = 64, 4
+    nxl = n // P
+    dk = synth.make_density(n, seed=31)
+    radii = np.array([8.0, 4.0, 2.0, 1.0, 0.0])
+    x, y = synth.invgrow_table("lcdm")
+    g = synth.growth_multipliers()
+
+    def body(f, r):
+        f.set_density(dk[r * nxl:(r + 1) * nxl])
+        f.set_invgrow(x, y); f.set_growth(g)
+        f.compute_fmax(radii, do_lpt=True)           # includes the one-off gather
+        f.reset_kernel_stats()
+        tv = f.compute_fmax(radii, do_lpt=True)
+        ex = [k for k in f.kernel_stats() if k["name"] == "exchange"]
+        return tv, f.products(), (ex[0]["launches"] if ex else 0)
+
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PF_REPLICATE_DK", mode)
+        monkeypatch.setenv("PF_EXCHANGE_ROWS", "0")
+        out[mode] = run_ranks(api, n, P, body, field_bytes=fb, timing=True)
+    for r in range(P):
+        assert np.array_equal(out["1"][r][0], out["0"][r][0])
+        for name in ("Fmax", "Rmax", "Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+            assert np.array_equal(out["1"][r][1][name], out["0"][r][1][name]), (r, name)
+        assert out["0"][r][2] == 5 * 3 + 2 + 12 and out["1"][r][2] == 12, (out["0"][r][2], out["1"][r][2])
 
 
 @pytest.mark.parametrize("P", [1, 2, 4])
@@ -431,6 +470,7 @@ def test_band_limited_radii_exchange_only_their_rows(api, P, pipeline, monkeypat
     n = 64
     nxl = n // P
     monkeypatch.setenv("PF_PIPELINE", str(pipeline))
+    monkeypatch.setenv("PF_REPLICATE_DK", "0")                  # the sweep's own transposes are what is under test here
     dk = synth.make_density(n, seed=23)
     radii = np.array([8.0, 6.0, 4.0, 3.2, 1.0, 0.0])           # bands 12, 16, 24, 30, none, none of 32
     x, y = synth.invgrow_table("lcdm")
@@ -463,15 +503,18 @@ def test_band_limited_radii_exchange_only_their_rows(api, P, pipeline, monkeypat
     assert 0.0 < sent["1"] < 0.8 * sent["0"], sent      # 4 of 6 radii keep 39-95 % of their rows and 41-97 % of their columns, LPT exchanges whole
 
 
+@pytest.mark.parametrize("replicate", [0, 1])
 @pytest.mark.parametrize("P,delay_us,fb", [(2, 4000, 8), (4, 2000, 8), (8, 1000, 8), (4, 2000, 4)])
-def test_pipelined_exchange_with_late_communication(api, P, delay_us, fb):
+def test_pipelined_exchange_with_late_communication(api, P, delay_us, fb, replicate, monkeypatch):
     """The fabric's all-to-all is asynchronous on the device (events, no stream synchronisation), so the exchange of
     transform i+1 really runs on the communication stream beside the y/z passes and the solve of transform i.  Here every
     exchange first idles its stream for milliseconds -- longer than all the kernels of a radius at this size -- so the
     compute stream runs far ahead: whatever the pipeline of pf_api.hip fails to wait for (receive set not yet filled,
     send set overwritten before it was pulled, receive set overwritten while the y-pass still reads it) changes the
     results, which must stay bitwise those of one rank.  Sweep (3 fields per item, band-limited and full radii, odd count)
-    and the displacement pipelines (2 fields, 1 field per item)."""
+    and the displacement pipelines (2 fields, 1 field per item).  replicate = 1: the sweep exchanges nothing, the LPT part still
+    does (and reuses the receive set the sweep wrote in place)."""
+    monkeypatch.setenv("PF_REPLICATE_DK", str(replicate))
     n = 64
     nxl = n // P
     dk = synth.make_density(n, seed=29)
@@ -509,6 +552,7 @@ def test_late_communication_exposes_a_missing_wait(api, fault, n, P, delay_us, m
     the exchange it consumes (exposed by a late communication stream); "send": the exchange does not wait for the x-pass
     that fills its blocks (the injected fault also holds the compute stream back by 2 ms before every x-pass, so the copies
     are certain to start first)"""
+    monkeypatch.setenv("PF_REPLICATE_DK", "0")                  # every radius goes through the exchange pipeline
     nxl = n // P
     dk = synth.make_density(n, seed=29)
     radii = np.array([8.0, 4.0, 3.2, 1.0, 0.0])
