@@ -247,7 +247,7 @@ static void read_tuning(PfTuning *t) {
   t->general = env_int("PF_GENERAL", 0) != 0;
 
   t->pipeline = env_int("PF_PIPELINE", 1) != 0;
-  t->replicate = env_int("PF_REPLICATE_DK", 1) != 0;
+  t->replicate = env_int("PF_REPLICATE_DK", -1);  // -1: by the number of ranks (pf_create), 0 / 1: off / on
   t->exact_libm = env_int("PF_EXACT_LIBM", 0) != 0;
   // fault injection for the tests of the exchange pipeline (tests/test_gpu_multirank.py): "recv" drops the wait of the
   // compute stream for the exchange it is about to consume, "send" the wait of the exchange for the x-pass that fills its blocks
@@ -285,7 +285,10 @@ static int create_body(pf_ctx *c, const pf_config *cfg) {
   for (int i = 0; i < 6; i++) PFCHK(c, dev_alloc(c, &c->B[i], c->field_bytes));
   for (int i = 0; i < 3; i++) PFCHK(c, dev_alloc(c, &c->S[i], c->field_bytes));
   if (c->P > 1) PFCHK(c, dev_alloc(c, &c->recvA, 3 * c->field_bytes));
-  c->replicate = c->P > 1 && !c->general && c->tune.replicate;
+  // default: up to four ranks.  There the all-to-alls of the sweep cost more link time than its kernels take (one xGMI link
+  // per peer pair: N^3 W / P^2 bytes per field and link), while the replicated x-pass costs each rank one more read of the
+  // whole delta(k) per radius; from eight ranks on the transposes are small enough to hide behind the kernels
+  c->replicate = c->P > 1 && !c->general && (c->tune.replicate < 0 ? c->P <= 4 : c->tune.replicate != 0);
   if (c->replicate) PFCHK(c, dev_alloc(c, &c->dk_full, (size_t)c->P * c->field_bytes));
   if (c->pipeline) {
     PFCHK(c, dev_alloc(c, (void **)&c->blockA2, 3 * c->field_bytes));

@@ -15,7 +15,8 @@ struct PfTuning {
   int zpass_persist;        // PF_ZPASS_PERSIST: workgroups per CU of the persistent z-pass, 0 = one-shot workgroups
   int zpass_inv_wg_per_cu;  // PF_ZPASS_INV_WG_PER_CU
   int collapse_wg_per_cu;   // PF_COLLAPSE_WG_PER_CU
-  bool spline_lut, exchange_rows, invariants, lpt_fuse, general, pipeline, exact_libm, replicate;
+  bool spline_lut, exchange_rows, invariants, lpt_fuse, general, pipeline, exact_libm;
+  int replicate;  // PF_REPLICATE_DK: -1 by rank count, 0 off, 1 on
   double prune_eps;
   int debug_fault;          // PF_DEBUG_PIPELINE_FAULT (tests only): 1 / 2 = one wait of the exchange pipeline left out
 };
