@@ -292,11 +292,11 @@ def main():
         ex = [s for s in stats if s["name"] == "exchange"]
         if world > 1:
             e = ex[0] if ex else {"launches": 0, "total_ms": 0.0, "alg_bytes": 0.0}
-            out["exchange"] = {"kind": exchange_kind, "calls_per_step": e["launches"] / args.steps, "GB_per_step_per_rank": e["alg_bytes"] / args.steps / 1e9,
+            out["exchange"] = {"kind": exchange_kind, "replicated_spectrum": bool(f.L.pf_replicated_spectrum(f.h)), "calls_per_step": e["launches"] / args.steps, "GB_per_step_per_rank": e["alg_bytes"] / args.steps / 1e9,
                                "ms_per_step_on_comm_stream": e["total_ms"] / args.steps,
                                "GBps_per_rank": e["alg_bytes"] / max(e["total_ms"], 1e-9) / 1e6,
                                "compute_ms_per_step": sum(s["total_ms"] for s in kern) / args.steps,
-                               "note": "rank 0's HIP events around its all-to-alls on the communication stream; they run beside the compute stream (DESIGN.md section 5): step time well below compute + exchange means the overlap works"}
+                               "note": "rank 0's HIP events around its all-to-alls on the communication stream; they run beside the compute stream (DESIGN.md section 5): step time well below compute + exchange means the overlap works.  replicated_spectrum (2-4 ranks by default): every rank keeps the whole delta(k), the sweep exchanges nothing and only the LPT sources transpose"}
         if exact:
             out["exact_libm"] = exact
         if world == 1 and args.cpu_n:

@@ -130,6 +130,10 @@ int pf_set_density(pf_ctx *ctx, const double *kdensity_slab);
    layout is a ky-slab anyway, so the regrouping all-to-all of the non-transposed boundary disappears.  Call it right
    after pf_create; results do not depend on it. */
 int pf_set_transposed_spectra(pf_ctx *ctx, int on);
+/* 1 if this context (nranks > 1) keeps the whole delta(k) on every rank, so that the second derivatives of the sweep and
+   the Zel'dovich displacements need no all-to-all (each rank transforms every x-line and stores its own slab): chosen at
+   pf_create -- up to four ranks, or PF_REPLICATE_DK=0|1.  Results do not depend on it. */
+int pf_replicated_spectrum(pf_ctx *ctx);
 /* synthetic delta(k) generated in HBM (bench / large property tests):
    Philox-4x32 white noise, P(k) ~ k^slope inside the Nyquist sphere, DC and
    Nyquist planes zero, sigma(R=0) = sigma0.  numpy mirror:

@@ -98,6 +98,7 @@ PROTOTYPES = {
     "pf_set_lpt_order": (C.c_int, [_vp, C.c_int]),
     "pf_set_ct_interpolation": (C.c_int, [_vp, C.c_int]),
     "pf_set_transposed_spectra": (C.c_int, [_vp, C.c_int]),
+    "pf_replicated_spectrum": (C.c_int, [_vp]),
     "pf_update_products": (C.c_int, [_vp, _vp, C.POINTER(ProductLayout)]),
     "pf_set_growth_table": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_double, C.c_double, C.c_double]),
     "pf_get_second_derivative": (C.c_int, [_vp, C.c_int, _dp]),

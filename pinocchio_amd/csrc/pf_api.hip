@@ -1263,6 +1263,7 @@ extern "C" int pf_sweep(pf_ctx *c, int ns, const double *radius_cells, double *t
   return rc;
 }
 extern "C" int pf_debug_invariant_reruns(pf_ctx *c) { return c ? c->inv_reruns : -1; }
+extern "C" int pf_replicated_spectrum(pf_ctx *c) { return c ? (c->replicate ? 1 : 0) : -1; }
 extern "C" int pf_set_transposed_spectra(pf_ctx *c, int on) {
   if (!c) return 1;
   c->transposed = on != 0;
