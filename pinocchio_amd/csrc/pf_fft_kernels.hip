@@ -29,6 +29,9 @@ __device__ __forceinline__ long long pf_addr(const PfAddr &a, int outer, int e, 
 // neighbouring tiles, which share 128-byte lines when T*sizeof(complex) < 128, meet in one L2.
 __device__ __forceinline__ long long pf_xcd_swizzle(long long b, long long per_xcd) { return (b & 7) * per_xcd + (b >> 3); }
 
+#ifndef PF_SLAB_STORE
+#define PF_SLAB_STORE 1  // (0 in an A/B build, profiles/tools/ab.sh: the kernel without the slab-store branch)
+#endif
 template <typename F, int N, int T, int DIR>
 __global__ void __launch_bounds__(T *N / 8) __attribute__((amdgpu_waves_per_eu(4))) k_strided(const PfStridedParams p, const long long nwork, const int ntiles) {
   using C = pfc<F>;
@@ -107,7 +110,7 @@ __global__ void __launch_bounds__(T *N / 8) __attribute__((amdgpu_waves_per_eu(4
         v, tlj, tw, [&](int pos, C val) { lds[pos * T + cj] = val; }, [&](int pos) { return lds[pos * T + cj]; });
     if (valid) {
       C *__restrict__ out = reinterpret_cast<C *>(p.job[j].out);
-      if (p.out_ne > 0) {  // uniform: the slab of the transformed axis this rank keeps
+      if (PF_SLAB_STORE && p.out_ne > 0) {  // uniform: the slab of the transformed axis this rank keeps
 #pragma unroll
         for (int m = 0; m < 8; m++) {
           const int e = tlj + m * NT;
