@@ -195,6 +195,52 @@ def test_transposed_spectra_at_the_boundary(api, P):
     assert np.array_equal(np.concatenate([tr[r][2] for r in range(P)], axis=0), dkt)
 
 
+@pytest.mark.parametrize("P", [2, 8])
+def test_double_precision_products_on_slabs(api, P):
+    """PF_FLAG_DOUBLE_PRODUCTS (-DDOUBLE_PRECISION_PRODUCTS) with more than one rank: fp64 Fmax and displacement columns, bit for
+    bit those of one rank (P = 2: replicated delta(k); P = 8: every transform through the all-to-all)"""
+    n = 32
+    dk = synth.make_density(n, seed=14)
+    x, y = synth.invgrow_table("lcdm")
+    g = synth.growth_multipliers()
+    radii = np.array([2.0, 1.0, 0.0])
+    nxl = n // P
+
+    def body(f, r):
+        f.set_density(dk[r * nxl:(r + 1) * nxl])
+        f.set_invgrow(x, y); f.set_growth(g)
+        f.compute_fmax(radii, do_lpt=True)
+        return f.products(), f.Fmax_PDF()
+
+    with api.Fmax(n, double_products=True) as f1:
+        f1.set_density(dk); f1.set_invgrow(x, y); f1.set_growth(g)
+        f1.compute_fmax(radii, do_lpt=True)
+        p1, h1 = f1.products(), f1.Fmax_PDF()
+    from pinocchio_amd import _lib
+    L = _lib.load()
+    fab = L.pf_fabric_create(P)
+    ctxs = [api.Fmax(n, rank=r, nranks=P, double_products=True) for r in range(P)]
+    for c in ctxs:
+        assert L.pf_fabric_attach(fab, c.h) == 0
+    out = [None] * P
+    th = [threading.Thread(target=lambda r=r: out.__setitem__(r, body(ctxs[r], r))) for r in range(P)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    for c in ctxs:
+        c.close()
+    L.pf_fabric_destroy(fab)
+    assert p1["Fmax"].dtype == np.float64
+    for r in range(P):
+        sl = slice(r * nxl, (r + 1) * nxl)
+        assert out[r] is not None and np.array_equal(out[r][1], h1)
+        for name in ("Fmax", "Rmax", "Vel", "Vel_2LPT", "Vel_3LPT_1"):
+            assert np.array_equal(out[r][0][name], p1[name][sl]), (r, name)
+        a, b = out[r][0]["Vel_3LPT_2"], p1["Vel_3LPT_2"][sl]
+        assert np.max(np.abs(a - b)) <= 1e-13 * np.max(np.abs(b))      # carries the all-reduced mean of the 2LPT source
+
+
 @pytest.mark.parametrize("order", [2, 1])
 def test_lower_lpt_orders_on_slabs(api, order):
     """pf_set_lpt_order (a build without -DTHREE_LPT / -DTWO_LPT) with the exchange pipeline: fewer fields go through it"""
