@@ -152,6 +152,12 @@ typedef struct {
   unsigned int RandomSeed;
   int FixedIC;    /* params.FixedIC: "non-random modules of the Fourier modes", no Rayleigh factor -log(ampl) (src/GenIC.c:375) */
   int PairedIC;   /* params.PairedIC: every phase shifted by pi (src/GenIC.c:371) */
+  /* pk_n > 0: a tabulated spectrum instead of Eisenstein & Hu (FileWithInputSpectrum <file> or CAMBTable: WhichSpectrum 2 / 5) --
+     P(k) = PkNorm 10^my_spline_eval(SPLINE[SP_PK], log10 k) / k^3 (PowerSpec_Tabulated, src/cosmo.c:1432-1435) with the knots of
+     SPLINE[SP_PK]: pk_logk[i] = log10 k [true 1/Mpc], pk_logk3p[i] = log10(k^3 P) (read_Pk_from_file :1099-1170,
+     read_Pk_table_from_CAMB :1290-1330); host arrays, copied.  The cosmology fields are then unused. */
+  int pk_n;
+  const double *pk_logk, *pk_logk3p;
 } pf_genic_params;
 int pf_pk_norm(const pf_genic_params *p, double sigma8, double *pknorm);
 int pf_genic_density(pf_ctx *ctx, const pf_genic_params *p);

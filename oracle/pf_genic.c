@@ -17,6 +17,10 @@
 
 #define ORC_PI 3.14159265358979323846
 
+/* pf_oracle.c: GSL's natural cubic spline and my_spline_eval on explicit arrays (for the tabulated spectrum) */
+int orc_cspline_coeffs(const double *xa, const double *ya, int size, double *sc);
+double orc_my_spline_eval(const double *sx, const double *sy, const double *sc, int size, double x);
+
 /* ------------------------------------------------------------ ranlxd1 ---- */
 typedef struct {
   double xdbl[12];
@@ -184,12 +188,26 @@ double orc_powerspec_EH(double k, const orc_cosmo *p) { return pow(k, p->Primord
    seed[jj*n + ii] = seed of the (ii, jj) column (spiral order, built by the caller).
    kdensity out: [n][n][n/2+1][2], already multiplied by n^3 (src/GenIC.c:430-445). */
 int orc_genic_ic(int n, double box, const unsigned int *seed, double pknorm, const orc_cosmo *cosmo, int FixedIC, int PairedIC, double *kdensity);
+int orc_genic_pk(int n, double box, const unsigned int *seed, double pknorm, const orc_cosmo *cosmo, int pk_n, const double *pk_logk,
+                 const double *pk_logk3p, int FixedIC, int PairedIC, double *kdensity);
 int orc_genic(int n, double box, const unsigned int *seed, double pknorm, const orc_cosmo *cosmo, double *kdensity) {
   return orc_genic_ic(n, box, seed, pknorm, cosmo, 0, 0, kdensity);
 }
 /* the same with the two run-time options of src/GenIC.c:370-376: PairedIC adds pi to every phase, FixedIC leaves the Rayleigh
    factor -log(ampl) out ("non-random modules of the Fourier modes") */
 int orc_genic_ic(int n, double box, const unsigned int *seed, double pknorm, const orc_cosmo *cosmo, int FixedIC, int PairedIC, double *kdensity) {
+  return orc_genic_pk(n, box, seed, pknorm, cosmo, 0, NULL, NULL, FixedIC, PairedIC, kdensity);
+}
+/* ... and with a tabulated spectrum (WhichSpectrum 2 and 5: FileWithInputSpectrum, CAMBTable): PowerSpec_Tabulated
+   (src/cosmo.c:1432-1435) = 10^my_spline_eval(SPLINE[SP_PK], log10 k) / k^3 with the knots log10 k [1/Mpc], log10(k^3 P)
+   of read_Pk_from_file / read_Pk_table_from_CAMB (:1099-1170, 1290-1330); pk_n = 0: Eisenstein & Hu */
+int orc_genic_pk(int n, double box, const unsigned int *seed, double pknorm, const orc_cosmo *cosmo, int pk_n, const double *pk_logk,
+                 const double *pk_logk3p, int FixedIC, int PairedIC, double *kdensity) {
+  double *pk_c = NULL;
+  if (pk_n > 0) {
+    pk_c = (double *)malloc(sizeof(double) * pk_n);
+    if (!pk_c || orc_cspline_coeffs(pk_logk, pk_logk3p, pk_n, pk_c)) { free(pk_c); return 1; }
+  }
   const int Nmesh = n, Nsample = n, Nmesh_2 = n / 2, Nmesh_odd = n % 2;
   const int nzh = n / 2 + 1;
   const double Box = box;
@@ -224,7 +242,8 @@ int orc_genic_ic(int n, double box, const unsigned int *seed, double pknorm, con
         double kmag2_local = kmag2_ij + kvec[2] * kvec[2];
         double kmag = sqrt(kmag2_local);
         if (kmag * Box / (2 * ORC_PI) > 1. * Nsample / 2) continue; /* NYQUIST = 1. */
-        double p_of_k = pknorm * orc_powerspec_EH(kmag, cosmo);
+        double p_of_k = pknorm * (pk_n > 0 ? pow(10., orc_my_spline_eval(pk_logk, pk_logk3p, pk_c, pk_n, log10(kmag))) / kmag / kmag / kmag
+                                           : orc_powerspec_EH(kmag, cosmo));
         double sign = 1.0;
         int addr_j = j;
         iii = ii; jjj = jj;
@@ -253,5 +272,6 @@ int orc_genic_ic(int n, double box, const unsigned int *seed, double pknorm, con
   }
   fac = pow((double)Nmesh, 3.0);
   for (size_t i = 0; i < 2 * (size_t)n * n * nzh; i++) kdensity[i] *= fac;
+  free(pk_c);
   return 0;
 }

@@ -440,6 +440,10 @@ static double my_spline_eval_arrays(const double *sx, const double *sy, const do
     return gsl_spline_eval_arrays(sx, sy, sc, size, x);
 }
 
+/* the same two for other files of the oracle (pf_genic.c: the tabulated power spectrum) */
+int orc_cspline_coeffs(const double *xa, const double *ya, int size, double *sc) { return natural_cspline(xa, ya, size, sc); }
+double orc_my_spline_eval(const double *sx, const double *sy, const double *sc, int size, double x) { return my_spline_eval_arrays(sx, sy, sc, size, x); }
+
 /* cosmo.c:2016-2027 my_spline_eval: linear extrapolation beyond the knots */
 double orc_spline_eval(orc_ctx *c, double x) {
   const double *sx = c->sx, *sy = c->sy;

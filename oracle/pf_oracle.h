@@ -131,6 +131,10 @@ double orc_ell_sng_F(double l1, double l2, double l3, double D_in, const double 
 int orc_set_modified_gravity(orc_ctx *c, double fr0, double h_over_c, int ns, const double *size);
 int orc_set_collapse_model(orc_ctx *c, int model, const double cosmo[4], int ns, const double *D_in);
 
+/* GSL's natural cubic spline (coefficients c) and my_spline_eval (src/cosmo.c:2016-2027) on explicit arrays */
+int orc_cspline_coeffs(const double *xa, const double *ya, int size, double *sc);
+double orc_my_spline_eval(const double *sx, const double *sy, const double *sc, int size, double x);
+
 /* Fmax >= flast (src/distribute.c:695), indices by descending Fmax (src/fragment.c:484-503, 118-126; ties by index).
    indices / fmax hold n^3 entries; returns the number selected. */
 size_t orc_select_sorted(orc_ctx *c, float flast, unsigned int *indices, float *fmax);

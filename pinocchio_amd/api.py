@@ -88,11 +88,21 @@ class Fmax:
         self._chk(self.L.pf_synth_density(self.h, C.c_uint64(seed), sigma0, slope))
 
     def genic_density(self, seed: int, box_true_mpc: float, omega0: float, omega_baryon: float, hubble100: float,
-                      primordial_index: float, sigma8: float = 0.0, pknorm: float = 0.0, fixed: bool = False, paired: bool = False) -> float:
+                      primordial_index: float, sigma8: float = 0.0, pknorm: float = 0.0, fixed: bool = False, paired: bool = False,
+                      pk_table=None) -> float:
         """GenIC_large (src/GenIC.c:73) on the device.  Give PkNorm, or sigma8 to have it computed
-        (normalize_PowerSpectrum, src/cosmo.c:1058).  Returns the PkNorm used."""
+        (normalize_PowerSpectrum, src/cosmo.c:1058).  pk_table = (log10 k [1/Mpc], log10(k^3 P)): a tabulated spectrum
+        (SPLINE[SP_PK]) instead of Eisenstein & Hu; PkNorm is then what the caller says (1 for a trusted table).
+        Returns the PkNorm used."""
         p = _lib.GenicParams(omega0, omega_baryon, hubble100, primordial_index, box_true_mpc, pknorm, seed, int(fixed), int(paired))
-        if pknorm <= 0.0:
+        if pk_table is not None:
+            lk = np.ascontiguousarray(pk_table[0], dtype=np.float64)
+            lp = np.ascontiguousarray(pk_table[1], dtype=np.float64)
+            assert lk.shape == lp.shape and lk.ndim == 1
+            p.pk_n, p.pk_logk, p.pk_logk3p = len(lk), _dp(lk), _dp(lp)
+            if pknorm <= 0.0:
+                p.PkNorm = 1.0
+        elif pknorm <= 0.0:
             v = C.c_double()
             self._chk(self.L.pf_pk_norm(C.byref(p), sigma8, C.byref(v)))
             p.PkNorm = v.value

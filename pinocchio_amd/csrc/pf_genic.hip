@@ -23,6 +23,8 @@
 
 #include "../../include/pinfmax.h"
 #include "pf_internal.h"
+#include "pf_collapse_core.h"  // pf_spline_coeffs: GSL's natural cubic spline (host)
+#include <string.h>
 
 #define PFG_PI 3.14159265358979323846
 
@@ -185,7 +187,26 @@ struct GenicArgs {
   double box, fac, pknorm, n3;
   EHConst eh;
   bool fixed, paired;        // params.FixedIC, params.PairedIC
+  int pkn;                   // > 0: tabulated spectrum, knots log10 k -> log10(k^3 P) with their natural-spline c
+  const double *pkx, *pky, *pkc;
 };
+// PowerSpec_Tabulated (src/cosmo.c:1432-1435): my_spline_eval of SPLINE[SP_PK] (linear beyond the knots), then 10^. / k^3
+__device__ __forceinline__ double pfg_powerspec_tab(double k, const GenicArgs &a) {
+  const double x = log10(k);
+  const double *xa = a.pkx, *ya = a.pky, *ca = a.pkc;
+  const int last = a.pkn - 1;
+  double s;
+  if (x < xa[0]) s = ya[0] + (x - xa[0]) * (ya[1] - ya[0]) / (xa[1] - xa[0]);
+  else if (x > xa[last]) s = ya[last] + (x - xa[last]) * (ya[last] - ya[last - 1]) / (xa[last] - xa[last - 1]);
+  else {
+    int lo = 0, hi = last;
+    while (hi > lo + 1) { const int m = (hi + lo) >> 1; if (xa[m] > x) hi = m; else lo = m; }
+    const double dx = xa[lo + 1] - xa[lo], dy = ya[lo + 1] - ya[lo], delx = x - xa[lo];
+    const double b = (dy / dx) - dx * (ca[lo + 1] + 2.0 * ca[lo]) / 3.0, d = (ca[lo + 1] - ca[lo]) / (3.0 * dx);
+    s = ya[lo] + delx * (b + delx * (ca[lo] + delx * d));
+  }
+  return pow(10., s) / k / k / k;
+}
 
 template <typename F>
 __global__ void __launch_bounds__(64) k_genic(const GenicArgs a) {
@@ -210,7 +231,7 @@ __global__ void __launch_bounds__(64) k_genic(const GenicArgs a) {
     const double kz = kk * 2 * PFG_PI / Box;
     const double kmag = sqrt(kmag2_ij + kz * kz);
     if (kmag * Box / (2 * PFG_PI) > 1. * n / 2) continue;  // NYQUIST = 1.
-    double p_of_k = a.pknorm * pfg_powerspec_EH(kmag, a.eh);
+    double p_of_k = a.pknorm * (a.pkn > 0 ? pfg_powerspec_tab(kmag, a) : pfg_powerspec_EH(kmag, a.eh));
     double sign = 1.0;
     if (kk == 0) {  // Hermitian partners on the kz = 0 plane (src/GenIC.c:289-368)
       if (ii == 0 && jj == Nmesh_2) continue;
@@ -270,11 +291,29 @@ int pf_genic_launch(int fb, void *dk, int n, int nzp, int nyl, int y0, const pf_
   a.dk = dk; a.seed = dseed; a.n = n; a.nzp = nzp; a.nyl = nyl; a.y0 = y0;
   a.box = p->BoxSize_true_Mpc; a.fac = pow(1. / a.box, 1.5); a.pknorm = p->PkNorm; a.n3 = pow((double)n, 3.0);
   a.fixed = p->FixedIC != 0; a.paired = p->PairedIC != 0;
+  a.pkn = 0; a.pkx = a.pky = a.pkc = nullptr;
+  double *dpk = nullptr;
+  if (p->pk_n > 0) {  // SPLINE[SP_PK]: GSL's natural cubic spline through the table, coefficients on the host
+    if (p->pk_n < 3 || !p->pk_logk || !p->pk_logk3p) return 1;
+    std::vector<double> tab(3 * (size_t)p->pk_n);
+    memcpy(tab.data(), p->pk_logk, sizeof(double) * p->pk_n);
+    memcpy(tab.data() + p->pk_n, p->pk_logk3p, sizeof(double) * p->pk_n);
+    if (pf_spline_coeffs(p->pk_logk, p->pk_logk3p, p->pk_n, tab.data() + 2 * (size_t)p->pk_n)) return 1;
+    if (hipMalloc(&dpk, tab.size() * sizeof(double)) != hipSuccess) return 1;
+    if (hipMemcpyAsync(dpk, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) return 1;
+    if (hipStreamSynchronize(st) != hipSuccess) return 1;  // `tab` is a local vector
+    a.pkn = p->pk_n; a.pkx = dpk; a.pky = dpk + p->pk_n; a.pkc = dpk + 2 * (size_t)p->pk_n;
+  }
   eh_constants(p, &a.eh);
   const long long ncol = (long long)n * nyl;
   const unsigned blocks = (unsigned)((ncol + 63) / 64);
   if (fb == 8) hipLaunchKernelGGL(k_genic<double>, dim3(blocks), dim3(64), 0, st, a);
   else hipLaunchKernelGGL(k_genic<float>, dim3(blocks), dim3(64), 0, st, a);
   *seed_dev_out = dseed;
-  return hipGetLastError() == hipSuccess ? 0 : 1;
+  const int rc = hipGetLastError() == hipSuccess ? 0 : 1;
+  if (dpk) {  // the kernel has the table for its lifetime only
+    if (hipStreamSynchronize(st) != hipSuccess) return 1;
+    hipFree(dpk);
+  }
+  return rc;
 }

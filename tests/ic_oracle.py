@@ -63,14 +63,24 @@ def pk_norm(p, sigma8: float) -> float:
     return sigma8 ** 2 / val
 
 
-def genic(n: int, box_true_mpc: float, seed: int, pknorm: float, p, fixed: bool = False, paired: bool = False) -> np.ndarray:
-    """fixed / paired: params.FixedIC / params.PairedIC (src/GenIC.c:370-376)"""
+def genic(n: int, box_true_mpc: float, seed: int, pknorm: float, p, fixed: bool = False, paired: bool = False, pk_table=None) -> np.ndarray:
+    """fixed / paired: params.FixedIC / params.PairedIC (src/GenIC.c:370-376); pk_table = (log10 k [1/Mpc], log10(k^3 P)): the knots of
+    SPLINE[SP_PK] for a tabulated spectrum (PowerSpec_Tabulated, src/cosmo.c:1432-1435) instead of Eisenstein & Hu"""
     L = _lib()
     cos = Cosmo(p["Omega0"], p["OmegaBaryon"], p["Hubble100"], p["PrimordialIndex"])
     st = seed_table(n, seed)
     out = np.zeros((n, n, n // 2 + 1), dtype=np.complex128)
-    rc = L.orc_genic_ic(n, box_true_mpc, st.ctypes.data_as(C.POINTER(C.c_uint)), pknorm, C.byref(cos), int(fixed), int(paired),
-                        out.view(np.float64).ctypes.data_as(C.POINTER(C.c_double)))
+    dp = C.POINTER(C.c_double)
+    if pk_table is None:
+        npk, lk, lp = 0, None, None
+    else:
+        lk = np.ascontiguousarray(pk_table[0], dtype=np.float64)
+        lp = np.ascontiguousarray(pk_table[1], dtype=np.float64)
+        npk = len(lk)
+    L.orc_genic_pk.argtypes = [C.c_int, C.c_double, C.POINTER(C.c_uint), C.c_double, C.c_void_p, C.c_int, dp, dp, C.c_int, C.c_int, dp]
+    rc = L.orc_genic_pk(n, box_true_mpc, st.ctypes.data_as(C.POINTER(C.c_uint)), pknorm, C.cast(C.byref(cos), C.c_void_p), npk,
+                        lk.ctypes.data_as(dp) if npk else None, lp.ctypes.data_as(dp) if npk else None, int(fixed), int(paired),
+                        out.view(np.float64).ctypes.data_as(dp))
     assert rc == 0
     return out
 

@@ -201,3 +201,81 @@ def test_hip_path_reproduces_the_f_of_R_run(mg):
         f.set_tabulated_ct(np.array(mg["variance"]))
         tv = f.sweep(np.array(mg["radii_Mpc"]) / (_box(p) / n))
         _check(mg, tv, f.Fmax_PDF(), l1_max=800, count_max=40)
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# READ_PK_TABLE + SCALE_DEPENDENT: the reference's committed run with a tabulated (CAMB) spectrum, tests/golden/readpk256_kat.json
+# (tests/golden/make_readpk256_kat.py).  The z = 0 table the run read gives SPLINE[SP_PK]; its growth does not depend on scale
+# (all ten k bins of scaledep.out agree), so SPLINE_INVGROW[ismooth] is one table for every radius.
+@pytest.fixture(scope="module")
+def rkat():
+    with open(os.path.join(GOLD, "readpk256_kat.json")) as f:
+        return json.load(f)
+
+
+def _pk_table(rkat):
+    """knots of SPLINE[SP_PK] (src/cosmo.c:1302-1309): log10 of k in true 1/Mpc, log10(k^3 P) with k in h/Mpc and P in (Mpc/h)^3"""
+    t = np.array(rkat["camb_z0_k_hMpc_P"])
+    return np.log10(t[:, 0] * rkat["params"]["Hubble100"]), np.log10(t[:, 0] ** 3 * t[:, 1])
+
+
+@pytest.fixture(scope="module")
+def rdensity(rkat):
+    p = rkat["params"]
+    return ic_oracle.genic(p["GridSize"], _box(p), p["RandomSeed"], 1.0, p, fixed=True, pk_table=_pk_table(rkat))
+
+
+def test_sigma8_of_the_camb_table(rkat):
+    """normalize_PowerSpectrum with Sigma8 = 0 (src/cosmo.c:1074-1079): the run logs the sigma8 of the table it was given"""
+    from scipy.integrate import quad
+    from scipy.interpolate import CubicSpline
+    lk, lp = _pk_table(rkat)
+    sp = CubicSpline(lk, lp, bc_type="natural")
+    R = 8.0 / rkat["params"]["Hubble100"]
+
+    def f(lnk):
+        k = np.exp(lnk)
+        x = np.log10(k)
+        y = sp(x) if lk[0] <= x <= lk[-1] else (lp[0] + (x - lk[0]) * (lp[1] - lp[0]) / (lk[1] - lk[0]) if x < lk[0]
+                                                else lp[-1] + (x - lk[-1]) * (lp[-1] - lp[-2]) / (lk[-1] - lk[-2]))
+        kr = k * R
+        w = 3.0 * (np.sin(kr) / kr ** 3 - np.cos(kr) / kr ** 2)
+        return 10.0 ** y * w * w / (2.0 * np.pi ** 2)          # P k^3 / (2 pi^2) per ln k
+    var = quad(f, np.log(1e-5), np.log(500.0 / R), limit=2000)[0]
+    assert np.sqrt(var) == pytest.approx(rkat["Sigma8_of_the_table"], rel=2e-4)     # 1.057903 as logged
+
+
+def test_oracle_reproduces_the_read_pk_table_run(rkat, rdensity):
+    p = rkat["params"]
+    n = p["GridSize"]
+    radii_cells = np.array(rkat["radii_Mpc"]) / (_box(p) / n)
+    xt, yt = _table_spline(rkat)
+    o = oracle_lib.Oracle(n, 0)
+    o.set_density(rdensity)
+    for i in range(len(radii_cells)):
+        o.set_invgrow_radius(i, xt, yt)
+    tv = o.compute_fmax(radii_cells, do_lpt=False)
+    _check(rkat, tv, o.fmax_pdf(), l1_max=2000, count_max=100)      # measured: 12 822 323 vs 12 822 323, L1 = 444 of 16 777 216
+
+
+@pytest.mark.gpu
+def test_hip_path_reproduces_the_read_pk_table_run(rkat, rdensity):
+    from pinocchio_amd import api
+    p = rkat["params"]
+    n = p["GridSize"]
+    radii_cells = np.array(rkat["radii_Mpc"]) / (_box(p) / n)
+    xt, yt = _table_spline(rkat)
+    with api.Fmax(n) as f:
+        f.set_density(rdensity)
+        for i in range(len(radii_cells)):
+            f.set_invgrow(xt, yt, ismooth=i)
+        tv = f.sweep(radii_cells)
+        _check(rkat, tv, f.Fmax_PDF(), l1_max=2000, count_max=100)
+        # entirely on the device: GenIC with the tabulated spectrum (PkNorm 1: the table is trusted), fixed amplitudes
+        f.genic_density(p["RandomSeed"], _box(p), p["Omega0"], p["OmegaBaryon"], p["Hubble100"], p["PrimordialIndex"],
+                        pknorm=1.0, fixed=True, pk_table=_pk_table(rkat))
+        dk = f.density()
+        assert np.max(np.abs(dk - rdensity)) <= 1e-11 * np.max(np.abs(rdensity))
+        tv2 = f.sweep(radii_cells)
+        assert np.allclose(tv2, tv, rtol=1e-11)
+        _check(rkat, tv2, f.Fmax_PDF(), l1_max=2000, count_max=100)
