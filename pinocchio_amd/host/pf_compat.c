@@ -261,7 +261,26 @@ int pf_compat_genic(double PkNorm) {
   g.RandomSeed = (unsigned int)params.RandomSeed;
   g.FixedIC = params.FixedIC; g.PairedIC = params.PairedIC; /* src/GenIC.c:371-376 */
   g.PkNorm = PkNorm;
-  if (PkNorm <= 0.0 && pf_pk_norm(&g, params.Sigma8, &g.PkNorm)) return 1;
+#ifdef PF_IN_PINOCCHIO_TREE
+  /* which spectrum (initialize_PowerSpectrum, src/cosmo.c:1003-1046): "no" = Eisenstein & Hu; a file name or CAMBTable = the
+     table behind SPLINE[SP_PK] (PowerSpec_Tabulated :1432-1435); the two other analytic forms are not on the device */
+  if (!strcmp(params.FileWithInputSpectrum, "Efstathiou") || !strcmp(params.FileWithInputSpectrum, "PowerLaw")) {
+    printf("ERROR on task %d: the device generator knows Eisenstein & Hu and tabulated spectra only (FileWithInputSpectrum %s)\n", ThisTask,
+           params.FileWithInputSpectrum);
+    return 1;
+  }
+  if (strcmp(params.FileWithInputSpectrum, "no")) {
+    g.pk_n = (int)SPLINE[SP_PK]->size; g.pk_logk = SPLINE[SP_PK]->x; g.pk_logk3p = SPLINE[SP_PK]->y;
+    if (PkNorm <= 0.0) { /* normalize_PowerSpectrum (:1061-1081): a trusted table (Sigma8 0, or CAMBTable) has PkNorm 1 */
+      if (params.Sigma8 != 0.0 && strcmp(params.FileWithInputSpectrum, "CAMBTable")) {
+        printf("ERROR on task %d: a tabulated spectrum renormalised to Sigma8 needs the PkNorm the reference printed\n", ThisTask);
+        return 1;
+      }
+      g.PkNorm = 1.0;
+    }
+  }
+#endif
+  if (g.PkNorm <= 0.0 && pf_pk_norm(&g, params.Sigma8, &g.PkNorm)) return 1;
   if (!ThisTask) printf("[%s] Generating the linear density field on the device, PkNorm=%g\n", fdate(), g.PkNorm);
   if (pf_genic_density(pf_context, &g)) return 1;
   pf_density_on_device = 1;

@@ -45,6 +45,7 @@ typedef struct gsl_interp_accel_tag gsl_interp_accel;
 #define SP_GROW2 (9 + NkBINS)
 #define SP_GROW31 (9 + 2 * NkBINS)
 #define SP_GROW32 (9 + 3 * NkBINS)
+#define SP_PK (9 + 8 * NkBINS)
 
 /* --- src/pinocchio.h: the path's state.  The records the adapter mirrors are taken from its own header, then the
    in-tree-only members are added through a differently named struct for params (k_for_GM, use_transposed_fft). --- */
@@ -57,7 +58,7 @@ typedef struct gsl_interp_accel_tag gsl_interp_accel;
 typedef struct /* src/pinocchio.h:311-352, the tags the adapter reads */
 {
   double Omega0, OmegaLambda, OmegaBaryon, Hubble100, Sigma8, PrimordialIndex, BoxSize_htrue, k_for_GM;
-  char RunFlag[SBLENGTH], DumpDir[SBLENGTH], CTtableFile[LBLENGTH];
+  char RunFlag[SBLENGTH], DumpDir[SBLENGTH], CTtableFile[LBLENGTH], FileWithInputSpectrum[LBLENGTH];
   int GridSize[3], RandomSeed, use_transposed_fft, FixedIC, PairedIC;
 } param_data;
 extern param_data params;
@@ -80,6 +81,7 @@ double my_spline_eval(gsl_spline *, double, gsl_interp_accel *);   /* :630 */
 
 /* names that exist only in the stand-alone build of the adapter: an in-tree branch must not touch them */
 #pragma GCC poison pf_invgrow_knots pf_GrowingMode pf_GrowingMode_2LPT pf_GrowingMode_3LPT_1 pf_GrowingMode_3LPT_2
+#pragma GCC poison pf_compat_lpt_order pf_compat_ct_interpolation
 #pragma GCC poison pf_compat_tabulated_ct pf_compat_ell_sng pf_Hubble pf_compat_fr0 pf_compat_scale_dependent pf_invgrow_knots_radius
 #pragma GCC poison params_standalone_unused
 
