@@ -196,6 +196,62 @@ def test_transposed_spectra_at_the_boundary(api, P):
 
 
 @pytest.mark.parametrize("P", [2, 8])
+def test_state_machine_on_slabs(api, P):
+    """the sequence test of tests/test_gpu_parity.py with more than one rank (P = 2: replicated delta(k), gathered again after every
+    new density; P = 8: exchanging path): every rank drives its long-lived context through the same seeded sequence, and after
+    each step holds the slab of what a fresh single-rank context computes"""
+    n = 32
+    nxl = n // P
+    x, y = synth.invgrow_table("lcdm")
+    g0 = synth.growth_multipliers()
+    rng = np.random.default_rng(5)
+    ops = []
+    seed, g, radii = 1, g0, np.array([2.0, 1.0, 0.0])
+    for _ in range(14):
+        op = int(rng.integers(0, 4))
+        if op == 0:
+            seed += 1
+        elif op == 1:
+            g = g0 * rng.uniform(0.5, 1.5, 4)
+        elif op == 3:
+            radii = np.array([float(rng.uniform(1.5, 4.0)), float(rng.uniform(0.5, 1.4)), 0.0])
+        ops.append((op, seed, g.copy(), radii.copy()))
+    want = []
+    for op, seed, g, radii in ops:                                  # single-rank truth for every step that computes
+        with api.Fmax(n) as f:
+            f.set_density(synth.make_density(n, seed=seed)); f.set_invgrow(x, y); f.set_growth(g)
+            tv = f.compute_fmax(radii, do_lpt=True)
+            want.append((tv, f.products()))
+
+    def body(f, r):
+        f.set_invgrow(x, y)
+        f.set_density(synth.make_density(n, seed=1)[r * nxl:(r + 1) * nxl]); f.set_growth(g0)
+        got = []
+        for op, seed, g, radii in ops:
+            if op == 0:
+                f.set_density(synth.make_density(n, seed=seed)[r * nxl:(r + 1) * nxl])
+            f.set_growth(g)
+            if op == 2:                                             # apart, with the Hessian disturbed in between
+                tv = f.sweep(radii)
+                f.compute_second_derivatives(1.3)
+                f.compute_displacements(1, 1)
+            else:
+                tv = f.compute_fmax(radii, do_lpt=True)
+            got.append((tv, f.products()))
+        return got
+
+    res = run_ranks(api, n, P, body)
+    for r in range(P):
+        sl = slice(r * nxl, (r + 1) * nxl)
+        for (tv, p), (tv0, p0) in zip(res[r], want):
+            assert np.allclose(tv, tv0, rtol=1e-13)
+            for name in ("Fmax", "Rmax", "Vel", "Vel_2LPT", "Vel_3LPT_1"):
+                assert np.array_equal(p[name], p0[name][sl]), (r, name)
+            a, b = p["Vel_3LPT_2"].astype(np.float64), p0["Vel_3LPT_2"][sl].astype(np.float64)
+            assert np.max(np.abs(a - b)) <= 2e-7 * np.max(np.abs(b))
+
+
+@pytest.mark.parametrize("P", [2, 8])
 def test_double_precision_products_on_slabs(api, P):
     """PF_FLAG_DOUBLE_PRODUCTS (-DDOUBLE_PRECISION_PRODUCTS) with more than one rank: fp64 Fmax and displacement columns, bit for
     bit those of one rank (P = 2: replicated delta(k); P = 8: every transform through the all-to-all)"""

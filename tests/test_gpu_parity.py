@@ -1252,3 +1252,74 @@ def test_fast_flavour_elementary_functions_on_the_device(api):
         assert ulps(run(f, 8, xe)[ok10], want10[ok10]).max() <= 1.0
         edge = np.array([-746.0, -1e10, -np.inf, 710.0, np.inf])
         assert np.array_equal(run(f, 7, edge), [0.0, 0.0, 0.0, np.inf, np.inf])
+
+
+@pytest.mark.parametrize("seed", [2024, 7, 99])
+def test_state_machine_of_one_context_against_fresh_contexts(api, seed):
+    """One long-lived context driven through a seeded random sequence of the entry points -- new density, growth factors, LPT order,
+    sweep + displacements apart or together (sources formed by the last solve), second derivatives at another radius in between,
+    re-entrant displacements -- must at every step hold exactly what a fresh context computes from scratch: the flags that say
+    which fields are current (Hessian, real-space sources, resident source spectra) may not go stale."""
+    n = 32
+    rng = np.random.default_rng(seed)
+    x, y = synth.invgrow_table("lcdm")
+    state = {"seed": 1, "g": synth.growth_multipliers(), "order": 3, "radii": np.array([2.0, 1.0, 0.0])}
+
+    def fresh(with_lpt=True, g=None):
+        with api.Fmax(n) as f:
+            f.set_density(synth.make_density(n, seed=state["seed"])); f.set_invgrow(x, y); f.set_growth(state["g"] if g is None else g)
+            f.set_lpt_order(state["order"])
+            tv = f.sweep(state["radii"])
+            if with_lpt:
+                f.compute_displacements(1, 0)
+            return tv, f.products()
+
+    def same(p, q, names):
+        for name in names:
+            assert np.array_equal(p[name], q[name]), name
+
+    vel = ("Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2")
+    with api.Fmax(n) as f:
+        f.set_invgrow(x, y)
+        f.set_density(synth.make_density(n, seed=state["seed"])); f.set_growth(state["g"])
+        have_spectra = False
+        for step in range(40):
+            op = rng.integers(0, 7)
+            if op == 0:                                            # new density
+                state["seed"] += 1
+                f.set_density(synth.make_density(n, seed=state["seed"]))
+                have_spectra = False
+            elif op == 1:                                          # other growth factors
+                state["g"] = synth.growth_multipliers() * rng.uniform(0.5, 1.5, 4)
+                f.set_growth(state["g"])
+            elif op == 2:                                          # other LPT order
+                state["order"] = int(rng.integers(1, 4))
+                f.set_lpt_order(state["order"])
+                have_spectra = False                               # (a lower order's spectra do not serve a higher one)
+            elif op == 3:                                          # compute_fmax: sources formed by the last solve
+                tv = f.compute_fmax(state["radii"], do_lpt=True)
+                tv0, p0 = fresh()
+                assert np.array_equal(tv, tv0)
+                same(f.products(), p0, ("Fmax", "Rmax") + vel)
+                have_spectra = True
+            elif op == 4:                                          # sweep, something else in between, then the displacements
+                tv = f.sweep(state["radii"])
+                f.compute_second_derivatives(1.3)                  # overwrites the R = 0 Hessian
+                f.compute_displacements(1, 1)                      # recompute_sd puts it back
+                tv0, p0 = fresh()
+                assert np.array_equal(tv, tv0)
+                same(f.products(), p0, ("Fmax", "Rmax") + vel)
+                have_spectra = True
+            elif op == 5 and have_spectra:                         # re-entrant displacements at another redshift
+                g2 = state["g"] * np.array([0.7, 0.5, 0.35, 0.35])
+                f.set_growth(g2)
+                f.compute_displacements(0, 0)
+                _, p0 = fresh(g=g2)
+                same(f.products(), p0, vel)
+                f.set_growth(state["g"])
+            elif op == 6:                                          # sweep with other radii, no displacements
+                state["radii"] = np.array([float(rng.uniform(1.5, 4.0)), float(rng.uniform(0.5, 1.4)), 0.0])
+                tv = f.sweep(state["radii"])
+                tv0, p0 = fresh(with_lpt=False)
+                assert np.array_equal(tv, tv0)
+                same(f.products(), p0, ("Fmax", "Rmax"))
