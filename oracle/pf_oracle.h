@@ -7,19 +7,24 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load it; the shipped library (libpinfmax_hip.so) never does.
  *
- * Parity pin: (1) END TO END against the reference's own committed validation run (HMF_Validation/: 128^3,
- * seed 486604, E&H, 9 radii): with the restated IC generator (pf_genic.c + tests/ic_oracle.py) the oracle
- * reproduces the logged per-radius sigma to the 4 printed decimals, the collapsed-cell count to 1 cell in
- * 1 230 386 and the 210-bin Fmax histogram to 70 cells in 2 097 152 (tests/test_hmf_validation_kat.py, data in
- * tests/golden/hmf_validation_kat.json).  (2) The per-cell solver against the known answers of the reference's
- * ell_classic / inverse_collapse_time (SURVEY.md Appendix D -> tests/golden/collapse_kat.json).  (3) The
- * field-level path (k-filter, c2r, LPT) against an independent numpy/pocketfft restatement
- * (tests/np_restatement.py).  The displacement fields have no reference output in the repository and are
- * pinned by (3) only.  The reference itself is UNBUILDABLE in this image (needs GSL, FFTW3-MPI and PFFT, all
- * absent; no stand-ins are written), so no oracle/_ref exists; see DESIGN.md "Oracle".
+ * Parity pin: (1) END TO END against the five runs the reference commits with their outputs, each reproduced with the
+ * restated IC generator (pf_genic.c + tests/ic_oracle.py) from seed and cosmology -- logged sigma of every radius to the 4
+ * printed decimals, collapsed-cell count, 210-bin Fmax histogram:
+ *   HMF_Validation/ (128^3, E&H, 9 radii): 1 230 387 vs 1 230 386 collapsed, histogram L1 70 of 2 097 152 (tests/test_hmf_validation_kat.py);
+ *   example/log (128^3, V5.1 default flags, 7 radii): 687 252 vs 687 249 (count only: the log holds no histogram);
+ *   tests/only_HMF_tests/RECOMPUTE_DISPLACEMENTS_LCDM = SCALE_DEP_LCDM (256^3, FixedIC, 9 radii; also with per-radius splines):
+ *     10 989 577 vs 10 989 578, L1 118 of 16 777 216;
+ *   tests/only_HMF_tests/READ_PK_TABLE_and_SCALE_DEP (256^3, tabulated CAMB spectrum, FixedIC, 10 radii): 12 822 323 vs 12 822 323, L1 444;
+ *   tests/only_HMF_tests/MOD_GRAV_and_SCALE_DEP (256^3, TABULATED_CT + ELL_SNG + MOD_GRAV_FR): 10 935 586 vs 10 935 578, L1 198
+ *   (tests/test_hmf256_kat.py; data in tests/golden/*_kat.json, made by the scripts beside them).
+ * (2) The per-cell solver against the known answers of the reference's ell_classic / inverse_collapse_time (SURVEY.md
+ * Appendix D -> tests/golden/collapse_kat.json).  (3) The displacement half, for which the reference commits no output, against
+ * closed-form plane-wave answers derived in exact arithmetic from the reference's formulas (tests/golden/lpt_analytic.json) and
+ * an independent numpy/pocketfft restatement (tests/np_restatement.py).  The reference itself is UNBUILDABLE in this image
+ * (needs GSL, FFTW3-MPI and PFFT, all absent; no stand-ins are written), so no oracle/_ref exists; see DESIGN.md "Oracle".
  *
- * Flags mirrored: -DTWO_LPT -DTHREE_LPT -DELL_CLASSIC (no SCALE_DEPENDENT,
- * no RECOMPUTE_DISPLACEMENTS, float products) == HMF_Validation build.
+ * Flags mirrored: -DTWO_LPT -DTHREE_LPT, ELL_CLASSIC or ELL_SNG (+ MOD_GRAV_FR), TABULATED_CT (three interpolations),
+ * SCALE_DEPENDENT pieces (per-radius splines, k-binned growth), float products (double ones: libpf_oracle_dp.so).
  */
 #ifndef PF_ORACLE_H
 #define PF_ORACLE_H
