@@ -16,7 +16,7 @@
  *     10 989 577 vs 10 989 578, L1 118 of 16 777 216;
  *   tests/only_HMF_tests/READ_PK_TABLE_and_SCALE_DEP (256^3, tabulated CAMB spectrum, FixedIC, 10 radii): 12 822 323 vs 12 822 323, L1 444;
  *   tests/only_HMF_tests/MOD_GRAV_and_SCALE_DEP (256^3, TABULATED_CT + ELL_SNG + MOD_GRAV_FR): 10 935 586 vs 10 935 578, L1 198
- *   (tests/test_hmf256_kat.py; data in tests/golden/*_kat.json, made by the scripts beside them).
+ *   (tests/test_hmf256_kat.py; data in the tests/golden/ fixtures named ..._kat.json, made by the scripts beside them).
  * (2) The per-cell solver against the known answers of the reference's ell_classic / inverse_collapse_time (SURVEY.md
  * Appendix D -> tests/golden/collapse_kat.json).  (3) The displacement half, for which the reference commits no output, against
  * closed-form plane-wave answers derived in exact arithmetic from the reference's formulas (tests/golden/lpt_analytic.json) and
