@@ -101,6 +101,7 @@ struct pf_ctx {
   // a 12-radius step, at the price of an x-pass that does not shrink with P.  Gathered once per density (dk_full_valid).
   void *dk_full;
   bool replicate, dk_full_valid;
+  double *INV[3];      // fp32 fields: the fp64 invariant rows of the sweep's z-pass (compact, pitch n), allocated at first use
   // P > 1: second set of send/receive fields and a communication stream, so that the all-to-all of transform i+1
   // runs beside the y/z passes (and the collapse solve) of transform i (pipelined(), PF_PIPELINE=0 to disable)
   bool pipeline;
@@ -362,7 +363,7 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   c->growth[0] = 1.0; c->growth[1] = 3. / 7.; c->growth[2] = -1. / 9.; c->growth[3] = 5. / 42.;
   for (int i = 0; i < 6; i++) { c->B[i] = nullptr; c->B2[i] = nullptr; }
   c->blockA = nullptr; c->dk = nullptr; c->recvA = nullptr; c->tw = nullptr;
-  c->blockA2 = nullptr; c->recvA2 = nullptr; c->cstream = nullptr; c->dk_full = nullptr; c->replicate = false; c->dk_full_valid = false;
+  c->blockA2 = nullptr; c->recvA2 = nullptr; c->cstream = nullptr; c->dk_full = nullptr; c->replicate = false; c->dk_full_valid = false; c->INV[0] = c->INV[1] = c->INV[2] = nullptr;
   c->fmax = nullptr; c->rmax = nullptr; c->vel12 = nullptr; c->partials = nullptr; c->scal = nullptr; c->hist = nullptr; c->spl = nullptr;
   c->gtab = nullptr; c->etab = nullptr; c->ct_block = nullptr;
   for (int i = 0; i < 2; i++) c->ev_x[i] = c->ev_r[i] = nullptr;
@@ -386,7 +387,7 @@ extern "C" int pf_destroy(pf_ctx *c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->cstream) hipStreamSynchronize(c->cstream);
   pf_rccl_release(c->rccl); c->rccl = nullptr;
-  hipFree(c->dk); hipFree(c->blockA); hipFree(c->recvA); hipFree(c->tw); hipFree(c->blockA2); hipFree(c->recvA2); hipFree(c->dk_full);
+  hipFree(c->dk); hipFree(c->blockA); hipFree(c->recvA); hipFree(c->tw); hipFree(c->blockA2); hipFree(c->recvA2); hipFree(c->dk_full); for (int k = 0; k < 3; k++) hipFree(c->INV[k]);
   for (int i = 0; i < 6; i++) { hipFree(c->B[i]); hipFree(c->B2[i]); }
   for (int i = 0; i < 3; i++) hipFree(c->S[i]);
   hipFree(c->fmax); hipFree(c->rmax); hipFree(c->vel12); hipFree(c->partials); hipFree(c->partials_src); hipFree(c->scal); hipFree(c->hist); hipFree(c->spl); hipFree(c->gtab); hipFree(c->etab); hipFree(c->ct_block); hipFree(c->W);
@@ -581,12 +582,19 @@ static int zpass_c2r(pf_ctx *c, int kind, int njobs, const ZJob *jobs, const dou
   if (acc) {  // six components in, none out: acc -= 2 phi2_ab h_ab with the first-order Hessian h in jobs[].out (src/LPT.c:134-137)
     p.acc = acc;
     KTimer t(c, KS_ZPASS_LPT3B, njobs * frac_in * spec_bytes_alg(c) + 8.0 * real_bytes_alg(c));
-    PFCHK(c, pf_launch_c2r_invariants(c->n, p, c->stream, 1));
+    PFCHK(c, pf_launch_c2r_invariants(c->fb, c->n, p, c->stream, 1));
     return 0;
   }
-  if (invariants) {  // six components in, the three invariants of the tensor out (fields 0..2)
-    KTimer t(c, KS_ZPASS_INV, njobs * frac_in * spec_bytes_alg(c) + 3.0 * real_bytes_alg(c));
-    PFCHK(c, pf_launch_c2r_invariants(c->n, p, c->stream));
+  if (invariants) {  // six components in, the three invariants of the tensor out (fields 0..2; fp32 fields: fp64 rows in INV)
+    if (c->fb == 4) {
+      for (int k = 0; k < 3; k++) {
+        if (!c->INV[k]) PFCHK(c, dev_alloc(c, (void **)&c->INV[k], ncell(c) * sizeof(double)));
+        p.inv_out[k] = c->INV[k];
+      }
+      p.inv_pitch = c->n;
+    }
+    KTimer t(c, KS_ZPASS_INV, njobs * frac_in * spec_bytes_alg(c) + 3.0 * (double)ncell(c) * 8.0);
+    PFCHK(c, pf_launch_c2r_invariants(c->fb, c->n, p, c->stream));
     return 0;
   }
   KTimer t(c, kind, njobs * frac_in * spec_bytes_alg(c) + outb);
@@ -1148,6 +1156,11 @@ static int collapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], hipStream_
   size_t nb = (ncell(c) + 255) / 256; if (nb > (size_t)c->collapse_blocks) nb = c->collapse_blocks;
   p.nblocks = (int)nb;
   if (invariants) p.invariants = 1;
+  int solve_fb = c->fb;
+  if (invariants && c->fb == 4) {  // the invariants of fp32 fields are fp64 rows of their own (k_c2r_invariants<float>)
+    for (int k = 0; k < 3; k++) p.h[k] = c->INV[k];
+    p.pitch = c->n; solve_fb = 8;
+  }
   sources = sources && c->lpt_order >= 2 && !invariants && !p.tabulated && !p.sng;
   if (sources) {  // K7 in the same pass (the grid is k_lpt_sources' own: identical partial sums of S2)
     p.sources = 1; p.src[0] = c->S[0]; p.src[1] = c->S[1]; p.src[2] = c->S[2]; p.src_partials = c->partials_src;
@@ -1155,8 +1168,8 @@ static int collapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], hipStream_
   }
   {
     KTimer t(c, sources ? KS_COLLAPSE_SRC : invariants ? KS_COLLAPSE_INV : KS_COLLAPSE,
-             (double)ncell(c) * ((invariants ? 3.0 : sources ? 9.0 : 6.0) * c->fb + 16.0), st);
-    PFCHK(c, pf_launch_collapse(c->fb, p, st));
+             (double)ncell(c) * ((invariants ? 3.0 * 8.0 / c->fb : sources ? 9.0 : 6.0) * c->fb + 16.0), st);
+    PFCHK(c, pf_launch_collapse(solve_fb, p, st));
   }
   PFCHK(c, pf_launch_final_sum(c->partials, p.nblocks, c->scal + SC_VAR0 + 2 * ismooth, st));
   if (sources) {
@@ -1208,7 +1221,8 @@ static int sweep_body(pf_ctx *c, int ns, const double *radius_cells, double *tru
   PFCHK(c, products_reset(c));
   c->sources_fresh = false;
   // (n <= 1024: the six-line workgroup of a 2048-point row would need 110 KB of dynamic LDS, a size this build never launches)
-  const bool invariants_ok = c->fb == 8 && c->n <= 1024 && !c->general && c->tab_ns == 0 && c->model == 0 && c->tune.invariants && !six_components;
+  // (n <= 1024 with fp64 fields, n <= 2048 with fp32 ones: the six lines of a row must fit the LDS of a workgroup)
+  const bool invariants_ok = c->n <= (c->fb == 8 ? 1024 : 2048) && !c->general && c->tab_ns == 0 && c->model == 0 && c->tune.invariants && !six_components;
   HIPCHK(c, hipMemsetAsync(c->scal + SC_INV_FLAG, 0, sizeof(double), c->stream));
   const bool rep = c->replicate;
   if (rep) PFCHK(c, ensure_dk_full(c));
@@ -1325,7 +1339,7 @@ extern "C" int pf_displacements(pf_ctx *c, int compute_sources, int recompute_sd
       // Hessian of the 2LPT potential contracted with the first-order one into the 3LPT(b) source (src/LPT.c:112-137).  fp64
       // fields: the z-pass does the contraction while it holds a row's six components (nothing of that Hessian is stored;
       // PF_LPT_FUSE=0: six fields out, then k_lpt_accum); same operations per cell either way
-      const bool fuse3b = c->fb == 8 && c->n <= 1024 && !c->general && c->tune.lpt_fuse;
+      const bool fuse3b = c->n <= (c->fb == 8 ? 1024 : 2048) && !c->general && c->tune.lpt_fuse;
       if (c->lpt_order < 3) {  // no THREE_LPT (src/LPT.c:78-92, 113-175): the 2LPT source alone
       } else if (fuse3b) {
         PFCHK(c, hessian_of(c, c->S[0], 0.0, c->scal + SC_DC_S2, c->B2, c->S[2], c->B));
@@ -1678,7 +1692,7 @@ extern "C" int pf_debug_lines(int field_bytes, int n, int pass, int mul, int ban
   double *flag_out = (pass == 4 && out) ? out + (size_t)3 * nouter * n : nullptr;  // pass 4: one more double after the rows, the q == 0 flag
   if (!in || !out || nouter < 1 || (field_bytes != 8 && field_bytes != 4) || n < 16 || n > 2048 || (n & (n - 1)) || pass < 0 || pass > 4)
     return pf_fail(0, "pf_debug_lines: bad argument");
-  if (pass == 4 && (field_bytes != 8 || n > 1024)) return pf_fail(0, "pf_debug_lines: the invariant z-pass takes fp64 rows of at most 1024 points");
+  if (pass == 4 && n > (field_bytes == 8 ? 1024 : 2048)) return pf_fail(0, "pf_debug_lines: the invariant z-pass takes fp64 rows of at most 1024 points, fp32 rows of at most 2048");
   const int fb = field_bytes, nzh = n / 2 + 1;
   pf_ctx *nc = nullptr;  // for the error macros
   size_t n_in, n_out;    // scalars of type F
@@ -1702,7 +1716,8 @@ extern "C" int pf_debug_lines(int field_bytes, int n, int pass, int mul, int ban
   int rc = 0;
   auto body = [&]() -> int {
     HIPCHK(nc, hipMalloc(&d_in, n_in_alloc * fb));
-    HIPCHK(nc, hipMalloc(&d_out, n_out * fb));
+    const size_t out_b = (pass == 4) ? 8 : (size_t)fb;  // the invariants are fp64 whatever the fields are
+    HIPCHK(nc, hipMalloc(&d_out, n_out * out_b));
     HIPCHK(nc, hipMalloc(&d_tw, tw.size()));
     HIPCHK(nc, hipMalloc((void **)&d_etab, (size_t)n * sizeof(double)));
     HIPCHK(nc, hipMalloc((void **)&d_flag, sizeof(double)));
@@ -1714,7 +1729,7 @@ extern "C" int pf_debug_lines(int field_bytes, int n, int pass, int mul, int ban
       for (size_t i = 0; i < n_in; i++) h[i] = (float)in[i];
       HIPCHK(nc, hipMemcpy(d_in, h.data(), n_in * 4, hipMemcpyHostToDevice));
     }
-    HIPCHK(nc, hipMemset(d_out, 0, n_out * fb));
+    HIPCHK(nc, hipMemset(d_out, 0, n_out * out_b));
     if (pass <= 1) {
       PfStridedParams p; memset(&p, 0, sizeof(p));
       p.njobs = 1; p.job[0].in = d_in; p.job[0].out = d_out; p.job[0].mul = mul;
@@ -1730,20 +1745,22 @@ extern "C" int pf_debug_lines(int field_bytes, int n, int pass, int mul, int ban
       static const int mul6[6] = {PF_MUL_ONE, PF_MUL_ONE, PF_MUL_K2, PF_MUL_ONE, PF_MUL_K, PF_MUL_K};
       for (int j = 0; j < p.njobs; j++) {
         p.job[j].in = (char *)d_in + (size_t)j * nouter * nzh * 2 * fb;
-        p.job[j].out = pass == 2 ? d_out : (char *)d_out + (size_t)(j % 3) * nouter * n * fb;
+        p.job[j].out = pass == 2 ? d_out : (char *)d_out + (size_t)(j % 3) * nouter * n * 8;
+        if (pass == 4 && j < 3) p.inv_out[j] = (double *)((char *)d_out + (size_t)j * nouter * n * 8);
         p.job[j].mul = pass == 2 ? mul : mul6[j]; p.job[j].out_f32 = 0;
       }
       p.nlines = nouter; p.in_pitch = nzh; p.out_pitch = n; p.norm = 1.0; p.dc = nullptr; p.tw = d_tw; p.band_k = band < n / 2 ? band : n;
       p.ncu = ncu; p.dev = dev; p.persist_per_cu = tune.zpass_persist; p.inv_per_cu = tune.zpass_inv_wg_per_cu; p.flag = d_flag;
+      p.inv_pitch = n;
       if (pass == 2) PFCHK0(pf_launch_c2r(fb, n, p, nullptr));
-      else PFCHK0(pf_launch_c2r_invariants(n, p, nullptr, 0));
+      else PFCHK0(pf_launch_c2r_invariants(fb, n, p, nullptr, 0));
     } else {
       PfR2CParams p; p.in = d_in; p.out = d_out; p.nlines = nouter; p.in_pitch = n; p.out_pitch = nzh; p.tw = d_tw;
       PFCHK0(pf_launch_r2c(fb, n, p, nullptr));
     }
     HIPCHK(nc, hipDeviceSynchronize());
     if (pass == 4 && flag_out) HIPCHK(nc, hipMemcpy(flag_out, d_flag, sizeof(double), hipMemcpyDeviceToHost));
-    if (fb == 8) HIPCHK(nc, hipMemcpy(out, d_out, n_out * 8, hipMemcpyDeviceToHost));
+    if (fb == 8 || pass == 4) HIPCHK(nc, hipMemcpy(out, d_out, n_out * 8, hipMemcpyDeviceToHost));
     else {
       std::vector<float> h(n_out);
       HIPCHK(nc, hipMemcpy(h.data(), d_out, n_out * 4, hipMemcpyDeviceToHost));

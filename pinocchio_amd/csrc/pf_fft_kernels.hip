@@ -274,14 +274,17 @@ __global__ void __launch_bounds__(TL *(N / 16)) k_c2r_persistent(const PfC2RPara
 // fields, in place: every input of row R is in registers or LDS before the first store).  Per radius the pass writes
 // 26 GB instead of 52 and the solve reads 26 instead of 52.  The component values are formed by the same expression as in
 // k_c2r (pf_norm_dc) and the invariants by the solve's own pf_invariants (no contraction): Fmax, Rmax and the variances
-// come out bit for bit as with the six-field path.  fp64 fields.
+// come out bit for bit as with the six-field path.  fp64 fields store the invariants in place (rows of the first three
+// fields); fp32 fields (F = float: the transforms in fp32 as in k_c2r, the reduction in fp64 from the fp32 components exactly
+// as k_collapse<float> forms it) store them as fp64 rows of pitch inv_pitch in the separate buffers inv_out[0..2].
 // MODE 1 (the Hessian of the 2LPT potential, src/LPT.c:112-137): the six rows are not stored at all; each cell's 3LPT(b)
 // source is updated in place from them and the six components of the first-order Hessian (read from job[c].out):
 // p.acc -= 2 phi2_ab h_ab, by the same pf_lpt3b_accumulate as k_lpt_accum.
-template <int N, int MODE = 0>
+template <typename F, int N, int MODE = 0>
 __global__ void __launch_bounds__(6 * (N / 16)) k_c2r_invariants(const PfC2RParams p, long long nrows) {
-  using F = double;
   using C = pfc<F>;
+  using F2 = typename pf_vec2<F>::type;
+  constexpr bool IN_PLACE = sizeof(F) == 8;  // fp64 invariants fit the rows they replace
   constexpr int M = N / 2, NT = M / 8, TL = 6;
   constexpr int LPL = (M + 1 > M + M / 8) ? M + 1 : M + M / 8;
   constexpr int NTHR = TL * NT;
@@ -300,8 +303,9 @@ __global__ void __launch_bounds__(6 * (N / 16)) k_c2r_invariants(const PfC2RPara
 #pragma unroll
   for (int j = 1; j < TL; j++)
     if (l == j) { in = reinterpret_cast<const C *>(p.job[j].in); mul = p.job[j].mul; }
-  F *__restrict__ o1 = reinterpret_cast<F *>(p.job[0].out), *__restrict__ o2 = reinterpret_cast<F *>(p.job[1].out),
-    *__restrict__ o3 = reinterpret_cast<F *>(p.job[2].out);
+  double *__restrict__ o1 = IN_PLACE ? reinterpret_cast<double *>(p.job[0].out) : p.inv_out[0],
+         *__restrict__ o2 = IN_PLACE ? reinterpret_cast<double *>(p.job[1].out) : p.inv_out[1],
+         *__restrict__ o3 = IN_PLACE ? reinterpret_cast<double *>(p.job[2].out) : p.inv_out[2];
 
   // a line is touched by its own threads only until the reduction: while those sit in one wave (N <= 1024) the LDS
   // queue keeps their accesses in order and no workgroup barrier is needed
@@ -348,10 +352,11 @@ __global__ void __launch_bounds__(6 * (N / 16)) k_c2r_invariants(const PfC2RPara
     __syncthreads();
     // per cell: six components -> three invariants; two neighbouring cells per thread (16-byte LDS reads and stores)
     for (int c = 2 * tidj; c < N; c += 2 * NTHR) {
-      double2 h[6];
+      F2 h[6];
 #pragma unroll
-      for (int k = 0; k < 6; k++) h[k] = *reinterpret_cast<const double2 *>(reinterpret_cast<const F *>(lds + k * LPL) + c);
-      const double da[6] = {h[0].x, h[1].x, h[2].x, h[3].x, h[4].x, h[5].x}, db[6] = {h[0].y, h[1].y, h[2].y, h[3].y, h[4].y, h[5].y};
+      for (int k = 0; k < 6; k++) h[k] = *reinterpret_cast<const F2 *>(reinterpret_cast<const F *>(lds + k * LPL) + c);
+      const double da[6] = {(double)h[0].x, (double)h[1].x, (double)h[2].x, (double)h[3].x, (double)h[4].x, (double)h[5].x},
+                   db[6] = {(double)h[0].y, (double)h[1].y, (double)h[2].y, (double)h[3].y, (double)h[4].y, (double)h[5].y};
       const long long a = R * p.out_pitch + c;
       if (MODE == 0) {
         double a1, a2, a3, b1, b2, b3;
@@ -360,19 +365,23 @@ __global__ void __launch_bounds__(6 * (N / 16)) k_c2r_invariants(const PfC2RPara
         // the solve's q == 0 case takes the tensor's own diagonal (src/collapse_times.c:722-727), which is not stored: it
         // will use mu1/3 three times.  The same unless the tensor is exactly that; otherwise the sweep is repeated (pf_sweep)
         if (pf_invariants_lose_diagonal(da, a1, a2) || pf_invariants_lose_diagonal(db, b1, b2)) *p.flag = 1.0;
-        *reinterpret_cast<double2 *>(o1 + a) = make_double2(a1, b1);
-        *reinterpret_cast<double2 *>(o2 + a) = make_double2(a2, b2);
-        *reinterpret_cast<double2 *>(o3 + a) = make_double2(a3, b3);
+        const long long ao = IN_PLACE ? a : R * p.inv_pitch + c;
+        *reinterpret_cast<double2 *>(o1 + ao) = make_double2(a1, b1);
+        *reinterpret_cast<double2 *>(o2 + ao) = make_double2(a2, b2);
+        *reinterpret_cast<double2 *>(o3 + ao) = make_double2(a3, b3);
       } else {
         double ha[6], hb[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) {
-          const double2 g = *reinterpret_cast<const double2 *>(reinterpret_cast<const F *>(p.job[k].out) + a);
-          ha[k] = g.x; hb[k] = g.y;
+          const F2 g = *reinterpret_cast<const F2 *>(reinterpret_cast<const F *>(p.job[k].out) + a);
+          ha[k] = (double)g.x; hb[k] = (double)g.y;
         }
-        double2 *acc = reinterpret_cast<double2 *>(reinterpret_cast<F *>(p.acc) + a);
-        const double2 s = *acc;
-        *acc = make_double2(pf_lpt3b_accumulate(s.x, da, ha), pf_lpt3b_accumulate(s.y, db, hb));
+        F2 *acc = reinterpret_cast<F2 *>(reinterpret_cast<F *>(p.acc) + a);
+        const F2 s = *acc;
+        F2 r;
+        r.x = (F)pf_lpt3b_accumulate((double)s.x, da, ha);
+        r.y = (F)pf_lpt3b_accumulate((double)s.y, db, hb);
+        *acc = r;
       }
     }
     __syncthreads();  // the lines are rewritten by the next phase A
@@ -483,7 +492,7 @@ static int launch_c2r_n(const PfC2RParams &p, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
-template <int N>
+template <typename F, int N>
 static int launch_c2r_invariants_n(const PfC2RParams &p, hipStream_t st, int mode) {
   constexpr int M = N / 2, NT = M / 8;
   constexpr int LPL = (M + 1 > M + M / 8) ? M + 1 : M + M / 8;
@@ -493,9 +502,9 @@ static int launch_c2r_invariants_n(const PfC2RParams &p, hipStream_t st, int mod
   // 64: 236 ms per step of eleven launches at 1024^3)
   long long g = (long long)(p.ncu > 0 ? p.ncu : 256) * (p.inv_per_cu > 0 ? p.inv_per_cu : 32);
   if (g > p.nlines) g = p.nlines;
-  const size_t shm = (size_t)6 * LPL * sizeof(pfc<double>);
-  if (mode == 1) hipLaunchKernelGGL((k_c2r_invariants<N, 1>), dim3((unsigned)g), dim3(6 * NT), shm, st, p, p.nlines);
-  else hipLaunchKernelGGL((k_c2r_invariants<N, 0>), dim3((unsigned)g), dim3(6 * NT), shm, st, p, p.nlines);
+  const size_t shm = (size_t)6 * LPL * sizeof(pfc<F>);
+  if (mode == 1) hipLaunchKernelGGL((k_c2r_invariants<F, N, 1>), dim3((unsigned)g), dim3(6 * NT), shm, st, p, p.nlines);
+  else hipLaunchKernelGGL((k_c2r_invariants<F, N, 0>), dim3((unsigned)g), dim3(6 * NT), shm, st, p, p.nlines);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
@@ -560,11 +569,19 @@ int pf_launch_c2r(int fb, int n, const PfC2RParams &p, hipStream_t st) {
   }
 }
 
-int pf_launch_c2r_invariants(int n, const PfC2RParams &p, hipStream_t st, int mode) {
-  if (p.njobs != 6 || (mode == 1 && !p.acc) || (mode == 0 && !p.flag) || n > 1024) return 2;
-#define CALL(NN) launch_c2r_invariants_n<NN>(p, st, mode)
-  PF_SWITCH_N(n, CALL)
+int pf_launch_c2r_invariants(int fb, int n, const PfC2RParams &p, hipStream_t st, int mode) {
+  // (the six lines of a 2048-point fp64 row would need 110 KB of LDS; fp32 fields go up to 2048)
+  if (p.njobs != 6 || (mode == 1 && !p.acc) || (mode == 0 && !p.flag) || n > (fb == 8 ? 1024 : 2048)) return 2;
+  if (fb == 8) {
+#define CALL(NN) launch_c2r_invariants_n<double, NN>(p, st, mode)
+    PF_SWITCH_N(n, CALL)
 #undef CALL
+  } else {
+    if (mode == 0 && (!p.inv_out[0] || !p.inv_out[1] || !p.inv_out[2])) return 2;
+#define CALL(NN) launch_c2r_invariants_n<float, NN>(p, st, mode)
+    PF_SWITCH_N(n, CALL)
+#undef CALL
+  }
 }
 
 int pf_launch_r2c(int fb, int n, const PfR2CParams &p, hipStream_t st) {

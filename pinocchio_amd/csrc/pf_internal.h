@@ -89,11 +89,13 @@ struct PfC2RParams {
   int ncu, dev;         // CUs of the device, device index
   int persist_per_cu;   // workgroups per CU of the persistent z-pass (0: one-shot kernel)
   int inv_per_cu;       // workgroups per CU of the invariant z-pass
+  double *inv_out[3];   // k_c2r_invariants<float> MODE 0: the fp64 invariant rows (pitch inv_pitch) -- fp32 rows cannot hold them
+  long long inv_pitch;
 };
 int pf_launch_c2r(int field_bytes, int n, const PfC2RParams &p, hipStream_t st);
-// six components (njobs == 6, fp64) -> the three invariants of the tensor into job[0..2].out (pf_fft_kernels.hip)
+// six components (njobs == 6) -> the three invariants of the tensor: fp64 fields into job[0..2].out, fp32 fields into inv_out
 // mode 1: nothing stored, p.acc -= 2 phi2_ab h_ab with h_ab read from job[c].out (the 3LPT(b) source, src/LPT.c:134-137)
-int pf_launch_c2r_invariants(int n, const PfC2RParams &p, hipStream_t st, int mode = 0);
+int pf_launch_c2r_invariants(int field_bytes, int n, const PfC2RParams &p, hipStream_t st, int mode = 0);
 
 struct PfR2CParams {
   const void *in;       // real rows, pitch in_pitch reals

@@ -32,11 +32,11 @@ def run(L, fb, n, pas, inp, out_shape, mul=0, band=1 << 30, nouter=1, ncols=1, p
     return out
 
 
-def run_invariants(L, n, x, rows):
-    """pass 4: six spectra rows -> (mu1, mu2, mu3) rows, plus the q == 0 flag"""
+def run_invariants(L, n, x, rows, fb=8):
+    """pass 4: six spectra rows -> (mu1, mu2, mu3) rows (fp64 whatever the fields are), plus the q == 0 flag"""
     x = np.ascontiguousarray(x)
     out = np.zeros(3 * rows * n + 1)
-    rc = L.pf_debug_lines(8, n, 4, 0, 1 << 30, rows, 1, 0, 0.0, 1.0, 0, _dp(x.view(np.float64)), _dp(out))
+    rc = L.pf_debug_lines(fb, n, 4, 0, 1 << 30, rows, 1, 0, 0.0, 1.0, 0, _dp(x.view(np.float64)), _dp(out))
     assert rc == 0, L.pf_last_error()
     return out[:-1].reshape(3, rows, n), out[-1]
 
@@ -125,6 +125,26 @@ def test_zpass_r2c_lines(L, n, fb):
     got = run(L, fb, n, 3, x, (rows, n // 2 + 1), nouter=rows)
     want = np.fft.rfft(x, axis=1)
     assert np.max(np.abs(got - want)) <= tol(fb, n) * np.max(np.abs(want)), (n, fb)
+
+
+@pytest.mark.parametrize("n", [16, 64, 256, 1024, 2048])
+def test_invariant_zpass_lines_fp32_fields(L, n):
+    """the same pass on fp32 fields (BASELINE config 5's arithmetic; rows of up to 2048 points fit): transforms in fp32, the
+    reduction in fp64 from the fp32 components, fp64 invariants out"""
+    rng = np.random.default_rng(13 * n)
+    rows, h = 11, n // 2 + 1
+    x = (rng.standard_normal((6, rows, h)) + 1j * rng.standard_normal((6, rows, h))).astype(np.complex64).astype(np.complex128)
+    kz = 2 * np.pi / n * np.arange(h)
+    mul6 = (0, 0, 2, 0, 1, 1)
+    d = [np.fft.irfft(x[j] * kfactor(mul6[j], kz)[None, :], n=n, axis=1) * n for j in range(6)]
+    got, flag = run_invariants(L, n, x, rows, fb=4)
+    assert flag == 0.0
+    mu1 = d[0] + d[1] + d[2]
+    mu2 = 0.5 * mu1 * mu1 - 0.5 * (d[0] ** 2 + d[1] ** 2 + d[2] ** 2) - (d[3] ** 2 + d[4] ** 2 + d[5] ** 2)
+    mu3 = d[0] * d[1] * d[2] + 2 * d[3] * d[4] * d[5] - d[0] * d[5] ** 2 - d[1] * d[4] ** 2 - d[2] * d[3] ** 2
+    amp = max(np.max(np.abs(v)) for v in d)
+    for gi, wi, p in ((got[0], mu1, 1), (got[1], mu2, 2), (got[2], mu3, 3)):
+        assert np.max(np.abs(gi - wi)) <= 8 * tol(4, n) * amp ** p, (n, p)
 
 
 @pytest.mark.parametrize("n", [16, 64, 256, 1024])

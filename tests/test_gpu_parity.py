@@ -397,6 +397,34 @@ def test_properties_on_the_box_of_the_metric(api):
         assert f.sweep(radii[1:]) == pytest.approx(4.0 * tv[1:], rel=1e-12)
 
 
+@pytest.mark.parametrize("n", [16, 64, 256])
+def test_invariant_zpass_equals_six_component_path_fp32_fields(api, n, monkeypatch):
+    """the same with fp32 fields: the invariants are formed in fp64 from the fp32 components the transforms produce, exactly
+    as the six-component solve forms them, and kept as fp64 rows of their own; the 3LPT(b) contraction inside the z-pass
+    likewise (PF_LPT_FUSE).  Every product bit for bit."""
+    dk = synth.make_density(n, seed=5 + n)
+    dk[0, 0, 0] = -0.11 * n ** 3
+    x, y = synth.invgrow_table("lcdm")
+    radii = np.array([n / 16.0, n / 40.0, 1.5, 0.6, 0.0])
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PF_INVARIANTS", mode)
+        monkeypatch.setenv("PF_LPT_FUSE", mode)
+        with api.Fmax(n, field_bytes=4, timing=True) as f:
+            f.set_density(dk)
+            f.set_invgrow(x, y)
+            f.set_growth(synth.growth_multipliers())
+            f.reset_kernel_stats()
+            tv = f.compute_fmax(radii, do_lpt=True)
+            classes = {k["name"] for k in f.kernel_stats()}
+            assert ("zpass_c2r_hess_6to3inv" in classes) == (mode == "1") and ("zpass_c2r_hess_6_lpt3b" in classes) == (mode == "1"), classes
+            out[mode] = (tv, f.products(), f.Fmax_PDF())
+    assert np.array_equal(out["0"][0], out["1"][0])
+    for name in ("Fmax", "Rmax", "Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+        assert np.array_equal(out["0"][1][name], out["1"][1][name]), name
+    assert np.array_equal(out["0"][2], out["1"][2])
+
+
 @pytest.mark.parametrize("n", [16, 64, 128, 256])
 def test_invariant_zpass_equals_six_component_path(api, n, monkeypatch):
     """Default sweep: for every radius but the last the z-pass stores the three invariants of the tensor (k_c2r_invariants)
