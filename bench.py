@@ -63,7 +63,7 @@ def symbol_of(cls: str, n: int, fb: int, fast: bool = True) -> str:
         return f"k_strided<{F}, {n}, {t}, -1>"
     if cls in ("zpass_c2r_hess_6", "zpass_c2r_disp_3", "zpass_c2r_plain"):
         return f"k_c2r_persistent<{F}, {n}, {tl}>"
-    return {"zpass_c2r_hess_6to3inv": f"k_c2r_invariants<{n}, 0>", "zpass_c2r_hess_6_lpt3b": f"k_c2r_invariants<{n}, 1>",
+    return {"zpass_c2r_hess_6to3inv": f"k_c2r_invariants<{F}, {n}, 0>", "zpass_c2r_hess_6_lpt3b": f"k_c2r_invariants<{F}, {n}, 1>",
             "collapse": f"k_collapse<{F}, {b}, float>", "collapse_inv": f"k_collapse_inv<{b}, float>", "lpt_sources": f"k_lpt_sources<{F}>",
             "collapse_lpt_sources": f"k_collapse_src<{F}, {b}, float>",      # last argument: PRODFLOAT of the build
             "lpt_accum": f"k_lpt_accum<{F}>", "zpass_r2c": f"k_r2c<{F}, {n}, {tl}>"}.get(cls, cls)
