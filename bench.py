@@ -53,7 +53,7 @@ def alg_bytes_per_cell(ns: int, w: int, lpt: bool) -> float:
 def symbol_of(cls: str, n: int, fb: int, fast: bool = True) -> str:
     """kernel function behind a launch class, spelled as rocprofv3 prints it (csrc/pf_fft_kernels.hip dispatch tables)"""
     F = "double" if fb == 8 else "float"
-    t = max(1, min(128 // (2 * fb), (64 * 1024) // (n * 2 * fb), 8192 // n))      # PfTileCols
+    t = max(1, min(128 // (2 * fb), (128 * 1024) // (n * 2 * fb), 8192 // n))     # PfTileCols (128 KB of LDS per tile)
     nt = n // 16
     tl = 1 if nt >= 256 else 256 // nt
     b = "true" if fast else "false"

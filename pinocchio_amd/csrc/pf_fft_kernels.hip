@@ -441,8 +441,13 @@ int pf_launch_exp_table(double *etab, int n, double rs, hipStream_t st) {
 
 // columns per workgroup of the strided passes: 128-byte row segments where LDS allows
 template <typename F, int N> struct PfTileCols {
+// LDS of one tile.  128 KB: eight fp64 columns of a 1024-point line -- every row segment a tile reads or writes is a whole
+// 128-byte line -- in one 1024-thread workgroup per CU (the same sixteen waves as two 64 KB workgroups).  Against 64 KB
+// (four columns, 64-byte segments) at 1024^3, four interleaved runs each on one box: x-pass 6.41 -> 5.69 ms, y-pass
+// 12.21 -> 11.31 ms per Hessian launch, 860 (854..863) -> 832 (831..833) ms per step, and the process-to-process spread of
+// the half-line layout is gone.  (Round 1 saw no gain from it with the x-major intermediate and without the tile prefetch.)
 #ifndef PF_TILE_LDS_KB
-#define PF_TILE_LDS_KB 64
+#define PF_TILE_LDS_KB 128
 #endif
   static constexpr int lds_budget = PF_TILE_LDS_KB * 1024;
   static constexpr int t0 = 128 / (2 * (int)sizeof(F));  // 8 (fp64) or 16 (fp32)
