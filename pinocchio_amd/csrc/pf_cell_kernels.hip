@@ -95,8 +95,13 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
     if (col >= p.n) { col -= p.n; row++; }
     const long long a = (long long)row * p.pitch + col;
     double d[6];
+#if PF_NT  // (read once per radius: streaming loads, pf_fft_core.h)
+    d[0] = (double)__builtin_nontemporal_load(&h0[a]); d[1] = (double)__builtin_nontemporal_load(&h1[a]); d[2] = (double)__builtin_nontemporal_load(&h2[a]);
+    if (!INV) { d[3] = (double)__builtin_nontemporal_load(&h3[a]); d[4] = (double)__builtin_nontemporal_load(&h4[a]); d[5] = (double)__builtin_nontemporal_load(&h5[a]); }
+#else
     d[0] = (double)h0[a]; d[1] = (double)h1[a]; d[2] = (double)h2[a];
     if (!INV) { d[3] = (double)h3[a]; d[4] = (double)h4[a]; d[5] = (double)h5[a]; }
+#endif
     // products[].Fmax is float, compared after promotion (quirk Q2); init -10 / -1 at ismooth 0.  Loaded here, with the
     // Hessian, so that its latency hides under the solve instead of sitting between the solve and the store.
     PR *__restrict__ fmax = (PR *)p.fmax;

@@ -37,11 +37,17 @@ template <int DIR, typename F> PF_HD pfc<F> pf_mul_i(pfc<F> a) {
   return DIR > 0 ? pf_mk<F>(-a.y, a.x) : pf_mk<F>(a.y, -a.x);
 }
 
-// streaming (non-temporal) access to once-touched field data; -DPF_NT selects it (experiment)
+// streaming (non-temporal) access to once-touched field data.  On since the strided passes move whole 128-byte lines (128 KB tiles):
+// three interleaved runs each on one box, x-pass 5.96 -> 5.45, y-pass 11.26 -> 10.85, z-passes -0.2..-0.4 ms per launch, 827.6 (826..830) ->
+// 808.2 (805..811) ms per step.  With 64-byte segments it cost the y-pass 13 % (round 1): half lines no longer merged in L2.
+// -DPF_NT=0 builds the plain accesses.
+#ifndef PF_NT
+#define PF_NT 1
+#endif
 #if defined(__HIPCC__)
 template <typename F> struct pf_vec2 { typedef F type __attribute__((ext_vector_type(2))); };
 template <typename F> __device__ __forceinline__ pfc<F> pf_ld_stream(const pfc<F> *p) {
-#ifdef PF_NT
+#if PF_NT
   const typename pf_vec2<F>::type v = __builtin_nontemporal_load(reinterpret_cast<const typename pf_vec2<F>::type *>(p));
   return pf_mk<F>(v.x, v.y);
 #else
@@ -49,7 +55,7 @@ template <typename F> __device__ __forceinline__ pfc<F> pf_ld_stream(const pfc<F
 #endif
 }
 template <typename F> __device__ __forceinline__ void pf_st_stream(pfc<F> *p, pfc<F> v) {
-#ifdef PF_NT
+#if PF_NT
   typename pf_vec2<F>::type t;
   t.x = v.x; t.y = v.y;
   __builtin_nontemporal_store(t, reinterpret_cast<typename pf_vec2<F>::type *>(p));

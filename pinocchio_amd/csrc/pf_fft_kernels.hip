@@ -366,9 +366,18 @@ __global__ void __launch_bounds__(6 * (N / 16)) k_c2r_invariants(const PfC2RPara
         // will use mu1/3 three times.  The same unless the tensor is exactly that; otherwise the sweep is repeated (pf_sweep)
         if (pf_invariants_lose_diagonal(da, a1, a2) || pf_invariants_lose_diagonal(db, b1, b2)) *p.flag = 1.0;
         const long long ao = IN_PLACE ? a : R * p.inv_pitch + c;
+#if PF_NT  // (written once, read once by the solve: streaming stores, pf_fft_core.h)
+        typedef double pf_d2 __attribute__((ext_vector_type(2)));
+        pf_d2 w1, w2, w3;
+        w1.x = a1; w1.y = b1; w2.x = a2; w2.y = b2; w3.x = a3; w3.y = b3;
+        __builtin_nontemporal_store(w1, reinterpret_cast<pf_d2 *>(o1 + ao));
+        __builtin_nontemporal_store(w2, reinterpret_cast<pf_d2 *>(o2 + ao));
+        __builtin_nontemporal_store(w3, reinterpret_cast<pf_d2 *>(o3 + ao));
+#else
         *reinterpret_cast<double2 *>(o1 + ao) = make_double2(a1, b1);
         *reinterpret_cast<double2 *>(o2 + ao) = make_double2(a2, b2);
         *reinterpret_cast<double2 *>(o3 + ao) = make_double2(a3, b3);
+#endif
       } else {
         double ha[6], hb[6];
 #pragma unroll
