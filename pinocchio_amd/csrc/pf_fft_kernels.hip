@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(TL *(N / 16)) k_c2r_persistent(const PfC2RPara
         float2 *o = reinterpret_cast<float2 *>(reinterpret_cast<float *>(p.job[job].out) + row * (long long)N);
 #pragma unroll
         for (int m = 0; m < 8; m++)
-          o[tlj + m * NT] = make_float2((float)pf_norm_dc(v[m].x, norm, dcv), (float)pf_norm_dc(v[m].y, norm, dcv));
+          pf_st_stream(reinterpret_cast<pfc<float> *>(&o[tlj + m * NT]), pf_mk<float>((float)pf_norm_dc(v[m].x, norm, dcv), (float)pf_norm_dc(v[m].y, norm, dcv)));
       } else {
         C *o = reinterpret_cast<C *>(reinterpret_cast<F *>(p.job[job].out) + row * (p.job[job].out_f32 == 2 ? (long long)N : p.out_pitch));
 #pragma unroll
@@ -415,7 +415,7 @@ __global__ void __launch_bounds__(TL *(N / 16)) k_r2c(const PfR2CParams p) {
   {
     const C *in = reinterpret_cast<const C *>(reinterpret_cast<const F *>(p.in) + row * p.in_pitch);
 #pragma unroll
-    for (int m = 0; m < 8; m++) v[m] = valid ? in[tl + m * NT] : pf_mk<F>(0, 0);
+    for (int m = 0; m < 8; m++) v[m] = valid ? pf_ld_stream(&in[tl + m * NT]) : pf_mk<F>(0, 0);
   }
   PfStages<F, M, -1, 2>::run(
       v, tl, tw, [&](int pos, C val) { L[pf_lpad(pos)] = val; }, [&](int pos) { return L[pf_lpad(pos)]; });
@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(TL *(N / 16)) k_r2c(const PfR2CParams p) {
     for (int m = 0; m < 8; m++) {
       const int k = tl + m * NT;
       const C zk = v[m], zmk = L[pf_lpad((M - k) & (M - 1))];
-      out[k] = pf_r2c_post<F>(zk, zmk, tw[k]);
+      pf_st_stream(&out[k], pf_r2c_post<F>(zk, zmk, tw[k]));
       if (k == 0) out[M] = pf_mk<F>(zk.x - zk.y, (F)0);
     }
   }
