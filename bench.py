@@ -3,6 +3,7 @@
 displacement build (BASELINE.json metric), on N MI355X of one node.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus 8 --steps 3 --warmup 1        (starts its own eight ranks: launch_ranks below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 3 --warmup 1
 
@@ -39,7 +40,8 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-from pinocchio_amd import _lib, api, synth  # noqa: E402
+# pinocchio_amd is imported inside the functions that run on a rank: the parent of a self-launched multi-GPU run
+# (launch_ranks) must neither load the HIP library nor touch the GPU.
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 PROFILE_ROUND = "r02"
@@ -70,7 +72,8 @@ def symbol_of(cls: str, n: int, fb: int, fast: bool = True) -> str:
 
 
 def committed_counters(kind: str, n: int, fb: int):
-    """profiles/r02_pmc_<kind>.json if it was measured on the kernel sources loaded now, else None"""
+    """profiles/<round>_pmc_<kind>.json if it was measured on the kernel sources loaded now, else None"""
+    from pinocchio_amd import _lib
     try:
         with open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_{kind}.json")) as fh:
             d = json.load(fh)
@@ -89,6 +92,7 @@ def cpu_baseline(n: int, ns: int, lpt: bool, ns_sample: int = 2) -> dict:
     whole displacement part; the sweep time is scaled by ns / ns_sample."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
+    from pinocchio_amd import synth
     cores = os.cpu_count() or 1
     threads = max(1, min(cores, n // 2))  # all hardware threads; the slab loops have n iterations
     dk = synth.philox_density(n, synth.SEED, 2.5, -2.0)
@@ -112,7 +116,7 @@ def cpu_baseline(n: int, ns: int, lpt: bool, ns_sample: int = 2) -> dict:
                       f"-> {t_full:.1f} s for the full job; same synthetic spectrum; host has {cores} hardware threads, {threads} used"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -124,17 +128,169 @@ def main():
     ap.add_argument("--cpu-n", type=int, default=512, help="grid side of the CPU-baseline sample (0: skip)")
     ap.add_argument("--exact-steps", type=int, default=1, help="steps of the PF_EXACT_LIBM=1 informational run (0: skip)")
     ap.add_argument("--exchange", default="rccl", choices=("rccl", "torch"))
-    args = ap.parse_args()
+    ap.add_argument("--replicate", default="both", choices=("auto", "0", "1", "both"),
+                    help="(N > 1) delta(k) kept whole on every rank (1), exchanged for every transform (0), the library's choice by rank "
+                         "count (auto), or -- at 2 and 4 ranks -- the library's choice timed as the line plus the other mode timed "
+                         "beside it in exchange.alternative (both, the default: one run decides DESIGN.md section 5's model)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launcher check: every rank prints its RANK / LOCAL_RANK / WORLD_SIZE as a JSON line and exits; nothing touches a GPU")
+    return ap.parse_args(argv)
 
+
+def gpu_untouched() -> bool:
+    """True while this process has neither loaded the HIP library nor imported torch"""
+    lib_mod = sys.modules.get("pinocchio_amd._lib")
+    return "torch" not in sys.modules and (lib_mod is None or lib_mod._lib is None)
+
+
+def launch_ranks(args, argv) -> int:
+    """`python bench.py --gpus N` invoked bare: start the N ranks as FRESH child processes through torch.distributed.run and
+    relay rank 0's line.  This parent never initialises the GPU (no torch import, no library load) and nothing is exec'ed
+    from a process that has: the children are ordinary subprocesses, the parent returns their exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["PF_BENCH_LAUNCHED_BY"] = str(os.getpid())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print(f"[bench] --gpus {args.gpus} without WORLD_SIZE: starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    lines = 0
+    for line in proc.stdout:          # JSON lines of the ranks go to stdout as they come; the ranks' stderr is inherited
+        if line.lstrip().startswith("{"):
+            sys.stdout.write(line)
+            sys.stdout.flush()
+            lines += 1
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if args.dry_launch:
+        print(json.dumps({"dry_launch": True, "role": "parent", "children_rc": rc, "json_lines_relayed": lines,
+                          "parent_gpu_untouched": gpu_untouched(), "command": cmd}), flush=True)
+    if rc == 0 and lines == 0:
+        print("[bench] the ranks exited 0 without printing a line", file=sys.stderr, flush=True)
+        return 4
+    return rc
+
+
+def run_config(args, rank, world, device, dist, torch, replicate_env, votes_out):
+    """One timed configuration on this rank: context, exchange, warm-up, exactly `steps` timed steps between fences.
+    replicate_env: None (the library's choice) or "0" / "1" for PF_REPLICATE_DK, read by pf_create.
+    -> dict of what rank 0 prints (every rank returns its own; only rank 0's is used)"""
+    from pinocchio_amd import api, synth
+    n, ns, lpt = args.n, args.ns, not args.no_lpt
+    if replicate_env is None:
+        os.environ.pop("PF_REPLICATE_DK", None)
+    else:
+        os.environ["PF_REPLICATE_DK"] = replicate_env
+    f = api.Fmax(n, rank=rank, nranks=world, device=device, field_bytes=args.field_bytes, timing=True)
+    keep = None
+    res = {"exchange_kind": None}
+    try:
+        if world > 1:
+            from pinocchio_amd import dist as pfdist
+            # built-in RCCL exchange first; if some rank cannot bind it, set it up or pass its self-test, the same collectives go
+            # through torch.distributed (also RCCL) on tensors aliasing the library's buffers.  Collective and vote-guarded: no
+            # rank is left inside a communicator set-up (pinocchio_amd/dist.py).  A failure here exits non-zero; nothing re-execs.
+            votes = []
+            res["exchange_kind"], keep = pfdist.negotiate_exchange(f, dist, torch, preferred=args.exchange, device="cuda", votes=votes)
+            votes_out[:] = votes
+            # how many ranks the communicator that moves the data really has: ncclCommCount for the built-in kind, the
+            # process group's size for the torch kind
+            rc_count = int(f.L.pf_rccl_comm_count(f.h))
+            res["ranks_in_communicator"] = rc_count if res["exchange_kind"] == "rccl" else int(dist.get_world_size())
+            rep = int(f.L.pf_replicated_spectrum(f.h))
+            if rep < 0:
+                raise RuntimeError("pf_replicated_spectrum failed")
+            res["replicated_spectrum"] = rep == 1
+            if rank == 0:
+                print(f"[bench] {world} ranks ({res['ranks_in_communicator']} in the communicator), all-to-all via '{res['exchange_kind']}', "
+                      f"delta(k) {'replicated' if rep else 'distributed'}", file=sys.stderr, flush=True)
+
+        f.synth_density(synth.SEED, 2.5, -2.0)
+        x, y = synth.invgrow_table("lcdm")
+        f.set_invgrow(x, y)
+        f.set_growth(synth.growth_multipliers())
+        radii = synth.radii_ladder(ns)
+
+        def step(ctx):
+            return ctx.compute_fmax(radii, do_lpt=lpt)   # the sweep, then compute_displacements(1, 0) as src/fmax.c:36-190
+
+        def fence(ctx):
+            ctx.synchronize()
+            if world > 1:
+                torch.cuda.synchronize()
+                dist.barrier()
+                torch.cuda.synchronize()
+
+        tv = None
+        for _ in range(args.warmup):
+            tv = step(f)
+        f.reset_kernel_stats()
+        f.reset_cputime()
+        fence(f)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            tv = step(f)
+        fence(f)
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        res.update(dt=dt, stats=f.kernel_stats(), cput=f.cputime(), device_gb=f.device_bytes / 1e9,
+                   reruns=int(f.L.pf_debug_invariant_reruns(f.h)), sigma_R0=float(np.sqrt(tv[-1])), step=step)
+    finally:
+        if keep is not None:
+            try:
+                keep.release()
+            except Exception:  # noqa: BLE001
+                pass
+        f.close()
+        del keep
+    return res
+
+
+def exchange_report(res, args):
+    ex = [s for s in res["stats"] if s["name"] == "exchange"]
+    kern = [s for s in res["stats"] if s["name"] != "exchange"]
+    e = ex[0] if ex else {"launches": 0, "total_ms": 0.0, "alg_bytes": 0.0}
+    return {"kind": res["exchange_kind"], "replicated_spectrum": res["replicated_spectrum"],
+            "ranks_in_communicator": res["ranks_in_communicator"],
+            "ms_per_step": 1e3 * res["dt"] / args.steps,
+            "calls_per_step": e["launches"] / args.steps, "GB_per_step_per_rank": e["alg_bytes"] / args.steps / 1e9,
+            "ms_per_step_on_comm_stream": e["total_ms"] / args.steps,
+            "GBps_per_rank": e["alg_bytes"] / max(e["total_ms"], 1e-9) / 1e6,
+            "compute_ms_per_step": sum(s["total_ms"] for s in kern) / args.steps}
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world_env = os.environ.get("WORLD_SIZE")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world_env is None:
+        raise SystemExit(launch_ranks(args, argv))
+    world = int(world_env or "1")
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, or unset WORLD_SIZE")
+    if args.dry_launch:
+        print(json.dumps({"dry_launch": True, "role": "rank", "rank": rank, "local_rank": local_rank, "world": world,
+                          "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}",
+                          "launched_by_bench": os.environ.get("PF_BENCH_LAUNCHED_BY") is not None,
+                          "gpu_untouched": gpu_untouched()}), flush=True)
+        return
+    from pinocchio_amd import _lib, api, synth
     lpt = not args.no_lpt
     n, ns = args.n, args.ns
 
     dist = torch = None
+    devices = None
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -146,64 +302,32 @@ def main():
         device = local_rank % ndev
         torch.cuda.set_device(device)
         dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        # which physical device each rank drives (N distinct ones, or the line says so)
+        props = torch.cuda.get_device_properties(device)
+        ident = str(getattr(props, "uuid", "")) or f"{getattr(props, 'pci_bus_id', device)}"
+        devices = [None] * world
+        dist.all_gather_object(devices, f"{os.uname().nodename}:{ident}")
     else:
         device = 0
 
-    f = api.Fmax(n, rank=rank, nranks=world, device=device, field_bytes=args.field_bytes, timing=True)
-    keep = None
-    exchange_kind = None
-    if world > 1:
-        from pinocchio_amd import dist as pfdist
-        # built-in RCCL exchange first; if some rank cannot bind it, set it up or pass its self-test, the same collectives go
-        # through torch.distributed (also RCCL) on tensors aliasing the library's buffers.  Collective and vote-guarded: no
-        # rank is left inside a communicator set-up (pinocchio_amd/dist.py).  A failure here exits non-zero; nothing re-execs.
-        try:
-            exchange_kind, keep = pfdist.negotiate_exchange(f, dist, torch, preferred=args.exchange, device="cuda")
-        except RuntimeError as e:
-            print(f"[rank {rank}] {e}", file=sys.stderr, flush=True)
-            f.close()
-            dist.destroy_process_group()
-            raise SystemExit(3)
-        if rank == 0:
-            print(f"[bench] {world} ranks, all-to-all via '{exchange_kind}'", file=sys.stderr, flush=True)
-
-    f.synth_density(synth.SEED, 2.5, -2.0)
-    x, y = synth.invgrow_table("lcdm")
-    f.set_invgrow(x, y)
-    f.set_growth(synth.growth_multipliers())
-    radii = synth.radii_ladder(ns)
-
-    def step(ctx):
-        return ctx.compute_fmax(radii, do_lpt=lpt)   # the sweep, then compute_displacements(1, 0) as src/fmax.c:36-190
-
-    def fence(ctx):
-        ctx.synchronize()
+    votes = []
+    modes = [None if args.replicate in ("auto", "both") else args.replicate]
+    try:
+        res = run_config(args, rank, world, device, dist, torch, modes[0], votes)
+        alt = None
+        if world in (2, 4) and args.replicate == "both":
+            # the other way of feeding the x-pass, same steps, same fences: the line is the library's
+            # default, the alternative is reported beside it
+            other = "0" if res["replicated_spectrum"] else "1"
+            alt = run_config(args, rank, world, device, dist, torch, other, [])
+            os.environ.pop("PF_REPLICATE_DK", None)
+    except (RuntimeError, api.PinfmaxError) as e:
+        print(f"[rank {rank}] {e}", file=sys.stderr, flush=True)
         if world > 1:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    tv = None
-    for _ in range(args.warmup):
-        tv = step(f)
-    f.reset_kernel_stats()
-    f.reset_cputime()
-    fence(f)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tv = step(f)
-    fence(f)
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    stats = f.kernel_stats()
-    cput = f.cputime()
-    device_gb = f.device_bytes / 1e9
-    reruns = f.L.pf_debug_invariant_reruns(f.h)
-    f.close()
-    del keep
+            dist.destroy_process_group()
+        raise SystemExit(3)
+    dt, stats, cput, device_gb, reruns, step = res["dt"], res["stats"], res["cput"], res["device_gb"], res["reruns"], res["step"]
+    exchange_kind = res["exchange_kind"]
 
     exact = None
     if world == 1 and args.exact_steps > 0:
@@ -213,6 +337,7 @@ def main():
         try:
             with api.Fmax(n, field_bytes=args.field_bytes) as fx:
                 fx.synth_density(synth.SEED, 2.5, -2.0)
+                x, y = synth.invgrow_table("lcdm")
                 fx.set_invgrow(x, y)
                 fx.set_growth(synth.growth_multipliers())
                 step(fx)
@@ -259,49 +384,61 @@ def main():
             if pmc and r["kernel"] in pmc["kernels"]:
                 k = pmc["kernels"][r["kernel"]]
                 r["traffic"] = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
-                r["traffic_source"] = f"profiles/{PROFILE_ROUND}_pmc_traffic.json"
+                r["traffic_source"] = f"profiles/{PROFILE_ROUND}_pmc_traffic.json (counter passes of this command on these kernel sources, not of this process)"
         pv = committed_counters("valu", n, w)
         if pv and roofline_cls["kernel"] in pv["kernels"]:
             roofline_cls["valu"] = dict(pv["kernels"][roofline_cls["kernel"]], source=f"profiles/{PROFILE_ROUND}_pmc_valu.json")
         if dom_cls["name"].startswith("collapse"):
             roofline_cls["note"] = "the collapse solve is fp64-VALU bound; its HBM stream is a consequence, see DESIGN.md section 6"
         design_bytes = sum(s["alg_bytes"] for s in kern) / args.steps
+        n_gpus = world
         out = {
             "metric": "grid-cells/sec for full Fmax sweep (all smoothing radii) + 3LPT, 1024^3 box"
                       if (n == 1024 and lpt) else f"grid-cells/sec, Fmax sweep{' + 3LPT' if lpt else ''}, {n}^3 box",
-            "value": value, "unit": "grid-cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "grid-cells/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64" if w == 8 else "f32 fields / f64 collapse", "data": "synthetic",
             "config": {"workload": f"{n}^3 box, {ns} smoothing radii, Fmax sweep{' + 2LPT/3LPT displacements' if lpt else ' only'}, "
                                    f"{'fp64' if w == 8 else 'fp32-field'} path, Philox white noise with P(k)~k^-2, sigma(R=0)=2.5",
                        "grid": n, "nsmooth": ns, "lpt": lpt, "parallelism": f"x-slabs over {world} GPU(s)" + (f", all-to-all via {exchange_kind}" if exchange_kind else ""),
-                       "device_GB": device_gb, "sigma_R0": float(np.sqrt(tv[-1])), "kernel_source_sha": _lib.source_sha(),
+                       "device_GB": device_gb, "sigma_R0": res["sigma_R0"], "kernel_source_sha": _lib.source_sha(),
                        "invariant_reruns": reruns},
             "roofline": roofline,
             "roofline_by_class": roofline_cls,
-            "path_roofline": {"contract_bytes_per_cell": alg_bytes_per_cell(ns, w, lpt),
-                              "frac_of_hbm_peak_contract": alg_bytes_per_cell(ns, w, lpt) * cells / (ms * 1e-3) / world / (HBM_PEAK_GBS * 1e9),
-                              "design_bytes_per_step_per_gpu": design_bytes,
+            "path_roofline": {"design_bytes_per_step_per_gpu": design_bytes,
                               "design_bytes_per_cell": design_bytes * world / cells,
                               "frac_of_hbm_peak_design": design_bytes / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9),
-                              "note": "contract: the survey's 6600 B per cell for the reference's structure; design: the bytes the shared-pass kernels really move (sum of the per-launch algorithmic bytes)"},
+                              "contract_bytes_per_cell": alg_bytes_per_cell(ns, w, lpt),
+                              "note": "design: the bytes the shared-pass kernels really move (sum of the per-launch algorithmic bytes) over the whole "
+                                      "step -- the whole-path roofline fraction; contract_bytes_per_cell is the survey's figure for the reference's "
+                                      "unshared structure, quoted for comparison only (no fraction is formed from it: this design never moves those bytes)"},
             "kernels": [{"name": s["name"], "symbol": s["symbol"], "launches": s["launches"], "ms_per_step": s["total_ms"] / args.steps,
                          "GBps": s["alg_bytes"] / max(s["total_ms"], 1e-9) / 1e6} for s in kern],
             "phases_s_per_step": {k: v / args.steps for k, v in cput.items()},
         }
-        ex = [s for s in stats if s["name"] == "exchange"]
         if world > 1:
-            e = ex[0] if ex else {"launches": 0, "total_ms": 0.0, "alg_bytes": 0.0}
-            out["exchange"] = {"kind": exchange_kind, "replicated_spectrum": bool(f.L.pf_replicated_spectrum(f.h)), "calls_per_step": e["launches"] / args.steps, "GB_per_step_per_rank": e["alg_bytes"] / args.steps / 1e9,
-                               "ms_per_step_on_comm_stream": e["total_ms"] / args.steps,
-                               "GBps_per_rank": e["alg_bytes"] / max(e["total_ms"], 1e-9) / 1e6,
-                               "compute_ms_per_step": sum(s["total_ms"] for s in kern) / args.steps,
-                               "note": "rank 0's HIP events around its all-to-alls on the communication stream; they run beside the compute stream (DESIGN.md section 5): step time well below compute + exchange means the overlap works.  replicated_spectrum (2-4 ranks by default): every rank keeps the whole delta(k), the sweep exchanges nothing and only the LPT sources transpose"}
+            ex = exchange_report(res, args)
+            ex["process_group_size"] = int(dist.get_world_size())
+            ex["kind_votes"] = votes
+            ex["devices"] = devices
+            ex["distinct_devices"] = len(set(devices))
+            # n_gpus is what the communicator and the device census say, not what the command line asked for
+            out["n_gpus"] = min(ex["ranks_in_communicator"], ex["distinct_devices"])
+            if out["n_gpus"] != world:
+                ex["warning"] = f"--gpus {world} but {ex['ranks_in_communicator']} ranks in the communicator on {ex['distinct_devices']} distinct devices"
+            ex["note"] = ("rank 0's HIP events around its all-to-alls on the communication stream; they run beside the compute stream (DESIGN.md "
+                          "section 5): step time well below compute + exchange means the overlap works.  replicated_spectrum (2-4 ranks by "
+                          "default): every rank keeps the whole delta(k), the sweep exchanges nothing and only the LPT sources transpose")
+            if alt is not None:
+                ex["alternative"] = exchange_report(alt, args)
+                ex["alternative"]["value"] = cells * args.steps / alt["dt"]
+                print("[bench] alternative: " + json.dumps(ex["alternative"]), file=sys.stderr, flush=True)
+            out["exchange"] = ex
         if exact:
             out["exact_libm"] = exact
         if world == 1 and args.cpu_n:
             out["cpu_baseline"] = cpu_baseline(args.cpu_n, ns, lpt)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -95,6 +95,9 @@ int pf_rccl_available(void);                        /* 1 when librccl can be bou
 int pf_rccl_unique_id(void *id128);                 /* rank 0: ncclGetUniqueId */
 int pf_init_rccl(pf_ctx *ctx, const void *id128);   /* all ranks: ncclCommInitRank; the context owns the communicator */
 int pf_release_rccl(pf_ctx *ctx);                   /* ncclCommDestroy + callbacks cleared (also done by pf_destroy) */
+int pf_rccl_comm_count(pf_ctx *ctx);                /* ncclCommCount of the built-in exchange's communicator: the number of ranks
+                                                       RCCL itself sees (the MPI_Comm_size of FFT_Comm, src/initialization.c:1317);
+                                                       0 when the built-in exchange is not installed, -1 on error */
 /* small reductions (MPI_Reduce/MPI_Bcast at src/collapse_times.c:656-667,
    src/fmax.c:527): sum `count` doubles / uint64 in place over all ranks */
 typedef int (*pf_allreduce_fn)(void *user, void *buf, size_t count, int is_u64, void *stream);

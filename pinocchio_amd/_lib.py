@@ -61,6 +61,7 @@ PROTOTYPES = {
     "pf_set_exchange_rows": (C.c_int, [_vp, ALLTOALLV_FN, _vp]),
     "pf_rccl_available": (C.c_int, []),
     "pf_release_rccl": (C.c_int, [_vp]),
+    "pf_rccl_comm_count": (C.c_int, [_vp]),
     "pf_rccl_unique_id": (C.c_int, [_vp]),
     "pf_init_rccl": (C.c_int, [_vp, _vp]),
     "pf_set_allreduce": (C.c_int, [_vp, ALLREDUCE_FN, _vp]),

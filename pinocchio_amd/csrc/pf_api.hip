@@ -30,6 +30,7 @@
 #include "pf_internal.h"
 
 extern "C" void pf_rccl_release(void *link);  // pf_rccl.cpp
+extern "C" int pf_rccl_link_count(void *link);
 
 // ------------------------------------------------------------------ errors --
 static thread_local char g_err[512] = "";
@@ -1153,7 +1154,12 @@ static int collapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], hipStream_
       return pf_fail(c->rank, "collapse-time table not built (pf_ct_build / pf_ct_load)");
     p.tabulated = 1; p.ct = c->ct; p.ct.flavour = c->ct_flavour;
   }
-  size_t nb = (ncell(c) + 255) / 256; if (nb > (size_t)c->collapse_blocks) nb = c->collapse_blocks;
+  sources = sources && c->lpt_order >= 2 && !invariants && !c->tab_ns && !p.sng;
+  // (with the sources formed in passing the grid is k_lpt_sources' own -- clamped to PF_NBLK, whatever PF_COLLAPSE_WG_PER_CU or
+  //  the CU count say -- so that the partial sums of S2 are added in the same order as by pf_displacements(1, 0) on its own)
+  size_t nb = (ncell(c) + 255) / 256;
+  const size_t cap = sources ? (size_t)PF_NBLK : (size_t)c->collapse_blocks;
+  if (nb > cap) nb = cap;
   p.nblocks = (int)nb;
   if (invariants) p.invariants = 1;
   int solve_fb = c->fb;
@@ -1161,7 +1167,6 @@ static int collapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], hipStream_
     for (int k = 0; k < 3; k++) p.h[k] = c->INV[k];
     p.pitch = c->n; solve_fb = 8;
   }
-  sources = sources && c->lpt_order >= 2 && !invariants && !p.tabulated && !p.sng;
   if (sources) {  // K7 in the same pass (the grid is k_lpt_sources' own: identical partial sums of S2)
     p.sources = 1; p.src[0] = c->S[0]; p.src[1] = c->S[1]; p.src[2] = c->S[2]; p.src_partials = c->partials_src;
     c->have_sources = false;  // S now holds real-space sources, not the resident LPT spectra
@@ -1790,6 +1795,10 @@ extern "C" int pf_release_rccl(pf_ctx *c) {
     c->a2a = nullptr; c->a2av = nullptr; c->ared = nullptr; c->a2a_user = c->a2av_user = c->ared_user = nullptr;
   }
   return 0;
+}
+extern "C" int pf_rccl_comm_count(pf_ctx *c) {
+  if (!c) return -1;
+  return c->rccl ? pf_rccl_link_count(c->rccl) : 0;
 }
 extern "C" int pf_ctx_rank_size(pf_ctx *c, int *rank, int *nranks) {
   if (!c) return 1;

@@ -14,6 +14,9 @@
 //
 // A strided launch carries several (input, multiplier, output) jobs grouped by
 // input: a workgroup reads its tile once and transforms it for every job on it.
+#include <atomic>
+#include <cstdio>
+
 #include "pf_internal.h"
 #include "pf_fft_core.h"
 
@@ -475,9 +478,18 @@ static int launch_strided_n(const PfStridedParams &p, hipStream_t st) {
   dim3 grid((unsigned)(((nwork + 7) >> 3) << 3), 1, 1), block(T * N / 8, 1, 1);
   const size_t shm = (size_t)N * T * sizeof(pfc<F>);
   if (shm > 64 * 1024) {
-    static bool raised[PF_MAX_DEVICES] = {};  // per instantiation and device
+    // LDS beyond 64 KB is opt-in per kernel function and device.  The flag is set only once the runtime has accepted the
+    // size (a refusal is reported: code 3 = "dynamic LDS opt-in refused", not a bare launch failure later on) and is atomic:
+    // several host threads launch the same instantiation (virtual ranks, tests).
+    static std::atomic<bool> raised[PF_MAX_DEVICES];  // per instantiation and device
     const int d = p.dev >= 0 && p.dev < PF_MAX_DEVICES ? p.dev : 0;
-    if (!raised[d]) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_strided<F, N, T, DIR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); raised[d] = true; }
+    if (!raised[d].load(std::memory_order_acquire)) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_strided<F, N, T, DIR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) {
+        fprintf(stderr, "ERROR on task 0: hipFuncSetAttribute(MaxDynamicSharedMemorySize = %zu) refused for the %d-point strided pass on device %d\n", shm, N, d);
+        return 3;
+      }
+      raised[d].store(true, std::memory_order_release);
+    }
   }
   hipLaunchKernelGGL((k_strided<F, N, T, DIR>), grid, block, shm, st, p, nwork, ntiles);
   return hipGetLastError() == hipSuccess ? 0 : 1;

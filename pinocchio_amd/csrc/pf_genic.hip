@@ -284,24 +284,25 @@ int pf_genic_launch(int fb, void *dk, int n, int nzp, int nyl, int y0, const pf_
   std::vector<unsigned int> seed;
   seed_plane(n, p->RandomSeed, seed);
   unsigned int *dseed = nullptr;
+  double *dpk = nullptr;
+  auto fail = [&]() { if (dseed) hipFree(dseed); if (dpk) hipFree(dpk); return 1; };  // nothing allocated here outlives an error
   if (hipMalloc(&dseed, seed.size() * sizeof(unsigned int)) != hipSuccess) return 1;
-  if (hipMemcpyAsync(dseed, seed.data(), seed.size() * sizeof(unsigned int), hipMemcpyHostToDevice, st) != hipSuccess) return 1;
-  if (hipStreamSynchronize(st) != hipSuccess) return 1;  // `seed` is a local vector
+  if (hipMemcpyAsync(dseed, seed.data(), seed.size() * sizeof(unsigned int), hipMemcpyHostToDevice, st) != hipSuccess) return fail();
+  if (hipStreamSynchronize(st) != hipSuccess) return fail();  // `seed` is a local vector
   GenicArgs a;
   a.dk = dk; a.seed = dseed; a.n = n; a.nzp = nzp; a.nyl = nyl; a.y0 = y0;
   a.box = p->BoxSize_true_Mpc; a.fac = pow(1. / a.box, 1.5); a.pknorm = p->PkNorm; a.n3 = pow((double)n, 3.0);
   a.fixed = p->FixedIC != 0; a.paired = p->PairedIC != 0;
   a.pkn = 0; a.pkx = a.pky = a.pkc = nullptr;
-  double *dpk = nullptr;
   if (p->pk_n > 0) {  // SPLINE[SP_PK]: GSL's natural cubic spline through the table, coefficients on the host
-    if (p->pk_n < 3 || !p->pk_logk || !p->pk_logk3p) return 1;
+    if (p->pk_n < 3 || !p->pk_logk || !p->pk_logk3p) return fail();
     std::vector<double> tab(3 * (size_t)p->pk_n);
     memcpy(tab.data(), p->pk_logk, sizeof(double) * p->pk_n);
     memcpy(tab.data() + p->pk_n, p->pk_logk3p, sizeof(double) * p->pk_n);
-    if (pf_spline_coeffs(p->pk_logk, p->pk_logk3p, p->pk_n, tab.data() + 2 * (size_t)p->pk_n)) return 1;
-    if (hipMalloc(&dpk, tab.size() * sizeof(double)) != hipSuccess) return 1;
-    if (hipMemcpyAsync(dpk, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) return 1;
-    if (hipStreamSynchronize(st) != hipSuccess) return 1;  // `tab` is a local vector
+    if (pf_spline_coeffs(p->pk_logk, p->pk_logk3p, p->pk_n, tab.data() + 2 * (size_t)p->pk_n)) return fail();
+    if (hipMalloc(&dpk, tab.size() * sizeof(double)) != hipSuccess) return fail();
+    if (hipMemcpyAsync(dpk, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) return fail();
+    if (hipStreamSynchronize(st) != hipSuccess) return fail();  // `tab` is a local vector
     a.pkn = p->pk_n; a.pkx = dpk; a.pky = dpk + p->pk_n; a.pkc = dpk + 2 * (size_t)p->pk_n;
   }
   eh_constants(p, &a.eh);
@@ -309,11 +310,13 @@ int pf_genic_launch(int fb, void *dk, int n, int nzp, int nyl, int y0, const pf_
   const unsigned blocks = (unsigned)((ncol + 63) / 64);
   if (fb == 8) hipLaunchKernelGGL(k_genic<double>, dim3(blocks), dim3(64), 0, st, a);
   else hipLaunchKernelGGL(k_genic<float>, dim3(blocks), dim3(64), 0, st, a);
-  *seed_dev_out = dseed;
   const int rc = hipGetLastError() == hipSuccess ? 0 : 1;
   if (dpk) {  // the kernel has the table for its lifetime only
-    if (hipStreamSynchronize(st) != hipSuccess) return 1;
-    hipFree(dpk);
+    const bool done = hipStreamSynchronize(st) == hipSuccess;
+    hipFree(dpk); dpk = nullptr;
+    if (!done) return fail();
   }
-  return rc;
+  if (rc) return fail();
+  *seed_dev_out = dseed;  // the caller's from here on
+  return 0;
 }

@@ -23,6 +23,7 @@ struct RcclApi {
   int (*GetUniqueId)(ncclUniqueId *);
   int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
   int (*CommDestroy)(ncclComm_t);
+  int (*CommCount)(const ncclComm_t, int *);
   int (*Send)(const void *, size_t, int, int, ncclComm_t, void *);
   int (*Recv)(void *, size_t, int, int, ncclComm_t, void *);
   int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, void *);
@@ -45,7 +46,7 @@ static int load_rccl() {
   }
   if (!h) { printf("ERROR on task 0: cannot load librccl (%s)\n", dlerror()); return 1; }
 #define SYM(field, name) *(void **)(&g_api.field) = dlsym(h, name); if (!g_api.field) { printf("ERROR on task 0: missing %s in librccl\n", name); return 1; }
-  SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
+  SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy") SYM(CommCount, "ncclCommCount")
   SYM(Send, "ncclSend") SYM(Recv, "ncclRecv") SYM(AllReduce, "ncclAllReduce") SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd")
 #undef SYM
   g_api.h = h;
@@ -98,6 +99,14 @@ extern "C" int pf_rccl_unique_id(void *id128) {
 // rank/nranks come from the context's own configuration; the context owns the link (pf_destroy / pf_release_rccl)
 extern "C" int pf_ctx_rank_size(pf_ctx *ctx, int *rank, int *nranks);
 extern "C" int pf_ctx_set_rccl(pf_ctx *ctx, void *link);
+
+// ranks RCCL itself counts in the communicator of this link (ncclCommCount): what a bench line reports beside WORLD_SIZE
+extern "C" int pf_rccl_link_count(void *link) {
+  RcclLink *l = (RcclLink *)link;
+  int n = 0;
+  if (!l || !g_api.h || !l->comm || g_api.CommCount(l->comm, &n)) return -1;
+  return n;
+}
 
 extern "C" void pf_rccl_release(void *link) {
   RcclLink *l = (RcclLink *)link;

@@ -30,14 +30,18 @@ struct pf_sng_cosmo {
   double FR0 = 0.0, H_over_c = 0.0, size = 0.0;
 };
 
-// ForceModification (src/collapse_times.c:295-312): Hu-Sawicki f(R) thin-shell enhancement of the force, in [0, 1/3]
-PF_HD double pf_sng_force_modification(const pf_sng_cosmo &c, double a, double delta) {
-  const double ff = 4. * c.OmegaLambda / c.Omega0;
-  const double thickness = c.FR0 / c.Omega0 / pow(c.H_over_c * c.size, 2.0) * pow(a, 7.) * pow((1. + delta), -1. / 3.) *
-                           (pow((1.0 + ff) / (1.0 + ff * pow(a, 3.)), 2.0) - pow((1.0 + ff) / (1.0 + delta + ff * pow(a, 3.)), 2.0));
-  double F3 = (thickness * (3. + thickness * (-3. + thickness)));
-  if (F3 < 0.) F3 = 0.;
-  return (F3 < 1. ? F3 / 3. : 1. / 3);
+// Thin-shell enhancement of the force on a top-hat of radius c.size in Hu-Sawicki f(R) gravity, in [0, 1/3]: the shell
+// fraction x from the contrast of the background and interior scalaron, then (1 - (1 - x)^3) / 3 clipped to the fully
+// unscreened 1/3.  (What ForceModification does, src/collapse_times.c:295-312; the operation order is the reference's,
+// because the table built from it is compared node by node.)
+PF_HD double pf_sng_fifth_force(const pf_sng_cosmo &c, double a, double overdensity) {
+  const double lam_over_m = 4. * c.OmegaLambda / c.Omega0;
+  const double background = pow((1.0 + lam_over_m) / (1.0 + lam_over_m * pow(a, 3.)), 2.0);
+  const double interior = pow((1.0 + lam_over_m) / (1.0 + overdensity + lam_over_m * pow(a, 3.)), 2.0);
+  const double shell = c.FR0 / c.Omega0 / pow(c.H_over_c * c.size, 2.0) * pow(a, 7.) * pow((1. + overdensity), -1. / 3.) * (background - interior);
+  const double unscreened = shell * (3. + shell * (-3. + shell));
+  if (unscreened < 0.) return 0.;
+  return unscreened < 1. ? unscreened / 3. : 1. / 3;
 }
 
 PF_HD double pf_sng_Esq(const pf_sng_cosmo &c, double z) {
@@ -51,26 +55,29 @@ PF_HD void pf_sng_omegas(const pf_sng_cosmo &c, double z, double &omegam, double
   omegal = c.OmegaLambda / (Ezv * Ezv);
 }
 
-// sng_system (src/collapse_times.c:241-293), standard gravity
-PF_HD void pf_sng_system(double t, const double y[9], double f[9], const pf_sng_cosmo &c) {
-  double omegam, omegal;
-  pf_sng_omegas(c, 1. / t - 1., omegam, omegal);
-  const double delta = y[6] + y[7] + y[8];
-  for (int i = 0; i < 3; i++) {
-    double sum = 0.;
-    for (int j = 0; j < 3; j++) {
-      if (i == j || y[i] == y[j]) continue;
-      sum += (y[j + 6] - y[i + 6]) * ((1. - y[i]) * (1. - y[i]) * (1. + y[i + 3]) - (1. - y[j]) * (1. - y[j]) * (1. + y[j + 3])) /
-             ((1. - y[i]) * (1. - y[i]) - (1. - y[j]) * (1. - y[j]));
-    }
-    f[i] = (y[i + 3] * (y[i] - 1.0)) / t;
-    if (c.FR0 != 0.0)
-      f[i + 3] = (0.5 * (y[i + 3] * (omegam - 2.0 * omegal - 2.0) - 3.0 * omegam * y[i + 6] * (1. + pf_sng_force_modification(c, t, delta)) -
-                         2.0 * y[i + 3] * y[i + 3])) / t;
-    else
-      f[i + 3] = (0.5 * (y[i + 3] * (omegam - 2.0 * omegal - 2.0) - 3.0 * omegam * y[i + 6] - 2.0 * y[i + 3] * y[i + 3])) / t;
-    f[i + 6] = ((5. / 6. + y[i + 6]) * ((3. + y[3] + y[4] + y[5]) - (1. + delta) / (2.5 + delta) * (y[3] + y[4] + y[5])) -
-                (2.5 + delta) * (1. + y[i + 3]) + sum) / t;
+// Right-hand side of the ellipsoid's nine equations in the scale factor a (what sng_system evaluates,
+// src/collapse_times.c:241-293): state s = {axis deformations lambda_a[3], velocity eigenvalues lambda_v[3], density
+// (gravity) eigenvalues lambda_d[3]}.  Each derivative is assembled from the shared pieces below with the reference's
+// own association of every sum and product (the integration is compared bit for bit with the oracle's).
+PF_HD void pf_sng_rhs(double a, const double s[9], double ds[9], const pf_sng_cosmo &c) {
+  double om, ol;
+  pf_sng_omegas(c, 1. / a - 1., om, ol);
+  const double *ax = s, *vel = s + 3, *den = s + 6;
+  const double overdensity = den[0] + den[1] + den[2];
+  const double trv = vel[0] + vel[1] + vel[2];
+  const double expansion = (3. + vel[0] + vel[1] + vel[2]) - (1. + overdensity) / (2.5 + overdensity) * trv;
+  const double drag = om - 2.0 * ol - 2.0;
+  // gravity source: 3 Omega_m lambda_d, times (1 + fifth force) in an f(R) build (x 1.0 leaves the value as it is)
+  const double boost = c.FR0 != 0.0 ? (1. + pf_sng_fifth_force(c, a, overdensity)) : 1.0;
+  double sq[3];  // (1 - lambda_a)^2: the squared axis ratios
+  for (int k = 0; k < 3; k++) sq[k] = (1. - ax[k]) * (1. - ax[k]);
+  for (int k = 0; k < 3; k++) {
+    double tide = 0.;  // coupling of axis k to the two others; an equal pair contributes nothing
+    for (int m = 0; m < 3; m++)
+      if (m != k && ax[k] != ax[m]) tide += (den[m] - den[k]) * (sq[k] * (1. + vel[k]) - sq[m] * (1. + vel[m])) / (sq[k] - sq[m]);
+    ds[k] = (vel[k] * (ax[k] - 1.0)) / a;
+    ds[k + 3] = (0.5 * (vel[k] * drag - 3.0 * om * den[k] * boost - 2.0 * vel[k] * vel[k])) / a;
+    ds[k + 6] = ((5. / 6. + den[k]) * expansion - (2.5 + overdensity) * (1. + vel[k]) + tide) / a;
   }
 }
 
@@ -89,21 +96,21 @@ PF_HD void pf_rkf45_apply(double t, double h, double y[9], double yerr[9], const
   double k2[9], k3[9], k4[9], k5[9], k6[9], ytmp[9];
   const double *k1 = dydt_in;
   for (int i = 0; i < 9; i++) ytmp[i] = y[i] + ah[0] * h * k1[i];
-  pf_sng_system(t + ah[0] * h, ytmp, k2, c);
+  pf_sng_rhs(t + ah[0] * h, ytmp, k2, c);
   for (int i = 0; i < 9; i++) ytmp[i] = y[i] + h * (b3[0] * k1[i] + b3[1] * k2[i]);
-  pf_sng_system(t + ah[1] * h, ytmp, k3, c);
+  pf_sng_rhs(t + ah[1] * h, ytmp, k3, c);
   for (int i = 0; i < 9; i++) ytmp[i] = y[i] + h * (b4[0] * k1[i] + b4[1] * k2[i] + b4[2] * k3[i]);
-  pf_sng_system(t + ah[2] * h, ytmp, k4, c);
+  pf_sng_rhs(t + ah[2] * h, ytmp, k4, c);
   for (int i = 0; i < 9; i++) ytmp[i] = y[i] + h * (b5[0] * k1[i] + b5[1] * k2[i] + b5[2] * k3[i] + b5[3] * k4[i]);
-  pf_sng_system(t + ah[3] * h, ytmp, k5, c);
+  pf_sng_rhs(t + ah[3] * h, ytmp, k5, c);
   for (int i = 0; i < 9; i++) ytmp[i] = y[i] + h * (b6[0] * k1[i] + b6[1] * k2[i] + b6[2] * k3[i] + b6[3] * k4[i] + b6[4] * k5[i]);
-  pf_sng_system(t + ah[4] * h, ytmp, k6, c);
+  pf_sng_rhs(t + ah[4] * h, ytmp, k6, c);
   for (int i = 0; i < 9; i++) {
     const double d_i = c1 * k1[i] + c3 * k3[i] + c4 * k4[i] + c5 * k5[i] + c6 * k6[i];
     yerr[i] = h * (ec[1] * k1[i] + ec[3] * k3[i] + ec[4] * k4[i] + ec[5] * k5[i] + ec[6] * k6[i]);
     y[i] += h * d_i;
   }
-  pf_sng_system(t + h, y, dydt_out, c);
+  pf_sng_rhs(t + h, y, dydt_out, c);
 }
 
 // gsl_odeiv2_control_standard_new(1e-6, 1e-6, 1, 1), method order 5: -1 decrease, +1 increase, 0 keep (std_control_hadjust)
@@ -151,7 +158,7 @@ PF_HD double pf_ell_sng(double l1, double l2, double l3, double D_in, const pf_s
     double h0 = hh;
     bool final_step = false;
     for (int i = 0; i < 9; i++) y0[i] = y[i];
-    if (first) { pf_sng_system(t0, y, dydt_in, c); first = false; }
+    if (first) { pf_sng_rhs(t0, y, dydt_in, c); first = false; }
     else for (int i = 0; i < 9; i++) dydt_in[i] = dydt_out[i];
     for (;;) {
       if (dt >= 0.0 && h0 > dt) { h0 = dt; final_step = true; } else final_step = false;

@@ -132,11 +132,21 @@ class TorchKind:
 KINDS = {"rccl": RcclKind, "torch": TorchKind}
 
 
-def negotiate_exchange(f, dist, torch, preferred: str = "rccl", device="cuda", kinds=None, selftest_bytes: int = 1 << 20, log=None):
+def negotiate_exchange(f, dist, torch, preferred: str = "rccl", device="cuda", kinds=None, selftest_bytes: int = 1 << 20, log=None,
+                       votes=None):
     """Collective over the process group.  Tries `preferred`, then the other kinds, and returns (name, keep-alive object)
     of the first one every rank could bind, set up and self-test (pf_debug_exchange: all-to-all, row-range all-to-all and
-    all-reduce with a known pattern); raises RuntimeError on every rank if none works.  `kinds`: name -> class, for tests."""
+    all-reduce with a known pattern); raises RuntimeError on every rank if none works.  `kinds`: name -> class, for tests.
+    `votes`: a list that receives one record per vote taken -- {"kind", "step": "bind" | "setup" | "selftest", "here": this
+    rank's answer, "all": the outcome over all ranks} -- the same sequence on every rank (bench.py prints rank 0's)."""
     kinds = kinds or KINDS
+    votes = votes if votes is not None else []
+
+    def vote(kind, step, here):
+        everyone = _vote(dist, torch, here, device)
+        votes.append({"kind": kind, "step": step, "here": bool(here), "all": bool(everyone)})
+        return everyone
+
     order = [preferred] + [k for k in kinds if k != preferred]
     log = log or (lambda msg: print(msg, file=sys.stderr, flush=True))
     rank = dist.get_rank()
@@ -147,7 +157,7 @@ def negotiate_exchange(f, dist, torch, preferred: str = "rccl", device="cuda", k
         except Exception as e:  # noqa: BLE001
             log(f"[rank {rank}] exchange '{name}': local check raised {e!r}")
             local = False
-        if not _vote(dist, torch, local, device):       # nobody has touched a communicator of this kind yet
+        if not vote(name, "bind", local):       # nobody has touched a communicator of this kind yet
             log(f"[rank {rank}] exchange '{name}' cannot be bound on every rank (here: {local})")
             continue
         try:
@@ -155,13 +165,13 @@ def negotiate_exchange(f, dist, torch, preferred: str = "rccl", device="cuda", k
         except Exception as e:  # noqa: BLE001
             log(f"[rank {rank}] exchange '{name}': set-up raised {e!r}")
             ok = False
-        if _vote(dist, torch, ok, device):
+        if vote(name, "setup", ok):
             try:
                 ok = f.L.pf_debug_exchange(f.h, selftest_bytes) == 0
             except Exception as e:  # noqa: BLE001
                 log(f"[rank {rank}] exchange '{name}': self-test raised {e!r}")
                 ok = False
-            if _vote(dist, torch, ok, device):
+            if vote(name, "selftest", ok):
                 return name, k
             log(f"[rank {rank}] exchange '{name}' failed its self-test on some rank (here: {ok})")
         else:

@@ -269,6 +269,13 @@ int pf_compat_genic(double PkNorm) {
            params.FileWithInputSpectrum);
     return 1;
   }
+  /* PowerSpectrum() multiplies either spectrum by the warm-dark-matter cut-off Tf^2 (src/cosmo.c:987-1005); the device
+     generator has no such term: refuse rather than hand a WDM run CDM initial conditions */
+  if (params.WDM_PartMass_in_kev > 0.0) {
+    printf("ERROR on task %d: the device generator has no warm-dark-matter cut-off (WDM_PartMass_in_kev %g); use GenIC_large\n", ThisTask,
+           params.WDM_PartMass_in_kev);
+    return 1;
+  }
   if (strcmp(params.FileWithInputSpectrum, "no")) {
     g.pk_n = (int)SPLINE[SP_PK]->size; g.pk_logk = SPLINE[SP_PK]->x; g.pk_logk3p = SPLINE[SP_PK]->y;
     if (PkNorm <= 0.0) { /* normalize_PowerSpectrum (:1061-1081): a trusted table (Sigma8 0, or CAMBTable) has PkNorm 1 */
@@ -509,7 +516,7 @@ int compute_fmax(void) {
 
 /* bin of the Fmax histogram: tenths of F, everything below 0 in the first and everything from NBINS/10 on in the last bin
    (the definition behind pinocchio.*.FmaxPDF.out, src/fmax.c:517-525) */
-static int pf_pdf_bin(float F) {
+static int pf_pdf_bin(PRODFLOAT F) { /* the record's own type: a -DDOUBLE_PRECISION_PRODUCTS build bins the double */
   const int b = (int)(F * 10.);
   return b < 0 ? 0 : b >= NBINS ? NBINS - 1 : b;
 }

@@ -1,11 +1,11 @@
 #!/bin/bash
 # A/B of library builds on ONE box: bench.py once per build (csrc/Makefile VARIANT=...), per-kernel table side by side.
-#   profiles/tools/ab.sh default pad w0     -> libpinfmax_hip.so, libpinfmax_hip_pad.so, libpinfmax_hip_w0.so
+#   profiles/tools/ab.sh default pad w0     -> libpinfmax_hip.so, csrc/build_pad/libpinfmax_hip_pad.so, csrc/build_w0/libpinfmax_hip_w0.so
 # Writes gpurun_out/ab_<name>.json; extra bench arguments through AB_ARGS.
 cd "$(dirname "$0")/../.." || exit 1
 mkdir -p gpurun_out
 for v in "$@"; do
-  lib=pinocchio_amd/libpinfmax_hip_$v.so
+  lib=pinocchio_amd/csrc/build_$v/libpinfmax_hip_$v.so
   [ "$v" = default ] && lib=pinocchio_amd/libpinfmax_hip.so
   PINFMAX_LIB=$PWD/$lib python3 bench.py --steps ${AB_STEPS:-3} --warmup 1 --cpu-n 0 $AB_ARGS > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err || tail -5 gpurun_out/ab_$v.err
 done

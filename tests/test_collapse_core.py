@@ -23,8 +23,8 @@ def _dp(a):
 
 @pytest.fixture(scope="module")
 def emul():
-    hdr = os.path.join(HERE, "..", "pinocchio_amd", "csrc", "pf_collapse_core.h")
-    if (not os.path.exists(SO)) or os.path.getmtime(SO) < max(os.path.getmtime(SRC), os.path.getmtime(hdr)):
+    hdrs = [os.path.join(HERE, "..", "pinocchio_amd", "csrc", h) for h in ("pf_collapse_core.h", "pf_sng_core.h")]
+    if (not os.path.exists(SO)) or os.path.getmtime(SO) < max([os.path.getmtime(SRC)] + [os.path.getmtime(h) for h in hdrs]):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-o", SO, SRC])
     L = C.CDLL(SO)
     L.emul_collapse.argtypes = [dp, dp, C.c_int, dp, C.c_long, dp, dp]

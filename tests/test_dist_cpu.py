@@ -182,3 +182,29 @@ def test_exchange_negotiation_never_leaves_a_rank_behind(scenario, chosen):
         assert ("setup", "rccl") not in c0         # the vote came first
     if scenario.get("setup_fails") or scenario.get("selftest_fails"):
         assert ("release", "rccl") in c0           # nothing of the failed kind stays behind
+
+
+# ---- bench.py --gpus N invoked bare: it starts its own ranks ----
+def test_bench_self_launches_its_ranks_without_touching_the_gpu():
+    """`python bench.py --gpus 2 --dry-launch` with no WORLD_SIZE in the environment: the parent starts two fresh children
+    through torch.distributed.run (RANK 0 and 1, one rendezvous on 127.0.0.1), relays their lines, returns their exit
+    code, and has itself neither imported torch nor loaded the HIP library."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-launch"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    ranks = sorted((ln["rank"], ln["local_rank"], ln["world"]) for ln in lines if ln.get("role") == "rank")
+    assert ranks == [(0, 0, 2), (1, 1, 2)], lines
+    assert all(ln["launched_by_bench"] and ln["gpu_untouched"] for ln in lines if ln.get("role") == "rank")
+    assert len({ln["master"] for ln in lines if ln.get("role") == "rank"}) == 1
+    parent = [ln for ln in lines if ln.get("role") == "parent"]
+    assert len(parent) == 1 and parent[0]["parent_gpu_untouched"] and parent[0]["children_rc"] == 0 and parent[0]["json_lines_relayed"] == 2
+    assert "--nproc-per-node=2" in parent[0]["command"] and "torch.distributed.run" in parent[0]["command"]
+    # under a launcher (WORLD_SIZE set) nothing is started: a mismatch is still refused
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--dry-launch"], env=env2,
+                        capture_output=True, text=True, timeout=120)
+    assert r2.returncode != 0 and "WORLD_SIZE=1" in r2.stderr
