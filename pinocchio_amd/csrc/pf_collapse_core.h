@@ -129,6 +129,18 @@ PF_HD double pf_horner(double r, double z, double c) {
   return fma(r, z, c);
 #endif
 }
+// The same step with the coefficient in a scalar register pair (a table in constant memory, fetched by scalar loads beside
+// the vector stream): left to itself the compiler copies such a coefficient into a VGPR pair (two v_mov_b32) for its
+// two-address v_fmac_f64 -- three vector instructions per step instead of one.
+PF_HD double pf_horner_s(double r, double z, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(r), "v"(z), "s"(c));
+  return d;
+#else
+  return fma(r, z, c);
+#endif
+}
 PF_HD void pf_sincos_third(double x, double &sn, double &cs) {
   const double z = x * x;
   double ps = pf_sc_coef[0];
@@ -166,6 +178,40 @@ PF_HD double pf_sqrt_fast(double x) {
 #else
   return sqrt(x);
 #endif
+}
+
+// The cosine triple of the trigonometric root formula without its transcendentals.  c_k = cos((acos x + 2 pi k) / 3) are
+// the roots of the Chebyshev cubic 4 c^3 - 3 c = x.  With y = sqrt((1 + x) / 2) = cos(3 theta / 2), theta = acos(x) / 3,
+// the largest root is c_1 = cos(2/3 acos y), and (1 - c_1) / (1 - x) = h(y) is analytic on [0, 1] (nearest singularity
+// y = -1): one degree-22 polynomial in t = 2 y - 1 (Chebyshev fit in 60-digit arithmetic, truncation 7e-18, within 1 ulp in
+// double Horner form; tests/test_collapse_core.py against mpmath).  Then c_1 = 1 - (1 - x) h, sin(theta) = sqrt((1 - x) h
+// (1 + c_1)) -- 1 - c_1^2 without the cancellation at x -> 1 -- and the rotation by 2 pi / 3 gives c_2, c_3.  52 operations
+// where acos (55) + sincos with its rotation (34) took 89; each result within ~2 ulp of the reference's cos(acos(.)/3)
+// calls where those are well conditioned, and conditioned like them at x -> +-1 (a degenerate pair of roots).  |x| > 1 by
+// round-off gives NaN in all three, as acos does (quirk Q4).
+#if defined(__HIP_DEVICE_COMPILE__)
+static __constant__ double pf_c3_coef[23] = {
+#else
+static const double pf_c3_coef[23] = {
+#endif
+    1.43396340762163678e-11,  -4.29427803767481323e-11, 4.61317068002735218e-11,  -1.38050045298289521e-10, 6.19161692721708188e-10,
+    -1.85273563663425955e-09, 5.24898621624865300e-09,  -1.56978011134299560e-08, 4.71941580314714327e-08,  -1.41043393253484189e-07,
+    4.21175556679195000e-07,  -1.25745808061941212e-06, 3.75178490461992615e-06,  -1.11842872488483324e-05, 3.33048358182611446e-05,
+    -9.90342153831625456e-05, 2.93911199246382684e-04,  -8.69842889830885636e-04, 2.56357950483709473e-03,  -7.50383677308579921e-03,
+    2.16901626784005916e-02,  -6.09591300458922972e-02, 1.55970371254014639e-01};
+PF_HD void pf_cos3_of_acos(double x, double &c1, double &c2, double &c3) {
+  const double s = pf_sqrt_fast(1.0 + x);                 // NaN for x < -1
+  const double t = fma(s, 1.41421356237309504880, -1.0);  // 2 y - 1
+  double h = pf_c3_coef[0];
+#pragma unroll
+  for (int i = 1; i < 23; i++) h = pf_horner_s(h, t, pf_c3_coef[i]);
+  const double u = (1.0 - x) * h;                         // 1 - c1
+  const double cs = 1.0 - u;
+  const double sn = pf_sqrt_fast(u * (1.0 + cs));         // NaN for x > 1
+  const double g = 0.86602540378443864676 * sn;          // sin(2 pi / 3) sin(theta)
+  c1 = fma(0.0, sn, cs);                                  // (... in all three)
+  c2 = -0.5 * cs - g;
+  c3 = -0.5 * cs + g;
 }
 
 // x / Y for a constant Y, correctly rounded, in three operations (Markstein): with c = RN(1/Y), q0 = RN(x c),
@@ -350,9 +396,9 @@ template <bool FAST = false> PF_HD double pf_ell_three_roots(const pf_cubic &c) 
   const double a1 = c.a1, q = c.q, r = c.r;
   const double sq = 2 * (FAST ? pf_sqrt_fast(q) : sqrt(q));
   const double inv_3 = 1.0 / 3;
-  const double t = FAST ? pf_acos_series(pf_div_fast(2 * r, q * sq)) : acos(2 * r / q / sq);
   double c1, c2, c3;
-  pf_cos3<FAST>(t, c1, c2, c3);
+  if (FAST) pf_cos3_of_acos(pf_div_fast(2 * r, q * sq), c1, c2, c3);
+  else pf_cos3<FAST>(acos(2 * r / q / sq), c1, c2, c3);
   double s1 = -sq * c1 - a1 * inv_3;
   double s2 = -sq * c2 - a1 * inv_3;
   double s3 = -sq * c3 - a1 * inv_3;
@@ -407,17 +453,36 @@ PF_HD double pf_lpt3b_accumulate(double s, const double phi2[6], const double h[
 // ... in two pieces: the three invariants of the tensor, and everything after them.  The invariants are all the solve
 // needs, so the z-pass of the sweep can store them (3 fields) instead of the six components (k_c2r_invariants); only an
 // exactly isotropic tensor (q == 0) takes its eigenvalues from the diagonal itself, `diag`.
-PF_HD void pf_invariants(const double d[6], double &mu1, double &mu2, double &mu3) {
+// (each invariant on its own too: the z-pass lets one wave form one of them for half a row, k_c2r_invariants; the same
+//  operations in the same order as in pf_invariants below, whichever way they are called)
+PF_HD double pf_invariant_mu1(const double d[6]) {
 #if defined(__clang__)
 #pragma clang fp contract(off)  // also when included from a translation unit built with contraction on (the z-pass)
 #endif
-  mu1 = d[0] + d[1] + d[2];
+  return d[0] + d[1] + d[2];
+}
+PF_HD double pf_invariant_mu2(const double d[6], double mu1) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
   const double mu1_2 = mu1 * mu1;
-  mu2 = 0.5 * mu1_2;
+  double mu2 = 0.5 * mu1_2;
   mu2 -= 0.5 * (d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
   const double add0 = d[3] * d[3], add1 = d[4] * d[4], add2 = d[5] * d[5];
   mu2 -= add0 + add1 + add2;
-  mu3 = d[0] * d[1] * d[2] + 2. * d[3] * d[4] * d[5] - d[0] * add2 - d[1] * add1 - d[2] * add0;
+  return mu2;
+}
+PF_HD double pf_invariant_mu3(const double d[6]) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  const double add0 = d[3] * d[3], add1 = d[4] * d[4], add2 = d[5] * d[5];
+  return d[0] * d[1] * d[2] + 2. * d[3] * d[4] * d[5] - d[0] * add2 - d[1] * add1 - d[2] * add0;
+}
+PF_HD void pf_invariants(const double d[6], double &mu1, double &mu2, double &mu3) {
+  mu1 = pf_invariant_mu1(d);
+  mu2 = pf_invariant_mu2(d, mu1);
+  mu3 = pf_invariant_mu3(d);
 }
 // q of pf_eigen_from_invariants is zero (or so small that the division by nine flushes it) although the diagonal is not
 // exactly (mu1/3, mu1/3, mu1/3) -- the one case in which the three invariants do not carry what the solve reads
@@ -444,10 +509,10 @@ template <bool FAST = false> PF_HD bool pf_eigen_from_invariants(double mu1, dou
       return false;
     }
     const double sq = 2 * (FAST ? pf_sqrt_fast(q) : sqrt(q));
-    const double t = FAST ? pf_acos_series(pf_div_fast(2 * r, q * sq)) : acos(2 * r / q / sq);
     const double inv_3 = 1.0 / 3.0;
     double c1, c2, c3;
-    pf_cos3<FAST>(t, c1, c2, c3);
+    if (FAST) pf_cos3_of_acos(pf_div_fast(2 * r, q * sq), c1, c2, c3);
+    else pf_cos3<FAST>(acos(2 * r / q / sq), c1, c2, c3);
     x1 = -sq * c1 + mu1 * inv_3;
     x2 = -sq * c2 + mu1 * inv_3;
     x3 = -sq * c3 + mu1 * inv_3;

@@ -104,3 +104,8 @@ extern "C" void emul_pow_third(const double *x, long count, double *out) {
 extern "C" void emul_exp(const double *x, long count, double *e, double *e10) {
   for (long i = 0; i < count; i++) { e[i] = pf_exp_series(x[i]); e10[i] = pf_exp10_series(x[i]); }
 }
+
+// the cosine triple of the trigonometric root formula (fast flavour: no acos, no sincos)
+extern "C" void emul_cos3(const double *x, long count, double *c) {
+  for (long i = 0; i < count; i++) pf_cos3_of_acos(x[i], c[3 * i], c[3 * i + 1], c[3 * i + 2]);
+}

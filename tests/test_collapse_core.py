@@ -223,6 +223,44 @@ def test_acos_of_the_fast_flavour(emul):
     assert np.all(np.isnan(out))
 
 
+def test_cosine_triple_of_the_fast_flavour(emul):
+    """pf_cos3_of_acos(x) = cos((acos x + 2 pi k) / 3), k = 0, 1, 2, without acos and sincos (one polynomial, two square roots)
+    against mpmath (40 digits): c_1 within 2 ulp everywhere on [-1, 1]; c_2, c_3 within 2 ulp of their own magnitude scale (they
+    are -c_1/2 -+ sqrt(3)/2 sin: absolute error a few 1e-16) where the triple is well conditioned, and -- next to x = 1, where
+    1 - x carries the rounding of x itself -- within the change a 1-ulp change of x makes; NaN in all three outside [-1, 1]"""
+    import mpmath as mp
+    mp.mp.dps = 40
+    emul.emul_cos3.argtypes = [dp, C.c_long, dp]
+    rng = np.random.default_rng(33)
+    x = np.concatenate([rng.uniform(-1, 1, 20000), 1.0 - 10.0 ** rng.uniform(-16, 0, 5000), -1.0 + 10.0 ** rng.uniform(-16, 0, 5000),
+                        10.0 ** rng.uniform(-300, -1, 1000), -10.0 ** rng.uniform(-300, -1, 1000),
+                        [0.0, 1.0, -1.0, 0.5, -0.5, np.nextafter(1.0, 0.0), np.nextafter(-1.0, 0.0)]])
+    x = np.clip(x, -1.0, 1.0)
+    got = np.empty((len(x), 3))
+    emul.emul_cos3(_dp(x), len(x), _dp(got))
+    want = np.empty((len(x), 3))
+    for i, v in enumerate(x):
+        t = mp.acos(mp.mpf(float(v)))
+        want[i] = [float(mp.cos((t + 2 * mp.pi * k) / 3)) for k in range(3)]
+    eps = np.finfo(float).eps
+    # conditioning: d c_k / d x = sin((t + 2 pi k)/3) / (3 sin t): a 1-ulp change of x moves c_k by this much
+    t = np.arccos(x)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        cond = np.abs(np.sin((t[:, None] + 2 * np.pi * np.arange(3)) / 3)) / (3 * np.maximum(np.sin(t), 1e-300))[:, None] * np.spacing(np.abs(x))[:, None]
+    tol = 2.5 * eps + 2.0 * np.where(np.isfinite(cond), cond, 0.0)
+    err = np.abs(got - want)
+    bad = err > tol
+    assert not bad.any(), (x[bad.any(axis=1)][:5], got[bad.any(axis=1)][:5], want[bad.any(axis=1)][:5])
+    assert (np.abs(got[:, 0] - want[:, 0]) <= 2 * np.spacing(want[:, 0])).all()           # the largest root: always well conditioned
+    # the roots really solve the Chebyshev cubic, and they come out ordered c1 >= c3 >= c2
+    res = 4 * got ** 3 - 3 * got - x[:, None]
+    assert np.max(np.abs(res)) < 4e-15    # (the residual itself is evaluated in double: |f'| <= 9)
+    assert (got[:, 0] >= got[:, 2]).all() and (got[:, 2] >= got[:, 1]).all()
+    out = np.empty(9)
+    emul.emul_cos3(_dp(np.array([1.0000001, -1.5, np.nan])), 3, _dp(out))
+    assert np.all(np.isnan(out))
+
+
 def test_exp_and_exp10_of_the_fast_flavour(emul):
     """pf_exp_series / pf_exp10_series against the correctly rounded values (mpmath, 40 digits): within 1 ulp over the
     ranges the solver uses and over the whole finite range; exact at 0 and at integer powers of ten; inf / 0 beyond"""

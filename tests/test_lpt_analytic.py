@@ -235,6 +235,76 @@ def test_lpt_identities_at_scale(api, n):
 
 
 @pytest.mark.gpu
+def test_full_bench_workload_on_the_box_of_the_metric(api):
+    """1024^3 fp64, compute_fmax(radii_ladder(12), do_lpt=True): the very step bench.py times, checked without the oracle
+    (which would need several hundred GB).  (1) TrueVariance of the last radius = sigma^2 of the synthetic field, the
+    variances grow down the ladder, the PDF counts every cell.  (2) The 2LPT and 3LPT(a) sources are the reference's
+    cell-by-cell formulas (src/LPT.c:64-93) of the library's own R = 0 Hessian, on sampled x-planes, with the source spectra
+    transformed back by an independent FFT (scipy / pocketfft).  (3) Every one of the four displacement fields (twelve
+    columns, read back one block at a time through pf_get_block) is the irrotational field with i k.Psi = -g S and zero
+    mean (src/fmax-pfft.c:366-384 with the growths of src/LPT.c:181-228), to fp32 storage.  The kernels that only run at
+    this size in this form -- k_collapse_src, k_c2r_invariants<1024, 1>, k_r2c<1024>, the displacement passes -- are all
+    on the path of what is compared here."""
+    import os
+    import scipy.fft as sfft
+    n = 1024
+    workers = os.cpu_count() or 1
+    x, y = synth.invgrow_table("lcdm")
+    g = synth.growth_multipliers()
+    radii = synth.radii_ladder(12)
+    rms = lambda a: float(np.sqrt(np.mean(np.abs(a) ** 2)))
+    kx, ky, kz = synth.kgrid(n)
+    h = n // 2
+    planes = [0, 1, 317, 512, 1023]
+    with api.Fmax(n) as f:
+        f.synth_density(synth.SEED, 2.5, -2.0)
+        f.set_invgrow(x, y)
+        f.set_growth(g)
+        tv = f.compute_fmax(radii, do_lpt=True)
+        assert np.sqrt(tv[-1]) == pytest.approx(2.5, rel=1e-10) and np.all(np.diff(tv) > 0)
+        assert int(f.Fmax_PDF().sum()) == n ** 3
+        # (2) sources against the Hessian that is still in place (the last radius of the ladder is R = 0)
+        d = [f.second_derivative(i)[planes] for i in range(6)]
+        kv = []
+        for w in range(3):
+            spec = f.kvector(w)
+            kv.append(spec)
+            if w < 2:
+                real = sfft.irfftn(spec, s=(n, n, n), axes=(0, 1, 2), workers=workers)[planes]
+                if w == 0:
+                    want = d[0] * d[1] + d[0] * d[2] + d[1] * d[2] - d[3] ** 2 - d[4] ** 2 - d[5] ** 2
+                else:
+                    want = 3.0 * (d[0] * (d[1] * d[2] - d[5] * d[5]) - d[3] * (d[3] * d[2] - d[4] * d[5]) + d[4] * (d[3] * d[5] - d[4] * d[1]))
+                assert rms(real - want) <= 1e-12 * rms(want), ("source", w)
+                del real, want
+        dk = f.density()
+        del d
+        # (3) displacements, one block (three fp32 columns, 12.9 GB) at a time
+        ok = np.ones((n, n, h + 1), dtype=bool)      # Nyquist planes excluded (k = +pi has no -pi partner), and k = 0
+        ok[h, :, :] = False; ok[:, h, :] = False; ok[:, :, h] = False; ok[0, 0, 0] = False
+        kk = (kx[:, None, None], ky[None, :, None], kz[None, None, :])
+        for blk, spec, go in (("ZEL ", dk, g[0]), ("2LPT", kv[0], g[1]), ("31PT", kv[1], g[2]), ("32PT", kv[2], g[3])):
+            vel = f.block(blk).reshape(n, n, n, 3)
+            assert np.isfinite(vel).all()
+            v = [sfft.rfftn(np.ascontiguousarray(vel[..., a], dtype=np.float64), axes=(0, 1, 2), workers=workers) for a in range(3)]
+            del vel
+            amp = rms(v[0][ok]) + rms(v[1][ok]) + rms(v[2][ok])
+            assert abs(v[0][0, 0, 0]) <= 1e-6 * amp * n ** 1.5 and abs(v[1][0, 0, 0]) <= 1e-6 * amp * n ** 1.5   # zero mean
+            div = 1j * (kk[0] * v[0])
+            div += 1j * (kk[1] * v[1])
+            div += 1j * (kk[2] * v[2])
+            div += go * spec
+            assert rms(div[ok]) <= 2e-6 * abs(go) * rms(spec[ok]), (blk, "div")                 # fp32 storage of the columns
+            del div
+            for a, b in ((0, 1), (0, 2), (1, 2)):
+                curl = kk[a] * v[b]
+                curl -= kk[b] * v[a]
+                assert rms(curl[ok]) <= 2e-6 * amp, (blk, "curl", a, b)
+                del curl
+            del v
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["three_waves", "axis_waves"])
 @pytest.mark.parametrize("n,nranks", [(16, 1), (32, 1), (64, 1), (32, 2)])
 def test_hip_scale_dependent_growth_vs_closed_form(api, name, n, nranks):
