@@ -84,36 +84,66 @@ def committed_counters(kind: str, n: int, fb: int):
     return None
 
 
-def cpu_baseline(n: int, ns: int, lpt: bool, ns_sample: int = 2) -> dict:
-    """The CPU oracle (a port of the reference's structure: one k-loop + one c2r
-    per derivative, per-cell ell_classic, AoS fp32 products) timed on this box's
-    host cores on a bounded sample of the same workload: the n^3 box, `ns_sample`
-    of the `ns` radii (the oracle does the same work for every radius) and the
-    whole displacement part; the sweep time is scaled by ns / ns_sample."""
+def cpu_baseline(n: int, ns: int, lpt: bool, budget_s: float = 60.0) -> dict:
+    """The CPU oracle (a port of the reference's structure: one k-loop + one c2r per derivative, per-cell ell_classic, AoS fp32
+    products; OpenMP over x-planes) timed on this box's host cores.  The host is shared (several GPU slots per node) and the
+    oracle's strided transforms stop scaling long before 256 threads, so the thread count is CALIBRATED first: a 256^3 box,
+    two radii + the 3LPT part, on 16 / 32 / 64 / 128 threads; the fastest count then runs the n^3 box with ALL `ns` radii and
+    the displacement part if the calibration predicts that fits `budget_s`, otherwise as many mid-ladder radii as fit
+    (the oracle does the same work for every radius) with the sweep part scaled -- the sample string says which."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    # one thread per core, spread over both sockets (the first touch in orc_create places the pages accordingly).  The wait
+    # policy stays the default: the oracle has many short parallel loops, and passive waiting costs 7x at 64^3 (measured)
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
+    os.environ.setdefault("OMP_PLACES", "cores")
     import oracle_lib
     from pinocchio_amd import synth
     cores = os.cpu_count() or 1
-    threads = max(1, min(cores, n // 2))  # all hardware threads; the slab loops have n iterations
-    dk = synth.philox_density(n, synth.SEED, 2.5, -2.0)
     x, y = synth.invgrow_table("lcdm")
-    o = oracle_lib.Oracle(n, threads)
-    o.set_density(dk)
-    o.set_invgrow(x, y)
-    o.set_growth(synth.growth_multipliers())
     full = synth.radii_ladder(ns)
-    ns_sample = max(1, min(ns_sample, ns))
-    radii = np.concatenate([full[len(full) // 2:len(full) // 2 + ns_sample - 1], full[-1:]])   # mid-ladder radii + R = 0
-    t0 = time.perf_counter()
-    o.compute_fmax(radii, do_lpt=lpt)
-    dt = time.perf_counter() - t0
-    tm = o.timers()
+
+    def run(nn, threads, radii):
+        dk = synth.philox_density(nn, synth.SEED, 2.5, -2.0)
+        o = oracle_lib.Oracle(nn, threads)
+        o.set_density(dk)
+        o.set_invgrow(x, y)
+        o.set_growth(synth.growth_multipliers())
+        t0 = time.perf_counter()
+        o.compute_fmax(radii, do_lpt=lpt)
+        dt = time.perf_counter() - t0
+        tm = o.timers()
+        o.close()
+        return dt, tm
+
+    two = np.array([full[len(full) // 2], full[-1]])
+    ncal = min(256, n)
+    cal = {}
+    for t in (16, 32, 64, 128):
+        if t <= cores:
+            cal[t] = run(ncal, t, two)
+    threads = min(cal, key=lambda t: cal[t][0]) if cal else max(1, cores)
+    dtc, tmc = cal[threads] if cal else run(ncal, threads, two)
+    t_lpt_c = tmc["lpt"] if lpt else 0.0
+    scale = (n / ncal) ** 3
+    per_radius = (dtc - t_lpt_c) / len(two) * scale
+    fit = int((budget_s - t_lpt_c * scale) / max(per_radius, 1e-9))
+    if fit >= ns:
+        radii, scaled = full, False
+    else:
+        k = max(1, min(ns - 1, fit - 1))
+        radii = np.concatenate([full[len(full) // 2:len(full) // 2 + k][:k], full[-1:]])   # mid-ladder radii + R = 0
+        scaled = True
+    dt, tm = run(n, threads, radii)
     t_lpt = tm["lpt"] if lpt else 0.0
-    t_full = (dt - t_lpt) * ns / len(radii) + t_lpt
+    t_full = (dt - t_lpt) * ns / len(radii) + t_lpt if scaled else dt
     return {"value": n ** 3 / t_full, "unit": "grid-cells/s", "cores": threads, "kind": "port",
-            "sample": f"{n}^3 box, {len(radii)} of the {ns} radii{' + the whole 3LPT part' if lpt else ''} timed in {dt:.2f} s "
-                      f"(fft {tm['fft']:.2f} s, collapse {tm['coll']:.2f} s, lpt {t_lpt:.2f} s), sweep time scaled by {ns}/{len(radii)} "
-                      f"-> {t_full:.1f} s for the full job; same synthetic spectrum; host has {cores} hardware threads, {threads} used"}
+            "calibration": {str(t): round(v[0], 3) for t, v in cal.items()},
+            "sample": f"{n}^3 box, " + (f"{len(radii)} of the {ns} radii" if scaled else f"all {ns} radii") +
+                      f"{' + the whole 3LPT part' if lpt else ''} timed in {dt:.2f} s on {threads} OpenMP threads "
+                      f"(fft {tm['fft']:.2f} s, collapse {tm['coll']:.2f} s, lpt {t_lpt:.2f} s)" +
+                      (f", sweep time scaled by {ns}/{len(radii)} -> {t_full:.1f} s for the full job" if scaled else ", nothing scaled") +
+                      f"; same synthetic spectrum; thread count picked by a {ncal}^3 calibration over {sorted(cal)} threads "
+                      f"(seconds: {', '.join(f'{t}: {v[0]:.2f}' for t, v in sorted(cal.items()))}); host has {cores} hardware threads, shared with other jobs"}
 
 
 def parse_args(argv=None):

@@ -316,11 +316,21 @@ static int compute_derivative(orc_ctx *c, int first_derivative, int second_deriv
   return 0;
 }
 
+/* a flat copy by all threads (same bytes as memcpy; the reference's copies are serial loops -- threaded here, like the k-loop,
+   so that the CPU baseline is not handicapped); chunked by x-planes, as every other loop of the oracle */
+static void par_copy(const orc_ctx *c, double *dst, const double *src, size_t count) {
+  const size_t chunk = (count + (size_t)c->n - 1) / (size_t)c->n;
+#pragma omp parallel for num_threads(c->nthreads) schedule(static)
+  for (int i = 0; i < c->n; i++) {
+    const size_t lo = (size_t)i * chunk, hi = lo + chunk < count ? lo + chunk : count;
+    if (lo < hi) memcpy(dst + lo, src + lo, sizeof(double) * (hi - lo));
+  }
+}
 /* fmax-pfft.c:459-560: flat copies */
-static void write_in_cvector(orc_ctx *c, const double *v) { memcpy(c->cvector, v, sizeof(double) * c->n_fft); }
-static void write_from_cvector(orc_ctx *c, double *v) { memcpy(v, c->cvector, sizeof(double) * c->n_fft); }
-static void write_in_rvector(orc_ctx *c, const double *v) { memcpy(c->rvector, v, sizeof(double) * c->n_r); }
-static void write_from_rvector(orc_ctx *c, double *v) { memcpy(v, c->rvector, sizeof(double) * c->n_r); }
+static void write_in_cvector(orc_ctx *c, const double *v) { par_copy(c, c->cvector, v, c->n_fft); }
+static void write_from_cvector(orc_ctx *c, double *v) { par_copy(c, v, c->cvector, c->n_fft); }
+static void write_in_rvector(orc_ctx *c, const double *v) { par_copy(c, c->rvector, v, c->n_r); }
+static void write_from_rvector(orc_ctx *c, double *v) { par_copy(c, v, c->rvector, c->n_r); }
 
 /* fmax-pfft.c:563-631 */
 static void write_from_rvector_to_products(orc_ctx *c, int ia, int order) {
@@ -1024,6 +1034,28 @@ orc_ctx *orc_create(int n, int nthreads) {
   c->kvector_3LPT_2 = (double *)calloc(1, bf);
   c->source_2LPT = c->kvector_2LPT; c->source_3LPT_1 = c->kvector_3LPT_1; c->source_3LPT_2 = c->kvector_3LPT_2;
   c->products = (orc_product *)calloc(c->n_r, sizeof(orc_product));
+  /* first touch by the threads that will work on the x-planes (the pages of a calloc'ed array are placed where they are
+     first written: by one thread they would all sit on one memory node of a two-socket host) */
+  {
+    double *big[12] = {c->kdensity, c->cvector, c->rvector, c->kvector_2LPT, c->kvector_3LPT_1, c->kvector_3LPT_2,
+                       c->second_derivatives[0], c->second_derivatives[1], c->second_derivatives[2],
+                       c->second_derivatives[3], c->second_derivatives[4], c->second_derivatives[5]};
+    const size_t cnt[12] = {c->n_fft, c->n_fft, c->n_fft, c->n_fft, c->n_fft, c->n_fft, c->n_r, c->n_r, c->n_r, c->n_r, c->n_r, c->n_r};
+    for (int b = 0; b < 12; b++) {
+      const size_t chunk = (cnt[b] + (size_t)n - 1) / (size_t)n;
+#pragma omp parallel for num_threads(c->nthreads) schedule(static)
+      for (int i = 0; i < n; i++) {
+        const size_t lo = (size_t)i * chunk, hi = lo + chunk < cnt[b] ? lo + chunk : cnt[b];
+        if (lo < hi) memset(big[b] + lo, 0, sizeof(double) * (hi - lo));
+      }
+    }
+    const size_t pchunk = (c->n_r + (size_t)n - 1) / (size_t)n;
+#pragma omp parallel for num_threads(c->nthreads) schedule(static)
+    for (int i = 0; i < n; i++) {
+      const size_t lo = (size_t)i * pchunk, hi = lo + pchunk < c->n_r ? lo + pchunk : c->n_r;
+      if (lo < hi) memset(c->products + lo, 0, sizeof(orc_product) * (hi - lo));
+    }
+  }
   c->growth[0] = 1.0; c->growth[1] = 3. / 7.; c->growth[2] = -1. / 9.; c->growth[3] = 5. / 42.;
   return c;
 }
@@ -1039,7 +1071,7 @@ void orc_destroy(orc_ctx *c) {
   free(c);
 }
 
-int orc_set_density(orc_ctx *c, const double *dk) { memcpy(c->kdensity, dk, sizeof(double) * c->n_fft); return 0; }
+int orc_set_density(orc_ctx *c, const double *dk) { par_copy(c, c->kdensity, dk, c->n_fft); return 0; }
 int orc_set_invgrow(orc_ctx *c, const double *x, const double *y, int nk) { return spline_init(c, x, y, nk); }
 int orc_set_invgrow_radius(orc_ctx *c, int ismooth, const double *x, const double *y, int nk) {
   if (ismooth < 0 || ismooth >= ORC_MAX_SMOOTH) return 1;

@@ -129,6 +129,106 @@ class TorchKind:
         self.keep = None
 
 
+class HostStagedKind:
+    """Bring-up / test transport for a process group WITHOUT device collectives (backend "gloo"): every exchange is staged
+    through host memory -- wait for the library's stream, copy the send blocks to the host, exchange them with the peers by
+    point-to-point messages of the CPU group, copy what arrived into the receive blocks.  Slow by construction; what it is for
+    is running the slab path with world_size > 1 real processes where RCCL has no second GPU to talk to (two ranks sharing one
+    device), through the same callback ABI (pf_set_exchange / pf_set_exchange_rows / pf_set_allreduce) the device kinds use.
+    Not in KINDS: bench.py never falls back to it."""
+    name = "host"
+
+    def __init__(self, f, dist, torch, device):
+        self.f, self.dist, self.torch = f, dist, torch
+        self.keep = None
+
+    def can_bind(self) -> bool:
+        return True
+
+    def _pairwise(self, sends, recvs):
+        """sends[q] / recvs[p]: CPU uint8 tensors (possibly empty) for every peer; the block to oneself is copied"""
+        dist, rank, world = self.dist, self.dist.get_rank(), self.dist.get_world_size()
+        if recvs[rank].numel():
+            recvs[rank].copy_(sends[rank])
+        ops = []
+        for q in range(world):
+            if q == rank:
+                continue
+            if sends[q].numel():
+                ops.append(dist.P2POp(dist.isend, sends[q], q))
+            if recvs[q].numel():
+                ops.append(dist.P2POp(dist.irecv, recvs[q], q))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+
+    def setup(self) -> bool:
+        f, dist, torch = self.f, self.dist, self.torch
+        world = dist.get_world_size()
+
+        def dev(ptr, nbytes):
+            return torch.as_tensor(_DevMem(ptr, nbytes), device="cuda")
+
+        def _a2a(user, send, recv, bytes_per_peer, stream):
+            try:
+                st = torch.cuda.ExternalStream(stream)
+                with torch.cuda.stream(st):
+                    st.synchronize()
+                    host = dev(send, bytes_per_peer * world).cpu()
+                    got = torch.empty_like(host)
+                    self._pairwise([host[q * bytes_per_peer:(q + 1) * bytes_per_peer] for q in range(world)],
+                                   [got[p * bytes_per_peer:(p + 1) * bytes_per_peer] for p in range(world)])
+                    dev(recv, bytes_per_peer * world).copy_(got)
+                    st.synchronize()
+                return 0
+            except Exception as e:  # noqa: BLE001 -- surfaces as "all-to-all failed" in the library
+                print("host-staged exchange failed:", repr(e), flush=True)
+                return 1
+
+        def _a2av(user, send, recv, block_bytes, send_off, send_bytes, recv_off, recv_bytes, stream):
+            try:
+                st = torch.cuda.ExternalStream(stream)
+                with torch.cuda.stream(st):
+                    st.synchronize()
+                    s = dev(send, block_bytes * world)
+                    r = dev(recv, block_bytes * world)
+                    sends = [s[q * block_bytes + send_off:q * block_bytes + send_off + send_bytes].cpu() for q in range(world)]
+                    recvs = [torch.empty(int(recv_bytes[p]), dtype=torch.uint8) for p in range(world)]
+                    self._pairwise(sends, recvs)
+                    for p_ in range(world):
+                        if recv_bytes[p_]:
+                            r[p_ * block_bytes + recv_off[p_]:p_ * block_bytes + recv_off[p_] + recv_bytes[p_]].copy_(recvs[p_])
+                    st.synchronize()
+                return 0
+            except Exception as e:  # noqa: BLE001
+                print("host-staged row-range exchange failed:", repr(e), flush=True)
+                return 1
+
+        def _ared(user, buf, count, is_u64, stream):
+            try:
+                st = torch.cuda.ExternalStream(stream)
+                with torch.cuda.stream(st):
+                    st.synchronize()
+                    t = torch.as_tensor(_DevMem(buf, count * 8, "<i8" if is_u64 else "<f8", 8), device="cuda")
+                    host = t.cpu()
+                    dist.all_reduce(host)
+                    t.copy_(host)
+                    st.synchronize()
+                return 0
+            except Exception as e:  # noqa: BLE001
+                print("host-staged all-reduce failed:", repr(e), flush=True)
+                return 1
+
+        cb1, cb2, cb3 = _lib.ALLTOALL_FN(_a2a), _lib.ALLREDUCE_FN(_ared), _lib.ALLTOALLV_FN(_a2av)
+        self.keep = (cb1, cb2, cb3)
+        L = f.L
+        return L.pf_set_exchange(f.h, cb1, None) == 0 and L.pf_set_exchange_rows(f.h, cb3, None) == 0 and \
+            L.pf_set_allreduce(f.h, cb2, None) == 0
+
+    def release(self):
+        self.keep = None
+
+
 KINDS = {"rccl": RcclKind, "torch": TorchKind}
 
 
@@ -167,7 +267,11 @@ def negotiate_exchange(f, dist, torch, preferred: str = "rccl", device="cuda", k
             ok = False
         if vote(name, "setup", ok):
             try:
-                ok = f.L.pf_debug_exchange(f.h, selftest_bytes) == 0
+                # no more than a field of this context holds (three fields in the exchange buffers; small grids in tests)
+                cap = C.c_size_t()
+                f.L.pf_exchange_buffers(f.h, None, None, C.byref(cap))
+                per_peer = min(selftest_bytes, (cap.value // 3 // dist.get_world_size()) // 8 * 8)
+                ok = f.L.pf_debug_exchange(f.h, per_peer) == 0
             except Exception as e:  # noqa: BLE001
                 log(f"[rank {rank}] exchange '{name}': self-test raised {e!r}")
                 ok = False

@@ -105,7 +105,12 @@ def _negotiate_worker(rank, world, port, scenario, q):
             def __init__(self):
                 self.installed = None
 
+            def pf_exchange_buffers(self, h, send, recv, cap):
+                cap._obj.value = 3 << 24      # (what byref() wraps: the capacity the self-test is sized from)
+                return 0
+
             def pf_debug_exchange(self, h, nbytes):
+                assert 0 < nbytes <= (1 << 24) // 2 and nbytes % 8 == 0
                 calls.append(("selftest", self.installed))
                 bad = scenario.get("selftest_fails", {}).get(self.installed, ())
                 return 1 if rank in bad else 0

@@ -1,0 +1,80 @@
+"""World size 2 with REAL processes on the one GPU of the box: two fresh interpreters (started before either touches the GPU),
+a torch.distributed gloo group between them, libpinfmax_hip.so contexts with rank 0 / 1 of 2 on device 0, the exchange
+negotiated by pinocchio_amd/dist.py with a failure injected on one rank only, the data moved by the host-staged kind through
+the callback ABI (pf_set_exchange, pf_set_exchange_rows, pf_set_allreduce).  Results: bitwise those of one rank.
+
+(The reference: one MPI rank per x-slab, src/initialization.c:1317-1325; the transposes inside pfft_execute,
+src/fmax-pfft.c:197, 211; the reductions at src/collapse_times.c:656-667 and src/fmax.c:527.)"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from pinocchio_amd import synth
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("replicate,scenario", [(1, "setup"), (0, "bind"), (0, "none")])
+def test_two_processes_on_one_gpu_match_one_rank(tmp_path, replicate, scenario):
+    from pinocchio_amd import api
+    n, world = 64, 2
+    port = _free_port()
+    env = dict(os.environ, PF_REPLICATE_DK=str(replicate), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "gloo_rank_worker.py"), str(r), str(world), str(port), str(n), str(tmp_path), scenario],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, (r, outs[r][-3000:])
+    meta = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(world)]
+    # both ranks took the same decision through the same votes: the flaky kind lost its vote on the step where ONE rank broke
+    assert meta[0]["kind"] == meta[1]["kind"] == "host"
+    assert [(v["kind"], v["step"], v["all"]) for v in meta[0]["votes"]] == [(v["kind"], v["step"], v["all"]) for v in meta[1]["votes"]]
+    if scenario != "none":
+        lost = [v for v in meta[0]["votes"] if not v["all"]]
+        assert len(lost) == 1 and lost[0]["kind"] == "flaky" and lost[0]["step"] == scenario
+        assert [v["here"] for v in meta[0]["votes"] if v["kind"] == "flaky" and v["step"] == scenario] == [True]     # rank 0 was fine
+        assert [v["here"] for v in meta[1]["votes"] if v["kind"] == "flaky" and v["step"] == scenario] == [False]    # rank 1 broke
+    assert meta[0]["replicated"] == meta[1]["replicated"] == replicate
+    assert meta[0]["exchange_calls"] > 0
+    if replicate:
+        # the sweep exchanges nothing: only the LPT transposes travel
+        assert meta[0]["exchange_calls"] < 20
+
+    # one rank, same inputs
+    dk = synth.make_density(n, seed=23)
+    dk[0, 0, 0] = 0.17 * n ** 3
+    x, y = synth.invgrow_table("lcdm")
+    with api.Fmax(n) as f:
+        f.set_density(dk)
+        f.set_invgrow(x, y)
+        f.set_growth(synth.growth_multipliers())
+        tv = f.compute_fmax(np.array([8.0, 2.0, 1.0, 0.0]), do_lpt=True)
+        pdf = f.Fmax_PDF()
+        p = f.products()
+    nxl = n // world
+    for r in range(world):
+        d = np.load(tmp_path / f"rank{r}.npz")
+        assert d["tv"] == pytest.approx(tv, rel=1e-13)
+        assert np.array_equal(d["pdf"], pdf)
+        for k in p.dtype.names:
+            assert np.array_equal(d[k], p[k][r * nxl:(r + 1) * nxl]), (r, k)
