@@ -44,7 +44,7 @@ import numpy as np  # noqa: E402
 # (launch_ranks) must neither load the HIP library nor touch the GPU.
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = os.environ.get("PROFILE_ROUND", "r03")  # which profiles/<round>_pmc_*.json the counters come from
 
 
 def alg_bytes_per_cell(ns: int, w: int, lpt: bool) -> float:
@@ -72,10 +72,10 @@ def symbol_of(cls: str, n: int, fb: int, fast: bool = True) -> str:
 
 
 def committed_counters(kind: str, n: int, fb: int):
-    """profiles/<round>_pmc_<kind>.json if it was measured on the kernel sources loaded now, else None"""
+    """profiles/<round>[_fp32]_pmc_<kind>.json if it was measured on the kernel sources loaded now, else None"""
     from pinocchio_amd import _lib
     try:
-        with open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_{kind}.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}{'_fp32' if fb == 4 else ''}_pmc_{kind}.json")) as fh:
             d = json.load(fh)
         if d.get("kernel_source_sha") == _lib.source_sha() and d.get("config") == {"grid": n, "field_bytes": fb}:
             return d

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round artefacts in one gpurun call (run from the repo root ON THE GPU BOX):
-#   profiles/tools/collect.sh r02
+#   profiles/tools/collect.sh r03                                  (the metric's configuration)
+#   BENCH_ARGS="--field-bytes 4" PF_SUMMARY_FB=4 profiles/tools/collect.sh r03_fp32   (another one: extra bench arguments, and what summarise.py stamps)
 # 1. smoke()  2. rocprofv3 --kernel-trace --stats of a bench command  3. counter passes of one bench
 # step, each in its own run with --kernel-trace only (gpurun refuses --pmc together with other trace domains):
 # FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU SQ_WAVES | SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES | GRBM_GUI_ACTIVE
@@ -14,11 +15,11 @@ mkdir -p gpurun_out
 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 rm -rf gpurun_out/prof_${tag} gpurun_out/pmc_${tag}_*
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag} -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-n 0 --exact-steps 0 \
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag} -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-n 0 --exact-steps 0 $BENCH_ARGS \
   > $R/gpurun_out/${tag}_bench_profiled.json 2> $R/gpurun_out/${tag}_bench_profiled.err
 pmc() {  # pmc <name> <counters...>
   name=$1; shift
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${tag}_$name -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-n 0 --exact-steps 0 \
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${tag}_$name -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-n 0 --exact-steps 0 $BENCH_ARGS \
     > $R/gpurun_out/pmc_${tag}_$name.out 2> $R/gpurun_out/pmc_${tag}_$name.err
 }
 pmc fetch FETCH_SIZE
@@ -31,5 +32,6 @@ python3 profiles/tools/summarise.py $tag
 # the default bench line last, with the counter summaries of THIS box and THESE kernel sources in place (bench.py attaches
 # roofline.traffic / valu only from profiles stamped with the sources it runs)
 cp gpurun_out/${tag}_pmc_traffic.json gpurun_out/${tag}_pmc_valu.json gpurun_out/${tag}_kernel_stats.csv profiles/
-timeout 1500 python3 bench.py > gpurun_out/${tag}_bench_default.json 2> gpurun_out/${tag}_bench_default.err
+[ -n "$PROFILE_ROUND" ] || export PROFILE_ROUND=${tag%_fp32}
+timeout 1500 python3 bench.py $BENCH_ARGS > gpurun_out/${tag}_bench_default.json 2> gpurun_out/${tag}_bench_default.err
 tail -c 400 gpurun_out/${tag}_bench_default.json; echo

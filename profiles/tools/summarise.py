@@ -21,7 +21,7 @@ from pinocchio_amd import _lib  # noqa: E402
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 GO = os.path.join(ROOT, "gpurun_out")
-N, FB = 1024, 8
+N, FB = int(os.environ.get("PF_SUMMARY_N", "1024")), int(os.environ.get("PF_SUMMARY_FB", "8"))
 CELLS = float(N) ** 3
 
 
@@ -72,7 +72,7 @@ def main():
     if spath:
         rows = list(csv.DictReader(open(spath)))
         with open(os.path.join(GO, f"{tag}_kernel_stats.csv"), "w") as out:
-            out.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --cpu-n 0 --exact-steps 0 ; kernel sources {sha}\n")
+            out.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --cpu-n 0 --exact-steps 0 {os.environ.get('BENCH_ARGS', '')}; kernel sources {sha}\n")
             out.write("kernel,calls,total_ns,average_ns,percent\n")
             for r in rows:
                 if float(r["Percentage"]) < 0.05:
