@@ -144,6 +144,9 @@ static void fft1d(double *a, int n, int sign, const double *tw, const int *brev)
   }
 }
 
+/* (The loops over planes of the transforms and of the k-space filter are scheduled dynamically: every iteration writes its own
+   plane, so the results do not depend on who runs it, and on a host shared with other jobs a thread that loses its core no
+   longer holds up a static team -- the oracle got SLOWER from 16 to 128 threads on such a host with static schedules.) */
 /* complex transforms along x and y of a half-spectrum array [n][n][nzh].  The lines are strided (nzh, n*nzh complex);
    ORC_FFT_BLOCK neighbouring kz columns are gathered together so that every cache line fetched is used whole.  Each
    line still goes through the same fft1d: results do not depend on the blocking. */
@@ -166,12 +169,12 @@ static void fft_xy(orc_ctx *c, double *spec, int sign) {
   {
     double *lines = (double *)malloc(sizeof(double) * 2 * n * ORC_FFT_BLOCK);
     /* y lines: fixed (x,kz), stride nzh */
-#pragma omp for schedule(static)
+#pragma omp for schedule(dynamic, 1)
     for (int x = 0; x < n; x++)
       for (int kz = 0; kz < nzh; kz += ORC_FFT_BLOCK)
         fft_strided_lines(c, spec + 2 * ((size_t)x * n * nzh + kz), (size_t)nzh, nzh - kz < ORC_FFT_BLOCK ? nzh - kz : ORC_FFT_BLOCK, sign, lines);
     /* x lines: fixed (y,kz), stride n*nzh */
-#pragma omp for schedule(static)
+#pragma omp for schedule(dynamic, 1)
     for (int y = 0; y < n; y++)
       for (int kz = 0; kz < nzh; kz += ORC_FFT_BLOCK)
         fft_strided_lines(c, spec + 2 * ((size_t)y * nzh + kz), (size_t)n * nzh, nzh - kz < ORC_FFT_BLOCK ? nzh - kz : ORC_FFT_BLOCK, sign, lines);
@@ -187,7 +190,7 @@ static void c2r_3d(orc_ctx *c, double *spec, double *real_out) {
 #pragma omp parallel num_threads(c->nthreads)
   {
     double *line = (double *)malloc(sizeof(double) * 2 * n);
-#pragma omp for schedule(static)
+#pragma omp for schedule(dynamic, 1)
     for (int x = 0; x < n; x++)
       for (int y = 0; y < n; y++) {
         const double *h = spec + 2 * ((size_t)x * n + y) * nzh;
@@ -209,7 +212,7 @@ static void r2c_3d(orc_ctx *c, const double *real_in, double *spec) {
 #pragma omp parallel num_threads(c->nthreads)
   {
     double *line = (double *)malloc(sizeof(double) * 2 * n);
-#pragma omp for schedule(static)
+#pragma omp for schedule(dynamic, 1)
     for (int x = 0; x < n; x++)
       for (int y = 0; y < n; y++) {
         const double *r = real_in + ((size_t)x * n + y) * n;
@@ -274,7 +277,7 @@ static int compute_derivative(orc_ctx *c, int first_derivative, int second_deriv
   }
   double *cv = c->cvector;
 
-#pragma omp parallel for num_threads(c->nthreads) schedule(static)
+#pragma omp parallel for num_threads(c->nthreads) schedule(dynamic, 1)
   for (int idx = 0; idx < n; idx++) {
     int ii[3];
     ii[0] = idx;

@@ -244,7 +244,7 @@ template <bool FAST> PF_HD double pf_pow_third(double x) {
   // needed to ~1e-2 only: exponent plus a quadratic in the mantissa (log2 m on [1/2, 1) to 0.009)
   int e;
   const double m = frexp(x, &e);
-  const double log2x = (double)e + fma(fma(-1.34752114, m, 3.98979292), m, -2.64898574);
+  const double log2x = (double)e + pf_horner(pf_horner(-1.34752114, m, 3.98979292), m, -2.64898574);
   return cbrt(x) * fma(log2x, -(3.515706244646329e-16 * 0.6931471805599453), 1.0);
 }
 // exp and 10^y of the fast flavour in 20 and 21 operations (the library calls cost 42 and 44 on gfx950, half of them
@@ -326,8 +326,10 @@ PF_HD double pf_log10_pos(double x) {
   const double s = pf_div_fast(f, 2.0 + f);
   const double z = s * s;
   const double w = z * z;
-  const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
-  const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
+  // (pf_horner: one v_fma_f64 per step -- as plain fma calls the coefficient, which lives on in its registers, is copied in
+  //  front of every two-address v_fmac_f64; same operations, same rounding)
+  const double t1 = w * pf_horner(w, pf_horner(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+  const double t2 = z * pf_horner(w, pf_horner(w, pf_horner(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
   const double R = t2 + t1;
   const double hfsq = 0.5 * f * f;
   const double dk = (double)e;

@@ -345,8 +345,11 @@ __global__ void __launch_bounds__(6 * (N / 16)) k_c2r_invariants(const PfC2RPara
     }
     line_sync();
     if (R + gridDim.x < nrows) fetch(R + gridDim.x);  // in flight during the stages and the reduction below
+#ifndef PF_ZI_HOIST_TW
+#define PF_ZI_HOIST_TW 0
+#endif
     PfStages<F, M, +1, 2, 0, (NT <= 64)>::run(
-        v, tlj, tw, [&](int pos, C val) { L[pf_lpad(pos)] = val; }, [&](int pos) { return L[pf_lpad(pos)]; });
+        v, tlj, tw, [&](int pos, C val) { L[pf_lpad(pos)] = val; }, [&](int pos) { return L[pf_lpad(pos)]; }, PF_ZI_HOIST_TW ? tl : -1);
     line_sync();  // every thread of the line is done with the exchange area
     // the real row of this component, in order, into its line
     C *H = L;

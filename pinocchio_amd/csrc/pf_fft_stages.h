@@ -29,16 +29,20 @@ struct PfStages {
     if constexpr (WAVE_LOCAL) pf_wave_sync(); else __syncthreads();
   }
   // entry (S = 0): stage 0 has no twiddles
+  // tl_tw: the same thread index, as the twiddle side sees it.  A row loop that hides its index from the optimiser (so that
+  // addresses are not hoisted into ~250 registers) may pass the plain, loop-invariant one here: the table values AND their
+  // powers w^2 .. w^7 are then formed once, outside the loop (48 registers for a 512-point line).
   template <typename WR, typename RD>
-  static __device__ __forceinline__ void run(pfc<F> (&v)[8], int tl, const pfc<F> *__restrict__ tw, WR wr, RD rd) {
+  static __device__ __forceinline__ void run(pfc<F> (&v)[8], int tl, const pfc<F> *__restrict__ tw, WR wr, RD rd, int tl_tw = -1) {
     static_assert(!WAVE_LOCAL || N / 8 <= 64, "a wave-local transform has at most 64 threads");
-    if constexpr (S == 0) pf_stage<F, N, 0, DIR, TWS>(v, tl, tw);
+    const int tt = tl_tw < 0 ? tl : tl_tw;
+    if constexpr (S == 0) pf_stage<F, N, 0, DIR, TWS>(v, tt, tw);
     if constexpr (S + 1 < pf_nstages(N)) {
       pfc<F> w[8 / pf_radix(N, S + 1)];
-      pf_stage_twiddles<F, N, S + 1, DIR, TWS>(tl, tw, w);
+      pf_stage_twiddles<F, N, S + 1, DIR, TWS>(tt, tw, w);
       exchange(v, tl, wr, rd);
       pf_stage_apply<F, N, S + 1, DIR>(v, w);
-      PfStages<F, N, DIR, TWS, S + 1, WAVE_LOCAL>::run(v, tl, tw, wr, rd);
+      PfStages<F, N, DIR, TWS, S + 1, WAVE_LOCAL>::run(v, tl, tw, wr, rd, tl_tw);
     }
   }
 };
