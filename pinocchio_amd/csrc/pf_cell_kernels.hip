@@ -61,9 +61,20 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
     }
   }
   __syncthreads();
-  if (!TAB) {  // interval-search start table over the knots now in LDS
-    for (int b = threadIdx.x; b < PF_SPLINE_LUT_BINS; b += blockDim.x) slut[b] = pf_spline_lut_entry(sk, nk, b);
+  double lut_x0 = 0.0, lut_inv_w = 0.0;
+  int lut_direct = 0;
+  if (!TAB) {  // interval-search start table over the knots now in LDS: the direct form if no bin holds two knots, else the walk form
+    pf_spline_lut_geometry(sk, nk, true, lut_x0, lut_inv_w);
+    for (int b = threadIdx.x; b < PF_SPLINE_LUT_BINS; b += blockDim.x) slut[b] = pf_spline_lut_entry(sk, nk, b, lut_x0, lut_inv_w, true);
     __syncthreads();
+    int crowded = 0;
+    for (int b = threadIdx.x; b + 1 < PF_SPLINE_LUT_BINS; b += blockDim.x) crowded |= (int)slut[b + 1] - (int)slut[b] > 1;
+    lut_direct = __syncthreads_or(crowded) ? 0 : 1;
+    if (!lut_direct) {
+      pf_spline_lut_geometry(sk, nk, false, lut_x0, lut_inv_w);
+      for (int b = threadIdx.x; b < PF_SPLINE_LUT_BINS; b += blockDim.x) slut[b] = pf_spline_lut_entry(sk, nk, b, lut_x0, lut_inv_w, false);
+      __syncthreads();
+    }
   }
   pf_ct_view tv;
   tv.delta = sk; tv.y = p.ct.y; tv.b = p.ct.b; tv.c = p.ct.c; tv.d = p.ct.d; tv.ampl = p.ct.ampl;
@@ -77,7 +88,7 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
     sc.Omega0 = p.ct.sng_cosmo[0]; sc.OmegaLambda = p.ct.sng_cosmo[1]; sc.OmegaRad = p.ct.sng_cosmo[2]; sc.OmegaK = p.ct.sng_cosmo[3];
     sc.FR0 = p.ct.sng_cosmo[4]; sc.H_over_c = p.ct.sng_cosmo[5]; sc.size = p.ct.sng_cosmo[6];
   }
-  if (!TAB && !p.no_lut) { sv.lut = slut; sv.lut_inv_w = (double)PF_SPLINE_LUT_BINS / (sk[nk - 1] - sk[0]); }
+  if (!TAB && !p.no_lut) { sv.lut = slut; sv.lut_inv_w = lut_inv_w; sv.lut_x0 = lut_x0; sv.lut_direct = lut_direct; sv.x_first = sk[0]; sv.x_last = sk[nk - 1]; }
 
   const F *__restrict__ h0 = (const F *)p.h[0], *__restrict__ h1 = (const F *)p.h[1],
           *__restrict__ h2 = (const F *)p.h[2], *__restrict__ h3 = (const F *)p.h[3],

@@ -42,41 +42,77 @@
 struct pf_spline_view {
   const double *x, *y, *c, *b, *d;
   int n;
-  // optional start index per bin of a uniform grid over [x[0], x[n-1]] (pf_spline_lut_build): the interval search then
-  // walks forward from there (0-2 steps for the growth table) instead of bisecting; the interval found is the same
+  // optional start index per bin of a uniform grid (pf_spline_lut_*): the interval search starts there instead of bisecting;
+  // the interval found is the same (host test against GSL's bisection on even and wildly uneven knots).  Two geometries:
+  //   walk   : PF_SPLINE_LUT_BINS bins over [x[0], x[n-1]]; the search starts one bin early and walks forward (any knots)
+  //   direct : bins of width 2^k from a multiple of 2^k (the bin of v is then exact up to a sliver of one rounding below a
+  //            bin edge, where it may come out one too high); usable when no bin holds more than one knot, i.e. when the
+  //            table entries of neighbouring bins differ by at most one: the interval is lut[bin] or one of its two
+  //            neighbours, decided by two comparisons with a pair of knots read together -- no loop
   const unsigned short *lut = nullptr;
-  double lut_inv_w = 0.0;
+  double lut_inv_w = 0.0, lut_x0 = 0.0;
+  int lut_direct = 0;
+  double x_first = 0.0, x_last = 0.0;  // x[0], x[n-1] when lut is set (registers instead of two broadcast reads per call)
 };
-#define PF_SPLINE_LUT_BINS 1024
+#define PF_SPLINE_LUT_BINS 4096
 
 PF_HD double pf_spline_eval(const pf_spline_view &s, double v) {
   const double *xa = s.x, *ya = s.y, *ca = s.c;
   const int last = s.n - 1;
-  if (v < xa[0]) return ya[0] + (v - xa[0]) * (ya[1] - ya[0]) / (xa[1] - xa[0]);
-  if (v > xa[last])
+  const double x0 = s.lut ? s.x_first : xa[0], xl = s.lut ? s.x_last : xa[last];
+  if (v < x0) return ya[0] + (v - xa[0]) * (ya[1] - ya[0]) / (xa[1] - xa[0]);
+  if (v > xl)
     return ya[last] + (v - xa[last]) * (ya[last] - ya[last - 1]) / (xa[last] - xa[last - 1]);
   // gsl_interp_bsearch(xa, v, 0, n-1): the largest i <= n-2 with xa[i] <= v
   int ilo = 0;
-  if (s.lut) {
-    int bin = (int)((v - xa[0]) * s.lut_inv_w) - 1;  // one bin early: immune to the rounding of the bin index
+  double xlo;
+  if (s.lut && s.lut_direct) {
+    int bin = (int)((v - s.lut_x0) * s.lut_inv_w);
     bin = bin < 0 ? 0 : (bin > PF_SPLINE_LUT_BINS - 1 ? PF_SPLINE_LUT_BINS - 1 : bin);
-    ilo = s.lut[bin];
-    while (ilo + 1 < last && xa[ilo + 1] <= v) ilo++;
+    const int st = s.lut[bin];
+    const double xs = xa[st], xn = xa[st + 1];  // st <= n-2: both in range
+    const bool up = st + 1 < last && xn <= v;
+    ilo = up ? st + 1 : st;
+    xlo = up ? xn : xs;
+    if (xs > v) { ilo = st - 1; xlo = xa[ilo]; }  // the sliver below a bin edge with a knot on that edge (v >= x[0], so st >= 1 here)
   } else {
-    int ihi = last;
-    while (ihi > ilo + 1) {
-      int i = (ihi + ilo) >> 1;
-      if (xa[i] > v) ihi = i; else ilo = i;
+    if (s.lut) {
+      int bin = (int)((v - x0) * s.lut_inv_w) - 1;  // one bin early: immune to the rounding of the bin index
+      bin = bin < 0 ? 0 : (bin > PF_SPLINE_LUT_BINS - 1 ? PF_SPLINE_LUT_BINS - 1 : bin);
+      ilo = s.lut[bin];
+      while (ilo + 1 < last && xa[ilo + 1] <= v) ilo++;
+    } else {
+      int ihi = last;
+      while (ihi > ilo + 1) {
+        int i = (ihi + ilo) >> 1;
+        if (xa[i] > v) ihi = i; else ilo = i;
+      }
     }
+    xlo = xa[ilo];
   }
-  const double delx = v - xa[ilo];
+  const double delx = v - xlo;
   return ya[ilo] + delx * (s.b[ilo] + delx * (ca[ilo] + delx * s.d[ilo]));
 }
 
-// lut[bin] = largest i <= n-2 with x[i] <= x[0] + bin * w, w = (x[n-1] - x[0]) / PF_SPLINE_LUT_BINS; one entry per call
-PF_HD unsigned short pf_spline_lut_entry(const double *xa, int n, int bin) {
-  const double w = (xa[n - 1] - xa[0]) / (double)PF_SPLINE_LUT_BINS;
-  const double v = xa[0] + bin * w;
+// geometry of the start table for knots xa[0..n-1].  Direct form: bin width w = 2^k, the smallest power of two that covers the
+// knot range with PF_SPLINE_LUT_BINS - 1 bins, first bin edge x0 = the multiple of w at or below xa[0] (bin edges x0 + b w are
+// then exact doubles and (v - x0) / w is exact at every edge).  Walk form: PF_SPLINE_LUT_BINS equal bins over the knot range.
+PF_HD void pf_spline_lut_geometry(const double *xa, int n, bool direct, double &x0, double &inv_w) {
+  const double range = xa[n - 1] - xa[0];
+  if (direct) {
+    int e;
+    (void)frexp(range / (double)(PF_SPLINE_LUT_BINS - 2), &e);  // 2^(e-1) <= range / (B - 2) < 2^e
+    const double w = ldexp(1.0, e);
+    x0 = floor(xa[0] / w) * w;
+    inv_w = ldexp(1.0, -e);
+  } else {
+    x0 = xa[0];
+    inv_w = (double)PF_SPLINE_LUT_BINS / range;
+  }
+}
+// lut[bin] = largest i <= n-2 with x[i] <= lower edge of the bin (0 when the edge lies below x[0]); one entry per call
+PF_HD unsigned short pf_spline_lut_entry(const double *xa, int n, int bin, double x0, double inv_w, bool direct) {
+  const double v = direct ? x0 + (double)bin / inv_w : xa[0] + bin * ((xa[n - 1] - xa[0]) / (double)PF_SPLINE_LUT_BINS);
   int ilo = 0, ihi = n - 1;
   while (ihi > ilo + 1) {
     int i = (ihi + ilo) >> 1;

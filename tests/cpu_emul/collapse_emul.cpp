@@ -64,13 +64,22 @@ extern "C" int emul_spline_lut(const double *sx, const double *sy, int nk, const
   std::vector<double> c(nk), b(nk), dd(nk);
   if (pf_spline_coeffs(sx, sy, nk, c.data())) return 1;
   pf_spline_bd(sx, sy, c.data(), nk, b.data(), dd.data());
+  // the table exactly as the kernel prologue builds it (pf_collapse_body): direct form unless a bin holds two knots
   std::vector<unsigned short> lut(PF_SPLINE_LUT_BINS);
-  for (int i = 0; i < PF_SPLINE_LUT_BINS; i++) lut[i] = pf_spline_lut_entry(sx, nk, i);
+  double x0, inv_w;
+  bool direct = true;
+  pf_spline_lut_geometry(sx, nk, true, x0, inv_w);
+  for (int i = 0; i < PF_SPLINE_LUT_BINS; i++) lut[i] = pf_spline_lut_entry(sx, nk, i, x0, inv_w, true);
+  for (int i = 0; i + 1 < PF_SPLINE_LUT_BINS; i++) if ((int)lut[i + 1] - (int)lut[i] > 1) direct = false;
+  if (!direct) {
+    pf_spline_lut_geometry(sx, nk, false, x0, inv_w);
+    for (int i = 0; i < PF_SPLINE_LUT_BINS; i++) lut[i] = pf_spline_lut_entry(sx, nk, i, x0, inv_w, false);
+  }
   pf_spline_view s{sx, sy, c.data(), b.data(), dd.data(), nk};
   s.lut = lut.data();
-  s.lut_inv_w = (double)PF_SPLINE_LUT_BINS / (sx[nk - 1] - sx[0]);
+  s.lut_inv_w = inv_w; s.lut_x0 = x0; s.lut_direct = direct ? 1 : 0; s.x_first = sx[0]; s.x_last = sx[nk - 1];
   for (long i = 0; i < count; i++) out[i] = pf_spline_eval(s, v[i]);
-  return 0;
+  return direct ? 2 : 0;  // (0 / 2: which form of the table was used; 1 is an error)
 }
 
 extern "C" void emul_div_const(const double *x, long count, double *q9, double *q54) {

@@ -154,21 +154,29 @@ def test_ell_sng_header_matches_oracle_bitwise(emul):
 
 
 def test_spline_interval_table_finds_the_bisection_interval(emul):
-    """the start-index table of k_collapse's spline lookup against plain bisection: identical values at the knots,
-    next to them (one ulp either side), at bin edges and at random abscissae; uniform and very uneven knot sets"""
+    """the start-index table of k_collapse's spline lookup against plain bisection: identical values at the knots, next to
+    them (one ulp either side), at the bin edges of both table geometries and at random abscissae.  Knot sets: the growth
+    table (direct form: bins of width 2^k, no loop), knots ON power-of-two multiples (direct form, with knots exactly on bin
+    edges: the sliver below an edge where the bin index comes out one too high), spacings over 24 orders of magnitude (two
+    knots in a bin: the walk form), and a three-knot spline"""
     emul.emul_spline_lut.argtypes = [dp, dp, C.c_int, dp, C.c_long, dp]
     rng = np.random.default_rng(2)
     x1, y1 = synth.invgrow_table("lcdm")
     x2 = np.cumsum(np.concatenate([[0.0], rng.uniform(1e-6, 1.0, 209) ** 4])) - 3.0   # spacings over 24 orders of magnitude
     y2 = np.sin(x2)
-    for x, y in ((x1, y1), (x2, y2), (x1[:3], y1[:3])):
+    x3 = -4.0 + 0.03125 * np.arange(210)                                              # knots on multiples of 2^-5
+    y3 = np.cos(x3)
+    for x, y, form in ((x1, y1, 2), (x2, y2, 0), (x3, y3, 2), (x1[:3], y1[:3], 2)):
         n = len(x)
-        edges = x[0] + (x[-1] - x[0]) / 1024.0 * np.arange(1025)
+        edges = x[0] + (x[-1] - x[0]) / 4096.0 * np.arange(4097)
+        w = 2.0 ** np.ceil(np.log2((x[-1] - x[0]) / 4094.0) + 1e-12)
+        e2 = np.floor(x[0] / w) * w + w * np.arange(4097)                              # the direct form's bin edges
+        e2 = e2[(e2 >= x[0]) & (e2 <= x[-1])]
         v = np.concatenate([x, np.nextafter(x, -np.inf), np.nextafter(x, np.inf), edges, np.nextafter(edges, -np.inf),
-                            rng.uniform(x[0] - 0.5, x[-1] + 0.5, 20000)])
+                            e2, np.nextafter(e2, -np.inf), np.nextafter(e2, np.inf), rng.uniform(x[0] - 0.5, x[-1] + 0.5, 20000)])
         a = np.empty(len(v)); b = np.empty(len(v))
         assert emul.emul_spline(_dp(x), _dp(y), n, _dp(v), len(v), _dp(a)) == 0
-        assert emul.emul_spline_lut(_dp(x), _dp(y), n, _dp(v), len(v), _dp(b)) == 0
+        assert emul.emul_spline_lut(_dp(x), _dp(y), n, _dp(v), len(v), _dp(b)) == form
         assert np.array_equal(a, b)
 
 
