@@ -1,7 +1,7 @@
 // pf_api.hip -- context, slab 3-D FFT pipelines and the C ABI of libpinfmax_hip.so.
 //
 // Data layout in HBM (per rank; P ranks, nxl = nyl = n/P, nzh = n/2+1,
-// nzp = n/2+8 so that every row of a half-spectrum starts on a 128-byte line):
+// nzp = n/2+8 (fp64; n/2+16 for fp32 fields) so that every row of a half-spectrum starts on a 128-byte line):
 //   KY  k-space, y-distributed : [n (kx)][nyl (ky slab)][nzp]  complex F   (dk, A*, S* spectra)
 //   XS  x-slab, k in y and z   : [nxl][n (ky)][nzp]            complex F   (B*)
 //   R   real x-slab            : [nxl][n][2*nzp]               F, first n of a row used
@@ -349,7 +349,7 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
     return pf_fail(rank, "pf_create: no HIP device available (libpinfmax_hip has no CPU path)");
   if (cfg->device < 0 || cfg->device >= ndev) return pf_fail(rank, "pf_create: device %d out of range (%d devices)", cfg->device, ndev);
   pf_ctx *c = new pf_ctx();
-  c->cfg = *cfg; c->rank = rank; c->P = cfg->nranks; c->n = (int)n; c->nzh = c->n / 2 + 1; c->nzp = c->n / 2 + 8;
+  c->cfg = *cfg; c->rank = rank; c->P = cfg->nranks; c->n = (int)n; c->nzh = c->n / 2 + 1; c->nzp = c->n / 2 + 64 / cfg->field_bytes;  // rows of whole 128-byte lines: + 8 complex (fp64), + 16 (fp32)
   c->tune = tune; c->dev = cfg->device; c->inv_reruns = 0;
   c->general = want_general; c->fft_c2r = c->fft_r2c = nullptr; c->W = nullptr;
   if (c->general) c->nzp = c->nzh;  // natural layout [n][n][n/2+1], the boundary layout itself
@@ -442,10 +442,11 @@ static int exchange(pf_ctx *c, const void *send, void *recv, hipStream_t st = nu
 // same offset in each of its P send blocks: rank p owns ky = p*nyl .. (p+1)*nyl - 1, in band if ky <= band or
 // ky >= n - band (one interval per rank once P >= 2, band < n/2).  Ranks without in-band rows send nothing.
 // ... and of those rows only the in-band kz columns: the blocks of a pruned item use the compact row pitch below
-// (a multiple of 8 complex = 128 bytes) instead of nzp, in the x-pass output, the exchange and the y-pass input alike
+// (a multiple of 128 bytes: 8 complex fp64, 16 fp32) instead of nzp, in the x-pass output, the exchange and the y-pass input alike
 static int band_zpitch(const pf_ctx *c, int band) {
   if (band >= c->n / 2) return c->nzp;
-  const int zp = (band + 1 + 7) & ~7;
+  const int m = 64 / c->fb;  // complex numbers per 128-byte line
+  const int zp = (band + 1 + m - 1) & ~(m - 1);
   return zp < c->nzp ? zp : c->nzp;
 }
 static void band_rows(const pf_ctx *c, int p, int band, int *lo, int *hi) {

@@ -37,6 +37,21 @@ template <int DIR, typename F> PF_HD pfc<F> pf_mul_i(pfc<F> a) {
   return DIR > 0 ? pf_mk<F>(-a.y, a.x) : pf_mk<F>(a.y, -a.x);
 }
 
+// The scalar behind a field type: itself, or the lane type of a two-lane vector.  pfc<pf_f32x2> is TWO neighbouring fp32
+// columns carried by one thread -- x = (re of column 0, re of column 1), y = the imaginary parts -- so that every operation
+// of the transforms below is one packed instruction for both (v_pk_fma_f32 and friends: the fp32 rate of the chip is quoted
+// on them), twiddles and k factors are shared, and a thread's loads, stores and LDS exchanges move 16 bytes as in the fp64
+// kernels.  Lane by lane the arithmetic is that of pfc<float>.
+#if defined(__HIPCC__)
+typedef float pf_f32x2 __attribute__((ext_vector_type(2)));
+#endif
+template <typename F> struct pf_lane { typedef F type; static constexpr int n = 1; };
+#if defined(__HIPCC__)
+template <> struct pf_lane<pf_f32x2> { typedef float type; static constexpr int n = 2; };
+#endif
+template <typename F> PF_HD pfc<F> pf_bcast(pfc<typename pf_lane<F>::type> a) { return pf_mk<F>((F)a.x, (F)a.y); }
+template <typename F> PF_HD pfc<F> pf_zero() { return pf_mk<F>((F)0, (F)0); }
+
 // streaming (non-temporal) access to once-touched field data.  On since the strided passes move whole 128-byte lines (128 KB tiles):
 // three interleaved runs each on one box, x-pass 5.96 -> 5.45, y-pass 11.26 -> 10.85, z-passes -0.2..-0.4 ms per launch, 827.6 (826..830) ->
 // 808.2 (805..811) ms per step.  With 64-byte segments it cost the y-pass 13 % (round 1): half lines no longer merged in L2.
@@ -88,9 +103,12 @@ template <int DIR, typename F> PF_HD void pf_bfly8(pfc<F> (&u)[8]) {
   pf_bfly4<DIR>(u[0], u[2], u[4], u[6]);  // E_0..3 in u[0],u[2],u[4],u[6]
   pf_bfly4<DIR>(u[1], u[3], u[5], u[7]);  // O_0..3 in u[1],u[3],u[5],u[7]
   const F h = (F)0.70710678118654752440;
-  pfc<F> o1 = pf_mk<F>(h * (u[3].x - DIR * u[3].y), h * (u[3].y + DIR * u[3].x));  // W8^1 = h(1, DIR)
+  // (DIR = +-1 written out: the same operations, and no int * vector products for the two-lane field type)
+  pfc<F> o1 = DIR > 0 ? pf_mk<F>(h * (u[3].x - u[3].y), h * (u[3].y + u[3].x))      // W8^1 = h(1, DIR)
+                      : pf_mk<F>(h * (u[3].x + u[3].y), h * (u[3].y - u[3].x));
   pfc<F> o2 = pf_mul_i<DIR>(u[5]);                                                  // W8^2 = DIR i
-  pfc<F> o3 = pf_mk<F>(h * (-u[7].x - DIR * u[7].y), h * (-u[7].y + DIR * u[7].x)); // W8^3 = h(-1, DIR)
+  pfc<F> o3 = DIR > 0 ? pf_mk<F>(h * (-u[7].x - u[7].y), h * (-u[7].y + u[7].x))    // W8^3 = h(-1, DIR)
+                      : pf_mk<F>(h * (-u[7].x + u[7].y), h * (-u[7].y - u[7].x));
   pfc<F> e0 = u[0], e1 = u[2], e2 = u[4], e3 = u[6], o0 = u[1];
   u[0] = e0 + o0; u[4] = e0 - o0;
   u[1] = e1 + o1; u[5] = e1 - o1;
@@ -118,7 +136,7 @@ constexpr int pf_ntw_total(int n) { return pf_ntw_before(n, pf_nstages(n)); }
 // (arrays by reference and compile-time offsets: the values must stay in registers -- through a pointer the compiler puts
 //  them in scratch memory, and a scratch reload waits on the same in-order counter as every global load before it)
 template <typename F, int N, int S, int DIR, int TWS, int OFF = 0, int NW>
-PF_HD void pf_stage_twiddles(int tl, const pfc<F> *__restrict__ tw, pfc<F> (&w)[NW]) {
+PF_HD void pf_stage_twiddles(int tl, const pfc<typename pf_lane<F>::type> *__restrict__ tw, pfc<F> (&w)[NW]) {
   constexpr int R = pf_radix(N, S), NS = pf_ns(N, S), Q = 8 / R, NT = N / 8;
   constexpr int TWM = (N / (NS * R)) * TWS;
   if (NS > 1) {
@@ -126,7 +144,7 @@ PF_HD void pf_stage_twiddles(int tl, const pfc<F> *__restrict__ tw, pfc<F> (&w)[
     for (int q = 0; q < Q; q++) {
       const int jb = tl + q * NT;
       const int k = jb & (NS - 1);
-      w[OFF + q] = tw[k * TWM];
+      w[OFF + q] = pf_bcast<F>(tw[k * TWM]);
       if (DIR < 0) w[OFF + q].y = -w[OFF + q].y;
     }
   }
@@ -168,7 +186,7 @@ PF_HD void pf_stage_apply(pfc<F> (&v)[8], const pfc<F> (&w)[NW]) {
 
 // stage S with its twiddles fetched on the spot
 template <typename F, int N, int S, int DIR, int TWS>
-PF_HD void pf_stage(pfc<F> (&v)[8], int tl, const pfc<F> *__restrict__ tw) {
+PF_HD void pf_stage(pfc<F> (&v)[8], int tl, const pfc<typename pf_lane<F>::type> *__restrict__ tw) {
   pfc<F> w[8 / pf_radix(N, S)];
   pf_stage_twiddles<F, N, S, DIR, TWS>(tl, tw, w);
   pf_stage_apply<F, N, S, DIR>(v, w);

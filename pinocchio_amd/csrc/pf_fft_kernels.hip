@@ -35,9 +35,52 @@ __device__ __forceinline__ long long pf_xcd_swizzle(long long b, long long per_x
 #ifndef PF_SLAB_STORE
 #define PF_SLAB_STORE 1  // (0 in an A/B build, profiles/tools/ab.sh: the kernel without the slab-store branch)
 #endif
+// How a thread of the strided passes reaches its column(s) in HBM.  One column per thread (fp64 fields; fp32 lines below 1024
+// points): an element is one complex.  Two neighbouring columns per thread (F = pf_f32x2: fp32 lines of 1024 points and more,
+// where the thread budget of a workgroup, not LDS, limits the tile): an element is 16 bytes -- both columns of a row in one
+// load / store -- so that a tile's row segments are 128 bytes (64 at 2048 points) as in the fp64 passes, and the arithmetic is
+// packed (pf_fft_core.h).  Offsets are in complex numbers of the lane type; `v1`: the second column exists (the number of
+// columns, n/2 + 1 or band + 1, may be odd).
+template <typename F> struct PfCols {
+  using S = F;
+  static constexpr int n = 1;
+  static __device__ __forceinline__ pfc<F> load(const pfc<S> *base, long long off) { return pf_ld_stream(base + off); }
+  static __device__ __forceinline__ void store(pfc<S> *base, long long off, pfc<F> v, bool) { pf_st_stream(base + off, v); }
+};
+template <> struct PfCols<pf_f32x2> {
+  using S = float;
+  static constexpr int n = 2;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ pfc<pf_f32x2> load(const pfc<float> *base, long long off) {
+#if PF_NT
+    const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(base + off));
+#else
+    const f4 t = *reinterpret_cast<const f4 *>(base + off);
+#endif
+    pfc<pf_f32x2> r;
+    r.x = (pf_f32x2){t.x, t.z}; r.y = (pf_f32x2){t.y, t.w};
+    return r;
+  }
+  static __device__ __forceinline__ void store(pfc<float> *base, long long off, pfc<pf_f32x2> v, bool v1) {
+    if (v1) {
+      const f4 t = (f4){v.x.x, v.y.x, v.x.y, v.y.y};
+#if PF_NT
+      __builtin_nontemporal_store(t, reinterpret_cast<f4 *>(base + off));
+#else
+      *reinterpret_cast<f4 *>(base + off) = t;
+#endif
+    } else {
+      pf_st_stream(base + off, pf_mk<float>(v.x.x, v.y.x));
+    }
+  }
+};
+
 template <typename F, int N, int T, int DIR>
 __global__ void __launch_bounds__(T *N / 8) __attribute__((amdgpu_waves_per_eu(4))) k_strided(const PfStridedParams p, const long long nwork, const int ntiles) {
   using C = pfc<F>;
+  using COLS = PfCols<F>;
+  using S = typename COLS::S;  // scalar of the field in memory
+  constexpr int NL = COLS::n;  // columns per thread
   constexpr int NT = N / 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   C *lds = reinterpret_cast<C *>(smem);  // [N][T]
@@ -47,9 +90,9 @@ __global__ void __launch_bounds__(T *N / 8) __attribute__((amdgpu_waves_per_eu(4
   const int c = tid % T, tl = tid / T;
   const int tile = (int)(w % ntiles);
   const int outer = (int)(w / ntiles);
-  const int col = tile * T + c;
-  const bool valid = col < p.ncols;
-  const C *__restrict__ tw = reinterpret_cast<const C *>(p.tw);
+  const int col = NL * (tile * T + c);    // (first) column of this thread
+  const bool valid = col < p.ncols, valid1 = NL > 1 && col + 1 < p.ncols;
+  const pfc<S> *__restrict__ tw = reinterpret_cast<const pfc<S> *>(p.tw);
   const double kf = 2.0 * 3.14159265358979323846 / (double)N;
   if (p.band_outer < N / 2) {  // whole line of tiles outside the band of the smoothed spectrum: its output is never read
     int so = outer + p.outer_offset;
@@ -59,17 +102,37 @@ __global__ void __launch_bounds__(T *N / 8) __attribute__((amdgpu_waves_per_eu(4
 
   C src[8], v[8];
   // a tile of input `in` into src: issued as early as src is free, consumed at the top of the job that uses it
+  // (two columns: the pair is loaded whole when its first column exists -- a row's padding holds the odd one out -- and the
+  //  second lane is cleared where it does not, so that nothing undefined enters the arithmetic)
   auto load_tile = [&](const void *inp, int tlj, int colj) {
-    const C *__restrict__ in = reinterpret_cast<const C *>(inp);
+    const pfc<S> *__restrict__ in = reinterpret_cast<const pfc<S> *>(inp);
 #pragma unroll
     for (int m = 0; m < 8; m++) {
       const int e = tlj + m * NT;
       const int se = e > N / 2 ? e - N : e;
       const bool inband = se <= p.band_e && se >= -p.band_e;
-      src[m] = (valid && inband) ? pf_ld_stream(&in[pf_addr(p.ain, outer, e, colj)]) : pf_mk<F>(0, 0);
+      src[m] = (valid && inband) ? COLS::load(in, pf_addr(p.ain, outer, e, colj)) : pf_zero<F>();
+      if constexpr (NL > 1) { if (!valid1) { src[m].x.y = 0.f; src[m].y.y = 0.f; } }
     }
   };
   load_tile(p.job[0].in, tl, col);
+  // first pass: window of the two untransformed axes times the growth factor, one exp per thread and column (none without
+  // smoothing).  Formed here, outside the loop over jobs: inside it the constants of exp() would live in ~24 registers
+  // through every job of the kernel.
+  double ko = 0.0, woc[NL];
+#pragma unroll
+  for (int l = 0; l < NL; l++) woc[l] = 1.0;
+  if (p.pre) {
+    int so = outer + p.outer_offset;
+    if (so > N / 2) so -= N;
+    ko = kf * so;
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+      const double kc = kf * (col + l);
+      const double ko2kc2 = ko * ko + kc * kc;
+      woc[l] = (p.rs != 0.0 ? exp(-0.5 * ko2kc2 * p.rs * p.rs) : 1.0) * p.growth;
+    }
+  }
 #pragma unroll 1
   for (int j = 0; j < p.njobs; j++) {
     // Everything below is loop invariant except the job; left to LICM the compiler hoists every
@@ -77,30 +140,31 @@ __global__ void __launch_bounds__(T *N / 8) __attribute__((amdgpu_waves_per_eu(4
     // opaque copy of the thread coordinates per iteration keeps the index math where it is used.
     int tlj = tl, cj = c;
     asm volatile("" : "+v"(tlj), "+v"(cj));
-    const int colj = tile * T + cj;
+    const int colj = NL * (tile * T + cj);
     // jobs are grouped by input: a tile is read from HBM once and transformed for every job that uses it
     if (p.pre && (j == 0 || p.job[j].in != p.job[j - 1].in)) {
-      int so = outer + p.outer_offset;
-      if (so > N / 2) so -= N;
-      const double ko = kf * so, kc = kf * colj;
-      const double ko2kc2 = ko * ko + kc * kc;
-      // window of the two untransformed axes times the growth factor: one exp per thread (none without smoothing)
-      const double woc = (p.rs != 0.0 ? exp(-0.5 * ko2kc2 * p.rs * p.rs) : 1.0) * p.growth;
+      // 1 / k^2 and the window along the transformed axis, column after column (one set of fp64 temporaries alive at a time)
 #pragma unroll
-      for (int m = 0; m < 8; m++) {
-        const int e = tlj + m * NT;
-        const double ke = kf * (e > N / 2 ? e - N : e);
-        const double k2 = ke * ke + ko2kc2;
-        const double we = p.rs != 0.0 ? p.etab[e] : 1.0;
-        const double fac = (k2 != 0.0) ? we * woc / k2 : 0.0;
-        src[m] = pf_scale(src[m], (F)fac);
+      for (int l = 0; l < NL; l++) {
+        const double kc = kf * (colj + l);
+        const double ko2kc2 = ko * ko + kc * kc;
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          const int e = tlj + m * NT;
+          const double ke = kf * (e > N / 2 ? e - N : e);
+          const double k2 = ke * ke + ko2kc2;
+          const double we = p.rs != 0.0 ? p.etab[e] : 1.0;
+          const S fac = (S)((k2 != 0.0) ? we * woc[l] / k2 : 0.0);
+          if constexpr (NL > 1) { src[m].x[l] = src[m].x[l] * fac; src[m].y[l] = src[m].y[l] * fac; }
+          else src[m] = pf_scale(src[m], (F)fac);
+        }
       }
     }
     const int mul = p.job[j].mul;
 #pragma unroll
     for (int m = 0; m < 8; m++) {
       const int e = tlj + m * NT;
-      const F ke = (F)(kf * (e > N / 2 ? e - N : e));
+      const F ke = (F)(S)(kf * (e > N / 2 ? e - N : e));
       C x = src[m];
       if (mul == PF_MUL_K) x = pf_scale(x, ke);
       else if (mul == PF_MUL_K2) x = pf_scale(x, ke * ke);
@@ -112,18 +176,18 @@ __global__ void __launch_bounds__(T *N / 8) __attribute__((amdgpu_waves_per_eu(4
     PfStages<F, N, DIR, 1>::run(
         v, tlj, tw, [&](int pos, C val) { lds[pos * T + cj] = val; }, [&](int pos) { return lds[pos * T + cj]; });
     if (valid) {
-      C *__restrict__ out = reinterpret_cast<C *>(p.job[j].out);
+      pfc<S> *__restrict__ out = reinterpret_cast<pfc<S> *>(p.job[j].out);
       if (PF_SLAB_STORE && p.out_ne > 0) {  // uniform: the slab of the transformed axis this rank keeps
 #pragma unroll
         for (int m = 0; m < 8; m++) {
           const int e = tlj + m * NT;
-          if ((unsigned)(e - p.out_e0) < (unsigned)p.out_ne) pf_st_stream(&out[pf_addr(p.aout, outer, e, colj)], v[m]);
+          if ((unsigned)(e - p.out_e0) < (unsigned)p.out_ne) COLS::store(out, pf_addr(p.aout, outer, e, colj), v[m], valid1);
         }
       } else {
 #pragma unroll
         for (int m = 0; m < 8; m++) {
           const int e = tlj + m * NT;
-          pf_st_stream(&out[pf_addr(p.aout, outer, e, colj)], v[m]);
+          COLS::store(out, pf_addr(p.aout, outer, e, colj), v[m], valid1);
         }
       }
     }
@@ -476,7 +540,8 @@ template <typename F, int N> struct PfTileCols {
 template <typename F, int N, int DIR>
 static int launch_strided_n(const PfStridedParams &p, hipStream_t st) {
   constexpr int T = PfTileCols<F, N>::value;
-  const int ntiles = (p.ncols + T - 1) / T;
+  constexpr int NL = pf_lane<F>::n;  // columns per thread
+  const int ntiles = (p.ncols + NL * T - 1) / (NL * T);
   const long long nwork = (long long)ntiles * p.nouter;
   dim3 grid((unsigned)(((nwork + 7) >> 3) << 3), 1, 1), block(T * N / 8, 1, 1);
   const size_t shm = (size_t)N * T * sizeof(pfc<F>);
@@ -496,6 +561,16 @@ static int launch_strided_n(const PfStridedParams &p, hipStream_t st) {
   }
   hipLaunchKernelGGL((k_strided<F, N, T, DIR>), grid, block, shm, st, p, nwork, ntiles);
   return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+// fp32 lines of 1024 points and more: two columns per thread (the thread budget, 8 N / 8 <= 1024, would otherwise leave 64-byte
+// row segments at 1024 points and 32-byte ones at 2048); PF_F32_PAIRS=0 builds the one-column kernels for them too
+#ifndef PF_F32_PAIRS
+#define PF_F32_PAIRS 1
+#endif
+template <int N, int DIR>
+static int launch_strided_f32(const PfStridedParams &p, hipStream_t st) {
+  if constexpr (PF_F32_PAIRS && N >= 1024) return launch_strided_n<pf_f32x2, N, DIR>(p, st);
+  else return launch_strided_n<float, N, DIR>(p, st);
 }
 
 template <typename F, int N>
@@ -575,11 +650,11 @@ int pf_launch_strided(int fb, int n, int dir, const PfStridedParams &p, hipStrea
     }
   } else {
     if (dir > 0) {
-#define CALL(NN) launch_strided_n<float, NN, +1>(p, st)
+#define CALL(NN) launch_strided_f32<NN, +1>(p, st)
       PF_SWITCH_N(n, CALL)
 #undef CALL
     } else {
-#define CALL(NN) launch_strided_n<float, NN, -1>(p, st)
+#define CALL(NN) launch_strided_f32<NN, -1>(p, st)
       PF_SWITCH_N(n, CALL)
 #undef CALL
     }

@@ -33,7 +33,7 @@ struct PfStages {
   // addresses are not hoisted into ~250 registers) may pass the plain, loop-invariant one here: the table values AND their
   // powers w^2 .. w^7 are then formed once, outside the loop (48 registers for a 512-point line).
   template <typename WR, typename RD>
-  static __device__ __forceinline__ void run(pfc<F> (&v)[8], int tl, const pfc<F> *__restrict__ tw, WR wr, RD rd, int tl_tw = -1) {
+  static __device__ __forceinline__ void run(pfc<F> (&v)[8], int tl, const pfc<typename pf_lane<F>::type> *__restrict__ tw, WR wr, RD rd, int tl_tw = -1) {
     static_assert(!WAVE_LOCAL || N / 8 <= 64, "a wave-local transform has at most 64 threads");
     const int tt = tl_tw < 0 ? tl : tl_tw;
     if constexpr (S == 0) pf_stage<F, N, 0, DIR, TWS>(v, tt, tw);

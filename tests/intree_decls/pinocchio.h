@@ -57,7 +57,7 @@ typedef struct gsl_interp_accel_tag gsl_interp_accel;
 
 typedef struct /* src/pinocchio.h:311-352, the tags the adapter reads */
 {
-  double Omega0, OmegaLambda, OmegaBaryon, Hubble100, Sigma8, PrimordialIndex, BoxSize_htrue, k_for_GM;
+  double Omega0, OmegaLambda, OmegaBaryon, Hubble100, Sigma8, PrimordialIndex, BoxSize_htrue, k_for_GM, WDM_PartMass_in_kev;
   char RunFlag[SBLENGTH], DumpDir[SBLENGTH], CTtableFile[LBLENGTH], FileWithInputSpectrum[LBLENGTH];
   int GridSize[3], RandomSeed, use_transposed_fft, FixedIC, PairedIC;
 } param_data;
