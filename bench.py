@@ -56,13 +56,17 @@ def symbol_of(cls: str, n: int, fb: int, fast: bool = True) -> str:
     """kernel function behind a launch class, spelled as rocprofv3 prints it (csrc/pf_fft_kernels.hip dispatch tables)"""
     F = "double" if fb == 8 else "float"
     t = max(1, min(128 // (2 * fb), (128 * 1024) // (n * 2 * fb), 8192 // n))     # PfTileCols (128 KB of LDS per tile)
+    FS = F
+    if fb == 4 and n >= 1024:      # fp32 lines of 1024 points and more: two columns per thread, 16-byte elements (launch_strided_f32)
+        FS = "float __vector(2)"
+        t = max(1, min(8, (128 * 1024) // (n * 16), 8192 // n))
     nt = n // 16
     tl = 1 if nt >= 256 else 256 // nt
     b = "true" if fast else "false"
     if cls in ("xpass_hess_1to3", "ypass_hess_3to6", "xpass_disp_1to2", "ypass_disp_2to3", "xpass_plain", "ypass_plain"):
-        return f"k_strided<{F}, {n}, {t}, 1>"
+        return f"k_strided<{FS}, {n}, {t}, 1>"
     if cls in ("xpass_fwd", "ypass_fwd"):
-        return f"k_strided<{F}, {n}, {t}, -1>"
+        return f"k_strided<{FS}, {n}, {t}, -1>"
     if cls in ("zpass_c2r_hess_6", "zpass_c2r_disp_3", "zpass_c2r_plain"):
         return f"k_c2r_persistent<{F}, {n}, {tl}>"
     return {"zpass_c2r_hess_6to3inv": f"k_c2r_invariants<{F}, {n}, 0>", "zpass_c2r_hess_6_lpt3b": f"k_c2r_invariants<{F}, {n}, 1>",
