@@ -11,6 +11,6 @@ python3 - <<'PY'
 import json, glob
 for f in sorted(glob.glob("gpurun_out/cfg_*.json")):
     d = json.load(open(f))
-    print("%-12s %8.2f ms/step  %.3e cells/s  contract frac %.2f  design frac %.2f  %5.1f GB" % (f.split("cfg_")[1][:-5], d["ms_per_step"], d["value"],
-          d["path_roofline"]["frac_of_hbm_peak_contract"], d["path_roofline"]["frac_of_hbm_peak_design"], d["config"]["device_GB"]))
+    print("%-12s %8.2f ms/step  %.3e cells/s  design bytes / 8 TB/s %.2f  %5.1f GB" % (f.split("cfg_")[1][:-5], d["ms_per_step"], d["value"],
+          d["path_roofline"]["frac_of_hbm_peak_design"], d["config"]["device_GB"]))
 PY
