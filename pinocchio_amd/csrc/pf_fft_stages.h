@@ -54,7 +54,7 @@ template <typename F> __device__ __forceinline__ F pf_norm_dc(F v, F norm, F dc)
 template <typename F>
 __device__ __forceinline__ pfc<F> pf_zfold(pfc<F> xk, pfc<F> xmk, int e, int M, int mul, F kf, pfc<F> wk) {
   if (mul != 0 /* PF_MUL_ONE */) {
-    F fk = kf * (F)(typename pf_lane<F>::type)e, fm = kf * (F)(typename pf_lane<F>::type)(M - e);
+    F fk = kf * (F)e, fm = kf * (F)(M - e);
     if (mul == 2 /* PF_MUL_K2 */) { fk *= fk; fm *= fm; }
     xk = pf_scale(xk, fk);
     xmk = pf_scale(xmk, fm);
