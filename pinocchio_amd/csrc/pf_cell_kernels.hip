@@ -266,9 +266,8 @@ __global__ void __launch_bounds__(PF_CELL_BLOCK) k_debug_math(int which, const d
     switch (which) {
       case 0: r = pf_div_fast(a[i], b[i]); break;
       case 1: r = pf_sqrt_fast(a[i]); break;
-      case 2: r = pf_acos_series(a[i]); break;
+      case 2: { double c1, c2, c3; pf_cos3_of_acos(a[i], c1, c2, c3); r = b[i] == 0.0 ? c1 : (b[i] == 1.0 ? c2 : c3); } break;
       case 3: r = pf_log10_pos(a[i]); break;
-      case 4: { double sn, cs; pf_sincos_third(a[i], sn, cs); r = b[i] != 0.0 ? sn : cs; } break;
       case 5: r = pf_pow_third<true>(a[i]); break;
       case 6: r = pf_div_const<9>(a[i]); break;
       case 7: r = pf_exp_series(a[i]); break;

@@ -132,27 +132,13 @@ inline void pf_spline_bd(const double *xa, const double *ya, const double *ca, i
 }
 
 // ---- the three transcendental hot spots, in two flavours ---------------------------------------
-// FAST = false: the reference's own calls (cos x3, pow(x, 0.333333333333333), pow(10., y)).
-// FAST = true : algebraically identical forms that cost ~1/3 of the instructions on gfx950
-//   cos(t/3), cos((t+2pi)/3), cos((t+4pi)/3)  ->  one sincos (series on [0, pi/3]) and a rotation by 2pi/3
+// FAST = false: the reference's own calls (cos x3, acos, pow(x, 0.333333333333333), pow(10., y), log10, exp, IEEE / and sqrt).
+// FAST = true : algebraically identical forms that cost a fraction of the instructions on gfx950
+//   cos((acos x + 2 pi k)/3), k = 0, 1, 2      ->  the roots of the Chebyshev cubic from one polynomial and two square roots (pf_cos3_of_acos)
 //   x / constant, x / a / b, 1 / 10^y           ->  x * (1/constant), x / (a*b), 10^-y
 //   pow(x, 0.333333333333333)                 ->  cbrt(x) * (1 - d ln x), d = 1/3 - 0.333333333333333
-//   pow(10., y)                               ->  exp10(y)
+//   pow(10., y), exp, log10                   ->  series forms (pf_exp10_series, pf_exp_series, pf_log10_pos)
 // Each differs from the reference call by about one ulp, like the device libm differs from glibc.
-// sin and cos on [0, pi/3] (t = acos(.) in [0, pi], so t/3 never leaves it): Taylor series in x^2, no range
-// reduction; truncation < 1e-19, rounding ~1 ulp.  The generic sincos costs 155 instructions on gfx950, this ~30.
-// Taylor coefficients of sin (odd, -1/19! ... -1/3!) then cos (even, 1/20! ... 1/4!).  On the device they sit in constant
-// memory and arrive through scalar loads: gfx950's VOP3 encodings take no 64-bit literal, so as inline constants each of
-// them costs two v_mov_b32 per cell once the SGPR file is full -- scalar loads issue beside the vector stream instead.
-#if defined(__HIP_DEVICE_COMPILE__)
-static __constant__ double pf_sc_coef[18] = {
-#else
-static const double pf_sc_coef[18] = {
-#endif
-    -8.2206352466243297e-18, 2.8114572543455206e-15,  -7.6471637318198164e-13, 1.6059043836821613e-10, -2.5052108385441720e-08,
-    2.7557319223985893e-06,  -1.9841269841269841e-04, 8.3333333333333332e-03,  -1.6666666666666666e-01,
-    4.1103176233121648e-19,  -1.5619206968586225e-16, 4.7794773323873853e-14,  -1.1470745597729725e-11, 2.0876756987868100e-09,
-    -2.7557319223985888e-07, 2.4801587301587302e-05,  -1.3888888888888889e-03, 4.1666666666666664e-02};
 // One Horner step r z + c as ONE v_fma_f64.  Left to itself the compiler selects the two-address v_fmac_f64 and, because
 // the coefficient is loop invariant and lives on in its VGPR pair, pays a v_mov_b64 copy in front of every step (60 of
 // the 1154 vector instructions of the collapse kernel).  Same operation, same rounding: results do not change.
@@ -176,17 +162,6 @@ PF_HD double pf_horner_s(double r, double z, double c) {
 #else
   return fma(r, z, c);
 #endif
-}
-PF_HD void pf_sincos_third(double x, double &sn, double &cs) {
-  const double z = x * x;
-  double ps = pf_sc_coef[0];
-#pragma unroll
-  for (int i = 1; i < 9; i++) ps = fma(ps, z, pf_sc_coef[i]);
-  sn = fma(x * z, ps, x);
-  double pc = pf_sc_coef[9];
-#pragma unroll
-  for (int i = 10; i < 18; i++) pc = fma(pc, z, pf_sc_coef[i]);
-  cs = fma(z * z, pc, fma(-0.5, z, 1.0));
 }
 // Division and square root of the fast flavour on the device: the hardware seeds (v_rcp_f64, v_rsq_f64) refined by
 // one Newton / Goldschmidt step and one final residual correction -- 6 and 10 operations instead of the 12 and 22 of the
@@ -259,20 +234,12 @@ template <int Y> PF_HD double pf_div_const(double x) {
   return fma(fma(-(double)Y, q0, x), c, q0);
 }
 
-template <bool FAST> PF_HD void pf_cos3(double t, double &c1, double &c2, double &c3) {
+// the reference's three cos calls (exact flavour; the fast one never forms t: pf_cos3_of_acos)
+PF_HD void pf_cos3_libm(double t, double &c1, double &c2, double &c3) {
   const double inv_3 = 1.0 / 3.0;
-  if (!FAST) {
-    c1 = cos(t * inv_3);
-    c2 = cos((t + 2. * PF_PI) * inv_3);
-    c3 = cos((t + 4. * PF_PI) * inv_3);
-  } else {
-    double sn, cs;
-    pf_sincos_third(t * inv_3, sn, cs);
-    const double h = 0.86602540378443864676 * sn;  // sin(2 pi / 3) sin(t/3)
-    c1 = cs;
-    c2 = -0.5 * cs - h;
-    c3 = -0.5 * cs + h;
-  }
+  c1 = cos(t * inv_3);
+  c2 = cos((t + 2. * PF_PI) * inv_3);
+  c3 = cos((t + 4. * PF_PI) * inv_3);
 }
 template <bool FAST> PF_HD double pf_pow_third(double x) {
   if (!FAST) return pow(x, 0.333333333333333);
@@ -321,33 +288,6 @@ PF_HD double pf_exp10_series(double y) {
 template <bool FAST> PF_HD double pf_pow10(double y) {
   if (!FAST) return pow(10., y);
   return pf_exp10_series(y);
-}
-
-// acos in ~55 operations (the library call costs 93 on gfx950), the classical reduction of fdlibm's e_acos.c with the
-// rational replaced by one degree-12 polynomial: asin(s) = s + s z R(z), z = s^2 <= 1/4, R fitted on [0, 1/4] (Chebyshev
-// fit in 50-digit arithmetic, z R(z) accurate to 5e-18).  |x| < 1/2: acos x = pi/2 - asin x;  x >= 1/2: s = sqrt((1-x)/2),
-// acos x = 2 asin s;  x <= -1/2: pi - 2 asin s.  |x| > 1 gives NaN through the square root, like the library call.
-PF_HD double pf_acos_series(double x) {
-  const double a = fabs(x);
-  const bool big = a >= 0.5;
-  const double z = big ? 0.5 * (1.0 - a) : a * a;
-  const double s = big ? pf_sqrt_fast(z) : a;
-  double r = 2.87578513674215663e-02;
-  r = pf_horner(r, z, -1.48518870712472037e-02);
-  r = pf_horner(r, z, 1.74008794426940214e-02);
-  r = pf_horner(r, z, 5.45750671864035815e-03);
-  r = pf_horner(r, z, 1.03228143501857793e-02);
-  r = pf_horner(r, z, 1.14791774151849057e-02);
-  r = pf_horner(r, z, 1.39712129735529329e-02);
-  r = pf_horner(r, z, 1.73523927208699726e-02);
-  r = pf_horner(r, z, 2.23721729421498886e-02);
-  r = pf_horner(r, z, 3.03819441385312465e-02);
-  r = pf_horner(r, z, 4.46428571463554288e-02);
-  r = pf_horner(r, z, 7.49999999999843292e-02);
-  r = pf_horner(r, z, 1.66666666666666685e-01);
-  const double as = fma(s * z, r, s);  // asin(s)
-  if (!big) return (1.57079632679489655800e+00 - copysign(as, x)) + 6.12323399573676603587e-17;
-  return x > 0.0 ? 2.0 * as : (3.14159265358979311600e+00 - 2.0 * as) + 1.22464679914735320717e-16;
 }
 
 // log10 of a positive finite double in ~45 operations (the library call costs 105 on gfx950): x = m 2^e with m in
@@ -436,7 +376,7 @@ template <bool FAST = false> PF_HD double pf_ell_three_roots(const pf_cubic &c) 
   const double inv_3 = 1.0 / 3;
   double c1, c2, c3;
   if (FAST) pf_cos3_of_acos(pf_div_fast(2 * r, q * sq), c1, c2, c3);
-  else pf_cos3<FAST>(acos(2 * r / q / sq), c1, c2, c3);
+  else pf_cos3_libm(acos(2 * r / q / sq), c1, c2, c3);
   double s1 = -sq * c1 - a1 * inv_3;
   double s2 = -sq * c2 - a1 * inv_3;
   double s3 = -sq * c3 - a1 * inv_3;
@@ -550,7 +490,7 @@ template <bool FAST = false> PF_HD bool pf_eigen_from_invariants(double mu1, dou
     const double inv_3 = 1.0 / 3.0;
     double c1, c2, c3;
     if (FAST) pf_cos3_of_acos(pf_div_fast(2 * r, q * sq), c1, c2, c3);
-    else pf_cos3<FAST>(acos(2 * r / q / sq), c1, c2, c3);
+    else pf_cos3_libm(acos(2 * r / q / sq), c1, c2, c3);
     x1 = -sq * c1 + mu1 * inv_3;
     x2 = -sq * c2 + mu1 * inv_3;
     x3 = -sq * c3 + mu1 * inv_3;

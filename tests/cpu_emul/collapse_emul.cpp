@@ -90,10 +90,6 @@ extern "C" void emul_log10(const double *x, long count, double *out) {
   for (long i = 0; i < count; i++) out[i] = pf_log10_pos(x[i]);
 }
 
-extern "C" void emul_acos(const double *x, long count, double *out) {
-  for (long i = 0; i < count; i++) out[i] = pf_acos_series(x[i]);
-}
-
 // the per-cell reductions the z-pass kernels share with the cell kernels
 extern "C" void emul_invariants(const double *d6, long count, double *mu3, double *lam3, int *ok) {
   for (long i = 0; i < count; i++) {

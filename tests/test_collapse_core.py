@@ -209,28 +209,6 @@ def test_log10_of_the_fast_flavour(emul):
     assert got[len(x) - 9] == 0.0          # log10(1)
 
 
-def test_acos_of_the_fast_flavour(emul):
-    """pf_acos_series against the correctly rounded value (mpmath, 40 digits): within 2 ulp on [-1, 1], dense next to the
-    branch points +-1/2 and the end points; NaN outside"""
-    import mpmath as mp
-    mp.mp.dps = 40
-    emul.emul_acos.argtypes = [dp, C.c_long, dp]
-    rng = np.random.default_rng(8)
-    x = np.concatenate([rng.uniform(-1, 1, 20000), 1.0 - 10.0 ** rng.uniform(-16, 0, 5000), -1.0 + 10.0 ** rng.uniform(-16, 0, 5000),
-                        0.5 + rng.uniform(-1e-6, 1e-6, 2000), -0.5 + rng.uniform(-1e-6, 1e-6, 2000), 10.0 ** rng.uniform(-300, -1, 2000),
-                        [0.0, 1.0, -1.0, 0.5, -0.5, np.nextafter(1.0, 0.0), np.nextafter(-1.0, 0.0)]])
-    x = np.clip(x, -1.0, 1.0)
-    got = np.empty(len(x))
-    emul.emul_acos(_dp(x), len(x), _dp(got))
-    want = np.array([float(mp.acos(mp.mpf(float(v)))) for v in x])
-    ulp = np.spacing(np.maximum(np.abs(want), 1e-300))
-    bad = np.abs(got - want) > 2 * ulp
-    assert not bad.any(), (x[bad][:5], got[bad][:5], want[bad][:5])
-    out = np.empty(3)
-    emul.emul_acos(_dp(np.array([1.0000001, -1.5, np.nan])), 3, _dp(out))
-    assert np.all(np.isnan(out))
-
-
 def test_cosine_triple_of_the_fast_flavour(emul):
     """pf_cos3_of_acos(x) = cos((acos x + 2 pi k) / 3), k = 0, 1, 2, without acos and sincos (one polynomial, two square roots)
     against mpmath (40 digits): c_1 within 2 ulp everywhere on [-1, 1]; c_2, c_3 within 2 ulp of their own magnitude scale (they
