@@ -166,6 +166,10 @@ def parse_args(argv=None):
                     help="(N > 1) delta(k) kept whole on every rank (1), exchanged for every transform (0), the library's choice by rank "
                          "count (auto), or -- at 2 and 4 ranks -- the library's choice timed as the line plus the other mode timed "
                          "beside it in exchange.alternative (both, the default: one run decides DESIGN.md section 5's model)")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo-host"),
+                    help="nccl (= RCCL): one rank per GPU, the measurement.  gloo-host: a bring-up path for boxes with ONE GPU -- gloo process "
+                         "group, every rank on device 0, exchanges staged through host memory (pinocchio_amd/dist.py HostStagedKind): it "
+                         "exercises this script's multi-rank code end to end (tests/test_gpu_gloo_ranks.py); its numbers mean nothing")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launcher check: every rank prints its RANK / LOCAL_RANK / WORLD_SIZE as a JSON line and exits; nothing touches a GPU")
     return ap.parse_args(argv)
@@ -231,7 +235,11 @@ def run_config(args, rank, world, device, dist, torch, replicate_env, votes_out)
             # through torch.distributed (also RCCL) on tensors aliasing the library's buffers.  Collective and vote-guarded: no
             # rank is left inside a communicator set-up (pinocchio_amd/dist.py).  A failure here exits non-zero; nothing re-execs.
             votes = []
-            res["exchange_kind"], keep = pfdist.negotiate_exchange(f, dist, torch, preferred=args.exchange, device="cuda", votes=votes)
+            if args.backend == "gloo-host":
+                res["exchange_kind"], keep = pfdist.negotiate_exchange(f, dist, torch, preferred="host", device="cpu", votes=votes,
+                                                                       kinds={"host": pfdist.HostStagedKind})
+            else:
+                res["exchange_kind"], keep = pfdist.negotiate_exchange(f, dist, torch, preferred=args.exchange, device="cuda", votes=votes)
             votes_out[:] = votes
             # how many ranks the communicator that moves the data really has: ncclCommCount for the built-in kind, the
             # process group's size for the torch kind
@@ -273,7 +281,7 @@ def run_config(args, rank, world, device, dist, torch, replicate_env, votes_out)
         fence(f)
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.backend == "gloo-host" else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         res.update(dt=dt, stats=f.kernel_stats(), cput=f.cputime(), device_gb=f.device_bytes / 1e9,
@@ -334,8 +342,13 @@ def main():
         if ndev < 1:
             raise SystemExit("no GPU visible")
         device = local_rank % ndev
-        torch.cuda.set_device(device)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        if args.backend == "gloo-host":
+            device = 0
+            torch.cuda.set_device(device)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(device)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         # which physical device each rank drives (N distinct ones, or the line says so)
         props = torch.cuda.get_device_properties(device)
         ident = str(getattr(props, "uuid", "")) or f"{getattr(props, 'pci_bus_id', device)}"

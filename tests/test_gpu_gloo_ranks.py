@@ -78,3 +78,29 @@ def test_two_processes_on_one_gpu_match_one_rank(tmp_path, replicate, scenario):
         assert np.array_equal(d["pdf"], pdf)
         for k in p.dtype.names:
             assert np.array_equal(d[k], p[k][r * nxl:(r + 1) * nxl]), (r, k)
+
+
+def test_bench_multi_rank_line_end_to_end_on_one_gpu():
+    """`python bench.py --gpus 2` invoked bare (no WORLD_SIZE): the launcher starts two ranks, which -- on this one-GPU box, through
+    the bring-up backend (gloo group, both on device 0, host-staged exchange) -- run the script's whole multi-rank path: negotiation,
+    timed steps between fences, the alternative delta(k) mode, and the assembly of the line.  The numbers mean nothing here; the
+    fields must be there and must tell the truth (two ranks in the communicator, ONE distinct device, hence n_gpus 1 and a warning)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PF_REPLICATE_DK")}
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--n", "64", "--ns", "4", "--steps", "1",
+                        "--warmup", "1", "--backend", "gloo-host", "--cpu-n", "0", "--exact-steps", "0"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = lines[0]
+    ex = d["exchange"]
+    assert d["steps"] == 1 and d["warmup"] == 1 and d["value"] > 0 and d["scaling"] == "strong"
+    assert ex["kind"] == "host" and ex["process_group_size"] == 2 and ex["ranks_in_communicator"] == 2
+    assert ex["distinct_devices"] == 1 and d["n_gpus"] == 1 and "warning" in ex
+    assert ex["kind_votes"] and all(v["all"] and v["here"] for v in ex["kind_votes"])
+    assert [v["step"] for v in ex["kind_votes"]] == ["bind", "setup", "selftest"]
+    assert ex["replicated_spectrum"] is True and ex["alternative"]["replicated_spectrum"] is False     # the default at two ranks, and the other mode
+    assert ex["alternative"]["calls_per_step"] > ex["calls_per_step"] > 0                                 # the sweep's transposes come on top of the LPT ones
+    assert ex["GB_per_step_per_rank"] > 0 and d["config"]["grid"] == 64
+    names = {k["name"] for k in d["kernels"]}
+    assert {"xpass_hess_1to3", "ypass_hess_3to6", "collapse_inv", "zpass_c2r_hess_6to3inv"} <= names
