@@ -193,8 +193,11 @@ def launch_ranks(args, argv) -> int:
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["PF_BENCH_LAUNCHED_BY"] = str(os.getpid())
+    # the arguments travel in the environment: torch.distributed.run's own parser would try to read script options that are a
+    # prefix of one of its own (`--n 64` is "ambiguous" to it: --nnodes, --nproc-per-node, ...) even behind the script name
+    env["PF_BENCH_ARGV"] = json.dumps(list(argv))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+           "--master-port", str(port), os.path.abspath(__file__)]
     print(f"[bench] --gpus {args.gpus} without WORLD_SIZE: starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
     lines = 0
@@ -312,6 +315,8 @@ def exchange_report(res, args):
 
 def main():
     argv = sys.argv[1:]
+    if not argv and os.environ.get("PF_BENCH_ARGV") and os.environ.get("PF_BENCH_LAUNCHED_BY"):
+        argv = json.loads(os.environ["PF_BENCH_ARGV"])   # a rank started by launch_ranks (see there)
     args = parse_args(argv)
     rank = int(os.environ.get("RANK", "0"))
     world_env = os.environ.get("WORLD_SIZE")
@@ -322,10 +327,10 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, or unset WORLD_SIZE")
     if args.dry_launch:
-        print(json.dumps({"dry_launch": True, "role": "rank", "rank": rank, "local_rank": local_rank, "world": world,
+        os.write(1, (json.dumps({"dry_launch": True, "role": "rank", "rank": rank, "local_rank": local_rank, "world": world,
                           "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}",
-                          "launched_by_bench": os.environ.get("PF_BENCH_LAUNCHED_BY") is not None,
-                          "gpu_untouched": gpu_untouched()}), flush=True)
+                          "launched_by_bench": os.environ.get("PF_BENCH_LAUNCHED_BY") is not None, "args": vars(args),
+                          "gpu_untouched": gpu_untouched()}) + "\n").encode())   # one write: the ranks share the pipe
         return
     from pinocchio_amd import _lib, api, synth
     lpt = not args.no_lpt

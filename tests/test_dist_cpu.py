@@ -197,7 +197,9 @@ def test_bench_self_launches_its_ranks_without_touching_the_gpu():
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-launch"],
+    # (--n and --ns: prefixes of torch.distributed.run's own options -- they must reach the ranks all the same)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--n", "64", "--ns", "3",
+                        "--dry-launch"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -208,6 +210,7 @@ def test_bench_self_launches_its_ranks_without_touching_the_gpu():
     parent = [ln for ln in lines if ln.get("role") == "parent"]
     assert len(parent) == 1 and parent[0]["parent_gpu_untouched"] and parent[0]["children_rc"] == 0 and parent[0]["json_lines_relayed"] == 2
     assert "--nproc-per-node=2" in parent[0]["command"] and "torch.distributed.run" in parent[0]["command"]
+    assert all(ln["args"]["n"] == 64 and ln["args"]["ns"] == 3 and ln["args"]["steps"] == 2 for ln in lines if ln.get("role") == "rank")
     # under a launcher (WORLD_SIZE set) nothing is started: a mismatch is still refused
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r2 = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--dry-launch"], env=env2,
