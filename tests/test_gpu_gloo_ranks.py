@@ -104,3 +104,19 @@ def test_bench_multi_rank_line_end_to_end_on_one_gpu():
     assert ex["GB_per_step_per_rank"] > 0 and d["config"]["grid"] == 64
     names = {k["name"] for k in d["kernels"]}
     assert {"xpass_hess_1to3", "ypass_hess_3to6", "collapse_inv", "zpass_c2r_hess_6to3inv"} <= names
+
+
+def test_bench_eight_ranks_exchange_every_transform_on_one_gpu():
+    """the same through eight real processes sharing the GPU: at eight ranks the library's default is the exchanging path (every
+    transform goes through the pipelined all-to-all, delta(k) stays distributed) and `--replicate both` has nothing to add"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PF_REPLICATE_DK")}
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "8", "--n", "64", "--ns", "3", "--steps", "1",
+                        "--warmup", "1", "--backend", "gloo-host", "--cpu-n", "0", "--exact-steps", "0"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    ex = d["exchange"]
+    assert ex["process_group_size"] == 8 and ex["ranks_in_communicator"] == 8 and ex["distinct_devices"] == 1 and d["n_gpus"] == 1
+    assert ex["replicated_spectrum"] is False and "alternative" not in ex
+    assert ex["calls_per_step"] >= 3 * 3 + 12          # three fields per radius in the sweep, twelve in the LPT part
+    assert d["value"] > 0 and np.isfinite(d["config"]["sigma_R0"]) and abs(d["config"]["sigma_R0"] - 2.5) < 1e-9
