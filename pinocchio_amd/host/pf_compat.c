@@ -225,6 +225,10 @@ int compute_fft_plans(void) {
     if (!ThisTask && pf_rccl_unique_id(id)) return 1;
     MPI_Bcast(id, 128, MPI_BYTE, 0, MPI_COMM_WORLD);
     if (pf_init_rccl(pf_context, id)) return 1;
+    if (pf_rccl_comm_count(pf_context) != NTasks) { /* the communicator RCCL built must be the one MPI started */
+      printf("ERROR on task %d: the RCCL communicator has %d ranks, MPI has %d tasks\n", ThisTask, pf_rccl_comm_count(pf_context), NTasks);
+      return 1;
+    }
   }
 #else
   if (NTasks > 1) {
