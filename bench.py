@@ -30,6 +30,7 @@ when those passes were made on the very kernel sources this run loads (hash of p
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -287,7 +288,15 @@ def run_config(args, rank, world, device, dist, torch, replicate_env, votes_out)
             t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.backend == "gloo-host" else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        res.update(dt=dt, stats=f.kernel_stats(), cput=f.cputime(), device_gb=f.device_bytes / 1e9,
+        # streaming yardsticks of this box and process, after the timed region: a kernel that only reads / writes / copies a field
+        stream = None
+        if world == 1 and not (n & (n - 1)):
+            stream = {}
+            v = C.c_double()
+            for kind, name in ((0, "read_GBps"), (1, "write_GBps"), (2, "copy_GBps")):
+                if f.L.pf_debug_stream_rate(f.h, kind, 5, C.byref(v)) == 0:
+                    stream[name] = v.value
+        res.update(dt=dt, stats=f.kernel_stats(), cput=f.cputime(), device_gb=f.device_bytes / 1e9, stream=stream,
                    reruns=int(f.L.pf_debug_invariant_reruns(f.h)), sigma_R0=float(np.sqrt(tv[-1])), step=step)
     finally:
         if keep is not None:
@@ -437,6 +446,16 @@ def main():
                 k = pmc["kernels"][r["kernel"]]
                 r["traffic"] = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
                 r["traffic_source"] = f"profiles/{PROFILE_ROUND}_pmc_traffic.json (counter passes of this command on these kernel sources, not of this process)"
+        # the same kernels against what THIS memory system gives plain streaming kernels (measured above, in this process): reads and
+        # writes share the bus, t = reads / read rate + writes / write rate; the split of a kernel's bytes comes from the counters
+        stream = res.get("stream")
+        if stream and stream.get("read_GBps") and stream.get("write_GBps"):
+            for r in (roofline, roofline_cls):
+                if pmc and r["kernel"] in pmc["kernels"]:
+                    k = pmc["kernels"][r["kernel"]]
+                    t_ceiling = k["fetch_bytes_per_launch"] / (stream["read_GBps"] * 1e9) + k["write_bytes_per_launch"] / (stream["write_GBps"] * 1e9)
+                    r["streaming_ceiling"] = {"ms_per_launch": 1e3 * t_ceiling, "frac": 1e3 * t_ceiling / r["avg_ms"],
+                                              "note": "time a plain streaming kernel of this box needs for the kernel's counted reads and writes (hbm_streaming), over its measured time"}
         pv = committed_counters("valu", n, w)
         if pv and roofline_cls["kernel"] in pv["kernels"]:
             roofline_cls["valu"] = dict(pv["kernels"][roofline_cls["kernel"]], source=f"profiles/{PROFILE_ROUND}_pmc_valu.json")
@@ -457,6 +476,9 @@ def main():
                        "invariant_reruns": reruns},
             "roofline": roofline,
             "roofline_by_class": roofline_cls,
+            "hbm_streaming": dict(stream, note="GB/s of kernels that only read, write or copy one field of this context (16 bytes per lane, 5 launches "
+                                               "between events), measured after the timed region: the practical ceiling of this memory system beside the "
+                                               "8 TB/s of the specification that `peak` quotes") if stream else None,
             "path_roofline": {"design_bytes_per_step_per_gpu": design_bytes,
                               "design_bytes_per_cell": design_bytes * world / cells,
                               "frac_of_hbm_peak_design": design_bytes / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9),

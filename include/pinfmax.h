@@ -291,6 +291,10 @@ int pf_derivative(pf_ctx *ctx, const double *spec_host, int first_derivative, in
    0 a/b, 1 sqrt(a), 2 acos(a), 3 log10(a), 4 sin (b != 0) or cos (b == 0) of a in [0, pi/3], 5 a^0.333333333333333, 6 a/9,
    7 exp(a), 8 10^a, 9 / 10 the raw hardware seeds v_rcp_f64(a) / v_rsq_f64(a) */
 int pf_debug_math(pf_ctx *ctx, int which, const double *a, const double *b, size_t count, double *out);
+/* measurement aid (bench.py): GB/s of a kernel that only reads (kind 0), only writes (1) or copies (2) one spectrum-sized field of this
+   context, `reps` launches between two events -- the streaming rates of this memory system, beside which the transform passes are
+   reported.  No counterpart in the reference. */
+int pf_debug_stream_rate(pf_ctx *ctx, int kind, int reps, double *gbps);
 /* test tap without a context: ONE pass kernel on a batch of lines, host in / host out in fp64 (converted to field_bytes on
    the way); every instantiation of the hand-written transforms -- N = 2048 of BASELINE config 5 included, whose box does
    not fit one GPU -- can so be compared line by line with an independent transform (tests/test_gpu_lines.py).

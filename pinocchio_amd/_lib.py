@@ -94,6 +94,7 @@ PROTOTYPES = {
     "pf_ct_build": (C.c_int, [_vp, C.c_int, C.c_double, C.POINTER(C.c_double)]),
     "pf_ct_load": (C.c_int, [_vp, C.c_int, C.c_double, C.POINTER(C.c_double)]),
     "pf_debug_math": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_double)]),
+    "pf_debug_stream_rate": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
     "pf_debug_lines": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, _dp, _dp]),
     "pf_debug_invariant_reruns": (C.c_int, [_vp]),
     "pf_set_sources_in_sweep": (C.c_int, [_vp, C.c_int]),

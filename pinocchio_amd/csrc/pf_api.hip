@@ -1599,6 +1599,26 @@ extern "C" int pf_debug_math(pf_ctx *c, int which, const double *a, const double
   return 0;
 }
 
+// Streaming yardsticks on this context's own buffers: GB/s of a kernel that only reads (kind 0: delta(k)), only writes (1) or copies
+// (2) one field, plain 16-byte accesses; the written field is a send buffer of the x-pass (scratch between transforms).
+extern "C" int pf_debug_stream_rate(pf_ctx *c, int kind, int reps, double *gbps) {
+  if (!c || !gbps || kind < 0 || kind > 2 || reps < 1) return 1;
+  if (c->general) return pf_fail(c->rank, "pf_debug_stream_rate: power-of-two grids only");
+  hipEvent_t e0, e1;
+  HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+  float *sink = (float *)(c->scal + SC_POWER);  // a device scalar nobody reads between generator runs (never written: the condition is never met)
+  PFCHK(c, pf_launch_stream(kind, c->dk, c->A[0], c->field_bytes, sink, c->stream));
+  HIPCHK(c, hipEventRecord(e0, c->stream));
+  for (int r = 0; r < reps; r++) PFCHK(c, pf_launch_stream(kind, c->dk, c->A[0], c->field_bytes, sink, c->stream));
+  HIPCHK(c, hipEventRecord(e1, c->stream));
+  HIPCHK(c, hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  *gbps = (kind == 2 ? 2.0 : 1.0) * (double)c->field_bytes * reps / (ms * 1e-3) / 1e9;
+  return 0;
+}
+
 // ------------------------------------------------------------- measurement --
 extern "C" int pf_get_cputime(pf_ctx *c, pf_cputime *t) {
   if (!c || !t) return 1;

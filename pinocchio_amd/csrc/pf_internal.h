@@ -214,6 +214,7 @@ struct PfShapeParams {
   const double *dscale;
 };
 int pf_launch_shape(int field_bytes, const PfShapeParams &p, hipStream_t st);
+int pf_launch_stream(int kind, const void *src, void *dst, size_t bytes, float *sink, hipStream_t st);  // 0 read, 1 write, 2 copy
 int pf_launch_sigma_scale(const double *power_sum, double sigma0, double n3, double *dscale, hipStream_t st);
 
 // ---- GenIC on the device (pf_genic.hip) ----

@@ -119,3 +119,28 @@ int pf_launch_sigma_scale(const double *power_sum, double sigma0, double n3, dou
   hipLaunchKernelGGL(k_sigma_scale, dim3(1), dim3(64), 0, st, power_sum, sigma0, n3, dscale);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
+
+// ---- streaming yardsticks (pf_debug_stream_rate): what this memory system gives a kernel that does nothing but read, write or
+// copy -- the rates the transform passes are measured against in bench.py beside the 8 TB/s of the specification.  16 bytes per
+// lane, plain (cached) accesses, grid-stride over the buffer.
+typedef float pf_f4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_stream_read(const pf_f4 *p, size_t n, float *sink) {
+  pf_f4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc += p[i];
+  if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[0] = 1.f;  // never true for field data; keeps the loads
+}
+__global__ void __launch_bounds__(256) k_stream_write(pf_f4 *p, size_t n, float v) {
+  const pf_f4 x = {v, v, v, v};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = x;
+}
+__global__ void __launch_bounds__(256) k_stream_copy(const pf_f4 *a, pf_f4 *b, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
+}
+int pf_launch_stream(int kind, const void *src, void *dst, size_t bytes, float *sink, hipStream_t st) {
+  const size_t n = bytes / 16;
+  const dim3 grid(2048), block(256);
+  if (kind == 0) hipLaunchKernelGGL(k_stream_read, grid, block, 0, st, (const pf_f4 *)src, n, sink);
+  else if (kind == 1) hipLaunchKernelGGL(k_stream_write, grid, block, 0, st, (pf_f4 *)dst, n, 0.f);
+  else hipLaunchKernelGGL(k_stream_copy, grid, block, 0, st, (const pf_f4 *)src, (pf_f4 *)dst, n);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
