@@ -19,7 +19,9 @@ What the line carries beyond the contract fields:
                      same kernel function are summed; achieved = algorithmic bytes / HIP-event time of those launches
   roofline_by_class  the same for the single most expensive launch class (the fp64-VALU-bound collapse solve, whose byte
                      rate is a consequence, with its issue-side counters)
-  path_roofline      whole step: the survey's contract bytes (6600 B per cell) AND the bytes this design really moves
+  hbm_streaming      GB/s of kernels that only read / write / copy one field, measured in this process after the timed region;
+                     roofline.streaming_ceiling prices the dominant kernel's counted reads and writes at those rates
+  path_roofline      whole step: the bytes this design really moves (the survey's contract figure is quoted beside it, no fraction)
   kernels            per launch class: launches, ms per step, algorithmic GB/s, symbol
   exchange           (N > 1) kind negotiated, bytes per step per rank, time on the communication stream
   exact_libm         (N = 1) step time with PF_EXACT_LIBM=1 (the reference's own libm calls in the solve), informational
