@@ -79,6 +79,62 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
   out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
+// probe: the two branches of the cubic executed on cells regrouped inside the workgroup (one-root cells to the low thread indices,
+// three-root cells to the high ones, through LDS), so that most waves run ONE branch; three barriers per iteration
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_regroup(const double *mu, size_t n, pf_spline_view s, double *out) {
+  __shared__ double sk[5 * 512];
+  __shared__ unsigned short slut[PF_SPLINE_LUT_BINS];
+  __shared__ double P[256 * 4];
+  __shared__ double E[256];
+  __shared__ unsigned short org[256];
+  __shared__ int cnt[8];
+  for (int i = threadIdx.x; i < s.n; i += blockDim.x) { sk[i] = s.x[i]; sk[512 + i] = s.y[i]; sk[1024 + i] = s.c[i]; sk[1536 + i] = s.b[i]; sk[2048 + i] = s.d[i]; }
+  __syncthreads();
+  pf_spline_view sv; sv.x = sk; sv.y = sk + 512; sv.c = sk + 1024; sv.b = sk + 1536; sv.d = sk + 2048; sv.n = s.n;
+  double lx0, inv_w;
+  pf_spline_lut_geometry(sk, s.n, true, lx0, inv_w);
+  for (int b = threadIdx.x; b < PF_SPLINE_LUT_BINS; b += blockDim.x) slut[b] = pf_spline_lut_entry(sk, s.n, b, lx0, inv_w, true);
+  __syncthreads();
+  sv.lut = slut; sv.lut_inv_w = inv_w; sv.lut_x0 = lx0; sv.lut_direct = 1; sv.x_first = sk[0]; sv.x_last = sk[s.n - 1];
+  const int tid = threadIdx.x, w = tid >> 6;
+  double acc = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + tid; i < n; i += (size_t)gridDim.x * blockDim.x) {  // n is a multiple of the grid: uniform trip count
+    const double m1 = mu[i], m2 = mu[n + i], m3 = mu[2 * n + i];
+    const double third = m1 * (1.0 / 3.0), diag[3] = {third, third, third};
+    double lam[3];
+    const bool ok = pf_eigen_from_invariants<true>(m1, m2, m3, diag, lam);
+    double ell = 0.0;
+    pf_cubic c;
+    c.a1 = c.q = c.r = c.disc = 0.0;
+    const int kind = ok ? pf_ell_setup<true>(lam[0], lam[1], lam[2], ell, c) : 0;
+    const unsigned long long b1 = __ballot(kind == 1), b2 = __ballot(kind == 2);
+    const int p1 = __builtin_amdgcn_mbcnt_hi((unsigned)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b1, 0));
+    const int p2 = __builtin_amdgcn_mbcnt_hi((unsigned)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b2, 0));
+    if ((tid & 63) == 0) { cnt[w] = __popcll(b1); cnt[4 + w] = __popcll(b2); }
+    __syncthreads();
+    int base1 = 0, base2 = 0, tot1 = 0, tot2 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int a = cnt[k], b = cnt[4 + k]; if (k < w) { base1 += a; base2 += b; } tot1 += a; tot2 += b; }
+    const int slot = kind == 1 ? base1 + p1 : 255 - (base2 + p2);
+    if (kind > 0) { P[4 * slot] = c.a1; P[4 * slot + 1] = c.q; P[4 * slot + 2] = c.r; P[4 * slot + 3] = c.disc; org[slot] = (unsigned short)tid; }
+    __syncthreads();
+    if (tid < tot1 || tid >= 256 - tot2) {
+      pf_cubic d; d.a1 = P[4 * tid]; d.q = P[4 * tid + 1]; d.r = P[4 * tid + 2]; d.disc = P[4 * tid + 3];
+      const double e = tid < tot1 ? pf_ell_one_root<true>(d) : pf_ell_three_roots<true>(d);
+      E[org[tid]] = e;
+    }
+    __syncthreads();
+    if (kind > 0) ell = E[tid];
+    double F = -10.0;
+    if (ok) {
+      ell = pf_ell_finish<true>(ell, lam[0], lam[1], lam[2]);
+      F = ell > 0.0 ? 1. + pf_inverse_growing_mode<true>(sv, ell) : 0.0;
+    }
+    acc += F;
+  }
+  out[(size_t)blockIdx.x * blockDim.x + tid] = acc;
+}
+
 int main(int argc, char **argv) {
   const size_t n = argc > 1 ? strtoull(argv[1], 0, 10) : (size_t)1 << 27;
   const double sigma = argc > 2 ? atof(argv[2]) : 1.0;
@@ -133,5 +189,14 @@ int main(int argc, char **argv) {
     prev = ps;                                                                                         \
   }
   RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13)
+  {
+    hipLaunchKernelGGL(k_regroup, dim3(grid), dim3(256), 0, 0, dmu, n, sv, dout);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int r = 0; r < 5; r++) hipLaunchKernelGGL(k_regroup, dim3(grid), dim3(256), 0, 0, dmu, n, sv, dout);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("%-40s %8.3f ms per 2^30 cells\n", "probe: branches regrouped in the workgroup", ms / 5 * 1e9 / (double)n * 1.073741824e9 / 1e9);
+  }
   return 0;
 }
