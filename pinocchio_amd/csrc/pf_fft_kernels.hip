@@ -143,7 +143,18 @@ __global__ void __launch_bounds__(T *N / 8) __attribute__((amdgpu_waves_per_eu(4
     const int colj = NL * (tile * T + cj);
     // jobs are grouped by input: a tile is read from HBM once and transformed for every job that uses it
     if (p.pre && (j == 0 || p.job[j].in != p.job[j - 1].in)) {
-      // 1 / k^2 and the window along the transformed axis, column after column (one set of fp64 temporaries alive at a time)
+      // the window along the transformed axis: the thread's eight table values requested together (as `p.rs != 0.0 ? p.etab[e] : 1.0`
+      // inside the loop below each load sat in a branch of its own, behind its own wait: eight L2 latencies in a row, with one
+      // workgroup per CU and nothing else to run)
+      double we[8];
+      if (p.rs != 0.0) {
+#pragma unroll
+        for (int m = 0; m < 8; m++) we[m] = p.etab[tlj + m * NT];
+      } else {
+#pragma unroll
+        for (int m = 0; m < 8; m++) we[m] = 1.0;
+      }
+      // 1 / k^2 and the window, column after column (one set of fp64 temporaries alive at a time)
 #pragma unroll
       for (int l = 0; l < NL; l++) {
         const double kc = kf * (colj + l);
@@ -153,8 +164,7 @@ __global__ void __launch_bounds__(T *N / 8) __attribute__((amdgpu_waves_per_eu(4
           const int e = tlj + m * NT;
           const double ke = kf * (e > N / 2 ? e - N : e);
           const double k2 = ke * ke + ko2kc2;
-          const double we = p.rs != 0.0 ? p.etab[e] : 1.0;
-          const S fac = (S)((k2 != 0.0) ? we * woc[l] / k2 : 0.0);
+          const S fac = (S)((k2 != 0.0) ? we[m] * woc[l] / k2 : 0.0);
           if constexpr (NL > 1) { src[m].x[l] = src[m].x[l] * fac; src[m].y[l] = src[m].y[l] * fac; }
           else src[m] = pf_scale(src[m], (F)fac);
         }
