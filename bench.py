@@ -164,6 +164,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-lpt", action="store_true", help="Fmax-only (BASELINE config 2)")
     ap.add_argument("--cpu-n", type=int, default=512, help="grid side of the CPU-baseline sample (0: skip)")
     ap.add_argument("--exact-steps", type=int, default=1, help="steps of the PF_EXACT_LIBM=1 informational run (0: skip)")
+    ap.add_argument("--table-steps", type=int, default=2,
+                    help="steps of the in-line pass the per-kernel table comes from when the timed configuration overlaps kernels (0: skip)")
     ap.add_argument("--exchange", default="rccl", choices=("rccl", "torch"))
     ap.add_argument("--replicate", default="both", choices=("auto", "0", "1", "both"),
                     help="(N > 1) delta(k) kept whole on every rank (1), exchanged for every transform (0), the library's choice by rank "
@@ -221,9 +223,11 @@ def launch_ranks(args, argv) -> int:
     return rc
 
 
-def run_config(args, rank, world, device, dist, torch, replicate_env, votes_out):
+def run_config(args, rank, world, device, dist, torch, replicate_env, votes_out, solve_inline=False):
     """One timed configuration on this rank: context, exchange, warm-up, exactly `steps` timed steps between fences.
     replicate_env: None (the library's choice) or "0" / "1" for PF_REPLICATE_DK, read by pf_create.
+    solve_inline: PF_SOLVE_BESIDE_Z=0 for this context -- every kernel in line on one stream, so that the HIP-event spans of
+    the kernels do not overlap (the pass the per-kernel table comes from; never the timed configuration).
     -> dict of what rank 0 prints (every rank returns its own; only rank 0's is used)"""
     from pinocchio_amd import api, synth
     n, ns, lpt = args.n, args.ns, not args.no_lpt
@@ -231,7 +235,17 @@ def run_config(args, rank, world, device, dist, torch, replicate_env, votes_out)
         os.environ.pop("PF_REPLICATE_DK", None)
     else:
         os.environ["PF_REPLICATE_DK"] = replicate_env
-    f = api.Fmax(n, rank=rank, nranks=world, device=device, field_bytes=args.field_bytes, timing=True)
+    user_beside = os.environ.get("PF_SOLVE_BESIDE_Z")
+    if solve_inline:
+        os.environ["PF_SOLVE_BESIDE_Z"] = "0"
+    try:
+        f = api.Fmax(n, rank=rank, nranks=world, device=device, field_bytes=args.field_bytes, timing=True)
+    finally:
+        if solve_inline:
+            if user_beside is None:
+                del os.environ["PF_SOLVE_BESIDE_Z"]
+            else:
+                os.environ["PF_SOLVE_BESIDE_Z"] = user_beside
     keep = None
     res = {"exchange_kind": None}
     try:
@@ -299,7 +313,8 @@ def run_config(args, rank, world, device, dist, torch, replicate_env, votes_out)
                 if f.L.pf_debug_stream_rate(f.h, kind, 5, C.byref(v)) == 0:
                     stream[name] = v.value
         res.update(dt=dt, stats=f.kernel_stats(), cput=f.cputime(), device_gb=f.device_bytes / 1e9, stream=stream,
-                   reruns=int(f.L.pf_debug_invariant_reruns(f.h)), sigma_R0=float(np.sqrt(tv[-1])), step=step)
+                   reruns=int(f.L.pf_debug_invariant_reruns(f.h)), sigma_R0=float(np.sqrt(tv[-1])), step=step,
+                   solve_beside=int(f.L.pf_solve_ran_beside_zpass(f.h)) == 1)
     finally:
         if keep is not None:
             try:
@@ -392,6 +407,20 @@ def main():
     dt, stats, cput, device_gb, reruns, step = res["dt"], res["stats"], res["cput"], res["device_gb"], res["reruns"], res["step"]
     exchange_kind = res["exchange_kind"]
 
+    # The timed configuration runs the solve of a sweep radius beside the z-pass of the next one (two streams): the HIP-event
+    # spans of those two kernel classes overlap and are no shares of the step.  The per-kernel table therefore comes from a
+    # second, short pass of the same step with every kernel in line (PF_SOLVE_BESIDE_Z=0); `value` never does.
+    inline = None
+    if world == 1 and res.get("solve_beside") and args.table_steps > 0:
+        import copy
+        a2 = copy.copy(args)
+        a2.steps, a2.warmup = args.table_steps, 1
+        try:
+            inline = run_config(a2, rank, world, device, dist, torch, modes[0], [], solve_inline=True)
+            inline["steps"] = a2.steps
+        except (RuntimeError, api.PinfmaxError) as e:
+            print(f"[bench] in-line pass for the kernel table failed: {e}", file=sys.stderr, flush=True)
+
     exact = None
     if world == 1 and args.exact_steps > 0:
         # the same step with the reference's own libm calls in the solve (bit-comparable with the CPU): what the default
@@ -419,27 +448,52 @@ def main():
         cells = float(n) ** 3
         value = cells * args.steps / dt
         w = args.field_bytes
-        kern = [s for s in stats if s["name"] != "exchange"]
+        kern = [s for s in stats if s["name"] != "exchange"]          # the timed region's own HIP events
         for s in kern:
             s["symbol"] = symbol_of(s["name"], n, w)
+        # the table: kernels in line (their spans add up to the step of that pass); without a second pass, the timed region's
+        table, table_steps = kern, args.steps
+        overlapped = set()
+        if inline:
+            table, table_steps = [s for s in inline["stats"] if s["name"] != "exchange"], inline["steps"]
+            for s in table:
+                s["symbol"] = symbol_of(s["name"], n, w)
+            overlapped = {"zpass_c2r_hess_6to3inv", "collapse_inv"}     # the two classes that share the chip in the timed region
+        elif res.get("solve_beside"):
+            overlapped = {"zpass_c2r_hess_6to3inv", "collapse_inv"}
+        table_total = sum(s["total_ms"] for s in table)
 
-        def roof(group, label):
+        def roof(group, label, steps):
             tms = sum(s["total_ms"] for s in group)
             byt = sum(s["alg_bytes"] for s in group)
             nl = sum(s["launches"] for s in group)
             ach = byt / (tms * 1e-3) / 1e9
             return {"bound": "hbm", "kernel": label, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "traffic": None, "launches": nl, "avg_ms": tms / nl, "alg_bytes_per_launch": byt / nl,
-                    "ms_per_step": tms / args.steps, "share_of_gpu_time": tms / sum(s["total_ms"] for s in kern),
-                    "classes": [s["name"] for s in group]}
+                    "ms_per_step": tms / steps, "classes": [s["name"] for s in group]}
+
+        def roof_of(names, label):
+            """roofline of the launch classes `names`: from the timed region's own events, unless one of them runs beside another
+            kernel there (its span is then no kernel time): those come from the in-line pass and say so"""
+            live = not (set(names) & overlapped) or not inline
+            src, steps = (kern, args.steps) if live else (table, table_steps)
+            r = roof([s for s in src if s["name"] in names], label, steps)
+            tgroup = [s for s in table if s["name"] in names]
+            r["share_of_gpu_time"] = sum(s["total_ms"] for s in tgroup) / table_total
+            r["measured"] = ("HIP events of the timed region" if live else
+                             f"HIP events of the in-line pass ({table_steps} steps, PF_SOLVE_BESIDE_Z=0): in the timed region this kernel shares the chip "
+                             "with another one and its span is not its time")
+            if live and inline:
+                r["avg_ms_in_line_pass"] = sum(s["total_ms"] for s in tgroup) / max(1, sum(s["launches"] for s in tgroup))
+            return r
 
         by_symbol = {}
-        for s in kern:
+        for s in table:
             by_symbol.setdefault(s["symbol"], []).append(s)
         dom_sym = max(by_symbol, key=lambda k: sum(s["total_ms"] for s in by_symbol[k]))
-        roofline = roof(by_symbol[dom_sym], dom_sym)
-        dom_cls = max(kern, key=lambda s: s["total_ms"])
-        roofline_cls = roof([dom_cls], dom_cls["symbol"])
+        roofline = roof_of([s["name"] for s in by_symbol[dom_sym]], dom_sym)
+        dom_cls = max(table, key=lambda s: s["total_ms"])
+        roofline_cls = roof_of([dom_cls["name"]], dom_cls["symbol"])
         roofline_cls["class"] = dom_cls["name"]
         # HBM bytes per launch from the PMC counters of the same command (profiles/tools/collect.sh), only if measured on these sources
         pmc = committed_counters("traffic", n, w)
@@ -488,8 +542,18 @@ def main():
                               "note": "design: the bytes the shared-pass kernels really move (sum of the per-launch algorithmic bytes) over the whole "
                                       "step -- the whole-path roofline fraction; contract_bytes_per_cell is the survey's figure for the reference's "
                                       "unshared structure, quoted for comparison only (no fraction is formed from it: this design never moves those bytes)"},
-            "kernels": [{"name": s["name"], "symbol": s["symbol"], "launches": s["launches"], "ms_per_step": s["total_ms"] / args.steps,
-                         "GBps": s["alg_bytes"] / max(s["total_ms"], 1e-9) / 1e6} for s in kern],
+            "kernels": [dict({"name": s["name"], "symbol": s["symbol"], "launches": s["launches"], "ms_per_step": s["total_ms"] / table_steps,
+                              "GBps": s["alg_bytes"] / max(s["total_ms"], 1e-9) / 1e6},
+                             **({"span_ms_per_step_in_timed_region": next((t["total_ms"] for t in kern if t["name"] == s["name"]), 0.0) / args.steps}
+                                if s["name"] in overlapped and inline else {})) for s in table],
+            "kernel_table": ({"order": "in line", "steps": table_steps, "ms_per_step": 1e3 * inline["dt"] / inline["steps"],
+                              "note": "per-kernel times of a second pass of the same step with every kernel in line (PF_SOLVE_BESIDE_Z=0): in the "
+                                      "timed region the solve of sweep radius i runs on its own stream beside the z-pass of radius i + 1 "
+                                      "(DESIGN.md section 3), their HIP-event spans overlap (span_ms_per_step_in_timed_region) and add up to more "
+                                      "than the step; every other class has the same time in both passes"} if inline else
+                             {"order": "timed region", "steps": args.steps,
+                              "note": ("the spans of zpass_c2r_hess_6to3inv and collapse_inv overlap (solve stream): they are not shares of the step"
+                                       if res.get("solve_beside") else "every kernel in line")}),
             "phases_s_per_step": {k: v / args.steps for k, v in cput.items()},
         }
         if world > 1:

@@ -310,6 +310,10 @@ int pf_debug_lines(int field_bytes, int n, int pass, int mul, int band, int nout
 /* how many sweeps of this context were repeated with six components per cell because the invariant z-pass met a tensor
    with q == 0 that is not exactly isotropic (the reference's "already diagonal" branch, src/collapse_times.c:722-727) */
 int pf_debug_invariant_reruns(pf_ctx *ctx);
+/* 1 when the last sweep of this context ran the collapse solve of its invariant radii on the solve stream, beside the z-pass of
+   the radius that follows (PF_SOLVE_BESIDE_Z): the two kernels' HIP-event spans then overlap -- per-kernel
+   times of pf_kernel_stats are spans, not shares of the step; 0 when every kernel ran in line */
+int pf_solve_ran_beside_zpass(pf_ctx *ctx);
 /* per-cell solver on a list of Hessians d[6*count] -> F[count] (tests of
    inverse_collapse_time, src/collapse_times.c:679-776), ismooth selects the spline */
 int pf_collapse_cells(pf_ctx *ctx, int ismooth, const double *d, size_t count, double *F);

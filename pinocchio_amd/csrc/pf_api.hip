@@ -23,6 +23,7 @@
 #include <string.h>
 
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "../../include/pinfmax.h"
@@ -87,6 +88,7 @@ struct pf_ctx {
   int collapse_blocks;
   bool fast_libm;
   int ncu, dev;
+  bool solve_ran_beside;  // the last sweep used the solve stream (pf_solve_ran_beside_zpass)
   int inv_reruns;       // sweeps repeated with six components because the invariant z-pass met a q == 0 cell (pf_sweep)
   PfTuning tune;        // run-time switches, read from the environment once, in pf_create
   double prune_eps;
@@ -102,11 +104,18 @@ struct pf_ctx {
   // a 12-radius step, at the price of an x-pass that does not shrink with P.  Gathered once per density (dk_full_valid).
   void *dk_full;
   bool replicate, dk_full_valid;
-  double *INV[3];      // fp32 fields: the fp64 invariant rows of the sweep's z-pass (compact, pitch n), allocated at first use
+  double *INV[2][3];   // fp32 fields: the fp64 invariant rows of the sweep's z-pass (compact, pitch n), allocated at first use; two
+                       // sets for the solve stream (the z-pass writes set inv_w while the solve of the radius before reads the other)
+  int inv_w;
   // P > 1: second set of send/receive fields and a communication stream, so that the all-to-all of transform i+1
   // runs beside the y/z passes (and the collapse solve) of transform i (pipelined(), PF_PIPELINE=0 to disable)
   bool pipeline;
   hipStream_t cstream;
+  // the solve stream of a sweep (PF_SOLVE_BESIDE_Z, sweep_body): the solve of radius i runs beside the z-pass of radius i + 1,
+  // whose passes write the other of the two field sets B / B2.  ev_y[set]: the y-pass that follows the z-pass which wrote the
+  // invariants of `set` is enqueued; ev_s[set]: the solve that read them is done
+  hipStream_t sstream;
+  hipEvent_t ev_y[2], ev_s[2];
   char *blockA2;
   void *recvA2;
   hipEvent_t ev_x[2], ev_r[2];
@@ -191,6 +200,7 @@ struct PhaseTimer {
 static void resolve_events(pf_ctx *c) {
   hipStreamSynchronize(c->stream);
   hipStreamSynchronize(c->cstream);
+  hipStreamSynchronize(c->sstream);
   for (auto &e : c->evs) {
     float ms = 0; hipEventElapsedTime(&ms, e.a, e.b);
     c->ks_ms[e.kind] += ms; c->ks_bytes[e.kind] += e.bytes; c->ks_n[e.kind]++;
@@ -251,6 +261,7 @@ static void read_tuning(PfTuning *t) {
   t->pipeline = env_int("PF_PIPELINE", 1) != 0;
   t->replicate = env_int("PF_REPLICATE_DK", -1);  // -1: by the number of ranks (pf_create), 0 / 1: off / on
   t->exact_libm = env_int("PF_EXACT_LIBM", 0) != 0;
+  t->solve_beside_z = env_int("PF_SOLVE_BESIDE_Z", 1) != 0;
   // fault injection for the tests of the exchange pipeline (tests/test_gpu_multirank.py): "recv" drops the wait of the
   // compute stream for the exchange it is about to consume, "send" the wait of the exchange for the x-pass that fills its blocks
   const char *fault = getenv("PF_DEBUG_PIPELINE_FAULT");
@@ -264,7 +275,14 @@ static int create_body(pf_ctx *c, const pf_config *cfg) {
   HIPCHK(c, hipSetDevice(cfg->device));
   HIPCHK(c, hipStreamCreate(&c->stream));
   HIPCHK(c, hipStreamCreate(&c->cstream));
+  {  // the solve stream takes what the compute stream leaves: lowest priority
+    int lo = 0, hi = 0;
+    HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIPCHK(c, hipStreamCreateWithPriority(&c->sstream, hipStreamNonBlocking, lo));
+  }
   for (int i = 0; i < 2; i++) {
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_y[i], hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_s[i], hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_x[i], hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_r[i], hipEventDisableTiming));
   }
@@ -364,10 +382,11 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   c->growth[0] = 1.0; c->growth[1] = 3. / 7.; c->growth[2] = -1. / 9.; c->growth[3] = 5. / 42.;
   for (int i = 0; i < 6; i++) { c->B[i] = nullptr; c->B2[i] = nullptr; }
   c->blockA = nullptr; c->dk = nullptr; c->recvA = nullptr; c->tw = nullptr;
-  c->blockA2 = nullptr; c->recvA2 = nullptr; c->cstream = nullptr; c->dk_full = nullptr; c->replicate = false; c->dk_full_valid = false; c->INV[0] = c->INV[1] = c->INV[2] = nullptr;
+  c->blockA2 = nullptr; c->recvA2 = nullptr; c->cstream = nullptr; c->dk_full = nullptr; c->replicate = false; c->dk_full_valid = false; for (int k = 0; k < 3; k++) c->INV[0][k] = c->INV[1][k] = nullptr; c->inv_w = 0;
   c->fmax = nullptr; c->rmax = nullptr; c->vel12 = nullptr; c->partials = nullptr; c->scal = nullptr; c->hist = nullptr; c->spl = nullptr;
   c->gtab = nullptr; c->etab = nullptr; c->ct_block = nullptr;
-  for (int i = 0; i < 2; i++) c->ev_x[i] = c->ev_r[i] = nullptr;
+  for (int i = 0; i < 2; i++) c->ev_x[i] = c->ev_r[i] = c->ev_y[i] = c->ev_s[i] = nullptr;
+  c->sstream = nullptr; c->solve_ran_beside = false;
   c->pipeline = c->P > 1 && tune.pipeline;
   for (int i = 0; i < 3; i++) { c->A[i] = nullptr; c->S[i] = nullptr; }
   memset(c->gt_n, 0, sizeof(c->gt_n));
@@ -387,8 +406,9 @@ extern "C" int pf_destroy(pf_ctx *c) {
   if (!c) return 0;
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->cstream) hipStreamSynchronize(c->cstream);
+  if (c->sstream) hipStreamSynchronize(c->sstream);
   pf_rccl_release(c->rccl); c->rccl = nullptr;
-  hipFree(c->dk); hipFree(c->blockA); hipFree(c->recvA); hipFree(c->tw); hipFree(c->blockA2); hipFree(c->recvA2); hipFree(c->dk_full); for (int k = 0; k < 3; k++) hipFree(c->INV[k]);
+  hipFree(c->dk); hipFree(c->blockA); hipFree(c->recvA); hipFree(c->tw); hipFree(c->blockA2); hipFree(c->recvA2); hipFree(c->dk_full); for (int k = 0; k < 3; k++) { hipFree(c->INV[0][k]); hipFree(c->INV[1][k]); }
   for (int i = 0; i < 6; i++) { hipFree(c->B[i]); hipFree(c->B2[i]); }
   for (int i = 0; i < 3; i++) hipFree(c->S[i]);
   hipFree(c->fmax); hipFree(c->rmax); hipFree(c->vel12); hipFree(c->partials); hipFree(c->partials_src); hipFree(c->scal); hipFree(c->hist); hipFree(c->spl); hipFree(c->gtab); hipFree(c->etab); hipFree(c->ct_block); hipFree(c->W);
@@ -398,7 +418,8 @@ extern "C" int pf_destroy(pf_ctx *c) {
   for (auto e : c->evpool) hipEventDestroy(e);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   if (c->cstream) hipStreamDestroy(c->cstream);
-  for (int i = 0; i < 2; i++) { if (c->ev_x[i]) hipEventDestroy(c->ev_x[i]); if (c->ev_r[i]) hipEventDestroy(c->ev_r[i]); }
+  if (c->sstream) hipStreamDestroy(c->sstream);
+  for (int i = 0; i < 2; i++) { if (c->ev_x[i]) hipEventDestroy(c->ev_x[i]); if (c->ev_r[i]) hipEventDestroy(c->ev_r[i]); if (c->ev_y[i]) hipEventDestroy(c->ev_y[i]); if (c->ev_s[i]) hipEventDestroy(c->ev_s[i]); }
   delete c;
   return 0;
 }
@@ -412,7 +433,7 @@ extern "C" int pf_set_stream(pf_ctx *c, void *stream) {
 }
 extern "C" void *pf_get_stream(pf_ctx *c) { return c ? (void *)c->stream : nullptr; }
 extern "C" int pf_synchronize(pf_ctx *c) {
-  HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->cstream));
+  HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->cstream)); HIPCHK(c, hipStreamSynchronize(c->sstream));
   return 0;
 }
 extern "C" size_t pf_device_bytes(pf_ctx *c) { return c ? c->dev_bytes : 0; }
@@ -590,8 +611,8 @@ static int zpass_c2r(pf_ctx *c, int kind, int njobs, const ZJob *jobs, const dou
   if (invariants) {  // six components in, the three invariants of the tensor out (fields 0..2; fp32 fields: fp64 rows in INV)
     if (c->fb == 4) {
       for (int k = 0; k < 3; k++) {
-        if (!c->INV[k]) PFCHK(c, dev_alloc(c, (void **)&c->INV[k], ncell(c) * sizeof(double)));
-        p.inv_out[k] = c->INV[k];
+        if (!c->INV[c->inv_w][k]) PFCHK(c, dev_alloc(c, (void **)&c->INV[c->inv_w][k], ncell(c) * sizeof(double)));
+        p.inv_out[k] = c->INV[c->inv_w][k];
       }
       p.inv_pitch = c->n;
     }
@@ -755,10 +776,11 @@ static int ensure_dk_full(pf_ctx *c) {
   return 0;
 }
 static int hess_yz(pf_ctx *c, const void *const R[3], const double *dc, void *const out[6], int band, bool invariants = false,
-                   void *acc = nullptr, void *const *hfirst = nullptr, bool in_local = false) {
+                   void *acc = nullptr, void *const *hfirst = nullptr, bool in_local = false, const std::function<int()> *between = nullptr) {
   const Job yj[6] = {{R[2], out[0], PF_MUL_ONE}, {R[1], out[3], PF_MUL_K}, {R[1], out[4], PF_MUL_ONE},
                      {R[0], out[1], PF_MUL_K2}, {R[0], out[5], PF_MUL_K},  {R[0], out[2], PF_MUL_ONE}};
   PFCHK(c, ypass(c, KS_YPASS_HESS, +1, 6, yj, true, false, 3, band, true, in_local));
+  if (between && (*between)()) return 1;  // (the solve stream of a sweep: what is to run beside the z-pass is enqueued here)
   const ZJob zj[6] = {{out[0], out[0], PF_MUL_ONE, 0}, {out[1], out[1], PF_MUL_ONE, 0}, {out[2], out[2], PF_MUL_K2, 0},
                       {out[3], out[3], PF_MUL_ONE, 0}, {out[4], out[4], PF_MUL_K, 0},   {out[5], out[5], PF_MUL_K, 0}};
   if (acc) {  // the z-pass contracts the six rows with the first-order Hessian `hfirst` into `acc` and stores nothing else
@@ -1132,7 +1154,7 @@ extern "C" int pf_second_derivatives(pf_ctx *c, double rs) {
 }
 
 static int collapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], hipStream_t st, bool build_table = true, bool invariants = false,
-                            bool sources = false) {
+                            bool sources = false, int inv_set = 0) {
   PfCollapseParams p; memset(&p, 0, sizeof(p));
   for (int i = 0; i < 6; i++) p.h[i] = H[i];
   p.pitch = rpitch(c); p.nrows = (long long)c->nxl * c->n; p.n = c->n; p.fmax = c->fmax; p.prod_f64 = c->pb == 8; p.rmax = c->rmax; p.ismooth = ismooth;
@@ -1165,7 +1187,7 @@ static int collapse_enqueue(pf_ctx *c, int ismooth, void *const H[6], hipStream_
   if (invariants) p.invariants = 1;
   int solve_fb = c->fb;
   if (invariants && c->fb == 4) {  // the invariants of fp32 fields are fp64 rows of their own (k_c2r_invariants<float>)
-    for (int k = 0; k < 3; k++) p.h[k] = c->INV[k];
+    for (int k = 0; k < 3; k++) p.h[k] = c->INV[inv_set][k];
     p.pitch = c->n; solve_fb = 8;
   }
   if (sources) {  // K7 in the same pass (the grid is k_lpt_sources' own: identical partial sums of S2)
@@ -1232,6 +1254,27 @@ static int sweep_body(pf_ctx *c, int ns, const double *radius_cells, double *tru
   HIPCHK(c, hipMemsetAsync(c->scal + SC_INV_FLAG, 0, sizeof(double), c->stream));
   const bool rep = c->replicate;
   if (rep) PFCHK(c, ensure_dk_full(c));
+  // The solve stream (PF_SOLVE_BESIDE_Z=0 turns it off; fp64 fields, invariant radii).  The solve is bound by fp64 issue, the
+  // z-pass leaves half of the issue slots free and one 256-thread workgroup of the solve fits a CU beside its two workgroups:
+  // the solve of radius i is enqueued on the solve stream (lowest priority) behind the y-pass of radius i + 1 and so starts with
+  // that z-pass; what is left of it when the z-pass is done has the chip to itself (the strided passes that follow need whole
+  // CUs).  The passes of consecutive radii alternate between the field sets B and B2 (B2: the six fields the LPT part needs
+  // anyway), so that y(i + 1) does not overwrite the invariants solve(i) reads.  Same kernels, same grids, same order of the
+  // running maximum: results are bit for bit those of the in-line order.  792 against 806 ms per step at 1024^3 (three boxes);
+  // a partition of the chip by CUs instead (the solve in 1024-thread workgroups holding 96 .. 144 CUs, the passes of the next
+  // radius on the others) gained nothing: 806 .. 874 ms, the passes lose what the solve wins (profiles/r03_experiments.md).
+  const bool beside_z = invariants_ok && c->tune.solve_beside_z;
+  const bool two_field_sets = beside_z && c->fb == 8;  // (fp32 fields keep their invariants apart, in INV: two sets of those)
+  struct { bool valid; int ismooth, set; } pending = {false, 0, 0};  // the solve that waits for the next z-pass
+  if (two_field_sets)
+    for (int i = 0; i < 6; i++)
+      if (!c->B2[i]) PFCHK(c, dev_alloc(c, &c->B2[i], c->field_bytes));
+  bool s_live[2] = {false, false};  // a solve on the solve stream reads set s; ev_s[s] tells when it is done
+  auto join_solves = [&]() -> int {  // the compute stream goes on behind everything the solve stream holds
+    for (int k = 0; k < 2; k++)
+      if (s_live[k]) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_s[k], 0)); s_live[k] = false; }
+    return 0;
+  };
   auto pre = [&](int ismooth, void *const *A) {
     PhaseTimer pt(c, 0);
     return hess_x(c, rep ? c->dk_full : c->dk, radius_cells[ismooth], A, hess_band(c, radius_cells[ismooth]), rep);
@@ -1240,10 +1283,46 @@ static int sweep_body(pf_ctx *c, int ns, const double *radius_cells, double *tru
     // every radius but the last (its Hessian stays in B for the LPT sources): the z-pass stores the three invariants of the
     // tensor instead of its six components and the solve starts from them (PF_INVARIANTS=0: six components throughout)
     const bool inv = invariants_ok && ismooth < ns - 1;
+    const bool side = inv && beside_z;
+    const int set = side ? (ismooth & 1) : 0;
+    void *const *H = set && two_field_sets ? c->B2 : c->B;
+    auto fields_of = [&](int s_) -> void *const * { return s_ && two_field_sets ? c->B2 : c->B; };
+    if (pending.valid && !side) {  // no invariant z-pass to run beside: the solve still waiting goes in line, first
+      if (join_solves()) return 1;
+      PhaseTimer pt(c, 1);
+      if (collapse_enqueue(c, pending.ismooth, fields_of(pending.set), c->stream, true, true, false, pending.set)) return 1;
+      pending.valid = false;
+    }
+    if (s_live[set]) {  // the y-pass rewrites this set: the solve that reads its invariants must be done
+      HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_s[set], 0));
+      s_live[set] = false;
+    }
+    const std::function<int()> between = [&]() -> int {  // called by hess_yz between its y-pass and its z-pass
+      if (!pending.valid) return 0;
+      const int ps = pending.set;
+      HIPCHK(c, hipEventRecord(c->ev_y[ps], c->stream));
+      HIPCHK(c, hipStreamWaitEvent(c->sstream, c->ev_y[ps], 0));
+      {
+        PhaseTimer pt(c, 1, c->sstream);
+        if (collapse_enqueue(c, pending.ismooth, fields_of(ps), c->sstream, true, true, false, ps)) return 1;
+      }
+      HIPCHK(c, hipEventRecord(c->ev_s[ps], c->sstream));
+      s_live[ps] = true;
+      pending.valid = false;
+      return 0;
+    };
+    c->inv_w = set;
     {
       PhaseTimer pt(c, 0);
-      PFCHK(c, hess_yz(c, R, c->scal + SC_DC_DK, c->B, hess_band(c, radius_cells[ismooth]), inv, nullptr, nullptr, rep));
+      PFCHK(c, hess_yz(c, R, c->scal + SC_DC_DK, H, hess_band(c, radius_cells[ismooth]), inv, nullptr, nullptr, rep, side ? &between : nullptr));
     }
+    c->inv_w = 0;
+    if (side) {
+      pending.valid = true; pending.ismooth = ismooth; pending.set = set;
+      return 0;
+    }
+    // in line: the running maximum and the partial sums follow the solves of the earlier radii
+    if (join_solves()) return 1;
     PhaseTimer pt(c, 1);
     return collapse_enqueue(c, ismooth, c->B, c->stream, true, inv, c->sweep_sources && ismooth == ns - 1);
   };
@@ -1258,6 +1337,9 @@ static int sweep_body(pf_ctx *c, int ns, const double *radius_cells, double *tru
     }
   } else if (pipelined_band(c, ns, 3, pre, [&](int, int set, int f) { return recv_field(c, set, f); }, post,
                             [&](int ismooth) { return hess_band(c, radius_cells[ismooth]); }, rep)) return 1;
+  c->solve_ran_beside = beside_z && ns > 2;
+  if (pending.valid) return pf_fail(c->rank, "pf_sweep: a solve was left waiting (internal error)");
+  if (join_solves()) return 1;
   // the R=0 Hessian (last radius) stays in B for the LPT sources
   c->have_hessian = true; c->last_ns = ns;
   PFCHK(c, allreduce_dev(c, c->scal + SC_INV_FLAG, 1 + 2 * (size_t)ns, 0));
@@ -1283,6 +1365,7 @@ extern "C" int pf_sweep(pf_ctx *c, int ns, const double *radius_cells, double *t
   return rc;
 }
 extern "C" int pf_debug_invariant_reruns(pf_ctx *c) { return c ? c->inv_reruns : -1; }
+extern "C" int pf_solve_ran_beside_zpass(pf_ctx *c) { return c ? (c->solve_ran_beside ? 1 : 0) : -1; }
 extern "C" int pf_replicated_spectrum(pf_ctx *c) { return c ? (c->replicate ? 1 : 0) : -1; }
 extern "C" int pf_set_transposed_spectra(pf_ctx *c, int on) {
   if (!c) return 1;

@@ -19,6 +19,7 @@ struct PfTuning {
   int replicate;  // PF_REPLICATE_DK: -1 by rank count, 0 off, 1 on
   double prune_eps;
   int debug_fault;          // PF_DEBUG_PIPELINE_FAULT (tests only): 1 / 2 = one wait of the exchange pipeline left out
+  bool solve_beside_z;      // PF_SOLVE_BESIDE_Z: the solve of sweep radius i runs on its own stream beside the z-pass of radius i + 1
 };
 
 // multiplier applied along the transformed axis before the 1-D transform
