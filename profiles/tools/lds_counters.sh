@@ -6,6 +6,7 @@
 tag=${1:-r03}
 R=$PWD
 export TMPDIR=/tmp
+export PF_SOLVE_BESIDE_Z=0  # every kernel in line, as in the counter passes of collect.sh (the same kernels doing the same work)
 mkdir -p gpurun_out
 cd /tmp
 rocprofv3 -L 2>/dev/null | grep -o "SQ_[A-Z0-9_]*" | sort -u > $R/gpurun_out/${tag}_sq_counter_names.txt

@@ -68,11 +68,14 @@ def counters(name, wanted):
 def main():
     sha = _lib.source_sha()
     # ---- kernel statistics of the profiled bench command
-    spath = newest(f"prof_{tag}/**/*kernel_stats.csv")
-    if spath:
+    for sub, suffix, how in (("", "", ""), ("_inline", "_inline", "PF_SOLVE_BESIDE_Z=0 (every kernel in line: no two durations overlap) ")):
+      spath = newest(f"prof_{tag}{sub}/**/*kernel_stats.csv")
+      if spath:
         rows = list(csv.DictReader(open(spath)))
-        with open(os.path.join(GO, f"{tag}_kernel_stats.csv"), "w") as out:
-            out.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --cpu-n 0 --exact-steps 0 {os.environ.get('BENCH_ARGS', '')}; kernel sources {sha}\n")
+        with open(os.path.join(GO, f"{tag}_kernel_stats{suffix}.csv"), "w") as out:
+            out.write(f"# {how}rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --cpu-n 0 --exact-steps 0 --table-steps 0 {os.environ.get('BENCH_ARGS', '')}; kernel sources {sha}\n")
+            if not suffix:
+                out.write("# (the durations of k_c2r_invariants<..., 0> and k_collapse_inv overlap here: the solve of sweep radius i runs beside the z-pass of radius i + 1; their own times are in the _inline file)\n")
             out.write("kernel,calls,total_ns,average_ns,percent\n")
             for r in rows:
                 if float(r["Percentage"]) < 0.05:
