@@ -117,7 +117,10 @@ int pf_debug_exchange(pf_ctx *ctx, size_t bytes_per_peer);
 /* device pointers + size (bytes) of the exchange buffers, so that a host
    harness can wrap them (e.g. torch tensors for torch.distributed) */
 int pf_exchange_buffers(pf_ctx *ctx, void **sendbuf, void **recvbuf, size_t *bytes);
-/* stream all work is enqueued on (hipStream_t); pf_set_stream adopts a caller stream */
+/* stream the work is enqueued on (hipStream_t); pf_set_stream adopts a caller stream.  Two internal streams run beside it, ordered
+   against it by events and joined before an entry point returns: the communication stream of a pipelined multi-rank run and the
+   solve stream of a sweep (the collapse solve of radius i beside the z-pass of radius i + 1; PF_SOLVE_BESIDE_Z=0: in line).  What
+   follows an entry point on this stream sees all of its results. */
 int pf_set_stream(pf_ctx *ctx, void *stream);
 void *pf_get_stream(pf_ctx *ctx);
 
