@@ -22,11 +22,15 @@ What the line carries beyond the contract fields:
   hbm_streaming      GB/s of kernels that only read / write / copy one field, measured in this process after the timed region;
                      roofline.streaming_ceiling prices the dominant kernel's counted reads and writes at those rates
   path_roofline      whole step: the bytes this design really moves (the survey's contract figure is quoted beside it, no fraction)
-  kernels            per launch class: launches, ms per step, algorithmic GB/s, symbol
+  kernels            per launch class: launches, ms per step, algorithmic GB/s, symbol.  In the timed configuration the collapse
+                     solve of sweep radius i runs on its own stream beside the z-pass of radius i + 1 and the
+                     HIP-event spans of those two classes overlap; the table -- and the time of a class that overlaps -- therefore
+                     comes from a second, short pass of the same step with every kernel in line (kernel_table says so and gives that
+                     pass's step time); the dominant kernel's roofline is still formed from the events of the timed region itself
   exchange           (N > 1) kind negotiated, bytes per step per rank, time on the communication stream
   exact_libm         (N = 1) step time with PF_EXACT_LIBM=1 (the reference's own libm calls in the solve), informational
   cpu_baseline       (N = 1) the CPU oracle on all host threads, on a bounded sample of the workload
-Counter-derived fields (`traffic`, `valu`) come from committed rocprofv3 passes (profiles/r02_*.json) and are emitted only
+Counter-derived fields (`traffic`, `valu`) come from committed rocprofv3 passes (profiles/<round>_pmc_*.json) and are emitted only
 when those passes were made on the very kernel sources this run loads (hash of pinocchio_amd/csrc); otherwise null.
 """
 from __future__ import annotations
@@ -336,7 +340,9 @@ def exchange_report(res, args):
             "calls_per_step": e["launches"] / args.steps, "GB_per_step_per_rank": e["alg_bytes"] / args.steps / 1e9,
             "ms_per_step_on_comm_stream": e["total_ms"] / args.steps,
             "GBps_per_rank": e["alg_bytes"] / max(e["total_ms"], 1e-9) / 1e6,
-            "compute_ms_per_step": sum(s["total_ms"] for s in kern) / args.steps}
+            "compute_ms_per_step": sum(s["total_ms"] for s in kern) / args.steps,
+            # (the solve of sweep radius i runs beside the z-pass of radius i + 1: those two classes' spans overlap and the sum above counts the shared time twice)
+            "compute_spans_overlap_on_solve_stream": bool(res.get("solve_beside"))}
 
 
 def main():
