@@ -179,6 +179,8 @@ def parse_args(argv=None):
                     help="nccl (= RCCL): one rank per GPU, the measurement.  gloo-host: a bring-up path for boxes with ONE GPU -- gloo process "
                          "group, every rank on device 0, exchanges staged through host memory (pinocchio_amd/dist.py HostStagedKind): it "
                          "exercises this script's multi-rank code end to end (tests/test_gpu_gloo_ranks.py); its numbers mean nothing")
+    ap.add_argument("--slab-of", type=int, default=0,
+                    help="P > 1: time the kernels of ONE rank of a P-rank run of the n^3 box on this GPU, exchange short-circuited (see run_slab)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launcher check: every rank prints its RANK / LOCAL_RANK / WORLD_SIZE as a JSON line and exits; nothing touches a GPU")
     return ap.parse_args(argv)
@@ -330,6 +332,54 @@ def run_config(args, rank, world, device, dist, torch, replicate_env, votes_out,
     return res
 
 
+def run_slab(args):
+    """--slab-of P: the compute side of ONE rank of a P-rank run of the n^3 box, on one GPU, with the exchange short-circuited
+    (pf_set_loopback_exchange: the rank's own blocks come back to it -- copied during the warm-up step so that every buffer holds
+    finite, field-like numbers, not moved at all in the timed steps -- and the reductions keep the rank's own contribution).  The
+    kernels run with the launch geometry of the real run (line lengths, pitches, tile counts, slab thickness); the numbers in
+    the fields are NOT those of the box, so nothing is checked and nothing here is a scaling measurement: it is the time the
+    kernels of one rank need per step, e.g. for BASELINE config 5 (2048^3, fp32 fields, eight GPUs), whose box fits no single GPU."""
+    from pinocchio_amd import _lib, api, synth
+    n, ns, lpt, P = args.n, args.ns, not args.no_lpt, args.slab_of
+    f = api.Fmax(n, rank=0, nranks=P, device=0, field_bytes=args.field_bytes, timing=True)
+    try:
+        f._chk(f.L.pf_set_loopback_exchange(f.h, 1 << 20))          # warm-up: every hand-back copies
+        f.synth_density(synth.SEED, 2.5, -2.0)
+        x, y = synth.invgrow_table("lcdm")
+        f.set_invgrow(x, y)
+        f.set_growth(synth.growth_multipliers())
+        radii = synth.radii_ladder(ns)
+        for _ in range(max(1, args.warmup)):
+            f.compute_fmax(radii, do_lpt=lpt)
+        f.synchronize()
+        f._chk(f.L.pf_set_loopback_exchange(f.h, 0))                # timed: nothing moves
+        f.reset_kernel_stats()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            f.compute_fmax(radii, do_lpt=lpt)
+        f.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        stats = [s for s in f.kernel_stats() if s["launches"] and s["name"] != "exchange"]
+        w = args.field_bytes
+        slab_cells = float(n) ** 3 / P
+        beside = int(f.L.pf_solve_ran_beside_zpass(f.h)) == 1
+        out = {"metric": f"compute side of one rank's slab, {n}^3 box on {P} ranks, loopback exchange (not a scaling measurement)",
+               "value": slab_cells / dt, "unit": "grid-cells/s per rank (kernels only)", "n_gpus": 1, "steps": args.steps, "warmup": max(1, args.warmup),
+               "ms_per_step": 1e3 * dt, "higher_is_better": True, "data": "synthetic, exchanged blocks replaced by the rank's own",
+               "dtype": "f64" if w == 8 else "f32 fields / f64 collapse",
+               "config": {"workload": f"rank 0 of {P}: slab of {n // P} planes of the {n}^3 box, {ns} radii{' + 3LPT' if lpt else ''}", "grid": n, "slab_of": P,
+                          "device_GB": f.device_bytes / 1e9, "kernel_source_sha": _lib.source_sha(),
+                          "replicated_spectrum": int(f.L.pf_replicated_spectrum(f.h)) == 1},
+               "box_cells_per_s_if_the_exchanges_hide": float(n) ** 3 / dt,
+               "kernels": [{"name": s["name"], "symbol": symbol_of(s["name"], n, w), "launches": s["launches"], "ms_per_step": s["total_ms"] / args.steps,
+                            "GBps": s["alg_bytes"] / max(s["total_ms"], 1e-9) / 1e6} for s in stats],
+               "note": ("kernel spans: zpass_c2r_hess_6to3inv and collapse_inv run beside each other (solve stream) and overlap; " if beside else "") +
+                       "an upper bound on what P GPUs can reach on this box: the all-to-alls (P - 1 of P of every field per transform) are not in it"}
+        print(json.dumps(out), flush=True)
+    finally:
+        f.close()
+
+
 def exchange_report(res, args):
     ex = [s for s in res["stats"] if s["name"] == "exchange"]
     kern = [s for s in res["stats"] if s["name"] != "exchange"]
@@ -367,6 +417,10 @@ def main():
     from pinocchio_amd import _lib, api, synth
     lpt = not args.no_lpt
     n, ns = args.n, args.ns
+    if args.slab_of > 1:
+        if world != 1:
+            raise SystemExit("--slab-of runs on one GPU")
+        return run_slab(args)
 
     dist = torch = None
     devices = None
@@ -493,14 +547,22 @@ def main():
                 r["avg_ms_in_line_pass"] = sum(s["total_ms"] for s in tgroup) / max(1, sum(s["launches"] for s in tgroup))
             return r
 
+        # ranking: by kernel time.  Without the in-line pass (--table-steps 0) the spans of the two classes that share the chip are
+        # no kernel times and cannot be ranked: the dominant kernel is then taken among the others, and the line says so
+        rank_pool = [s for s in table if s["name"] not in overlapped] if (overlapped and not inline) else table
         by_symbol = {}
-        for s in table:
+        for s in rank_pool:
             by_symbol.setdefault(s["symbol"], []).append(s)
         dom_sym = max(by_symbol, key=lambda k: sum(s["total_ms"] for s in by_symbol[k]))
         roofline = roof_of([s["name"] for s in by_symbol[dom_sym]], dom_sym)
-        dom_cls = max(table, key=lambda s: s["total_ms"])
+        dom_cls = max(rank_pool, key=lambda s: s["total_ms"])
         roofline_cls = roof_of([dom_cls["name"]], dom_cls["symbol"])
         roofline_cls["class"] = dom_cls["name"]
+        if overlapped and not inline:
+            for r in (roofline, roofline_cls):
+                r["ranking"] = ("among the kernels whose spans do not overlap: no in-line pass was made (--table-steps 0), and the spans of "
+                                + " and ".join(sorted(overlapped)) + " -- which run beside each other -- are not their times")
+                r["share_of_gpu_time"] = None
         # HBM bytes per launch from the PMC counters of the same command (profiles/tools/collect.sh), only if measured on these sources
         pmc = committed_counters("traffic", n, w)
         for r in (roofline, roofline_cls):

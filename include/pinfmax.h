@@ -114,6 +114,12 @@ int pf_fabric_attach(pf_fabric *f, pf_ctx *ctx);
 int pf_fabric_set_delay(pf_fabric *f, int microseconds);
 /* self-test of the installed exchange (pattern through the all-to-all and the all-reduce), any nranks >= 1 */
 int pf_debug_exchange(pf_ctx *ctx, size_t bytes_per_peer);
+/* Measurement aid: ONE rank of an nranks-rank decomposition on its own.  The all-to-all hands this rank's own blocks back to it
+   (copied for the first `copies` calls, so that the receive buffers hold finite, field-like numbers; afterwards nothing moves) and
+   the all-reduce leaves the rank's contribution.  The kernels then run on the rank's slab of the full-size box with the launch
+   geometry of the real run; the results are NOT those of the box.  Used by `bench.py --slab-of P` to time the compute side of a
+   configuration whose box does not fit one GPU (BASELINE config 5: 2048^3 with fp32 fields on eight GPUs). */
+int pf_set_loopback_exchange(pf_ctx *ctx, int copies);
 /* device pointers + size (bytes) of the exchange buffers, so that a host
    harness can wrap them (e.g. torch tensors for torch.distributed) */
 int pf_exchange_buffers(pf_ctx *ctx, void **sendbuf, void **recvbuf, size_t *bytes);

@@ -80,6 +80,8 @@ struct EvPair { int kind; hipEvent_t a, b; double bytes; };
 
 struct SplineHost { std::vector<double> x, y, c; };
 
+struct PfLoopback { int copies_left; int nranks; };  // pf_set_loopback_exchange
+
 struct pf_ctx {
   pf_config cfg;
   int n, nzh, nzp, P, rank, nxl, nyl, fb;
@@ -161,6 +163,7 @@ struct pf_ctx {
   void *fft_c2r, *fft_r2c;  // hipfft plans (Z2D, D2Z), bound at run time (pf_general_fft_*)
   bool vel_zero_pending;  // the Vel* columns are to read as zero (src/collapse_times.c:472-489) but have not been cleared yet
   int last_ns;
+  PfLoopback *loopback;
   pf_alltoall_fn a2a; void *a2a_user;
   pf_alltoallv_fn a2av; void *a2av_user;  // optional: exchange of a row range of every block (pruned radii)
   pf_allreduce_fn ared; void *ared_user;
@@ -386,7 +389,7 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   c->fmax = nullptr; c->rmax = nullptr; c->vel12 = nullptr; c->partials = nullptr; c->scal = nullptr; c->hist = nullptr; c->spl = nullptr;
   c->gtab = nullptr; c->etab = nullptr; c->ct_block = nullptr;
   for (int i = 0; i < 2; i++) c->ev_x[i] = c->ev_r[i] = c->ev_y[i] = c->ev_s[i] = nullptr;
-  c->sstream = nullptr; c->solve_ran_beside = false;
+  c->sstream = nullptr; c->solve_ran_beside = false; c->loopback = nullptr;
   c->pipeline = c->P > 1 && tune.pipeline;
   for (int i = 0; i < 3; i++) { c->A[i] = nullptr; c->S[i] = nullptr; }
   memset(c->gt_n, 0, sizeof(c->gt_n));
@@ -408,6 +411,7 @@ extern "C" int pf_destroy(pf_ctx *c) {
   if (c->cstream) hipStreamSynchronize(c->cstream);
   if (c->sstream) hipStreamSynchronize(c->sstream);
   pf_rccl_release(c->rccl); c->rccl = nullptr;
+  delete c->loopback; c->loopback = nullptr;
   hipFree(c->dk); hipFree(c->blockA); hipFree(c->recvA); hipFree(c->tw); hipFree(c->blockA2); hipFree(c->recvA2); hipFree(c->dk_full); for (int k = 0; k < 3; k++) { hipFree(c->INV[0][k]); hipFree(c->INV[1][k]); }
   for (int i = 0; i < 6; i++) { hipFree(c->B[i]); hipFree(c->B2[i]); }
   for (int i = 0; i < 3; i++) hipFree(c->S[i]);
@@ -441,6 +445,28 @@ extern "C" size_t pf_device_bytes(pf_ctx *c) { return c ? c->dev_bytes : 0; }
 extern "C" int pf_set_exchange(pf_ctx *c, pf_alltoall_fn fn, void *user) { c->a2a = fn; c->a2a_user = user; return 0; }
 extern "C" int pf_set_exchange_rows(pf_ctx *c, pf_alltoallv_fn fn, void *user) { c->a2av = fn; c->a2av_user = user; return 0; }
 extern "C" int pf_set_allreduce(pf_ctx *c, pf_allreduce_fn fn, void *user) { c->ared = fn; c->ared_user = user; return 0; }
+// Measurement aid (pf_set_loopback_exchange): one rank of a P-rank decomposition on its own.  The all-to-all hands every block of
+// the send buffer back to this rank -- copied for the first `copies` calls, so that the receive buffers hold finite, field-like
+// numbers, then not at all -- and the all-reduce leaves the rank's own contribution.  The kernels of the rank run on the slab of
+// the full-size box with the launch geometry of the real run (line lengths, tile counts, pitches); the RESULTS ARE NOT THOSE OF
+// THE BOX.  What it gives is the compute time per rank of a configuration whose box does not fit one GPU (BASELINE config 5).
+static int loopback_a2a(void *user, const void *send, void *recv, size_t bytes_per_peer, void *stream) {
+  PfLoopback *lb = (PfLoopback *)user;
+  if (lb->copies_left <= 0) return 0;
+  lb->copies_left--;
+  // (the whole field: P blocks of bytes_per_peer; the block from "peer" p is this rank's own block p)
+  return hipMemcpyAsync(recv, send, bytes_per_peer * (size_t)lb->nranks, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess;
+}
+static int loopback_ared(void *, void *, size_t, int, void *) { return 0; }
+
+extern "C" int pf_set_loopback_exchange(pf_ctx *c, int copies) {
+  if (!c) return 1;
+  if (!c->loopback) c->loopback = new PfLoopback;
+  c->loopback->copies_left = copies; c->loopback->nranks = c->P;
+  c->a2a = loopback_a2a; c->a2a_user = c->loopback; c->a2av = nullptr; c->a2av_user = nullptr;
+  c->ared = loopback_ared; c->ared_user = nullptr;
+  return 0;
+}
 extern "C" int pf_exchange_buffers(pf_ctx *c, void **sendbuf, void **recvbuf, size_t *bytes) {
   if (sendbuf) *sendbuf = c->blockA;
   if (recvbuf) *recvbuf = c->recvA;

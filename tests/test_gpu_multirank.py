@@ -3,6 +3,7 @@
 in-process fabric (device-to-device copies instead of RCCL).  Results must not
 depend on the decomposition: the per-line transforms are the same operations
 whatever P is, only the small reductions change their summation order."""
+import os
 import threading
 
 import numpy as np
@@ -673,3 +674,30 @@ def test_late_communication_exposes_a_missing_wait(api, fault, n, P, delay_us, m
     monkeypatch.setenv("PF_DEBUG_PIPELINE_FAULT", fault)
     res = run_ranks(api, n, P, body, delay_us=delay_us)
     assert any(not np.array_equal(res[r], fm1[r * nxl:(r + 1) * nxl]) for r in range(P))
+
+
+def test_one_rank_slab_with_loopback_exchange(api):
+    """the measurement aid behind `bench.py --slab-of P` (pf_set_loopback_exchange): one rank of a P-rank decomposition runs the whole
+    step on its own, its own blocks handed back by the all-to-all -- copied at first, then not moved at all.  Nothing about the
+    numbers is claimed except that they are finite and that the step runs in both modes, with fp64 and fp32 fields, with the
+    spectrum replicated or exchanged; a context without an exchange refuses."""
+    x, y = synth.invgrow_table("lcdm")
+    radii = synth.radii_ladder(12)[[0, 6, 11]] * (64 / 1024.0)
+    radii[-1] = 0.0
+    for fb, nranks, rep in ((8, 4, "1"), (8, 8, "0"), (4, 4, "0")):
+        os.environ["PF_REPLICATE_DK"] = rep
+        try:
+            with api.Fmax(64, rank=0, nranks=nranks, field_bytes=fb) as f:
+                f.set_invgrow(x, y)
+                with pytest.raises(api.PinfmaxError):
+                    f.synth_density(synth.SEED, 2.5, -2.0)          # no exchange installed
+                f._chk(f.L.pf_set_loopback_exchange(f.h, 1 << 20))
+                f.synth_density(synth.SEED, 2.5, -2.0)
+                tv = f.compute_fmax(radii, do_lpt=True)
+                f._chk(f.L.pf_set_loopback_exchange(f.h, 0))
+                tv2 = f.compute_fmax(radii, do_lpt=True)
+                fm = f.block("FMAX")
+                assert np.isfinite(tv).all() and np.isfinite(tv2).all() and np.isfinite(fm).all()
+                assert fm.size == 64 ** 3 // nranks
+        finally:
+            del os.environ["PF_REPLICATE_DK"]
