@@ -332,6 +332,89 @@ def run_config(args, rank, world, device, dist, torch, replicate_env, votes_out,
     return res
 
 
+def kernel_report(stats, steps, n, w, inline=None, solve_beside=False, stream=None):
+    """Everything the line says about single kernels, from the HIP-event statistics of the timed region (`stats`, `steps`) and -- when
+    the timed configuration runs two kernel classes beside each other -- of the in-line pass (`inline`: {"stats", "steps", "dt"}).
+    -> (kern, table, table_steps, overlapped, roofline, roofline_cls)   (pure: tests/test_bench_report.py feeds it synthetic statistics)"""
+    kern = [s for s in stats if s["name"] != "exchange"]          # the timed region's own HIP events
+    for s in kern:
+        s["symbol"] = symbol_of(s["name"], n, w)
+    # the table: kernels in line (their spans add up to the step of that pass); without a second pass, the timed region's
+    table, table_steps = kern, steps
+    overlapped = set()
+    if inline:
+        table, table_steps = [s for s in inline["stats"] if s["name"] != "exchange"], inline["steps"]
+        for s in table:
+            s["symbol"] = symbol_of(s["name"], n, w)
+        overlapped = {"zpass_c2r_hess_6to3inv", "collapse_inv"}     # the two classes that share the chip in the timed region
+    elif solve_beside:
+        overlapped = {"zpass_c2r_hess_6to3inv", "collapse_inv"}
+    table_total = sum(s["total_ms"] for s in table)
+
+    def roof(group, label, steps):
+        tms = sum(s["total_ms"] for s in group)
+        byt = sum(s["alg_bytes"] for s in group)
+        nl = sum(s["launches"] for s in group)
+        ach = byt / (tms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": label, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": None, "launches": nl, "avg_ms": tms / nl, "alg_bytes_per_launch": byt / nl,
+                "ms_per_step": tms / steps, "classes": [s["name"] for s in group]}
+
+    def roof_of(names, label):
+        """roofline of the launch classes `names`: from the timed region's own events, unless one of them runs beside another
+        kernel there (its span is then no kernel time): those come from the in-line pass and say so"""
+        live = not (set(names) & overlapped) or not inline
+        src, nsteps = (kern, steps) if live else (table, table_steps)
+        r = roof([s for s in src if s["name"] in names], label, nsteps)
+        tgroup = [s for s in table if s["name"] in names]
+        r["share_of_gpu_time"] = sum(s["total_ms"] for s in tgroup) / table_total
+        r["measured"] = ("HIP events of the timed region" if live else
+                         f"HIP events of the in-line pass ({table_steps} steps, PF_SOLVE_BESIDE_Z=0): in the timed region this kernel shares the chip "
+                         "with another one and its span is not its time")
+        if live and inline:
+            r["avg_ms_in_line_pass"] = sum(s["total_ms"] for s in tgroup) / max(1, sum(s["launches"] for s in tgroup))
+        return r
+
+    # ranking: by kernel time.  Without the in-line pass (--table-steps 0) the spans of the two classes that share the chip are
+    # no kernel times and cannot be ranked: the dominant kernel is then taken among the others, and the line says so
+    rank_pool = [s for s in table if s["name"] not in overlapped] if (overlapped and not inline) else table
+    by_symbol = {}
+    for s in rank_pool:
+        by_symbol.setdefault(s["symbol"], []).append(s)
+    dom_sym = max(by_symbol, key=lambda k: sum(s["total_ms"] for s in by_symbol[k]))
+    roofline = roof_of([s["name"] for s in by_symbol[dom_sym]], dom_sym)
+    dom_cls = max(rank_pool, key=lambda s: s["total_ms"])
+    roofline_cls = roof_of([dom_cls["name"]], dom_cls["symbol"])
+    roofline_cls["class"] = dom_cls["name"]
+    if overlapped and not inline:
+        for r in (roofline, roofline_cls):
+            r["ranking"] = ("among the kernels whose spans do not overlap: no in-line pass was made (--table-steps 0), and the spans of "
+                            + " and ".join(sorted(overlapped)) + " -- which run beside each other -- are not their times")
+            r["share_of_gpu_time"] = None
+    # HBM bytes per launch from the PMC counters of the same command (profiles/tools/collect.sh), only if measured on these sources
+    pmc = committed_counters("traffic", n, w)
+    for r in (roofline, roofline_cls):
+        if pmc and r["kernel"] in pmc["kernels"]:
+            k = pmc["kernels"][r["kernel"]]
+            r["traffic"] = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
+            r["traffic_source"] = f"profiles/{PROFILE_ROUND}_pmc_traffic.json (counter passes of this command on these kernel sources, not of this process)"
+    # the same kernels against what THIS memory system gives plain streaming kernels (measured above, in this process): reads and
+    # writes share the bus, t = reads / read rate + writes / write rate; the split of a kernel's bytes comes from the counters
+    if stream and stream.get("read_GBps") and stream.get("write_GBps"):
+        for r in (roofline, roofline_cls):
+            if pmc and r["kernel"] in pmc["kernels"]:
+                k = pmc["kernels"][r["kernel"]]
+                t_ceiling = k["fetch_bytes_per_launch"] / (stream["read_GBps"] * 1e9) + k["write_bytes_per_launch"] / (stream["write_GBps"] * 1e9)
+                r["streaming_ceiling"] = {"ms_per_launch": 1e3 * t_ceiling, "frac": 1e3 * t_ceiling / r["avg_ms"],
+                                          "note": "time a plain streaming kernel of this box needs for the kernel's counted reads and writes (hbm_streaming), over its measured time"}
+    pv = committed_counters("valu", n, w)
+    if pv and roofline_cls["kernel"] in pv["kernels"]:
+        roofline_cls["valu"] = dict(pv["kernels"][roofline_cls["kernel"]], source=f"profiles/{PROFILE_ROUND}_pmc_valu.json")
+    if dom_cls["name"].startswith("collapse"):
+        roofline_cls["note"] = "the collapse solve is fp64-VALU bound; its HBM stream is a consequence, see DESIGN.md section 6"
+    return kern, table, table_steps, overlapped, roofline, roofline_cls
+
+
 def run_slab(args):
     """--slab-of P: the compute side of ONE rank of a P-rank run of the n^3 box, on one GPU, with the exchange short-circuited
     (pf_set_loopback_exchange: the rank's own blocks come back to it -- copied during the warm-up step so that every buffer holds
@@ -508,83 +591,8 @@ def main():
         cells = float(n) ** 3
         value = cells * args.steps / dt
         w = args.field_bytes
-        kern = [s for s in stats if s["name"] != "exchange"]          # the timed region's own HIP events
-        for s in kern:
-            s["symbol"] = symbol_of(s["name"], n, w)
-        # the table: kernels in line (their spans add up to the step of that pass); without a second pass, the timed region's
-        table, table_steps = kern, args.steps
-        overlapped = set()
-        if inline:
-            table, table_steps = [s for s in inline["stats"] if s["name"] != "exchange"], inline["steps"]
-            for s in table:
-                s["symbol"] = symbol_of(s["name"], n, w)
-            overlapped = {"zpass_c2r_hess_6to3inv", "collapse_inv"}     # the two classes that share the chip in the timed region
-        elif res.get("solve_beside"):
-            overlapped = {"zpass_c2r_hess_6to3inv", "collapse_inv"}
-        table_total = sum(s["total_ms"] for s in table)
-
-        def roof(group, label, steps):
-            tms = sum(s["total_ms"] for s in group)
-            byt = sum(s["alg_bytes"] for s in group)
-            nl = sum(s["launches"] for s in group)
-            ach = byt / (tms * 1e-3) / 1e9
-            return {"bound": "hbm", "kernel": label, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": None, "launches": nl, "avg_ms": tms / nl, "alg_bytes_per_launch": byt / nl,
-                    "ms_per_step": tms / steps, "classes": [s["name"] for s in group]}
-
-        def roof_of(names, label):
-            """roofline of the launch classes `names`: from the timed region's own events, unless one of them runs beside another
-            kernel there (its span is then no kernel time): those come from the in-line pass and say so"""
-            live = not (set(names) & overlapped) or not inline
-            src, steps = (kern, args.steps) if live else (table, table_steps)
-            r = roof([s for s in src if s["name"] in names], label, steps)
-            tgroup = [s for s in table if s["name"] in names]
-            r["share_of_gpu_time"] = sum(s["total_ms"] for s in tgroup) / table_total
-            r["measured"] = ("HIP events of the timed region" if live else
-                             f"HIP events of the in-line pass ({table_steps} steps, PF_SOLVE_BESIDE_Z=0): in the timed region this kernel shares the chip "
-                             "with another one and its span is not its time")
-            if live and inline:
-                r["avg_ms_in_line_pass"] = sum(s["total_ms"] for s in tgroup) / max(1, sum(s["launches"] for s in tgroup))
-            return r
-
-        # ranking: by kernel time.  Without the in-line pass (--table-steps 0) the spans of the two classes that share the chip are
-        # no kernel times and cannot be ranked: the dominant kernel is then taken among the others, and the line says so
-        rank_pool = [s for s in table if s["name"] not in overlapped] if (overlapped and not inline) else table
-        by_symbol = {}
-        for s in rank_pool:
-            by_symbol.setdefault(s["symbol"], []).append(s)
-        dom_sym = max(by_symbol, key=lambda k: sum(s["total_ms"] for s in by_symbol[k]))
-        roofline = roof_of([s["name"] for s in by_symbol[dom_sym]], dom_sym)
-        dom_cls = max(rank_pool, key=lambda s: s["total_ms"])
-        roofline_cls = roof_of([dom_cls["name"]], dom_cls["symbol"])
-        roofline_cls["class"] = dom_cls["name"]
-        if overlapped and not inline:
-            for r in (roofline, roofline_cls):
-                r["ranking"] = ("among the kernels whose spans do not overlap: no in-line pass was made (--table-steps 0), and the spans of "
-                                + " and ".join(sorted(overlapped)) + " -- which run beside each other -- are not their times")
-                r["share_of_gpu_time"] = None
-        # HBM bytes per launch from the PMC counters of the same command (profiles/tools/collect.sh), only if measured on these sources
-        pmc = committed_counters("traffic", n, w)
-        for r in (roofline, roofline_cls):
-            if pmc and r["kernel"] in pmc["kernels"]:
-                k = pmc["kernels"][r["kernel"]]
-                r["traffic"] = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
-                r["traffic_source"] = f"profiles/{PROFILE_ROUND}_pmc_traffic.json (counter passes of this command on these kernel sources, not of this process)"
-        # the same kernels against what THIS memory system gives plain streaming kernels (measured above, in this process): reads and
-        # writes share the bus, t = reads / read rate + writes / write rate; the split of a kernel's bytes comes from the counters
-        stream = res.get("stream")
-        if stream and stream.get("read_GBps") and stream.get("write_GBps"):
-            for r in (roofline, roofline_cls):
-                if pmc and r["kernel"] in pmc["kernels"]:
-                    k = pmc["kernels"][r["kernel"]]
-                    t_ceiling = k["fetch_bytes_per_launch"] / (stream["read_GBps"] * 1e9) + k["write_bytes_per_launch"] / (stream["write_GBps"] * 1e9)
-                    r["streaming_ceiling"] = {"ms_per_launch": 1e3 * t_ceiling, "frac": 1e3 * t_ceiling / r["avg_ms"],
-                                              "note": "time a plain streaming kernel of this box needs for the kernel's counted reads and writes (hbm_streaming), over its measured time"}
-        pv = committed_counters("valu", n, w)
-        if pv and roofline_cls["kernel"] in pv["kernels"]:
-            roofline_cls["valu"] = dict(pv["kernels"][roofline_cls["kernel"]], source=f"profiles/{PROFILE_ROUND}_pmc_valu.json")
-        if dom_cls["name"].startswith("collapse"):
-            roofline_cls["note"] = "the collapse solve is fp64-VALU bound; its HBM stream is a consequence, see DESIGN.md section 6"
+        kern, table, table_steps, overlapped, roofline, roofline_cls = kernel_report(stats, args.steps, n, w, inline=inline,
+                                                                                     solve_beside=bool(res.get("solve_beside")), stream=res.get("stream"))
         design_bytes = sum(s["alg_bytes"] for s in kern) / args.steps
         n_gpus = world
         out = {
