@@ -591,8 +591,9 @@ def main():
         cells = float(n) ** 3
         value = cells * args.steps / dt
         w = args.field_bytes
+        stream = res.get("stream")
         kern, table, table_steps, overlapped, roofline, roofline_cls = kernel_report(stats, args.steps, n, w, inline=inline,
-                                                                                     solve_beside=bool(res.get("solve_beside")), stream=res.get("stream"))
+                                                                                     solve_beside=bool(res.get("solve_beside")), stream=stream)
         design_bytes = sum(s["alg_bytes"] for s in kern) / args.steps
         n_gpus = world
         out = {
