@@ -451,6 +451,38 @@ def test_invariant_zpass_equals_six_component_path(api, n, monkeypatch):
     assert (out["1"][1]["Rmax"] > 0).any() and (out["1"][1]["Rmax"] < 4).any()
 
 
+@pytest.mark.parametrize("n,fb", [(16, 8), (64, 8), (256, 8), (64, 4), (256, 4)])
+def test_solve_beside_the_next_zpass_equals_the_in_line_order(api, n, fb, monkeypatch):
+    """Default sweep: the collapse solve of radius i runs on its own stream beside the z-pass of radius i + 1, the passes of
+    consecutive radii alternating between two field sets (fp32 fields: two sets of invariant rows); PF_SOLVE_BESIDE_Z=0 runs every
+    kernel in line on one stream.  The same kernels on the same grids in the same order of the running maximum: TrueVariance,
+    Fmax, Rmax, the histogram and the displacements bit for bit, over two consecutive steps of one context (the second step
+    reuses both field sets), with two, three and six radii (zero, one and four solves that have a z-pass to run beside)."""
+    dk = synth.make_density(n, seed=29 + n)
+    dk[0, 0, 0] = 0.21 * n ** 3
+    x, y = synth.invgrow_table("lcdm")
+    ladders = [np.array([1.5, 0.0]), np.array([n / 40.0, 1.5, 0.0]), np.array([n / 16.0, n / 40.0, 1.5, 0.9, 0.6, 0.0])]
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PF_SOLVE_BESIDE_Z", mode)
+        res = []
+        with api.Fmax(n, field_bytes=fb) as f:
+            f.set_density(dk)
+            f.set_invgrow(x, y)
+            f.set_growth(synth.growth_multipliers())
+            for radii in ladders + ladders[-1:]:
+                tv = f.compute_fmax(radii, do_lpt=True)
+                beside = int(f.L.pf_solve_ran_beside_zpass(f.h))
+                assert beside == (1 if mode == "1" and len(radii) > 2 else 0), (mode, len(radii), beside)
+                res.append((tv, f.products(), f.Fmax_PDF()))
+        out[mode] = res
+    for a, b in zip(out["0"], out["1"]):
+        assert np.array_equal(a[0], b[0])
+        for name in ("Fmax", "Rmax", "Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+            assert np.array_equal(a[1][name], b[1][name]), name
+        assert np.array_equal(a[2], b[2])
+
+
 @pytest.mark.parametrize("n", [16, 64, 256])
 def test_fused_3lpt_source_equals_separate_kernels(api, n, monkeypatch):
     """Default: the z-pass of the 2LPT potential's Hessian contracts its six components with the first-order Hessian into the
