@@ -60,7 +60,11 @@ typedef struct {
 } pf_product_layout;
 void pf_layout_3lpt(pf_product_layout *l);
 
-/* cputime_data (src/pinocchio.h:368-378), seconds, device time by HIP events */
+/* cputime_data (src/pinocchio.h:368-378), seconds, device time by HIP events.  fmax, deriv, coll, lpt are spans between events
+   on the streams the phases run on.  In a sweep whose collapse passes ran beside the z-passes of the following radii (the
+   default, pf_solve_ran_beside_zpass) `coll` is what they add to the sweep beyond the derivative passes, so that
+   deriv + coll <= fmax as in the reference's report (src/fmax.c:160-170); with every kernel in line (PF_SOLVE_BESIDE_Z=0)
+   both are the plain spans. */
 typedef struct {
   double fmax, deriv, fft, coll, lpt, mem_transf;
 } pf_cputime;
@@ -119,7 +123,8 @@ int pf_debug_exchange(pf_ctx *ctx, size_t bytes_per_peer);
    the all-reduce leaves the rank's contribution.  The kernels then run on the rank's slab of the full-size box with the launch
    geometry of the real run; the results are NOT those of the box.  Used by `bench.py --slab-of P` to time the compute side of a
    configuration whose box does not fit one GPU (BASELINE config 5: 2048^3 with fp32 fields on eight GPUs). */
-int pf_set_loopback_exchange(pf_ctx *ctx, int copies);
+int pf_set_loopback_exchange(pf_ctx *ctx, int copies);   /* refused when a real exchange (RCCL, callbacks, fabric) is installed */
+int pf_loopback_active(pf_ctx *ctx);                      /* 1 when the loopback stands in for the exchange (results are no box's) */
 /* device pointers + size (bytes) of the exchange buffers, so that a host
    harness can wrap them (e.g. torch tensors for torch.distributed) */
 int pf_exchange_buffers(pf_ctx *ctx, void **sendbuf, void **recvbuf, size_t *bytes);

@@ -1063,6 +1063,36 @@ orc_ctx *orc_create(int n, int nthreads) {
   return c;
 }
 
+/* A context WITHOUT the field arrays: twiddles, splines and scalars only.  For the sampled-plane functions below
+   (orc_plane_*), which restate the path on a few x-planes of a box whose whole oracle would not fit the host (the 1024^3
+   of the metric: ~450 GB with the test's own arrays).  Every whole-box entry point needs orc_create. */
+orc_ctx *orc_create_planes(int n, int nthreads) {
+  if (n < 4 || (n & 1)) return NULL;
+  orc_ctx *c = (orc_ctx *)calloc(1, sizeof(orc_ctx));
+  c->n = n; c->nzh = n / 2 + 1;
+#ifdef _OPENMP
+  c->nthreads = nthreads > 0 ? nthreads : omp_get_max_threads();
+#else
+  c->nthreads = 1;
+#endif
+  c->n_r = 0; c->n_fft = 0;  /* no fields */
+  c->norm = (double)1.0 / ((double)n * (double)n * (double)n);
+  c->tw = (double *)malloc(sizeof(double) * 2 * n);
+  for (int j = 0; j < n; j++) {
+    c->tw[2 * j] = cos(2. * ORC_PI * j / n);
+    c->tw[2 * j + 1] = sin(2. * ORC_PI * j / n);
+  }
+  c->brev = (int *)malloc(sizeof(int) * n);
+  int lg = 0; while ((1 << lg) < n) lg++;
+  for (int i = 0; i < n; i++) {
+    int r = 0;
+    for (int b = 0; b < lg; b++) if (i & (1 << b)) r |= 1 << (lg - 1 - b);
+    c->brev[i] = r;
+  }
+  c->growth[0] = 1.0; c->growth[1] = 3. / 7.; c->growth[2] = -1. / 9.; c->growth[3] = 5. / 42.;
+  return c;
+}
+
 void orc_destroy(orc_ctx *c) {
   if (!c) return;
   free(c->tw); free(c->brev); free(c->kdensity); free(c->cvector); free(c->rvector);
@@ -1159,4 +1189,139 @@ size_t orc_select_sorted(orc_ctx *c, float flast, unsigned int *indices, float *
   qsort((void *)indices, m, sizeof(unsigned int), index_compare_F);
   for (size_t i = 0; i < m; i++) fmax[i] = c->products[indices[i]].Fmax;
   return m;
+}
+
+/* ----------------------------------------------------------------------------------------------------------------
+ * Sampled x-planes of a box that is too large for the whole oracle.
+ *
+ * compute_derivative (src/fmax-pfft.c:255-441) multiplies every mode by green * smoothing * growth and transforms back
+ * (reverse_transform, :203-228).  The value of that 3-D c2r on ONE x-plane needs only
+ *     G(ky, kz) = sum_kx  cvector(kx, ky, kz) e^{+2 pi i kx x / n}
+ * followed by the y and z transforms of that plane -- the very same operations per mode, the x-transform written as the
+ * plain sum for the sampled x only (O(n) per mode and plane instead of the FFT's O(log n) per mode for all planes).
+ * ncomp components (ia[c], ib[c]) as compute_derivative takes them: (a, b) with 1 <= a <= b <= 3 a second derivative,
+ * (-1, -1) the plain transform.  First derivatives (the `swap` of :389-396) are not needed by the callers and refused.
+ * ScaleDep.order = 0 (second derivatives: growth_rate = 1, :344-364).
+ * spec: [n][n][n/2+1] complex (not modified); out: [ncomp][nplanes][n][n] reals, times 1/n^3 (:220-225).
+ * ---------------------------------------------------------------------------------------------------------------- */
+int orc_plane_derivatives(orc_ctx *c, const double *spec, double rs_cells, int ncomp, const int *ia, const int *ib,
+                          int nplanes, const int *xs, double *out) {
+  const int n = c->n, nzh = c->nzh, Nhalf = n / 2;
+  const double knorm = 2. * ORC_PI / (double)n;
+  const double Rsmooth = rs_cells;
+  if (ncomp < 1 || ncomp > 6 || nplanes < 1) return 1;
+  for (int k = 0; k < ncomp; k++) {
+    const int plain = ia[k] == -1 && ib[k] == -1;
+    if (!plain && !(ia[k] >= 1 && ia[k] <= 3 && ib[k] >= 1 && ib[k] <= 3)) return 1;
+  }
+  for (int p = 0; p < nplanes; p++) if (xs[p] < 0 || xs[p] >= n) return 1;
+  const size_t plane_c = (size_t)n * nzh;  /* complex per plane of G */
+  double *G = (double *)malloc(sizeof(double) * 2 * plane_c * (size_t)ncomp * nplanes);
+  if (!G) return 1;
+  /* e^{+2 pi i kx x / n} from the transform's own twiddle table */
+  double *E = (double *)malloc(sizeof(double) * 2 * (size_t)n * nplanes);
+  for (int p = 0; p < nplanes; p++)
+    for (int idx = 0; idx < n; idx++) {
+      const int j = (int)(((long long)idx * xs[p]) % n);
+      E[2 * ((size_t)p * n + idx)] = c->tw[2 * j]; E[2 * ((size_t)p * n + idx) + 1] = c->tw[2 * j + 1];
+    }
+#pragma omp parallel num_threads(c->nthreads)
+  {
+    double *acc = (double *)malloc(sizeof(double) * 2 * (size_t)nzh * ncomp * nplanes);
+#pragma omp for schedule(dynamic, 1)
+    for (int idy = 0; idy < n; idy++) {
+      memset(acc, 0, sizeof(double) * 2 * (size_t)nzh * ncomp * nplanes);
+      int ii[3];
+      ii[1] = idy; if (ii[1] > Nhalf) ii[1] -= n;
+      const double k_y = knorm * ii[1];
+      for (int idx = 0; idx < n; idx++) {
+        ii[0] = idx; if (ii[0] > Nhalf) ii[0] -= n;
+        const double k_x = knorm * ii[0];
+        const double k2_0 = k_x * k_x;
+        const double k2_1 = k2_0 + k_y * k_y;
+        const double *row = spec + 2 * (((size_t)idx * n + idy) * nzh);
+        for (int idz = 0; idz < nzh; idz++) {
+          ii[2] = idz; if (ii[2] > Nhalf) ii[2] -= n;
+          const double k_z = knorm * ii[2];
+          const double k_squared = k2_1 + k_z * k_z;
+          double smoothing = 1.0;
+          double diff_comp[4];
+          diff_comp[0] = 1.0; diff_comp[1] = k_x; diff_comp[2] = k_y; diff_comp[3] = k_z;
+          if (k_squared != 0.) smoothing = exp(-0.5 * k_squared * Rsmooth * Rsmooth);
+          for (int k = 0; k < ncomp; k++) {
+            double re = row[2 * idz], im = row[2 * idz + 1];
+            if (k_squared != 0.) {  /* the k = 0 mode is left untouched (:368) */
+              const double green = greens_function(diff_comp, k_squared, ia[k], ib[k]);
+              const double growth_rate = 1.0;
+              re *= green * smoothing * growth_rate;
+              im *= green * smoothing * growth_rate;
+            }
+            for (int p = 0; p < nplanes; p++) {
+              const double er = E[2 * ((size_t)p * n + idx)], ei = E[2 * ((size_t)p * n + idx) + 1];
+              double *a = acc + 2 * (((size_t)k * nplanes + p) * nzh + idz);
+              a[0] += re * er - im * ei;
+              a[1] += re * ei + im * er;
+            }
+          }
+        }
+      }
+      for (int k = 0; k < ncomp; k++)
+        for (int p = 0; p < nplanes; p++)
+          memcpy(G + 2 * (((size_t)k * nplanes + p) * plane_c + (size_t)idy * nzh), acc + 2 * (((size_t)k * nplanes + p) * nzh),
+                 sizeof(double) * 2 * nzh);
+    }
+    free(acc);
+    /* y lines of every plane (fixed kz, stride nzh), then the c2r rows along z: what c2r_3d does for a whole box */
+    double *lines = (double *)malloc(sizeof(double) * 2 * n * ORC_FFT_BLOCK);
+    const int nblk = (nzh + ORC_FFT_BLOCK - 1) / ORC_FFT_BLOCK;
+#pragma omp for schedule(dynamic, 1)
+    for (int w = 0; w < ncomp * nplanes * nblk; w++) {
+      const int kz = (w % nblk) * ORC_FFT_BLOCK;
+      double *g = G + 2 * ((size_t)(w / nblk) * plane_c);
+      fft_strided_lines(c, g + 2 * kz, (size_t)nzh, nzh - kz < ORC_FFT_BLOCK ? nzh - kz : ORC_FFT_BLOCK, +1, lines);
+    }
+    free(lines);
+    double *line = (double *)malloc(sizeof(double) * 2 * n);
+#pragma omp for schedule(dynamic, 16)
+    for (long long w = 0; w < (long long)ncomp * nplanes * n; w++) {
+      const double *h = G + 2 * ((size_t)w * nzh);
+      for (int k = 0; k < nzh; k++) { line[2 * k] = h[2 * k]; line[2 * k + 1] = h[2 * k + 1]; }
+      for (int k = nzh; k < n; k++) { line[2 * k] = h[2 * (n - k)]; line[2 * k + 1] = -h[2 * (n - k) + 1]; }
+      line[1] = 0.0; line[2 * (n / 2) + 1] = 0.0;
+      fft1d(line, n, +1, c->tw, c->brev);
+      double *r = out + (size_t)w * n;
+      for (int z = 0; z < n; z++) r[z] = line[2 * z] * c->norm;
+    }
+    free(line);
+  }
+  free(E); free(G);
+  return 0;
+}
+
+/* compute_collapse_times (src/collapse_times.c:431-673) on a list of cells: d6 = [6][ncells] in the storage order
+   11,22,33,12,13,23; fmax / rmax are the cells' products.Fmax (float, compared after promotion: quirk Q2) and Rmax,
+   initialised here at ismooth 0 (:461-492) and updated by the running maximum. */
+int orc_plane_collapse_times(orc_ctx *c, int ismooth, size_t ncells, const double *d6, ORC_PRODFLOAT *fmax, int *rmax) {
+  double *dx = c->sx, *dy = c->sy, *dc = c->sc;
+  const int dn = c->nk;
+  const int per_radius = ismooth >= 0 && ismooth < ORC_MAX_SMOOTH && c->rnk[ismooth];
+  if (per_radius) { c->sx = c->rsx[ismooth]; c->sy = c->rsy[ismooth]; c->sc = c->rsc[ismooth]; c->nk = c->rnk[ismooth]; }
+  c->cur_ismooth = ismooth;
+  int all_fails = 0;
+#pragma omp parallel for num_threads(c->nthreads) schedule(static) reduction(+ : all_fails)
+  for (size_t index = 0; index < ncells; index++) {
+    if (!ismooth) { fmax[index] = -10.0; rmax[index] = -1; }
+    double diff_ten[6];
+    for (int i = 0; i < 6; i++) diff_ten[i] = d6[(size_t)i * ncells + index];
+    double lambda1, lambda2, lambda3;
+    int fail;
+    const double Fnew = orc_inverse_collapse_time(c, diff_ten, &lambda1, &lambda2, &lambda3, &fail);
+    if (fail) all_fails += 1;
+    if (fmax[index] < Fnew) {
+      fmax[index] = Fnew;
+      rmax[index] = ismooth;
+    }
+  }
+  if (per_radius) { c->sx = dx; c->sy = dy; c->sc = dc; c->nk = dn; }
+  return all_fails ? 1 : 0;
 }

@@ -144,4 +144,16 @@ double orc_my_spline_eval(const double *sx, const double *sy, const double *sc, 
    indices / fmax hold n^3 entries; returns the number selected. */
 size_t orc_select_sorted(orc_ctx *c, float flast, unsigned int *indices, float *fmax);
 
+/* Sampled x-planes of a box too large for the whole oracle (the 1024^3 of the metric; tests/test_lpt_analytic.py).
+   orc_create_planes: a context without field arrays (twiddles, splines, scalars); only the orc_plane_* entry points and the
+   per-cell functions may be used with it.  orc_plane_derivatives: compute_derivative + reverse_transform
+   (src/fmax-pfft.c:255-441, 203-228) evaluated on the x-planes xs[] only -- the x-transform as the plain sum over kx for
+   those planes, the same filter expression per mode; components (ia, ib) as compute_derivative takes them ((-1,-1): plain
+   transform); out [ncomp][nplanes][n][n].  orc_plane_collapse_times: compute_collapse_times (src/collapse_times.c:431-673)
+   on a list of cells, d6 = [6][ncells], running maximum in fmax / rmax (initialised at ismooth 0). */
+orc_ctx *orc_create_planes(int n, int nthreads);
+int orc_plane_derivatives(orc_ctx *c, const double *spec, double rs_cells, int ncomp, const int *ia, const int *ib,
+                          int nplanes, const int *xs, double *out);
+int orc_plane_collapse_times(orc_ctx *c, int ismooth, size_t ncells, const double *d6, ORC_PRODFLOAT *fmax, int *rmax);
+
 #endif

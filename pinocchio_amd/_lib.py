@@ -99,6 +99,7 @@ PROTOTYPES = {
     "pf_debug_invariant_reruns": (C.c_int, [_vp]),
     "pf_solve_ran_beside_zpass": (C.c_int, [_vp]),
     "pf_set_loopback_exchange": (C.c_int, [_vp, C.c_int]),
+    "pf_loopback_active": (C.c_int, [_vp]),
     "pf_set_sources_in_sweep": (C.c_int, [_vp, C.c_int]),
     "pf_set_lpt_order": (C.c_int, [_vp, C.c_int]),
     "pf_set_ct_interpolation": (C.c_int, [_vp, C.c_int]),

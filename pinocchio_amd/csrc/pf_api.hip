@@ -461,12 +461,16 @@ static int loopback_ared(void *, void *, size_t, int, void *) { return 0; }
 
 extern "C" int pf_set_loopback_exchange(pf_ctx *c, int copies) {
   if (!c) return 1;
+  // never on top of a real exchange: the results would silently be those of no box at all
+  if (c->rccl || (c->a2a && c->a2a != loopback_a2a) || (c->ared && c->ared != loopback_ared))
+    return pf_fail(c->rank, "pf_set_loopback_exchange: an exchange is already installed (pf_init_rccl / pf_set_exchange / fabric); release it first");
   if (!c->loopback) c->loopback = new PfLoopback;
   c->loopback->copies_left = copies; c->loopback->nranks = c->P;
   c->a2a = loopback_a2a; c->a2a_user = c->loopback; c->a2av = nullptr; c->a2av_user = nullptr;
   c->ared = loopback_ared; c->ared_user = nullptr;
   return 0;
 }
+extern "C" int pf_loopback_active(pf_ctx *c) { return c ? (c->a2a == loopback_a2a ? 1 : 0) : -1; }
 extern "C" int pf_exchange_buffers(pf_ctx *c, void **sendbuf, void **recvbuf, size_t *bytes) {
   if (sendbuf) *sendbuf = c->blockA;
   if (recvbuf) *recvbuf = c->recvA;
@@ -1270,7 +1274,21 @@ extern "C" int pf_collapse_times(pf_ctx *c, int ismooth, double *tv) {
   return 0;
 }
 
+static int sweep_body_run(pf_ctx *c, int ns, const double *radius_cells, double *true_variance, bool six_components);
+// Whatever way the body returns, the context is left in order: the fp32 invariant set index back at 0, and after a failure
+// nothing still running on the solve stream that later entry points (which share c->partials, fmax, B / B2 with it) could race with
 static int sweep_body(pf_ctx *c, int ns, const double *radius_cells, double *true_variance, bool six_components) {
+  const int rc = sweep_body_run(c, ns, radius_cells, true_variance, six_components);
+  c->inv_w = 0;
+  if (rc && rc != 2) {
+    std::string msg = g_err;  // (the synchronisation below must not disturb the message of the failure)
+    hipStreamSynchronize(c->sstream);
+    (void)hipGetLastError();
+    snprintf(g_err, sizeof(g_err), "%s", msg.c_str());
+  }
+  return rc;
+}
+static int sweep_body_run(pf_ctx *c, int ns, const double *radius_cells, double *true_variance, bool six_components) {
   PhaseTimer ft(c, 4);
   PFCHK(c, products_reset(c));
   c->sources_fresh = false;
@@ -1289,12 +1307,22 @@ static int sweep_body(pf_ctx *c, int ns, const double *radius_cells, double *tru
   // running maximum: results are bit for bit those of the in-line order.  792 against 806 ms per step at 1024^3 (three boxes);
   // a partition of the chip by CUs instead (the solve in 1024-thread workgroups holding 96 .. 144 CUs, the passes of the next
   // radius on the others) gained nothing: 806 .. 874 ms, the passes lose what the solve wins (profiles/r03_experiments.md).
-  const bool beside_z = invariants_ok && c->tune.solve_beside_z;
+  bool beside_z = invariants_ok && c->tune.solve_beside_z;
+  // the second field set B2 (six fields: 52 GB at 1024^3 on one rank) is what the LPT part allocates anyway; an Fmax-only run that
+  // cannot have it keeps every kernel in line on one field set instead of failing
+  if (beside_z && c->fb == 8) {
+    void *fresh[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 6; i++) {
+      if (c->B2[i]) continue;
+      if (hipMalloc(&c->B2[i], c->field_bytes) != hipSuccess) { (void)hipGetLastError(); c->B2[i] = nullptr; beside_z = false; break; }
+      fresh[i] = c->B2[i]; c->dev_bytes += c->field_bytes;
+    }
+    if (!beside_z)
+      for (int i = 0; i < 6; i++)
+        if (fresh[i]) { hipFree(fresh[i]); c->B2[i] = nullptr; c->dev_bytes -= c->field_bytes; }
+  }
   const bool two_field_sets = beside_z && c->fb == 8;  // (fp32 fields keep their invariants apart, in INV: two sets of those)
   struct { bool valid; int ismooth, set; } pending = {false, 0, 0};  // the solve that waits for the next z-pass
-  if (two_field_sets)
-    for (int i = 0; i < 6; i++)
-      if (!c->B2[i]) PFCHK(c, dev_alloc(c, &c->B2[i], c->field_bytes));
   bool s_live[2] = {false, false};  // a solve on the solve stream reads set s; ev_s[s] tells when it is done
   auto join_solves = [&]() -> int {  // the compute stream goes on behind everything the solve stream holds
     for (int k = 0; k < 2; k++)
@@ -1733,6 +1761,10 @@ extern "C" int pf_get_cputime(pf_ctx *c, pf_cputime *t) {
   if (!c || !t) return 1;
   resolve_events(c);
   *t = c->cpu;
+  // deriv and coll are spans on their streams.  With the solve stream on (PF_SOLVE_BESIDE_Z) the collapse pass of radius i runs
+  // beside the z-pass of radius i + 1, both spans cover that time, and the reference's report adds the two (src/fmax.c:160-170):
+  // coll keeps what the collapse passes ADD to the sweep -- the part of their span the derivative passes do not cover
+  if (c->solve_ran_beside && t->fmax > 0.0 && t->deriv + t->coll > t->fmax) t->coll = t->fmax > t->deriv ? t->fmax - t->deriv : 0.0;
   // FFT share: every pass kernel (src/fmax-pfft.c:195-199 times pfft_execute only)
   resolve_events(c);
   double fft = 0;
@@ -1831,6 +1863,9 @@ extern "C" int pf_debug_lines(int field_bytes, int n, int pass, int mul, int ban
   const int fb = field_bytes, nzh = n / 2 + 1;
   pf_ctx *nc = nullptr;  // for the error macros
   size_t n_in, n_out;    // scalars of type F
+  // strided passes: rows of `ncols` complex on the host, of an EVEN pitch on the device -- the two-column fp32 kernels move a
+  // column pair per 16-byte access and expect what the library's fields give them (an even, padded row: nzp)
+  const int pc = (ncols + 1) & ~1;
   if (pass <= 1) { if (ncols < 1) return pf_fail(0, "pf_debug_lines: ncols"); n_in = n_out = (size_t)nouter * n * ncols * 2; }
   else if (pass == 2) { n_in = (size_t)nouter * nzh * 2; n_out = (size_t)nouter * n; }
   else if (pass == 3) { n_in = (size_t)nouter * n; n_out = (size_t)nouter * nzh * 2; }
@@ -1850,25 +1885,32 @@ extern "C" int pf_debug_lines(int field_bytes, int n, int pass, int mul, int ban
   host_twiddles(n, fb, tw);
   int rc = 0;
   auto body = [&]() -> int {
-    HIPCHK(nc, hipMalloc(&d_in, n_in_alloc * fb));
+    const size_t nrows01 = (size_t)nouter * n;                        // rows of a strided pass
+    const size_t dev01 = nrows01 * (size_t)pc * 2;                     // ... and its scalars on the device
+    HIPCHK(nc, hipMalloc(&d_in, (pass <= 1 ? dev01 : n_in_alloc) * fb));
     const size_t out_b = (pass == 4) ? 8 : (size_t)fb;  // the invariants are fp64 whatever the fields are
-    HIPCHK(nc, hipMalloc(&d_out, n_out * out_b));
+    HIPCHK(nc, hipMalloc(&d_out, (pass <= 1 ? dev01 : n_out) * out_b));
     HIPCHK(nc, hipMalloc(&d_tw, tw.size()));
     HIPCHK(nc, hipMalloc((void **)&d_etab, (size_t)n * sizeof(double)));
     HIPCHK(nc, hipMalloc((void **)&d_flag, sizeof(double)));
     HIPCHK(nc, hipMemset(d_flag, 0, sizeof(double)));
     HIPCHK(nc, hipMemcpy(d_tw, tw.data(), tw.size(), hipMemcpyHostToDevice));
-    if (fb == 8) HIPCHK(nc, hipMemcpy(d_in, in, n_in * 8, hipMemcpyHostToDevice));
-    else {
+    const size_t hrow = (size_t)ncols * 2 * fb, drow = (size_t)pc * 2 * fb;  // bytes of a host / device row (strided passes)
+    if (pass <= 1) HIPCHK(nc, hipMemset(d_in, 0, dev01 * fb));
+    if (fb == 8) {
+      if (pass <= 1) HIPCHK(nc, hipMemcpy2D(d_in, drow, in, hrow, hrow, nrows01, hipMemcpyHostToDevice));
+      else HIPCHK(nc, hipMemcpy(d_in, in, n_in * 8, hipMemcpyHostToDevice));
+    } else {
       std::vector<float> h(n_in);
       for (size_t i = 0; i < n_in; i++) h[i] = (float)in[i];
-      HIPCHK(nc, hipMemcpy(d_in, h.data(), n_in * 4, hipMemcpyHostToDevice));
+      if (pass <= 1) HIPCHK(nc, hipMemcpy2D(d_in, drow, h.data(), hrow, hrow, nrows01, hipMemcpyHostToDevice));
+      else HIPCHK(nc, hipMemcpy(d_in, h.data(), n_in * 4, hipMemcpyHostToDevice));
     }
-    HIPCHK(nc, hipMemset(d_out, 0, n_out * out_b));
+    HIPCHK(nc, hipMemset(d_out, 0, (pass <= 1 ? dev01 : n_out) * out_b));
     if (pass <= 1) {
       PfStridedParams p; memset(&p, 0, sizeof(p));
       p.njobs = 1; p.job[0].in = d_in; p.job[0].out = d_out; p.job[0].mul = mul;
-      p.ain.os = (long long)n * ncols; p.ain.el_shift = ilog2i(n); p.ain.ehs = 0; p.ain.els = ncols; p.aout = p.ain;
+      p.ain.os = (long long)n * pc; p.ain.el_shift = ilog2i(n); p.ain.ehs = 0; p.ain.els = pc; p.aout = p.ain;
       p.ncols = ncols; p.nouter = nouter; p.pre = pre; p.outer_offset = outer_offset; p.rs = rs; p.growth = growth; p.tw = d_tw; p.etab = d_etab;
       p.band_e = p.band_outer = n; p.dev = dev;
       if (band < n / 2) p.band_e = band;
@@ -1895,10 +1937,13 @@ extern "C" int pf_debug_lines(int field_bytes, int n, int pass, int mul, int ban
     }
     HIPCHK(nc, hipDeviceSynchronize());
     if (pass == 4 && flag_out) HIPCHK(nc, hipMemcpy(flag_out, d_flag, sizeof(double), hipMemcpyDeviceToHost));
-    if (fb == 8 || pass == 4) HIPCHK(nc, hipMemcpy(out, d_out, n_out * 8, hipMemcpyDeviceToHost));
-    else {
+    if (fb == 8 || pass == 4) {
+      if (pass <= 1) HIPCHK(nc, hipMemcpy2D(out, hrow, d_out, drow, hrow, nrows01, hipMemcpyDeviceToHost));
+      else HIPCHK(nc, hipMemcpy(out, d_out, n_out * 8, hipMemcpyDeviceToHost));
+    } else {
       std::vector<float> h(n_out);
-      HIPCHK(nc, hipMemcpy(h.data(), d_out, n_out * 4, hipMemcpyDeviceToHost));
+      if (pass <= 1) HIPCHK(nc, hipMemcpy2D(h.data(), hrow, d_out, drow, hrow, nrows01, hipMemcpyDeviceToHost));
+      else HIPCHK(nc, hipMemcpy(h.data(), d_out, n_out * 4, hipMemcpyDeviceToHost));
       for (size_t i = 0; i < n_out; i++) out[i] = (double)h[i];
     }
     return 0;

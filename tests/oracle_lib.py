@@ -93,6 +93,11 @@ def lib(double_products: bool = False):
         L.orc_set_modified_gravity.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int, dp]
         L.orc_select_sorted.restype = C.c_size_t
         L.orc_select_sorted.argtypes = [C.c_void_p, C.c_float, C.POINTER(C.c_uint), C.POINTER(C.c_float)]
+        ip = C.POINTER(C.c_int)
+        L.orc_create_planes.restype = C.c_void_p
+        L.orc_create_planes.argtypes = [C.c_int, C.c_int]
+        L.orc_plane_derivatives.argtypes = [C.c_void_p, dp, C.c_double, C.c_int, ip, ip, C.c_int, ip, dp]
+        L.orc_plane_collapse_times.argtypes = [C.c_void_p, C.c_int, C.c_size_t, dp, C.c_void_p, ip]
         if double_products:
             _lib_dp = L
         else:
@@ -257,6 +262,68 @@ class Oracle:
         t = np.zeros(5)
         self.L.orc_timers(self.h, _dp(t))
         return dict(total=t[0], deriv=t[1], fft=t[2], coll=t[3], lpt=t[4])
+
+
+class PlaneOracle:
+    """The oracle on sampled x-planes of a box whose whole oracle would not fit the host (orc_plane_*, oracle/pf_oracle.c):
+    the reference's filter per mode, its transforms with the x-transform written as the plain sum for the sampled planes,
+    its per-cell collapse pass with the running maximum."""
+
+    HESSIAN = ((1, 1), (2, 2), (3, 3), (1, 2), (1, 3), (2, 3))  # storage order 11,22,33,12,13,23 (src/LPT.c:36-44)
+
+    def __init__(self, n: int, planes, nthreads: int = 0):
+        self.L = lib()
+        self.n = n
+        self.planes = np.ascontiguousarray(planes, dtype=np.int32)
+        if nthreads <= 0:
+            nthreads = max(1, min(os.cpu_count() or 1, n // 4))
+        self.h = self.L.orc_create_planes(n, nthreads)
+        if not self.h:
+            raise ValueError("orc_create_planes failed")
+        ncell = len(self.planes) * n * n
+        self.fmax = np.empty(ncell, dtype=np.float32)
+        self.rmax = np.empty(ncell, dtype=np.int32)
+
+    def close(self):
+        if self.h:
+            self.L.orc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def set_invgrow(self, x, y):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        assert self.L.orc_set_invgrow(self.h, _dp(x), _dp(y), len(x)) == 0
+
+    def derivatives(self, spec: np.ndarray, rs_cells: float, comps) -> np.ndarray:
+        """-> [ncomp][nplanes][n][n]: compute_derivative(ia, ib) of `spec` at smoothing rs_cells on the sampled planes"""
+        n = self.n
+        assert spec.dtype == np.complex128 and spec.shape == (n, n, n // 2 + 1) and spec.flags.c_contiguous
+        ia = np.ascontiguousarray([c[0] for c in comps], dtype=np.int32)
+        ib = np.ascontiguousarray([c[1] for c in comps], dtype=np.int32)
+        out = np.empty((len(comps), len(self.planes), n, n))
+        ip = C.POINTER(C.c_int)
+        rc = self.L.orc_plane_derivatives(self.h, _dp(spec.view(np.float64)), float(rs_cells), len(comps), ia.ctypes.data_as(ip),
+                                          ib.ctypes.data_as(ip), len(self.planes), self.planes.ctypes.data_as(ip), _dp(out))
+        assert rc == 0
+        return out
+
+    def collapse_times(self, ismooth: int, d6: np.ndarray):
+        """the collapse pass of radius ismooth on the planes' cells; d6 = [6][nplanes][n][n]"""
+        d6 = np.ascontiguousarray(d6, dtype=np.float64).reshape(6, -1)
+        assert d6.shape[1] == len(self.fmax)
+        rc = self.L.orc_plane_collapse_times(self.h, int(ismooth), d6.shape[1], _dp(d6), self.fmax.ctypes.data_as(C.c_void_p),
+                                             self.rmax.ctypes.data_as(C.POINTER(C.c_int)))
+        assert rc == 0
+
+    def sweep(self, dk: np.ndarray, radii_cells):
+        """compute_fmax's loop over the radii (src/fmax.c:81-157) on the sampled planes -> (Fmax, Rmax) [nplanes][n][n]"""
+        for ismooth, rs in enumerate(radii_cells):
+            self.collapse_times(ismooth, self.derivatives(dk, rs, self.HESSIAN))
+        shape = (len(self.planes), self.n, self.n)
+        return self.fmax.reshape(shape), self.rmax.reshape(shape)
 
 
 def ell_classic(l1, l2, l3) -> float:

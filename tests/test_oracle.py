@@ -515,3 +515,38 @@ def test_grid_sizes_that_are_not_a_power_of_two(n):
         assert np.max(np.abs(p[name].astype(np.float64) - d[name])) <= 4e-7 * np.max(np.abs(d[name]))
     with pytest.raises(ValueError):
         oracle_lib.Oracle(15, 1)
+
+
+@pytest.mark.parametrize("n", [16, 32, 24])
+def test_sampled_plane_oracle_is_the_whole_oracle_on_its_planes(n):
+    """orc_plane_derivatives / orc_plane_collapse_times (the form the 1024^3 test of the GPU suite uses: the whole oracle
+    would need ~450 GB there) against the whole-box oracle: second derivatives of every radius to rounding, plain
+    transform, Fmax / Rmax after the sweep, on planes that include the first and the last"""
+    dk = synth.make_density(n, seed=11 + n)
+    radii = synth.radii_ladder(5) / (64.0 / n)
+    radii[-1] = 0.0
+    x, y = synth.invgrow_table("lcdm")
+    planes = [0, 1, n // 3, n // 2, n - 1]
+    o = oracle_lib.Oracle(n, 2)
+    o.set_density(dk)
+    o.set_invgrow(x, y)
+    po = oracle_lib.PlaneOracle(n, planes, 2)
+    po.set_invgrow(x, y)
+    for rs in radii:
+        want = o.second_derivatives(rs)
+        got = po.derivatives(dk, rs, po.HESSIAN)
+        scale = max(np.max(np.abs(w)) for w in want)
+        for i in range(6):
+            assert np.max(np.abs(got[i] - want[i][planes])) <= 1e-13 * scale, (rs, i)
+    plain = po.derivatives(dk, 0.0, [(-1, -1)])[0]
+    want = o.c2r(dk) / n ** 3
+    assert np.max(np.abs(plain - want[planes])) <= 1e-13 * np.max(np.abs(want))
+    o.compute_fmax(radii, do_lpt=False)
+    p = o.products()
+    fmax, rmax = po.sweep(dk, radii)
+    wf, wr = p["Fmax"][planes], p["Rmax"][planes]
+    ulp = np.spacing(np.maximum(np.abs(wf), 1.0).astype(np.float32)).astype(np.float64)
+    diff = np.abs(fmax.astype(np.float64) - wf.astype(np.float64))
+    assert np.mean(diff > 2 * ulp) <= 1e-3 and np.mean(diff > 0) < 5e-3   # two correct transforms differ by rounding
+    assert np.mean(rmax != wr) < 1e-3
+    assert fmax.max() > 1.0
