@@ -1863,9 +1863,9 @@ extern "C" int pf_debug_lines(int field_bytes, int n, int pass, int mul, int ban
   const int fb = field_bytes, nzh = n / 2 + 1;
   pf_ctx *nc = nullptr;  // for the error macros
   size_t n_in, n_out;    // scalars of type F
-  // strided passes: rows of `ncols` complex on the host, of an EVEN pitch on the device -- the two-column fp32 kernels move a
-  // column pair per 16-byte access and expect what the library's fields give them (an even, padded row: nzp)
-  const int pc = (ncols + 1) & ~1;
+  // strided passes: rows of `ncols` complex on the host, padded to whole tiles on the device as the library's fields are (nzp):
+  // the two-column fp32 kernels move a column pair per 16-byte access, the unpredicated kernels whole tiles
+  const int pc = (ncols + 15) & ~15;  // (whole tiles of every instantiation: 8 fp64, 16 fp32 columns -- the unpredicated form of the pass runs too)
   if (pass <= 1) { if (ncols < 1) return pf_fail(0, "pf_debug_lines: ncols"); n_in = n_out = (size_t)nouter * n * ncols * 2; }
   else if (pass == 2) { n_in = (size_t)nouter * nzh * 2; n_out = (size_t)nouter * n; }
   else if (pass == 3) { n_in = (size_t)nouter * n; n_out = (size_t)nouter * nzh * 2; }

@@ -27,6 +27,22 @@ __device__ __forceinline__ long long pf_addr(const PfAddr &a, int outer, int e, 
   return (long long)outer * a.os + (long long)(e >> a.el_shift) * a.ehs + (long long)(e & ((1 << a.el_shift) - 1)) * a.els + col;
 }
 
+// The same address split into a part that is the same for every lane of a workgroup and a 32-bit part per lane, for the
+// element e = tl + m * NT of a thread (m = 0..7 a constant after unrolling).  When a slab holds whole multiples of NT elements
+// (el = 1 << el_shift >= NT: up to eight ranks), e >> el_shift and e & (el - 1) follow from m alone:
+//   m = q r + s, r = el / NT:  e >> el_shift = q,  e & (el - 1) = tl + s NT
+// so that  address = [outer os + q ehs + s NT els + tile's first column]  +  [tl els + column in the tile].
+// The first bracket lives in scalar registers (scalar unit, 64-bit), the second is one 32-bit register per thread and job, and a
+// load or store takes them as they are (global_load ... v_offset, s[base]) -- as one 64-bit address per element the eight
+// addresses of a job cost ~110 vector instructions, among them 24 quarter-rate 64-bit multiply-adds, a fifth of the job's
+// vector work (which is what bounds the pass: profiles/r04_notes.md).
+template <int NT> __device__ __forceinline__ long long pf_addr_uniform(const PfAddr &a, int outer, int m, int col0) {
+  const int rs = a.el_shift - pf_ilog2(NT);
+  const int q = m >> rs, s = m & ((1 << rs) - 1);
+  return (long long)outer * a.os + (long long)q * a.ehs + (long long)(s * NT) * a.els + col0;
+}
+__device__ __forceinline__ unsigned pf_addr_lane(const PfAddr &a, int tl, int c) { return (unsigned)tl * (unsigned)a.els + (unsigned)c; }
+
 // XCD-aware work-item id: hardware deals consecutive workgroups round-robin over the 8 XCDs
 // (speed only, never correctness); give each XCD a contiguous range of tiles so that
 // neighbouring tiles, which share 128-byte lines when T*sizeof(complex) < 128, meet in one L2.
@@ -46,6 +62,13 @@ template <typename F> struct PfCols {
   static constexpr int n = 1;
   static __device__ __forceinline__ pfc<F> load(const pfc<S> *base, long long off) { return pf_ld_stream(base + off); }
   static __device__ __forceinline__ void store(pfc<S> *base, long long off, pfc<F> v, bool) { pf_st_stream(base + off, v); }
+  // uniform base (complex elements) + per-lane offset (complex elements, 32 bits)
+  static __device__ __forceinline__ pfc<F> load_ul(const pfc<S> *base, long long u, unsigned lane) {
+    return pf_ld_stream(reinterpret_cast<const pfc<S> *>(reinterpret_cast<const char *>(base + u) + (size_t)(lane * (unsigned)sizeof(pfc<S>))));
+  }
+  static __device__ __forceinline__ void store_ul(pfc<S> *base, long long u, unsigned lane, pfc<F> v, bool) {
+    pf_st_stream(reinterpret_cast<pfc<S> *>(reinterpret_cast<char *>(base + u) + (size_t)(lane * (unsigned)sizeof(pfc<S>))), v);
+  }
 };
 template <> struct PfCols<pf_f32x2> {
   using S = float;
@@ -73,9 +96,16 @@ template <> struct PfCols<pf_f32x2> {
       pf_st_stream(base + off, pf_mk<float>(v.x.x, v.y.x));
     }
   }
+  static __device__ __forceinline__ pfc<pf_f32x2> load_ul(const pfc<float> *base, long long u, unsigned lane) {
+    return load(reinterpret_cast<const pfc<float> *>(reinterpret_cast<const char *>(base + u) + (size_t)(lane * (unsigned)sizeof(pfc<float>))), 0);
+  }
+  static __device__ __forceinline__ void store_ul(pfc<float> *base, long long u, unsigned lane, pfc<pf_f32x2> v, bool v1) {
+    store(reinterpret_cast<pfc<float> *>(reinterpret_cast<char *>(base + u) + (size_t)(lane * (unsigned)sizeof(pfc<float>))), 0, v, v1);
+  }
 };
 
-template <typename F, int N, int T, int DIR>
+// FA: addresses as a uniform 64-bit part plus a 32-bit part per lane (pf_addr_uniform; the launcher checks the conditions)
+template <typename F, int N, int T, int DIR, bool FA>
 __global__ void __launch_bounds__(T *N / 8) __attribute__((amdgpu_waves_per_eu(4))) k_strided(const PfStridedParams p, const long long nwork, const int ntiles) {
   using C = pfc<F>;
   using COLS = PfCols<F>;
@@ -111,7 +141,8 @@ __global__ void __launch_bounds__(T *N / 8) __attribute__((amdgpu_waves_per_eu(4
       const int e = tlj + m * NT;
       const int se = e > N / 2 ? e - N : e;
       const bool inband = se <= p.band_e && se >= -p.band_e;
-      src[m] = (valid && inband) ? COLS::load(in, pf_addr(p.ain, outer, e, colj)) : pf_zero<F>();
+      if constexpr (FA) src[m] = (valid && inband) ? COLS::load_ul(in, pf_addr_uniform<NT>(p.ain, outer, m, NL * tile * T), pf_addr_lane(p.ain, tlj, colj - NL * tile * T)) : pf_zero<F>();
+      else src[m] = (valid && inband) ? COLS::load(in, pf_addr(p.ain, outer, e, colj)) : pf_zero<F>();
       if constexpr (NL > 1) { if (!valid1) { src[m].x.y = 0.f; src[m].y.y = 0.f; } }
     }
   };
@@ -185,6 +216,13 @@ __global__ void __launch_bounds__(T *N / 8) __attribute__((amdgpu_waves_per_eu(4
     if (j + 1 < p.njobs && p.job[j + 1].in != p.job[j].in) load_tile(p.job[j + 1].in, tlj, colj);
     PfStages<F, N, DIR, 1>::run(
         v, tlj, tw, [&](int pos, C val) { lds[pos * T + cj] = val; }, [&](int pos) { return lds[pos * T + cj]; });
+#if defined(PF_DUMMY_VALU) && PF_DUMMY_VALU > 0  // (A/B probe: how much of the arithmetic of a job is hidden behind its memory traffic)
+    if constexpr (NL == 1) {
+      double a = (double)v[0].x;
+      for (int i = 0; i < PF_DUMMY_VALU; i++) a = __builtin_fma(a, 1.0000001, 1e-30);
+      v[0].x = (F)a;
+    }
+#endif
     if (valid) {
       pfc<S> *__restrict__ out = reinterpret_cast<pfc<S> *>(p.job[j].out);
       if (PF_SLAB_STORE && p.out_ne > 0) {  // uniform: the slab of the transformed axis this rank keeps
@@ -193,6 +231,10 @@ __global__ void __launch_bounds__(T *N / 8) __attribute__((amdgpu_waves_per_eu(4
           const int e = tlj + m * NT;
           if ((unsigned)(e - p.out_e0) < (unsigned)p.out_ne) COLS::store(out, pf_addr(p.aout, outer, e, colj), v[m], valid1);
         }
+      } else if constexpr (FA) {
+        const unsigned lane = pf_addr_lane(p.aout, tlj, colj - NL * tile * T);
+#pragma unroll
+        for (int m = 0; m < 8; m++) COLS::store_ul(out, pf_addr_uniform<NT>(p.aout, outer, m, NL * tile * T), lane, v[m], valid1);
       } else {
 #pragma unroll
         for (int m = 0; m < 8; m++) {
@@ -547,12 +589,9 @@ template <typename F, int N> struct PfTileCols {
   static constexpr int value = b < 1 ? 1 : b;
 };
 
-template <typename F, int N, int DIR>
-static int launch_strided_n(const PfStridedParams &p, hipStream_t st) {
+template <typename F, int N, int DIR, bool FA>
+static int launch_strided_v(const PfStridedParams &p, hipStream_t st, int ntiles, long long nwork) {
   constexpr int T = PfTileCols<F, N>::value;
-  constexpr int NL = pf_lane<F>::n;  // columns per thread
-  const int ntiles = (p.ncols + NL * T - 1) / (NL * T);
-  const long long nwork = (long long)ntiles * p.nouter;
   dim3 grid((unsigned)(((nwork + 7) >> 3) << 3), 1, 1), block(T * N / 8, 1, 1);
   const size_t shm = (size_t)N * T * sizeof(pfc<F>);
   if (shm > 64 * 1024) {
@@ -562,15 +601,31 @@ static int launch_strided_n(const PfStridedParams &p, hipStream_t st) {
     static std::atomic<bool> raised[PF_MAX_DEVICES];  // per instantiation and device
     const int d = p.dev >= 0 && p.dev < PF_MAX_DEVICES ? p.dev : 0;
     if (!raised[d].load(std::memory_order_acquire)) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_strided<F, N, T, DIR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_strided<F, N, T, DIR, FA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) {
         fprintf(stderr, "ERROR on task 0: hipFuncSetAttribute(MaxDynamicSharedMemorySize = %zu) refused for the %d-point strided pass on device %d\n", shm, N, d);
         return 3;
       }
       raised[d].store(true, std::memory_order_release);
     }
   }
-  hipLaunchKernelGGL((k_strided<F, N, T, DIR>), grid, block, shm, st, p, nwork, ntiles);
+  hipLaunchKernelGGL((k_strided<F, N, T, DIR, FA>), grid, block, shm, st, p, nwork, ntiles);
   return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+template <typename F, int N, int DIR>
+static int launch_strided_n(const PfStridedParams &p, hipStream_t st) {
+  constexpr int T = PfTileCols<F, N>::value;
+  constexpr int NL = pf_lane<F>::n;  // columns per thread
+  constexpr int NT = N / 8;
+  using S = typename pf_lane<F>::type;
+  const int ntiles = (p.ncols + NL * T - 1) / (NL * T);
+  const long long nwork = (long long)ntiles * p.nouter;
+  // split addresses (pf_addr_uniform): a slab is a whole number of NT elements on both sides (up to eight ranks), and the
+  // per-lane part -- at most (NT - 1) rows of the transformed axis plus a tile's columns -- fits 32 bits in bytes
+  auto lane_fits = [&](const PfAddr &a) {
+    return (1 << a.el_shift) >= NT && a.els > 0 && ((unsigned long long)(NT - 1) * (unsigned long long)a.els + (unsigned long long)(NL * T)) * sizeof(pfc<S>) < (1ull << 32);
+  };
+  if (lane_fits(p.ain) && lane_fits(p.aout)) return launch_strided_v<F, N, DIR, true>(p, st, ntiles, nwork);
+  return launch_strided_v<F, N, DIR, false>(p, st, ntiles, nwork);
 }
 // fp32 lines of 1024 points and more: two columns per thread (the thread budget, 8 N / 8 <= 1024, would otherwise leave 64-byte
 // row segments at 1024 points and 32-byte ones at 2048); PF_F32_PAIRS=0 builds the one-column kernels for them too

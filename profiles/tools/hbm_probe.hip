@@ -67,8 +67,11 @@ struct TileShape {
 // ORDER 1: m outermost, outputs inside (a row's segments of all outputs together);
 // ORDER 2: as 0, rows remapped so that a thread's 8 stores go to 8 CONSECUTIVE rows (e = 8 tl + m): a wave then covers 64
 //          consecutive rows of 128 B over its 8 instructions instead of 8 rows 128 apart per instruction.
+// spin: dependent fp64 fma per thread and job between the loads and the stores, in six pieces with a workgroup barrier behind
+// each (the arithmetic and the LDS exchanges of a 1024-point transform: ~500 fp64 instructions per job); fence: 1 = an
+// s_waitcnt vmcnt(0) behind the first piece of every job (what a global twiddle load in the job loop amounts to)
 template <bool NTL, bool NTS, int ORDER>
-__global__ void __launch_bounds__(1024) k_tile(const f4 *__restrict__ in, f4 *__restrict__ out, TileShape s, long long nwork) {
+__global__ void __launch_bounds__(1024) k_tile(const f4 *__restrict__ in, f4 *__restrict__ out, TileShape s, long long nwork, int spin, int fence) {
   extern __shared__ char smem[];  // 128 KB: one workgroup per CU, as the passes
   const long long per = (nwork + 7) >> 3;
   const long long w = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
@@ -94,6 +97,15 @@ __global__ void __launch_bounds__(1024) k_tile(const f4 *__restrict__ in, f4 *__
     __syncthreads();
     v[0] = reinterpret_cast<f4 *>(smem)[tid ^ 1];
     __syncthreads();
+    if (spin > 0) {
+      double a = (double)v[0].x, b = 1.0000001;
+      for (int piece = 0; piece < 6; piece++) {
+        for (int i = 0; i < spin / 6; i++) a = __builtin_fma(a, b, 1e-9);
+        if (piece == 0 && fence) __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0) (gfx9 encoding: vmcnt low bits 3:0 and 15:14 = 0, others max)
+        __syncthreads();
+      }
+      v[0].x = (float)a;
+    }
     if (ORDER == 1) {
 #pragma unroll
       for (int m = 0; m < 8; m++)
@@ -164,17 +176,17 @@ static void run_lin_all(const f4 *a, f4 *b, size_t n, float *sink, int ncu, hipS
 }
 
 template <bool NTL, bool NTS, int ORDER>
-static void run_tile(const char *name, const TileShape &s, const f4 *in, f4 *out, hipStream_t st) {
+static void run_tile(const char *name, const TileShape &s, const f4 *in, f4 *out, hipStream_t st, int spin = 0, int fence = 0) {
   const long long nwork = (long long)s.ntiles * s.nouter;
   const unsigned grid = (unsigned)(((nwork + 7) >> 3) << 3);
   const size_t shm = 128 * 1024;
   static bool raised = false;
   if (!raised) { CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile<NTL, NTS, ORDER>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); raised = true; }
-  const double ms = time_best(3, st, [&]() { hipLaunchKernelGGL((k_tile<NTL, NTS, ORDER>), dim3(grid), dim3(1024), shm, st, in, out, s, nwork); });
+  const double ms = time_best(3, st, [&]() { hipLaunchKernelGGL((k_tile<NTL, NTS, ORDER>), dim3(grid), dim3(1024), shm, st, in, out, s, nwork, spin, fence); });
   const double bytes = (double)nwork * 1024.0 * 128.0 * (s.nin + s.nout);
-  printf("{\"family\": \"tile\", \"shape\": \"%s\", \"nin\": %d, \"nout\": %d, \"nt_load\": %d, \"nt_store\": %d, \"order\": %d, \"ms\": %.4f, \"TBps\": %.3f, "
+  printf("{\"family\": \"tile\", \"shape\": \"%s\", \"nin\": %d, \"nout\": %d, \"nt_load\": %d, \"nt_store\": %d, \"order\": %d, \"spin\": %d, \"fence\": %d, \"ms\": %.4f, \"TBps\": %.3f, "
          "\"read_GB\": %.2f, \"write_GB\": %.2f}\n",
-         name, s.nin, s.nout, (int)NTL, (int)NTS, ORDER, ms, bytes / ms * 1e-9, (double)nwork * 131072.0 * s.nin * 1e-9, (double)nwork * 131072.0 * s.nout * 1e-9);
+         name, s.nin, s.nout, (int)NTL, (int)NTS, ORDER, spin, fence, ms, bytes / ms * 1e-9, (double)nwork * 131072.0 * s.nin * 1e-9, (double)nwork * 131072.0 * s.nout * 1e-9);
   fflush(stdout);
 }
 template <int ORDER>
@@ -187,6 +199,7 @@ static void run_tile_nt(const char *name, const TileShape &s, const f4 *in, f4 *
 
 int main(int argc, char **argv) {
   const bool quick = argc > 1 && !strcmp(argv[1], "quick");
+  const bool tiles_only = argc > 1 && !strcmp(argv[1], "tiles");
   hipDeviceProp_t prop;
   CHECK(hipGetDeviceProperties(&prop, 0));
   const int ncu = prop.multiProcessorCount;
@@ -194,7 +207,7 @@ int main(int argc, char **argv) {
   CHECK(hipStreamCreate(&st));
   fprintf(stderr, "%s, %d CUs\n", prop.name, ncu);
   // ---- flat arrays: 4 GiB each (16 x the Infinity Cache)
-  {
+  if (!tiles_only) {
     const size_t bytes = quick ? (size_t)1 << 30 : (size_t)4 << 30, n = bytes / 16;
     f4 *a, *b; float *sink;
     CHECK(hipMalloc(&a, bytes)); CHECK(hipMalloc(&b, bytes)); CHECK(hipMalloc(&sink, 4));
@@ -209,8 +222,10 @@ int main(int argc, char **argv) {
   {
     const long long zp = 520, n = quick ? 256 : 1024, plane = n * zp, field = n * plane;
     f4 *in, *out;
-    CHECK(hipMalloc(&in, (size_t)3 * field * 16)); CHECK(hipMalloc(&out, (size_t)6 * field * 16));
-    CHECK(hipMemset(in, 0, (size_t)3 * field * 16)); CHECK(hipMemset(out, 0, (size_t)6 * field * 16));
+    const size_t slack = (size_t)8 << 21;  // room for the field pads below
+    CHECK(hipMalloc(&in, (size_t)3 * field * 16 + slack)); CHECK(hipMalloc(&out, (size_t)6 * field * 16 + slack));
+    CHECK(hipMemset(in, 0, (size_t)3 * field * 16 + slack)); CHECK(hipMemset(out, 0, (size_t)6 * field * 16 + slack));
+    fprintf(stderr, "in %p out %p\n", (void *)in, (void *)out);
     TileShape x13 = {1, 3, plane, zp, zp, n * zp, 65, (int)n, field};   // x-pass: reads [kx][ky][kz] along kx, writes [ky][x][kz]
     TileShape y36 = {3, 6, n * zp, zp, zp, n * zp, 65, (int)n, field};  // y-pass: reads [ky][x][kz] along ky (plane stride), writes [x][y][kz]
     TileShape x12 = x13; x12.nout = 2;
@@ -231,6 +246,22 @@ int main(int argc, char **argv) {
       run_tile<true, true, 0>("ypass_1to1", y11, in, out, st);
       run_tile<true, true, 0>("ypass_3to6_rowstride_in", y36r, in, out, st);
       run_tile<true, true, 2>("ypass_3to6_rowstride_in", y36r, in, out, st);
+      // the same shapes with arithmetic between the loads and the stores, with and without a fence in every job
+      for (int spin : {240, 480, 720})
+        for (int fence : {0, 1}) {
+          run_tile<true, true, 0>("xpass_1to3", x13, in, out, st, spin, fence);
+          run_tile<true, true, 0>("ypass_3to6", y36, in, out, st, spin, fence);
+        }
+      // fields whose bases are not congruent modulo a large power of two (the library's fields are 65 x 2^27 bytes each)
+      for (long long pad_bytes : {0LL, 4096LL, 69632LL, 1052672LL, 2101248LL}) {
+        TileShape yp = y36, xp = x13;
+        yp.field = field + pad_bytes / 16; xp.field = field + pad_bytes / 16;
+        char nm[64];
+        snprintf(nm, sizeof(nm), "ypass_3to6_fieldpad_%lld", pad_bytes);
+        run_tile<true, true, 0>(nm, yp, in, out, st);
+        snprintf(nm, sizeof(nm), "xpass_1to3_fieldpad_%lld", pad_bytes);
+        run_tile<true, true, 0>(nm, xp, in, out, st);
+      }
     }
     CHECK(hipFree(in)); CHECK(hipFree(out));
   }
