@@ -290,9 +290,9 @@ def test_full_bench_workload_on_the_box_of_the_metric(api):
         for ismooth, rs in enumerate(radii):
             hess.append(po.derivatives(dk, rs, po.HESSIAN))
             po.collapse_times(ismooth, hess[-1])
-        amp = max(float(np.max(np.abs(h))) for h in hess[-1])
+        hamp = max(float(np.max(np.abs(hh))) for hh in hess[-1])
         for i in range(6):   # the R = 0 Hessian still in place on the device
-            assert np.max(np.abs(d[i] - hess[-1][i])) <= 1e-12 * amp, ("hessian", i)
+            assert np.max(np.abs(d[i] - hess[-1][i])) <= 1e-12 * hamp, ("hessian", i)
         shape = (len(planes), n, n)
         wf, wr = po.fmax.reshape(shape), po.rmax.reshape(shape)
         gf = f.block("FMAX").reshape(n, n, n)[planes]
@@ -307,11 +307,11 @@ def test_full_bench_workload_on_the_box_of_the_metric(api):
         rng = np.random.default_rng(1)
         for c in far:
             ir = int(gr[c])
-            h = np.array([hess[ir][i][c] for i in range(6)])
+            hc = np.array([hess[ir][i][c] for i in range(6)])
             o8 = oracle_lib.Oracle(8, 1)
             o8.set_invgrow(x, y)
-            fo = o8.inverse_collapse_time(h)[0]
-            spread = max(abs(o8.inverse_collapse_time(h * (1.0 + rng.uniform(-4.4e-16, 4.4e-16, 6)))[0] - fo) for _ in range(64))
+            fo = o8.inverse_collapse_time(hc)[0]
+            spread = max(abs(o8.inverse_collapse_time(hc * (1.0 + rng.uniform(-4.4e-16, 4.4e-16, 6)))[0] - fo) for _ in range(64))
             assert abs(float(gf[c]) - fo) <= max(8.0 * spread, 2.0 * float(ulp[c])), (c, fo, float(gf[c]), spread)
         del hess, gf, gr
         # (5) the 3LPT(b) source (src/LPT.c:89-91, 134-137) on the same planes: 2 (d11 + d22 + d33) S2 minus the contraction of
