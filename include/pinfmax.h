@@ -328,6 +328,10 @@ int pf_debug_invariant_reruns(pf_ctx *ctx);
    the radius that follows (PF_SOLVE_BESIDE_Z): the two kernels' HIP-event spans then overlap -- per-kernel
    times of pf_kernel_stats are spans, not shares of the step; 0 when every kernel ran in line */
 int pf_solve_ran_beside_zpass(pf_ctx *ctx);
+/* 1: in the default (fast) arithmetic the inverse growing mode of radius `ismooth` (-1: the shared spline) comes from the
+   polynomial table built from its knots by pf_set_invgrow (csrc/pf_gtab.h; *max_rel_err: its largest relative error against
+   the composite 10^(-S(log10 D)) in long double); 0: the series forms are used (table refused, PF_GTAB=0, PF_EXACT_LIBM=1) */
+int pf_invgrow_table_status(pf_ctx *ctx, int ismooth, double *max_rel_err);
 /* per-cell solver on a list of Hessians d[6*count] -> F[count] (tests of
    inverse_collapse_time, src/collapse_times.c:679-776), ismooth selects the spline */
 int pf_collapse_cells(pf_ctx *ctx, int ismooth, const double *d, size_t count, double *F);

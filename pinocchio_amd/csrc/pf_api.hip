@@ -133,6 +133,11 @@ struct pf_ctx {
   double *spl;         // device spline tables: [slot][5][PF_KNOT_CAP] = x, y, c, b, d
   int spl_n[PF_MAX_SMOOTH + 1];
   bool spl_set[PF_MAX_SMOOTH + 1];
+  // the same splines as polynomial tables of 10^(-S(log10 D)) in D (pf_gtab.h): [slot][PF_GT_DOUBLES], start tables [slot][PF_GT_MAX_BINS]
+  double *gt;
+  unsigned short *gt_lut;
+  bool gt_ok[PF_MAX_SMOOTH + 1];
+  double gt_err[PF_MAX_SMOOTH + 1];
   double growth[4];
   // k-binned growth (SCALE_DEPENDENT build): per order log10-growth table on the device, 0 entries = scalar
   int gt_n[4];
@@ -177,6 +182,7 @@ struct pf_ctx {
   std::vector<EvPair> phase_evs;  // kind: 0 deriv 1 coll 2 lpt 3 mem
 };
 
+#define PF_GT_DOUBLES (PF_GT_HEADER + (PF_GT_MAX_INT + 1) * PF_GT_REC)
 #define PF_NBLK 2048
 #define PF_KNOT_CAP 512
 #define PF_KBIN_CAP 32
@@ -265,6 +271,7 @@ static void read_tuning(PfTuning *t) {
   t->replicate = env_int("PF_REPLICATE_DK", -1);  // -1: by the number of ranks (pf_create), 0 / 1: off / on
   t->exact_libm = env_int("PF_EXACT_LIBM", 0) != 0;
   t->solve_beside_z = env_int("PF_SOLVE_BESIDE_Z", 1) != 0;
+  t->gtab = env_int("PF_GTAB", 1) != 0;
   // fault injection for the tests of the exchange pipeline (tests/test_gpu_multirank.py): "recv" drops the wait of the
   // compute stream for the exchange it is about to consume, "send" the wait of the exchange for the x-pass that fills its blocks
   const char *fault = getenv("PF_DEBUG_PIPELINE_FAULT");
@@ -332,6 +339,8 @@ static int create_body(pf_ctx *c, const pf_config *cfg) {
   PFCHK(c, dev_alloc(c, (void **)&c->hist, PF_NBINS * sizeof(unsigned long long)));
   PFCHK(c, dev_alloc(c, (void **)&c->spl, (size_t)(PF_MAX_SMOOTH + 1) * 5 * PF_KNOT_CAP * sizeof(double)));
   PFCHK(c, dev_alloc(c, (void **)&c->gtab, 4 * PF_KBIN_CAP * sizeof(double)));
+  PFCHK(c, dev_alloc(c, (void **)&c->gt, (size_t)(PF_MAX_SMOOTH + 1) * PF_GT_DOUBLES * sizeof(double)));
+  PFCHK(c, dev_alloc(c, (void **)&c->gt_lut, (size_t)(PF_MAX_SMOOTH + 1) * PF_GT_MAX_BINS * sizeof(unsigned short)));
   PFCHK(c, dev_alloc(c, (void **)&c->etab, (size_t)c->n * sizeof(double)));
   HIPCHK(c, hipMemsetAsync(c->scal, 0, SC_COUNT * sizeof(double), c->stream));
   {
@@ -387,7 +396,8 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   c->blockA = nullptr; c->dk = nullptr; c->recvA = nullptr; c->tw = nullptr;
   c->blockA2 = nullptr; c->recvA2 = nullptr; c->cstream = nullptr; c->dk_full = nullptr; c->replicate = false; c->dk_full_valid = false; for (int k = 0; k < 3; k++) c->INV[0][k] = c->INV[1][k] = nullptr; c->inv_w = 0;
   c->fmax = nullptr; c->rmax = nullptr; c->vel12 = nullptr; c->partials = nullptr; c->scal = nullptr; c->hist = nullptr; c->spl = nullptr;
-  c->gtab = nullptr; c->etab = nullptr; c->ct_block = nullptr;
+  c->gtab = nullptr; c->etab = nullptr; c->ct_block = nullptr; c->gt = nullptr; c->gt_lut = nullptr;
+  memset(c->gt_ok, 0, sizeof(c->gt_ok)); memset(c->gt_err, 0, sizeof(c->gt_err));
   for (int i = 0; i < 2; i++) c->ev_x[i] = c->ev_r[i] = c->ev_y[i] = c->ev_s[i] = nullptr;
   c->sstream = nullptr; c->solve_ran_beside = false; c->loopback = nullptr;
   c->pipeline = c->P > 1 && tune.pipeline;
@@ -415,7 +425,7 @@ extern "C" int pf_destroy(pf_ctx *c) {
   hipFree(c->dk); hipFree(c->blockA); hipFree(c->recvA); hipFree(c->tw); hipFree(c->blockA2); hipFree(c->recvA2); hipFree(c->dk_full); for (int k = 0; k < 3; k++) { hipFree(c->INV[0][k]); hipFree(c->INV[1][k]); }
   for (int i = 0; i < 6; i++) { hipFree(c->B[i]); hipFree(c->B2[i]); }
   for (int i = 0; i < 3; i++) hipFree(c->S[i]);
-  hipFree(c->fmax); hipFree(c->rmax); hipFree(c->vel12); hipFree(c->partials); hipFree(c->partials_src); hipFree(c->scal); hipFree(c->hist); hipFree(c->spl); hipFree(c->gtab); hipFree(c->etab); hipFree(c->ct_block); hipFree(c->W);
+  hipFree(c->fmax); hipFree(c->rmax); hipFree(c->vel12); hipFree(c->partials); hipFree(c->partials_src); hipFree(c->scal); hipFree(c->hist); hipFree(c->spl); hipFree(c->gt); hipFree(c->gt_lut); hipFree(c->gtab); hipFree(c->etab); hipFree(c->ct_block); hipFree(c->W);
   pf_gfft_destroy(c->fft_c2r); pf_gfft_destroy(c->fft_r2c);
   for (auto &e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   for (auto &e : c->phase_evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -1061,7 +1071,25 @@ extern "C" int pf_set_invgrow(pf_ctx *c, int ismooth, const double *x, const dou
   const int slot = ismooth + 1;  // slot 0 = shared spline
   HIPCHK(c, hipMemcpy(c->spl + (size_t)slot * 5 * PF_KNOT_CAP, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
   c->spl_n[slot] = n; c->spl_set[slot] = true;
+  {  // the polynomial table of the fast flavour (refused for knots it cannot serve: the solve then takes the series forms)
+    std::vector<double> g(PF_GT_DOUBLES);
+    std::vector<unsigned short> lut(PF_GT_MAX_BINS);
+    const bool ok = pf_gtab_build(&h[0], &h[PF_KNOT_CAP], &h[2 * PF_KNOT_CAP], &h[3 * PF_KNOT_CAP], &h[4 * PF_KNOT_CAP], n, g.data(), lut.data()) == 0;
+    c->gt_ok[slot] = ok; c->gt_err[slot] = g[5];
+    if (ok) {
+      HIPCHK(c, hipMemcpy(c->gt + (size_t)slot * PF_GT_DOUBLES, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice));
+      HIPCHK(c, hipMemcpy(c->gt_lut + (size_t)slot * PF_GT_MAX_BINS, lut.data(), lut.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+    }
+  }
   return 0;
+}
+// 1: the spline of `ismooth` (-1: the shared one) is served by its polynomial table in the fast flavour; *max_rel_err: the
+// table's largest relative error against the long double composite, found when it was built
+extern "C" int pf_invgrow_table_status(pf_ctx *c, int ismooth, double *max_rel_err) {
+  if (!c || ismooth < -1 || ismooth >= PF_MAX_SMOOTH) return -1;
+  const int slot = (ismooth >= 0 && c->spl_set[ismooth + 1]) ? ismooth + 1 : 0;
+  if (max_rel_err) *max_rel_err = c->gt_err[slot];
+  return c->spl_set[slot] && c->gt_ok[slot] && c->tune.gtab && c->fast_libm ? 1 : 0;
 }
 static int spline_for(pf_ctx *c, int ismooth, PfSplineDev *s) {
   int slot = (ismooth >= 0 && ismooth < PF_MAX_SMOOTH && c->spl_set[ismooth + 1]) ? ismooth + 1 : 0;
@@ -1069,6 +1097,9 @@ static int spline_for(pf_ctx *c, int ismooth, PfSplineDev *s) {
   const double *t = c->spl + (size_t)slot * 5 * PF_KNOT_CAP;
   s->x = t; s->y = t + PF_KNOT_CAP; s->c = t + 2 * PF_KNOT_CAP; s->b = t + 3 * PF_KNOT_CAP; s->d = t + 4 * PF_KNOT_CAP;
   s->n = c->spl_n[slot];
+  const bool gt = c->gt_ok[slot] && c->tune.gtab;
+  s->gt = gt ? c->gt + (size_t)slot * PF_GT_DOUBLES : nullptr;
+  s->gt_lut = gt ? c->gt_lut + (size_t)slot * PF_GT_MAX_BINS : nullptr;
   return 0;
 }
 

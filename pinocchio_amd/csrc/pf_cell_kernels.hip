@@ -45,11 +45,26 @@ PF_HD void pf_lpt_sources_cell(const double d[6], double &src2, double &src31, d
 // PR: PRODFLOAT, the type of products.Fmax (float; double in a -DDOUBLE_PRECISION_PRODUCTS build, src/pinocchio.h:219-225)
 template <typename F, bool FAST, bool TAB = false, bool INV = false, bool SNG = false, bool SRC = false, int FLAV = 0, typename PR = float>
 __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
-  __shared__ double sk[TAB ? PF_CT_NBINS_D : 5 * PF_MAX_KNOTS];
+  // GT: the fast flavour's inverse growing mode from the polynomial table of the spline (pf_gtab.h), staged in LDS in place
+  // of the knot arrays; D outside the table (or no table: refused knots, PF_GTAB=0) takes the series forms on the knot arrays --
+  // in global memory (L2) when the table has their place in LDS, staged as before otherwise, then with plain bisection (the
+  // start table of the knots has no room beside the larger array)
+  constexpr bool GT = FAST && !TAB && !SNG;
+  constexpr int SK = TAB ? PF_CT_NBINS_D : GT ? (PF_GT_MAX_INT + 1) * PF_GT_REC : 5 * PF_MAX_KNOTS;
+  static_assert(!GT || SK >= 5 * PF_MAX_KNOTS, "the knot arrays fit the table's place");
+  __shared__ double sk[SK];
   __shared__ double red[2 * (PF_CELL_BLOCK / 64)];
-  __shared__ unsigned short slut[TAB ? 1 : PF_SPLINE_LUT_BINS];
+  __shared__ unsigned short slut[TAB ? 1 : GT ? PF_GT_MAX_BINS : PF_SPLINE_LUT_BINS];
   const int nk = p.spline.n;
-  if (TAB) {
+  const bool gt = GT && p.spline.gt != nullptr;  // uniform
+  pf_spline_view sv;
+  if (gt) {
+    const double *g = p.spline.gt;
+    const int nint = (int)g[0], nbins = (int)g[1];
+    for (int i = threadIdx.x; i < (nint + 1) * PF_GT_REC; i += blockDim.x) sk[i] = g[PF_GT_HEADER + i];
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x) slut[i] = p.spline.gt_lut[i];
+    sv.gt.rec = sk; sv.gt.lut = slut; sv.gt.bin0 = (unsigned)g[2]; sv.gt.lo_all = g[3]; sv.gt.hi_all = g[4];
+  } else if (TAB) {
     for (int i = threadIdx.x; i < PF_CT_NBINS_D; i += blockDim.x) sk[i] = p.ct.delta[i];
   } else {
     for (int i = threadIdx.x; i < nk; i += blockDim.x) {
@@ -63,7 +78,7 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
   __syncthreads();
   double lut_x0 = 0.0, lut_inv_w = 0.0;
   int lut_direct = 0;
-  if (!TAB) {  // interval-search start table over the knots now in LDS: the direct form if no bin holds two knots, else the walk form
+  if (!TAB && !GT) {  // interval-search start table over the knots now in LDS: the direct form if no bin holds two knots, else the walk form
     pf_spline_lut_geometry(sk, nk, true, lut_x0, lut_inv_w);
     for (int b = threadIdx.x; b < PF_SPLINE_LUT_BINS; b += blockDim.x) slut[b] = pf_spline_lut_entry(sk, nk, b, lut_x0, lut_inv_w, true);
     __syncthreads();
@@ -78,17 +93,16 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
   }
   pf_ct_view tv;
   tv.delta = sk; tv.y = p.ct.y; tv.b = p.ct.b; tv.c = p.ct.c; tv.d = p.ct.d; tv.ampl = p.ct.ampl;
-  pf_spline_view sv;
-  sv.x = sk;
-  if (!TAB) { sv.y = sk + PF_MAX_KNOTS; sv.c = sk + 2 * PF_MAX_KNOTS; sv.b = sk + 3 * PF_MAX_KNOTS; sv.d = sk + 4 * PF_MAX_KNOTS; }
-  else sv.y = sv.c = sv.b = sv.d = sk;
+  if (gt) { sv.x = p.spline.x; sv.y = p.spline.y; sv.c = p.spline.c; sv.b = p.spline.b; sv.d = p.spline.d; }
+  else if (!TAB) { sv.x = sk; sv.y = sk + PF_MAX_KNOTS; sv.c = sk + 2 * PF_MAX_KNOTS; sv.b = sk + 3 * PF_MAX_KNOTS; sv.d = sk + 4 * PF_MAX_KNOTS; }
+  else { sv.x = sk; sv.y = sv.c = sv.b = sv.d = sk; }
   sv.n = nk;
   pf_sng_cosmo sc;
   if (SNG) {
     sc.Omega0 = p.ct.sng_cosmo[0]; sc.OmegaLambda = p.ct.sng_cosmo[1]; sc.OmegaRad = p.ct.sng_cosmo[2]; sc.OmegaK = p.ct.sng_cosmo[3];
     sc.FR0 = p.ct.sng_cosmo[4]; sc.H_over_c = p.ct.sng_cosmo[5]; sc.size = p.ct.sng_cosmo[6];
   }
-  if (!TAB && !p.no_lut) { sv.lut = slut; sv.lut_inv_w = lut_inv_w; sv.lut_x0 = lut_x0; sv.lut_direct = lut_direct; sv.x_first = sk[0]; sv.x_last = sk[nk - 1]; }
+  if (!TAB && !GT && !p.no_lut) { sv.lut = slut; sv.lut_inv_w = lut_inv_w; sv.lut_x0 = lut_x0; sv.lut_direct = lut_direct; sv.x_first = sk[0]; sv.x_last = sk[nk - 1]; }
 
   const F *__restrict__ h0 = (const F *)p.h[0], *__restrict__ h1 = (const F *)p.h[1],
           *__restrict__ h2 = (const F *)p.h[2], *__restrict__ h3 = (const F *)p.h[3],
@@ -252,6 +266,7 @@ template <bool FAST>
 __global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse_cells(const double *d, size_t count, PfSplineDev s, double *F) {
   pf_spline_view sv;
   sv.x = s.x; sv.y = s.y; sv.c = s.c; sv.b = s.b; sv.d = s.d; sv.n = s.n;
+  if (FAST && s.gt) { sv.gt.rec = s.gt + PF_GT_HEADER; sv.gt.lut = s.gt_lut; sv.gt.bin0 = (unsigned)s.gt[2]; sv.gt.lo_all = s.gt[3]; sv.gt.hi_all = s.gt[4]; }
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
     double t[6], lam[3];
     for (int k = 0; k < 6; k++) t[k] = d[6 * i + k];

@@ -16,6 +16,7 @@
 // this header against the oracle's known answers; not a CPU path of the library).
 #pragma once
 #include <math.h>
+#include "pf_gtab.h"
 
 // No FMA contraction in the solver: several steps subtract nearly equal numbers
 // (r*r - q*q*q at a double root, the cubic's -(s + q/s) - a1/3), where a fused
@@ -53,6 +54,8 @@ struct pf_spline_view {
   double lut_inv_w = 0.0, lut_x0 = 0.0;
   int lut_direct = 0;
   double x_first = 0.0, x_last = 0.0;  // x[0], x[n-1] when lut is set (registers instead of two broadcast reads per call)
+  // fast flavour: the composite 10^(-S(log10 D)) as one table of polynomials in D (pf_gtab.h); rec == nullptr: none
+  pf_gtab_view gt;
 };
 #define PF_SPLINE_LUT_BINS 4096
 
@@ -316,7 +319,11 @@ PF_HD double pf_log10_pos(double x) {
 }
 
 template <bool FAST = false> PF_HD double pf_inverse_growing_mode(const pf_spline_view &s, double D) {
-  if (FAST) return pf_exp10_series(-pf_spline_eval(s, pf_log10_pos(D))) - 1.;
+  if (FAST) {
+    double Y;
+    if (s.gt.rec && pf_gtab_eval(s.gt, D, Y)) return Y - 1.;  // (D inside the table: every collapsing cell but the odd extreme one)
+    return pf_exp10_series(-pf_spline_eval(s, pf_log10_pos(D))) - 1.;
+  }
   return 1. / pf_pow10<FAST>(pf_spline_eval(s, log10(D))) - 1.;
 }
 

@@ -6,12 +6,12 @@
 // every interval between two knots of the spline S (where S is one cubic in log10 D) and a power law beyond the last knot
 // (my_spline_eval extrapolates linearly): on each such interval it is approximated here by its degree-7 Chebyshev
 // interpolant in D itself, fitted on the host in long double arithmetic from the very knots and cspline coefficients the
-// reference evaluates.  Intervals: the knot intervals [10^x_j, 10^x_{j+1}), then, beyond the last knot and up to 2^10,
-// sixteen per octave in geometric progression.  The truncation error of the interpolant is below 1e-15
-// relative (an analytic function on an interval of relative width <= 6 %: the Chebyshev series falls by >= 60 per term);
-// the table is checked against the long double composite at build time and refused beyond 1e-14 -- the reference's own
-// chain log10 -> spline -> pow carries ~1e-15 of rounding -- in which case, as for D outside the table, the solve takes
-// the series forms of pf_collapse_core.h.  The interval of D comes from the bits of D: 64 bins per octave, a start table
+// reference evaluates.  Intervals: the knot intervals [10^x_j, 10^x_{j+1}) (split once where the fit asks for it), then,
+// beyond the last knot and up to 2^10, sixteen or more per octave in geometric progression.  The truncation error of the interpolant
+// is ~1e-15 relative on the knot intervals and, on the power law D^-p beyond them, grows with p (p = 3.8 for a LCDM table
+// that ends at a = 1.5: twenty per octave for 9e-15); the table is checked against the long double composite at build time and refused beyond
+// 2e-14 -- the reference's own chain log10 -> spline -> pow carries ~4e-15 of rounding -- in which case, as for D outside
+// the table, the solve takes the series forms of pf_collapse_core.h.  The interval of D comes from the bits of D: 64 bins per octave, a start table
 // and two comparisons with the next intervals' lower edges (no bin holds more than two edges: checked at build time).
 // A cell on the "wrong" side of a knot by one rounding of log10 changes nothing visible: S is C^2 at its knots.
 //
@@ -33,8 +33,9 @@
 #define PF_GT_MAX_INT 432   /* intervals (a sentinel record with the table's upper end follows the last) */
 #define PF_GT_LUT_BITS 6    /* start table: 64 bins per octave */
 #define PF_GT_MAX_BINS 2048
-#define PF_GT_ZONE_K 16     /* intervals per octave beyond the last knot */
+#define PF_GT_ZONE_K 16     /* intervals per octave beyond the last knot, at least (more where the power law there is steep) */
 #define PF_GT_HI_EXP 10     /* the table ends at the first zone edge at or above 2^10 */
+#define PF_GT_ACCEPT 2e-14L /* largest relative error of an accepted table (a stored fp32 Fmax then differs on ~2 err / 2^-24 = 7e-7 of the cells at most) */
 #define PF_GT_HEADER 8      /* doubles in front of the records: nint, nbins, bin0, lo_all, hi_all, max_rel_err, valid, 0 */
 
 struct pf_gtab_view {
@@ -101,16 +102,6 @@ static inline int pf_gtab_build(const double *xa, const double *ya, const double
     edge[ne] = (double)powl(10.0L, (long double)xa[j]); piece[ne] = j; ne++;
     if (j && !(edge[ne - 1] > edge[ne - 2])) return 1;
   }
-  {  // beyond the last knot: PF_GT_ZONE_K intervals per octave, geometric (every one of relative width 2^(1/K) - 1 = 4.4 %)
-    const double last = edge[ne - 1], top = ldexp(1.0, PF_GT_HI_EXP);
-    if (!(last < top)) return 1;
-    for (int k = 1;; k++) {
-      if (ne > PF_GT_MAX_INT) return 1;
-      const double v = (double)((long double)last * powl(2.0L, (long double)k / PF_GT_ZONE_K));
-      edge[ne] = v; piece[ne] = n - 1; ne++;
-      if (v >= top) break;
-    }
-  }
   double *rec = out + PF_GT_HEADER;
   long double worst = 0.0L;
   // fit interval i of the current edge list; returns its largest relative error against the long double composite
@@ -158,6 +149,30 @@ static inline int pf_gtab_build(const double *xa, const double *ya, const double
     }
     return w;
   };
+  {  // beyond the last knot: K intervals per octave in geometric progression.  On the power law D^-p there every interval has
+     // the same relative error, growing with p: the smallest K of the list that brings it below 8e-15 and fits is taken
+    const double last = edge[ne - 1], top = ldexp(1.0, PF_GT_HI_EXP);
+    if (!(last < top) || ne + 2 > PF_GT_MAX_INT) return 1;
+    const double octaves = log2(top / last);
+    static const int ks[] = {PF_GT_ZONE_K, 20, 24, 28, 32, 40, 48};
+    int K = PF_GT_ZONE_K;
+    double tmp[PF_GT_REC];
+    for (int q = 0; q < 7; q++) {
+      if (ks[q] < K) continue;
+      if (ne + (int)ceil(octaves * ks[q]) + 12 > PF_GT_MAX_INT) break;  // (12: room for split knot intervals)
+      K = ks[q];
+      edge[ne] = (double)((long double)last * powl(2.0L, 1.0L / K)); piece[ne] = n - 1;
+      piece[ne - 1] = n - 1;
+      const long double e = fit(ne - 1, tmp);
+      if (e <= 8e-15L) break;
+    }
+    for (int k = 1;; k++) {
+      if (ne > PF_GT_MAX_INT) return 1;
+      const double v = (double)((long double)last * powl(2.0L, (long double)k / K));
+      edge[ne] = v; piece[ne] = n - 1; ne++;
+      if (v >= top) break;
+    }
+  }
   // a knot interval on which S wiggles (the ends of a natural spline) is split once, at its geometric middle
   {
     double tmp[PF_GT_REC];
@@ -200,6 +215,6 @@ static inline int pf_gtab_build(const double *xa, const double *ya, const double
     }
   }
   out[0] = nint; out[1] = nbins; out[2] = (double)bin0; out[3] = edge[0]; out[4] = edge[nint]; out[5] = (double)worst;
-  out[6] = worst <= 1e-14L ? 1.0 : 0.0;
+  out[6] = worst <= PF_GT_ACCEPT ? 1.0 : 0.0;
   return out[6] != 0.0 ? 0 : 1;
 }

@@ -20,6 +20,7 @@ struct PfTuning {
   double prune_eps;
   int debug_fault;          // PF_DEBUG_PIPELINE_FAULT (tests only): 1 / 2 = one wait of the exchange pipeline left out
   bool solve_beside_z;      // PF_SOLVE_BESIDE_Z: the solve of sweep radius i runs on its own stream beside the z-pass of radius i + 1
+  bool gtab;                // PF_GTAB: the inverse growing mode of the fast flavour from the polynomial table (pf_gtab.h)
 };
 
 // multiplier applied along the transformed axis before the 1-D transform
@@ -110,6 +111,9 @@ int pf_launch_r2c(int field_bytes, int n, const PfR2CParams &p, hipStream_t st);
 struct PfSplineDev {
   const double *x, *y, *c, *b, *d;  // knots, GSL cspline c_i, and the per-interval b_i, d_i (pf_spline_bd)
   int n;
+  // pf_gtab.h: header + records of the polynomial table of this spline and its start table; null: none (table refused or PF_GTAB=0)
+  const double *gt;
+  const unsigned short *gt_lut;
 };
 // TABULATED_CT table of one radius on the device (pf_collapse_core.h pf_ct_view)
 struct PfCtDev {

@@ -12,14 +12,39 @@ extern "C" int emul_collapse(const double *sx, const double *sy, int nk, const d
   for (long i = 0; i < count; i++) F[i] = pf_inverse_collapse_time(d + 6 * i, s, lam + 3 * i);
   return 0;
 }
+// the fast flavour as the kernels run it: the inverse growing mode from the polynomial table of the spline (pf_gtab.h) when
+// `with_table` and the table is accepted, the series forms otherwise.  Returns 0, or 2 when the table was built and used.
 extern "C" int emul_collapse_fast(const double *sx, const double *sy, int nk, const double *d, long count,
-                                  double *F, double *lam) {
+                                  double *F, double *lam, int with_table) {
   std::vector<double> c(nk), b(nk), dd(nk);
   if (pf_spline_coeffs(sx, sy, nk, c.data())) return 1;
   pf_spline_bd(sx, sy, c.data(), nk, b.data(), dd.data());
   pf_spline_view s{sx, sy, c.data(), b.data(), dd.data(), nk};
+  std::vector<double> g(PF_GT_HEADER + (PF_GT_MAX_INT + 1) * PF_GT_REC);
+  std::vector<unsigned short> lut(PF_GT_MAX_BINS);
+  const bool tab = with_table && pf_gtab_build(sx, sy, c.data(), b.data(), dd.data(), nk, g.data(), lut.data()) == 0;
+  if (tab) { s.gt.rec = g.data() + PF_GT_HEADER; s.gt.lut = lut.data(); s.gt.bin0 = (unsigned)g[2]; s.gt.lo_all = g[3]; s.gt.hi_all = g[4]; }
   for (long i = 0; i < count; i++) F[i] = pf_inverse_collapse_time<true>(d + 6 * i, s, lam + 3 * i);
-  return 0;
+  return tab ? 2 : 0;
+}
+// the table alone: Y[i] = 10^(-S(log10 D[i])) from the table (NaN where D lies outside it); info = the table's header
+// (nint, nbins, bin0, lo_all, hi_all, max_rel_err, valid, 0); bcd = the cspline's c, b, d (3 * nk) for an independent check
+extern "C" int emul_gtab(const double *sx, const double *sy, int nk, const double *D, long count, double *Y, double *info, double *bcd) {
+  std::vector<double> c(nk), b(nk), dd(nk);
+  if (pf_spline_coeffs(sx, sy, nk, c.data())) return 1;
+  pf_spline_bd(sx, sy, c.data(), nk, b.data(), dd.data());
+  std::vector<double> g(PF_GT_HEADER + (PF_GT_MAX_INT + 1) * PF_GT_REC);
+  std::vector<unsigned short> lut(PF_GT_MAX_BINS);
+  const int rc = pf_gtab_build(sx, sy, c.data(), b.data(), dd.data(), nk, g.data(), lut.data());
+  for (int i = 0; i < PF_GT_HEADER; i++) info[i] = g[i];
+  for (int i = 0; i < nk; i++) { bcd[i] = c[i]; bcd[nk + i] = b[i]; bcd[2 * nk + i] = dd[i]; }
+  pf_gtab_view v;
+  v.rec = g.data() + PF_GT_HEADER; v.lut = lut.data(); v.bin0 = (unsigned)g[2]; v.lo_all = g[3]; v.hi_all = g[4];
+  for (long i = 0; i < count; i++) {
+    double y;
+    Y[i] = (rc == 0 && pf_gtab_eval(v, D[i], y)) ? y : NAN;
+  }
+  return rc;
 }
 extern "C" double emul_ell_classic(double a, double b, double c) { return pf_ell_classic(a, b, c); }
 extern "C" int emul_spline(const double *sx, const double *sy, int nk, const double *v, long count, double *out) {

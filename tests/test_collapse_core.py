@@ -77,10 +77,12 @@ def test_spline(emul):
     assert np.array_equal(out, want)
 
 
-def test_fast_flavour_agrees_to_ulps(emul):
-    """sincos-rotation / cbrt / exp10 forms of the three hot spots: same values to ~1e-15 where the
+@pytest.mark.parametrize("with_table", [1, 0])
+def test_fast_flavour_agrees_to_ulps(emul, with_table):
+    """sincos-rotation / cbrt / exp10 forms of the three hot spots -- and the inverse growing mode from the polynomial table
+    of the spline (pf_gtab.h: what the kernels run), or from the series forms --: same values to ~1e-15 where the
     cubic is well conditioned, identical sentinels and zeros"""
-    emul.emul_collapse_fast.argtypes = [dp, dp, C.c_int, dp, C.c_long, dp, dp]
+    emul.emul_collapse_fast.argtypes = [dp, dp, C.c_int, dp, C.c_long, dp, dp, C.c_int]
     rng = np.random.default_rng(6)
     x, y = synth.invgrow_table("lcdm")
     n = 200000
@@ -89,7 +91,7 @@ def test_fast_flavour_agrees_to_ulps(emul):
     d[50:60] = 0.0
     F0 = np.empty(n); F1 = np.empty(n); lam = np.empty((n, 3))
     assert emul.emul_collapse(_dp(x), _dp(y), len(x), _dp(d), n, _dp(F0), _dp(lam)) == 0
-    assert emul.emul_collapse_fast(_dp(x), _dp(y), len(x), _dp(d), n, _dp(F1), _dp(lam)) == 0
+    assert emul.emul_collapse_fast(_dp(x), _dp(y), len(x), _dp(d), n, _dp(F1), _dp(lam), with_table) == (2 if with_table else 0)
     nan = np.isnan(F0) & np.isnan(F1)
     assert np.array_equal(F0 == -10.0, F1 == -10.0) and np.array_equal(F0 == 0.0, F1 == 0.0)
     rel = np.abs(F1 - F0) / np.maximum(1.0, np.abs(F0))
@@ -103,6 +105,54 @@ def test_fast_flavour_agrees_to_ulps(emul):
     assert rel.max() < 1e-5
     # stored value: fp32
     assert np.mean(F0.astype(np.float32) != F1.astype(np.float32)) < 2e-4
+
+
+@pytest.mark.parametrize("kind", ["lcdm", "eds", "wiggly", "dense"])
+def test_inverse_growth_table_of_the_fast_flavour(emul, kind):
+    """pf_gtab.h: 10^(-S(log10 D)) as piecewise degree-7 polynomials in D -- against the composite evaluated by mpmath from the
+    same knots and cspline coefficients (50 digits): within 2e-14 everywhere inside the table, 3e-15 on the knot intervals (the
+    reference's own chain log10 -> gsl spline -> pow carries ~4e-15 of rounding), NaN (= "take the series forms") outside; knots too dense for the
+    start table are refused"""
+    mp = pytest.importorskip("mpmath")
+    mp.mp.dps = 50
+    emul.emul_gtab.argtypes = [dp, dp, C.c_int, dp, C.c_long, dp, dp, dp]
+    x, y = synth.invgrow_table("eds" if kind == "eds" else "lcdm")
+    if kind == "wiggly":     # a table whose natural spline oscillates at its ends: intervals are split where the fit asks for it
+        y = y + 1e-4 * np.sin(40.0 * x)
+    if kind == "dense":      # ten times the knots: more than one bin of the start table can hold
+        xx = np.linspace(x[0], x[-1], 500)
+        y = np.interp(xx, x, y); x = xx
+    n = len(x)
+    rng = np.random.default_rng(12)
+    D = 10.0 ** rng.uniform(x[0] - 0.3, 3.3, 20000)
+    D[:4] = [10.0 ** x[0], np.nextafter(10.0 ** x[0], 0), 1023.0, 1e4]
+    Y = np.empty(len(D)); info = np.empty(8); bcd = np.empty(3 * n)
+    rc = emul.emul_gtab(_dp(x), _dp(y), n, _dp(D), len(D), _dp(Y), _dp(info), _dp(bcd))
+    if kind == "dense":
+        assert rc == 1 and info[6] == 0.0 and np.isnan(Y).all()
+        return
+    assert rc == 0 and info[6] == 1.0 and info[5] <= 2e-14, info
+    lo, hi = info[3], info[4]
+    assert lo == pytest.approx(10.0 ** x[0], rel=1e-15) and hi >= 1024.0
+    inside = (D >= lo) & (D < hi)
+    assert np.array_equal(np.isnan(Y), ~inside) and inside.sum() > 15000
+    c, b, d = bcd[:n], bcd[n:2 * n], bcd[2 * n:]
+    slope = (mp.mpf(y[-1]) - mp.mpf(y[-2])) / (mp.mpf(x[-1]) - mp.mpf(x[-2]))
+    worst = worst_knots = 0.0
+    for Di, Yi in zip(D[inside][:6000], Y[inside][:6000]):
+        xl = mp.log10(mp.mpf(float(Di)))
+        if xl > x[-1]:
+            S = mp.mpf(y[-1]) + (xl - mp.mpf(x[-1])) * slope
+        else:
+            j = min(max(int(np.searchsorted(x, float(xl), side="right")) - 1, 0), n - 2)
+            dx = xl - mp.mpf(x[j])
+            S = mp.mpf(y[j]) + dx * (mp.mpf(b[j]) + dx * (mp.mpf(c[j]) + dx * mp.mpf(d[j])))
+        want = mp.power(10, -S)
+        err = float(abs((mp.mpf(float(Yi)) - want) / want))
+        worst = max(worst, err)
+        if xl <= x[-1]:
+            worst_knots = max(worst_knots, err)
+    assert worst <= 2e-14 and worst_knots <= 3e-15, (worst, worst_knots)
 
 
 def test_tabulated_ct_header_matches_oracle_bitwise(emul):
