@@ -81,10 +81,22 @@ template <typename F> __device__ __forceinline__ void pf_st_stream(pfc<F> *p, pf
 #endif
 
 constexpr int pf_ilog2(int n) { return n <= 1 ? 0 : 1 + pf_ilog2(n >> 1); }
-// stage plan for 8 points per thread: radix 8 as long as it fits, the remainder (2 or 4) last
-constexpr int pf_nstages(int n) { return (pf_ilog2(n) + 2) / 3; }
-constexpr int pf_radix(int n, int s) { return s < pf_ilog2(n) / 3 ? 8 : (1 << (pf_ilog2(n) - 3 * (pf_ilog2(n) / 3))); }
-constexpr int pf_ns(int n, int s) { return s == 0 ? 1 : pf_ns(n, s - 1) * pf_radix(n, s - 1); }
+// stage plan for 8 points per thread: radix 8 as long as it fits, the remainder (2 or 4) last.
+// p16 -- the PAIRED plan for N = 16 * 8^k, k >= 1 (128, 1024: lengths whose plain plan ends on a radix-2 stage): the first stage
+// is a radix-16 butterfly done by two neighbouring threads (tl, tl ^ 1) -- each its own radix 8, then one radix-2 step across
+// the pair through the lanes of the wave (pf_pair16_local / pf_pair16_combine) -- followed by radix-8 stages only: one LDS
+// exchange (eight 16-byte writes, eight reads and two barriers per thread) less than the plain plan; a 1024-point line
+// crosses LDS twice instead of three times.
+constexpr bool pf_pair16_length(int n) { return n >= 128 && pf_ilog2(n) % 3 == 1; }  // (16 itself would end on the paired stage, whose outputs are not in line order)
+constexpr int pf_nstages(int n, bool p16 = false) { return p16 ? (pf_ilog2(n) - 4) / 3 + 1 : (pf_ilog2(n) + 2) / 3; }
+constexpr int pf_radix(int n, int s, bool p16 = false) {
+  return p16 ? (s == 0 ? 16 : 8) : (s < pf_ilog2(n) / 3 ? 8 : (1 << (pf_ilog2(n) - 3 * (pf_ilog2(n) / 3))));
+}
+constexpr int pf_ns(int n, int s, bool p16 = false) { return s == 0 ? 1 : pf_ns(n, s - 1, p16) * pf_radix(n, s - 1, p16); }
+// the point of the line that register m of thread tl holds BEFORE the first stage (what a kernel loads there)
+template <int N, bool P16 = false> PF_HD int pf_line_index(int tl, int m) {
+  return P16 ? (tl >> 1) + (N / 16) * (tl & 1) + m * (N / 8) : tl + m * (N / 8);
+}
 
 // X_k = sum_t u_t w^{kt}, w = exp(DIR 2 pi i / R), natural order in and out
 template <int DIR, typename F> PF_HD void pf_bfly2(pfc<F> &a, pfc<F> &b) {
@@ -117,8 +129,9 @@ template <int DIR, typename F> PF_HD void pf_bfly8(pfc<F> (&u)[8]) {
 }
 
 // LDS/HBM position of register m of thread tl AFTER stage S of a length-N line
-template <int N, int S> PF_HD int pf_stage_pos(int tl, int m) {
-  constexpr int R = pf_radix(N, S), NS = pf_ns(N, S), Q = 8 / R, NT = N / 8;
+template <int N, int S, bool P16 = false> PF_HD int pf_stage_pos(int tl, int m) {
+  if (P16 && S == 0) return 16 * (tl >> 1) + 8 * (tl & 1) + m;  // output t = m + 8 h of the pair's butterfly u = tl >> 1
+  constexpr int R = (P16 && S == 0) ? 8 : pf_radix(N, S, P16), NS = pf_ns(N, S, P16), Q = 8 / R, NT = N / 8;
   const int q = m % Q, t = m / Q;
   const int jb = tl + q * NT;
   const int k = jb & (NS - 1);
@@ -128,16 +141,16 @@ template <int N, int S> PF_HD int pf_stage_pos(int tl, int m) {
 // Twiddles of stage S: one table value w^1 per butterfly of the thread (Q = 8/R of them; none in stage 0, where NS = 1).
 // They depend on the thread's place in the line only -- not on the line, the job or the row -- so a kernel may fetch them
 // wherever their latency is hidden (before the LDS exchange that precedes the stage, or once outside its loop over rows).
-constexpr int pf_stage_ntw(int n, int s) { return pf_ns(n, s) > 1 ? 8 / pf_radix(n, s) : 0; }
-constexpr int pf_ntw_before(int n, int s) { return s == 0 ? 0 : pf_ntw_before(n, s - 1) + pf_stage_ntw(n, s - 1); }
-constexpr int pf_ntw_total(int n) { return pf_ntw_before(n, pf_nstages(n)); }
+constexpr int pf_stage_ntw(int n, int s, bool p16 = false) { return pf_ns(n, s, p16) > 1 ? 8 / pf_radix(n, s, p16) : 0; }
+constexpr int pf_ntw_before(int n, int s, bool p16 = false) { return s == 0 ? 0 : pf_ntw_before(n, s - 1, p16) + pf_stage_ntw(n, s - 1, p16); }
+constexpr int pf_ntw_total(int n, bool p16 = false) { return pf_ntw_before(n, pf_nstages(n, p16), p16); }
 
 // tw[j] = exp(+2 pi i j / (N*TWS))
 // (arrays by reference and compile-time offsets: the values must stay in registers -- through a pointer the compiler puts
 //  them in scratch memory, and a scratch reload waits on the same in-order counter as every global load before it)
-template <typename F, int N, int S, int DIR, int TWS, int OFF = 0, int NW>
+template <typename F, int N, int S, int DIR, int TWS, int OFF = 0, bool P16 = false, int NW>
 PF_HD void pf_stage_twiddles(int tl, const pfc<typename pf_lane<F>::type> *__restrict__ tw, pfc<F> (&w)[NW]) {
-  constexpr int R = pf_radix(N, S), NS = pf_ns(N, S), Q = 8 / R, NT = N / 8;
+  constexpr int R = pf_radix(N, S, P16), NS = pf_ns(N, S, P16), Q = 8 / R, NT = N / 8;
   constexpr int TWM = (N / (NS * R)) * TWS;
   if (NS > 1) {
 #pragma unroll
@@ -151,9 +164,9 @@ PF_HD void pf_stage_twiddles(int tl, const pfc<typename pf_lane<F>::type> *__res
 }
 
 // stage S on the 8 registers of a thread, with its twiddles w[0..Q-1] in hand
-template <typename F, int N, int S, int DIR, int OFF = 0, int NW>
+template <typename F, int N, int S, int DIR, int OFF = 0, bool P16 = false, int NW>
 PF_HD void pf_stage_apply(pfc<F> (&v)[8], const pfc<F> (&w)[NW]) {
-  constexpr int R = pf_radix(N, S), NS = pf_ns(N, S), Q = 8 / R;
+  constexpr int R = pf_radix(N, S, P16), NS = pf_ns(N, S, P16), Q = 8 / R;
 #pragma unroll
   for (int q = 0; q < Q; q++) {
     if (NS > 1) {
@@ -190,6 +203,37 @@ PF_HD void pf_stage(pfc<F> (&v)[8], int tl, const pfc<typename pf_lane<F>::type>
   pfc<F> w[8 / pf_radix(N, S)];
   pf_stage_twiddles<F, N, S, DIR, TWS>(tl, tw, w);
   pf_stage_apply<F, N, S, DIR>(v, w);
+}
+
+// ---- the paired first stage (plan p16).  The pair (tl, tl ^ 1) = (h = 0, h = 1) of butterfly u = tl >> 1 holds the sixteen
+// inputs x_q = line[u + q N/16], q = 2 m + h (pf_line_index).  X[t] = sum_q x_q W16^(q t), t = ta + 8 tb:
+//   each thread: Y_h[ta] = DFT8_m(x_{2m+h})                              (pf_bfly8, natural order)
+//   the odd one: Y_1[ta] *= W16^ta                                       (pf_pair16_local)
+//   across the pair: X[ta] = Y_0[ta] + Y_1[ta] stays with h = 0, X[ta + 8] = Y_0[ta] - Y_1[ta] with h = 1   (pf_pair16_combine:
+//   `o` = the partner's eight values, fetched through the lanes of the wave -- the partner sits T = 8 lanes away)
+template <int DIR, typename F> PF_HD void pf_pair16_local(pfc<F> (&v)[8], int tl) {
+  pf_bfly8<DIR>(v);
+  if (tl & 1) {
+    const F c1 = (F)0.92387953251128675613, s1 = (F)0.38268343236508977173, h = (F)0.70710678118654752440;
+    // W16^1 = (c1, DIR s1), ^2 = h (1, DIR), ^3 = (s1, DIR c1), ^4 = DIR i, ^5 = (-s1, DIR c1), ^6 = h (-1, DIR), ^7 = (-c1, DIR s1)
+    v[1] = DIR > 0 ? pf_mk<F>(c1 * v[1].x - s1 * v[1].y, c1 * v[1].y + s1 * v[1].x) : pf_mk<F>(c1 * v[1].x + s1 * v[1].y, c1 * v[1].y - s1 * v[1].x);
+    v[2] = DIR > 0 ? pf_mk<F>(h * (v[2].x - v[2].y), h * (v[2].y + v[2].x)) : pf_mk<F>(h * (v[2].x + v[2].y), h * (v[2].y - v[2].x));
+    v[3] = DIR > 0 ? pf_mk<F>(s1 * v[3].x - c1 * v[3].y, s1 * v[3].y + c1 * v[3].x) : pf_mk<F>(s1 * v[3].x + c1 * v[3].y, s1 * v[3].y - c1 * v[3].x);
+    v[4] = pf_mul_i<DIR>(v[4]);
+    v[5] = DIR > 0 ? pf_mk<F>(-s1 * v[5].x - c1 * v[5].y, -s1 * v[5].y + c1 * v[5].x) : pf_mk<F>(-s1 * v[5].x + c1 * v[5].y, -s1 * v[5].y - c1 * v[5].x);
+    v[6] = DIR > 0 ? pf_mk<F>(h * (-v[6].x - v[6].y), h * (-v[6].y + v[6].x)) : pf_mk<F>(h * (-v[6].x + v[6].y), h * (-v[6].y - v[6].x));
+    v[7] = DIR > 0 ? pf_mk<F>(-c1 * v[7].x - s1 * v[7].y, -c1 * v[7].y + s1 * v[7].x) : pf_mk<F>(-c1 * v[7].x + s1 * v[7].y, -c1 * v[7].y - s1 * v[7].x);
+  }
+}
+// one value at a time (the kernels: eight partner values held at once would not fit beside src and v): sgn = -1 for the odd
+// thread, +1 for the even one; o + sgn v is v + o or o - v, rounded once either way
+template <typename F> PF_HD pfc<F> pf_pair16_combine1(pfc<F> v, pfc<F> o, F sgn) { return pf_mk<F>(o.x + sgn * v.x, o.y + sgn * v.y); }
+template <typename F> PF_HD void pf_pair16_combine(pfc<F> (&v)[8], const pfc<F> (&o)[8], int tl) {
+  const F sgn = (tl & 1) ? (F)-1 : (F)1;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int m = 0; m < 8; m++) v[m] = pf_pair16_combine1(v[m], o[m], sgn);
 }
 
 // LDS padding for contiguous-line kernels: breaks the stride-8 write pattern of stage 0

@@ -112,6 +112,12 @@ __global__ void __launch_bounds__(T *N / 8) __attribute__((amdgpu_waves_per_eu(4
   using S = typename COLS::S;  // scalar of the field in memory
   constexpr int NL = COLS::n;  // columns per thread
   constexpr int NT = N / 8;
+#ifndef PF_PAIR16
+#define PF_PAIR16 1  // (0 in an A/B build: the plain plan, whose 1024-point line ends on a radix-2 stage behind a third LDS exchange)
+#endif
+  // the paired first stage (pf_fft_core.h): lengths 16 * 8^k in tiles of eight columns -- the partner thread tl ^ 1 is then
+  // eight lanes away, in the same row of sixteen lanes.  A thread's register m then holds point pf_line_index(tl, m).
+  constexpr bool P16 = PF_PAIR16 && pf_pair16_length(N) && T == 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   C *lds = reinterpret_cast<C *>(smem);  // [N][T]
   const long long w = pf_xcd_swizzle(blockIdx.x, (nwork + 7) >> 3);
@@ -138,10 +144,10 @@ __global__ void __launch_bounds__(T *N / 8) __attribute__((amdgpu_waves_per_eu(4
     const pfc<S> *__restrict__ in = reinterpret_cast<const pfc<S> *>(inp);
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-      const int e = tlj + m * NT;
+      const int e = pf_line_index<N, P16>(tlj, m);  // (= e0 + m NT with e0 = pf_line_index(tl, 0) < NT in either plan)
       const int se = e > N / 2 ? e - N : e;
       const bool inband = se <= p.band_e && se >= -p.band_e;
-      if constexpr (FA) src[m] = (valid && inband) ? COLS::load_ul(in, pf_addr_uniform<NT>(p.ain, outer, m, NL * tile * T), pf_addr_lane(p.ain, tlj, colj - NL * tile * T)) : pf_zero<F>();
+      if constexpr (FA) src[m] = (valid && inband) ? COLS::load_ul(in, pf_addr_uniform<NT>(p.ain, outer, m, NL * tile * T), pf_addr_lane(p.ain, pf_line_index<N, P16>(tlj, 0), colj - NL * tile * T)) : pf_zero<F>();
       else src[m] = (valid && inband) ? COLS::load(in, pf_addr(p.ain, outer, e, colj)) : pf_zero<F>();
       if constexpr (NL > 1) { if (!valid1) { src[m].x.y = 0.f; src[m].y.y = 0.f; } }
     }
@@ -180,7 +186,7 @@ __global__ void __launch_bounds__(T *N / 8) __attribute__((amdgpu_waves_per_eu(4
       double we[8];
       if (p.rs != 0.0) {
 #pragma unroll
-        for (int m = 0; m < 8; m++) we[m] = p.etab[tlj + m * NT];
+        for (int m = 0; m < 8; m++) we[m] = p.etab[pf_line_index<N, P16>(tlj, m)];
       } else {
 #pragma unroll
         for (int m = 0; m < 8; m++) we[m] = 1.0;
@@ -192,7 +198,7 @@ __global__ void __launch_bounds__(T *N / 8) __attribute__((amdgpu_waves_per_eu(4
         const double ko2kc2 = ko * ko + kc * kc;
 #pragma unroll
         for (int m = 0; m < 8; m++) {
-          const int e = tlj + m * NT;
+          const int e = pf_line_index<N, P16>(tlj, m);
           const double ke = kf * (e > N / 2 ? e - N : e);
           const double k2 = ke * ke + ko2kc2;
           const S fac = (S)((k2 != 0.0) ? we[m] * woc[l] / k2 : 0.0);
@@ -204,7 +210,7 @@ __global__ void __launch_bounds__(T *N / 8) __attribute__((amdgpu_waves_per_eu(4
     const int mul = p.job[j].mul;
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-      const int e = tlj + m * NT;
+      const int e = pf_line_index<N, P16>(tlj, m);
       const F ke = (F)(S)(kf * (e > N / 2 ? e - N : e));
       C x = src[m];
       if (mul == PF_MUL_K) x = pf_scale(x, ke);
@@ -214,7 +220,7 @@ __global__ void __launch_bounds__(T *N / 8) __attribute__((amdgpu_waves_per_eu(4
     }
     // src is free once the last job on this input has taken its copy: the next input's tile travels during the stages
     if (j + 1 < p.njobs && p.job[j + 1].in != p.job[j].in) load_tile(p.job[j + 1].in, tlj, colj);
-    PfStages<F, N, DIR, 1>::run(
+    PfStages<F, N, DIR, 1, 0, false, P16>::run(
         v, tlj, tw, [&](int pos, C val) { lds[pos * T + cj] = val; }, [&](int pos) { return lds[pos * T + cj]; });
 #if defined(PF_DUMMY_VALU) && PF_DUMMY_VALU > 0  // (A/B probe: how much of the arithmetic of a job is hidden behind its memory traffic)
     if constexpr (NL == 1) {

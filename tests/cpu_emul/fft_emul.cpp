@@ -23,6 +23,58 @@ static void run_stages(std::vector<C> &reg, std::vector<C> &lds, const C *tw, in
   }
 }
 
+// the paired plan (pf_fft_core.h, p16): first stage by thread pairs -- every thread's own part first, then the combination with
+// what the partner holds (on the device: through the lanes of the wave) --, radix-8 stages after it
+template <int N, int S, int DIR>
+static void run_stages_p16(std::vector<C> &reg, std::vector<C> &lds, const C *tw) {
+  constexpr int NT = N / 8;
+  if constexpr (S < pf_nstages(N, true)) {
+    if constexpr (S == 0) {
+      for (int tl = 0; tl < NT; tl++) {
+        C v[8];
+        for (int m = 0; m < 8; m++) v[m] = reg[tl * 8 + m];
+        pf_pair16_local<DIR>(v, tl);
+        for (int m = 0; m < 8; m++) reg[tl * 8 + m] = v[m];
+      }
+      std::vector<C> part(reg);
+      for (int tl = 0; tl < NT; tl++) {
+        C v[8], o[8];
+        for (int m = 0; m < 8; m++) { v[m] = part[tl * 8 + m]; o[m] = part[(tl ^ 1) * 8 + m]; }
+        pf_pair16_combine(v, o, tl);
+        for (int m = 0; m < 8; m++) lds[pf_stage_pos<N, 0, true>(tl, m)] = v[m];
+      }
+    } else {
+      for (int tl = 0; tl < NT; tl++) {
+        C v[8], w[1];
+        for (int m = 0; m < 8; m++) v[m] = reg[tl * 8 + m];
+        pf_stage_twiddles<double, N, S, DIR, 1, 0, true>(tl, tw, w);
+        pf_stage_apply<double, N, S, DIR, 0, true>(v, w);
+        for (int m = 0; m < 8; m++) lds[pf_stage_pos<N, S, true>(tl, m)] = v[m];
+      }
+    }
+    for (int tl = 0; tl < NT; tl++)
+      for (int m = 0; m < 8; m++) reg[tl * 8 + m] = lds[tl + m * NT];
+    run_stages_p16<N, S + 1, DIR>(reg, lds, tw);
+  }
+}
+template <int N, int DIR>
+static void fft_line_p16(const C *in, C *out) {
+  constexpr int NT = N / 8;
+  std::vector<C> tw(N), reg(N), lds(N);
+  for (int j = 0; j < N; j++) tw[j] = pf_mk<double>(cos(2 * M_PI * j / N), sin(2 * M_PI * j / N));
+  for (int tl = 0; tl < NT; tl++)
+    for (int m = 0; m < 8; m++) reg[tl * 8 + m] = in[pf_line_index<N, true>(tl, m)];
+  run_stages_p16<N, 0, DIR>(reg, lds, tw.data());
+  for (int tl = 0; tl < NT; tl++)
+    for (int m = 0; m < 8; m++) out[tl + m * NT] = reg[tl * 8 + m];
+}
+extern "C" int emul_fft_p16(int n, int dir, const double *in, double *out) {
+  if (n == 128) { if (dir > 0) fft_line_p16<128, +1>((const C *)in, (C *)out); else fft_line_p16<128, -1>((const C *)in, (C *)out); }
+  else if (n == 1024) { if (dir > 0) fft_line_p16<1024, +1>((const C *)in, (C *)out); else fft_line_p16<1024, -1>((const C *)in, (C *)out); }
+  else return 1;
+  return 0;
+}
+
 template <int N, int DIR>
 static void fft_line(const C *in, C *out) {
   constexpr int NT = N / 8;

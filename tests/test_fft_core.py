@@ -41,6 +41,19 @@ def test_complex_line(emul, n, direction):
     assert np.max(np.abs(out - want)) < 2e-15 * np.sqrt(n) * np.max(np.abs(want)) * 4
 
 
+@pytest.mark.parametrize("n", [128, 1024])
+@pytest.mark.parametrize("direction", [+1, -1])
+def test_complex_line_paired_plan(emul, n, direction):
+    """the paired plan of the strided passes (N = 16 * 8^k): radix 16 by thread pairs first, then radix 8 only"""
+    emul.emul_fft_p16.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    rng = np.random.default_rng(n + 7)
+    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    out = np.empty(n, dtype=np.complex128)
+    assert emul.emul_fft_p16(n, direction, _dp(x.view(np.float64)), _dp(out.view(np.float64))) == 0
+    want = np.fft.fft(x) if direction < 0 else np.fft.ifft(x) * n
+    assert np.max(np.abs(out - want)) < 2e-15 * np.sqrt(n) * np.max(np.abs(want)) * 4
+
+
 @pytest.mark.parametrize("n", [16, 32, 64, 256, 1024, 2048])
 def test_real_lines(emul, n):
     rng = np.random.default_rng(n + 1)
