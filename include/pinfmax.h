@@ -328,6 +328,10 @@ int pf_debug_invariant_reruns(pf_ctx *ctx);
    the radius that follows (PF_SOLVE_BESIDE_Z): the two kernels' HIP-event spans then overlap -- per-kernel
    times of pf_kernel_stats are spans, not shares of the step; 0 when every kernel ran in line */
 int pf_solve_ran_beside_zpass(pf_ctx *ctx);
+/* which transforms serve the context's grid size (the reference plans any GridSize, src/fmax-pfft.c:139-188): 0 the hand-written
+   power-of-two passes, 1 the hand-written passes with run-time stage plans (n = 8 m, m = 2^a 3^b 5^c; one rank),
+   2 library transforms, one per component (any other even n on one rank, or PF_GENERAL=1) */
+int pf_transform_path(pf_ctx *ctx);
 /* 1: in the default (fast) arithmetic the inverse growing mode of radius `ismooth` (-1: the shared spline) comes from the
    polynomial table built from its knots by pf_set_invgrow (csrc/pf_gtab.h; *max_rel_err: its largest relative error against
    the composite 10^(-S(log10 D)) in long double); 0: the series forms are used (table refused, PF_GTAB=0, PF_EXACT_LIBM=1) */

@@ -98,6 +98,7 @@ PROTOTYPES = {
     "pf_debug_lines": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, _dp, _dp]),
     "pf_debug_invariant_reruns": (C.c_int, [_vp]),
     "pf_solve_ran_beside_zpass": (C.c_int, [_vp]),
+    "pf_transform_path": (C.c_int, [_vp]),
     "pf_invgrow_table_status": (C.c_int, [_vp, C.c_int, _dp]),
     "pf_set_loopback_exchange": (C.c_int, [_vp, C.c_int]),
     "pf_loopback_active": (C.c_int, [_vp]),

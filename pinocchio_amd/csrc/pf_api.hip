@@ -361,16 +361,20 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   const bool pow2 = !(n & (n - 1));
   PfTuning tune;
   read_tuning(&tune);
-  const bool want_general = !pow2 || tune.general;
+  // not a power of two: the run-time stage plans of pf_mixed_kernels.hip where they apply (n = 8 m, m = 2^a 3^b 5^c; one rank),
+  // library transforms (the "general path") for the rest
+  const bool mixed = !pow2 && !tune.general && cfg->nranks == 1 && pf_mixed_supported((int)n);
+  const bool want_general = (!pow2 && !mixed) || tune.general;
   if (want_general) {
     if (n < 4 || n > 4096 || (n & 1)) return pf_fail(rank, "pf_create: grid size %lld must be even, in [4, 4096]", n);
     if (cfg->nranks != 1 || cfg->field_bytes != 8)
       return pf_fail(rank, "pf_create: grid size %lld is not a power of two: the library-transform path takes one rank and fp64 fields "
                            "(slab decomposition and fp32 fields need a power of two in [16, 2048])", n);
-  } else if (n < 16 || n > 2048) return pf_fail(rank, "pf_create: grid size %lld must be a power of two in [16, 2048] (or any even size on one rank)", n);
+  } else if (!mixed && (n < 16 || n > 2048)) return pf_fail(rank, "pf_create: grid size %lld must be a power of two in [16, 2048] (or any even size on one rank)", n);
   if (cfg->nranks < 1 || n % cfg->nranks || cfg->rank < 0 || cfg->rank >= cfg->nranks)
     return pf_fail(rank, "pf_create: nranks %d must divide the grid size %lld (slab decomposition)", cfg->nranks, n);
   if (cfg->nranks & (cfg->nranks - 1)) return pf_fail(rank, "pf_create: nranks %d must be a power of two", cfg->nranks);
+  if (!pow2 && !want_general && cfg->nranks != 1) return pf_fail(rank, "pf_create: grid size %lld is not a power of two: one rank only", n);
   if (cfg->field_bytes != 8 && cfg->field_bytes != 4) return pf_fail(rank, "pf_create: field_bytes must be 8 or 4");
   if ((cfg->flags & PF_FLAG_DOUBLE_PRODUCTS) && cfg->field_bytes != 8)
     return pf_fail(rank, "pf_create: PF_FLAG_DOUBLE_PRODUCTS (fp64 Fmax and displacements) needs fp64 fields");
@@ -1325,7 +1329,7 @@ static int sweep_body_run(pf_ctx *c, int ns, const double *radius_cells, double 
   c->sources_fresh = false;
   // (n <= 1024: the six-line workgroup of a 2048-point row would need 110 KB of dynamic LDS, a size this build never launches)
   // (n <= 1024 with fp64 fields, n <= 2048 with fp32 ones: the six lines of a row must fit the LDS of a workgroup)
-  const bool invariants_ok = c->n <= (c->fb == 8 ? 1024 : 2048) && !c->general && c->tab_ns == 0 && c->model == 0 && c->tune.invariants && !six_components;
+  const bool invariants_ok = c->n <= (c->fb == 8 ? 1024 : 2048) && !(c->n & (c->n - 1)) && !c->general && c->tab_ns == 0 && c->model == 0 && c->tune.invariants && !six_components;
   HIPCHK(c, hipMemsetAsync(c->scal + SC_INV_FLAG, 0, sizeof(double), c->stream));
   const bool rep = c->replicate;
   if (rep) PFCHK(c, ensure_dk_full(c));
@@ -1452,6 +1456,9 @@ extern "C" int pf_sweep(pf_ctx *c, int ns, const double *radius_cells, double *t
 extern "C" int pf_debug_invariant_reruns(pf_ctx *c) { return c ? c->inv_reruns : -1; }
 extern "C" int pf_solve_ran_beside_zpass(pf_ctx *c) { return c ? (c->solve_ran_beside ? 1 : 0) : -1; }
 extern "C" int pf_replicated_spectrum(pf_ctx *c) { return c ? (c->replicate ? 1 : 0) : -1; }
+// which transforms serve this grid size: 0 the power-of-two passes (pf_fft_kernels.hip), 1 the run-time stage plans for
+// n = 8 m, m = 2^a 3^b 5^c (pf_mixed_kernels.hip), 2 library transforms, one per component (pf_gfft.cpp)
+extern "C" int pf_transform_path(pf_ctx *c) { return !c ? -1 : c->general ? 2 : (c->n & (c->n - 1)) ? 1 : 0; }
 extern "C" int pf_set_transposed_spectra(pf_ctx *c, int on) {
   if (!c) return 1;
   c->transposed = on != 0;
@@ -1513,7 +1520,7 @@ extern "C" int pf_displacements(pf_ctx *c, int compute_sources, int recompute_sd
       // Hessian of the 2LPT potential contracted with the first-order one into the 3LPT(b) source (src/LPT.c:112-137).  fp64
       // fields: the z-pass does the contraction while it holds a row's six components (nothing of that Hessian is stored;
       // PF_LPT_FUSE=0: six fields out, then k_lpt_accum); same operations per cell either way
-      const bool fuse3b = c->n <= (c->fb == 8 ? 1024 : 2048) && !c->general && c->tune.lpt_fuse;
+      const bool fuse3b = c->n <= (c->fb == 8 ? 1024 : 2048) && !(c->n & (c->n - 1)) && !c->general && c->tune.lpt_fuse;
       if (c->lpt_order < 3) {  // no THREE_LPT (src/LPT.c:78-92, 113-175): the 2LPT source alone
       } else if (fuse3b) {
         PFCHK(c, hessian_of(c, c->S[0], 0.0, c->scal + SC_DC_S2, c->B2, c->S[2], c->B));
@@ -1888,8 +1895,13 @@ extern "C" int pf_debug_exchange(pf_ctx *c, size_t bytes_per_peer) {
 extern "C" int pf_debug_lines(int field_bytes, int n, int pass, int mul, int band, int nouter, int ncols, int pre, double rs,
                               double growth, int outer_offset, const double *in, double *out) {
   double *flag_out = (pass == 4 && out) ? out + (size_t)3 * nouter * n : nullptr;  // pass 4: one more double after the rows, the q == 0 flag
-  if (!in || !out || nouter < 1 || (field_bytes != 8 && field_bytes != 4) || n < 16 || n > 2048 || (n & (n - 1)) || pass < 0 || pass > 4)
+  if (!in || !out || nouter < 1 || (field_bytes != 8 && field_bytes != 4) || n < 8 || n > 2048 || pass < 0 || pass > 4)
     return pf_fail(0, "pf_debug_lines: bad argument");
+  if (n & (n - 1)) {  // not a power of two: the run-time stage plans (pf_mixed_kernels.hip), where they apply
+    PfMixedPlan pl;
+    if (pass == 4 || !(pass <= 1 ? pf_mixed_plan(n, false, &pl) : (n % 2 == 0 && pf_mixed_plan(n / 2, true, &pl))))
+      return pf_fail(0, "pf_debug_lines: no stage plan for %d points in pass %d", n, pass);
+  } else if (n < 16) return pf_fail(0, "pf_debug_lines: bad argument");
   if (pass == 4 && n > (field_bytes == 8 ? 1024 : 2048)) return pf_fail(0, "pf_debug_lines: the invariant z-pass takes fp64 rows of at most 1024 points, fp32 rows of at most 2048");
   const int fb = field_bytes, nzh = n / 2 + 1;
   pf_ctx *nc = nullptr;  // for the error macros

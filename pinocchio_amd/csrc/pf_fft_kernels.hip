@@ -709,6 +709,7 @@ static int launch_r2c_n(const PfR2CParams &p, hipStream_t st) {
   }
 
 int pf_launch_strided(int fb, int n, int dir, const PfStridedParams &p, hipStream_t st) {
+  if (n & (n - 1)) return pf_launch_mixed_strided(fb, n, dir, p, st);  // not a power of two: run-time stage plan
   if (fb == 8) {
     if (dir > 0) {
 #define CALL(NN) launch_strided_n<double, NN, +1>(p, st)
@@ -733,6 +734,7 @@ int pf_launch_strided(int fb, int n, int dir, const PfStridedParams &p, hipStrea
 }
 
 int pf_launch_c2r(int fb, int n, const PfC2RParams &p, hipStream_t st) {
+  if (n & (n - 1)) return pf_launch_mixed_c2r(fb, n, p, st);
   if (fb == 8) {
 #define CALL(NN) launch_c2r_n<double, NN>(p, st)
     PF_SWITCH_N(n, CALL)
@@ -746,7 +748,7 @@ int pf_launch_c2r(int fb, int n, const PfC2RParams &p, hipStream_t st) {
 
 int pf_launch_c2r_invariants(int fb, int n, const PfC2RParams &p, hipStream_t st, int mode) {
   // (the six lines of a 2048-point fp64 row would need 110 KB of LDS; fp32 fields go up to 2048)
-  if (p.njobs != 6 || (mode == 1 && !p.acc) || (mode == 0 && !p.flag) || n > (fb == 8 ? 1024 : 2048)) return 2;
+  if (p.njobs != 6 || (mode == 1 && !p.acc) || (mode == 0 && !p.flag) || n > (fb == 8 ? 1024 : 2048) || (n & (n - 1))) return 2;
   if (fb == 8) {
 #define CALL(NN) launch_c2r_invariants_n<double, NN>(p, st, mode)
     PF_SWITCH_N(n, CALL)
@@ -760,6 +762,7 @@ int pf_launch_c2r_invariants(int fb, int n, const PfC2RParams &p, hipStream_t st
 }
 
 int pf_launch_r2c(int fb, int n, const PfR2CParams &p, hipStream_t st) {
+  if (n & (n - 1)) return pf_launch_mixed_r2c(fb, n, p, st);
   if (fb == 8) {
 #define CALL(NN) launch_r2c_n<double, NN>(p, st)
     PF_SWITCH_N(n, CALL)

@@ -1,0 +1,409 @@
+// pf_mixed_kernels.hip -- the three 1-D passes for grid sizes that are NOT a power of two (gfx950).
+//
+// The reference takes any GridSize through FFTW / PFFT (plans at src/fmax-pfft.c:139-188; the example parameter file uses
+// 200).  The passes of pf_fft_kernels.hip are specialised on the line length (compile-time stage plans of 8 points per
+// thread) and cover N = 2^k; here the line length is a RUN-TIME argument and the stage plan a small table (PfMixedPlan):
+// N = R0 * R1 * ... with radices from {8, 5, 4, 3, 2}, R0 = 8 (strided passes; N a multiple of 8) or 8 / 4 (half-length
+// lines of the z-pass), Stockham auto-sort as in pf_fft_core.h:
+//   stage s, butterfly b of N / R_s:  inputs line[b + q N / R_s], q < R_s, times w^(q k), k = b mod NS_s,
+//                                     w = exp(+-2 pi i / (NS_s R_s)), NS_s = R_0 ... R_{s-1};  DFT_{R_s};
+//                                     outputs to (b - k) R_s + k + t NS_s, t < R_s.
+// A line has N / R0 threads; stage 0 is one butterfly per thread on the points it loaded from HBM (kept for every job on
+// the same input, as in k_strided), later stages deal their N / R_s butterflies over the same threads (ceil(R0 / R_s) each)
+// and exchange through LDS; the last stage stores straight to HBM.  Same semantics, same parameter blocks and the same
+// layouts as the power-of-two kernels -- filter on load, k multipliers, band limits, fp32 product rows -- so that the
+// sweep keeps its shared passes (x 1 -> 3, y 3 -> 6, z 6 -> 6) instead of one library transform per component.
+// What these kernels do not have: tile prefetch, the paired radix-16 stage, two columns per thread, the invariant z-pass
+// (six components per cell are stored), workgroups that walk over rows.  One rank.
+#include <cstring>
+
+#include "pf_internal.h"
+#include "pf_fft_core.h"
+#include "pf_fft_stages.h"
+
+// hardware deals consecutive workgroups round-robin over the 8 XCDs: a contiguous range of tiles per XCD (as pf_fft_kernels.hip)
+__device__ __forceinline__ long long pf_xcd_swizzle_mixed(long long b, long long per_xcd) { return (b & 7) * per_xcd + (b >> 3); }
+
+// ---- small DFTs in registers: X_k = sum_t u_t w^(k t), w = exp(DIR 2 pi i / R), natural order in and out ----
+template <int DIR, typename F> __device__ __forceinline__ void pf_bfly3(pfc<F> &a, pfc<F> &b, pfc<F> &c) {
+  const F s = (F)0.86602540378443864676;  // sin(2 pi / 3)
+  const pfc<F> t1 = b + c, d = b - c;
+  const pfc<F> t2 = pf_mk<F>(a.x - (F)0.5 * t1.x, a.y - (F)0.5 * t1.y);
+  const pfc<F> t3 = pf_mul_i<DIR>(pf_scale(d, s));
+  a = a + t1;
+  b = t2 + t3;
+  c = t2 - t3;
+}
+template <int DIR, typename F> __device__ __forceinline__ void pf_bfly5(pfc<F> &x0, pfc<F> &x1, pfc<F> &x2, pfc<F> &x3, pfc<F> &x4) {
+  const F c1 = (F)0.30901699437494742410, c2 = (F)-0.80901699437494742410;  // cos 72, cos 144
+  const F s1 = (F)0.95105651629515357212, s2 = (F)0.58778525229247312917;   // sin 72, sin 144
+  const pfc<F> t1 = x1 + x4, t2 = x2 + x3, t3 = x1 - x4, t4 = x2 - x3;
+  const pfc<F> m1 = pf_mk<F>(x0.x + c1 * t1.x + c2 * t2.x, x0.y + c1 * t1.y + c2 * t2.y);
+  const pfc<F> m2 = pf_mk<F>(x0.x + c2 * t1.x + c1 * t2.x, x0.y + c2 * t1.y + c1 * t2.y);
+  const pfc<F> n1 = pf_mul_i<DIR>(pf_mk<F>(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y));
+  const pfc<F> n2 = pf_mul_i<DIR>(pf_mk<F>(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y));
+  x0 = x0 + t1 + t2;
+  x1 = m1 + n1; x4 = m1 - n1;
+  x2 = m2 + n2; x3 = m2 - n2;
+}
+template <int R, int DIR, typename F> __device__ __forceinline__ void pf_dft_small(pfc<F> (&u)[R]) {
+  if constexpr (R == 8) pf_bfly8<DIR>(u);
+  else if constexpr (R == 5) pf_bfly5<DIR>(u[0], u[1], u[2], u[3], u[4]);
+  else if constexpr (R == 4) pf_bfly4<DIR>(u[0], u[1], u[2], u[3]);
+  else if constexpr (R == 3) pf_bfly3<DIR>(u[0], u[1], u[2]);
+  else pf_bfly2<DIR>(u[0], u[1]);
+}
+
+// One stage s >= 1 of a line through LDS.  rd(pos) / wr(pos, val): the line's exchange area; sync(): every thread of the line
+// is past its reads (writes).  LAST: the results go to out(pos, val) instead (HBM, or the post-processing of the caller).
+// tw[j tws] = exp(+2 pi i j / n) (tws = 2: the half-length lines of the z-pass use the table of the full length).  Every thread
+// of the line must call this (barriers inside).
+template <int R, int R0, int DIR, bool LAST, typename F, typename RD, typename WR, typename SYNC, typename OUT>
+__device__ __forceinline__ void pf_mixed_stage(int n, int ns, int nt, int tl, const pfc<F> *__restrict__ tw, int tws, RD rd, WR wr, SYNC sync, OUT out) {
+  constexpr int LOOPS = (R0 + R - 1) / R;  // butterflies per thread: ceil((n / R) / (n / R0))
+  const int nb = n / R;                    // butterflies of the stage = distance of a butterfly's inputs
+  const int twm = n / (ns * R);
+  pfc<F> u[LOOPS][R];
+#pragma unroll
+  for (int i = 0; i < LOOPS; i++) {
+    const int b = tl + i * nt;
+    if (b < nb) {
+#pragma unroll
+      for (int q = 0; q < R; q++) u[i][q] = rd(b + q * nb);
+    }
+  }
+  sync();
+#pragma unroll
+  for (int i = 0; i < LOOPS; i++) {
+    const int b = tl + i * nt;
+    if (b < nb) {
+      const int k = b % ns;
+      if (ns > 1) {
+        int idx = 0;  // (q k twm) mod n, stepped
+        const int step = (int)(((long long)k * twm) % n);
+#pragma unroll
+        for (int q = 1; q < R; q++) {
+          idx += step; if (idx >= n) idx -= n;
+          pfc<F> w = tw[idx * tws];
+          if (DIR < 0) w.y = -w.y;
+          u[i][q] = pf_cmul(u[i][q], w);
+        }
+      }
+      pf_dft_small<R, DIR>(u[i]);
+      const int base = (b - k) * R + k;
+#pragma unroll
+      for (int t = 0; t < R; t++) {
+        if (LAST) out(base + t * ns, u[i][t]);
+        else wr(base + t * ns, u[i][t]);
+      }
+    }
+  }
+  if (!LAST) sync();
+}
+
+// stages 1 .. nstages-1 of the plan (stage 0 done by the caller, its outputs already written through wr and synced)
+template <int R0, int DIR, typename F, typename RD, typename WR, typename SYNC, typename OUT>
+__device__ __forceinline__ void pf_mixed_tail(const PfMixedPlan &pl, int tl, const pfc<F> *__restrict__ tw, int tws, RD rd, WR wr, SYNC sync, OUT out) {
+  const int nt = pl.n / R0;
+  int ns = R0;
+  for (int s = 1; s < pl.nstages; s++) {
+    const int R = pl.radix[s];
+    const bool last = s + 1 == pl.nstages;
+#define PF_MIXED_CASE(RR)                                                                                              \
+  case RR:                                                                                                             \
+    if (last) pf_mixed_stage<RR, R0, DIR, true>(pl.n, ns, nt, tl, tw, tws, rd, wr, sync, out);                               \
+    else pf_mixed_stage<RR, R0, DIR, false>(pl.n, ns, nt, tl, tw, tws, rd, wr, sync, out);                                   \
+    break;
+    switch (R) {
+      PF_MIXED_CASE(8)
+      PF_MIXED_CASE(5)
+      PF_MIXED_CASE(4)
+      PF_MIXED_CASE(3)
+      default:
+        if (last) pf_mixed_stage<2, R0, DIR, true>(pl.n, ns, nt, tl, tw, tws, rd, wr, sync, out);
+        else pf_mixed_stage<2, R0, DIR, false>(pl.n, ns, nt, tl, tw, tws, rd, wr, sync, out);
+        break;
+    }
+#undef PF_MIXED_CASE
+    ns *= R;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ strided passes ----
+// x- or y-pass: a workgroup owns T adjacent columns of one line of tiles and all n points along the transformed axis
+// (n / 8 threads per column).  Parameters and semantics: PfStridedParams, as k_strided.
+template <typename F, int DIR>
+__global__ void __launch_bounds__(1024) k_mixed_strided(const PfStridedParams p, const PfMixedPlan pl, const int T, const long long nwork, const int ntiles) {
+  using C = pfc<F>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  C *lds = reinterpret_cast<C *>(smem);  // [n][T]
+  const long long w = pf_xcd_swizzle_mixed(blockIdx.x, (nwork + 7) >> 3);
+  if (w >= nwork) return;
+  const int n = pl.n, nt = n / 8;
+  const int tid = threadIdx.x;
+  const int c = tid % T, tl = tid / T;
+  const int tile = (int)(w % ntiles), outer = (int)(w / ntiles);
+  const int col = tile * T + c;
+  const bool valid = col < p.ncols;
+  const C *__restrict__ tw = reinterpret_cast<const C *>(p.tw);
+  const double kf = 2.0 * 3.14159265358979323846 / (double)n;
+  const int half = n / 2;
+  if (p.band_outer < half) {
+    int so = outer + p.outer_offset;
+    if (so > half) so -= n;
+    if (so > p.band_outer || so < -p.band_outer) return;  // (uniform: the whole workgroup leaves)
+  }
+  auto addr = [&](const PfAddr &a, int e) { return (long long)outer * a.os + (long long)(e >> a.el_shift) * a.ehs + (long long)(e & ((1 << a.el_shift) - 1)) * a.els + col; };
+  C src[8], v[8];
+  double ko = 0.0, woc = 1.0;
+  if (p.pre) {
+    int so = outer + p.outer_offset;
+    if (so > half) so -= n;
+    ko = kf * so;
+    const double kc = kf * col;
+    woc = (p.rs != 0.0 ? exp(-0.5 * (ko * ko + kc * kc) * p.rs * p.rs) : 1.0) * p.growth;
+  }
+  auto sync = [&]() { __syncthreads(); };
+  for (int j = 0; j < p.njobs; j++) {
+    if (j == 0 || p.job[j].in != p.job[j - 1].in) {  // jobs are grouped by input: a tile is read from HBM once
+      const C *__restrict__ in = reinterpret_cast<const C *>(p.job[j].in);
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        const int e = tl + m * nt;
+        const int se = e > half ? e - n : e;
+        const bool inband = se <= p.band_e && se >= -p.band_e;
+        src[m] = (valid && inband) ? pf_ld_stream(in + addr(p.ain, e)) : pf_zero<F>();
+        if (p.pre) {  // exp(-k^2 rs^2 / 2) g / k^2, zero at k = 0 (src/fmax-pfft.c:366-384)
+          const double ke = kf * se;
+          const double k2 = ke * ke + ko * ko + (kf * col) * (kf * col);
+          const double we = p.rs != 0.0 ? p.etab[e] : 1.0;
+          src[m] = pf_scale(src[m], (F)((k2 != 0.0) ? we * woc / k2 : 0.0));
+        }
+      }
+    }
+    const int mul = p.job[j].mul;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int e = tl + m * nt;
+      const F ke = (F)(kf * (e > half ? e - n : e));
+      C x = src[m];
+      if (mul == PF_MUL_K) x = pf_scale(x, ke);
+      else if (mul == PF_MUL_K2) x = pf_scale(x, ke * ke);
+      else if (mul == PF_MUL_IK) x = pf_mul_i<+1>(pf_scale(x, ke));
+      v[m] = x;
+    }
+    C *__restrict__ outp = reinterpret_cast<C *>(p.job[j].out);
+    auto store = [&](int e, C val) {
+      if (!valid) return;
+      if (p.out_ne > 0 && (unsigned)(e - p.out_e0) >= (unsigned)p.out_ne) return;
+      pf_st_stream(outp + addr(p.aout, e), val);
+    };
+    pf_bfly8<DIR>(v);  // stage 0: the thread's own eight points (NS = 1: no twiddles)
+    if (pl.nstages == 1) {
+#pragma unroll
+      for (int t = 0; t < 8; t++) store(tl + t * nt, v[t]);  // n = 8: (b - k) R + k + t NS with b = k = 0
+    } else {
+#pragma unroll
+      for (int t = 0; t < 8; t++) lds[(tl * 8 + t) * T + c] = v[t];  // outputs of butterfly b = tl: b R + t
+      __syncthreads();
+      pf_mixed_tail<8, DIR, F>(
+          pl, tl, tw, 1, [&](int pos) { return lds[pos * T + c]; }, [&](int pos, C val) { lds[pos * T + c] = val; }, sync, store);
+      __syncthreads();  // the next job rewrites the exchange area
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------------------- z-pass ----
+// c2r rows: Hermitian rows of n/2+1 -> n reals through the half-length complex transform (pf_c2r_pre), kz factor, 1/N^3 and
+// the DC constant as k_c2r.  TL rows per workgroup, M / R0 threads per row (M = n / 2, R0 = 8 or 4).
+template <typename F, int R0>
+__global__ void __launch_bounds__(1024) k_mixed_c2r(const PfC2RParams p, const PfMixedPlan pl, const int TL) {
+  using C = pfc<F>;
+  const int M = pl.n, n = 2 * M, nt = M / R0;
+  const int LPL = M + 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  C *lds = reinterpret_cast<C *>(smem);
+  const int tid = threadIdx.x, nthr = TL * nt;
+  const int l = tid / nt, tl = tid % nt;
+  const int job = blockIdx.x % p.njobs;
+  const long long line0 = (long long)(blockIdx.x / p.njobs) * TL;
+  const C *__restrict__ in = reinterpret_cast<const C *>(p.job[job].in);
+  const int mul = p.job[job].mul;
+  const C *__restrict__ tw = reinterpret_cast<const C *>(p.tw);   // exp(+2 pi i j / n), n entries
+  for (int idx = tid; idx < TL * (M + 1); idx += nthr) {
+    const int ll = idx / (M + 1), k = idx % (M + 1);
+    const long long row = line0 + ll;
+    lds[ll * LPL + k] = (row < p.nlines && k <= p.band_k) ? in[row * p.in_pitch + k] : pf_mk<F>(0, 0);
+  }
+  __syncthreads();
+  C *L = lds + l * LPL;
+  const F kf = (F)(2.0 * 3.14159265358979323846 / (double)n);
+  C v[R0];
+#pragma unroll
+  for (int m = 0; m < R0; m++) {
+    const int e = tl + m * nt;
+    v[m] = pf_zfold<F>(L[e], L[M - e], e, M, mul, kf, tw[e]);
+  }
+  __syncthreads();
+  const long long row = line0 + l;
+  const F norm = (F)p.norm;
+  const F dcv = p.dc ? (F)(*p.dc) : (F)0;
+  const int of32 = p.job[job].out_f32;
+  auto store = [&](int pos, C val) {  // complex j of the half-length line = reals 2 j, 2 j + 1 of the row
+    if (row >= p.nlines) return;
+    const F a = pf_norm_dc(val.x, norm, dcv), b = pf_norm_dc(val.y, norm, dcv);
+    if (of32 == 1) reinterpret_cast<float2 *>(reinterpret_cast<float *>(p.job[job].out) + row * (long long)n)[pos] = make_float2((float)a, (float)b);
+    else reinterpret_cast<C *>(reinterpret_cast<F *>(p.job[job].out) + row * (of32 == 2 ? (long long)n : p.out_pitch))[pos] = pf_mk<F>(a, b);
+  };
+  auto sync = [&]() { __syncthreads(); };
+  pf_dft_small<R0, +1>(v);
+  if (pl.nstages == 1) {
+#pragma unroll
+    for (int t = 0; t < R0; t++) store(tl + t * nt, v[t]);
+  } else {
+#pragma unroll
+    for (int t = 0; t < R0; t++) L[tl * R0 + t] = v[t];
+    __syncthreads();
+    pf_mixed_tail<R0, +1, F>(
+        pl, tl, tw, 2, [&](int pos) { return L[pos]; }, [&](int pos, C val) { L[pos] = val; }, sync, store);
+  }
+}
+
+// r2c rows (forward z-pass of the LPT sources), in place like k_r2c: real row -> n/2+1 complex
+template <typename F, int R0>
+__global__ void __launch_bounds__(1024) k_mixed_r2c(const PfR2CParams p, const PfMixedPlan pl, const int TL) {
+  using C = pfc<F>;
+  const int M = pl.n, nt = M / R0;
+  const int LPL = M + 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  C *lds = reinterpret_cast<C *>(smem);
+  const int tid = threadIdx.x, nthr = TL * nt;
+  const int l = tid / nt, tl = tid % nt;
+  const long long line0 = (long long)blockIdx.x * TL;
+  const long long row = line0 + l;
+  const bool valid = row < p.nlines;
+  const C *__restrict__ tw = reinterpret_cast<const C *>(p.tw);
+  C *L = lds + l * LPL;
+  C v[R0];
+  {
+    const C *in = reinterpret_cast<const C *>(reinterpret_cast<const F *>(p.in) + row * p.in_pitch);
+#pragma unroll
+    for (int m = 0; m < R0; m++) v[m] = valid ? in[tl + m * nt] : pf_mk<F>(0, 0);
+  }
+  auto sync = [&]() { __syncthreads(); };
+  auto keep = [&](int pos, C val) { L[pos] = val; };  // the last stage leaves Z in LDS: the post-processing reads Z[k] and Z[M - k]
+  __syncthreads();  // (in place: every row of the tile is in registers before anything is stored)
+  pf_dft_small<R0, -1>(v);
+  if (pl.nstages == 1) {
+#pragma unroll
+    for (int t = 0; t < R0; t++) L[tl + t * nt] = v[t];
+  } else {
+#pragma unroll
+    for (int t = 0; t < R0; t++) L[tl * R0 + t] = v[t];
+    __syncthreads();
+    pf_mixed_tail<R0, -1, F>(
+        pl, tl, tw, 2, [&](int pos) { return L[pos]; }, keep, sync, keep);
+  }
+  __syncthreads();
+  // every thread of the tile helps with every row of the tile (rows of the same tile: all loads happened above)
+  for (int idx = tid; idx < TL * (M + 1); idx += nthr) {
+    const int ll = idx / (M + 1), k = idx % (M + 1);
+    const long long r = line0 + ll;
+    if (r >= p.nlines) continue;
+    const C *Z = lds + ll * LPL;
+    C *out = reinterpret_cast<C *>(p.out) + r * p.out_pitch;
+    if (k == M) out[M] = pf_mk<F>(Z[0].x - Z[0].y, (F)0);
+    else out[k] = pf_r2c_post<F>(Z[k], Z[k == 0 ? 0 : M - k], tw[k]);
+  }
+}
+
+// --------------------------------------------------------------------------------------------------------- launch ----
+// radices of a line of n points: first R0 (8, or 4 where allowed), then 8s, a 4 or a 2, 5s and 3s.  false: n has another
+// prime factor (or no admissible first radix) -- the caller keeps the library-transform path for such sizes.
+bool pf_mixed_plan(int n, bool allow4, PfMixedPlan *pl) {
+  memset(pl, 0, sizeof(*pl));
+  pl->n = n;
+  int r0 = (n % 8 == 0) ? 8 : ((allow4 && n % 4 == 0) ? 4 : 0);
+  if (!r0 || n < r0) return false;
+  int rest = n / r0, ns = 0;
+  pl->radix[ns++] = r0;
+  while (rest % 8 == 0) { if (ns >= PF_MIXED_MAX_STAGES) return false; pl->radix[ns++] = 8; rest /= 8; }
+  if (rest % 4 == 0) { if (ns >= PF_MIXED_MAX_STAGES) return false; pl->radix[ns++] = 4; rest /= 4; }
+  if (rest % 2 == 0) { if (ns >= PF_MIXED_MAX_STAGES) return false; pl->radix[ns++] = 2; rest /= 2; }
+  while (rest % 5 == 0) { if (ns >= PF_MIXED_MAX_STAGES) return false; pl->radix[ns++] = 5; rest /= 5; }
+  while (rest % 3 == 0) { if (ns >= PF_MIXED_MAX_STAGES) return false; pl->radix[ns++] = 3; rest /= 3; }
+  if (rest != 1) return false;
+  if (r0 == 4) for (int s = 1; s < ns; s++) if (pl->radix[s] == 8) return false;  // (cannot happen: n / 4 odd multiple... kept as a guard)
+  pl->nstages = ns;
+  return true;
+}
+bool pf_mixed_supported(int n) {
+  PfMixedPlan a, b;
+  return n >= 8 && n <= 2048 && n % 8 == 0 && pf_mixed_plan(n, false, &a) && pf_mixed_plan(n / 2, true, &b);
+}
+
+template <typename F> static int pf_mixed_raise_lds(const void *fn, size_t shm) {
+  if (shm <= 64 * 1024) return 0;
+  return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess ? 0 : 3;
+}
+int pf_launch_mixed_strided(int fb, int n, int dir, const PfStridedParams &p, hipStream_t st) {
+  PfMixedPlan pl;
+  if (!pf_mixed_plan(n, false, &pl)) return 2;
+  const int nt = n / 8;
+  const int w = fb == 8 ? 16 : 8;  // bytes of a complex element
+  int T = 128 / w;                 // whole 128-byte row segments where LDS and the thread budget allow
+  while (T > 1 && ((size_t)n * T * w > 128 * 1024 || nt * T > 1024)) T >>= 1;
+  if (nt * T > 1024 || (size_t)n * T * w > 160 * 1024) return 2;
+  const int ntiles = (p.ncols + T - 1) / T;
+  const long long nwork = (long long)ntiles * p.nouter;
+  const dim3 grid((unsigned)(((nwork + 7) >> 3) << 3)), block(T * nt);
+  const size_t shm = (size_t)n * T * w;
+#define PF_MIXED_LAUNCH(FF, DD)                                                                                      \
+  do {                                                                                                               \
+    if (pf_mixed_raise_lds<FF>(reinterpret_cast<const void *>(&k_mixed_strided<FF, DD>), shm)) return 3;             \
+    hipLaunchKernelGGL((k_mixed_strided<FF, DD>), grid, block, shm, st, p, pl, T, nwork, ntiles);                    \
+  } while (0)
+  if (fb == 8) { if (dir > 0) PF_MIXED_LAUNCH(double, +1); else PF_MIXED_LAUNCH(double, -1); }
+  else { if (dir > 0) PF_MIXED_LAUNCH(float, +1); else PF_MIXED_LAUNCH(float, -1); }
+#undef PF_MIXED_LAUNCH
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+static int pf_mixed_rows_per_wg(int nt) { int tl = 256 / nt; return tl < 1 ? 1 : tl; }
+int pf_launch_mixed_c2r(int fb, int n, const PfC2RParams &p, hipStream_t st) {
+  PfMixedPlan pl;
+  const int M = n / 2;
+  if (!pf_mixed_plan(M, true, &pl)) return 2;
+  const int r0 = pl.radix[0], nt = M / r0, TL = pf_mixed_rows_per_wg(nt);
+  if (TL * nt > 1024) return 2;
+  const long long nblk = (p.nlines + TL - 1) / TL;
+  const dim3 grid((unsigned)(nblk * p.njobs)), block(TL * nt);
+  const size_t shm = (size_t)TL * (M + 1) * (fb == 8 ? 16 : 8);
+#define PF_MIXED_LAUNCH(FF, RR)                                                                                      \
+  do {                                                                                                               \
+    if (pf_mixed_raise_lds<FF>(reinterpret_cast<const void *>(&k_mixed_c2r<FF, RR>), shm)) return 3;                 \
+    hipLaunchKernelGGL((k_mixed_c2r<FF, RR>), grid, block, shm, st, p, pl, TL);                                      \
+  } while (0)
+  if (fb == 8) { if (r0 == 8) PF_MIXED_LAUNCH(double, 8); else PF_MIXED_LAUNCH(double, 4); }
+  else { if (r0 == 8) PF_MIXED_LAUNCH(float, 8); else PF_MIXED_LAUNCH(float, 4); }
+#undef PF_MIXED_LAUNCH
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+int pf_launch_mixed_r2c(int fb, int n, const PfR2CParams &p, hipStream_t st) {
+  PfMixedPlan pl;
+  const int M = n / 2;
+  if (!pf_mixed_plan(M, true, &pl)) return 2;
+  const int r0 = pl.radix[0], nt = M / r0, TL = pf_mixed_rows_per_wg(nt);
+  if (TL * nt > 1024) return 2;
+  const long long nblk = (p.nlines + TL - 1) / TL;
+  const dim3 grid((unsigned)nblk), block(TL * nt);
+  const size_t shm = (size_t)TL * (M + 1) * (fb == 8 ? 16 : 8);
+#define PF_MIXED_LAUNCH(FF, RR)                                                                                      \
+  do {                                                                                                               \
+    if (pf_mixed_raise_lds<FF>(reinterpret_cast<const void *>(&k_mixed_r2c<FF, RR>), shm)) return 3;                 \
+    hipLaunchKernelGGL((k_mixed_r2c<FF, RR>), grid, block, shm, st, p, pl, TL);                          \
+  } while (0)
+  if (fb == 8) { if (r0 == 8) PF_MIXED_LAUNCH(double, 8); else PF_MIXED_LAUNCH(double, 4); }
+  else { if (r0 == 8) PF_MIXED_LAUNCH(float, 8); else PF_MIXED_LAUNCH(float, 4); }
+#undef PF_MIXED_LAUNCH
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}

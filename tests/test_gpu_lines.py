@@ -11,6 +11,11 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 SIZES = [16, 64, 256, 1024, 2048]
+# grid sizes that are not a power of two: the run-time stage plans of csrc/pf_mixed_kernels.hip (radices 8, 5, 4, 3, 2) --
+# 24 = 8.3, 40 = 8.5, 96 = 8.4.3, 120 = 8.5.3, 200 = 8.5.5 (the reference's example size), 384 = 8.8.2.3, 768 = 8.8.4.3,
+# 1000 = 8.5.5.5, 1536 = 8.8.8.3; their z-passes run on the half lengths 12 = 4.3, 20 = 4.5, 48, 60, 100 = 4.5.5, 192, ...
+MIXED = [24, 40, 96, 120, 200, 384, 768, 1000, 1536]
+ALL_SIZES = SIZES + MIXED
 
 
 @pytest.fixture(scope="module")
@@ -54,7 +59,7 @@ def tol(fb, n):
     return (2e-15 if fb == 8 else 1e-6) * np.log2(n)
 
 
-@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("n", ALL_SIZES)
 @pytest.mark.parametrize("fb", [8, 4])
 def test_strided_pass_lines(L, n, fb):
     rng = np.random.default_rng(n + fb)
@@ -76,7 +81,7 @@ def test_strided_pass_lines(L, n, fb):
     assert np.max(np.abs(got - want)) <= tol(fb, n) * np.max(np.abs(want)), (n, fb, "band")
 
 
-@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("n", ALL_SIZES)
 @pytest.mark.parametrize("fb", [8, 4])
 def test_first_pass_filter_on_lines(L, n, fb):
     """the x-pass of the sweep: window, 1/k^2, growth and the factor of its own axis fused into the load"""
@@ -97,7 +102,7 @@ def test_first_pass_filter_on_lines(L, n, fb):
         assert np.max(np.abs(got - want)) <= 4 * tol(fb, n) * np.max(np.abs(want)), (n, fb, rs, mul)
 
 
-@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("n", ALL_SIZES)
 @pytest.mark.parametrize("fb", [8, 4])
 @pytest.mark.parametrize("persist", ["24", "0"])
 def test_zpass_c2r_lines(L, n, fb, persist, monkeypatch):
@@ -116,7 +121,7 @@ def test_zpass_c2r_lines(L, n, fb, persist, monkeypatch):
     assert np.max(np.abs(got - want)) <= tol(fb, n) * np.max(np.abs(want)), (n, fb, "band")
 
 
-@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("n", ALL_SIZES)
 @pytest.mark.parametrize("fb", [8, 4])
 def test_zpass_r2c_lines(L, n, fb):
     rng = np.random.default_rng(7 * n + fb)

@@ -1091,11 +1091,13 @@ def test_edge_case_fields_vs_oracle(api, case, monkeypatch):
             assert not p["Vel"].any() and np.all(p["Rmax"] == po["Rmax"]) and np.array_equal(p["Fmax"], po["Fmax"])
 
 
-@pytest.mark.parametrize("n", [24, 40])
-def test_general_grid_sizes_vs_oracle(api, n):
-    """grid sizes that are not a power of two (the reference takes any GridSize; 200^3 in INSTALLATION:101): the
-    library-transform path against the oracle (plain O(n^2) transforms at these sizes), full path + taps"""
+@pytest.mark.parametrize("n,general,path", [(24, "0", 1), (40, "0", 1), (48, "0", 1), (24, "1", 2), (40, "1", 2), (20, "0", 2), (36, "0", 2)])
+def test_general_grid_sizes_vs_oracle(api, n, general, path, monkeypatch):
+    """grid sizes that are not a power of two (the reference takes any GridSize; 200^3 in INSTALLATION:101) against the oracle
+    (plain O(n^2) transforms at these sizes), full path + taps: the hand-written passes with run-time stage plans where they
+    apply (n = 8 m with m = 2^a 3^b 5^c: path 1), the library-transform path for the rest and under PF_GENERAL=1 (path 2)"""
     import np_restatement as npr
+    monkeypatch.setenv("PF_GENERAL", general)
     dk = synth.make_density(n, seed=n)
     dk[0, 0, 0] = 0.11 * n ** 3
     x, y = synth.invgrow_table("lcdm")
@@ -1107,6 +1109,7 @@ def test_general_grid_sizes_vs_oracle(api, n):
     po = o.products()
     hes_o = o.second_derivatives(1.3)
     with api.Fmax(n) as f:
+        assert f.L.pf_transform_path(f.h) == path
         f.set_density(dk); f.set_invgrow(x, y); f.set_growth(g)
         tv = f.compute_fmax(radii, do_lpt=True)
         p = f.products()
@@ -1156,12 +1159,16 @@ def test_general_path_equals_fused_path_on_a_power_of_two(api, monkeypatch):
         assert np.max(np.abs(p1[name].astype(np.float64) - p0[name])) <= 4e-7 * np.max(np.abs(p0[name])), name
 
 
-def test_reference_example_size_200(api):
-    """BASELINE config 1 (200^3, INSTALLATION:101-102) through the general path: size-independent properties and the
-    device IC generator at that size"""
+@pytest.mark.parametrize("general", ["0", "1"])
+def test_reference_example_size_200(api, general, monkeypatch):
+    """BASELINE config 1 (200^3, INSTALLATION:101-102): size-independent properties and the device IC generator at that size,
+    through the hand-written passes (200 = 8.5.5: run-time stage plan) and through the library-transform path; the two
+    against each other in test_grid_200_mixed_passes_vs_library_transforms_and_oracle"""
     n = 200
+    monkeypatch.setenv("PF_GENERAL", general)
     x, y = synth.invgrow_table("lcdm")
     with api.Fmax(n) as f:
+        assert f.L.pf_transform_path(f.h) == (2 if general == "1" else 1)
         f.synth_density(synth.SEED, 2.5, -2.0)
         f.set_invgrow(x, y); f.set_growth(synth.growth_multipliers())
         tv = f.compute_fmax(np.array([8.0, 2.0, 0.0]), do_lpt=True)
@@ -1175,6 +1182,37 @@ def test_reference_example_size_200(api):
         assert np.max(np.abs(h[0] + h[1] + h[2] - back)) < 1e-10 * np.max(np.abs(back))   # Laplacian identity
         p = f.products()
         assert (p["Fmax"] >= 1.0).mean() > 0.2 and np.isfinite(p["Vel"]).all() and p["Vel_2LPT"].any()
+
+
+def test_grid_200_mixed_passes_vs_library_transforms_and_oracle(api, monkeypatch):
+    """200^3 (the reference's example size): the shared-pass path on run-time stage plans against the library-transform path
+    (products of a three-radius sweep with displacements), and its Hessian at one radius against the oracle"""
+    n = 200
+    x, y = synth.invgrow_table("lcdm")
+    g = synth.growth_multipliers()
+    radii = np.array([6.0, 1.5, 0.0])
+    dk = synth.philox_density(n, synth.SEED, 2.5, -2.0)
+    out = []
+    for general in ("0", "1"):
+        monkeypatch.setenv("PF_GENERAL", general)
+        with api.Fmax(n) as f:
+            f.set_density(dk); f.set_invgrow(x, y); f.set_growth(g)
+            tv = f.compute_fmax(radii, do_lpt=True)
+            p = f.products()
+            f.compute_second_derivatives(1.5)
+            out.append((tv, p, [f.second_derivative(i) for i in range(6)]))
+    (tv0, p0, h0), (tv1, p1, h1) = out
+    assert np.allclose(tv0, tv1, rtol=1e-12)
+    for a, b in zip(h0, h1):
+        assert np.max(np.abs(a - b)) <= 1e-12 * np.max(np.abs(b))
+    _fmax_close(p0["Fmax"], p1["Fmax"], max_abs=None)
+    assert np.mean(p0["Rmax"] != p1["Rmax"]) < 1e-3
+    for name in ("Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+        assert np.max(np.abs(p0[name].astype(np.float64) - p1[name])) <= 4e-7 * np.max(np.abs(p1[name])), name
+    o = oracle_lib.Oracle(n, 0)
+    o.set_density(dk)
+    for a, b in zip(h0, o.second_derivatives(1.5)):
+        assert np.max(np.abs(a - b)) <= 1e-12 * np.max(np.abs(b))
 
 
 def test_contexts_release_their_memory(api):
