@@ -109,7 +109,7 @@ int pf_launch_r2c(int field_bytes, int n, const PfR2CParams &p, hipStream_t st);
 
 // ---- grid sizes that are not a power of two (pf_mixed_kernels.hip): the same three passes with a run-time stage plan ----
 #define PF_MIXED_MAX_STAGES 12
-struct PfMixedPlan { int n, nstages; int radix[PF_MIXED_MAX_STAGES]; };
+struct PfMixedPlan { int n, nstages; int radix[PF_MIXED_MAX_STAGES]; unsigned magic[PF_MIXED_MAX_STAGES]; };
 bool pf_mixed_plan(int n, bool allow4, PfMixedPlan *pl);
 bool pf_mixed_supported(int n);   // n = 8 m with m = 2^a 3^b 5^c, up to 2048: strided passes on n, z-passes on n / 2
 int pf_launch_mixed_strided(int field_bytes, int n, int dir, const PfStridedParams &p, hipStream_t st);

@@ -9,7 +9,7 @@
 //                                     w = exp(+-2 pi i / (NS_s R_s)), NS_s = R_0 ... R_{s-1};  DFT_{R_s};
 //                                     outputs to (b - k) R_s + k + t NS_s, t < R_s.
 // A line has N / R0 threads; stage 0 is one butterfly per thread on the points it loaded from HBM (kept for every job on
-// the same input, as in k_strided), later stages deal their N / R_s butterflies over the same threads (ceil(R0 / R_s) each)
+// the same input), later stages deal their N / R_s butterflies over the same threads (ceil(R0 / R_s) each)
 // and exchange through LDS; the last stage stores straight to HBM.  Same semantics, same parameter blocks and the same
 // layouts as the power-of-two kernels -- filter on load, k multipliers, band limits, fp32 product rows -- so that the
 // sweep keeps its shared passes (x 1 -> 3, y 3 -> 6, z 6 -> 6) instead of one library transform per component.
@@ -59,9 +59,9 @@ template <int R, int DIR, typename F> __device__ __forceinline__ void pf_dft_sma
 // tw[j tws] = exp(+2 pi i j / n) (tws = 2: the half-length lines of the z-pass use the table of the full length).  Every thread
 // of the line must call this (barriers inside).
 template <int R, int R0, int DIR, bool LAST, typename F, typename RD, typename WR, typename SYNC, typename OUT>
-__device__ __forceinline__ void pf_mixed_stage(int n, int ns, int nt, int tl, const pfc<F> *__restrict__ tw, int tws, RD rd, WR wr, SYNC sync, OUT out) {
+__device__ __forceinline__ void pf_mixed_stage(int n, int ns, unsigned magic, int nt, int tl, const pfc<F> *__restrict__ tw, int tws, RD rd, WR wr, SYNC sync, OUT out) {
   constexpr int LOOPS = (R0 + R - 1) / R;  // butterflies per thread: ceil((n / R) / (n / R0))
-  const int nb = n / R;                    // butterflies of the stage = distance of a butterfly's inputs
+  const int nb = n / R;                    // butterflies of the stage = distance of a butterfly's inputs (uniform: scalar unit)
   const int twm = n / (ns * R);
   pfc<F> u[LOOPS][R];
 #pragma unroll
@@ -77,14 +77,14 @@ __device__ __forceinline__ void pf_mixed_stage(int n, int ns, int nt, int tl, co
   for (int i = 0; i < LOOPS; i++) {
     const int b = tl + i * nt;
     if (b < nb) {
-      const int k = b % ns;
-      if (ns > 1) {
-        int idx = 0;  // (q k twm) mod n, stepped
-        const int step = (int)(((long long)k * twm) % n);
+      const int k = b - ns * (int)__umulhi((unsigned)b, magic);  // b mod ns (magic = ceil(2^32 / ns), exact for b < 2^11)
+      {
+        const int step = k * twm * tws;  // k twm < n / R: the index q k twm stays below n, no reduction needed
+        int idx = 0;
 #pragma unroll
         for (int q = 1; q < R; q++) {
-          idx += step; if (idx >= n) idx -= n;
-          pfc<F> w = tw[idx * tws];
+          idx += step;
+          pfc<F> w = tw[idx];
           if (DIR < 0) w.y = -w.y;
           u[i][q] = pf_cmul(u[i][q], w);
         }
@@ -106,13 +106,19 @@ template <int R0, int DIR, typename F, typename RD, typename WR, typename SYNC, 
 __device__ __forceinline__ void pf_mixed_tail(const PfMixedPlan &pl, int tl, const pfc<F> *__restrict__ tw, int tws, RD rd, WR wr, SYNC sync, OUT out) {
   const int nt = pl.n / R0;
   int ns = R0;
+#pragma unroll 1
   for (int s = 1; s < pl.nstages; s++) {
     const int R = pl.radix[s];
+    const unsigned magic = pl.magic[s];
     const bool last = s + 1 == pl.nstages;
+    // (an opaque copy of the thread index per stage: left to itself the compiler hoists the index arithmetic of every radix
+    //  case out of this loop and spills what it hoisted -- the same cure as in k_strided)
+    int tls = tl;
+    asm volatile("" : "+v"(tls));
 #define PF_MIXED_CASE(RR)                                                                                              \
   case RR:                                                                                                             \
-    if (last) pf_mixed_stage<RR, R0, DIR, true>(pl.n, ns, nt, tl, tw, tws, rd, wr, sync, out);                               \
-    else pf_mixed_stage<RR, R0, DIR, false>(pl.n, ns, nt, tl, tw, tws, rd, wr, sync, out);                                   \
+    if (last) pf_mixed_stage<RR, R0, DIR, true>(pl.n, ns, magic, nt, tls, tw, tws, rd, wr, sync, out);                  \
+    else pf_mixed_stage<RR, R0, DIR, false>(pl.n, ns, magic, nt, tls, tw, tws, rd, wr, sync, out);                      \
     break;
     switch (R) {
       PF_MIXED_CASE(8)
@@ -120,8 +126,8 @@ __device__ __forceinline__ void pf_mixed_tail(const PfMixedPlan &pl, int tl, con
       PF_MIXED_CASE(4)
       PF_MIXED_CASE(3)
       default:
-        if (last) pf_mixed_stage<2, R0, DIR, true>(pl.n, ns, nt, tl, tw, tws, rd, wr, sync, out);
-        else pf_mixed_stage<2, R0, DIR, false>(pl.n, ns, nt, tl, tw, tws, rd, wr, sync, out);
+        if (last) pf_mixed_stage<2, R0, DIR, true>(pl.n, ns, magic, nt, tls, tw, tws, rd, wr, sync, out);
+        else pf_mixed_stage<2, R0, DIR, false>(pl.n, ns, magic, nt, tls, tw, tws, rd, wr, sync, out);
         break;
     }
 #undef PF_MIXED_CASE
@@ -132,82 +138,78 @@ __device__ __forceinline__ void pf_mixed_tail(const PfMixedPlan &pl, int tl, con
 // ------------------------------------------------------------------------------------------------ strided passes ----
 // x- or y-pass: a workgroup owns T adjacent columns of one line of tiles and all n points along the transformed axis
 // (n / 8 threads per column).  Parameters and semantics: PfStridedParams, as k_strided.
+// Threads: (c, tl) = (threadIdx.x, threadIdx.y), T = blockDim.x columns.  One rank: a line's element e sits at e * els (the
+// slab split of PfAddr is not needed; the launcher checks it), so an address is a 64-bit base per job plus a 32-bit offset.
+// The tile is loaded for every job (jobs on the same input find it in L2): the eight points of a thread then live only
+// through one job, which is what lets the run-time plan fit the register file.
 template <typename F, int DIR>
-__global__ void __launch_bounds__(1024) k_mixed_strided(const PfStridedParams p, const PfMixedPlan pl, const int T, const long long nwork, const int ntiles) {
+__global__ void __launch_bounds__(1024) k_mixed_strided(const PfStridedParams p, const PfMixedPlan pl, const long long nwork, const int ntiles) {
   using C = pfc<F>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   C *lds = reinterpret_cast<C *>(smem);  // [n][T]
   const long long w = pf_xcd_swizzle_mixed(blockIdx.x, (nwork + 7) >> 3);
   if (w >= nwork) return;
-  const int n = pl.n, nt = n / 8;
-  const int tid = threadIdx.x;
-  const int c = tid % T, tl = tid / T;
+  const int n = pl.n, nt = n / 8, T = blockDim.x;
+  const int c = threadIdx.x, tl = threadIdx.y;
   const int tile = (int)(w % ntiles), outer = (int)(w / ntiles);
   const int col = tile * T + c;
   const bool valid = col < p.ncols;
   const C *__restrict__ tw = reinterpret_cast<const C *>(p.tw);
   const double kf = 2.0 * 3.14159265358979323846 / (double)n;
   const int half = n / 2;
-  if (p.band_outer < half) {
-    int so = outer + p.outer_offset;
-    if (so > half) so -= n;
-    if (so > p.band_outer || so < -p.band_outer) return;  // (uniform: the whole workgroup leaves)
-  }
-  auto addr = [&](const PfAddr &a, int e) { return (long long)outer * a.os + (long long)(e >> a.el_shift) * a.ehs + (long long)(e & ((1 << a.el_shift) - 1)) * a.els + col; };
-  C src[8], v[8];
-  double ko = 0.0, woc = 1.0;
+  int so = outer + p.outer_offset;
+  if (so > half) so -= n;
+  if (p.band_outer < half && (so > p.band_outer || so < -p.band_outer)) return;  // (uniform: the whole workgroup leaves)
+  const long long base_in = (long long)outer * p.ain.os + col, base_out = (long long)outer * p.aout.os + col;
+  const unsigned els_in = (unsigned)p.ain.els, els_out = (unsigned)p.aout.els;
+  double ko2kc2 = 0.0, woc = 1.0;
   if (p.pre) {
-    int so = outer + p.outer_offset;
-    if (so > half) so -= n;
-    ko = kf * so;
-    const double kc = kf * col;
-    woc = (p.rs != 0.0 ? exp(-0.5 * (ko * ko + kc * kc) * p.rs * p.rs) : 1.0) * p.growth;
+    const double ko = kf * so, kc = kf * col;
+    ko2kc2 = ko * ko + kc * kc;
+    woc = (p.rs != 0.0 ? exp(-0.5 * ko2kc2 * p.rs * p.rs) : 1.0) * p.growth;
   }
   auto sync = [&]() { __syncthreads(); };
+#pragma unroll 1
   for (int j = 0; j < p.njobs; j++) {
-    if (j == 0 || p.job[j].in != p.job[j - 1].in) {  // jobs are grouped by input: a tile is read from HBM once
-      const C *__restrict__ in = reinterpret_cast<const C *>(p.job[j].in);
-#pragma unroll
-      for (int m = 0; m < 8; m++) {
-        const int e = tl + m * nt;
-        const int se = e > half ? e - n : e;
-        const bool inband = se <= p.band_e && se >= -p.band_e;
-        src[m] = (valid && inband) ? pf_ld_stream(in + addr(p.ain, e)) : pf_zero<F>();
-        if (p.pre) {  // exp(-k^2 rs^2 / 2) g / k^2, zero at k = 0 (src/fmax-pfft.c:366-384)
-          const double ke = kf * se;
-          const double k2 = ke * ke + ko * ko + (kf * col) * (kf * col);
-          const double we = p.rs != 0.0 ? p.etab[e] : 1.0;
-          src[m] = pf_scale(src[m], (F)((k2 != 0.0) ? we * woc / k2 : 0.0));
-        }
-      }
-    }
+    const C *__restrict__ in = reinterpret_cast<const C *>(p.job[j].in) + base_in;
     const int mul = p.job[j].mul;
+    int tlj = tl;
+    asm volatile("" : "+v"(tlj));  // (keeps the per-element index and filter arithmetic inside the job loop: hoisted, it spills)
+    C v[8];
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-      const int e = tl + m * nt;
-      const F ke = (F)(kf * (e > half ? e - n : e));
-      C x = src[m];
-      if (mul == PF_MUL_K) x = pf_scale(x, ke);
-      else if (mul == PF_MUL_K2) x = pf_scale(x, ke * ke);
-      else if (mul == PF_MUL_IK) x = pf_mul_i<+1>(pf_scale(x, ke));
+      const int e = tlj + m * nt;
+      const int se = e > half ? e - n : e;
+      const bool inband = se <= p.band_e && se >= -p.band_e;
+      C x = (valid && inband) ? pf_ld_stream(in + (size_t)((unsigned)e * els_in)) : pf_zero<F>();
+      const double ke = kf * se;
+      if (p.pre) {  // exp(-k^2 rs^2 / 2) g / k^2, zero at k = 0 (src/fmax-pfft.c:366-384)
+        const double k2 = ke * ke + ko2kc2;
+        const double we = p.rs != 0.0 ? p.etab[e] : 1.0;
+        x = pf_scale(x, (F)((k2 != 0.0) ? we * woc / k2 : 0.0));
+      }
+      const F kef = (F)ke;
+      if (mul == PF_MUL_K) x = pf_scale(x, kef);
+      else if (mul == PF_MUL_K2) x = pf_scale(x, kef * kef);
+      else if (mul == PF_MUL_IK) x = pf_mul_i<+1>(pf_scale(x, kef));
       v[m] = x;
     }
-    C *__restrict__ outp = reinterpret_cast<C *>(p.job[j].out);
+    C *__restrict__ outp = reinterpret_cast<C *>(p.job[j].out) + base_out;
     auto store = [&](int e, C val) {
       if (!valid) return;
       if (p.out_ne > 0 && (unsigned)(e - p.out_e0) >= (unsigned)p.out_ne) return;
-      pf_st_stream(outp + addr(p.aout, e), val);
+      pf_st_stream(outp + (size_t)((unsigned)e * els_out), val);
     };
     pf_bfly8<DIR>(v);  // stage 0: the thread's own eight points (NS = 1: no twiddles)
     if (pl.nstages == 1) {
 #pragma unroll
-      for (int t = 0; t < 8; t++) store(tl + t * nt, v[t]);  // n = 8: (b - k) R + k + t NS with b = k = 0
+      for (int t = 0; t < 8; t++) store(tlj + t * nt, v[t]);  // n = 8: (b - k) R + k + t NS with b = k = 0
     } else {
 #pragma unroll
-      for (int t = 0; t < 8; t++) lds[(tl * 8 + t) * T + c] = v[t];  // outputs of butterfly b = tl: b R + t
+      for (int t = 0; t < 8; t++) lds[(tlj * 8 + t) * T + c] = v[t];  // outputs of butterfly b = tl: b R + t
       __syncthreads();
       pf_mixed_tail<8, DIR, F>(
-          pl, tl, tw, 1, [&](int pos) { return lds[pos * T + c]; }, [&](int pos, C val) { lds[pos * T + c] = val; }, sync, store);
+          pl, tlj, tw, 1, [&](int pos) { return lds[pos * T + c]; }, [&](int pos, C val) { lds[pos * T + c] = val; }, sync, store);
       __syncthreads();  // the next job rewrites the exchange area
     }
   }
@@ -217,26 +219,22 @@ __global__ void __launch_bounds__(1024) k_mixed_strided(const PfStridedParams p,
 // c2r rows: Hermitian rows of n/2+1 -> n reals through the half-length complex transform (pf_c2r_pre), kz factor, 1/N^3 and
 // the DC constant as k_c2r.  TL rows per workgroup, M / R0 threads per row (M = n / 2, R0 = 8 or 4).
 template <typename F, int R0>
-__global__ void __launch_bounds__(1024) k_mixed_c2r(const PfC2RParams p, const PfMixedPlan pl, const int TL) {
+__global__ void __launch_bounds__(256) k_mixed_c2r(const PfC2RParams p, const PfMixedPlan pl) {
   using C = pfc<F>;
-  const int M = pl.n, n = 2 * M, nt = M / R0;
+  const int M = pl.n, n = 2 * M, nt = M / R0, TL = blockDim.y;
   const int LPL = M + 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   C *lds = reinterpret_cast<C *>(smem);
-  const int tid = threadIdx.x, nthr = TL * nt;
-  const int l = tid / nt, tl = tid % nt;
+  const int tl = threadIdx.x, l = threadIdx.y;  // (thread of the row, row of the tile)
   const int job = blockIdx.x % p.njobs;
-  const long long line0 = (long long)(blockIdx.x / p.njobs) * TL;
-  const C *__restrict__ in = reinterpret_cast<const C *>(p.job[job].in);
+  const long long row = (long long)(blockIdx.x / p.njobs) * TL + l;
+  const bool rvalid = row < p.nlines;
+  const C *__restrict__ in = reinterpret_cast<const C *>(p.job[job].in) + (rvalid ? row : 0) * p.in_pitch;
   const int mul = p.job[job].mul;
   const C *__restrict__ tw = reinterpret_cast<const C *>(p.tw);   // exp(+2 pi i j / n), n entries
-  for (int idx = tid; idx < TL * (M + 1); idx += nthr) {
-    const int ll = idx / (M + 1), k = idx % (M + 1);
-    const long long row = line0 + ll;
-    lds[ll * LPL + k] = (row < p.nlines && k <= p.band_k) ? in[row * p.in_pitch + k] : pf_mk<F>(0, 0);
-  }
-  __syncthreads();
   C *L = lds + l * LPL;
+  for (int k = tl; k <= M; k += nt) L[k] = (rvalid && k <= p.band_k) ? pf_ld_stream(in + k) : pf_mk<F>(0, 0);  // the row's own threads stage it
+  __syncthreads();
   const F kf = (F)(2.0 * 3.14159265358979323846 / (double)n);
   C v[R0];
 #pragma unroll
@@ -245,15 +243,16 @@ __global__ void __launch_bounds__(1024) k_mixed_c2r(const PfC2RParams p, const P
     v[m] = pf_zfold<F>(L[e], L[M - e], e, M, mul, kf, tw[e]);
   }
   __syncthreads();
-  const long long row = line0 + l;
   const F norm = (F)p.norm;
   const F dcv = p.dc ? (F)(*p.dc) : (F)0;
   const int of32 = p.job[job].out_f32;
+  float2 *__restrict__ o32 = reinterpret_cast<float2 *>(reinterpret_cast<float *>(p.job[job].out) + row * (long long)n);
+  C *__restrict__ o64 = reinterpret_cast<C *>(reinterpret_cast<F *>(p.job[job].out) + row * (of32 == 2 ? (long long)n : p.out_pitch));
   auto store = [&](int pos, C val) {  // complex j of the half-length line = reals 2 j, 2 j + 1 of the row
-    if (row >= p.nlines) return;
+    if (!rvalid) return;
     const F a = pf_norm_dc(val.x, norm, dcv), b = pf_norm_dc(val.y, norm, dcv);
-    if (of32 == 1) reinterpret_cast<float2 *>(reinterpret_cast<float *>(p.job[job].out) + row * (long long)n)[pos] = make_float2((float)a, (float)b);
-    else reinterpret_cast<C *>(reinterpret_cast<F *>(p.job[job].out) + row * (of32 == 2 ? (long long)n : p.out_pitch))[pos] = pf_mk<F>(a, b);
+    if (of32 == 1) o32[pos] = make_float2((float)a, (float)b);
+    else pf_st_stream(o64 + pos, pf_mk<F>(a, b));
   };
   auto sync = [&]() { __syncthreads(); };
   pf_dft_small<R0, +1>(v);
@@ -271,16 +270,14 @@ __global__ void __launch_bounds__(1024) k_mixed_c2r(const PfC2RParams p, const P
 
 // r2c rows (forward z-pass of the LPT sources), in place like k_r2c: real row -> n/2+1 complex
 template <typename F, int R0>
-__global__ void __launch_bounds__(1024) k_mixed_r2c(const PfR2CParams p, const PfMixedPlan pl, const int TL) {
+__global__ void __launch_bounds__(256) k_mixed_r2c(const PfR2CParams p, const PfMixedPlan pl) {
   using C = pfc<F>;
-  const int M = pl.n, nt = M / R0;
+  const int M = pl.n, nt = M / R0, TL = blockDim.y;
   const int LPL = M + 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   C *lds = reinterpret_cast<C *>(smem);
-  const int tid = threadIdx.x, nthr = TL * nt;
-  const int l = tid / nt, tl = tid % nt;
-  const long long line0 = (long long)blockIdx.x * TL;
-  const long long row = line0 + l;
+  const int tl = threadIdx.x, l = threadIdx.y;
+  const long long row = (long long)blockIdx.x * TL + l;
   const bool valid = row < p.nlines;
   const C *__restrict__ tw = reinterpret_cast<const C *>(p.tw);
   C *L = lds + l * LPL;
@@ -288,7 +285,7 @@ __global__ void __launch_bounds__(1024) k_mixed_r2c(const PfR2CParams p, const P
   {
     const C *in = reinterpret_cast<const C *>(reinterpret_cast<const F *>(p.in) + row * p.in_pitch);
 #pragma unroll
-    for (int m = 0; m < R0; m++) v[m] = valid ? in[tl + m * nt] : pf_mk<F>(0, 0);
+    for (int m = 0; m < R0; m++) v[m] = valid ? pf_ld_stream(in + tl + m * nt) : pf_mk<F>(0, 0);
   }
   auto sync = [&]() { __syncthreads(); };
   auto keep = [&](int pos, C val) { L[pos] = val; };  // the last stage leaves Z in LDS: the post-processing reads Z[k] and Z[M - k]
@@ -305,15 +302,12 @@ __global__ void __launch_bounds__(1024) k_mixed_r2c(const PfR2CParams p, const P
         pl, tl, tw, 2, [&](int pos) { return L[pos]; }, keep, sync, keep);
   }
   __syncthreads();
-  // every thread of the tile helps with every row of the tile (rows of the same tile: all loads happened above)
-  for (int idx = tid; idx < TL * (M + 1); idx += nthr) {
-    const int ll = idx / (M + 1), k = idx % (M + 1);
-    const long long r = line0 + ll;
-    if (r >= p.nlines) continue;
-    const C *Z = lds + ll * LPL;
-    C *out = reinterpret_cast<C *>(p.out) + r * p.out_pitch;
-    if (k == M) out[M] = pf_mk<F>(Z[0].x - Z[0].y, (F)0);
-    else out[k] = pf_r2c_post<F>(Z[k], Z[k == 0 ? 0 : M - k], tw[k]);
+  if (valid) {  // the row's own threads write it back: X[k] from Z[k] and Z[M - k]
+    C *out = reinterpret_cast<C *>(p.out) + row * p.out_pitch;
+    for (int k = tl; k <= M; k += nt) {
+      if (k == M) out[M] = pf_mk<F>(L[0].x - L[0].y, (F)0);
+      else pf_st_stream(out + k, pf_r2c_post<F>(L[k], L[k == 0 ? 0 : M - k], tw[k]));
+    }
   }
 }
 
@@ -335,6 +329,11 @@ bool pf_mixed_plan(int n, bool allow4, PfMixedPlan *pl) {
   if (rest != 1) return false;
   if (r0 == 4) for (int s = 1; s < ns; s++) if (pl->radix[s] == 8) return false;  // (cannot happen: n / 4 odd multiple... kept as a guard)
   pl->nstages = ns;
+  unsigned long long nsv = 1;
+  for (int s = 0; s < ns; s++) {  // ceil(2^32 / NS_s): b mod NS_s by one multiply-high (pf_mixed_stage); stage 0 needs none
+    pl->magic[s] = s == 0 ? 0u : (unsigned)(((1ull << 32) + nsv - 1) / nsv);
+    nsv *= (unsigned long long)pl->radix[s];
+  }
   return true;
 }
 bool pf_mixed_supported(int n) {
@@ -356,32 +355,35 @@ int pf_launch_mixed_strided(int fb, int n, int dir, const PfStridedParams &p, hi
   if (nt * T > 1024 || (size_t)n * T * w > 160 * 1024) return 2;
   const int ntiles = (p.ncols + T - 1) / T;
   const long long nwork = (long long)ntiles * p.nouter;
-  const dim3 grid((unsigned)(((nwork + 7) >> 3) << 3)), block(T * nt);
+  // one rank: the slab split of PfAddr is the identity (e >> el_shift == 0 for every e < n)
+  if ((1 << p.ain.el_shift) < n || (1 << p.aout.el_shift) < n) return 2;
+  if ((unsigned long long)(n - 1) * (unsigned long long)p.ain.els >= (1ull << 32) || (unsigned long long)(n - 1) * (unsigned long long)p.aout.els >= (1ull << 32)) return 2;
+  const dim3 grid((unsigned)(((nwork + 7) >> 3) << 3)), block(T, nt);
   const size_t shm = (size_t)n * T * w;
 #define PF_MIXED_LAUNCH(FF, DD)                                                                                      \
   do {                                                                                                               \
     if (pf_mixed_raise_lds<FF>(reinterpret_cast<const void *>(&k_mixed_strided<FF, DD>), shm)) return 3;             \
-    hipLaunchKernelGGL((k_mixed_strided<FF, DD>), grid, block, shm, st, p, pl, T, nwork, ntiles);                    \
+    hipLaunchKernelGGL((k_mixed_strided<FF, DD>), grid, block, shm, st, p, pl, nwork, ntiles);                    \
   } while (0)
   if (fb == 8) { if (dir > 0) PF_MIXED_LAUNCH(double, +1); else PF_MIXED_LAUNCH(double, -1); }
   else { if (dir > 0) PF_MIXED_LAUNCH(float, +1); else PF_MIXED_LAUNCH(float, -1); }
 #undef PF_MIXED_LAUNCH
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
-static int pf_mixed_rows_per_wg(int nt) { int tl = 256 / nt; return tl < 1 ? 1 : tl; }
+static int pf_mixed_rows_per_wg(int nt) { int tl = 256 / nt; return tl < 1 ? 1 : tl; }  // (z-pass workgroups: at most 256 threads)
 int pf_launch_mixed_c2r(int fb, int n, const PfC2RParams &p, hipStream_t st) {
   PfMixedPlan pl;
   const int M = n / 2;
   if (!pf_mixed_plan(M, true, &pl)) return 2;
   const int r0 = pl.radix[0], nt = M / r0, TL = pf_mixed_rows_per_wg(nt);
-  if (TL * nt > 1024) return 2;
+  if (TL * nt > 256) return 2;
   const long long nblk = (p.nlines + TL - 1) / TL;
-  const dim3 grid((unsigned)(nblk * p.njobs)), block(TL * nt);
+  const dim3 grid((unsigned)(nblk * p.njobs)), block(nt, TL);
   const size_t shm = (size_t)TL * (M + 1) * (fb == 8 ? 16 : 8);
 #define PF_MIXED_LAUNCH(FF, RR)                                                                                      \
   do {                                                                                                               \
     if (pf_mixed_raise_lds<FF>(reinterpret_cast<const void *>(&k_mixed_c2r<FF, RR>), shm)) return 3;                 \
-    hipLaunchKernelGGL((k_mixed_c2r<FF, RR>), grid, block, shm, st, p, pl, TL);                                      \
+    hipLaunchKernelGGL((k_mixed_c2r<FF, RR>), grid, block, shm, st, p, pl);                                      \
   } while (0)
   if (fb == 8) { if (r0 == 8) PF_MIXED_LAUNCH(double, 8); else PF_MIXED_LAUNCH(double, 4); }
   else { if (r0 == 8) PF_MIXED_LAUNCH(float, 8); else PF_MIXED_LAUNCH(float, 4); }
@@ -393,14 +395,14 @@ int pf_launch_mixed_r2c(int fb, int n, const PfR2CParams &p, hipStream_t st) {
   const int M = n / 2;
   if (!pf_mixed_plan(M, true, &pl)) return 2;
   const int r0 = pl.radix[0], nt = M / r0, TL = pf_mixed_rows_per_wg(nt);
-  if (TL * nt > 1024) return 2;
+  if (TL * nt > 256) return 2;
   const long long nblk = (p.nlines + TL - 1) / TL;
-  const dim3 grid((unsigned)nblk), block(TL * nt);
+  const dim3 grid((unsigned)nblk), block(nt, TL);
   const size_t shm = (size_t)TL * (M + 1) * (fb == 8 ? 16 : 8);
 #define PF_MIXED_LAUNCH(FF, RR)                                                                                      \
   do {                                                                                                               \
     if (pf_mixed_raise_lds<FF>(reinterpret_cast<const void *>(&k_mixed_r2c<FF, RR>), shm)) return 3;                 \
-    hipLaunchKernelGGL((k_mixed_r2c<FF, RR>), grid, block, shm, st, p, pl, TL);                          \
+    hipLaunchKernelGGL((k_mixed_r2c<FF, RR>), grid, block, shm, st, p, pl);                          \
   } while (0)
   if (fb == 8) { if (r0 == 8) PF_MIXED_LAUNCH(double, 8); else PF_MIXED_LAUNCH(double, 4); }
   else { if (r0 == 8) PF_MIXED_LAUNCH(float, 8); else PF_MIXED_LAUNCH(float, 4); }
