@@ -110,6 +110,21 @@ def cpu_baseline(n: int, ns: int, lpt: bool, budget_s: float = 60.0) -> dict:
     import oracle_lib
     from pinocchio_amd import synth
     cores = os.cpu_count() or 1
+    # what the job may actually use: the CPU-time quota of its control group (cpu.max = "<quota> <period>": on the boxes of this
+    # pool 16 of the host's 256 hardware threads -- more threads than that only get throttled, which is why the oracle "stopped
+    # scaling" at 16 in rounds 2 and 3) and the CPU set it may run on
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(float(q) / float(per)))
+    except (OSError, ValueError):
+        pass
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    usable = min(cores, quota) if quota else cores
     x, y = synth.invgrow_table("lcdm")
     full = synth.radii_ladder(ns)
 
@@ -129,7 +144,7 @@ def cpu_baseline(n: int, ns: int, lpt: bool, budget_s: float = 60.0) -> dict:
     two = np.array([full[len(full) // 2], full[-1]])
     ncal = min(256, n)
     cal = {}
-    for t in (16, 32, 64, 128):
+    for t in sorted({usable, max(1, usable // 2)} if quota else {16, 32, 64, 128}):
         if t <= cores:
             cal[t] = run(ncal, t, two)
     threads = min(cal, key=lambda t: cal[t][0]) if cal else max(1, cores)
@@ -148,13 +163,16 @@ def cpu_baseline(n: int, ns: int, lpt: bool, budget_s: float = 60.0) -> dict:
     t_lpt = tm["lpt"] if lpt else 0.0
     t_full = (dt - t_lpt) * ns / len(radii) + t_lpt if scaled else dt
     return {"value": n ** 3 / t_full, "unit": "grid-cells/s", "cores": threads, "kind": "port",
+            "host": {"hardware_threads": os.cpu_count(), "cgroup_cpu_quota_cores": quota, "usable": usable,
+                     "note": "the job's control group caps its CPU time (cpu.max); `cores` = the threads used, all the job may have"},
             "calibration": {str(t): round(v[0], 3) for t, v in cal.items()},
             "sample": f"{n}^3 box, " + (f"{len(radii)} of the {ns} radii" if scaled else f"all {ns} radii") +
                       f"{' + the whole 3LPT part' if lpt else ''} timed in {dt:.2f} s on {threads} OpenMP threads "
                       f"(fft {tm['fft']:.2f} s, collapse {tm['coll']:.2f} s, lpt {t_lpt:.2f} s)" +
                       (f", sweep time scaled by {ns}/{len(radii)} -> {t_full:.1f} s for the full job" if scaled else ", nothing scaled") +
                       f"; same synthetic spectrum; thread count picked by a {ncal}^3 calibration over {sorted(cal)} threads "
-                      f"(seconds: {', '.join(f'{t}: {v[0]:.2f}' for t, v in sorted(cal.items()))}); host has {cores} hardware threads, shared with other jobs"}
+                      f"(seconds: {', '.join(f'{t}: {v[0]:.2f}' for t, v in sorted(cal.items()))}); host has {os.cpu_count()} hardware threads, of which the job's "
+                      f"control group allows {quota if quota else 'all'}"}
 
 
 def parse_args(argv=None):
@@ -511,6 +529,7 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")   # RCCL's own account of a failure goes to stderr (a first multi-GPU lease must not be lost to a silent one)
         # one process per GPU: LOCAL_RANK names the device, unless the launcher already narrowed the visible devices to one
         ndev = torch.cuda.device_count()
         if ndev < 1:
@@ -544,6 +563,13 @@ def main():
             os.environ.pop("PF_REPLICATE_DK", None)
     except (RuntimeError, api.PinfmaxError) as e:
         print(f"[rank {rank}] {e}", file=sys.stderr, flush=True)
+        print(f"[rank {rank}] exchange negotiation so far: {json.dumps(votes)}", file=sys.stderr, flush=True)
+        try:
+            b = C.c_int(0)
+            print(f"[rank {rank}] RCCL bound at run time: {_lib.load().pf_rccl_version(C.byref(b))}, built against {b.value}; "
+                  f"library error: {_lib.load().pf_last_error().decode(errors='replace')}", file=sys.stderr, flush=True)
+        except Exception:
+            pass
         if world > 1:
             dist.destroy_process_group()
         raise SystemExit(3)

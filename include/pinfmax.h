@@ -96,8 +96,12 @@ int pf_set_exchange_rows(pf_ctx *ctx, pf_alltoallv_fn fn, void *user);
 int pf_rccl_available(void);                        /* 1 when librccl can be bound in this process (host side only: no
                                                        communicator, no collective -- what the ranks vote on before any of them
                                                        enters ncclCommInitRank) */
+#define PF_RCCL_ID_BYTES 128                         /* sizeof(ncclUniqueId); checked at build time against rccl.h */
 int pf_rccl_unique_id(void *id128);                 /* rank 0: ncclGetUniqueId */
 int pf_init_rccl(pf_ctx *ctx, const void *id128);   /* all ranks: ncclCommInitRank; the context owns the communicator */
+/* version code of the RCCL bound at run time (0: none bound); *build_code: NCCL_VERSION_CODE of the header the library was built
+   against.  Binding refuses a run-time library of another major version (types and enumerators come from that header). */
+int pf_rccl_version(int *build_code);
 int pf_release_rccl(pf_ctx *ctx);                   /* ncclCommDestroy + callbacks cleared (also done by pf_destroy) */
 int pf_rccl_comm_count(pf_ctx *ctx);                /* ncclCommCount of the built-in exchange's communicator: the number of ranks
                                                        RCCL itself sees (the MPI_Comm_size of FFT_Comm, src/initialization.c:1317);

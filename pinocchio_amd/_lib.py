@@ -63,6 +63,7 @@ PROTOTYPES = {
     "pf_release_rccl": (C.c_int, [_vp]),
     "pf_rccl_comm_count": (C.c_int, [_vp]),
     "pf_rccl_unique_id": (C.c_int, [_vp]),
+    "pf_rccl_version": (C.c_int, [C.POINTER(C.c_int)]),
     "pf_init_rccl": (C.c_int, [_vp, _vp]),
     "pf_set_allreduce": (C.c_int, [_vp, ALLREDUCE_FN, _vp]),
     "pf_fabric_create": (_vp, [C.c_int]),

@@ -8,16 +8,19 @@
 
 #include "pf_internal.h"
 
-typedef struct hipfftHandle_t *hipfftHandle;
-enum { HIPFFT_D2Z_ = 0x6a, HIPFFT_Z2D_ = 0x6c };
+// types, transform codes and prototypes from the hipFFT header of the build (never copied by hand); the library bound at run
+// time must report the same major version
+#include <hipfft/hipfft.h>
+#include <hipfft/hipfft-version.h>
 
 static struct {
   void *h;
-  int (*Plan3d)(hipfftHandle *, int, int, int, int);
-  int (*SetStream)(hipfftHandle, hipStream_t);
-  int (*ExecZ2D)(hipfftHandle, void *, double *);
-  int (*ExecD2Z)(hipfftHandle, double *, void *);
-  int (*Destroy)(hipfftHandle);
+  decltype(&hipfftGetVersion) GetVersion;
+  decltype(&hipfftPlan3d) Plan3d;
+  decltype(&hipfftSetStream) SetStream;
+  decltype(&hipfftExecZ2D) ExecZ2D;
+  decltype(&hipfftExecD2Z) ExecD2Z;
+  decltype(&hipfftDestroy) Destroy;
 } g_fft = {};
 
 static int load_hipfft() {
@@ -30,8 +33,15 @@ static int load_hipfft() {
   }
   if (!h) { printf("ERROR on task 0: cannot load libhipfft (%s)\n", dlerror()); return 1; }
 #define SYM(field, name) *(void **)(&g_fft.field) = dlsym(h, name); if (!g_fft.field) { printf("ERROR on task 0: missing %s in libhipfft\n", name); return 1; }
+  SYM(GetVersion, "hipfftGetVersion")
   SYM(Plan3d, "hipfftPlan3d") SYM(SetStream, "hipfftSetStream") SYM(ExecZ2D, "hipfftExecZ2D") SYM(ExecD2Z, "hipfftExecD2Z") SYM(Destroy, "hipfftDestroy")
 #undef SYM
+  int v = 0;
+  if (g_fft.GetVersion(&v) != HIPFFT_SUCCESS || (v / 10000 != hipfftVersionMajor && v / 1000 != hipfftVersionMajor)) {  // (major * 10000 + minor * 100 + patch)
+    printf("ERROR on task 0: libhipfft at run time reports version %d, libpinfmax_hip was built against major %d: refusing to bind it\n", v, hipfftVersionMajor);
+    g_fft = {};
+    return 1;
+  }
   g_fft.h = h;
   return 0;
 }
@@ -39,11 +49,11 @@ static int load_hipfft() {
 int pf_gfft_create(int n, hipStream_t st, void **c2r, void **r2c) {
   if (load_hipfft()) return 1;
   hipfftHandle a = nullptr, b = nullptr;
-  if (g_fft.Plan3d(&a, n, n, n, HIPFFT_Z2D_) || g_fft.Plan3d(&b, n, n, n, HIPFFT_D2Z_)) return 2;
-  if (g_fft.SetStream(a, st) || g_fft.SetStream(b, st)) return 3;
+  if (g_fft.Plan3d(&a, n, n, n, HIPFFT_Z2D) != HIPFFT_SUCCESS || g_fft.Plan3d(&b, n, n, n, HIPFFT_D2Z) != HIPFFT_SUCCESS) return 2;
+  if (g_fft.SetStream(a, st) != HIPFFT_SUCCESS || g_fft.SetStream(b, st) != HIPFFT_SUCCESS) return 3;
   *c2r = a; *r2c = b;
   return 0;
 }
-int pf_gfft_c2r(void *plan, void *spec, void *real) { return g_fft.ExecZ2D((hipfftHandle)plan, spec, (double *)real); }
-int pf_gfft_r2c(void *plan, void *real, void *spec) { return g_fft.ExecD2Z((hipfftHandle)plan, (double *)real, spec); }
+int pf_gfft_c2r(void *plan, void *spec, void *real) { return g_fft.ExecZ2D((hipfftHandle)plan, (hipfftDoubleComplex *)spec, (double *)real) != HIPFFT_SUCCESS; }
+int pf_gfft_r2c(void *plan, void *real, void *spec) { return g_fft.ExecD2Z((hipfftHandle)plan, (double *)real, (hipfftDoubleComplex *)spec) != HIPFFT_SUCCESS; }
 void pf_gfft_destroy(void *plan) { if (plan && g_fft.Destroy) g_fft.Destroy((hipfftHandle)plan); }

@@ -14,21 +14,27 @@
 
 #include "../../include/pinfmax.h"
 
-typedef void *ncclComm_t;
-typedef struct { char internal[128]; } ncclUniqueId;
-enum { ncclChar_ = 0, ncclUint64_ = 5, ncclDouble_ = 8, ncclSum_ = 0 };
+// Types, enumerators and prototypes come from the RCCL header this library is BUILT against (/opt/rocm/include/rccl/rccl.h:
+// ncclUniqueId, ncclChar / ncclUint64 / ncclDouble, ncclSum ...), never from values copied by hand; the library bound at run time
+// must then be of the same major version (ncclGetVersion against NCCL_MAJOR, checked in load_rccl): a drift of the ABI is refused
+// with a message instead of passing a wrong enumerator to a collective.
+#include <rccl/rccl.h>
+static_assert(sizeof(ncclUniqueId) == PF_RCCL_ID_BYTES, "pf_rccl_unique_id / pf_init_rccl pass the id as PF_RCCL_ID_BYTES bytes");
 
 struct RcclApi {
   void *h;
-  int (*GetUniqueId)(ncclUniqueId *);
-  int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
-  int (*CommDestroy)(ncclComm_t);
-  int (*CommCount)(const ncclComm_t, int *);
-  int (*Send)(const void *, size_t, int, int, ncclComm_t, void *);
-  int (*Recv)(void *, size_t, int, int, ncclComm_t, void *);
-  int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, void *);
-  int (*GroupStart)();
-  int (*GroupEnd)();
+  int version;
+  decltype(&ncclGetVersion) GetVersion;
+  decltype(&ncclGetErrorString) GetErrorString;
+  decltype(&ncclGetUniqueId) GetUniqueId;
+  decltype(&ncclCommInitRank) CommInitRank;
+  decltype(&ncclCommDestroy) CommDestroy;
+  decltype(&ncclCommCount) CommCount;
+  decltype(&ncclSend) Send;
+  decltype(&ncclRecv) Recv;
+  decltype(&ncclAllReduce) AllReduce;
+  decltype(&ncclGroupStart) GroupStart;
+  decltype(&ncclGroupEnd) GroupEnd;
 };
 static RcclApi g_api = {};
 
@@ -46,11 +52,27 @@ static int load_rccl() {
   }
   if (!h) { printf("ERROR on task 0: cannot load librccl (%s)\n", dlerror()); return 1; }
 #define SYM(field, name) *(void **)(&g_api.field) = dlsym(h, name); if (!g_api.field) { printf("ERROR on task 0: missing %s in librccl\n", name); return 1; }
+  SYM(GetVersion, "ncclGetVersion") SYM(GetErrorString, "ncclGetErrorString")
   SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy") SYM(CommCount, "ncclCommCount")
   SYM(Send, "ncclSend") SYM(Recv, "ncclRecv") SYM(AllReduce, "ncclAllReduce") SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd")
 #undef SYM
+  // the library at run time against the header at build time: same major version, or nothing is bound
+  int v = 0;
+  if (g_api.GetVersion(&v) != ncclSuccess) { printf("ERROR on task 0: ncclGetVersion failed\n"); return 1; }
+  const int major = v >= 10000 ? v / 10000 : v / 1000;  // (NCCL_VERSION_CODE: X * 10000 + Y * 100 + Z since 2.9)
+  if (major != NCCL_MAJOR) {
+    printf("ERROR on task 0: librccl at run time is version %d, libpinfmax_hip was built against %d.%d.x: refusing to bind it\n", v, NCCL_MAJOR, NCCL_MINOR);
+    memset(&g_api, 0, sizeof(g_api));
+    return 1;
+  }
+  g_api.version = v;
   g_api.h = h;
   return 0;
+}
+// run-time / build-time versions of RCCL (0 / the header's code when nothing is bound)
+extern "C" int pf_rccl_version(int *build_code) {
+  if (build_code) *build_code = NCCL_VERSION_CODE;
+  return g_api.h ? g_api.version : 0;
 }
 
 struct RcclLink { ncclComm_t comm; int rank, nranks; };
@@ -62,8 +84,8 @@ static int rccl_alltoall(void *user, const void *send, void *recv, size_t bytes,
   if (g_api.GroupStart()) return 1;
   int bad = 0;
   for (int q = 0; q < l->nranks && !bad; q++) {
-    bad |= g_api.Send((const char *)send + (size_t)q * bytes, bytes, ncclChar_, q, l->comm, stream) != 0;
-    if (!bad) bad |= g_api.Recv((char *)recv + (size_t)q * bytes, bytes, ncclChar_, q, l->comm, stream) != 0;
+    bad |= g_api.Send((const char *)send + (size_t)q * bytes, bytes, ncclChar, q, l->comm, (hipStream_t)stream) != ncclSuccess;
+    if (!bad) bad |= g_api.Recv((char *)recv + (size_t)q * bytes, bytes, ncclChar, q, l->comm, (hipStream_t)stream) != ncclSuccess;
   }
   return (g_api.GroupEnd() != 0) | bad;
 }
@@ -74,14 +96,14 @@ static int rccl_alltoallv(void *user, const void *send, void *recv, size_t block
   if (g_api.GroupStart()) return 1;
   int bad = 0;
   for (int q = 0; q < l->nranks && !bad; q++) {
-    if (send_bytes) bad |= g_api.Send((const char *)send + (size_t)q * block_bytes + send_off, send_bytes, ncclChar_, q, l->comm, stream) != 0;
-    if (!bad && recv_bytes[q]) bad |= g_api.Recv((char *)recv + (size_t)q * block_bytes + recv_off[q], recv_bytes[q], ncclChar_, q, l->comm, stream) != 0;
+    if (send_bytes) bad |= g_api.Send((const char *)send + (size_t)q * block_bytes + send_off, send_bytes, ncclChar, q, l->comm, (hipStream_t)stream) != ncclSuccess;
+    if (!bad && recv_bytes[q]) bad |= g_api.Recv((char *)recv + (size_t)q * block_bytes + recv_off[q], recv_bytes[q], ncclChar, q, l->comm, (hipStream_t)stream) != ncclSuccess;
   }
   return (g_api.GroupEnd() != 0) | bad;
 }
 static int rccl_allreduce(void *user, void *buf, size_t count, int is_u64, void *stream) {
   RcclLink *l = (RcclLink *)user;
-  return g_api.AllReduce(buf, buf, count, is_u64 ? ncclUint64_ : ncclDouble_, ncclSum_, l->comm, stream) ? 1 : 0;
+  return g_api.AllReduce(buf, buf, count, is_u64 ? ncclUint64 : ncclDouble, ncclSum, l->comm, (hipStream_t)stream) != ncclSuccess ? 1 : 0;
 }
 
 // host-side only: can this process bind RCCL at all?  No collective, no communicator -- safe to call before the ranks
@@ -121,8 +143,9 @@ extern "C" int pf_init_rccl(pf_ctx *ctx, const void *id128) {
   if (pf_ctx_rank_size(ctx, &l->rank, &l->nranks)) { delete l; return 1; }
   ncclUniqueId id;
   memcpy(&id, id128, sizeof(id));
-  if (g_api.CommInitRank(&l->comm, l->nranks, id, l->rank)) {
-    printf("ERROR on task %d: ncclCommInitRank failed\n", l->rank);
+  const ncclResult_t rc = g_api.CommInitRank(&l->comm, l->nranks, id, l->rank);
+  if (rc != ncclSuccess) {
+    printf("ERROR on task %d: ncclCommInitRank failed: %s (NCCL_DEBUG=WARN shows RCCL's own account)\n", l->rank, g_api.GetErrorString(rc));
     delete l;
     return 1;
   }
