@@ -51,7 +51,7 @@ import numpy as np  # noqa: E402
 # (launch_ranks) must neither load the HIP library nor touch the GPU.
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-PROFILE_ROUND = os.environ.get("PROFILE_ROUND", "r03")  # which profiles/<round>_pmc_*.json the counters come from
+PROFILE_ROUND = os.environ.get("PROFILE_ROUND", "r04")  # which profiles/<round>_pmc_*.json the counters come from
 
 
 def alg_bytes_per_cell(ns: int, w: int, lpt: bool) -> float:
@@ -70,10 +70,21 @@ def symbol_of(cls: str, n: int, fb: int, fast: bool = True) -> str:
     nt = n // 16
     tl = 1 if nt >= 256 else 256 // nt
     b = "true" if fast else "false"
+    if n & (n - 1):   # not a power of two: the run-time stage plans of csrc/pf_mixed_kernels.hip
+        r0 = 8 if (n // 2) % 8 == 0 else 4
+        if cls in ("xpass_hess_1to3", "ypass_hess_3to6", "xpass_disp_1to2", "ypass_disp_2to3", "xpass_plain", "ypass_plain"):
+            return f"k_mixed_strided<{F}, 1>"
+        if cls in ("xpass_fwd", "ypass_fwd"):
+            return f"k_mixed_strided<{F}, -1>"
+        if cls in ("zpass_c2r_hess_6", "zpass_c2r_disp_3", "zpass_c2r_plain"):
+            return f"k_mixed_c2r<{F}, {r0}>"
+        if cls == "zpass_r2c":
+            return f"k_mixed_r2c<{F}, {r0}>"
+    # last template argument of k_strided: addresses split into a scalar and a 32-bit lane part (one rank and up to eight: true)
     if cls in ("xpass_hess_1to3", "ypass_hess_3to6", "xpass_disp_1to2", "ypass_disp_2to3", "xpass_plain", "ypass_plain"):
-        return f"k_strided<{FS}, {n}, {t}, 1>"
+        return f"k_strided<{FS}, {n}, {t}, 1, true>"
     if cls in ("xpass_fwd", "ypass_fwd"):
-        return f"k_strided<{FS}, {n}, {t}, -1>"
+        return f"k_strided<{FS}, {n}, {t}, -1, true>"
     if cls in ("zpass_c2r_hess_6", "zpass_c2r_disp_3", "zpass_c2r_plain"):
         return f"k_c2r_persistent<{F}, {n}, {tl}>"
     return {"zpass_c2r_hess_6to3inv": f"k_c2r_invariants<{F}, {n}, 0>", "zpass_c2r_hess_6_lpt3b": f"k_c2r_invariants<{F}, {n}, 1>",

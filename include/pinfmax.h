@@ -33,9 +33,11 @@ typedef struct pf_ctx pf_ctx;
 
 /* grid_data / FFT decomposition (src/pinocchio.h:295-308, src/fmax-pfft.c:80-134) */
 typedef struct {
-  int64_t n;        /* GSglobal[_x_] = [_y_] = [_z_] : cubic grid.  Power of two in 16..2048: the hand-written transform
-                       passes (any nranks, fp64 or fp32 fields).  Any other even size in 4..4096: library (hipFFT)
-                       transforms, one rank and fp64 fields only (the reference accepts any GridSize) */
+  int64_t n;        /* GSglobal[_x_] = [_y_] = [_z_] : cubic grid (the reference accepts any GridSize: src/fmax-pfft.c:139-188).
+                       Power of two in 16..2048: the hand-written transform passes (any nranks, fp64 or fp32 fields).
+                       n = 8 m, m = 2^a 3^b 5^c, up to 2048 (24, 40, 200, 384, 768, 1000, 1536 ...): the hand-written passes on
+                       run-time stage plans, one rank, fp64 or fp32 fields.  Any other even size in 4..4096: library (hipFFT)
+                       transforms, one rank and fp64 fields only.  pf_transform_path() says which */
   int     rank;     /* ThisTask */
   int     nranks;   /* NTasks; x-slabs, nranks must divide n */
   int     device;   /* HIP device ordinal of this rank */
@@ -179,6 +181,13 @@ typedef struct {
      read_Pk_table_from_CAMB :1290-1330); host arrays, copied.  The cosmology fields are then unused. */
   int pk_n;
   const double *pk_logk, *pk_logk3p;
+  /* the other forms of PowerSpectrum() (src/cosmo.c:953-1007).  spectrum: 0 = by pk_n as above (Eisenstein & Hu or the table);
+     3 = the Efstathiou fit (FileWithInputSpectrum "Efstathiou": PowerSpec_Efstathiou :1437-1440, Gamma = SHAPE_EFST = 0.21);
+     4 = a power law k^PrimordialIndex ("PowerLaw", :1442-1445).  WDM_PartMass_in_kev > 0: every form is multiplied by the
+     warm-dark-matter cut-off Tf^2 of Bode, Ostriker & Turok (:987-1005; needs Omega0, OmegaBaryon, Hubble100);
+     UnitLength_in_cm: the reference's global of that name (0 = its default 3.085678e24, i.e. Mpc) */
+  int spectrum;
+  double WDM_PartMass_in_kev, UnitLength_in_cm;
 } pf_genic_params;
 int pf_pk_norm(const pf_genic_params *p, double sigma8, double *pknorm);
 int pf_genic_density(pf_ctx *ctx, const pf_genic_params *p);

@@ -201,8 +201,35 @@ int orc_genic_ic(int n, double box, const unsigned int *seed, double pknorm, con
 /* ... and with a tabulated spectrum (WhichSpectrum 2 and 5: FileWithInputSpectrum, CAMBTable): PowerSpec_Tabulated
    (src/cosmo.c:1432-1435) = 10^my_spline_eval(SPLINE[SP_PK], log10 k) / k^3 with the knots log10 k [1/Mpc], log10(k^3 P)
    of read_Pk_from_file / read_Pk_table_from_CAMB (:1099-1170, 1290-1330); pk_n = 0: Eisenstein & Hu */
+/* PowerSpectrum() without its PkNorm (src/cosmo.c:953-1007): WhichSpectrum 1 Eisenstein & Hu, 2 / 5 tabulated, 3 the Efstathiou fit
+   (PowerSpec_Efstathiou :1437-1440, SHAPE_EFST = 0.21 :44), 4 a power law (:1442-1445); then, for params.WDM_PartMass_in_kev > 0, the
+   warm-dark-matter cut-off Tf^2 of Bode, Ostriker & Turok (the form just after their A7, :998-1004; unit_length_cm = UnitLength_in_cm) */
+#define ORC_SHAPE_EFST ((double)0.21)
+double orc_power_spectrum_form(double k, int which, const orc_cosmo *p, int pk_n, const double *pk_logk, const double *pk_logk3p, const double *pk_c,
+                               double wdm_mass_kev, double unit_length_cm) {
+  double power, alpha, Tf;
+  switch (which) {
+    case 1: power = orc_powerspec_EH(k, p); break;
+    case 2: case 5: power = pow(10., orc_my_spline_eval(pk_logk, pk_logk3p, pk_c, pk_n, log10(k))) / k / k / k; break;
+    case 3: power = pow(k, p->PrimordialIndex) / pow(1 + pow(6.4 / ORC_SHAPE_EFST * k + pow(3.0 / ORC_SHAPE_EFST * k, 1.5) + pow(1.7 / ORC_SHAPE_EFST, 2.0) * k * k, 1.13), 2 / 1.13); break;
+    case 4: power = pow(k, p->PrimordialIndex); break;
+    default: power = 0.0; break;
+  }
+  if (wdm_mass_kev > 0.) {
+    alpha = 0.05 * pow((p->Omega0 - p->OmegaBaryon) / 0.4, 0.15) * pow(p->Hubble100 / 0.65, 1.3) * pow(1.0 / wdm_mass_kev, 1.15);
+    Tf = pow(1 + pow(alpha * k / p->Hubble100 * (3.085678e24 / unit_length_cm), 2), -5.0);
+    power *= Tf * Tf;
+  }
+  return power;
+}
+int orc_genic_form(int n, double box, const unsigned int *seed, double pknorm, const orc_cosmo *cosmo, int which, double wdm_mass_kev,
+                   double unit_length_cm, int pk_n, const double *pk_logk, const double *pk_logk3p, int FixedIC, int PairedIC, double *kdensity);
 int orc_genic_pk(int n, double box, const unsigned int *seed, double pknorm, const orc_cosmo *cosmo, int pk_n, const double *pk_logk,
                  const double *pk_logk3p, int FixedIC, int PairedIC, double *kdensity) {
+  return orc_genic_form(n, box, seed, pknorm, cosmo, pk_n > 0 ? 2 : 1, 0.0, 3.085678e24, pk_n, pk_logk, pk_logk3p, FixedIC, PairedIC, kdensity);
+}
+int orc_genic_form(int n, double box, const unsigned int *seed, double pknorm, const orc_cosmo *cosmo, int which, double wdm_mass_kev,
+                   double unit_length_cm, int pk_n, const double *pk_logk, const double *pk_logk3p, int FixedIC, int PairedIC, double *kdensity) {
   double *pk_c = NULL;
   if (pk_n > 0) {
     pk_c = (double *)malloc(sizeof(double) * pk_n);
@@ -242,8 +269,7 @@ int orc_genic_pk(int n, double box, const unsigned int *seed, double pknorm, con
         double kmag2_local = kmag2_ij + kvec[2] * kvec[2];
         double kmag = sqrt(kmag2_local);
         if (kmag * Box / (2 * ORC_PI) > 1. * Nsample / 2) continue; /* NYQUIST = 1. */
-        double p_of_k = pknorm * (pk_n > 0 ? pow(10., orc_my_spline_eval(pk_logk, pk_logk3p, pk_c, pk_n, log10(kmag))) / kmag / kmag / kmag
-                                           : orc_powerspec_EH(kmag, cosmo));
+        double p_of_k = pknorm * orc_power_spectrum_form(kmag, which, cosmo, pk_n, pk_logk, pk_logk3p, pk_c, wdm_mass_kev, unit_length_cm);
         double sign = 1.0;
         int addr_j = j;
         iii = ii; jjj = jj;

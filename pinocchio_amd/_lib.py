@@ -32,7 +32,8 @@ class GenicParams(C.Structure):
     _fields_ = [("Omega0", C.c_double), ("OmegaBaryon", C.c_double), ("Hubble100", C.c_double),
                 ("PrimordialIndex", C.c_double), ("BoxSize_true_Mpc", C.c_double), ("PkNorm", C.c_double),
                 ("RandomSeed", C.c_uint), ("FixedIC", C.c_int), ("PairedIC", C.c_int),
-                ("pk_n", C.c_int), ("pk_logk", C.POINTER(C.c_double)), ("pk_logk3p", C.POINTER(C.c_double))]
+                ("pk_n", C.c_int), ("pk_logk", C.POINTER(C.c_double)), ("pk_logk3p", C.POINTER(C.c_double)),
+                ("spectrum", C.c_int), ("WDM_PartMass_in_kev", C.c_double), ("UnitLength_in_cm", C.c_double)]
 
 
 class CpuTime(C.Structure):

@@ -89,12 +89,15 @@ class Fmax:
 
     def genic_density(self, seed: int, box_true_mpc: float, omega0: float, omega_baryon: float, hubble100: float,
                       primordial_index: float, sigma8: float = 0.0, pknorm: float = 0.0, fixed: bool = False, paired: bool = False,
-                      pk_table=None) -> float:
+                      pk_table=None, spectrum: str = "EH", wdm_mass_kev: float = 0.0) -> float:
         """GenIC_large (src/GenIC.c:73) on the device.  Give PkNorm, or sigma8 to have it computed
         (normalize_PowerSpectrum, src/cosmo.c:1058).  pk_table = (log10 k [1/Mpc], log10(k^3 P)): a tabulated spectrum
         (SPLINE[SP_PK]) instead of Eisenstein & Hu; PkNorm is then what the caller says (1 for a trusted table).
-        Returns the PkNorm used."""
+        spectrum "Efstathiou" / "PowerLaw": the other two analytic forms of PowerSpectrum(); wdm_mass_kev > 0: its warm-dark-matter
+        cut-off (src/cosmo.c:953-1007).  Returns the PkNorm used."""
         p = _lib.GenicParams(omega0, omega_baryon, hubble100, primordial_index, box_true_mpc, pknorm, seed, int(fixed), int(paired))
+        p.spectrum = {"EH": 0, "Efstathiou": 3, "PowerLaw": 4}[spectrum]   # FileWithInputSpectrum (src/cosmo.c:1009-1046)
+        p.WDM_PartMass_in_kev = wdm_mass_kev
         if pk_table is not None:
             lk = np.ascontiguousarray(pk_table[0], dtype=np.float64)
             lp = np.ascontiguousarray(pk_table[1], dtype=np.float64)

@@ -189,7 +189,23 @@ struct GenicArgs {
   bool fixed, paired;        // params.FixedIC, params.PairedIC
   int pkn;                   // > 0: tabulated spectrum, knots log10 k -> log10(k^3 P) with their natural-spline c
   const double *pkx, *pky, *pkc;
+  int form;                  // 1 Eisenstein & Hu, 2 tabulated, 3 Efstathiou, 4 power law (WhichSpectrum, src/cosmo.c:953-986)
+  double wdm_alpha, hubble, unit_ratio;  // warm-dark-matter cut-off (src/cosmo.c:987-1005): alpha [Mpc/h], Hubble100, 3.085678e24 / UnitLength_in_cm; alpha 0: none
 };
+#define PFG_SHAPE_EFST 0.21  // src/cosmo.c:44
+// PowerSpec_Efstathiou, PowerSpec_PowerLaw (src/cosmo.c:1437-1445) and the cut-off Tf^2 (:998-1004), as the reference writes them
+__host__ __device__ inline double pfg_powerspec_efstathiou(double k, double ns) {
+  return pow(k, ns) / pow(1 + pow(6.4 / PFG_SHAPE_EFST * k + pow(3.0 / PFG_SHAPE_EFST * k, 1.5) + pow(1.7 / PFG_SHAPE_EFST, 2.0) * k * k, 1.13), 2 / 1.13);
+}
+__host__ __device__ inline double pfg_wdm_cutoff(double k, double alpha, double hubble, double unit_ratio) {
+  const double Tf = pow(1 + pow(alpha * k / hubble * unit_ratio, 2), -5.0);
+  return Tf * Tf;
+}
+static double pfg_wdm_alpha(const pf_genic_params *p) {
+  return p->WDM_PartMass_in_kev > 0.
+             ? 0.05 * pow((p->Omega0 - p->OmegaBaryon) / 0.4, 0.15) * pow(p->Hubble100 / 0.65, 1.3) * pow(1.0 / p->WDM_PartMass_in_kev, 1.15)
+             : 0.0;
+}
 // PowerSpec_Tabulated (src/cosmo.c:1432-1435): my_spline_eval of SPLINE[SP_PK] (linear beyond the knots), then 10^. / k^3
 __device__ __forceinline__ double pfg_powerspec_tab(double k, const GenicArgs &a) {
   const double x = log10(k);
@@ -231,7 +247,10 @@ __global__ void __launch_bounds__(64) k_genic(const GenicArgs a) {
     const double kz = kk * 2 * PFG_PI / Box;
     const double kmag = sqrt(kmag2_ij + kz * kz);
     if (kmag * Box / (2 * PFG_PI) > 1. * n / 2) continue;  // NYQUIST = 1.
-    double p_of_k = a.pknorm * (a.pkn > 0 ? pfg_powerspec_tab(kmag, a) : pfg_powerspec_EH(kmag, a.eh));
+    double power = a.form == 2 ? pfg_powerspec_tab(kmag, a) : a.form == 3 ? pfg_powerspec_efstathiou(kmag, a.eh.ns)
+                   : a.form == 4 ? pow(kmag, a.eh.ns) : pfg_powerspec_EH(kmag, a.eh);
+    if (a.wdm_alpha > 0.) power *= pfg_wdm_cutoff(kmag, a.wdm_alpha, a.hubble, a.unit_ratio);
+    double p_of_k = a.pknorm * power;
     double sign = 1.0;
     if (kk == 0) {  // Hermitian partners on the kz = 0 plane (src/GenIC.c:289-368)
       if (ii == 0 && jj == Nmesh_2) continue;
@@ -266,13 +285,17 @@ extern "C" int pf_pk_norm(const pf_genic_params *p, double sigma8, double *pknor
   const double gw[4] = {0.3478548451374538, 0.6521451548625461, 0.6521451548625461, 0.3478548451374538};
   double sum = 0.0;
   const double h = (hi - lo) / panels;
+  if (p->pk_n > 0) return 1;  // (a tabulated spectrum comes with its own normalisation: the caller passes PkNorm)
+  const double wdm_alpha = pfg_wdm_alpha(p), unit_ratio = 3.085678e24 / (p->UnitLength_in_cm > 0. ? p->UnitLength_in_cm : 3.085678e24);
   for (int i = 0; i < panels; i++) {
     const double c = lo + (i + 0.5) * h;
     for (int g = 0; g < 4; g++) {
       const double k = exp(c + 0.5 * h * gx[g]);
       const double kr = k * R, kr2 = kr * kr;
       const double w = (kr < 1.e-5) ? 1.0 : 3. * (sin(kr) / kr2 / kr - cos(kr) / kr2);
-      sum += gw[g] * 0.5 * h * pfg_powerspec_EH(k, e) * w * w * k * k * k / (2. * PFG_PI * PFG_PI);
+      double power = p->spectrum == 3 ? pfg_powerspec_efstathiou(k, p->PrimordialIndex) : p->spectrum == 4 ? pow(k, p->PrimordialIndex) : pfg_powerspec_EH(k, e);
+      if (wdm_alpha > 0.) power *= pfg_wdm_cutoff(k, wdm_alpha, p->Hubble100, unit_ratio);
+      sum += gw[g] * 0.5 * h * power * w * w * k * k * k / (2. * PFG_PI * PFG_PI);
     }
   }
   *pknorm = sigma8 * sigma8 / sum;
@@ -306,6 +329,9 @@ int pf_genic_launch(int fb, void *dk, int n, int nzp, int nyl, int y0, const pf_
     a.pkn = p->pk_n; a.pkx = dpk; a.pky = dpk + p->pk_n; a.pkc = dpk + 2 * (size_t)p->pk_n;
   }
   eh_constants(p, &a.eh);
+  a.form = p->pk_n > 0 ? 2 : (p->spectrum == 3 || p->spectrum == 4) ? p->spectrum : 1;
+  a.wdm_alpha = pfg_wdm_alpha(p); a.hubble = p->Hubble100;
+  a.unit_ratio = 3.085678e24 / (p->UnitLength_in_cm > 0. ? p->UnitLength_in_cm : 3.085678e24);
   const long long ncol = (long long)n * nyl;
   const unsigned blocks = (unsigned)((ncol + 63) / 64);
   if (fb == 8) hipLaunchKernelGGL(k_genic<double>, dim3(blocks), dim3(64), 0, st, a);

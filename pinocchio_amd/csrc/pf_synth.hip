@@ -122,25 +122,37 @@ int pf_launch_sigma_scale(const double *power_sum, double sigma0, double n3, dou
 
 // ---- streaming yardsticks (pf_debug_stream_rate): what this memory system gives a kernel that does nothing but read, write or
 // copy -- the rates the transform passes are measured against in bench.py beside the 8 TB/s of the specification.  16 bytes per
-// lane, plain (cached) accesses, grid-stride over the buffer.
+// lane, grid-stride over the buffer, in the best form each kind showed in the sweep of profiles/tools/hbm_probe.hip
+// (profiles/r04_hbm_ceilings.json: 144 / 144 / 216 variants of unroll, workgroup size, workgroups per CU, plain / non-temporal,
+// grid-stride / one range per XCD): reads want many waves (non-temporal loads, 8 workgroups of 256 per CU: 7.2-7.3 TB/s against
+// 6.6 for round 3's plain form), writes want FEW (one workgroup of 256 per CU: 6.4-6.5 TB/s; 8 per CU, round 3's yardstick: 5.0),
+// a copy sits between (one workgroup per CU, two to four loads in flight per lane: 5.6-5.7 against 4.7).
 typedef float pf_f4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256) k_stream_read(const pf_f4 *p, size_t n, float *sink) {
   pf_f4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc += p[i];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc += __builtin_nontemporal_load(p + i);
   if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[0] = 1.f;  // never true for field data; keeps the loads
 }
 __global__ void __launch_bounds__(256) k_stream_write(pf_f4 *p, size_t n, float v) {
   const pf_f4 x = {v, v, v, v};
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) __builtin_nontemporal_store(x, p + i);
 }
 __global__ void __launch_bounds__(256) k_stream_copy(const pf_f4 *a, pf_f4 *b, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
+  const size_t nthr = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * nthr < n; i += 4 * nthr) {
+    const pf_f4 v0 = a[i], v1 = a[i + nthr], v2 = a[i + 2 * nthr], v3 = a[i + 3 * nthr];
+    b[i] = v0; b[i + nthr] = v1; b[i + 2 * nthr] = v2; b[i + 3 * nthr] = v3;
+  }
+  for (; i < n; i += nthr) b[i] = a[i];
 }
 int pf_launch_stream(int kind, const void *src, void *dst, size_t bytes, float *sink, hipStream_t st) {
   const size_t n = bytes / 16;
-  const dim3 grid(2048), block(256);
-  if (kind == 0) hipLaunchKernelGGL(k_stream_read, grid, block, 0, st, (const pf_f4 *)src, n, sink);
-  else if (kind == 1) hipLaunchKernelGGL(k_stream_write, grid, block, 0, st, (pf_f4 *)dst, n, 0.f);
-  else hipLaunchKernelGGL(k_stream_copy, grid, block, 0, st, (const pf_f4 *)src, (pf_f4 *)dst, n);
+  int dev = 0, ncu = 256;
+  if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v; }
+  const dim3 block(256);
+  if (kind == 0) hipLaunchKernelGGL(k_stream_read, dim3(8 * ncu), block, 0, st, (const pf_f4 *)src, n, sink);
+  else if (kind == 1) hipLaunchKernelGGL(k_stream_write, dim3(ncu), block, 0, st, (pf_f4 *)dst, n, 0.f);
+  else hipLaunchKernelGGL(k_stream_copy, dim3(ncu), block, 0, st, (const pf_f4 *)src, (pf_f4 *)dst, n);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }

@@ -266,21 +266,14 @@ int pf_compat_genic(double PkNorm) {
   g.FixedIC = params.FixedIC; g.PairedIC = params.PairedIC; /* src/GenIC.c:371-376 */
   g.PkNorm = PkNorm;
 #ifdef PF_IN_PINOCCHIO_TREE
-  /* which spectrum (initialize_PowerSpectrum, src/cosmo.c:1003-1046): "no" = Eisenstein & Hu; a file name or CAMBTable = the
-     table behind SPLINE[SP_PK] (PowerSpec_Tabulated :1432-1435); the two other analytic forms are not on the device */
-  if (!strcmp(params.FileWithInputSpectrum, "Efstathiou") || !strcmp(params.FileWithInputSpectrum, "PowerLaw")) {
-    printf("ERROR on task %d: the device generator knows Eisenstein & Hu and tabulated spectra only (FileWithInputSpectrum %s)\n", ThisTask,
-           params.FileWithInputSpectrum);
-    return 1;
-  }
-  /* PowerSpectrum() multiplies either spectrum by the warm-dark-matter cut-off Tf^2 (src/cosmo.c:987-1005); the device
-     generator has no such term: refuse rather than hand a WDM run CDM initial conditions */
-  if (params.WDM_PartMass_in_kev > 0.0) {
-    printf("ERROR on task %d: the device generator has no warm-dark-matter cut-off (WDM_PartMass_in_kev %g); use GenIC_large\n", ThisTask,
-           params.WDM_PartMass_in_kev);
-    return 1;
-  }
-  if (strcmp(params.FileWithInputSpectrum, "no")) {
+  /* which spectrum (initialize_PowerSpectrum, src/cosmo.c:1009-1046): "no" / "EH" = Eisenstein & Hu; "Efstathiou" and "PowerLaw" the two
+     other analytic forms; a file name or CAMBTable = the table behind SPLINE[SP_PK] (PowerSpec_Tabulated :1432-1435); the
+     warm-dark-matter cut-off of PowerSpectrum() (:987-1005) multiplies any of them */
+  g.WDM_PartMass_in_kev = params.WDM_PartMass_in_kev;
+  g.UnitLength_in_cm = 3.085678e24; /* UnitLength_in_cm, a constant private to src/cosmo.c:41 */
+  if (!strcmp(params.FileWithInputSpectrum, "Efstathiou")) g.spectrum = 3;
+  else if (!strcmp(params.FileWithInputSpectrum, "PowerLaw")) g.spectrum = 4;
+  else if (strcmp(params.FileWithInputSpectrum, "no") && strcmp(params.FileWithInputSpectrum, "EH")) {
     g.pk_n = (int)SPLINE[SP_PK]->size; g.pk_logk = SPLINE[SP_PK]->x; g.pk_logk3p = SPLINE[SP_PK]->y;
     if (PkNorm <= 0.0) { /* normalize_PowerSpectrum (:1061-1081): a trusted table (Sigma8 0, or CAMBTable) has PkNorm 1 */
       if (params.Sigma8 != 0.0 && strcmp(params.FileWithInputSpectrum, "CAMBTable")) {

@@ -63,9 +63,14 @@ def pk_norm(p, sigma8: float) -> float:
     return sigma8 ** 2 / val
 
 
-def genic(n: int, box_true_mpc: float, seed: int, pknorm: float, p, fixed: bool = False, paired: bool = False, pk_table=None) -> np.ndarray:
+SPECTRUM_CODES = {"EH": 1, "Efstathiou": 3, "PowerLaw": 4}   # WhichSpectrum (src/cosmo.c:1009-1046)
+
+
+def genic(n: int, box_true_mpc: float, seed: int, pknorm: float, p, fixed: bool = False, paired: bool = False, pk_table=None,
+          spectrum: str = "EH", wdm_mass_kev: float = 0.0) -> np.ndarray:
     """fixed / paired: params.FixedIC / params.PairedIC (src/GenIC.c:370-376); pk_table = (log10 k [1/Mpc], log10(k^3 P)): the knots of
-    SPLINE[SP_PK] for a tabulated spectrum (PowerSpec_Tabulated, src/cosmo.c:1432-1435) instead of Eisenstein & Hu"""
+    SPLINE[SP_PK] for a tabulated spectrum (PowerSpec_Tabulated, src/cosmo.c:1432-1435) instead of Eisenstein & Hu; spectrum
+    "Efstathiou" / "PowerLaw" and wdm_mass_kev: the other forms of PowerSpectrum() and its warm-dark-matter cut-off (:953-1007)"""
     L = _lib()
     cos = Cosmo(p["Omega0"], p["OmegaBaryon"], p["Hubble100"], p["PrimordialIndex"])
     st = seed_table(n, seed)
@@ -77,10 +82,12 @@ def genic(n: int, box_true_mpc: float, seed: int, pknorm: float, p, fixed: bool 
         lk = np.ascontiguousarray(pk_table[0], dtype=np.float64)
         lp = np.ascontiguousarray(pk_table[1], dtype=np.float64)
         npk = len(lk)
-    L.orc_genic_pk.argtypes = [C.c_int, C.c_double, C.POINTER(C.c_uint), C.c_double, C.c_void_p, C.c_int, dp, dp, C.c_int, C.c_int, dp]
-    rc = L.orc_genic_pk(n, box_true_mpc, st.ctypes.data_as(C.POINTER(C.c_uint)), pknorm, C.cast(C.byref(cos), C.c_void_p), npk,
-                        lk.ctypes.data_as(dp) if npk else None, lp.ctypes.data_as(dp) if npk else None, int(fixed), int(paired),
-                        out.view(np.float64).ctypes.data_as(dp))
+    L.orc_genic_form.argtypes = [C.c_int, C.c_double, C.POINTER(C.c_uint), C.c_double, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, dp, dp,
+                                 C.c_int, C.c_int, dp]
+    which = 2 if npk else SPECTRUM_CODES[spectrum]
+    rc = L.orc_genic_form(n, box_true_mpc, st.ctypes.data_as(C.POINTER(C.c_uint)), pknorm, C.cast(C.byref(cos), C.c_void_p), which,
+                          wdm_mass_kev, 3.085678e24, npk, lk.ctypes.data_as(dp) if npk else None, lp.ctypes.data_as(dp) if npk else None,
+                          int(fixed), int(paired), out.view(np.float64).ctypes.data_as(dp))
     assert rc == 0
     return out
 

@@ -23,7 +23,7 @@ def _stats(zinv_ms, solve_ms):
 def test_every_kernel_in_line():
     kern, table, table_steps, overlapped, roofline, cls = bench.kernel_report(_stats(190.0, 215.0), STEPS, 1024, 8)
     assert not overlapped and table is kern and table_steps == STEPS
-    assert roofline["kernel"] == "k_strided<double, 1024, 8, 1>"                      # 269 ms per step by symbol against 215 and 190
+    assert roofline["kernel"] == "k_strided<double, 1024, 8, 1, true>"                      # 269 ms per step by symbol against 215 and 190
     assert set(roofline["classes"]) == {"xpass_hess_1to3", "ypass_hess_3to6", "xpass_disp_1to2", "ypass_disp_2to3"}
     assert abs(roofline["ms_per_step"] - 269.0) < 1e-9 and abs(roofline["avg_ms"] - 538.0 / 68) < 1e-9
     assert abs(roofline["achieved"] - (6.0e11 + 1.5e12 + 2.0e11 + 3.4e11) / 0.538 / 1e9) < 1e-6
@@ -40,7 +40,7 @@ def test_overlapping_spans_with_an_in_line_pass():
     assert overlapped == {"zpass_c2r_hess_6to3inv", "collapse_inv"}
     assert table is not kern and all("symbol" in s for s in table)
     # ranking on the in-line table: the strided passes, not the 370 ms span of the z-pass
-    assert roofline["kernel"] == "k_strided<double, 1024, 8, 1>" and roofline["measured"] == "HIP events of the timed region"
+    assert roofline["kernel"] == "k_strided<double, 1024, 8, 1, true>" and roofline["measured"] == "HIP events of the timed region"
     assert abs(roofline["avg_ms_in_line_pass"] - 538.0 / 68) < 1e-9
     # the most expensive class is the solve, and its time is the in-line one, not its span
     assert cls["class"] == "collapse_inv" and abs(cls["ms_per_step"] - 215.0) < 1e-9 and "in-line pass" in cls["measured"]
@@ -51,13 +51,13 @@ def test_overlapping_spans_with_an_in_line_pass():
 def test_overlapping_spans_without_an_in_line_pass():
     kern, table, table_steps, overlapped, roofline, cls = bench.kernel_report(_stats(370.0, 243.0), STEPS, 1024, 8, inline=None, solve_beside=True)
     assert overlapped and table is kern
-    assert roofline["kernel"] == "k_strided<double, 1024, 8, 1>"    # the 370 ms span does not make the z-pass dominant
+    assert roofline["kernel"] == "k_strided<double, 1024, 8, 1, true>"    # the 370 ms span does not make the z-pass dominant
     assert cls["class"] == "ypass_hess_3to6"                         # ... nor the solve's span the most expensive class
     for r in (roofline, cls):
         assert r["share_of_gpu_time"] is None and "ranking" in r
 
 
 def test_fp32_symbols():
-    assert bench.symbol_of("ypass_hess_3to6", 1024, 4) == "k_strided<float __vector(2), 1024, 8, 1>"
-    assert bench.symbol_of("ypass_hess_3to6", 2048, 4) == "k_strided<float __vector(2), 2048, 4, 1>"
+    assert bench.symbol_of("ypass_hess_3to6", 1024, 4) == "k_strided<float __vector(2), 1024, 8, 1, true>"
+    assert bench.symbol_of("ypass_hess_3to6", 2048, 4) == "k_strided<float __vector(2), 2048, 4, 1, true>"
     assert bench.symbol_of("zpass_c2r_hess_6to3inv", 2048, 4) == "k_c2r_invariants<float, 2048, 0>"

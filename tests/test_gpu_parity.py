@@ -655,6 +655,46 @@ def test_genic_on_device_vs_oracle(api):
         assert np.max(np.abs(got - want)) <= 1e-12 * np.max(np.abs(want))  # device libm vs glibc in log/cos/sin/pow
 
 
+@pytest.mark.parametrize("spectrum,wdm", [("Efstathiou", 0.0), ("PowerLaw", 0.0), ("EH", 2.5), ("Efstathiou", 1.0)])
+def test_genic_other_spectra_on_device_vs_oracle(api, spectrum, wdm):
+    """the other forms of PowerSpectrum() (src/cosmo.c:953-1007): the Efstathiou fit, a power law, and the warm-dark-matter
+    cut-off that multiplies any of them -- device generator against the restated CPU generator, and the sigma8
+    normalisation (pf_pk_norm) against a scipy quadrature of the same integrand"""
+    import ic_oracle
+    with open(os.path.join(GOLD, "hmf_validation_kat.json")) as fh:
+        p = dict(json.load(fh)["params"])
+    if spectrum == "PowerLaw":
+        p["PrimordialIndex"] = -1.5
+    n, seed = 32, 11
+    box = float(n) / p["Hubble100"]
+    with api.Fmax(n) as f:
+        pkn = f.genic_density(seed, box, p["Omega0"], p["OmegaBaryon"], p["Hubble100"], p["PrimordialIndex"], sigma8=0.8,
+                              spectrum=spectrum, wdm_mass_kev=wdm)
+        got = f.density()
+    want = ic_oracle.genic(n, box, seed, pkn, p, spectrum=spectrum, wdm_mass_kev=wdm)
+    assert np.count_nonzero(want) > n ** 3 // 8
+    assert np.array_equal(got == 0, want == 0)
+    assert np.max(np.abs(got - want)) <= 1e-12 * np.max(np.abs(want))
+    # the normalisation: sigma8^2 over the top-hat variance at 8/h Mpc of the un-normalised spectrum
+    from scipy.integrate import quad
+    import ctypes as C
+    L = ic_oracle._lib()
+    L.orc_power_spectrum_form.restype = C.c_double
+    L.orc_power_spectrum_form.argtypes = [C.c_double, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double]
+    cos = ic_oracle.Cosmo(p["Omega0"], p["OmegaBaryon"], p["Hubble100"], p["PrimordialIndex"])
+    R = 8.0 / p["Hubble100"]
+
+    def integrand(logk):
+        k = np.exp(logk)
+        kr = k * R
+        w = 1.0 if kr < 1e-5 else 3.0 * (np.sin(kr) / kr ** 3 - np.cos(kr) / kr ** 2)
+        pw = L.orc_power_spectrum_form(k, ic_oracle.SPECTRUM_CODES[spectrum], C.cast(C.byref(cos), C.c_void_p), 0, None, None, None, wdm, 3.085678e24)
+        return pw * w * w * k ** 3 / (2.0 * np.pi ** 2)
+
+    val, _ = quad(integrand, -10.0, np.log(500.0 / R), epsabs=0, epsrel=1e-10, limit=2000)
+    assert pkn == pytest.approx(0.8 ** 2 / val, rel=1e-6)
+
+
 def test_hmf_validation_run_entirely_on_device(api):
     """seed + cosmology -> pf_genic_density -> pf_sweep -> Fmax PDF, nothing but parameters from the host: the
     reference's committed validation numbers again (sigma per radius, collapsed count, histogram)"""
