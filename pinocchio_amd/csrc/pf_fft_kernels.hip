@@ -405,13 +405,38 @@ __global__ void __launch_bounds__(TL *(N / 16)) k_c2r_persistent(const PfC2RPara
 // MODE 1 (the Hessian of the 2LPT potential, src/LPT.c:112-137): the six rows are not stored at all; each cell's 3LPT(b)
 // source is updated in place from them and the six components of the first-order Hessian (read from job[c].out):
 // p.acc -= 2 phi2_ab h_ab, by the same pf_lpt3b_accumulate as k_lpt_accum.
+// Round 4: fp64 rows of 512 points and more run THREE workgroups per CU instead of two.  The row of an iteration is loaded at the
+// top of that iteration (PF_ZI_PREFETCH = 0: no row carried in registers across the stages: 78 instead of 114 registers) and the
+// exchange area of a line is padded by p >> 4 instead of p >> 3 (544 instead of 576 complex per 512-point line: 52.2 KB per
+// workgroup; the stride-8 writes of stage 0 still fall on distinct banks) -- eighteen waves per CU hide a row's load latency better than twelve with a row in flight each:
+// 16.8 -> 15.7 ms per launch at 1024^3, 743 -> 722 ms per step (A/B on one box, profiles/r04_notes.md).  Carrying the row and asking
+// for five waves per SIMD spills (92 bytes) and takes 26.7 ms; requesting the next row late, behind the stages, needs 114 registers
+// again.  fp32 rows (28 KB of lines, 86 registers) already fit three workgroups with the row carried and keep it.
+#ifndef PF_ZI_PREFETCH
+#define PF_ZI_PREFETCH -1   // -1: by field type and length (above); 0 / 1: force (A/B builds)
+#endif
+#ifndef PF_ZI_WAVES
+#define PF_ZI_WAVES 0       // (A/B: waves per SIMD the compiler is asked to make room for; 0: its own choice)
+#endif
+template <typename F, int M> struct PfZiPlan {
+  static constexpr bool lean = PF_ZI_PREFETCH < 0 ? (sizeof(F) == 8 && M >= 256) : PF_ZI_PREFETCH == 0;  // no carried row, narrow pad
+  static constexpr int full = (M + 1 > M + M / 8) ? M + 1 : M + M / 8, narrow = (M + 1 > M + M / 16) ? M + 1 : M + M / 16;
+  static constexpr int line = (lean && M >= 256) ? narrow : full;  // complex per LDS line
+  static __device__ __forceinline__ int pad(int p) { return (lean && M >= 256) ? p + (p >> 4) : pf_lpad(p); }
+};
 template <typename F, int N, int MODE = 0>
-__global__ void __launch_bounds__(6 * (N / 16)) k_c2r_invariants(const PfC2RParams p, long long nrows) {
+__global__ void __launch_bounds__(6 * (N / 16))
+#if PF_ZI_WAVES > 0
+__attribute__((amdgpu_waves_per_eu(PF_ZI_WAVES, PF_ZI_WAVES)))
+#endif
+k_c2r_invariants(const PfC2RParams p, long long nrows) {
   using C = pfc<F>;
   using F2 = typename pf_vec2<F>::type;
   constexpr bool IN_PLACE = sizeof(F) == 8;  // fp64 invariants fit the rows they replace
   constexpr int M = N / 2, NT = M / 8, TL = 6;
-  constexpr int LPL = (M + 1 > M + M / 8) ? M + 1 : M + M / 8;
+  using PLAN = PfZiPlan<F, M>;
+  constexpr int LPL = PLAN::line;
+  constexpr bool PREFETCH = !PLAN::lean;
   constexpr int NTHR = TL * NT;
   static_assert((size_t)LPL * sizeof(C) >= (size_t)N * sizeof(F), "a line's LDS holds its real row");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -447,11 +472,12 @@ __global__ void __launch_bounds__(6 * (N / 16)) k_c2r_invariants(const PfC2RPara
   };
 
   long long R = blockIdx.x;
-  if (R < nrows) fetch(R);
+  if (PREFETCH && R < nrows) fetch(R);
 #pragma unroll 1
   for (; R < nrows; R += gridDim.x) {
     int tlj = tl, lj = l, tidj = tid;
     asm volatile("" : "+v"(tlj), "+v"(lj), "+v"(tidj));  // keep the index math inside the loop (see k_strided)
+    if (!PREFETCH) fetch(R);
     C *L = lds + lj * LPL;
     // phase A: the prefetched row of this component -> its LDS line
 #pragma unroll
@@ -466,12 +492,12 @@ __global__ void __launch_bounds__(6 * (N / 16)) k_c2r_invariants(const PfC2RPara
       v[m] = pf_zfold<F>(L[e], L[M - e], e, M, mul, kf, tw[e]);
     }
     line_sync();
-    if (R + gridDim.x < nrows) fetch(R + gridDim.x);  // in flight during the stages and the reduction below
+    if (PREFETCH && R + gridDim.x < nrows) fetch(R + gridDim.x);  // in flight during the stages and the reduction below
 #ifndef PF_ZI_HOIST_TW
 #define PF_ZI_HOIST_TW 0
 #endif
     PfStages<F, M, +1, 2, 0, (NT <= 64)>::run(
-        v, tlj, tw, [&](int pos, C val) { L[pf_lpad(pos)] = val; }, [&](int pos) { return L[pf_lpad(pos)]; }, PF_ZI_HOIST_TW ? tl : -1);
+        v, tlj, tw, [&](int pos, C val) { L[PLAN::pad(pos)] = val; }, [&](int pos) { return L[PLAN::pad(pos)]; }, PF_ZI_HOIST_TW ? tl : -1);
     line_sync();  // every thread of the line is done with the exchange area
     // the real row of this component, in order, into its line
     C *H = L;
@@ -670,7 +696,7 @@ static int launch_c2r_n(const PfC2RParams &p, hipStream_t st) {
 template <typename F, int N>
 static int launch_c2r_invariants_n(const PfC2RParams &p, hipStream_t st, int mode) {
   constexpr int M = N / 2, NT = M / 8;
-  constexpr int LPL = (M + 1 > M + M / 8) ? M + 1 : M + M / 8;
+  constexpr int LPL = PfZiPlan<F, M>::line;
   // (a second row of prefetch per workgroup -- 159 VGPRs, still two workgroups per CU -- made the pass slower: 222-227 ms
   // against 190-194 ms per step; more rows in flight on six fields at once cost more in DRAM locality than they hide)
   // two workgroups fit per CU; 32 per CU in the grid evens out the tail (measured 6: 254, 8: 248, 16: 241, 32: 235-237,
