@@ -10,6 +10,14 @@
 #include "pf_sng_core.h"
 
 #define PF_CELL_BLOCK 256
+// the solve on the invariants (k_collapse_inv) has its own workgroup size and wave budget: its LDS (the 38 KB polynomial table) lets
+// four workgroups share a CU, its registers decide how many waves those may hold (A/B knobs: -DPF_SOLVE_INV_BLOCK=320 -DPF_SOLVE_INV_WAVES=5)
+#ifndef PF_SOLVE_INV_BLOCK
+#define PF_SOLVE_INV_BLOCK 256
+#endif
+#ifndef PF_SOLVE_INV_WAVES
+#define PF_SOLVE_INV_WAVES 4
+#endif
 #define PF_MAX_KNOTS 512
 
 // deterministic block reduction of two doubles: wave shuffle, then thread 0 sums the waves in order
@@ -53,7 +61,7 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
   constexpr int SK = TAB ? PF_CT_NBINS_D : GT ? (PF_GT_MAX_INT + 1) * PF_GT_REC : 5 * PF_MAX_KNOTS;
   static_assert(!GT || SK >= 5 * PF_MAX_KNOTS, "the knot arrays fit the table's place");
   __shared__ double sk[SK];
-  __shared__ double red[2 * (PF_CELL_BLOCK / 64)];
+  __shared__ double red[2 * ((PF_SOLVE_INV_BLOCK > PF_CELL_BLOCK ? PF_SOLVE_INV_BLOCK : PF_CELL_BLOCK) / 64)];
   __shared__ unsigned short slut[TAB ? 1 : GT ? PF_GT_MAX_BINS : PF_SPLINE_LUT_BINS];
   const int nk = p.spline.n;
   const bool gt = GT && p.spline.gt != nullptr;  // uniform
@@ -197,7 +205,7 @@ template <typename F, bool FAST, typename PR = float>
 __global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse_sng(const PfCollapseParams p) { pf_collapse_body<F, FAST, false, false, true, false, 0, PR>(p); }
 // the solve on the three invariants per cell that k_c2r_invariants leaves in h[0..2] (fp64 fields)
 template <bool FAST, typename PR = float>
-__global__ void __launch_bounds__(PF_CELL_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) k_collapse_inv(const PfCollapseParams p) { pf_collapse_body<double, FAST, false, true, false, false, 0, PR>(p); }
+__global__ void __launch_bounds__(PF_SOLVE_INV_BLOCK) __attribute__((amdgpu_waves_per_eu(PF_SOLVE_INV_WAVES))) k_collapse_inv(const PfCollapseParams p) { pf_collapse_body<double, FAST, false, true, false, false, 0, PR>(p); }
 
 // initialize_collapse_times (src/collapse_times.c:956-972): CT_table[i] = ell(ismooth, l1, l2, l3) on the
 // (delta, x, y) grid, i = id + 100 * (ix + 50 * iy)
@@ -615,8 +623,8 @@ template <typename PR> static int pf_launch_collapse_as(int fb, const PfCollapse
   }
   if (p.invariants) {
     if (fb != 8 || p.tabulated) return 2;
-    if (p.fast) hipLaunchKernelGGL((k_collapse_inv<true, PR>), g, b, 0, st, p);
-    else hipLaunchKernelGGL((k_collapse_inv<false, PR>), g, b, 0, st, p);
+    if (p.fast) hipLaunchKernelGGL((k_collapse_inv<true, PR>), g, dim3(PF_SOLVE_INV_BLOCK), 0, st, p);
+    else hipLaunchKernelGGL((k_collapse_inv<false, PR>), g, dim3(PF_SOLVE_INV_BLOCK), 0, st, p);
     return PF_CHECK_LAUNCH();
   }
   PF_BY_FIELD_AND_LIBM(k_collapse);

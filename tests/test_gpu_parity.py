@@ -1311,7 +1311,7 @@ def test_baseline_config_sizes_vs_oracle(api, n, ns, lpt):
     outliers = _fmax_close(p["Fmax"], po["Fmax"], max_abs=None)
     d = np.abs(p["Fmax"].astype(np.float64) - po["Fmax"])
     far = [tuple(c) for c in outliers if d[tuple(c)] > 2e-3]
-    assert len(far) <= max(64, int(1e-6 * d.size)), len(far)
+    assert len(far) <= max(8, int(3e-7 * d.size)), len(far)   # (observed: 1 at 256^3, ~1e-7 of the cells at 512^3 and 1024^3)
     if far:
         o8 = oracle_lib.Oracle(8, 1)
         o8.set_invgrow(x, y)
