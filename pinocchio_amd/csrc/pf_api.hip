@@ -184,7 +184,6 @@ struct pf_ctx {
 
 #define PF_GT_DOUBLES (PF_GT_HEADER + (PF_GT_MAX_INT + 1) * PF_GT_REC)
 #define PF_NBLK 2048
-#define PF_KNOT_CAP 512
 #define PF_KBIN_CAP 32
 enum { SC_SUM = 0, SC_SUM2 = 1, SC_DC_DK = 2, SC_DC_S2 = 3, SC_POWER = 4, SC_DSCALE = 5, SC_DC_TMP = 6, SC_INV_FLAG = 7 /* raised by the invariant z-pass, see pf_sweep; adjacent to SC_VAR0: one all-reduce */, SC_VAR0 = 8 /* 2 per radius */, SC_COUNT = 8 + 2 * PF_MAX_SMOOTH };
 

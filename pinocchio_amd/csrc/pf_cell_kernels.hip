@@ -71,7 +71,7 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
     const int nint = (int)g[0], nbins = (int)g[1];
     for (int i = threadIdx.x; i < (nint + 1) * PF_GT_REC; i += blockDim.x) sk[i] = g[PF_GT_HEADER + i];
     for (int i = threadIdx.x; i < nbins; i += blockDim.x) slut[i] = p.spline.gt_lut[i];
-    sv.gt.rec = sk; sv.gt.lut = slut; sv.gt.bin0 = (unsigned)g[2]; sv.gt.lo_all = g[3]; sv.gt.hi_all = g[4];
+    sv.gt.bin0 = (unsigned)g[2]; sv.gt.lo_all = g[3]; sv.gt.hi_all = g[4];
   } else if (TAB) {
     for (int i = threadIdx.x; i < PF_CT_NBINS_D; i += blockDim.x) sk[i] = p.ct.delta[i];
   } else {
@@ -101,7 +101,16 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
   }
   pf_ct_view tv;
   tv.delta = sk; tv.y = p.ct.y; tv.b = p.ct.b; tv.c = p.ct.c; tv.d = p.ct.d; tv.ampl = p.ct.ampl;
-  if (gt) { sv.x = p.spline.x; sv.y = p.spline.y; sv.c = p.spline.c; sv.b = p.spline.b; sv.d = p.spline.d; }
+  if (GT) {
+    // Scalar registers are what this kernel is short of (the fp64 constants of the series live there): with the table's place in
+    // LDS a compile-time address, "no table" an empty range [inf, 0) instead of a flag, the range's ends in vector registers and
+    // the five knot arrays of the rare series path addressed from one pointer (spline_for lays them out PF_KNOT_CAP apart), the
+    // loop keeps what is left without the ~27 v_readlane / v_writelane per cell that reloading spilled scalars cost (round 4).
+    sv.gt.rec = sk; sv.gt.lut = slut;
+    if (!gt) { sv.gt.lo_all = HUGE_VAL; sv.gt.hi_all = 0.0; sv.gt.bin0 = 0; }
+    asm volatile("" : "+v"(sv.gt.lo_all), "+v"(sv.gt.hi_all));
+  }
+  if (gt) { sv.x = p.spline.x; sv.y = sv.x + PF_KNOT_CAP; sv.c = sv.x + 2 * PF_KNOT_CAP; sv.b = sv.x + 3 * PF_KNOT_CAP; sv.d = sv.x + 4 * PF_KNOT_CAP; }
   else if (!TAB) { sv.x = sk; sv.y = sk + PF_MAX_KNOTS; sv.c = sk + 2 * PF_MAX_KNOTS; sv.b = sk + 3 * PF_MAX_KNOTS; sv.d = sk + 4 * PF_MAX_KNOTS; }
   else { sv.x = sk; sv.y = sv.c = sv.b = sv.d = sk; }
   sv.n = nk;

@@ -201,7 +201,9 @@ __global__ void __launch_bounds__(T *N / 8) __attribute__((amdgpu_waves_per_eu(4
           const int e = pf_line_index<N, P16>(tlj, m);
           const double ke = kf * (e > N / 2 ? e - N : e);
           const double k2 = ke * ke + ko2kc2;
-          const S fac = (S)((k2 != 0.0) ? we[m] * woc[l] / k2 : 0.0);
+          // (the quotient from the hardware reciprocal, one Newton step and the residual correction: the correctly rounded one but for
+          //  rare 1-ulp cases, in 6 operations where the IEEE division takes 12 -- eight per thread and input tile)
+          const S fac = (S)((k2 != 0.0) ? pf_div_fast(we[m] * woc[l], k2) : 0.0);
           if constexpr (NL > 1) { src[m].x[l] = src[m].x[l] * fac; src[m].y[l] = src[m].y[l] * fac; }
           else src[m] = pf_scale(src[m], (F)fac);
         }
@@ -418,6 +420,9 @@ __global__ void __launch_bounds__(TL *(N / 16)) k_c2r_persistent(const PfC2RPara
 #ifndef PF_ZI_WAVES
 #define PF_ZI_WAVES 0       // (A/B: waves per SIMD the compiler is asked to make room for; 0: its own choice)
 #endif
+#ifndef PF_ZI_DMA
+#define PF_ZI_DMA 0         // (A/B) 1: 1024-point fp64 rows are loaded straight into LDS
+#endif
 template <typename F, int M> struct PfZiPlan {
   static constexpr bool lean = PF_ZI_PREFETCH < 0 ? (sizeof(F) == 8 && M >= 256) : PF_ZI_PREFETCH == 0;  // no carried row, narrow pad
   static constexpr int full = (M + 1 > M + M / 8) ? M + 1 : M + M / 8, narrow = (M + 1 > M + M / 16) ? M + 1 : M + M / 16;
@@ -436,6 +441,7 @@ k_c2r_invariants(const PfC2RParams p, long long nrows) {
   constexpr int M = N / 2, NT = M / 8, TL = 6;
   using PLAN = PfZiPlan<F, M>;
   constexpr int LPL = PLAN::line;
+  constexpr bool DMA = PF_ZI_DMA && PLAN::lean && NT == 64 && sizeof(C) == 16;  // rows straight into LDS (below)
   constexpr bool PREFETCH = !PLAN::lean;
   constexpr int NTHR = TL * NT;
   static_assert((size_t)LPL * sizeof(C) >= (size_t)N * sizeof(F), "a line's LDS holds its real row");
@@ -477,12 +483,31 @@ k_c2r_invariants(const PfC2RParams p, long long nrows) {
   for (; R < nrows; R += gridDim.x) {
     int tlj = tl, lj = l, tidj = tid;
     asm volatile("" : "+v"(tlj), "+v"(lj), "+v"(tidj));  // keep the index math inside the loop (see k_strided)
-    if (!PREFETCH) fetch(R);
     C *L = lds + lj * LPL;
-    // phase A: the prefetched row of this component -> its LDS line
+    if (DMA) {
+      // phase A without registers: each 64-lane piece of the row that lies inside the band goes from memory straight into the
+      // line (global_load_lds_dwordx4: wave-uniform LDS base + 16 bytes per lane, which is the line's own order); pieces cut by
+      // the band or beyond it are written as before.  The wave waits for its own transfers (vmcnt) before it reads the line.
+      const C *__restrict__ row = in + R * p.in_pitch;
+      const unsigned lbase = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) char *)(lds + (tid / NT) * LPL));
 #pragma unroll
-    for (int m = 0; m < 8; m++) L[tlj + m * NT] = nxt[m];
-    if (tlj == 0) L[M] = nxt[8];
+      for (int m = 0; m < 8; m++) {
+        const int k = tlj + m * NT;
+        if (m * NT + NT - 1 <= p.band_k)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(&row[k]),
+                                           (__attribute__((address_space(3))) void *)(size_t)(lbase + m * NT * (unsigned)sizeof(C)), 16, 0, PF_NT ? 2 : 0);
+        else
+          L[k] = (k <= p.band_k) ? pf_ld_stream(&row[k]) : pf_mk<F>(0, 0);
+      }
+      if (tlj == 0) L[M] = (M <= p.band_k) ? pf_ld_stream(&row[M]) : pf_mk<F>(0, 0);
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0) (gfx9 encoding: lgkmcnt and expcnt left at their maxima)
+    } else {
+      if (!PREFETCH) fetch(R);
+      // phase A: the prefetched row of this component -> its LDS line
+#pragma unroll
+      for (int m = 0; m < 8; m++) L[tlj + m * NT] = nxt[m];
+      if (tlj == 0) L[M] = nxt[8];
+    }
     line_sync();
     // phase B: kz factor + Hermitian fold into the half-length complex line
     C v[8];

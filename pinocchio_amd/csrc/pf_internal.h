@@ -117,6 +117,7 @@ int pf_launch_mixed_c2r(int field_bytes, int n, const PfC2RParams &p, hipStream_
 int pf_launch_mixed_r2c(int field_bytes, int n, const PfR2CParams &p, hipStream_t st);
 
 // ---- per-cell kernels (pf_cell_kernels.hip) ----
+#define PF_KNOT_CAP 512  // knots per spline at most; the five arrays of a spline lie PF_KNOT_CAP doubles apart (y = x + PF_KNOT_CAP ...: spline_for)
 struct PfSplineDev {
   const double *x, *y, *c, *b, *d;  // knots, GSL cspline c_i, and the per-interval b_i, d_i (pf_spline_bd)
   int n;
