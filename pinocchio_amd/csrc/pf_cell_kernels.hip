@@ -19,6 +19,9 @@
 #define PF_SOLVE_INV_WAVES 4
 #endif
 #define PF_MAX_KNOTS 512
+#ifndef PF_C3_TABLE
+#define PF_C3_TABLE 1  // (0 in an A/B build: the cosine triple from its single degree-22 polynomial)
+#endif
 
 // deterministic block reduction of two doubles: wave shuffle, then thread 0 sums the waves in order
 __device__ __forceinline__ void pf_block_sum2(double &a, double &b, double *sh /* 2*nwaves */) {
@@ -63,6 +66,11 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
   __shared__ double sk[SK];
   __shared__ double red[2 * ((PF_SOLVE_INV_BLOCK > PF_CELL_BLOCK ? PF_SOLVE_INV_BLOCK : PF_CELL_BLOCK) / 64)];
   __shared__ unsigned short slut[TAB ? 1 : GT ? PF_GT_MAX_BINS : PF_SPLINE_LUT_BINS];
+  // C3: the fast flavour's cosine triple from its table of short polynomials (pf_c3tab.h; 2 KB: with the 34.6 + 4 KB above a
+  // workgroup stays under the 40 KB that let four share a CU)
+  constexpr bool C3 = FAST && !SNG && PF_C3_TABLE;
+  __shared__ double sc3[C3 ? PF_C3_DOUBLES : 1];
+  if (C3) for (int i = threadIdx.x; i < PF_C3_DOUBLES; i += blockDim.x) sc3[i] = pf_c3_tab[i];
   const int nk = p.spline.n;
   const bool gt = GT && p.spline.gt != nullptr;  // uniform
   pf_spline_view sv;
@@ -114,6 +122,9 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
   else if (!TAB) { sv.x = sk; sv.y = sk + PF_MAX_KNOTS; sv.c = sk + 2 * PF_MAX_KNOTS; sv.b = sk + 3 * PF_MAX_KNOTS; sv.d = sk + 4 * PF_MAX_KNOTS; }
   else { sv.x = sk; sv.y = sv.c = sv.b = sv.d = sk; }
   sv.n = nk;
+  const double *c3tab = C3 ? sc3 : nullptr;
+  if (C3) __builtin_assume(c3tab != nullptr);  // (an LDS address is not known to differ from null: without this both forms are kept, behind a branch)
+  sv.c3tab = c3tab;
   pf_sng_cosmo sc;
   if (SNG) {
     sc.Omega0 = p.ct.sng_cosmo[0]; sc.OmegaLambda = p.ct.sng_cosmo[1]; sc.OmegaRad = p.ct.sng_cosmo[2]; sc.OmegaK = p.ct.sng_cosmo[3];
@@ -164,9 +175,9 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
     if (INV) {
       const double third = d[0] * (1.0 / 3.0);  // an exactly isotropic tensor: its diagonal is not stored
       const double diag[3] = {third, third, third};
-      have_lam = pf_eigen_from_invariants<FAST>(d[0], d[1], d[2], diag, lam);
+      have_lam = pf_eigen_from_invariants<FAST>(d[0], d[1], d[2], diag, lam, c3tab);
     } else {
-      have_lam = pf_ordered_eigenvalues<FAST>(d, lam);
+      have_lam = pf_ordered_eigenvalues<FAST>(d, lam, c3tab);
     }
     // TABULATED_CT: the same eigenvalues, then the table instead of ell() (src/collapse_times.c:749)
     const double Fnew = !have_lam ? -10.0

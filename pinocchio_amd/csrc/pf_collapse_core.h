@@ -17,6 +17,7 @@
 #pragma once
 #include <math.h>
 #include "pf_gtab.h"
+#include "pf_c3tab.h"
 
 // No FMA contraction in the solver: several steps subtract nearly equal numbers
 // (r*r - q*q*q at a double root, the cubic's -(s + q/s) - a1/3), where a fused
@@ -56,6 +57,8 @@ struct pf_spline_view {
   double x_first = 0.0, x_last = 0.0;  // x[0], x[n-1] when lut is set (registers instead of two broadcast reads per call)
   // fast flavour: the composite 10^(-S(log10 D)) as one table of polynomials in D (pf_gtab.h); rec == nullptr: none
   pf_gtab_view gt;
+  // fast flavour: the table form of the cosine triple (pf_cos3_of_acos_tab); nullptr: the single polynomial
+  const double *c3tab = nullptr;
 };
 #define PF_SPLINE_LUT_BINS 4096
 
@@ -228,6 +231,39 @@ PF_HD void pf_cos3_of_acos(double x, double &c1, double &c2, double &c3) {
   c3 = -0.5 * cs + g;
 }
 
+// The same triple with h from a table of short polynomials (pf_c3tab.h: 32 pieces of t in [-1, 1], degree 7 in u = t - centre,
+// Chebyshev interpolants fitted in 60-digit arithmetic by profiles/tools/make_c3tab.py; 2 KB, in LDS in the cell kernels): the piece
+// from s itself (t + 1 = s sqrt 2), 7 Horner steps instead of 22 -- 13 operations for h where the single polynomial takes 22.  Each
+// piece lies 64 and more of its half-widths from the singularity at t = -3: truncation below 1e-17, the result within the same
+// 2 ulp of the reference's calls as the single polynomial (tests/test_collapse_core.py, both forms against mpmath).
+PF_HD void pf_cos3_of_acos_tab(const double *tab, double x, double &c1, double &c2, double &c3) {
+  const double s = pf_sqrt_fast(1.0 + x);                 // NaN for x < -1
+  int i = (int)(s * (PF_C3_BINS * 0.70710678118654752440));
+#if !defined(__HIP_DEVICE_COMPILE__)
+  if (!(s >= 0.0)) i = 0;                                 // (the device's conversion gives 0 for NaN; the NaN itself goes on through u)
+#endif
+  i = i < PF_C3_BINS - 1 ? i : PF_C3_BINS - 1;            // x = 1: the last piece
+  const double u = fma((double)i, -2.0 / PF_C3_BINS, fma(s, 1.41421356237309504880, -1.0 / PF_C3_BINS));  // t - centre_i
+  const double *r = tab + i * (PF_C3_DEG + 1);
+  double h = r[PF_C3_DEG];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int k = PF_C3_DEG - 1; k >= 0; k--) h = fma(h, u, r[k]);
+  const double w = (1.0 - x) * h;                         // 1 - c1
+  const double cs = 1.0 - w;
+  const double sn = pf_sqrt_fast(w * (1.0 + cs));         // NaN for x > 1
+  const double g = 0.86602540378443864676 * sn;
+  c1 = fma(0.0, sn, cs);
+  c2 = -0.5 * cs - g;
+  c3 = -0.5 * cs + g;
+}
+// (tab: the table where the caller has one at hand -- a compile-time fact in the kernels -- else the single polynomial)
+PF_HD void pf_cos3_fast(const double *tab, double x, double &c1, double &c2, double &c3) {
+  if (tab) pf_cos3_of_acos_tab(tab, x, c1, c2, c3);
+  else pf_cos3_of_acos(x, c1, c2, c3);
+}
+
 // x / Y for a constant Y, correctly rounded, in three operations (Markstein): with c = RN(1/Y), q0 = RN(x c),
 // the residual x - Y q0 is exact in an fma and q0 + residual c rounds to RN(x / Y) -- the same double the
 // reference's division produces, so the q^3 < r^2 sentinel test sees the reference's own q and r
@@ -377,12 +413,12 @@ template <bool FAST = false> PF_HD double pf_ell_one_root(const pf_cubic &c) {
   if (ell < 0.) ell = -.1;
   return ell;
 }
-template <bool FAST = false> PF_HD double pf_ell_three_roots(const pf_cubic &c) {
+template <bool FAST = false> PF_HD double pf_ell_three_roots(const pf_cubic &c, const double *c3tab = nullptr) {
   const double a1 = c.a1, q = c.q, r = c.r;
   const double sq = 2 * (FAST ? pf_sqrt_fast(q) : sqrt(q));
   const double inv_3 = 1.0 / 3;
   double c1, c2, c3;
-  if (FAST) pf_cos3_of_acos(pf_div_fast(2 * r, q * sq), c1, c2, c3);
+  if (FAST) pf_cos3_fast(c3tab, pf_div_fast(2 * r, q * sq), c1, c2, c3);
   else pf_cos3_libm(acos(2 * r / q / sq), c1, c2, c3);
   double s1 = -sq * c1 - a1 * inv_3;
   double s2 = -sq * c2 - a1 * inv_3;
@@ -405,12 +441,12 @@ template <bool FAST = false> PF_HD double pf_ell_finish(double ell, double l1, d
   }
   return ell;
 }
-template <bool FAST = false> PF_HD double pf_ell_classic(double l1, double l2, double l3) {
+template <bool FAST = false> PF_HD double pf_ell_classic(double l1, double l2, double l3, const double *c3tab = nullptr) {
   double ell = 0.0;
   pf_cubic c;
   const int kind = pf_ell_setup<FAST>(l1, l2, l3, ell, c);
   if (kind == 1) ell = pf_ell_one_root<FAST>(c);
-  else if (kind == 2) ell = pf_ell_three_roots<FAST>(c);
+  else if (kind == 2) ell = pf_ell_three_roots<FAST>(c, c3tab);
   return pf_ell_finish<FAST>(ell, l1, l2, l3);
 }
 
@@ -480,7 +516,7 @@ PF_HD bool pf_invariants_lose_diagonal(const double d[6], double mu1, double mu2
   const double third = mu1 * (1.0 / 3.0);
   return !(d[0] == third && d[1] == third && d[2] == third);
 }
-template <bool FAST = false> PF_HD bool pf_eigen_from_invariants(double mu1, double mu2, double mu3, const double diag[3], double lam[3]) {
+template <bool FAST = false> PF_HD bool pf_eigen_from_invariants(double mu1, double mu2, double mu3, const double diag[3], double lam[3], const double *c3tab = nullptr) {
   const double mu1_2 = mu1 * mu1;
   const double q = FAST ? pf_div_const<9>(mu1_2 - 3.0 * mu2) : (mu1_2 - 3.0 * mu2) / 9.0;
   double x1, x2, x3;
@@ -496,7 +532,7 @@ template <bool FAST = false> PF_HD bool pf_eigen_from_invariants(double mu1, dou
     const double sq = 2 * (FAST ? pf_sqrt_fast(q) : sqrt(q));
     const double inv_3 = 1.0 / 3.0;
     double c1, c2, c3;
-    if (FAST) pf_cos3_of_acos(pf_div_fast(2 * r, q * sq), c1, c2, c3);
+    if (FAST) pf_cos3_fast(c3tab, pf_div_fast(2 * r, q * sq), c1, c2, c3);
     else pf_cos3_libm(acos(2 * r / q / sq), c1, c2, c3);
     x1 = -sq * c1 + mu1 * inv_3;
     x2 = -sq * c2 + mu1 * inv_3;
@@ -511,15 +547,15 @@ template <bool FAST = false> PF_HD bool pf_eigen_from_invariants(double mu1, dou
   lam[0] = hi; lam[1] = mid; lam[2] = lo;
   return true;
 }
-template <bool FAST = false> PF_HD bool pf_ordered_eigenvalues(const double d[6], double lam[3]) {
+template <bool FAST = false> PF_HD bool pf_ordered_eigenvalues(const double d[6], double lam[3], const double *c3tab = nullptr) {
   double mu1, mu2, mu3;
   pf_invariants(d, mu1, mu2, mu3);
-  return pf_eigen_from_invariants<FAST>(mu1, mu2, mu3, d, lam);
+  return pf_eigen_from_invariants<FAST>(mu1, mu2, mu3, d, lam, c3tab);
 }
 
 // ell (src/collapse_times.c:404-427, ELL_CLASSIC): F = 1 + z_collapse, or 0 when the ellipsoid never collapses
 template <bool FAST = false> PF_HD double pf_ell(const pf_spline_view &s, double l1, double l2, double l3) {
-  const double bc = pf_ell_classic<FAST>(l1, l2, l3);
+  const double bc = pf_ell_classic<FAST>(l1, l2, l3, s.c3tab);
   if (bc > 0.0) return 1. + pf_inverse_growing_mode<FAST>(s, bc);
   return 0.0;
 }
@@ -527,7 +563,7 @@ template <bool FAST = false> PF_HD double pf_ell(const pf_spline_view &s, double
 // d = {11,22,33,12,13,23}.  Returns F = 1 + z_collapse (0: never collapses,
 // -10: eigen-solver sentinel).  lam[3] receives the ordered eigenvalues.
 template <bool FAST = false> PF_HD double pf_inverse_collapse_time(const double d[6], const pf_spline_view &s, double lam[3]) {
-  if (!pf_ordered_eigenvalues<FAST>(d, lam)) return -10.0;
+  if (!pf_ordered_eigenvalues<FAST>(d, lam, s.c3tab)) return -10.0;
   return pf_ell<FAST>(s, lam[0], lam[1], lam[2]);
 }
 

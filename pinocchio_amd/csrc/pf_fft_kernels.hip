@@ -420,6 +420,9 @@ __global__ void __launch_bounds__(TL *(N / 16)) k_c2r_persistent(const PfC2RPara
 #ifndef PF_ZI_WAVES
 #define PF_ZI_WAVES 0       // (A/B: waves per SIMD the compiler is asked to make room for; 0: its own choice)
 #endif
+#ifndef PF_ZI_OWN
+#define PF_ZI_OWN 1         // (A/B) 0: phase B reads both operands of the fold from LDS
+#endif
 #ifndef PF_ZI_DMA
 #define PF_ZI_DMA 0         // (A/B) 1: 1024-point fp64 rows are loaded straight into LDS
 #endif
@@ -514,7 +517,8 @@ k_c2r_invariants(const PfC2RParams p, long long nrows) {
 #pragma unroll
     for (int m = 0; m < 8; m++) {
       const int e = tlj + m * NT;
-      v[m] = pf_zfold<F>(L[e], L[M - e], e, M, mul, kf, tw[e]);
+      // (element e itself is still in the register it was loaded into, where the row was loaded by this iteration)
+      v[m] = pf_zfold<F>((PF_ZI_OWN && !PREFETCH && !DMA) ? nxt[m] : L[e], L[M - e], e, M, mul, kf, tw[e]);
     }
     line_sync();
     if (PREFETCH && R + gridDim.x < nrows) fetch(R + gridDim.x);  // in flight during the stages and the reduction below

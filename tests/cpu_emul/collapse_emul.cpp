@@ -139,3 +139,7 @@ extern "C" void emul_exp(const double *x, long count, double *e, double *e10) {
 extern "C" void emul_cos3(const double *x, long count, double *c) {
   for (long i = 0; i < count; i++) pf_cos3_of_acos(x[i], c[3 * i], c[3 * i + 1], c[3 * i + 2]);
 }
+// ... and its table form (pf_c3tab.h), as the cell kernels call it
+extern "C" void emul_cos3_tab(const double *x, long count, double *c) {
+  for (long i = 0; i < count; i++) pf_cos3_fast(pf_c3_tab, x[i], c[3 * i], c[3 * i + 1], c[3 * i + 2]);
+}

@@ -259,21 +259,26 @@ def test_log10_of_the_fast_flavour(emul):
     assert got[len(x) - 9] == 0.0          # log10(1)
 
 
-def test_cosine_triple_of_the_fast_flavour(emul):
-    """pf_cos3_of_acos(x) = cos((acos x + 2 pi k) / 3), k = 0, 1, 2, without acos and sincos (one polynomial, two square roots)
+@pytest.mark.parametrize("form", ["emul_cos3", "emul_cos3_tab"])
+def test_cosine_triple_of_the_fast_flavour(emul, form):
+    """pf_cos3_of_acos(x) = cos((acos x + 2 pi k) / 3), k = 0, 1, 2, without acos and sincos (one polynomial, two square roots;
+    emul_cos3_tab: the polynomial from the table of 32 short ones, pf_c3tab.h, the form the cell kernels run)
     against mpmath (40 digits): c_1 within 2 ulp everywhere on [-1, 1]; c_2, c_3 within 2 ulp of their own magnitude scale (they
     are -c_1/2 -+ sqrt(3)/2 sin: absolute error a few 1e-16) where the triple is well conditioned, and -- next to x = 1, where
     1 - x carries the rounding of x itself -- within the change a 1-ulp change of x makes; NaN in all three outside [-1, 1]"""
     import mpmath as mp
     mp.mp.dps = 40
-    emul.emul_cos3.argtypes = [dp, C.c_long, dp]
+    cos3 = getattr(emul, form)
+    cos3.argtypes = [dp, C.c_long, dp]
     rng = np.random.default_rng(33)
     x = np.concatenate([rng.uniform(-1, 1, 20000), 1.0 - 10.0 ** rng.uniform(-16, 0, 5000), -1.0 + 10.0 ** rng.uniform(-16, 0, 5000),
                         10.0 ** rng.uniform(-300, -1, 1000), -10.0 ** rng.uniform(-300, -1, 1000),
                         [0.0, 1.0, -1.0, 0.5, -0.5, np.nextafter(1.0, 0.0), np.nextafter(-1.0, 0.0)]])
+    edges = 2.0 * (np.arange(33) / 32.0) ** 2 - 1.0   # the ends of the table's pieces (y = j / 32), and their neighbours
+    x = np.concatenate([x, edges, np.nextafter(edges, 2.0), np.nextafter(edges, -2.0), np.nextafter(np.nextafter(edges, 2.0), 2.0)])
     x = np.clip(x, -1.0, 1.0)
     got = np.empty((len(x), 3))
-    emul.emul_cos3(_dp(x), len(x), _dp(got))
+    cos3(_dp(x), len(x), _dp(got))
     want = np.empty((len(x), 3))
     for i, v in enumerate(x):
         t = mp.acos(mp.mpf(float(v)))
@@ -293,7 +298,7 @@ def test_cosine_triple_of_the_fast_flavour(emul):
     assert np.max(np.abs(res)) < 4e-15    # (the residual itself is evaluated in double: |f'| <= 9)
     assert (got[:, 0] >= got[:, 2]).all() and (got[:, 2] >= got[:, 1]).all()
     out = np.empty(9)
-    emul.emul_cos3(_dp(np.array([1.0000001, -1.5, np.nan])), 3, _dp(out))
+    cos3(_dp(np.array([1.0000001, -1.5, np.nan])), 3, _dp(out))
     assert np.all(np.isnan(out))
 
 
