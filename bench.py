@@ -208,6 +208,8 @@ def parse_args(argv=None):
                     help="nccl (= RCCL): one rank per GPU, the measurement.  gloo-host: a bring-up path for boxes with ONE GPU -- gloo process "
                          "group, every rank on device 0, exchanges staged through host memory (pinocchio_amd/dist.py HostStagedKind): it "
                          "exercises this script's multi-rank code end to end (tests/test_gpu_gloo_ranks.py); its numbers mean nothing")
+    ap.add_argument("--check", type=int, default=1,
+                    help="1: after the timed region, fingerprint Fmax / Rmax / the displacements and compare with the single-GPU golden of the configuration (tests/golden/bench_fingerprints.json)")
     ap.add_argument("--slab-of", type=int, default=0,
                     help="P > 1: time the kernels of ONE rank of a P-rank run of the n^3 box on this GPU, exchange short-circuited (see run_slab)")
     ap.add_argument("--dry-launch", action="store_true",
@@ -256,6 +258,60 @@ def launch_ranks(args, argv) -> int:
         print("[bench] the ranks exited 0 without printing a line", file=sys.stderr, flush=True)
         return 4
     return rc
+
+
+FINGERPRINT_STRIDE = 7      # every 7th cell of the box (a stride coprime to the grid: every plane, row and column is sampled)
+FINGERPRINT_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "bench_fingerprints.json")
+
+
+def fingerprint_of_column(values: np.ndarray, first_global: int) -> int:
+    """Order-independent, exact fingerprint of one column of products: the sum over the sampled cells of (bits of the value) x
+    (a 64-bit weight of the cell's GLOBAL index), modulo 2^64.  Integer arithmetic: the sums of the ranks add up to the
+    single-GPU number exactly, whatever the decomposition, if and only if every sampled value is bit for bit the same.
+    values: this rank's slab, one 32-bit word per entry ((cells,) or (cells, 3)), first_global: global index of its first entry"""
+    flat = np.ascontiguousarray(values).reshape(-1).view(np.uint32)
+    total = 0
+    chunk = 1 << 24
+    start = (-first_global) % FINGERPRINT_STRIDE
+    with np.errstate(over="ignore"):
+        for a in range(start, flat.size, chunk * FINGERPRINT_STRIDE):
+            v = flat[a:a + chunk * FINGERPRINT_STRIDE:FINGERPRINT_STRIDE].astype(np.uint64)
+            g = np.uint64(first_global + a) + np.arange(v.size, dtype=np.uint64) * np.uint64(FINGERPRINT_STRIDE)
+            w = (g * np.uint64(0x9E3779B97F4A7C15)) ^ (g >> np.uint64(7)) | np.uint64(1)
+            total = (total + int(np.sum(v * w, dtype=np.uint64))) & 0xFFFFFFFFFFFFFFFF
+    return total
+
+
+def result_fingerprint(f, rank: int, lpt: bool) -> dict:
+    """this rank's share of the fingerprints of Fmax, Rmax and (with the LPT part) the last-formed displacement, 3LPT(b)"""
+    cells = f.nxl * f.n * f.n
+    out = {"FMAX": fingerprint_of_column(f.block("FMAX"), rank * cells), "RMAX": fingerprint_of_column(f.block("RMAX"), rank * cells)}
+    if lpt:
+        for name in ("ZEL ", "2LPT", "31PT"):
+            out[name] = fingerprint_of_column(f.block(name), 3 * rank * cells)
+        # the 3LPT(b) displacement carries the all-reduced mean of the 2LPT source, whose summation order is the decomposition's:
+        # equal to a few ulp, not bit for bit (tests/test_gpu_multirank.py) -- its sampled sum of squares instead, in float
+        v = f.block("32PT").reshape(-1)[(-3 * rank * cells) % FINGERPRINT_STRIDE::FINGERPRINT_STRIDE].astype(np.float64)
+        out["32PT_sumsq"] = float(np.dot(v, v))
+    return out
+
+
+def fingerprints_agree(a: dict, b: dict) -> bool:
+    """hex entries (exact sums) equal; float entries (sums of squares of the one column that is not bit-reproducible over
+    decompositions) to 1e-6"""
+    if set(a) != set(b):
+        return False
+    for k in a:
+        if isinstance(a[k], str) or isinstance(b[k], str):
+            if a[k] != b[k]:
+                return False
+        elif abs(a[k] - b[k]) > 1e-6 * abs(b[k]):
+            return False
+    return True
+
+
+def fingerprint_key(n: int, ns: int, lpt: bool, fb: int) -> str:
+    return f"n{n}_ns{ns}_{'lpt' if lpt else 'fmax'}_fb{fb}"
 
 
 def run_config(args, rank, world, device, dist, torch, replicate_env, votes_out, solve_inline=False):
@@ -339,6 +395,25 @@ def run_config(args, rank, world, device, dist, torch, replicate_env, votes_out,
             t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.backend == "gloo-host" else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+        # what the timed steps left in `products`, after the timed region: exact fingerprints (and the Fmax histogram), to be held
+        # against those of a single-GPU run of the same configuration -- a decomposition that moves a block to the wrong place
+        # still runs at full speed
+        check = None
+        if args.check and not solve_inline:
+            try:
+                pdf = f.Fmax_PDF()   # (collective: all-reduced over the ranks)
+                mine = result_fingerprint(f, rank, lpt)
+                parts = [mine]
+                if world > 1:
+                    parts = [None] * world
+                    dist.all_gather_object(parts, mine)
+                fp = {k: ("%016x" % (sum(p[k] for p in parts) & 0xFFFFFFFFFFFFFFFF) if isinstance(mine[k], int) else float(sum(p[k] for p in parts)))
+                      for k in mine}
+                fp["PDF"] = "%016x" % (int(np.sum(pdf * (np.arange(1, pdf.size + 1, dtype=np.uint64) * np.uint64(0x100000001B3)), dtype=np.uint64)) & 0xFFFFFFFFFFFFFFFF)
+                check = {"fingerprint": fp, "cells_in_fmax_pdf": int(pdf.sum())}
+            except (RuntimeError, api.PinfmaxError) as e:
+                check = {"error": str(e)}
+        res["check"] = check
         # streaming yardsticks of this box and process, after the timed region: a kernel that only reads / writes / copies a field
         stream = None
         if world == 1 and not (n & (n - 1)):
@@ -688,6 +763,25 @@ def main():
                 ex["alternative"]["value"] = cells * args.steps / alt["dt"]
                 print("[bench] alternative: " + json.dumps(ex["alternative"]), file=sys.stderr, flush=True)
             out["exchange"] = ex
+        chk = res.get("check")
+        if chk is not None:
+            golden = None
+            try:
+                golden = json.load(open(FINGERPRINT_FILE)).get(fingerprint_key(n, ns, lpt, w))
+            except (OSError, ValueError):
+                pass
+            if "fingerprint" in chk:
+                chk["golden"] = golden["fingerprint"] if golden else None
+                chk["matches_single_gpu_golden"] = fingerprints_agree(chk["fingerprint"], golden["fingerprint"]) if golden else None
+                # (a golden made from other kernel sources may legitimately differ in last bits: say which it is)
+                chk["golden_from_these_sources"] = (golden.get("kernel_source_sha") == _lib.source_sha()) if golden else None
+                chk["note"] = ("hex entries: sums over every 7th cell of (bits of the value) x (weight of the global cell index) mod 2^64, added over the ranks -- equal to "
+                               "the golden (a single-GPU run of this configuration, tests/golden/make_bench_fingerprints.py) iff those cells are bit for "
+                               "bit the same; 32PT_sumsq: the one column whose last bits depend on the summation order of an all-reduce, compared to 1e-6; "
+                               "PDF: the 210-bin Fmax histogram; computed after the timed region")
+                if golden and not chk["matches_single_gpu_golden"]:
+                    print(f"[bench] RESULT CHECK FAILED: fingerprints {chk['fingerprint']} differ from the single-GPU golden {golden['fingerprint']}", file=sys.stderr, flush=True)
+            out["result_check"] = chk
         if exact:
             out["exact_libm"] = exact
         if world == 1 and args.cpu_n:

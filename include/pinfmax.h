@@ -36,7 +36,7 @@ typedef struct {
   int64_t n;        /* GSglobal[_x_] = [_y_] = [_z_] : cubic grid (the reference accepts any GridSize: src/fmax-pfft.c:139-188).
                        Power of two in 16..2048: the hand-written transform passes (any nranks, fp64 or fp32 fields).
                        n = 8 m, m = 2^a 3^b 5^c, up to 2048 (24, 40, 200, 384, 768, 1000, 1536 ...): the hand-written passes on
-                       run-time stage plans, one rank, fp64 or fp32 fields.  Any other even size in 4..4096: library (hipFFT)
+                       run-time stage plans, any nranks (a power of two), fp64 or fp32 fields.  Any other even size in 4..4096: library (hipFFT)
                        transforms, one rank and fp64 fields only.  pf_transform_path() says which */
   int     rank;     /* ThisTask */
   int     nranks;   /* NTasks; x-slabs, nranks must divide n */

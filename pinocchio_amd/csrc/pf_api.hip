@@ -360,9 +360,9 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   const bool pow2 = !(n & (n - 1));
   PfTuning tune;
   read_tuning(&tune);
-  // not a power of two: the run-time stage plans of pf_mixed_kernels.hip where they apply (n = 8 m, m = 2^a 3^b 5^c; one rank),
-  // library transforms (the "general path") for the rest
-  const bool mixed = !pow2 && !tune.general && cfg->nranks == 1 && pf_mixed_supported((int)n);
+  // not a power of two: the run-time stage plans of pf_mixed_kernels.hip where they apply (n = 8 m, m = 2^a 3^b 5^c; slabs of
+  // n / P planes over 1, 2, 4 or 8 ... ranks), library transforms (the "general path", one rank) for the rest
+  const bool mixed = !pow2 && !tune.general && pf_mixed_supported((int)n);
   const bool want_general = (!pow2 && !mixed) || tune.general;
   if (want_general) {
     if (n < 4 || n > 4096 || (n & 1)) return pf_fail(rank, "pf_create: grid size %lld must be even, in [4, 4096]", n);
@@ -373,7 +373,6 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   if (cfg->nranks < 1 || n % cfg->nranks || cfg->rank < 0 || cfg->rank >= cfg->nranks)
     return pf_fail(rank, "pf_create: nranks %d must divide the grid size %lld (slab decomposition)", cfg->nranks, n);
   if (cfg->nranks & (cfg->nranks - 1)) return pf_fail(rank, "pf_create: nranks %d must be a power of two", cfg->nranks);
-  if (!pow2 && !want_general && cfg->nranks != 1) return pf_fail(rank, "pf_create: grid size %lld is not a power of two: one rank only", n);
   if (cfg->field_bytes != 8 && cfg->field_bytes != 4) return pf_fail(rank, "pf_create: field_bytes must be 8 or 4");
   if ((cfg->flags & PF_FLAG_DOUBLE_PRODUCTS) && cfg->field_bytes != 8)
     return pf_fail(rank, "pf_create: PF_FLAG_DOUBLE_PRODUCTS (fp64 Fmax and displacements) needs fp64 fields");
@@ -547,10 +546,10 @@ static int allreduce_dev(pf_ctx *c, void *buf, size_t count, int is_u64) {
 // ---------------------------------------------------------- pass helpers ----
 static int ilog2i(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
 static PfAddr addr_ky_x(const pf_ctx *c) {  // KY layout, e = x, outer = y_local
-  PfAddr a; a.os = c->nzp; a.el_shift = ilog2i(c->n); a.ehs = 0; a.els = (long long)c->nyl * c->nzp; return a;
+  PfAddr a; a.os = c->nzp; a.el_shift = ilog2i(c->n); a.el_len = c->n; a.ehs = 0; a.els = (long long)c->nyl * c->nzp; return a;
 }
 static PfAddr addr_blocks_y(const pf_ctx *c) {  // P blocks [p][nxl][nyl][nzp], e = y = p*nyl + yl, outer = x_local
-  PfAddr a; a.os = (long long)c->nyl * c->nzp; a.el_shift = ilog2i(c->nyl); a.ehs = (long long)c->nxl * c->nyl * c->nzp; a.els = c->nzp; return a;
+  PfAddr a; a.os = (long long)c->nyl * c->nzp; a.el_shift = ilog2i(c->nyl); a.el_len = c->nyl; a.ehs = (long long)c->nxl * c->nyl * c->nzp; a.els = c->nzp; return a;
 }
 // inverse transforms: the x-pass outputs are laid out with the slab row slowest, [q][y_local][x_local][nzp] -- the send /
 // receive blocks of a multi-rank run, and for one rank simply [y][x][nzp]: the x-pass then writes its 1024 segments of a
@@ -559,24 +558,24 @@ static PfAddr addr_blocks_y(const pf_ctx *c) {  // P blocks [p][nxl][nyl][nzp], 
 // (unchanged within the box-to-box spread).
 // zp: row pitch inside the blocks (nzp, or the compact pitch of a band-limited item); the blocks keep their places
 static PfAddr addr_yblocks_x(const pf_ctx *c, int zp) {  // x-pass output: e = x = q*nxl + xl, outer = y_local
-  PfAddr a; a.os = (long long)c->nxl * zp; a.el_shift = ilog2i(c->nxl); a.ehs = (long long)c->nyl * c->nxl * c->nzp; a.els = zp; return a;
+  PfAddr a; a.os = (long long)c->nxl * zp; a.el_shift = ilog2i(c->nxl); a.el_len = c->nxl; a.ehs = (long long)c->nyl * c->nxl * c->nzp; a.els = zp; return a;
 }
 static PfAddr addr_yblocks_y(const pf_ctx *c, int zp) {  // y-pass input: e = y = p*nyl + yl, outer = x_local
-  PfAddr a; a.os = zp; a.el_shift = ilog2i(c->nyl); a.ehs = (long long)c->nyl * c->nxl * c->nzp; a.els = (long long)c->nxl * zp; return a;
+  PfAddr a; a.os = zp; a.el_shift = ilog2i(c->nyl); a.el_len = c->nyl; a.ehs = (long long)c->nyl * c->nxl * c->nzp; a.els = (long long)c->nxl * zp; return a;
 }
 // replicated delta(k): the x-pass reads the whole spectrum [kx][ky][kz] (outer = global ky) ...
 static PfAddr addr_full_x(const pf_ctx *c) {
-  PfAddr a; a.os = c->nzp; a.el_shift = ilog2i(c->n); a.ehs = 0; a.els = (long long)c->n * c->nzp; return a;
+  PfAddr a; a.os = c->nzp; a.el_shift = ilog2i(c->n); a.el_len = c->n; a.ehs = 0; a.els = (long long)c->n * c->nzp; return a;
 }
 // ... and writes this rank's x-slab of every line as [ky][x_local][zp]: what the y-pass then reads in place (e = ky)
 static PfAddr addr_local_x(const pf_ctx *c, int zp) {
-  PfAddr a; a.os = (long long)c->nxl * zp; a.el_shift = ilog2i(c->nxl); a.ehs = 0; a.els = zp; return a;
+  PfAddr a; a.os = (long long)c->nxl * zp; a.el_shift = ilog2i(c->nxl); a.el_len = c->nxl; a.ehs = 0; a.els = zp; return a;
 }
 static PfAddr addr_local_y(const pf_ctx *c, int zp) {
-  PfAddr a; a.os = zp; a.el_shift = ilog2i(c->n); a.ehs = 0; a.els = (long long)c->nxl * zp; return a;
+  PfAddr a; a.os = zp; a.el_shift = ilog2i(c->n); a.el_len = c->n; a.ehs = 0; a.els = (long long)c->nxl * zp; return a;
 }
 static PfAddr addr_xs_y(const pf_ctx *c) {  // XS layout, e = y, outer = x_local
-  PfAddr a; a.os = (long long)c->n * c->nzp; a.el_shift = ilog2i(c->n); a.ehs = 0; a.els = c->nzp; return a;
+  PfAddr a; a.os = (long long)c->n * c->nzp; a.el_shift = ilog2i(c->n); a.el_len = c->n; a.ehs = 0; a.els = c->nzp; return a;
 }
 
 struct Job { const void *in; void *out; int mul; };
@@ -1952,7 +1951,7 @@ extern "C" int pf_debug_lines(int field_bytes, int n, int pass, int mul, int ban
     if (pass <= 1) {
       PfStridedParams p; memset(&p, 0, sizeof(p));
       p.njobs = 1; p.job[0].in = d_in; p.job[0].out = d_out; p.job[0].mul = mul;
-      p.ain.os = (long long)n * pc; p.ain.el_shift = ilog2i(n); p.ain.ehs = 0; p.ain.els = pc; p.aout = p.ain;
+      p.ain.os = (long long)n * pc; p.ain.el_shift = ilog2i(n); p.ain.el_len = n; p.ain.ehs = 0; p.ain.els = pc; p.aout = p.ain;
       p.ncols = ncols; p.nouter = nouter; p.pre = pre; p.outer_offset = outer_offset; p.rs = rs; p.growth = growth; p.tw = d_tw; p.etab = d_etab;
       p.band_e = p.band_outer = n; p.dev = dev;
       if (band < n / 2) p.band_e = band;

@@ -32,8 +32,9 @@ enum { PF_MUL_ONE = 0, PF_MUL_K = 1, PF_MUL_K2 = 2, PF_MUL_IK = 3 };
 // (e / el, e % el) lets the y-pass read the P received all-to-all blocks in place.
 struct PfAddr {
   long long os;
-  int el_shift;  // el = 1 << el_shift (slab thickness; a power of two because n and P are)
+  int el_shift;  // el = 1 << el_shift (slab thickness; a power of two where n and P are: what the power-of-two kernels split by)
   long long ehs, els;
+  int el_len;    // the slab thickness itself (n, n / P): what the mixed-radix kernels split by (multiply-high), any length
 };
 
 struct PfStridedJob {
@@ -109,7 +110,7 @@ int pf_launch_r2c(int field_bytes, int n, const PfR2CParams &p, hipStream_t st);
 
 // ---- grid sizes that are not a power of two (pf_mixed_kernels.hip): the same three passes with a run-time stage plan ----
 #define PF_MIXED_MAX_STAGES 12
-struct PfMixedPlan { int n, nstages; int radix[PF_MIXED_MAX_STAGES]; unsigned magic[PF_MIXED_MAX_STAGES]; };
+struct PfMixedPlan { int n, nstages; int radix[PF_MIXED_MAX_STAGES]; unsigned magic[PF_MIXED_MAX_STAGES]; unsigned magic_in, magic_out; /* ceil(2^32 / el_len) of the launch's input and output layouts (strided passes) */ };
 bool pf_mixed_plan(int n, bool allow4, PfMixedPlan *pl);
 bool pf_mixed_supported(int n);   // n = 8 m with m = 2^a 3^b 5^c, up to 2048: strided passes on n, z-passes on n / 2
 int pf_launch_mixed_strided(int field_bytes, int n, int dir, const PfStridedParams &p, hipStream_t st);

@@ -138,8 +138,8 @@ __device__ __forceinline__ void pf_mixed_tail(const PfMixedPlan &pl, int tl, con
 // ------------------------------------------------------------------------------------------------ strided passes ----
 // x- or y-pass: a workgroup owns T adjacent columns of one line of tiles and all n points along the transformed axis
 // (n / 8 threads per column).  Parameters and semantics: PfStridedParams, as k_strided.
-// Threads: (c, tl) = (threadIdx.x, threadIdx.y), T = blockDim.x columns.  One rank: a line's element e sits at e * els (the
-// slab split of PfAddr is not needed; the launcher checks it), so an address is a 64-bit base per job plus a 32-bit offset.
+// Threads: (c, tl) = (threadIdx.x, threadIdx.y), T = blockDim.x columns.  A line's element e sits in slab e / el_len at row
+// e % el_len (PfAddr: the blocks of a multi-rank layout; one rank: e * els) -- the quotient by multiply-high, any slab length.
 // The tile is loaded for every job (jobs on the same input find it in L2): the eight points of a thread then live only
 // through one job, which is what lets the run-time plan fit the register file.
 template <typename F, int DIR>
@@ -161,7 +161,20 @@ __global__ void __launch_bounds__(1024) k_mixed_strided(const PfStridedParams p,
   if (so > half) so -= n;
   if (p.band_outer < half && (so > p.band_outer || so < -p.band_outer)) return;  // (uniform: the whole workgroup leaves)
   const long long base_in = (long long)outer * p.ain.os + col, base_out = (long long)outer * p.aout.os + col;
-  const unsigned els_in = (unsigned)p.ain.els, els_out = (unsigned)p.aout.els;
+  // element e of a line: slab e / el_len, row e % el_len of it (PfAddr) -- one rank, or a layout whose slabs follow each other
+  // at their own length: e * els.  The quotient by multiply-high (exact for e < 2^16 with the rounded-up reciprocal).
+  const unsigned len_in = (unsigned)p.ain.el_len, len_out = (unsigned)p.aout.el_len;
+  const unsigned mg_in = pl.magic_in, mg_out = pl.magic_out;
+  auto off_in = [&](unsigned e) -> size_t {
+    if (len_in >= (unsigned)n) return (size_t)e * (size_t)p.ain.els;
+    const unsigned q = __umulhi(e, mg_in), s = e - q * len_in;
+    return (size_t)q * (size_t)p.ain.ehs + (size_t)s * (size_t)p.ain.els;
+  };
+  auto off_out = [&](unsigned e) -> size_t {
+    if (len_out >= (unsigned)n) return (size_t)e * (size_t)p.aout.els;
+    const unsigned q = __umulhi(e, mg_out), s = e - q * len_out;
+    return (size_t)q * (size_t)p.aout.ehs + (size_t)s * (size_t)p.aout.els;
+  };
   double ko2kc2 = 0.0, woc = 1.0;
   if (p.pre) {
     const double ko = kf * so, kc = kf * col;
@@ -181,7 +194,7 @@ __global__ void __launch_bounds__(1024) k_mixed_strided(const PfStridedParams p,
       const int e = tlj + m * nt;
       const int se = e > half ? e - n : e;
       const bool inband = se <= p.band_e && se >= -p.band_e;
-      C x = (valid && inband) ? pf_ld_stream(in + (size_t)((unsigned)e * els_in)) : pf_zero<F>();
+      C x = (valid && inband) ? pf_ld_stream(in + off_in((unsigned)e)) : pf_zero<F>();
       const double ke = kf * se;
       if (p.pre) {  // exp(-k^2 rs^2 / 2) g / k^2, zero at k = 0 (src/fmax-pfft.c:366-384)
         const double k2 = ke * ke + ko2kc2;
@@ -198,7 +211,7 @@ __global__ void __launch_bounds__(1024) k_mixed_strided(const PfStridedParams p,
     auto store = [&](int e, C val) {
       if (!valid) return;
       if (p.out_ne > 0 && (unsigned)(e - p.out_e0) >= (unsigned)p.out_ne) return;
-      pf_st_stream(outp + (size_t)((unsigned)e * els_out), val);
+      pf_st_stream(outp + off_out((unsigned)e), val);
     };
     pf_bfly8<DIR>(v);  // stage 0: the thread's own eight points (NS = 1: no twiddles)
     if (pl.nstages == 1) {
@@ -355,9 +368,10 @@ int pf_launch_mixed_strided(int fb, int n, int dir, const PfStridedParams &p, hi
   if (nt * T > 1024 || (size_t)n * T * w > 160 * 1024) return 2;
   const int ntiles = (p.ncols + T - 1) / T;
   const long long nwork = (long long)ntiles * p.nouter;
-  // one rank: the slab split of PfAddr is the identity (e >> el_shift == 0 for every e < n)
-  if ((1 << p.ain.el_shift) < n || (1 << p.aout.el_shift) < n) return 2;
-  if ((unsigned long long)(n - 1) * (unsigned long long)p.ain.els >= (1ull << 32) || (unsigned long long)(n - 1) * (unsigned long long)p.aout.els >= (1ull << 32)) return 2;
+  // slabs of any length (PfAddr::el_len): the split by multiply-high
+  if (p.ain.el_len < 2 || p.aout.el_len < 2) return 2;  // (a slab of one plane would need the quotient e itself: 2^32 does not fit the multiplier)
+  pl.magic_in = (unsigned)((0x100000000ull + (unsigned)p.ain.el_len - 1) / (unsigned)p.ain.el_len);
+  pl.magic_out = (unsigned)((0x100000000ull + (unsigned)p.aout.el_len - 1) / (unsigned)p.aout.el_len);
   const dim3 grid((unsigned)(((nwork + 7) >> 3) << 3)), block(T, nt);
   const size_t shm = (size_t)n * T * w;
 #define PF_MIXED_LAUNCH(FF, DD)                                                                                      \

@@ -61,3 +61,27 @@ def test_fp32_symbols():
     assert bench.symbol_of("ypass_hess_3to6", 1024, 4) == "k_strided<float __vector(2), 1024, 8, 1, true>"
     assert bench.symbol_of("ypass_hess_3to6", 2048, 4) == "k_strided<float __vector(2), 2048, 4, 1, true>"
     assert bench.symbol_of("zpass_c2r_hess_6to3inv", 2048, 4) == "k_c2r_invariants<float, 2048, 0>"
+
+
+def test_result_fingerprint_adds_up_over_any_decomposition():
+    """bench.fingerprint_of_column: the sums of the parts of a column, each with the global index of its first entry, equal the sum
+    of the whole (mod 2^64) wherever it is cut -- and a single changed bit in a sampled cell changes it"""
+    import numpy as np
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal(100003).astype(np.float32)
+    whole = bench.fingerprint_of_column(a, 0)
+    for cut in (1, 6, 7, 8, 50000, 99999):
+        assert (bench.fingerprint_of_column(a[:cut], 0) + bench.fingerprint_of_column(a[cut:], cut)) & 0xFFFFFFFFFFFFFFFF == whole
+    parts = np.array_split(a, 8)
+    first = np.cumsum([0] + [len(p) for p in parts[:-1]])
+    assert sum(bench.fingerprint_of_column(p, int(f)) for p, f in zip(parts, first)) & 0xFFFFFFFFFFFFFFFF == whole
+    b = a.copy()
+    b[14 * bench.FINGERPRINT_STRIDE] = np.nextafter(b[14 * bench.FINGERPRINT_STRIDE], np.float32(9))
+    assert bench.fingerprint_of_column(b, 0) != whole
+    c = a.copy()
+    c[[0, bench.FINGERPRINT_STRIDE]] = c[[bench.FINGERPRINT_STRIDE, 0]]          # two sampled cells exchanged: the weights notice
+    assert bench.fingerprint_of_column(c, 0) != whole
+    v = rng.standard_normal((1000, 3)).astype(np.float32)                          # a vector block: three words per cell
+    assert (bench.fingerprint_of_column(v[:400], 0) + bench.fingerprint_of_column(v[400:], 1200)) & 0xFFFFFFFFFFFFFFFF == bench.fingerprint_of_column(v, 0)
+    r = rng.integers(-1, 12, 5000).astype(np.int32)                                 # Rmax: int32 words
+    assert (bench.fingerprint_of_column(r[:123], 0) + bench.fingerprint_of_column(r[123:], 123)) & 0xFFFFFFFFFFFFFFFF == bench.fingerprint_of_column(r, 0)

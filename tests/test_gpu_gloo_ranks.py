@@ -102,6 +102,8 @@ def test_bench_multi_rank_line_end_to_end_on_one_gpu():
     assert ex["replicated_spectrum"] is True and ex["alternative"]["replicated_spectrum"] is False     # the default at two ranks, and the other mode
     assert ex["alternative"]["calls_per_step"] > ex["calls_per_step"] > 0                                 # the sweep's transposes come on top of the LPT ones
     assert ex["GB_per_step_per_rank"] > 0 and d["config"]["grid"] == 64
+    # what the two ranks left in `products` is, bit for bit on the sampled cells, what one GPU leaves (tests/golden/make_bench_fingerprints.py)
+    assert d["result_check"]["matches_single_gpu_golden"] is True, d["result_check"]
     names = {k["name"] for k in d["kernels"]}
     assert {"xpass_hess_1to3", "ypass_hess_3to6", "collapse_inv", "zpass_c2r_hess_6to3inv"} <= names
 
@@ -120,3 +122,4 @@ def test_bench_eight_ranks_exchange_every_transform_on_one_gpu():
     assert ex["replicated_spectrum"] is False and "alternative" not in ex
     assert ex["calls_per_step"] >= 3 * 3 + 12          # three fields per radius in the sweep, twelve in the LPT part
     assert d["value"] > 0 and np.isfinite(d["config"]["sigma_R0"]) and abs(d["config"]["sigma_R0"] - 2.5) < 1e-9
+    assert d["result_check"]["matches_single_gpu_golden"] is True, d["result_check"]       # eight slabs, every transform exchanged: one GPU's bits
