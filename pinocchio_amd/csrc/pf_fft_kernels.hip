@@ -420,6 +420,28 @@ __global__ void __launch_bounds__(TL *(N / 16)) k_c2r_persistent(const PfC2RPara
 #ifndef PF_ZI_WAVES
 #define PF_ZI_WAVES 0       // (A/B: waves per SIMD the compiler is asked to make room for; 0: its own choice)
 #endif
+#define PF_ZI_PRAGMA_(x) _Pragma(#x)
+#define PF_ZI_PRAGMA(x) PF_ZI_PRAGMA_(x)
+#ifndef PF_ZI_SPEC_F32
+#define PF_ZI_SPEC_F32 1    // the same for fp32 rows of 1024 points (60 registers: four workgroups per CU; 13.0 -> 10.6 ms per launch)
+#endif
+#ifndef PF_ZI_SPEC_LPT
+#define PF_ZI_SPEC_LPT 0    // (A/B) ... and for MODE 1, the contraction into the 3LPT(b) source: its reduction reads seven more fields, and two
+                            // waves are too few to keep those loads in flight (23.5 -> 24.4 ms)
+#endif
+#ifndef PF_ZI_RUNROLL
+#define PF_ZI_RUNROLL 1     // (A/B) unrolling of the per-cell reduction loop
+#endif
+#ifndef PF_ZI_LATE
+#define PF_ZI_LATE 0
+#endif
+#ifndef PF_ZI_SPEC
+#define PF_ZI_SPEC 1        // (0 in an A/B build: every wave transforms a line and takes part in the reduction)
+#endif
+#ifndef PF_ZI_ROT
+#define PF_ZI_ROT 2         // wave w of a workgroup takes component (w + PF_ZI_ROT) % 6: with 2 the two components with a kz factor fall on
+                            // waves 2 and 3, which have a SIMD to themselves within the workgroup (A/B: 14.84 -> 14.68 ms per launch)
+#endif
 #ifndef PF_ZI_OWN
 #define PF_ZI_OWN 1         // (A/B) 0: phase B reads both operands of the fold from LDS
 #endif
@@ -431,13 +453,14 @@ template <typename F, int M> struct PfZiPlan {
   static constexpr int full = (M + 1 > M + M / 8) ? M + 1 : M + M / 8, narrow = (M + 1 > M + M / 16) ? M + 1 : M + M / 16;
   static constexpr int line = (lean && M >= 256) ? narrow : full;  // complex per LDS line
   static __device__ __forceinline__ int pad(int p) { return (lean && M >= 256) ? p + (p >> 4) : pf_lpad(p); }
+  // SPEC (fp64 rows of 1024 points, the invariants of the sweep): two more waves per workgroup do nothing but the per-cell reduction
+  // of a row, and the six transform waves request their next row the moment they have handed this one over -- the request then
+  // travels during the reduction and a row's load latency is off the workgroup's critical path (profiles/r04_notes.md, section 3f)
+  static constexpr bool spec0 = PF_ZI_SPEC && M == 512 && !PF_ZI_DMA && (lean || (PF_ZI_SPEC_F32 && sizeof(F) == 4));
+  static constexpr bool spec(int mode) { return spec0 && (mode == 0 || PF_ZI_SPEC_LPT); }
 };
-template <typename F, int N, int MODE = 0>
-__global__ void __launch_bounds__(6 * (N / 16))
-#if PF_ZI_WAVES > 0
-__attribute__((amdgpu_waves_per_eu(PF_ZI_WAVES, PF_ZI_WAVES)))
-#endif
-k_c2r_invariants(const PfC2RParams p, long long nrows) {
+template <typename F, int N, int MODE, bool SPEC>
+__device__ __forceinline__ void pf_c2r_invariants_body(const PfC2RParams &p, long long nrows) {
   using C = pfc<F>;
   using F2 = typename pf_vec2<F>::type;
   constexpr bool IN_PLACE = sizeof(F) == 8;  // fp64 invariants fit the rows they replace
@@ -445,13 +468,16 @@ k_c2r_invariants(const PfC2RParams p, long long nrows) {
   using PLAN = PfZiPlan<F, M>;
   constexpr int LPL = PLAN::line;
   constexpr bool DMA = PF_ZI_DMA && PLAN::lean && NT == 64 && sizeof(C) == 16;  // rows straight into LDS (below)
-  constexpr bool PREFETCH = !PLAN::lean;
+  constexpr bool PREFETCH = !PLAN::lean && !SPEC;
+  constexpr bool LATE = PF_ZI_LATE && PLAN::lean && !SPEC && !DMA && MODE == 0;  // (A/B) six waves, each requesting its next row in front of the reduction
   constexpr int NTHR = TL * NT;
   static_assert((size_t)LPL * sizeof(C) >= (size_t)N * sizeof(F), "a line's LDS holds its real row");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   C *lds = reinterpret_cast<C *>(smem);
   const int tid = threadIdx.x;
-  const int l = tid / NT, tl = tid % NT;
+  const int lw = tid / NT, tl = tid % NT;
+  const bool reducer = SPEC && lw >= TL;                    // (uniform per wave) waves 6, 7: the reduction only
+  const int l = reducer ? 0 : (lw + PF_ZI_ROT) % TL;        // the component this wave transforms (PF_ZI_ROT: A/B)
   const C *__restrict__ tw = reinterpret_cast<const C *>(p.tw);
   const F kf = (F)(2.0 * 3.14159265358979323846 / (double)N);
   const F norm = (F)p.norm;
@@ -480,61 +506,10 @@ k_c2r_invariants(const PfC2RParams p, long long nrows) {
     nxt[8] = (tl == 0 && M <= p.band_k) ? pf_ld_stream(&row[M]) : pf_mk<F>(0, 0);
   };
 
-  long long R = blockIdx.x;
-  if (PREFETCH && R < nrows) fetch(R);
-#pragma unroll 1
-  for (; R < nrows; R += gridDim.x) {
-    int tlj = tl, lj = l, tidj = tid;
-    asm volatile("" : "+v"(tlj), "+v"(lj), "+v"(tidj));  // keep the index math inside the loop (see k_strided)
-    C *L = lds + lj * LPL;
-    if (DMA) {
-      // phase A without registers: each 64-lane piece of the row that lies inside the band goes from memory straight into the
-      // line (global_load_lds_dwordx4: wave-uniform LDS base + 16 bytes per lane, which is the line's own order); pieces cut by
-      // the band or beyond it are written as before.  The wave waits for its own transfers (vmcnt) before it reads the line.
-      const C *__restrict__ row = in + R * p.in_pitch;
-      const unsigned lbase = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) char *)(lds + (tid / NT) * LPL));
-#pragma unroll
-      for (int m = 0; m < 8; m++) {
-        const int k = tlj + m * NT;
-        if (m * NT + NT - 1 <= p.band_k)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(&row[k]),
-                                           (__attribute__((address_space(3))) void *)(size_t)(lbase + m * NT * (unsigned)sizeof(C)), 16, 0, PF_NT ? 2 : 0);
-        else
-          L[k] = (k <= p.band_k) ? pf_ld_stream(&row[k]) : pf_mk<F>(0, 0);
-      }
-      if (tlj == 0) L[M] = (M <= p.band_k) ? pf_ld_stream(&row[M]) : pf_mk<F>(0, 0);
-      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0) (gfx9 encoding: lgkmcnt and expcnt left at their maxima)
-    } else {
-      if (!PREFETCH) fetch(R);
-      // phase A: the prefetched row of this component -> its LDS line
-#pragma unroll
-      for (int m = 0; m < 8; m++) L[tlj + m * NT] = nxt[m];
-      if (tlj == 0) L[M] = nxt[8];
-    }
-    line_sync();
-    // phase B: kz factor + Hermitian fold into the half-length complex line
-    C v[8];
-#pragma unroll
-    for (int m = 0; m < 8; m++) {
-      const int e = tlj + m * NT;
-      // (element e itself is still in the register it was loaded into, where the row was loaded by this iteration)
-      v[m] = pf_zfold<F>((PF_ZI_OWN && !PREFETCH && !DMA) ? nxt[m] : L[e], L[M - e], e, M, mul, kf, tw[e]);
-    }
-    line_sync();
-    if (PREFETCH && R + gridDim.x < nrows) fetch(R + gridDim.x);  // in flight during the stages and the reduction below
-#ifndef PF_ZI_HOIST_TW
-#define PF_ZI_HOIST_TW 0
-#endif
-    PfStages<F, M, +1, 2, 0, (NT <= 64)>::run(
-        v, tlj, tw, [&](int pos, C val) { L[PLAN::pad(pos)] = val; }, [&](int pos) { return L[PLAN::pad(pos)]; }, PF_ZI_HOIST_TW ? tl : -1);
-    line_sync();  // every thread of the line is done with the exchange area
-    // the real row of this component, in order, into its line
-    C *H = L;
-#pragma unroll
-    for (int m = 0; m < 8; m++) H[tlj + m * NT] = pf_mk<F>(pf_norm_dc(v[m].x, norm, dcv), pf_norm_dc(v[m].y, norm, dcv));
-    __syncthreads();
-    // per cell: six components -> three invariants; two neighbouring cells per thread (16-byte LDS reads and stores)
-    for (int c = 2 * tidj; c < N; c += 2 * NTHR) {
+  // per cell: six components -> three invariants; two neighbouring cells per thread (16-byte LDS reads and stores)
+  auto reduce_row = [&](long long R, int c0, int cstep) {
+PF_ZI_PRAGMA(unroll PF_ZI_RUNROLL)
+    for (int c = c0; c < N; c += cstep) {
       F2 h[6];
 #pragma unroll
       for (int k = 0; k < 6; k++) h[k] = *reinterpret_cast<const F2 *>(reinterpret_cast<const F *>(lds + k * LPL) + c);
@@ -576,9 +551,95 @@ k_c2r_invariants(const PfC2RParams p, long long nrows) {
         *acc = r;
       }
     }
+  };
+  if (SPEC && reducer) {  // waves 6, 7: between the two barriers of a row, its reduction (a loop of their own: nothing of the transform waves' state is alive here)
+#pragma unroll 1
+    for (long long Rr = blockIdx.x; Rr < nrows; Rr += gridDim.x) {
+      int tr = tid - TL * NT;
+      asm volatile("" : "+v"(tr));
+      __syncthreads();
+      reduce_row(Rr, 2 * tr, 4 * NT);
+      __syncthreads();
+    }
+    return;
+  }
+  long long R = blockIdx.x;
+  if ((PREFETCH || SPEC || LATE) && R < nrows) fetch(R);
+#pragma unroll 1
+  for (; R < nrows; R += gridDim.x) {
+    int tlj = tl, lj = l, tidj = tid;
+    asm volatile("" : "+v"(tlj), "+v"(lj), "+v"(tidj));  // keep the index math inside the loop (see k_strided)
+    C *L = lds + lj * LPL;
+    if (DMA) {
+      // phase A without registers: each 64-lane piece of the row that lies inside the band goes from memory straight into the
+      // line (global_load_lds_dwordx4: wave-uniform LDS base + 16 bytes per lane, which is the line's own order); pieces cut by
+      // the band or beyond it are written as before.  The wave waits for its own transfers (vmcnt) before it reads the line.
+      const C *__restrict__ row = in + R * p.in_pitch;
+      const unsigned lbase = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) char *)(lds + (tid / NT) * LPL));
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        const int k = tlj + m * NT;
+        if (m * NT + NT - 1 <= p.band_k)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(&row[k]),
+                                           (__attribute__((address_space(3))) void *)(size_t)(lbase + m * NT * (unsigned)sizeof(C)), 16, 0, PF_NT ? 2 : 0);
+        else
+          L[k] = (k <= p.band_k) ? pf_ld_stream(&row[k]) : pf_mk<F>(0, 0);
+      }
+      if (tlj == 0) L[M] = (M <= p.band_k) ? pf_ld_stream(&row[M]) : pf_mk<F>(0, 0);
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0) (gfx9 encoding: lgkmcnt and expcnt left at their maxima)
+    } else {
+      if (!PREFETCH && !SPEC && !LATE) fetch(R);
+      // phase A: the prefetched row of this component -> its LDS line
+#pragma unroll
+      for (int m = 0; m < 8; m++) L[tlj + m * NT] = nxt[m];
+      if (tlj == 0) L[M] = nxt[8];
+    }
+    line_sync();
+    // phase B: kz factor + Hermitian fold into the half-length complex line
+    C v[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int e = tlj + m * NT;
+      // (element e itself is still in the register it was loaded into, where the row was loaded by this iteration)
+      v[m] = pf_zfold<F>((PF_ZI_OWN && !PREFETCH && !DMA) ? nxt[m] : L[e], L[M - e], e, M, mul, kf, tw[e]);  // (SPEC: nxt holds this row since the end of the iteration before)
+    }
+    line_sync();
+    if (PREFETCH && R + gridDim.x < nrows) fetch(R + gridDim.x);  // in flight during the stages and the reduction below
+#ifndef PF_ZI_HOIST_TW
+#define PF_ZI_HOIST_TW 0
+#endif
+    PfStages<F, M, +1, 2, 0, (NT <= 64)>::run(
+        v, tlj, tw, [&](int pos, C val) { L[PLAN::pad(pos)] = val; }, [&](int pos) { return L[PLAN::pad(pos)]; }, PF_ZI_HOIST_TW ? tl : -1);
+    line_sync();  // every thread of the line is done with the exchange area
+    // the real row of this component, in order, into its line
+    C *H = L;
+#pragma unroll
+    for (int m = 0; m < 8; m++) H[tlj + m * NT] = pf_mk<F>(pf_norm_dc(v[m].x, norm, dcv), pf_norm_dc(v[m].y, norm, dcv));
+    __syncthreads();
+    // the transform waves are done with this row: their next one travels while waves 6, 7 reduce.  (Past the last row: zeros, not
+    // "nothing" -- a conditional request would keep the OLD row alive through the stages, in 36 registers the kernel does not have)
+    if (SPEC || LATE) {
+      if (R + gridDim.x < nrows) fetch(R + gridDim.x);
+      else {
+#pragma unroll
+        for (int m = 0; m < 9; m++) nxt[m] = pf_mk<F>(0, 0);
+      }
+    }
+    if (!SPEC) reduce_row(R, 2 * tidj, 2 * NTHR);  // (LATE: with every wave's next row in flight)
     __syncthreads();  // the lines are rewritten by the next phase A
   }
 }
+template <typename F, int N, int MODE = 0>
+__global__ void __launch_bounds__(6 * (N / 16))
+#if PF_ZI_WAVES > 0
+__attribute__((amdgpu_waves_per_eu(PF_ZI_WAVES, PF_ZI_WAVES)))
+#endif
+k_c2r_invariants(const PfC2RParams p, long long nrows) { pf_c2r_invariants_body<F, N, MODE, false>(p, nrows); }
+// eight waves: six transform, two reduce (PfZiPlan::spec).  Six waves per SIMD = three workgroups per CU is what the 52 KB of lines
+// allow: the kernel must stay within 80 registers.
+template <typename F, int N, int MODE = 0>
+__global__ void __launch_bounds__(8 * (N / 16)) __attribute__((amdgpu_waves_per_eu(6)))
+k_c2r_invariants_spec(const PfC2RParams p, long long nrows) { pf_c2r_invariants_body<F, N, MODE, true>(p, nrows); }
 
 template <typename F, int N, int TL>
 __global__ void __launch_bounds__(TL *(N / 16)) k_r2c(const PfR2CParams p) {
@@ -733,7 +794,10 @@ static int launch_c2r_invariants_n(const PfC2RParams &p, hipStream_t st, int mod
   long long g = (long long)(p.ncu > 0 ? p.ncu : 256) * (p.inv_per_cu > 0 ? p.inv_per_cu : 32);
   if (g > p.nlines) g = p.nlines;
   const size_t shm = (size_t)6 * LPL * sizeof(pfc<F>);
-  if (mode == 1) hipLaunchKernelGGL((k_c2r_invariants<F, N, 1>), dim3((unsigned)g), dim3(6 * NT), shm, st, p, p.nlines);
+  if (mode == 1) {
+    if constexpr (PfZiPlan<F, M>::spec(1)) hipLaunchKernelGGL((k_c2r_invariants_spec<F, N, 1>), dim3((unsigned)g), dim3(8 * NT), shm, st, p, p.nlines);
+    else hipLaunchKernelGGL((k_c2r_invariants<F, N, 1>), dim3((unsigned)g), dim3(6 * NT), shm, st, p, p.nlines);
+  } else if constexpr (PfZiPlan<F, M>::spec(0)) hipLaunchKernelGGL((k_c2r_invariants_spec<F, N, 0>), dim3((unsigned)g), dim3(8 * NT), shm, st, p, p.nlines);
   else hipLaunchKernelGGL((k_c2r_invariants<F, N, 0>), dim3((unsigned)g), dim3(6 * NT), shm, st, p, p.nlines);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
