@@ -425,6 +425,9 @@ __global__ void __launch_bounds__(TL *(N / 16)) k_c2r_persistent(const PfC2RPara
 #ifndef PF_ZI_SPEC_F32
 #define PF_ZI_SPEC_F32 1    // the same for fp32 rows of 1024 points (60 registers: four workgroups per CU; 13.0 -> 10.6 ms per launch)
 #endif
+#ifndef PF_ZI_SPEC_2048
+#define PF_ZI_SPEC_2048 1   // ... and for fp32 rows of 2048 points (BASELINE config 5): twelve transform waves, four that reduce
+#endif
 #ifndef PF_ZI_SPEC_LPT
 #define PF_ZI_SPEC_LPT 0    // (A/B) ... and for MODE 1, the contraction into the 3LPT(b) source: its reduction reads seven more fields, and two
                             // waves are too few to keep those loads in flight (23.5 -> 24.4 ms)
@@ -456,8 +459,10 @@ template <typename F, int M> struct PfZiPlan {
   // SPEC (fp64 rows of 1024 points, the invariants of the sweep): two more waves per workgroup do nothing but the per-cell reduction
   // of a row, and the six transform waves request their next row the moment they have handed this one over -- the request then
   // travels during the reduction and a row's load latency is off the workgroup's critical path (profiles/r04_notes.md, section 3f)
-  static constexpr bool spec0 = PF_ZI_SPEC && M == 512 && !PF_ZI_DMA && (lean || (PF_ZI_SPEC_F32 && sizeof(F) == 4));
+  static constexpr bool spec0 = PF_ZI_SPEC && !PF_ZI_DMA &&
+                                ((M == 512 && (lean || (PF_ZI_SPEC_F32 && sizeof(F) == 4))) || (M == 1024 && sizeof(F) == 4 && PF_ZI_SPEC_2048));
   static constexpr bool spec(int mode) { return spec0 && (mode == 0 || PF_ZI_SPEC_LPT); }
+  static constexpr int reducer_waves = M / 256;  // 2 for rows of 1024 points, 4 for 2048 (two waves per line there: sixteen waves in all)
 };
 template <typename F, int N, int MODE, bool SPEC>
 __device__ __forceinline__ void pf_c2r_invariants_body(const PfC2RParams &p, long long nrows) {
@@ -552,13 +557,17 @@ PF_ZI_PRAGMA(unroll PF_ZI_RUNROLL)
       }
     }
   };
-  if (SPEC && reducer) {  // waves 6, 7: between the two barriers of a row, its reduction (a loop of their own: nothing of the transform waves' state is alive here)
+  if (SPEC && reducer) {  // the reducing waves: between the two barriers of a row, its reduction (a loop of their own: nothing of the transform waves' state is alive here)
+    // (lines of two waves -- 2048 points -- synchronise their halves by workgroup barriers: the reducing waves join those too)
+    constexpr int LINE_BARRIERS = NT > 64 ? 3 + 2 * (pf_nstages(M) - 1) : 0;
 #pragma unroll 1
     for (long long Rr = blockIdx.x; Rr < nrows; Rr += gridDim.x) {
       int tr = tid - TL * NT;
       asm volatile("" : "+v"(tr));
+#pragma unroll
+      for (int i = 0; i < LINE_BARRIERS; i++) __syncthreads();
       __syncthreads();
-      reduce_row(Rr, 2 * tr, 4 * NT);
+      reduce_row(Rr, 2 * tr, 2 * 64 * PLAN::reducer_waves);
       __syncthreads();
     }
     return;
@@ -638,7 +647,7 @@ k_c2r_invariants(const PfC2RParams p, long long nrows) { pf_c2r_invariants_body<
 // eight waves: six transform, two reduce (PfZiPlan::spec).  Six waves per SIMD = three workgroups per CU is what the 52 KB of lines
 // allow: the kernel must stay within 80 registers.
 template <typename F, int N, int MODE = 0>
-__global__ void __launch_bounds__(8 * (N / 16)) __attribute__((amdgpu_waves_per_eu(6)))
+__global__ void __launch_bounds__(6 * (N / 16) + 64 * (N / 512)) __attribute__((amdgpu_waves_per_eu(N >= 2048 ? 8 : 6)))
 k_c2r_invariants_spec(const PfC2RParams p, long long nrows) { pf_c2r_invariants_body<F, N, MODE, true>(p, nrows); }
 
 template <typename F, int N, int TL>
@@ -795,9 +804,9 @@ static int launch_c2r_invariants_n(const PfC2RParams &p, hipStream_t st, int mod
   if (g > p.nlines) g = p.nlines;
   const size_t shm = (size_t)6 * LPL * sizeof(pfc<F>);
   if (mode == 1) {
-    if constexpr (PfZiPlan<F, M>::spec(1)) hipLaunchKernelGGL((k_c2r_invariants_spec<F, N, 1>), dim3((unsigned)g), dim3(8 * NT), shm, st, p, p.nlines);
+    if constexpr (PfZiPlan<F, M>::spec(1)) hipLaunchKernelGGL((k_c2r_invariants_spec<F, N, 1>), dim3((unsigned)g), dim3(6 * NT + 64 * PfZiPlan<F, M>::reducer_waves), shm, st, p, p.nlines);
     else hipLaunchKernelGGL((k_c2r_invariants<F, N, 1>), dim3((unsigned)g), dim3(6 * NT), shm, st, p, p.nlines);
-  } else if constexpr (PfZiPlan<F, M>::spec(0)) hipLaunchKernelGGL((k_c2r_invariants_spec<F, N, 0>), dim3((unsigned)g), dim3(8 * NT), shm, st, p, p.nlines);
+  } else if constexpr (PfZiPlan<F, M>::spec(0)) hipLaunchKernelGGL((k_c2r_invariants_spec<F, N, 0>), dim3((unsigned)g), dim3(6 * NT + 64 * PfZiPlan<F, M>::reducer_waves), shm, st, p, p.nlines);
   else hipLaunchKernelGGL((k_c2r_invariants<F, N, 0>), dim3((unsigned)g), dim3(6 * NT), shm, st, p, p.nlines);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
