@@ -40,7 +40,7 @@ except Exception as e:
     print('stats csv',e)
 sv=v['kernels']; 
 def vk(prefix): return [x for k,x in sv.items() if k.startswith(prefix)][0]
-solve=vk('k_collapse_inv'); strided=vk('k_strided<double, 1024, 8, 1'); zinv=vk('k_c2r_invariants<double, 1024, 0')
+solve=vk('k_collapse_inv'); strided=vk('k_strided<double, 1024, 8, 1'); zinv=vk('k_c2r_invariants_spec<double, 1024, 0')
 tr=t['kernels']
 def trk(prefix): return [x for k,x in tr.items() if k.startswith(prefix)][0]
 def trs(x): 
@@ -48,7 +48,7 @@ def trs(x):
     rd=[x[k] for k in keys if 'fetch' in k.lower() or 'read' in k.lower()]
     return x
 tstr=[]
-for pref,label in (('k_strided<double, 1024, 8, 1','`k_strided<…, 1, true>`'),('k_c2r_invariants<double, 1024, 0','`k_c2r_invariants<1024, 0>`'),('k_collapse_inv','`k_collapse_inv`')):
+for pref,label in (('k_strided<double, 1024, 8, 1','`k_strided<…, 1, true>`'),('k_c2r_invariants_spec<double, 1024, 0','`k_c2r_invariants_spec<1024, 0>`'),('k_collapse_inv','`k_collapse_inv`')):
     x=trk(pref)
     rd=x.get('fetch_bytes_per_launch'); wr=x.get('write_bytes_per_launch')
     rd=rd/1e9 if rd is not None else None; wr=wr/1e9 if wr is not None else None

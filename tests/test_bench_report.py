@@ -60,7 +60,9 @@ def test_overlapping_spans_without_an_in_line_pass():
 def test_fp32_symbols():
     assert bench.symbol_of("ypass_hess_3to6", 1024, 4) == "k_strided<float __vector(2), 1024, 8, 1, true>"
     assert bench.symbol_of("ypass_hess_3to6", 2048, 4) == "k_strided<float __vector(2), 2048, 4, 1, true>"
-    assert bench.symbol_of("zpass_c2r_hess_6to3inv", 2048, 4) == "k_c2r_invariants<float, 2048, 0>"
+    assert bench.symbol_of("zpass_c2r_hess_6to3inv", 2048, 4) == "k_c2r_invariants_spec<float, 2048, 0>"
+    assert bench.symbol_of("zpass_c2r_hess_6to3inv", 512, 8) == "k_c2r_invariants<double, 512, 0>"
+    assert bench.symbol_of("zpass_c2r_hess_6to3inv", 1024, 8) == "k_c2r_invariants_spec<double, 1024, 0>"
 
 
 def test_result_fingerprint_adds_up_over_any_decomposition():
