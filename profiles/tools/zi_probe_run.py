@@ -1,3 +1,6 @@
+"""Phase probe of the invariant z-pass (profiles/r04_notes.md, section 3f): cycle stamps at the phase boundaries of k_c2r_invariants,
+wave by wave.  Needs a scratch build of the library with profiles/r04_zi_probe.diff applied to csrc/pf_fft_kernels.hip (as of commit
+ac95c49) and built as the variant `zprobe` (profiles/tools/mk_variant.sh zprobe <patched file> "-I."); run on a GPU box from the repo root."""
 import ctypes as C, os, sys, json
 sys.path.insert(0, os.getcwd())
 os.environ["PINFMAX_LIB"] = os.path.join(os.getcwd(), "pinocchio_amd/csrc/build_zprobe/libpinfmax_hip_zprobe.so")
