@@ -44,7 +44,8 @@ int main(void) {
   const double radius[9] = {20.635922, 13.996056, 9.026099, 5.465945, 3.058354, 1.548258, 0.689079, 0.258729, 0.0};
   pf_config cfg = {n, 0, 1, 0, 8, 0};
   pf_ctx *ctx = NULL;
-  pf_genic_params ic = {0.25, 0.044, h100, 0.96, box, 2.03146e7 /* PkNorm as logged */, 486604u, 0, 0, 0, NULL, NULL /* Eisenstein & Hu, no table */};
+  pf_genic_params ic = {0.25, 0.044, h100, 0.96, box, 2.03146e7 /* PkNorm as logged */, 486604u, 0, 0, 0, NULL, NULL /* Eisenstein & Hu, no table */,
+                        0 /* spectrum: by pk_n */, 0.0 /* no warm-dark-matter cut-off */, 0.0 /* UnitLength_in_cm: the default */};
   double x[NKNOTS], y[NKNOTS], rs[9], tv[9], d1;
   unsigned long long pdf[PF_NBINS], coll = 0;
 
