@@ -87,8 +87,8 @@ def symbol_of(cls: str, n: int, fb: int, fast: bool = True) -> str:
         return f"k_strided<{FS}, {n}, {t}, -1, true>"
     if cls in ("zpass_c2r_hess_6", "zpass_c2r_disp_3", "zpass_c2r_plain"):
         return f"k_c2r_persistent<{F}, {n}, {tl}>"
-    # the invariant z-pass of rows of 1024 points (and of 2048 with fp32 fields) runs with two (four) more waves that only reduce: PfZiPlan::spec
-    zinv = "k_c2r_invariants_spec" if (n == 1024 or (n == 2048 and fb == 4)) else "k_c2r_invariants"
+    # the invariant z-pass of rows of 512 and 1024 points (and of 2048 with fp32 fields) runs with two (four) more waves that only reduce: PfZiPlan::spec
+    zinv = "k_c2r_invariants_spec" if (n in (512, 1024) or (n == 2048 and fb == 4)) else "k_c2r_invariants"
     return {"zpass_c2r_hess_6to3inv": f"{zinv}<{F}, {n}, 0>", "zpass_c2r_hess_6_lpt3b": f"k_c2r_invariants<{F}, {n}, 1>",
             "collapse": f"k_collapse<{F}, {b}, float>", "collapse_inv": f"k_collapse_inv<{b}, float>", "lpt_sources": f"k_lpt_sources<{F}>",
             "collapse_lpt_sources": f"k_collapse_src<{F}, {b}, float>",      # last argument: PRODFLOAT of the build

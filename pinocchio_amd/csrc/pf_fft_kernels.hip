@@ -425,6 +425,10 @@ __global__ void __launch_bounds__(TL *(N / 16)) k_c2r_persistent(const PfC2RPara
 #ifndef PF_ZI_SPEC_F32
 #define PF_ZI_SPEC_F32 1    // the same for fp32 rows of 1024 points (60 registers: four workgroups per CU; 13.0 -> 10.6 ms per launch)
 #endif
+#ifndef PF_ZI_SPEC_512
+#define PF_ZI_SPEC_512 1    // ... and for rows of 512 points (two lines per wave: three transform waves and one that reduces; 512^3: 1.86 -> 1.80 ms
+                            // per launch, fp32 fields 1.48 -> 1.36)
+#endif
 #ifndef PF_ZI_SPEC_2048
 #define PF_ZI_SPEC_2048 1   // ... and for fp32 rows of 2048 points (BASELINE config 5): twelve transform waves, four that reduce
 #endif
@@ -460,7 +464,8 @@ template <typename F, int M> struct PfZiPlan {
   // of a row, and the six transform waves request their next row the moment they have handed this one over -- the request then
   // travels during the reduction and a row's load latency is off the workgroup's critical path (profiles/r04_notes.md, section 3f)
   static constexpr bool spec0 = PF_ZI_SPEC && !PF_ZI_DMA &&
-                                ((M == 512 && (lean || (PF_ZI_SPEC_F32 && sizeof(F) == 4))) || (M == 1024 && sizeof(F) == 4 && PF_ZI_SPEC_2048));
+                                (((M == 512 || (M == 256 && PF_ZI_SPEC_512)) && (lean || (PF_ZI_SPEC_F32 && sizeof(F) == 4))) ||
+                                 (M == 1024 && sizeof(F) == 4 && PF_ZI_SPEC_2048));
   static constexpr bool spec(int mode) { return spec0 && (mode == 0 || PF_ZI_SPEC_LPT); }
   static constexpr int reducer_waves = M / 256;  // 2 for rows of 1024 points, 4 for 2048 (two waves per line there: sixteen waves in all)
 };

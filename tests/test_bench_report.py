@@ -61,7 +61,8 @@ def test_fp32_symbols():
     assert bench.symbol_of("ypass_hess_3to6", 1024, 4) == "k_strided<float __vector(2), 1024, 8, 1, true>"
     assert bench.symbol_of("ypass_hess_3to6", 2048, 4) == "k_strided<float __vector(2), 2048, 4, 1, true>"
     assert bench.symbol_of("zpass_c2r_hess_6to3inv", 2048, 4) == "k_c2r_invariants_spec<float, 2048, 0>"
-    assert bench.symbol_of("zpass_c2r_hess_6to3inv", 512, 8) == "k_c2r_invariants<double, 512, 0>"
+    assert bench.symbol_of("zpass_c2r_hess_6to3inv", 256, 8) == "k_c2r_invariants<double, 256, 0>"
+    assert bench.symbol_of("zpass_c2r_hess_6to3inv", 512, 8) == "k_c2r_invariants_spec<double, 512, 0>"
     assert bench.symbol_of("zpass_c2r_hess_6to3inv", 1024, 8) == "k_c2r_invariants_spec<double, 1024, 0>"
 
 

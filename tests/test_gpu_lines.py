@@ -132,7 +132,7 @@ def test_zpass_r2c_lines(L, n, fb):
     assert np.max(np.abs(got - want)) <= tol(fb, n) * np.max(np.abs(want)), (n, fb)
 
 
-@pytest.mark.parametrize("n", [16, 64, 256, 1024, 2048])
+@pytest.mark.parametrize("n", [16, 64, 256, 512, 1024, 2048])      # (512, 1024, 2048: the forms with waves that only reduce)
 def test_invariant_zpass_lines_fp32_fields(L, n):
     """the same pass on fp32 fields (BASELINE config 5's arithmetic; rows of up to 2048 points fit): transforms in fp32, the
     reduction in fp64 from the fp32 components, fp64 invariants out"""
@@ -152,7 +152,7 @@ def test_invariant_zpass_lines_fp32_fields(L, n):
         assert np.max(np.abs(gi - wi)) <= 8 * tol(4, n) * amp ** p, (n, p)
 
 
-@pytest.mark.parametrize("n", [16, 64, 256, 1024])
+@pytest.mark.parametrize("n", [16, 64, 256, 512, 1024])
 def test_invariant_zpass_lines(L, n):
     """six rows in, the three invariants of each cell's tensor out (what the solve of every radius but the last reads)"""
     rng = np.random.default_rng(11 * n)
