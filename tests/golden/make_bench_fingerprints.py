@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-CONFIGS = [(64, 3, True, 8), (64, 4, True, 8), (256, 12, True, 8), (1024, 12, True, 8), (1024, 12, True, 4)]
+CONFIGS = [(64, 3, True, 8), (64, 4, True, 8), (256, 12, True, 8), (512, 12, True, 8), (1024, 12, True, 8), (1024, 12, True, 4)]
 
 
 def main():
