@@ -88,3 +88,17 @@ def test_result_fingerprint_adds_up_over_any_decomposition():
     assert (bench.fingerprint_of_column(v[:400], 0) + bench.fingerprint_of_column(v[400:], 1200)) & 0xFFFFFFFFFFFFFFFF == bench.fingerprint_of_column(v, 0)
     r = rng.integers(-1, 12, 5000).astype(np.int32)                                 # Rmax: int32 words
     assert (bench.fingerprint_of_column(r[:123], 0) + bench.fingerprint_of_column(r[123:], 123)) & 0xFFFFFFFFFFFFFFFF == bench.fingerprint_of_column(r, 0)
+
+
+def test_fingerprint_goldens_cover_the_configurations_that_are_held_against_them():
+    """tests/golden/bench_fingerprints.json (made on a GPU by make_bench_fingerprints.py) has the default bench configurations and
+    the ones the multi-process GPU tests assert; every entry carries the exact columns, the one float column and the sources' stamp"""
+    import json
+    g = json.load(open(bench.FINGERPRINT_FILE))
+    for n, ns, lpt, fb in ((1024, 12, True, 8), (1024, 12, True, 4), (512, 12, True, 8), (256, 12, True, 8), (64, 3, True, 8), (64, 4, True, 8)):
+        e = g[bench.fingerprint_key(n, ns, lpt, fb)]
+        fp = e["fingerprint"]
+        assert set(fp) == {"FMAX", "RMAX", "ZEL ", "2LPT", "31PT", "32PT_sumsq", "PDF"}
+        assert all(isinstance(fp[k], str) and len(fp[k]) == 16 for k in fp if k != "32PT_sumsq") and fp["32PT_sumsq"] > 0
+        assert e["cells_in_fmax_pdf"] == n ** 3 and len(e["kernel_source_sha"]) == 16
+        assert bench.fingerprints_agree(fp, dict(fp)) and not bench.fingerprints_agree(fp, dict(fp, FMAX="0" * 16))
