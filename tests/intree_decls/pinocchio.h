@@ -4,8 +4,9 @@
  * Lets `cc -fsyntax-only -DPF_IN_PINOCCHIO_TREE pinocchio_amd/host/pf_compat.c` see the names the in-tree build of the
  * adapter binds with the types src/pinocchio.h, src/def_splines.h, <mpi.h> and <gsl/gsl_spline.h>
  * give them, so that those #ifdef branches are type-checked here, where MPI, GSL, FFTW and PFFT are not installed.
- * Nothing is defined, nothing links, nothing runs: this is NOT a build of the reference and NOT an oracle -- it pins
- * no result.  Only what pf_compat.c touches is declared; the shared mirrors (product_data, grid_data, ...) come from
+ * Nothing is defined here: this is NOT a build of the reference and NOT an oracle -- it pins no result.  (One test does
+ * link and run the adapter compiled against it -- tests/test_mpi_boundary.py, with the globals defined by its own driver and
+ * every pf_* entry point replaced by a recording mock: the MPI call order of the adapter is what it checks.)  Only what pf_compat.c touches is declared; the shared mirrors (product_data, grid_data, ...) come from
  * the adapter's own pf_compat_types.h, whose members follow src/pinocchio.h:233-378.
  */
 #ifndef PF_TEST_INTREE_PINOCCHIO_H
@@ -17,7 +18,11 @@
 #include <stdlib.h>
 #include <string.h>
 
-/* --- <mpi.h>: the calls and handles the adapter uses --- */
+/* --- <mpi.h>: the calls and handles the adapter uses (-DPF_TEST_REAL_MPI: the header of an installed MPI instead, for
+   tests/test_mpi_boundary.py, which links the adapter against a recording mock of the C ABI and runs it under mpiexec) --- */
+#ifdef PF_TEST_REAL_MPI
+#include <mpi.h>
+#else
 typedef int MPI_Comm;
 typedef int MPI_Datatype;
 typedef int MPI_Op;
@@ -27,6 +32,7 @@ extern MPI_Op MPI_SUM;
 int MPI_Bcast(void *buffer, int count, MPI_Datatype datatype, int root, MPI_Comm comm);
 int MPI_Reduce(const void *sendbuf, void *recvbuf, int count, MPI_Datatype datatype, MPI_Op op, int root, MPI_Comm comm);
 int MPI_Barrier(MPI_Comm comm);
+#endif
 
 /* --- <gsl/gsl_spline.h>: the members my_spline_eval and the adapter dereference --- */
 typedef struct { size_t size; double *x; double *y; } gsl_spline;
