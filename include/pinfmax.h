@@ -334,6 +334,10 @@ int pf_debug_stream_rate(pf_ctx *ctx, int kind, int reps, double *gbps);
            one more double: 1.0 when a cell raised the q == 0 flag (see pf_debug_invariant_reruns). */
 int pf_debug_lines(int field_bytes, int n, int pass, int mul, int band, int nouter, int ncols, int pre, double rs,
                    double growth, int outer_offset, const double *in, double *out);
+/* test tap without a context: one operation of the packed (re, im) fp32 algebra the sixteen-point strided pass is written in
+   (csrc/pf_fft16.h) on `count` pairs: which = 0 / 1 a +- i b, 2 / 3 +- i a, 4 / 5 a * b, a * conj(b), 6 / 7 the same with b[0] in scalar
+   registers, 8 / 9 a * (c +- i s) for a constant, 10 a - i b */
+int pf_debug_pk(int which, const float *a, const float *b, float *out, int count);
 /* how many sweeps of this context were repeated with six components per cell because the invariant z-pass met a tensor
    with q == 0 that is not exactly isotropic (the reference's "already diagonal" branch, src/collapse_times.c:722-727) */
 int pf_debug_invariant_reruns(pf_ctx *ctx);

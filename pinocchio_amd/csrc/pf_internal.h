@@ -69,6 +69,8 @@ struct PfStridedParams {
 // one x- or y-pass: for every job, out = FFT_e[ in * pre * mul ]  (dir = +1 inverse, -1 forward)
 int pf_launch_strided(int field_bytes, int n, int dir, const PfStridedParams &p, hipStream_t st);
 int pf_launch_exp_table(double *etab, int n, double rs, hipStream_t st);
+// 2048-point fp32 lines, sixteen points per thread (pf_fft16_kernels.hip); -1: not a case of that kernel
+int pf_launch_strided16(int field_bytes, int n, int dir, const PfStridedParams &p, hipStream_t st);
 
 struct PfC2RJob {
   const void *in;   // complex rows

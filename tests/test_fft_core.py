@@ -68,3 +68,23 @@ def test_real_lines(emul, n):
     assert emul.emul_c2r(n, _dp(s.view(np.float64)), _dp(back)) == 0
     want = np.fft.irfft(s, n) * n
     assert np.max(np.abs(back - want)) < 1e-13 * np.max(np.abs(want))
+
+
+@pytest.mark.parametrize("alg", [0, 1])
+@pytest.mark.parametrize("direction", [+1, -1])
+def test_sixteen_points_per_thread_plan(alg, direction):
+    """pf_fft16.h: 2048 = 16 x 16 x 8 with sixteen points per thread (the strided passes of 2048-point fp32 lines), its index
+    algebra and butterflies on the host -- the double algebra (0) and the host form of the packed (re, im) fp32 algebra (1)"""
+    src, so = os.path.join(HERE, "cpu_emul", "fft16_emul.cpp"), os.path.join(HERE, "cpu_emul", "libfft16_emul.so")
+    hdr = os.path.join(HERE, "..", "pinocchio_amd", "csrc", "pf_fft16.h")
+    if (not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-o", so, src])
+    L = C.CDLL(so)
+    L.emul_fft16.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    n = 2048
+    rng = np.random.default_rng(160 + alg)
+    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    out = np.empty(n, dtype=np.complex128)
+    assert L.emul_fft16(alg, direction, _dp(x.view(np.float64)), _dp(out.view(np.float64))) == 0
+    want = np.fft.fft(x) if direction < 0 else np.fft.ifft(x) * n
+    assert np.max(np.abs(out - want)) < (2e-15 if alg == 0 else 1e-6) * np.sqrt(n) * np.max(np.abs(want))

@@ -193,3 +193,21 @@ def test_invariant_zpass_flags_tensors_it_cannot_serve(L):
     assert flag_of([1.0, 1.0, 1.0, 2.0 ** -30, 0, 0]) == 1.0                 # the same through an off-diagonal component
     assert flag_of([1e-170, 2e-170, -1e-170, 1e-171, 0, 0]) == 1.0           # squares underflow
     assert flag_of([1.0, 1.1, 0.9, 0.01, 0.0, 0.0]) == 0.0                   # an ordinary tensor
+
+
+def test_packed_complex_algebra_of_the_sixteen_point_pass(L):
+    """csrc/pf_fft16.h: a column's complex number is a (re, im) register pair and a +- i b, a * w are packed instructions whose
+    operand halves are swapped / negated by modifiers in inline assembly -- each held against its definition"""
+    rng = np.random.default_rng(16)
+    cnt = 4096
+    a = (rng.standard_normal(cnt) + 1j * rng.standard_normal(cnt)).astype(np.complex64)
+    b = (rng.standard_normal(cnt) + 1j * rng.standard_normal(cnt)).astype(np.complex64)
+    fp = C.POINTER(C.c_float)
+    w16 = np.complex64(0.92387953251128675613 + 0.38268343236508977173j)
+    want = {0: a + 1j * b, 1: a - 1j * b, 2: 1j * a, 3: -1j * a, 4: a * b, 5: a * np.conj(b), 6: a * b[0], 7: a * np.conj(b[0]),
+            8: a * w16, 9: a * np.conj(w16), 10: a - 1j * b}
+    for which, ref in want.items():
+        out = np.zeros(cnt, dtype=np.complex64)
+        rc = L.pf_debug_pk(which, a.view(np.float32).ctypes.data_as(fp), b.view(np.float32).ctypes.data_as(fp), out.view(np.float32).ctypes.data_as(fp), cnt)
+        assert rc == 0
+        assert np.max(np.abs(out - ref.astype(np.complex64))) <= 4e-7 * np.max(np.abs(ref)), which
