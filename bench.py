@@ -80,6 +80,10 @@ def symbol_of(cls: str, n: int, fb: int, fast: bool = True) -> str:
             return f"k_mixed_c2r<{F}, {r0}>"
         if cls == "zpass_r2c":
             return f"k_mixed_r2c<{F}, {r0}>"
+    # fp32 lines of 1024 / 2048 points: the kernels in packed (re, im) arithmetic (csrc/pf_fft16_kernels.hip), one instantiation per
+    # (direction, first-pass filter, band limit) -- a launch class runs several of them (pruned and unpruned radii): the family is named
+    if fb == 4 and n in (1024, 2048) and cls in ("xpass_hess_1to3", "ypass_hess_3to6", "xpass_disp_1to2", "ypass_disp_2to3", "xpass_plain", "ypass_plain", "xpass_fwd", "ypass_fwd"):
+        return f"{'k_strided16' if n == 2048 else 'k_strided_pk8'}<{-1 if cls.endswith('_fwd') else 1}, pre, band>"
     # last template argument of k_strided: addresses split into a scalar and a 32-bit lane part (one rank and up to eight: true)
     if cls in ("xpass_hess_1to3", "ypass_hess_3to6", "xpass_disp_1to2", "ypass_disp_2to3", "xpass_plain", "ypass_plain"):
         return f"k_strided<{FS}, {n}, {t}, 1, true>"
@@ -700,6 +704,7 @@ def main():
         finally:
             del os.environ["PF_EXACT_LIBM"]
 
+    invalid = False   # set by rank 0 when the result check says the timed steps computed something else (see result_check below)
     if rank == 0:
         ms = 1e3 * dt / args.steps
         cells = float(n) ** 3
@@ -783,14 +788,43 @@ def main():
                                "PDF: the 210-bin Fmax histogram; computed after the timed region")
                 if golden and not chk["matches_single_gpu_golden"]:
                     print(f"[bench] RESULT CHECK FAILED: fingerprints {chk['fingerprint']} differ from the single-GPU golden {golden['fingerprint']}", file=sys.stderr, flush=True)
+            # the other way of feeding the x-pass that was timed beside the line (exchange.alternative): its results are held against the same golden
+            ac = alt.get("check") if (world > 1 and alt is not None) else None
+            if ac is not None and "exchange" in out and "alternative" in out["exchange"]:
+                a = out["exchange"]["alternative"]
+                a["result_check_error"] = ac.get("error")
+                a["matches_single_gpu_golden"] = (fingerprints_agree(ac["fingerprint"], golden["fingerprint"]) if (golden and "fingerprint" in ac) else None)
+            # A wrong result must not pass as a measurement.  With a golden made from THESE kernel sources a mismatch means a block went to
+            # the wrong place (or a rank computed something else), and a check that could not run says nothing good either: the line is
+            # kept for diagnosis, marked invalid, its metric nulled, and the process exits non-zero.  (A golden from other sources may differ
+            # in last bits legitimately: reported, not fatal.)
+            same_src = bool(golden) and golden.get("kernel_source_sha") == _lib.source_sha()
+            bad = []
+            if golden and "error" in chk:
+                bad.append("the result check raised: " + str(chk["error"]))
+            if same_src and chk.get("matches_single_gpu_golden") is False:
+                bad.append("fingerprints differ from the single-GPU golden of these kernel sources")
+            if same_src and ac is not None and (("error" in ac) or out["exchange"]["alternative"].get("matches_single_gpu_golden") is False):
+                bad.append("the alternative exchange mode's results differ from the golden (or its check raised)")
             out["result_check"] = chk
+            if bad:
+                out["valid"] = False
+                out["invalid_because"] = bad
+                out["value_as_measured"] = out["value"]
+                out["value"] = None
+                invalid = True
         if exact:
             out["exact_libm"] = exact
         if world == 1 and args.cpu_n:
             out["cpu_baseline"] = cpu_baseline(args.cpu_n, ns, lpt)
         print(json.dumps(out), flush=True)
     if world > 1:
+        bad_flag = torch.tensor([1 if invalid else 0])
+        dist.broadcast(bad_flag, src=0)   # every rank leaves with rank 0's verdict (the launcher reports the first non-zero exit)
+        invalid = bool(bad_flag.item())
         dist.destroy_process_group()
+    if invalid:
+        sys.exit(5)
 
 
 if __name__ == "__main__":

@@ -144,21 +144,47 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
   const int srow = (int)(stride / p.n), scol = (int)(stride - (long long)srow * p.n);
   const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   int row = (int)(i0 / p.n), col = (int)(i0 - (long long)row * p.n);
-  for (long long i = i0; i < ncell; i += stride, row += srow, col += scol) {
-    if (col >= p.n) { col -= p.n; row++; }
-    const long long a = (long long)row * p.pitch + col;
-    double d[6];
-#if PF_NT  // (read once per radius: streaming loads, pf_fft_core.h)
-    d[0] = (double)__builtin_nontemporal_load(&h0[a]); d[1] = (double)__builtin_nontemporal_load(&h1[a]); d[2] = (double)__builtin_nontemporal_load(&h2[a]);
-    if (!INV) { d[3] = (double)__builtin_nontemporal_load(&h3[a]); d[4] = (double)__builtin_nontemporal_load(&h4[a]); d[5] = (double)__builtin_nontemporal_load(&h5[a]); }
-#else
-    d[0] = (double)h0[a]; d[1] = (double)h1[a]; d[2] = (double)h2[a];
-    if (!INV) { d[3] = (double)h3[a]; d[4] = (double)h4[a]; d[5] = (double)h5[a]; }
+#ifndef PF_SOLVE_PREFETCH
+#define PF_SOLVE_PREFETCH 0  // (1 in an A/B build: see below -- measured: no gain, 16.2 against 15.9 ms per launch)
 #endif
-    // products[].Fmax is float, compared after promotion (quirk Q2); init -10 / -1 at ismooth 0.  Loaded here, with the
-    // Hessian, so that its latency hides under the solve instead of sitting between the solve and the store.
-    PR *__restrict__ fmax = (PR *)p.fmax;
-    const PR fold = p.ismooth ? fmax[i] : (PR)-10.0f;
+  // PF_SOLVE_PREFETCH=1 (A/B, round 5): the inputs of a thread's NEXT cell are requested before it solves the current one.  No gain
+  // (16.2 against 15.9 ms per launch at 1024^3): the wait at the top of the next iteration then also covers this iteration's two
+  // conditional stores -- the counter is in order and the compiler cannot count stores behind a branch -- which costs what the
+  // early request saves.  products[].Fmax is float, compared after promotion (quirk Q2); init -10 / -1 at ismooth 0.
+  PR *__restrict__ fmax = (PR *)p.fmax;
+  double dn[6] = {0, 0, 0, 0, 0, 0};
+  PR foldn = (PR)-10.0f;
+  long long an = 0;
+  auto fetch = [&](long long i, long long a) {
+#if PF_NT  // (read once per radius: streaming loads, pf_fft_core.h)
+    dn[0] = (double)__builtin_nontemporal_load(&h0[a]); dn[1] = (double)__builtin_nontemporal_load(&h1[a]); dn[2] = (double)__builtin_nontemporal_load(&h2[a]);
+    if (!INV) { dn[3] = (double)__builtin_nontemporal_load(&h3[a]); dn[4] = (double)__builtin_nontemporal_load(&h4[a]); dn[5] = (double)__builtin_nontemporal_load(&h5[a]); }
+#else
+    dn[0] = (double)h0[a]; dn[1] = (double)h1[a]; dn[2] = (double)h2[a];
+    if (!INV) { dn[3] = (double)h3[a]; dn[4] = (double)h4[a]; dn[5] = (double)h5[a]; }
+#endif
+    foldn = p.ismooth ? fmax[i] : (PR)-10.0f;
+    an = a;
+  };
+  if (PF_SOLVE_PREFETCH && i0 < ncell) {
+    if (col >= p.n) { col -= p.n; row++; }
+    fetch(i0, (long long)row * p.pitch + col);
+  }
+  for (long long i = i0; i < ncell; i += stride) {
+    if (!PF_SOLVE_PREFETCH) {
+      if (col >= p.n) { col -= p.n; row++; }
+      fetch(i, (long long)row * p.pitch + col);
+    }
+    double d[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) d[k] = dn[k];
+    const PR fold = foldn;
+    const long long a = an;
+    row += srow; col += scol;
+    if (PF_SOLVE_PREFETCH && i + stride < ncell) {
+      if (col >= p.n) { col -= p.n; row++; }
+      fetch(i + stride, (long long)row * p.pitch + col);
+    }
     if (SRC) {
       double src2, src31, src32;
       pf_lpt_sources_cell(d, src2, src31, src32);

@@ -184,10 +184,20 @@ PF_HD double pf_div_fast(double a, double b) {
   return a / b;
 #endif
 }
+#ifndef PF_SQRT_BRANCHLESS
+#define PF_SQRT_BRANCHLESS 1  // (0 in an A/B build: zero, negative and NaN arguments through a branch to the library's sqrt)
+#endif
 PF_HD double pf_sqrt_fast(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
+#if PF_SQRT_BRANCHLESS
+  // no branch: a negative or NaN argument gives NaN through the seed itself, as the library's sqrt; a zero (seed +inf) keeps its own
+  // value by a seed of zero.  Round 5: the branch cut the solve into small blocks, each with its own exec-mask bookkeeping and with
+  // hazard s_nops the scheduler had nothing to fill with -- six square roots per cell
+  const double y = x == 0.0 ? 0.0 : __builtin_amdgcn_rsq(x);  // 2^-24.2
+#else
   if (!(x > 0.0)) return x == 0.0 ? x : sqrt(x);  // zero, negative and NaN as the library
   const double y = __builtin_amdgcn_rsq(x);  // 2^-24.2
+#endif
   double g = x * y, h = 0.5 * y;
   const double r = fma(-h, g, 0.5);
   g = fma(g, r, g); h = fma(h, r, h);        // 2^-47.8
@@ -296,7 +306,31 @@ template <bool FAST> PF_HD double pf_pow_third(double x) {
 // (tests/test_collapse_core.py).  The argument is clamped to the range where the result is finite and non-zero plus one
 // step, so overflow and underflow come out of the scaling as inf and 0; a NaN argument (not reachable from the callers:
 // ordered eigenvalues over a positive trace, a spline value) would give 0.
+#ifndef PF_EXP_ONE_ASM
+#define PF_EXP_ONE_ASM 1  // (0 in an A/B build: one inline-assembly statement per Horner step)
+#endif
 PF_HD double pf_exp_reduced(double r) {
+#if defined(__HIP_DEVICE_COMPILE__) && PF_EXP_ONE_ASM
+  // The twelve steps as ONE assembly statement, coefficients in scalar registers: between two single-instruction statements the
+  // compiler places an s_nop (it cannot see what they are), and a coefficient in a vector register costs two v_mov per step.
+  double p = 2.51003854955103203e-08;
+  asm("v_fma_f64 %0, %0, %1, %2\n\t"
+      "v_fma_f64 %0, %0, %1, %3\n\t"
+      "v_fma_f64 %0, %0, %1, %4\n\t"
+      "v_fma_f64 %0, %0, %1, %5\n\t"
+      "v_fma_f64 %0, %0, %1, %6\n\t"
+      "v_fma_f64 %0, %0, %1, %7\n\t"
+      "v_fma_f64 %0, %0, %1, %8\n\t"
+      "v_fma_f64 %0, %0, %1, %9\n\t"
+      "v_fma_f64 %0, %0, %1, %10\n\t"
+      "v_fma_f64 %0, %0, %1, 1.0\n\t"
+      "v_fma_f64 %0, %0, %1, 1.0"
+      : "+v"(p)
+      : "v"(r), "s"(2.76200884454097462e-07), "s"(2.75572684599970641e-06), "s"(2.48015212959543761e-05), "s"(1.98412698630536177e-04),
+        "s"(1.38888889172137167e-03), "s"(8.33333333333006153e-03), "s"(4.16666666666241289e-02), "s"(1.66666666666666685e-01),
+        "s"(5.00000000000000111e-01));
+  return p;
+#else
   double p = 2.51003854955103203e-08;
   p = pf_horner(p, r, 2.76200884454097462e-07);
   p = pf_horner(p, r, 2.75572684599970641e-06);
@@ -309,6 +343,7 @@ PF_HD double pf_exp_reduced(double r) {
   p = pf_horner(p, r, 5.00000000000000111e-01);
   p = fma(p, r, 1.0);
   return fma(p, r, 1.0);
+#endif
 }
 PF_HD double pf_exp_series(double x) {
   x = fmin(fmax(x, -746.0), 710.0);  // e^-746 = 0 and e^710 = inf in double: k stays a small integer for every x

@@ -122,20 +122,22 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4))) 
     const int mul = p.job[j].mul;
     const float kff = (float)kfd;
     if (PRE) {
+      const bool windowed = p.rs != 0.0;
 #pragma unroll
       for (int m = 0; m < 16; m++) {
         const int e = pf16_line_index(tlj, m);
         const float ke = kff * (float)(e > N / 2 ? e - N : e);
-        const float we = p.rs != 0.0 ? (float)p.etab[e] : 1.f;
-        float km = 1.f;
-        if (mul == PF_MUL_K || mul == PF_MUL_IK) km = ke;
-        else if (mul == PF_MUL_K2) km = ke * ke;
-        const float k2a = fmaf(ke, ke, ko2kc2[0]), k2b = fmaf(ke, ke, ko2kc2[1]);
-        const float fa = k2a != 0.f ? we * wocf[0] * km * __builtin_amdgcn_rcpf(k2a) : 0.f;
-        const float fb = k2b != 0.f ? we * wocf[1] * km * __builtin_amdgcn_rcpf(k2b) : 0.f;
+        float wk = windowed ? (float)p.etab[e] : 1.f;  // the window along the transformed axis ...
+        if (mul == PF_MUL_K || mul == PF_MUL_IK) wk *= ke;  // ... times this job's power of k
+        else if (mul == PF_MUL_K2) wk *= ke * ke;
+        // 1 / k^2 by the hardware reciprocal (1 ulp of fp32: the precision of the field).  k = 0 -- one element of the whole grid,
+        // left untouched by the reference (src/fmax-pfft.c:368) and zero here -- is dealt with below, not by a test per element
+        const float fa = wk * wocf[0] * __builtin_amdgcn_rcpf(fmaf(ke, ke, ko2kc2[0]));
+        const float fb = wk * wocf[1] * __builtin_amdgcn_rcpf(fmaf(ke, ke, ko2kc2[1]));
         va[m] = va[m] * fa;
         vb[m] = vb[m] * fb;
       }
+      if (ko2kc2[0] == 0.f && tlj == 0) va[0] = (C){0.f, 0.f};  // k = 0: row 0 of the thread whose first column and outer wavenumber are zero
     } else if (mul != PF_MUL_ONE) {
 #pragma unroll
       for (int m = 0; m < 16; m++) {
@@ -226,30 +228,201 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4))) 
   }
 }
 
-// 0: launched; 1: launch failed; 3: LDS opt-in refused; -1: not a case of this kernel (the caller runs k_strided)
+// ---- 1024-point fp32 lines: EIGHT points x two columns per thread (the tile, 128 KB, fits LDS and a second copy of it fits the
+// registers: the input of several jobs is kept, as in k_strided), in the same packed (re, im) arithmetic.  Plan 16 x 8 x 8 with the
+// paired first stage of pf_fft_core.h: each thread its radix 8, the odd one of a pair the twiddle W16^k, then one radix-2 step
+// across the pair through the lanes of the wave (row_ror:8).  What k_strided<pf_f32x2, 1024, 8> spends beside its butterflies --
+// lane shuffles on every load and store (its pairs are (re, re), (im, im)), twiddle powers and constants in separate registers
+// per half, ~940 vector instructions per job -- is gone: ~420.
+#ifndef PF_STRIDED_PK8
+#define PF_STRIDED_PK8 1  // (0 in an A/B build: 1024-point fp32 lines on k_strided<pf_f32x2, 1024, 8>)
+#endif
+__device__ __forceinline__ pf_f2 pf_pk_xor8(pf_f2 v) { pf_f2 r; r.x = pf_lane_xor8(v.x); r.y = pf_lane_xor8(v.y); return r; }
+
+template <int DIR, bool PRE, bool BAND>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4))) k_strided_pk8(const PfStridedParams p, const long long nwork, const int ntiles) {
+  using A = PfCxPk;
+  using C = pf_f2;
+  constexpr int N = 1024, T = 8, NT = N / 8;  // 128 threads per column pair
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  pf_f4 *lds = reinterpret_cast<pf_f4 *>(smem);  // [N][T] column pairs (128 KB)
+  const long long w = pf_xcd_swizzle(blockIdx.x, (nwork + 7) >> 3);
+  if (w >= nwork) return;
+  const int tid = threadIdx.x;
+  const int c = tid % T, tl = tid / T;
+  const int tile = (int)(w % ntiles);
+  const int outer = (int)(w / ntiles);
+  const int col = 2 * (tile * T + c);
+  const pf_f2 *__restrict__ tw = reinterpret_cast<const pf_f2 *>(p.tw);
+  const double kfd = 2.0 * 3.14159265358979323846 / (double)N;
+  const float kff = (float)kfd;
+  if (BAND && p.band_outer < N / 2) {
+    int so = outer + p.outer_offset;
+    if (so > N / 2) so -= N;
+    if (so > p.band_outer || so < -p.band_outer) return;
+  }
+  float wocf[2] = {1.f, 1.f}, ko2kc2[2] = {0.f, 0.f};
+  if (PRE) {
+    int so = outer + p.outer_offset;
+    if (so > N / 2) so -= N;
+    const double ko = kfd * so;
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+      const double kc = kfd * (col + l);
+      const double s = ko * ko + kc * kc;
+      wocf[l] = (float)((p.rs != 0.0 ? exp(-0.5 * s * p.rs * p.rs) : 1.0) * p.growth);
+      ko2kc2[l] = (float)s;
+    }
+  }
+  pf_f4 src[8];
+  // a tile of input `in` into src: rows pf_line_index<N, true>(tl, m) = lane part + 128 m, a block of 128 rows at a time (uniform band
+  // test per block, the rows beyond the band inside a block cleared; nothing predicated by column: see k_strided16)
+  auto load_tile = [&](const void *inp, int tlj, int cj) {
+    const pfc<float> *__restrict__ in = reinterpret_cast<const pfc<float> *>(inp);
+    const int e0 = pf_line_index<N, true>(tlj, 0);
+    const unsigned lane = pf_addr_lane(p.ain, e0, 2 * cj);
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const bool inband = !BAND || (m < 4 ? 128 * m <= p.band_e : N - (128 * m + 127) <= p.band_e);
+      pf_f4 t = (pf_f4){0.f, 0.f, 0.f, 0.f};
+      if (inband) {
+        long long u = pf_addr_uniform<NT>(p.ain, outer, m, 2 * tile * T);
+        asm volatile("" : "+s"(u));
+        t = pf16_ld(in, u, lane);
+        if (BAND) {
+          const int e = e0 + m * NT, se = e > N / 2 ? e - N : e;
+          if (se > p.band_e || se < -p.band_e) t = (pf_f4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      src[m] = t;
+    }
+  };
+  load_tile(p.job[0].in, tl, c);
+#pragma unroll 1
+  for (int j = 0; j < p.njobs; j++) {
+    int tlj = tl, cj = c;
+    asm volatile("" : "+v"(tlj), "+v"(cj));
+    const int e0 = pf_line_index<N, true>(tlj, 0);
+    // jobs are grouped by input: a tile is read once, filtered once, and transformed for every job that uses it
+    if (PRE && (j == 0 || p.job[j].in != p.job[j - 1].in)) {
+      const bool windowed = p.rs != 0.0;
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        const int e = e0 + m * NT;
+        const float ke = kff * (float)(e > N / 2 ? e - N : e);
+        const float wk = windowed ? (float)p.etab[e] : 1.f;
+        const float fa = wk * wocf[0] * __builtin_amdgcn_rcpf(fmaf(ke, ke, ko2kc2[0]));
+        const float fb = wk * wocf[1] * __builtin_amdgcn_rcpf(fmaf(ke, ke, ko2kc2[1]));
+        src[m] = (pf_f4){src[m].x * fa, src[m].y * fa, src[m].z * fb, src[m].w * fb};
+      }
+      if (ko2kc2[0] == 0.f && e0 == 0) { src[0].x = 0.f; src[0].y = 0.f; }  // k = 0 (see k_strided16)
+    }
+    const int mul = p.job[j].mul;
+    C va[8], vb[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      va[m] = (C){src[m].x, src[m].y}; vb[m] = (C){src[m].z, src[m].w};
+      if (mul != PF_MUL_ONE) {
+        const int e = e0 + m * NT;
+        const float ke = kff * (float)(e > N / 2 ? e - N : e);
+        const float km = mul == PF_MUL_K2 ? ke * ke : ke;
+        va[m] = va[m] * km; vb[m] = vb[m] * km;
+        if (mul == PF_MUL_IK) { va[m] = A::muli<+1>(va[m]); vb[m] = A::muli<+1>(vb[m]); }
+      }
+    }
+    // src is free once the last job on this input has taken its copy: the next input's tile travels during the stages
+    if (j + 1 < p.njobs && p.job[j + 1].in != p.job[j].in) load_tile(p.job[j + 1].in, tlj, cj);
+    // twiddles of the two later stages: w^1 of this thread's butterfly (pf_stage_twiddles: k = tl & (NS - 1), table step N / (NS R))
+    const C w1 = tw[(tlj & 15) * 8], w2 = tw[tlj & 127];
+    // ---- stage 0: the pair (tl, tl ^ 1) = (h = 0, 1) of butterfly tl >> 1
+    pfx_bfly8<A, DIR>(va);
+    pfx_bfly8<A, DIR>(vb);
+    {
+      const bool odd = tlj & 1;
+      if (odd) {
+        const double c1 = 0.92387953251128675613, s1 = 0.38268343236508977173, h = 0.70710678118654752440;
+#define PF_W16(k, cc, ss) va[k] = A::cmulc<DIR>(va[k], cc, ss); vb[k] = A::cmulc<DIR>(vb[k], cc, ss);
+        PF_W16(1, c1, s1) PF_W16(2, h, h) PF_W16(3, s1, c1) PF_W16(5, -s1, c1) PF_W16(6, -h, h) PF_W16(7, -c1, s1)
+#undef PF_W16
+        va[4] = A::muli<DIR>(va[4]); vb[4] = A::muli<DIR>(vb[4]);
+      }
+      const float sg = odd ? -1.f : 1.f;  // X[ta] = Y0 + Y1 stays with h = 0, X[ta + 8] = Y0 - Y1 with h = 1: o + sgn v
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        const C oa = pf_pk_xor8(va[m]), ob = pf_pk_xor8(vb[m]);
+        va[m] = __builtin_elementwise_fma(va[m], (C){sg, sg}, oa);
+        vb[m] = __builtin_elementwise_fma(vb[m], (C){sg, sg}, ob);
+      }
+    }
+    // ---- exchange, stage 1 (NS = 16), exchange, stage 2 (NS = 128): positions of pf_stage_pos<N, S, true>
+#pragma unroll
+    for (int S = 0; S < 2; S++) {
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        const int pos = S == 0 ? pf_stage_pos<N, 0, true>(tlj, m) : pf_stage_pos<N, 1, true>(tlj, m);
+        lds[pos * T + cj] = (pf_f4){va[m].x, va[m].y, vb[m].x, vb[m].y};
+      }
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < 8; m++) { const pf_f4 t = lds[(tlj + m * NT) * T + cj]; va[m] = (C){t.x, t.y}; vb[m] = (C){t.z, t.w}; }
+      __syncthreads();
+      C wp[7];
+      pfx_powers7<A>(S == 0 ? w1 : w2, wp);
+#pragma unroll
+      for (int r = 1; r < 8; r++) { va[r] = A::cmul<DIR>(va[r], wp[r - 1]); vb[r] = A::cmul<DIR>(vb[r], wp[r - 1]); }
+      pfx_bfly8<A, DIR>(va);
+      pfx_bfly8<A, DIR>(vb);
+    }
+    // ---- store: register m is element tl + 128 m
+    {
+      pfc<float> *__restrict__ out = reinterpret_cast<pfc<float> *>(p.job[j].out);
+      const unsigned lane = pf_addr_lane(p.aout, tlj, 2 * cj);
+      if (2 * (tile + 1) * T <= p.ncols) {
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          long long u = pf_addr_uniform<NT>(p.aout, outer, m, 2 * tile * T);
+          asm volatile("" : "+s"(u));
+          pf16_st4(out, u, lane, va[m], vb[m]);
+        }
+      } else {
+        const int colj = 2 * (tile * T + cj);
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          const long long u = pf_addr_uniform<NT>(p.aout, outer, m, 2 * tile * T);
+          if (colj + 1 < p.ncols) pf16_st4(out, u, lane, va[m], vb[m]);
+          else if (colj < p.ncols) pf16_st2(out, u, lane, va[m]);
+        }
+      }
+    }
+  }
+}
+
+// 0: launched; 1: launch failed; 3: LDS opt-in refused; -1: not a case of these kernels (the caller runs k_strided)
 int pf_launch_strided16(int fb, int n, int dir, const PfStridedParams &p, hipStream_t st) {
-  if (!PF_STRIDED16 || fb != 4 || n != PF16_N || p.out_ne > 0) return -1;
-  constexpr int T = 8, NT = PF16_N / 16;
-  // split addresses (pf_addr_uniform): a slab holds whole multiples of 128 elements of the transformed axis on both sides (up to
-  // sixteen ranks) and the per-lane part -- at most 127 rows plus a tile's columns -- fits 32 bits in bytes
+  if (fb != 4 || p.out_ne > 0) return -1;
+  if (!((n == PF16_N && PF_STRIDED16) || (n == 1024 && PF_STRIDED_PK8))) return -1;
+  constexpr int T = 8, NT = 128;  // both kernels: 128 threads per column pair, elements lane part (< 128) + 128 m
+  // split addresses (pf_addr_uniform): a slab holds whole multiples of 128 elements of the transformed axis on both sides and the
+  // per-lane part -- at most 127 rows plus a tile's columns -- fits 32 bits in bytes
   auto lane_fits = [&](const PfAddr &a) {
     return (1 << a.el_shift) >= NT && a.els > 0 && ((unsigned long long)(NT - 1) * (unsigned long long)a.els + (unsigned long long)(2 * T)) * sizeof(pfc<float>) < (1ull << 32);
   };
   if (!lane_fits(p.ain) || !lane_fits(p.aout)) return -1;
   const int ntiles = (p.ncols + 2 * T - 1) / (2 * T);
   const long long nwork = (long long)ntiles * p.nouter;
-  const size_t shm = (size_t)PF16_N * T * sizeof(pf_f2);  // 128 KB
+  const size_t shm = 128 * 1024;
   // instantiations: inverse passes with and without the first-pass filter, band-limited or not; forward passes carry neither
-  const bool band = p.band_e < PF16_N / 2 || p.band_outer < PF16_N / 2;
+  const bool band = p.band_e < n / 2 || p.band_outer < n / 2;
   if (dir < 0 && (p.pre || band)) return -1;
-  const int k = dir < 0 ? 4 : (p.pre ? 2 : 0) + (band ? 1 : 0);
+  const int k = (n == 1024 ? 5 : 0) + (dir < 0 ? 4 : (p.pre ? 2 : 0) + (band ? 1 : 0));
   typedef void (*kern_t)(const PfStridedParams, const long long, const int);
-  static const kern_t kern[5] = {k_strided16<+1, false, false>, k_strided16<+1, false, true>, k_strided16<+1, true, false>, k_strided16<+1, true, true>, k_strided16<-1, false, false>};
-  static std::atomic<bool> raised[5][PF_MAX_DEVICES];
+  static const kern_t kern[10] = {k_strided16<+1, false, false>, k_strided16<+1, false, true>, k_strided16<+1, true, false>, k_strided16<+1, true, true>, k_strided16<-1, false, false>,
+                                  k_strided_pk8<+1, false, false>, k_strided_pk8<+1, false, true>, k_strided_pk8<+1, true, false>, k_strided_pk8<+1, true, true>, k_strided_pk8<-1, false, false>};
+  static std::atomic<bool> raised[10][PF_MAX_DEVICES];
   const int d = p.dev >= 0 && p.dev < PF_MAX_DEVICES ? p.dev : 0;
   if (!raised[k][d].load(std::memory_order_acquire)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern[k]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) {
-      fprintf(stderr, "ERROR on task 0: hipFuncSetAttribute(MaxDynamicSharedMemorySize = %zu) refused for the sixteen-point strided pass on device %d\n", shm, d);
+      fprintf(stderr, "ERROR on task 0: hipFuncSetAttribute(MaxDynamicSharedMemorySize = %zu) refused for the packed fp32 strided pass on device %d\n", shm, d);
       return 3;
     }
     raised[k][d].store(true, std::memory_order_release);

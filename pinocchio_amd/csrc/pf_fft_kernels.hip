@@ -746,7 +746,7 @@ static int launch_strided_n(const PfStridedParams &p, hipStream_t st) {
 #endif
 template <int N, int DIR>
 static int launch_strided_f32(const PfStridedParams &p, hipStream_t st) {
-  if constexpr (N == 2048) {  // sixteen points per thread, 128-byte row segments (pf_fft16_kernels.hip), where its addressing applies
+  if constexpr (N == 2048 || N == 1024) {  // the kernels in packed (re, im) arithmetic (pf_fft16_kernels.hip), where their addressing applies
     const int rc = pf_launch_strided16(4, N, DIR, p, st);
     if (rc >= 0) return rc;
   }

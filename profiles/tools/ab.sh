@@ -28,7 +28,7 @@ for r in rows:
     line = "%-26s" % r
     for v, d in runs.items():
         k = [x for x in d["kernels"] if x["name"] == r]
-        line += "%12.3f" % (k[0]["ms_per_step"] * d["steps"] / k[0]["launches"]) if k else "%12s" % "-"
+        line += "%12.3f" % (k[0]["ms_per_step"] * (d.get("kernel_table") or {}).get("steps", d["steps"]) / k[0]["launches"]) if k else "%12s" % "-"
     print(line)
 print("%-26s" % "ms per step" + "".join("%12.1f" % d["ms_per_step"] for d in runs.values()))
 PY

@@ -58,8 +58,11 @@ def test_overlapping_spans_without_an_in_line_pass():
 
 
 def test_fp32_symbols():
-    assert bench.symbol_of("ypass_hess_3to6", 1024, 4) == "k_strided<float __vector(2), 1024, 8, 1, true>"
-    assert bench.symbol_of("ypass_hess_3to6", 2048, 4) == "k_strided<float __vector(2), 2048, 4, 1, true>"
+    # fp32 lines of 1024 / 2048 points: the packed-arithmetic kernels of csrc/pf_fft16_kernels.hip, named by family
+    assert bench.symbol_of("ypass_hess_3to6", 1024, 4) == "k_strided_pk8<1, pre, band>"
+    assert bench.symbol_of("ypass_hess_3to6", 2048, 4) == "k_strided16<1, pre, band>"
+    assert bench.symbol_of("xpass_fwd", 2048, 4) == "k_strided16<-1, pre, band>"
+    assert bench.symbol_of("ypass_hess_3to6", 512, 4) == "k_strided<float, 512, 16, 1, true>"
     assert bench.symbol_of("zpass_c2r_hess_6to3inv", 2048, 4) == "k_c2r_invariants_spec<float, 2048, 0>"
     assert bench.symbol_of("zpass_c2r_hess_6to3inv", 256, 8) == "k_c2r_invariants<double, 256, 0>"
     assert bench.symbol_of("zpass_c2r_hess_6to3inv", 512, 8) == "k_c2r_invariants_spec<double, 512, 0>"
