@@ -573,19 +573,64 @@ def run_slab(args):
         f.close()
 
 
-def exchange_report(res, args):
+XGMI_GBS_PER_LINK = 153.0   # one xGMI link between two GPUs of a node, per direction
+
+
+def slab_model(n: int, P: int, fb: int, replicated: bool):
+    """the compute side of one rank of a P-rank run of the n^3 box as measured on ONE GPU with the exchange short-circuited
+    (`bench.py --slab-of P`, committed as profiles/<round>_slab_<n>_p<P>[_rep<0|1>][_fp32].json): ms per step and rank, or None"""
+    names = [f"{PROFILE_ROUND}_slab_{n}_p{P}{'_fp32' if fb == 4 else ''}.json", f"{PROFILE_ROUND}_slab_{n}_p{P}_rep{1 if replicated else 0}{'_fp32' if fb == 4 else ''}.json"]
+    for nm in names:
+        try:
+            with open(os.path.join(ROOT, "profiles", nm)) as fh:
+                d = json.loads(fh.read().strip().splitlines()[-1])
+            if bool(d["config"].get("replicated_spectrum")) == bool(replicated):
+                return {"ms_per_step_per_rank": d["ms_per_step"], "file": "profiles/" + nm, "kernel_source_sha": d["config"].get("kernel_source_sha")}
+        except (OSError, ValueError, KeyError, IndexError):
+            continue
+    return None
+
+
+def exchange_report(res, args, world=None):
+    """what rank 0 saw of the all-to-alls, and what it means: per transposed field the time on the communication stream against the
+    compute time beside it, the rate per xGMI link (every peer pair has its own link: a rank's field goes out in P - 1 pieces of
+    1 / P each), and the prediction of the one-GPU slab measurements + the survey's link rate for this rank count -- so that ONE
+    run on real peers says whether the exchanges hide, whether the link rate is what was assumed, and which way of feeding the
+    x-pass (exchange.alternative) is the right default"""
     ex = [s for s in res["stats"] if s["name"] == "exchange"]
     kern = [s for s in res["stats"] if s["name"] != "exchange"]
     e = ex[0] if ex else {"launches": 0, "total_ms": 0.0, "alg_bytes": 0.0}
-    return {"kind": res["exchange_kind"], "replicated_spectrum": res["replicated_spectrum"],
-            "ranks_in_communicator": res["ranks_in_communicator"],
-            "ms_per_step": 1e3 * res["dt"] / args.steps,
-            "calls_per_step": e["launches"] / args.steps, "GB_per_step_per_rank": e["alg_bytes"] / args.steps / 1e9,
-            "ms_per_step_on_comm_stream": e["total_ms"] / args.steps,
-            "GBps_per_rank": e["alg_bytes"] / max(e["total_ms"], 1e-9) / 1e6,
-            "compute_ms_per_step": sum(s["total_ms"] for s in kern) / args.steps,
-            # (the solve of sweep radius i runs beside the z-pass of radius i + 1: those two classes' spans overlap and the sum above counts the shared time twice)
-            "compute_spans_overlap_on_solve_stream": bool(res.get("solve_beside"))}
+    P = int(world) if world else int(res.get("ranks_in_communicator") or 0)
+    calls = e["launches"] / args.steps
+    comm_ms = e["total_ms"] / args.steps
+    compute_ms = sum(s["total_ms"] for s in kern) / args.steps
+    gb = e["alg_bytes"] / args.steps / 1e9          # bytes of the exchanged fields of this rank, its own block included
+    step_ms = 1e3 * res["dt"] / args.steps
+    out = {"kind": res["exchange_kind"], "replicated_spectrum": res["replicated_spectrum"],
+           "ranks_in_communicator": res["ranks_in_communicator"],
+           "ms_per_step": step_ms,
+           "calls_per_step": calls, "GB_per_step_per_rank": gb,
+           "ms_per_step_on_comm_stream": comm_ms,
+           "GBps_per_rank": e["alg_bytes"] / max(e["total_ms"], 1e-9) / 1e6,
+           "compute_ms_per_step": compute_ms,
+           # (the solve of sweep radius i runs beside the z-pass of radius i + 1: those two classes' spans overlap and the sum above counts the shared time twice)
+           "compute_spans_overlap_on_solve_stream": bool(res.get("solve_beside"))}
+    if calls > 0 and P > 1:
+        wire_gb_per_link = gb / P                    # one of the P - 1 equal pieces that leave over P - 1 links at once
+        out["per_transposed_field"] = {"ms_on_comm_stream": comm_ms / calls, "compute_ms_beside_it": compute_ms / calls,
+                                       "MB_per_link": 1e3 * wire_gb_per_link / calls}
+        out["GBps_per_link"] = wire_gb_per_link / max(comm_ms, 1e-9) * 1e3
+        out["link_rate_assumed_GBps"] = XGMI_GBS_PER_LINK
+        out["exchange_hidden_fraction"] = max(0.0, min(1.0, (compute_ms + comm_ms - step_ms) / max(comm_ms, 1e-9)))
+        m = slab_model(args.n, P, args.field_bytes, bool(res["replicated_spectrum"]))
+        wire_ms = 1e3 * wire_gb_per_link / XGMI_GBS_PER_LINK
+        pred = {"wire_ms_per_step_at_assumed_link_rate": wire_ms}
+        if m:
+            pred.update({"compute_ms_per_step_per_rank_on_one_gpu": m["ms_per_step_per_rank"], "from": m["file"],
+                         "step_ms_if_exchanges_hide": max(m["ms_per_step_per_rank"], wire_ms), "step_ms_if_nothing_hides": m["ms_per_step_per_rank"] + wire_ms,
+                         "measured_step_over_hidden_prediction": step_ms / max(m["ms_per_step_per_rank"], wire_ms)})
+        out["model"] = pred
+    return out
 
 
 def main():
@@ -753,7 +798,7 @@ def main():
             "phases_s_per_step": {k: v / args.steps for k, v in cput.items()},
         }
         if world > 1:
-            ex = exchange_report(res, args)
+            ex = exchange_report(res, args, world)
             ex["process_group_size"] = int(dist.get_world_size())
             ex["kind_votes"] = votes
             ex["devices"] = devices
@@ -766,7 +811,7 @@ def main():
                           "section 5): step time well below compute + exchange means the overlap works.  replicated_spectrum (2-4 ranks by "
                           "default): every rank keeps the whole delta(k), the sweep exchanges nothing and only the LPT sources transpose")
             if alt is not None:
-                ex["alternative"] = exchange_report(alt, args)
+                ex["alternative"] = exchange_report(alt, args, world)
                 ex["alternative"]["value"] = cells * args.steps / alt["dt"]
                 print("[bench] alternative: " + json.dumps(ex["alternative"]), file=sys.stderr, flush=True)
             out["exchange"] = ex

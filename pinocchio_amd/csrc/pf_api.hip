@@ -165,7 +165,7 @@ struct pf_ctx {
   // general path: grid sizes that are not a power of two (one rank, fp64) go through library transforms
   bool general;
   void *W;                  // scratch spectrum of the filter
-  void *fft_c2r, *fft_r2c;  // hipfft plans (Z2D, D2Z), bound at run time (pf_general_fft_*)
+  void *fft_c2r, *fft_r2c;  // the chirp-z plan of the general path (pf_gfft.hip: one plan under both names)
   bool vel_zero_pending;  // the Vel* columns are to read as zero (src/collapse_times.c:472-489) but have not been cleared yet
   int last_ns;
   PfLoopback *loopback;
@@ -326,7 +326,7 @@ static int create_body(pf_ctx *c, const pf_config *cfg) {
   if (c->general) {
     PFCHK(c, dev_alloc(c, &c->W, c->field_bytes));
     const int rc = pf_gfft_create(c->n, c->stream, &c->fft_c2r, &c->fft_r2c);
-    if (rc) return pf_fail(rank, "pf_create: hipFFT plans for %d^3 failed (%d): grid sizes that are not a power of two need libhipfft", c->n, rc);
+    if (rc) return pf_fail(rank, "pf_create: the chirp-z plan of the general transform path for %d^3 failed (%d)", c->n, rc);
   }
   const size_t nc = ncell(c);
   PFCHK(c, dev_alloc(c, (void **)&c->fmax, nc * (size_t)c->pb));
@@ -365,11 +365,11 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   const bool mixed = !pow2 && !tune.general && pf_mixed_supported((int)n);
   const bool want_general = (!pow2 && !mixed) || tune.general;
   if (want_general) {
-    if (n < 4 || n > 4096 || (n & 1)) return pf_fail(rank, "pf_create: grid size %lld must be even, in [4, 4096]", n);
+    if (n < 4 || n > 2048 || (n & 1)) return pf_fail(rank, "pf_create: grid size %lld must be even, in [4, 2048]", n);
     if (cfg->nranks != 1 || cfg->field_bytes != 8)
-      return pf_fail(rank, "pf_create: grid size %lld is not a power of two: the library-transform path takes one rank and fp64 fields "
-                           "(slab decomposition and fp32 fields need a power of two in [16, 2048])", n);
-  } else if (!mixed && (n < 16 || n > 2048)) return pf_fail(rank, "pf_create: grid size %lld must be a power of two in [16, 2048] (or any even size on one rank)", n);
+      return pf_fail(rank, "pf_create: grid size %lld is not 8 * 2^a 3^b 5^c: the chirp-z transform path (any even size) takes one rank and fp64 fields; "
+                           "slab decomposition and fp32 fields need n = 8 * 2^a 3^b 5^c in [16, 2048] and a power-of-two number of ranks", n);
+  } else if (!mixed && (n < 16 || n > 2048)) return pf_fail(rank, "pf_create: grid size %lld must lie in [16, 2048] (n = 8 * 2^a 3^b 5^c on any power-of-two number of ranks, any even size on one rank)", n);
   if (cfg->nranks < 1 || n % cfg->nranks || cfg->rank < 0 || cfg->rank >= cfg->nranks)
     return pf_fail(rank, "pf_create: nranks %d must divide the grid size %lld (slab decomposition)", cfg->nranks, n);
   if (cfg->nranks & (cfg->nranks - 1)) return pf_fail(rank, "pf_create: nranks %d must be a power of two", cfg->nranks);
@@ -428,7 +428,8 @@ extern "C" int pf_destroy(pf_ctx *c) {
   for (int i = 0; i < 6; i++) { hipFree(c->B[i]); hipFree(c->B2[i]); }
   for (int i = 0; i < 3; i++) hipFree(c->S[i]);
   hipFree(c->fmax); hipFree(c->rmax); hipFree(c->vel12); hipFree(c->partials); hipFree(c->partials_src); hipFree(c->scal); hipFree(c->hist); hipFree(c->spl); hipFree(c->gt); hipFree(c->gt_lut); hipFree(c->gtab); hipFree(c->etab); hipFree(c->ct_block); hipFree(c->W);
-  pf_gfft_destroy(c->fft_c2r); pf_gfft_destroy(c->fft_r2c);
+  pf_gfft_destroy(c->fft_c2r);
+  if (c->fft_r2c != c->fft_c2r) pf_gfft_destroy(c->fft_r2c);
   for (auto &e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   for (auto &e : c->phase_evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   for (auto e : c->evpool) hipEventDestroy(e);
@@ -732,7 +733,7 @@ static void *recv_field(pf_ctx *c, int set, int f) { return (char *)(set ? c->re
 
 // ---------------------------------------------------------------------------------------------- general path ----
 // Grid sizes that are not a power of two (one rank, fp64): the reference's own structure -- one k-space filter and one
-// 3-D c2r per component (compute_derivative, src/fmax-pfft.c:255-441) -- with hipFFT transforms on the natural layouts
+// 3-D c2r per component (compute_derivative, src/fmax-pfft.c:255-441) -- with the chirp-z transforms of pf_gfft.hip on the natural layouts
 // (spectrum [n][n][n/2+1] = the boundary layout, real fields [n][n][n]).  Per-cell kernels are the same as in the
 // fused path.  Unfused, so it moves ~2x the bytes of the power-of-two path; it exists for completeness of the drop-in.
 static int g_filter(pf_ctx *c, const void *in, void *out, int a, int b, double rs, int order, bool normalise) {
@@ -747,12 +748,12 @@ static int g_filter(pf_ctx *c, const void *in, void *out, int a, int b, double r
 }
 static int g_c2r(pf_ctx *c, void *spec, void *real) {
   KTimer t(c, KS_ZPASS_PLAIN, spec_bytes_alg(c) + real_bytes_alg(c));
-  if (pf_gfft_c2r(c->fft_c2r, spec, real)) return pf_fail(c->rank, "hipfftExecZ2D failed");
+  if (pf_gfft_c2r(c->fft_c2r, spec, real)) return pf_fail(c->rank, "the c2r transform of the general path failed");
   return 0;
 }
 static int g_r2c(pf_ctx *c, void *real, void *spec) {
   KTimer t(c, KS_R2C_Z, spec_bytes_alg(c) + real_bytes_alg(c));
-  if (pf_gfft_r2c(c->fft_r2c, real, spec)) return pf_fail(c->rank, "hipfftExecD2Z failed");
+  if (pf_gfft_r2c(c->fft_r2c, real, spec)) return pf_fail(c->rank, "the r2c transform of the general path failed");
   return 0;
 }
 static int g_hessian_of(pf_ctx *c, const void *spec, double rs, void *const out[6]) {

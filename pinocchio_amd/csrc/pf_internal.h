@@ -206,7 +206,7 @@ int pf_launch_gen_filter(const void *in, void *out, int n, int a, int b, double 
                          double dlogk, double sign, double norm, hipStream_t st);
 int pf_launch_real_to_col(const double *src, void *dst, size_t ncell, int pb, hipStream_t st);
 int pf_launch_scale_real(double *f, size_t ncell, double s, hipStream_t st);
-// pf_gfft.cpp: hipFFT plans (double precision, n^3, natural layouts: spectrum [n][n][n/2+1], real [n][n][n])
+// pf_gfft.hip: chirp-z (Bluestein) 3-D transforms for any even n (double precision, natural layouts: spectrum [n][n][n/2+1], real [n][n][n])
 int pf_gfft_create(int n, hipStream_t st, void **c2r, void **r2c);
 int pf_gfft_c2r(void *plan, void *spec, void *real);   // unnormalised, out of place; may destroy spec
 int pf_gfft_r2c(void *plan, void *real, void *spec);   // unnormalised, out of place

@@ -47,7 +47,7 @@ def test_create_rejects_bad_configs_and_missing_gpu(lib, capfd):
     L = lib.load()
     h = C.c_void_p()
     # odd, too small, too large, rank count not dividing / not a power of two; sizes that are not a power of two are
-    # one-rank fp64 only (library-transform path)
+    # one-rank fp64 only (chirp-z transform path)
     for n, nranks, fb in ((101, 1, 8), (2, 1, 8), (8192, 1, 8), (64, 3, 8), (100, 2, 8), (100, 1, 4), (4096, 1, 4)):
         cfg = lib.Config(n=n, rank=0, nranks=nranks, device=0, field_bytes=fb, flags=0)
         assert L.pf_create(C.byref(h), C.byref(cfg)) != 0

@@ -105,3 +105,30 @@ def test_fingerprint_goldens_cover_the_configurations_that_are_held_against_them
         assert all(isinstance(fp[k], str) and len(fp[k]) == 16 for k in fp if k != "32PT_sumsq") and fp["32PT_sumsq"] > 0
         assert e["cells_in_fmax_pdf"] == n ** 3 and len(e["kernel_source_sha"]) == 16
         assert bench.fingerprints_agree(fp, dict(fp)) and not bench.fingerprints_agree(fp, dict(fp, FMAX="0" * 16))
+
+
+def test_exchange_report_per_field_and_per_link_numbers():
+    """bench.exchange_report: what an N > 1 line says about its all-to-alls -- per transposed field the time on the communication
+    stream and the compute beside it, the rate per xGMI link (a rank's field leaves in P - 1 pieces of 1 / P over P - 1 links at
+    once), how much of the exchange time hid behind the kernels, and the prediction from the one-GPU slab measurements"""
+    import argparse
+    args = argparse.Namespace(steps=2, n=1024, field_bytes=8)
+    P = 8
+    field_gb = 1024 ** 2 * 520 * 16 / P / 1e9            # one rank's share of a half spectrum
+    stats = [dict(name="xpass_hess_1to3", launches=26, total_ms=60.0, alg_bytes=1e11), dict(name="collapse_inv", launches=22, total_ms=100.0, alg_bytes=1e11),
+             dict(name="exchange", launches=100, total_ms=90.0, alg_bytes=100 * field_gb * 1e9)]
+    res = dict(stats=stats, dt=0.2, exchange_kind="rccl", replicated_spectrum=False, ranks_in_communicator=P, solve_beside=True)
+    ex = bench.exchange_report(res, args, P)
+    assert ex["calls_per_step"] == 50 and abs(ex["ms_per_step_on_comm_stream"] - 45.0) < 1e-12 and abs(ex["compute_ms_per_step"] - 80.0) < 1e-12
+    f = ex["per_transposed_field"]
+    assert abs(f["ms_on_comm_stream"] - 0.9) < 1e-12 and abs(f["compute_ms_beside_it"] - 1.6) < 1e-12
+    assert abs(f["MB_per_link"] - 1e3 * field_gb / P) < 1e-9
+    assert abs(ex["GBps_per_link"] - (50 * field_gb / P) / 0.045) < 1e-6
+    # step 100 ms, compute 80 + exchange 45 = 125: 25 of the 45 ms of exchanges ran beside kernels
+    assert abs(ex["exchange_hidden_fraction"] - 25.0 / 45.0) < 1e-12
+    m = ex["model"]
+    assert abs(m["wire_ms_per_step_at_assumed_link_rate"] - 1e3 * (50 * field_gb / P) / bench.XGMI_GBS_PER_LINK) < 1e-9
+    if "from" in m:   # a committed slab measurement of this configuration exists for the profile round in use
+        assert m["step_ms_if_exchanges_hide"] <= m["step_ms_if_nothing_hides"] and m["compute_ms_per_step_per_rank_on_one_gpu"] > 0
+    one = bench.exchange_report(dict(res, stats=stats[:2]), args, P)   # a sweep that exchanged nothing: no per-field numbers, no division by zero
+    assert one["calls_per_step"] == 0 and "per_transposed_field" not in one

@@ -102,6 +102,12 @@ def test_bench_multi_rank_line_end_to_end_on_one_gpu():
     assert ex["replicated_spectrum"] is True and ex["alternative"]["replicated_spectrum"] is False     # the default at two ranks, and the other mode
     assert ex["alternative"]["calls_per_step"] > ex["calls_per_step"] > 0                                 # the sweep's transposes come on top of the LPT ones
     assert ex["GB_per_step_per_rank"] > 0 and d["config"]["grid"] == 64
+    # per transposed field: time on the communication stream, compute beside it, bytes and rate per link, the model's wire time
+    for e in (ex, ex["alternative"]):
+        f = e["per_transposed_field"]
+        assert f["ms_on_comm_stream"] > 0 and f["compute_ms_beside_it"] > 0 and f["MB_per_link"] > 0
+        assert e["GBps_per_link"] > 0 and 0.0 <= e["exchange_hidden_fraction"] <= 1.0 and e["model"]["wire_ms_per_step_at_assumed_link_rate"] > 0
+    assert ex["alternative"]["matches_single_gpu_golden"] is True and d.get("valid", True) is True
     # what the two ranks left in `products` is, bit for bit on the sampled cells, what one GPU leaves (tests/golden/make_bench_fingerprints.py)
     assert d["result_check"]["matches_single_gpu_golden"] is True, d["result_check"]
     names = {k["name"] for k in d["kernels"]}
@@ -121,5 +127,6 @@ def test_bench_eight_ranks_exchange_every_transform_on_one_gpu():
     assert ex["process_group_size"] == 8 and ex["ranks_in_communicator"] == 8 and ex["distinct_devices"] == 1 and d["n_gpus"] == 1
     assert ex["replicated_spectrum"] is False and "alternative" not in ex
     assert ex["calls_per_step"] >= 3 * 3 + 12          # three fields per radius in the sweep, twelve in the LPT part
+    assert ex["per_transposed_field"]["MB_per_link"] > 0 and ex["GBps_per_link"] > 0 and "model" in ex
     assert d["value"] > 0 and np.isfinite(d["config"]["sigma_R0"]) and abs(d["config"]["sigma_R0"] - 2.5) < 1e-9
     assert d["result_check"]["matches_single_gpu_golden"] is True, d["result_check"]       # eight slabs, every transform exchanged: one GPU's bits

@@ -1131,11 +1131,13 @@ def test_edge_case_fields_vs_oracle(api, case, monkeypatch):
             assert not p["Vel"].any() and np.all(p["Rmax"] == po["Rmax"]) and np.array_equal(p["Fmax"], po["Fmax"])
 
 
-@pytest.mark.parametrize("n,general,path", [(24, "0", 1), (40, "0", 1), (48, "0", 1), (24, "1", 2), (40, "1", 2), (20, "0", 2), (36, "0", 2)])
+@pytest.mark.parametrize("n,general,path", [(24, "0", 1), (40, "0", 1), (48, "0", 1), (24, "1", 2), (40, "1", 2), (20, "0", 2), (36, "0", 2),
+                                            (14, "0", 2), (22, "0", 2), (26, "0", 2), (28, "0", 2), (44, "0", 2)])
 def test_general_grid_sizes_vs_oracle(api, n, general, path, monkeypatch):
     """grid sizes that are not a power of two (the reference takes any GridSize; 200^3 in INSTALLATION:101) against the oracle
     (plain O(n^2) transforms at these sizes), full path + taps: the hand-written passes with run-time stage plans where they
-    apply (n = 8 m with m = 2^a 3^b 5^c: path 1), the library-transform path for the rest and under PF_GENERAL=1 (path 2)"""
+    apply (n = 8 m with m = 2^a 3^b 5^c: path 1); for the rest -- multiples of 2 and 4 only, prime factors 7, 11, 13 -- and under
+    PF_GENERAL=1 the chirp-z transforms of csrc/pf_gfft.hip on the power-of-two stages (path 2).  No library transform anywhere."""
     import np_restatement as npr
     monkeypatch.setenv("PF_GENERAL", general)
     dk = synth.make_density(n, seed=n)
@@ -1178,7 +1180,7 @@ def test_general_grid_sizes_vs_oracle(api, n, general, path, monkeypatch):
 
 
 def test_general_path_equals_fused_path_on_a_power_of_two(api, monkeypatch):
-    """PF_GENERAL=1 forces the library-transform path on a size the hand-written passes also cover: same products"""
+    """PF_GENERAL=1 forces the chirp-z transform path (one 3-D transform per component) on a size the shared passes also cover: same products"""
     n = 64
     dk = synth.make_density(n, seed=6)
     x, y = synth.invgrow_table("lcdm")
@@ -1202,8 +1204,8 @@ def test_general_path_equals_fused_path_on_a_power_of_two(api, monkeypatch):
 @pytest.mark.parametrize("general", ["0", "1"])
 def test_reference_example_size_200(api, general, monkeypatch):
     """BASELINE config 1 (200^3, INSTALLATION:101-102): size-independent properties and the device IC generator at that size,
-    through the hand-written passes (200 = 8.5.5: run-time stage plan) and through the library-transform path; the two
-    against each other in test_grid_200_mixed_passes_vs_library_transforms_and_oracle"""
+    through the shared passes (200 = 8.5.5: run-time stage plan) and through the chirp-z transform path; the two
+    against each other in test_grid_200_mixed_passes_vs_chirp_z_transforms_and_oracle"""
     n = 200
     monkeypatch.setenv("PF_GENERAL", general)
     x, y = synth.invgrow_table("lcdm")
@@ -1224,8 +1226,8 @@ def test_reference_example_size_200(api, general, monkeypatch):
         assert (p["Fmax"] >= 1.0).mean() > 0.2 and np.isfinite(p["Vel"]).all() and p["Vel_2LPT"].any()
 
 
-def test_grid_200_mixed_passes_vs_library_transforms_and_oracle(api, monkeypatch):
-    """200^3 (the reference's example size): the shared-pass path on run-time stage plans against the library-transform path
+def test_grid_200_mixed_passes_vs_chirp_z_transforms_and_oracle(api, monkeypatch):
+    """200^3 (the reference's example size): the shared-pass path on run-time stage plans against the chirp-z transform path
     (products of a three-radius sweep with displacements), and its Hessian at one radius against the oracle"""
     n = 200
     x, y = synth.invgrow_table("lcdm")
