@@ -339,6 +339,9 @@ int pf_debug_lines(int field_bytes, int n, int pass, int mul, int band, int nout
    (csrc/pf_fft16.h) on `count` pairs: which = 0 / 1 a +- i b, 2 / 3 +- i a, 4 / 5 a * b, a * conj(b), 6 / 7 the same with b[0] in scalar
    registers, 8 / 9 a * (c +- i s) for a constant, 10 a - i b */
 int pf_debug_pk(int which, const float *a, const float *b, float *out, int count);
+/* test tap without a context: the chirp-z 3-D transforms of the general path (csrc/pf_gfft.hip: any even n in 4..2048, no library) on
+   host arrays in the natural layouts; dir > 0: spectrum [n][n][n/2+1] complex -> real [n][n][n] (unnormalised), dir < 0: real -> spectrum */
+int pf_debug_gfft(int n, int dir, const double *in, double *out);
 /* how many sweeps of this context were repeated with six components per cell because the invariant z-pass met a tensor
    with q == 0 that is not exactly isotropic (the reference's "already diagonal" branch, src/collapse_times.c:722-727) */
 int pf_debug_invariant_reruns(pf_ctx *ctx);
@@ -352,7 +355,8 @@ int pf_solve_ran_beside_zpass(pf_ctx *ctx);
 int pf_transform_path(pf_ctx *ctx);
 /* 1: in the default (fast) arithmetic the inverse growing mode of radius `ismooth` (-1: the shared spline) comes from the
    polynomial table built from its knots by pf_set_invgrow (csrc/pf_gtab.h; *max_rel_err: its largest relative error against
-   the composite 10^(-S(log10 D)) in long double); 0: the series forms are used (table refused, PF_GTAB=0, PF_EXACT_LIBM=1) */
+   the composite 10^(-S(log10 D)) in long double; NaN when the build was refused before it got to check one: meaningful with
+   status 1, or with status 0 of a table refused for its error); 0: the series forms are used (table refused, PF_GTAB=0, PF_EXACT_LIBM=1) */
 int pf_invgrow_table_status(pf_ctx *ctx, int ismooth, double *max_rel_err);
 /* per-cell solver on a list of Hessians d[6*count] -> F[count] (tests of
    inverse_collapse_time, src/collapse_times.c:679-776), ismooth selects the spline */

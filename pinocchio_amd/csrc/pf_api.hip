@@ -1077,8 +1077,9 @@ extern "C" int pf_set_invgrow(pf_ctx *c, int ismooth, const double *x, const dou
   {  // the polynomial table of the fast flavour (refused for knots it cannot serve: the solve then takes the series forms)
     std::vector<double> g(PF_GT_DOUBLES);
     std::vector<unsigned short> lut(PF_GT_MAX_BINS);
+    g[5] = NAN;  // (a build that is refused before its accuracy check -- too many or too dense knots -- leaves no error figure: NaN, not 0)
     const bool ok = pf_gtab_build(&h[0], &h[PF_KNOT_CAP], &h[2 * PF_KNOT_CAP], &h[3 * PF_KNOT_CAP], &h[4 * PF_KNOT_CAP], n, g.data(), lut.data()) == 0;
-    c->gt_ok[slot] = ok; c->gt_err[slot] = g[5];
+    c->gt_ok[slot] = ok; c->gt_err[slot] = ok || g[5] > 0.0 ? g[5] : NAN;
     if (ok) {
       HIPCHK(c, hipMemcpy(c->gt + (size_t)slot * PF_GT_DOUBLES, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice));
       HIPCHK(c, hipMemcpy(c->gt_lut + (size_t)slot * PF_GT_MAX_BINS, lut.data(), lut.size() * sizeof(unsigned short), hipMemcpyHostToDevice));

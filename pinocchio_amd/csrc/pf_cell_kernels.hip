@@ -13,7 +13,7 @@
 // the solve on the invariants (k_collapse_inv) has its own workgroup size and wave budget: its LDS (the 38 KB polynomial table) lets
 // four workgroups share a CU, its registers decide how many waves those may hold (A/B knobs: -DPF_SOLVE_INV_BLOCK=320 -DPF_SOLVE_INV_WAVES=5)
 #ifndef PF_SOLVE_INV_BLOCK
-#define PF_SOLVE_INV_BLOCK 256
+#define PF_SOLVE_INV_BLOCK 512  // (round 5: 15.9 -> 15.4 ms per launch against 256; 1024: 17.0; 640 threads at five waves per SIMD: 21.0)
 #endif
 #ifndef PF_SOLVE_INV_WAVES
 #define PF_SOLVE_INV_WAVES 4
@@ -36,6 +36,24 @@ __device__ __forceinline__ void pf_block_sum2(double &a, double &b, double *sh /
   if (threadIdx.x == 0) {
     double sa = 0, sb = 0;
     for (int i = 0; i < nw; i++) { sa += sh[2 * i]; sb += sh[2 * i + 1]; }
+    a = sa; b = sb;
+  }
+}
+// The same by GROUPS of PF_CELL_BLOCK threads: a workgroup of several such groups leaves one pair of partial sums per group, in the
+// first thread of the group -- the very sums, in the very order, that workgroups of PF_CELL_BLOCK threads on a grid with as many
+// threads leave (the grid-stride walk hands a thread the same cells either way): TrueVariance does not depend on the workgroup size
+__device__ __forceinline__ void pf_group_sum2(double &a, double &b, double *sh /* 2*nwaves */) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_down(a, off, 64);
+    b += __shfl_down(b, off, 64);
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { sh[2 * w] = a; sh[2 * w + 1] = b; }
+  __syncthreads();
+  if (threadIdx.x % 256 == 0) {
+    double sa = 0, sb = 0;
+    for (int i = w; i < w + 4; i++) { sa += sh[2 * i]; sb += sh[2 * i + 1]; }
     a = sa; b = sb;
   }
 }
@@ -218,10 +236,12 @@ __device__ __forceinline__ void pf_collapse_body(const PfCollapseParams &p) {
       p.rmax[i] = -1;
     }
   }
-  pf_block_sum2(sum, sum2, red);
-  if (threadIdx.x == 0) {
-    p.partials[2 * blockIdx.x] = sum;
-    p.partials[2 * blockIdx.x + 1] = sum2;
+  static_assert(PF_CELL_BLOCK == 256, "pf_group_sum2 sums groups of four waves");
+  pf_group_sum2(sum, sum2, red);
+  if (threadIdx.x % PF_CELL_BLOCK == 0) {
+    const int slot = blockIdx.x * (blockDim.x / PF_CELL_BLOCK) + threadIdx.x / PF_CELL_BLOCK;
+    p.partials[2 * slot] = sum;
+    p.partials[2 * slot + 1] = sum2;
   }
   if (SRC) {  // the same grid and walk as k_lpt_sources: the same partial sums
     double dummy = 0.0;
@@ -252,6 +272,145 @@ __global__ void __launch_bounds__(PF_CELL_BLOCK) k_collapse_sng(const PfCollapse
 // the solve on the three invariants per cell that k_c2r_invariants leaves in h[0..2] (fp64 fields)
 template <bool FAST, typename PR = float>
 __global__ void __launch_bounds__(PF_SOLVE_INV_BLOCK) __attribute__((amdgpu_waves_per_eu(PF_SOLVE_INV_WAVES))) k_collapse_inv(const PfCollapseParams p) { pf_collapse_body<double, FAST, false, true, false, false, 0, PR>(p); }
+
+// ---- the solve on the invariants, default arithmetic, with the one-root lanes run compacted (round 5) ----
+// The reduced cubic of ell_classic has one real root for about one cell in eight (pf_ell_setup: kind 1) and three for the rest; the
+// two branches share nothing, and practically every wave holds cells of both kinds, so every wave used to run both (~60 of its ~400
+// vector instructions per cell for one lane in eight).  Here a lane whose cell needs the one-root branch puts the cell aside -- its
+// eigenvalues and index into a queue of its wave in LDS -- and goes on as if it had no cell; when 64 cells have gathered the wave
+// runs the one-root branch, the spherical correction, the inverse growing mode and the comparison for all of them at once, every
+// lane busy.  The same per-cell functions on the same inputs in another lane at another time: bit for bit the results of
+// pf_collapse_body.  One workgroup of 1024 threads per CU: ONE copy of the polynomial tables (40.8 KB) beside the sixteen queues
+// (16 x 3.5 KB), sixteen waves per CU as before.
+#ifndef PF_SOLVE_QUEUE
+#define PF_SOLVE_QUEUE 0  // 1 (A/B build): this kernel for the default arithmetic.  MEASURED SLOWER: 18.6 against 15.7 ms per launch at 1024^3 (profiles/r05_notes.md), not used
+#endif
+#ifndef PF_SQ_BLOCK
+#define PF_SQ_BLOCK 512   // two workgroups per CU, each with its tables (40.8 KB) and eight queues (28 KB): eight waves start and end together instead of sixteen (A/B: 1024)
+#endif
+#define PF_SQ_SLOTS 128
+template <typename PR>
+__global__ void __launch_bounds__(PF_SQ_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) k_collapse_invq(const PfCollapseParams p) {
+  constexpr int SK = (PF_GT_MAX_INT + 1) * PF_GT_REC;
+  __shared__ double sk[SK];
+  __shared__ double red[2 * (PF_SQ_BLOCK / 64)];
+  __shared__ unsigned short slut[PF_GT_MAX_BINS];
+  __shared__ double sc3[PF_C3_DOUBLES];
+  __shared__ double ql[PF_SQ_BLOCK / 64][3][PF_SQ_SLOTS];     // eigenvalues of the cells put aside, per wave
+  __shared__ unsigned int qi[PF_SQ_BLOCK / 64][PF_SQ_SLOTS];  // ... and their index
+  for (int i = threadIdx.x; i < PF_C3_DOUBLES; i += blockDim.x) sc3[i] = pf_c3_tab[i];
+  const bool gt = p.spline.gt != nullptr;  // uniform
+  pf_spline_view sv;
+  if (gt) {
+    const double *g = p.spline.gt;
+    const int nint = (int)g[0], nbins = (int)g[1];
+    for (int i = threadIdx.x; i < (nint + 1) * PF_GT_REC; i += blockDim.x) sk[i] = g[PF_GT_HEADER + i];
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x) slut[i] = p.spline.gt_lut[i];
+    sv.gt.bin0 = (unsigned)g[2]; sv.gt.lo_all = g[3]; sv.gt.hi_all = g[4];
+  }
+  __syncthreads();
+  sv.gt.rec = sk; sv.gt.lut = slut;
+  if (!gt) { sv.gt.lo_all = HUGE_VAL; sv.gt.hi_all = 0.0; sv.gt.bin0 = 0; }  // no table: an empty range (the series forms on the knot arrays)
+  asm volatile("" : "+v"(sv.gt.lo_all), "+v"(sv.gt.hi_all));
+  sv.x = p.spline.x; sv.y = sv.x + PF_KNOT_CAP; sv.c = sv.x + 2 * PF_KNOT_CAP; sv.b = sv.x + 3 * PF_KNOT_CAP; sv.d = sv.x + 4 * PF_KNOT_CAP;
+  sv.n = p.spline.n;
+  const double *c3tab = sc3;
+  __builtin_assume(c3tab != nullptr);
+  sv.c3tab = c3tab;
+
+  const double *__restrict__ h0 = (const double *)p.h[0], *__restrict__ h1 = (const double *)p.h[1], *__restrict__ h2 = (const double *)p.h[2];
+  PR *__restrict__ fmax = (PR *)p.fmax;
+  const long long ncell = p.nrows * p.n;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double *q1 = ql[wv][0], *q2 = ql[wv][1], *q3 = ql[wv][2];
+  unsigned int *qx = qi[wv];
+  int qcount = 0;  // cells waiting in this wave's queue (uniform)
+  double sum = 0.0, sum2 = 0.0;
+  // everything behind the root of the cubic, for one cell per lane: src/collapse_times.c:395-427 and the update of :749-773
+  auto finish = [&](bool live, double ell, double l1, double l2, double l3, long long i, PR fold) {
+    if (!live) return;
+    const double bc = pf_ell_finish<true>(ell, l1, l2, l3);
+    const double Fnew = bc > 0.0 ? 1. + pf_inverse_growing_mode<true>(sv, bc) : 0.0;
+    if ((double)fold < Fnew) {
+      fmax[i] = (PR)Fnew;
+      p.rmax[i] = p.ismooth;
+    } else if (!p.ismooth) {
+      fmax[i] = (PR)-10.0f;
+      p.rmax[i] = -1;
+    }
+  };
+  // the cells put aside, 64 at a time (or what is left at the end): lane L takes entry first + L
+  auto drain = [&](int first, int count) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const bool live = lane < count;
+    const int e = first + (live ? lane : 0);
+    const double l1 = q1[e], l2 = q2[e], l3 = q3[e];
+    const long long i = (long long)qx[e];
+    const PR fold = (live && p.ismooth) ? fmax[i] : (PR)-10.0f;
+    double ell = 0.0;
+    pf_cubic c;
+    const int kind = pf_ell_setup<true>(l1, l2, l3, ell, c);   // (the same setup again: kind 1, the same cubic)
+    if (kind == 1) ell = pf_ell_one_root<true>(c);
+    finish(live, ell, l1, l2, l3, i, fold);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  // grid-stride walk, a wave at a time (every lane of a wave makes the same number of trips: the queue is the wave's)
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const int srow = (int)(stride / p.n), scol = (int)(stride - (long long)srow * p.n);
+  const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  int row = (int)(i0 / p.n), col = (int)(i0 - (long long)row * p.n);
+  for (long long i = i0; i - lane < ncell; i += stride, row += srow, col += scol) {
+    if (col >= p.n) { col -= p.n; row++; }
+    const bool active = i < ncell;
+    const long long a = (long long)row * p.pitch + col;
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0;
+    PR fold = (PR)-10.0f;
+    if (active) {
+#if PF_NT
+      d0 = __builtin_nontemporal_load(&h0[a]); d1 = __builtin_nontemporal_load(&h1[a]); d2 = __builtin_nontemporal_load(&h2[a]);
+#else
+      d0 = h0[a]; d1 = h1[a]; d2 = h2[a];
+#endif
+      if (p.ismooth) fold = fmax[i];
+      sum += d0;
+      sum2 += d0 * d0;
+    }
+    double lam[3] = {0.0, 0.0, 0.0};
+    const double third = d0 * (1.0 / 3.0);  // an exactly isotropic tensor: its diagonal is not stored
+    const double diag[3] = {third, third, third};
+    const bool have_lam = active && pf_eigen_from_invariants<true>(d0, d1, d2, diag, lam, c3tab);
+    double ell = 0.0;
+    pf_cubic c;
+    int kind = 0;
+    if (have_lam) kind = pf_ell_setup<true>(lam[0], lam[1], lam[2], ell, c);
+    const bool aside = have_lam && kind == 1;
+    const unsigned long long m = __ballot(aside);
+    if (m) {  // (uniform)
+      if (aside) {
+        const int pos = qcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        q1[pos] = lam[0]; q2[pos] = lam[1]; q3[pos] = lam[2]; qx[pos] = (unsigned int)i;
+      }
+      qcount += __popcll(m);
+    }
+    if (active && !have_lam) {  // the -10 sentinel of inverse_collapse_time: never above a stored Fmax, only the first radius writes
+      if (!p.ismooth) { fmax[i] = (PR)-10.0f; p.rmax[i] = -1; }
+    }
+    if (have_lam && kind == 2) ell = pf_ell_three_roots<true>(c, c3tab);
+    finish(have_lam && !aside, ell, lam[0], lam[1], lam[2], i, fold);
+    if (qcount >= 64) { qcount -= 64; drain(qcount, 64); }
+  }
+  if (qcount > 0) drain(0, qcount);
+  pf_group_sum2(sum, sum2, red);
+  if (threadIdx.x % PF_CELL_BLOCK == 0) {
+    const int slot = blockIdx.x * (blockDim.x / PF_CELL_BLOCK) + threadIdx.x / PF_CELL_BLOCK;
+    p.partials[2 * slot] = sum;
+    p.partials[2 * slot + 1] = sum2;
+  }
+}
 
 // initialize_collapse_times (src/collapse_times.c:956-972): CT_table[i] = ell(ismooth, l1, l2, l3) on the
 // (delta, x, y) grid, i = id + 100 * (ix + 50 * iy)
@@ -669,8 +828,14 @@ template <typename PR> static int pf_launch_collapse_as(int fb, const PfCollapse
   }
   if (p.invariants) {
     if (fb != 8 || p.tabulated) return 2;
-    if (p.fast) hipLaunchKernelGGL((k_collapse_inv<true, PR>), g, dim3(PF_SOLVE_INV_BLOCK), 0, st, p);
-    else hipLaunchKernelGGL((k_collapse_inv<false, PR>), g, dim3(PF_SOLVE_INV_BLOCK), 0, st, p);
+    // (workgroups of several groups of PF_CELL_BLOCK threads: as many threads in the grid, one pair of partial sums per group)
+    static_assert(PF_SOLVE_INV_BLOCK % PF_CELL_BLOCK == 0 && PF_SQ_BLOCK % PF_CELL_BLOCK == 0, "whole groups");
+    const int gi = PF_SOLVE_INV_BLOCK / PF_CELL_BLOCK, gq = PF_SQ_BLOCK / PF_CELL_BLOCK;
+    if (p.fast && PF_SOLVE_QUEUE && p.nrows * p.n < (1ll << 32) && p.nblocks % gq == 0)  // (the queue holds 32-bit cell indices)
+      hipLaunchKernelGGL((k_collapse_invq<PR>), dim3(p.nblocks / gq), dim3(PF_SQ_BLOCK), 0, st, p);
+    else if (p.nblocks % gi) return 2;
+    else if (p.fast) hipLaunchKernelGGL((k_collapse_inv<true, PR>), dim3(p.nblocks / gi), dim3(PF_SOLVE_INV_BLOCK), 0, st, p);
+    else hipLaunchKernelGGL((k_collapse_inv<false, PR>), dim3(p.nblocks / gi), dim3(PF_SOLVE_INV_BLOCK), 0, st, p);
     return PF_CHECK_LAUNCH();
   }
   PF_BY_FIELD_AND_LIBM(k_collapse);

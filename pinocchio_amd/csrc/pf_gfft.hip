@@ -17,6 +17,7 @@
 // path of completeness, at a fraction of the hand-planned sizes' speed (profiles/r05_notes.md).
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "pf_internal.h"
@@ -43,7 +44,10 @@ struct PfBlueParams {
   double scale;        // 1 / M
 };
 
-template <int M>
+// (MODE is a template parameter: with the three load / store forms behind run-time branches on p.mode, ROCm 7.2's compiler merged
+//  their tails and lost the index of the chirp table on the real-input path -- a wild address; one instantiation per mode has no
+//  such branches)
+template <int M, int MODE>
 __global__ void __launch_bounds__(1024) k_blue(const PfBlueParams p) {
   using C = pfc<double>;
   constexpr int NT = M / 8;              // threads per line
@@ -63,9 +67,9 @@ __global__ void __launch_bounds__(1024) k_blue(const PfBlueParams p) {
     const int j = tl + m * NT;
     C x = pf_mk<double>(0.0, 0.0);
     if (valid && j < n) {
-      if (p.mode == 0) {
+      if (MODE == 0) {
         x = reinterpret_cast<const C *>(p.in)[lo * p.os_in + li * p.ls_in + (long long)j * p.es_in];
-      } else if (p.mode == 1) {  // Hermitian extension of the row: X[n - j] = conj X[j]; Im X[0], Im X[n/2] ignored
+      } else if (MODE == 1) {  // Hermitian extension of the row: X[n - j] = conj X[j]; Im X[0], Im X[n/2] ignored
         const C *row = reinterpret_cast<const C *>(p.in) + lo * p.os_in + li * p.ls_in;
         if (j <= h) { x = row[(long long)j * p.es_in]; if (j == 0 || j == h) x.y = 0.0; }
         else x = pf_conj(row[(long long)(n - j) * p.es_in]);
@@ -97,24 +101,27 @@ __global__ void __launch_bounds__(1024) k_blue(const PfBlueParams p) {
       const int k = pf_stage_pos<M, LAST>(tl, m);
       if (k >= n) continue;
       const C y = pf_scale(pf_cmul(v[m], p.b[k]), p.scale);
-      if (p.mode == 0) reinterpret_cast<C *>(p.out)[lo * p.os_out + li * p.ls_out + (long long)k * p.es_out] = y;
-      else if (p.mode == 1) reinterpret_cast<double *>(p.out)[lo * p.os_out + li * p.ls_out + (long long)k * p.es_out] = y.x;
+      if (MODE == 0) reinterpret_cast<C *>(p.out)[lo * p.os_out + li * p.ls_out + (long long)k * p.es_out] = y;
+      else if (MODE == 1) reinterpret_cast<double *>(p.out)[lo * p.os_out + li * p.ls_out + (long long)k * p.es_out] = y.x;
       else if (k <= h) reinterpret_cast<C *>(p.out)[lo * p.os_out + li * p.ls_out + (long long)k * p.es_out] = (k == 0 || k == h) ? pf_mk<double>(y.x, 0.0) : y;
     }
   }
 }
 
-template <int M> static int blue_launch(const PfBlueParams &p, hipStream_t st) {
+template <int M, int MODE> static int blue_launch_m(const PfBlueParams &p, hipStream_t st) {
   constexpr int NT = M / 8, T = 1024 / NT < 1 ? 1 : 1024 / NT;
   const size_t shm = (size_t)M * T * sizeof(pfc<double>);
   static bool raised = false;
   if (shm > 64 * 1024 && !raised) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blue<M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return 3;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blue<M, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return 3;
     raised = true;
   }
   const long long nblk = (p.nlines + T - 1) / T;
-  hipLaunchKernelGGL((k_blue<M>), dim3((unsigned)nblk), dim3(NT * T), shm, st, p);
+  hipLaunchKernelGGL((k_blue<M, MODE>), dim3((unsigned)nblk), dim3(NT * T), shm, st, p);
   return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+template <int M> static int blue_launch(const PfBlueParams &p, hipStream_t st) {
+  return p.mode == 0 ? blue_launch_m<M, 0>(p, st) : p.mode == 1 ? blue_launch_m<M, 1>(p, st) : blue_launch_m<M, 2>(p, st);
 }
 static int blue_dispatch(int M, const PfBlueParams &p, hipStream_t st) {
   switch (M) {
@@ -231,14 +238,17 @@ int pf_gfft_r2c(void *plan, void *real, void *spec) {
   const long long n = pl->n, nzh = n / 2 + 1;
   PfBlueParams p;
   blue_common(pl, p, 1);
+  const char *dbg = getenv("PF_GFFT_DEBUG_PASSES");  // (debugging aid: bit 0 z, bit 1 y, bit 2 x; unset: all)
+  const int passes = dbg ? atoi(dbg) : 7;
   p.in = real; p.out = spec; p.mode = 2;
   p.os_in = 0; p.ls_in = n; p.es_in = 1; p.os_out = 0; p.ls_out = nzh; p.es_out = 1; p.ninner = (int)(n * n); p.nlines = n * n;
-  if (int rc = blue_dispatch(pl->M, p, pl->st)) return rc;
+  if (passes & 1) if (int rc = blue_dispatch(pl->M, p, pl->st)) return rc;
   p.in = spec; p.mode = 0;
   p.os_in = p.os_out = n * nzh; p.ls_in = p.ls_out = 1; p.es_in = p.es_out = nzh; p.ninner = (int)nzh; p.nlines = n * nzh;
-  if (int rc = blue_dispatch(pl->M, p, pl->st)) return rc;
+  if (passes & 2) if (int rc = blue_dispatch(pl->M, p, pl->st)) return rc;
   p.os_in = p.os_out = 0; p.ls_in = p.ls_out = 1; p.es_in = p.es_out = n * nzh; p.ninner = (int)(n * nzh); p.nlines = n * nzh;
-  return blue_dispatch(pl->M, p, pl->st);
+  if (passes & 4) return blue_dispatch(pl->M, p, pl->st);
+  return 0;
 }
 void pf_gfft_destroy(void *plan) {
   if (!plan) return;
@@ -246,4 +256,26 @@ void pf_gfft_destroy(void *plan) {
   for (int s = 0; s < 2; s++) { (void)hipFree(pl->b[s]); (void)hipFree(pl->H[s]); }
   (void)hipFree(pl->tw);
   delete pl;
+}
+
+// test tap without a context: the 3-D transforms above on host arrays (natural layouts), n even: dir > 0: spectrum [n][n][n/2+1]
+// complex -> real [n][n][n]; dir < 0: real -> spectrum.  tests/test_gpu_lines.py holds them against numpy's pocketfft.
+extern "C" int pf_debug_gfft(int n, int dir, const double *in, double *out) {
+  void *a = nullptr, *b = nullptr;
+  if (pf_gfft_create(n, nullptr, &a, &b)) return 1;
+  const size_t nspec = (size_t)n * n * (n / 2 + 1) * 2, nreal = (size_t)n * n * n;
+  double *dspec = nullptr, *dreal = nullptr;
+  int rc = 1;
+  if (hipMalloc((void **)&dspec, nspec * sizeof(double)) == hipSuccess && hipMalloc((void **)&dreal, nreal * sizeof(double)) == hipSuccess) {
+    if (dir > 0) {
+      if (hipMemcpy(dspec, in, nspec * sizeof(double), hipMemcpyHostToDevice) == hipSuccess && pf_gfft_c2r(a, dspec, dreal) == 0 &&
+          hipDeviceSynchronize() == hipSuccess && hipMemcpy(out, dreal, nreal * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess) rc = 0;
+    } else {
+      if (hipMemcpy(dreal, in, nreal * sizeof(double), hipMemcpyHostToDevice) == hipSuccess && pf_gfft_r2c(a, dreal, dspec) == 0 &&
+          hipDeviceSynchronize() == hipSuccess && hipMemcpy(out, dspec, nspec * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess) rc = 0;
+    }
+  }
+  (void)hipFree(dspec); (void)hipFree(dreal);
+  pf_gfft_destroy(a);
+  return rc;
 }

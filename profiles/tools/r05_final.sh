@@ -1,0 +1,16 @@
+#!/bin/bash
+# round 5, the committed artefacts in one call (run from the repo root ON THE GPU BOX, after the last change to pinocchio_amd/csrc):
+#   goldens of the bench configurations on these sources; collect.sh for the metric's configuration, for fp32 fields on one GPU and for
+#   BASELINE config 5's slab; the slab matrix.  Everything lands in gpurun_out/ (merged back by gpurun), to be copied into profiles/.
+mkdir -p gpurun_out/r05
+python3 tests/golden/make_bench_fingerprints.py > gpurun_out/r05/goldens.log 2>&1; tail -3 gpurun_out/r05/goldens.log
+cp tests/golden/bench_fingerprints.json gpurun_out/r05/bench_fingerprints.json
+bash profiles/tools/collect.sh r05 > gpurun_out/r05/collect_r05.log 2>&1; tail -2 gpurun_out/r05/collect_r05.log
+BENCH_ARGS="--field-bytes 4" PF_SUMMARY_FB=4 bash profiles/tools/collect.sh r05_fp32 > gpurun_out/r05/collect_r05_fp32.log 2>&1; tail -2 gpurun_out/r05/collect_r05_fp32.log
+BENCH_ARGS="--slab-of 8 --n 2048 --field-bytes 4" PF_SUMMARY_N=2048 PF_SUMMARY_FB=4 PF_SUMMARY_SLAB_OF=8 PROFILE_ROUND=r05 bash profiles/tools/collect.sh r05_2048 > gpurun_out/r05/collect_r05_2048.log 2>&1; tail -2 gpurun_out/r05/collect_r05_2048.log
+bash profiles/tools/slab_matrix.sh r05 > gpurun_out/r05/slab_matrix.log 2>&1; tail -14 gpurun_out/r05/slab_matrix.log
+PF_SOLVE_BESIDE_Z=0 timeout 600 python3 bench.py --slab-of 8 --n 2048 --field-bytes 4 --steps 3 --warmup 1 > gpurun_out/r05_slab_2048_p8_fp32_inline.json 2> gpurun_out/r05/slab2048_inline.err
+timeout 900 python3 bench.py --n 768 --steps 3 --warmup 1 --cpu-n 0 --exact-steps 0 > gpurun_out/r05_bench_768.json 2> gpurun_out/r05/bench_768.err
+timeout 300 python3 bench.py --n 200 --steps 5 --warmup 1 --cpu-n 0 --exact-steps 0 > gpurun_out/r05_bench_200.json 2> gpurun_out/r05/bench_200.err
+PF_GENERAL=1 timeout 300 python3 bench.py --n 200 --steps 3 --warmup 1 --cpu-n 0 --exact-steps 0 > gpurun_out/r05_bench_200_chirpz.json 2> gpurun_out/r05/bench_200_chirpz.err
+ls gpurun_out | head -80

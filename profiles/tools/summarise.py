@@ -22,7 +22,8 @@ from pinocchio_amd import _lib  # noqa: E402
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 GO = os.path.join(ROOT, "gpurun_out")
 N, FB = int(os.environ.get("PF_SUMMARY_N", "1024")), int(os.environ.get("PF_SUMMARY_FB", "8"))
-CELLS = float(N) ** 3
+SLAB_OF = int(os.environ.get("PF_SUMMARY_SLAB_OF", "1"))   # bench.py --slab-of P: one rank's slab of the n^3 box
+CELLS = float(N) ** 3 / SLAB_OF
 
 
 def short(name):
@@ -89,7 +90,7 @@ def main():
                           "bench command (12 radii + 3LPT, pruning on: the same launch mix as the timed region); counter unit KB -> bytes; FETCH_SIZE "
                           "doubled (MI355X_MICROARCH.md: on gfx950 it reports half the bytes of 16-byte-per-lane streaming reads); summed over the "
                           "dispatches of a kernel symbol and divided by their number",
-               "kernel_source_sha": sha, "config": {"grid": N, "field_bytes": FB}, "kernels": {}}
+               "kernel_source_sha": sha, "config": dict({"grid": N, "field_bytes": FB}, **({"slab_of": SLAB_OF} if SLAB_OF > 1 else {})), "kernels": {}}
     for k in sorted(set(fe) & set(wr)):
         (f, nf), (w, nw) = fe[k], wr[k]
         if nf != nw or f.get("FETCH_SIZE", 0) + w.get("WRITE_SIZE", 0) < 1e6:
@@ -104,7 +105,7 @@ def main():
     valu = {"_method": "rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES | SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES | GRBM_GUI_ACTIVE, separate passes with --kernel-trace only, "
                        "one bench step; per launch.  insts_per_cell = SQ_INSTS_VALU * 64 lanes / cells; issue_ms = wave-instructions * 4 cycles / (1024 SIMDs * clock); "
                        "engine clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel time of the same run",
-            "kernel_source_sha": sha, "config": {"grid": N, "field_bytes": FB}, "kernels": {}}
+            "kernel_source_sha": sha, "config": dict({"grid": N, "field_bytes": FB}, **({"slab_of": SLAB_OF} if SLAB_OF > 1 else {})), "kernels": {}}
     for k, (v, nv) in va.items():
         if "collapse" not in k and "invariants" not in k and "strided" not in k:
             continue

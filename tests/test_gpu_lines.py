@@ -211,3 +211,21 @@ def test_packed_complex_algebra_of_the_sixteen_point_pass(L):
         rc = L.pf_debug_pk(which, a.view(np.float32).ctypes.data_as(fp), b.view(np.float32).ctypes.data_as(fp), out.view(np.float32).ctypes.data_as(fp), cnt)
         assert rc == 0
         assert np.max(np.abs(out - ref.astype(np.complex64))) <= 4e-7 * np.max(np.abs(ref)), which
+
+
+@pytest.mark.parametrize("n", [6, 10, 14, 20, 22, 26, 36, 44, 50, 100])
+def test_chirp_z_transforms_of_the_general_path(L, n):
+    """csrc/pf_gfft.hip: the 3-D c2r / r2c of any even grid size -- prime factors 3, 5, 7, 11, 13 here -- as Bluestein convolutions on
+    the power-of-two stages, against numpy's pocketfft (the reference plans any GridSize through FFTW / PFFT, src/fmax-pfft.c:139-188)"""
+    rng = np.random.default_rng(n)
+    real = rng.standard_normal((n, n, n))
+    spec = np.zeros((n, n, n // 2 + 1), dtype=np.complex128)
+    assert L.pf_debug_gfft(n, -1, _dp(real), _dp(spec.view(np.float64))) == 0
+    want = np.fft.rfftn(real)
+    assert np.max(np.abs(spec - want)) <= 2e-14 * np.max(np.abs(want))
+    s = rng.standard_normal(spec.shape) + 1j * rng.standard_normal(spec.shape)   # junk imaginary parts in the DC / Nyquist planes: ignored along z, like irfftn
+    s = np.fft.rfftn(np.fft.irfftn(s, s=(n, n, n))) + 0j                           # ... but Hermitian in x and y, as every spectrum of a real field
+    back = np.zeros((n, n, n))
+    assert L.pf_debug_gfft(n, +1, _dp(np.ascontiguousarray(s).view(np.float64)), _dp(back)) == 0
+    want = np.fft.irfftn(s, s=(n, n, n)) * n ** 3
+    assert np.max(np.abs(back - want)) <= 2e-14 * np.max(np.abs(want))
