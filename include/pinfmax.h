@@ -47,6 +47,11 @@ typedef struct {
 } pf_config;
 
 #define PF_FLAG_TIMING 1  /* record per-kernel HIP-event timings (pf_kernel_stats) */
+/* Environment, read once per context in pf_create (DESIGN.md section 6 has the whole table).  One of them changes what is computed:
+   PF_EXACT_LIBM=1 makes the collapse solve call the reference's own libm functions (cos x3, acos, pow, pow, log10, exp, IEEE / and sqrt)
+   instead of the series / table / hardware-seeded forms of the default arithmetic.  It is a DIAGNOSTIC mode -- the flavour in which
+   the oracle's solver fed with the device's Hessian reproduces the device's Fmax bit for bit (tests) -- not a supported speed: 1.6x the
+   step time, kernels with scratch, never tuned or profiled. */
 /* a -DDOUBLE_PRECISION_PRODUCTS build (src/Makefile:68, src/pinocchio.h:219-225: PRODFLOAT double): Fmax and the Vel*
    fields of product_data are doubles.  Fmax is then kept and compared in fp64 (no rounding of the running maximum to fp32
    between radii, cf. src/collapse_times.c:587-590) and the displacements leave the z-pass as the doubles it computes.
@@ -342,6 +347,11 @@ int pf_debug_pk(int which, const float *a, const float *b, float *out, int count
 /* test tap without a context: the chirp-z 3-D transforms of the general path (csrc/pf_gfft.hip: any even n in 4..2048, no library) on
    host arrays in the natural layouts; dir > 0: spectrum [n][n][n/2+1] complex -> real [n][n][n] (unnormalised), dir < 0: real -> spectrum */
 int pf_debug_gfft(int n, int dir, const double *in, double *out);
+/* test tap without a context: ONE strided (inverse) launch with several jobs as the passes of the sweep issue them: job j transforms
+   input field in_of[j] (of `nin` complex fields [nouter][n][ncols], fp64 on the host) with the factor mul[j] (0 one, 1 k, 2 k^2, 3 i k)
+   along the transformed axis into out[j] ([njobs][nouter][n][ncols]); jobs on the same input must be adjacent.  n a power of two. */
+int pf_debug_strided_jobs(int field_bytes, int n, int njobs, int nin, const int *in_of, const int *mul, int nouter, int ncols,
+                          const double *in, double *out);
 /* how many sweeps of this context were repeated with six components per cell because the invariant z-pass met a tensor
    with q == 0 that is not exactly isotropic (the reference's "already diagonal" branch, src/collapse_times.c:722-727) */
 int pf_debug_invariant_reruns(pf_ctx *ctx);

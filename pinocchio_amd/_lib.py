@@ -100,6 +100,7 @@ PROTOTYPES = {
     "pf_debug_lines": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, _dp, _dp]),
     "pf_debug_pk": (C.c_int, [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]),
     "pf_debug_gfft": (C.c_int, [C.c_int, C.c_int, _dp, _dp]),
+    "pf_debug_strided_jobs": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, _dp, _dp]),
     "pf_debug_invariant_reruns": (C.c_int, [_vp]),
     "pf_solve_ran_beside_zpass": (C.c_int, [_vp]),
     "pf_transform_path": (C.c_int, [_vp]),

@@ -1996,6 +1996,62 @@ extern "C" int pf_debug_lines(int field_bytes, int n, int pass, int mul, int ban
   return rc;
 }
 
+// Test tap without a context: ONE strided launch with several jobs, as the passes of the sweep issue them -- job j transforms input
+// in_of[j] (one of `nin` complex fields [nouter][n][ncols]) with the factor mul[j] into its own output field; jobs that share an input
+// are adjacent (the launch's contract).  What pf_debug_lines cannot reach: tiles that serve several jobs (kept in registers, or read
+// again by every job / by one workgroup per job).  out: [njobs][nouter][n][ncols].
+extern "C" int pf_debug_strided_jobs(int field_bytes, int n, int njobs, int nin, const int *in_of, const int *mul, int nouter, int ncols,
+                                     const double *in, double *out) {
+  if (!in || !out || !in_of || !mul || njobs < 1 || njobs > PF_MAX_JOBS || nin < 1 || nin > njobs || nouter < 1 || ncols < 1 || (field_bytes != 8 && field_bytes != 4) ||
+      n < 16 || n > 2048 || (n & (n - 1)))
+    return pf_fail(0, "pf_debug_strided_jobs: bad argument");
+  const int fb = field_bytes, pc = (ncols + 15) & ~15;
+  pf_ctx *nc = nullptr;
+  const size_t nrows = (size_t)nouter * n, field = nrows * (size_t)pc * 2;  // scalars of one device field
+  void *d_in = nullptr, *d_out = nullptr, *d_tw = nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return pf_fail(0, "pf_debug_strided_jobs: no HIP device");
+  std::vector<char> tw;
+  host_twiddles(n, fb, tw);
+  auto body = [&]() -> int {
+    HIPCHK(nc, hipMalloc(&d_in, (size_t)nin * field * fb));
+    HIPCHK(nc, hipMalloc(&d_out, (size_t)njobs * field * fb));
+    HIPCHK(nc, hipMalloc(&d_tw, tw.size()));
+    HIPCHK(nc, hipMemcpy(d_tw, tw.data(), tw.size(), hipMemcpyHostToDevice));
+    HIPCHK(nc, hipMemset(d_in, 0, (size_t)nin * field * fb));
+    HIPCHK(nc, hipMemset(d_out, 0, (size_t)njobs * field * fb));
+    const size_t hrow = (size_t)ncols * 2 * fb, drow = (size_t)pc * 2 * fb, hfield = nrows * (size_t)ncols * 2;
+    std::vector<float> hf;
+    for (int i = 0; i < nin; i++) {
+      const void *src = in + (size_t)i * hfield;
+      if (fb == 4) { hf.resize(hfield); for (size_t k = 0; k < hfield; k++) hf[k] = (float)in[(size_t)i * hfield + k]; src = hf.data(); }
+      HIPCHK(nc, hipMemcpy2D((char *)d_in + (size_t)i * field * fb, drow, src, hrow, hrow, nrows, hipMemcpyHostToDevice));
+    }
+    PfStridedParams p; memset(&p, 0, sizeof(p));
+    p.njobs = njobs;
+    for (int j = 0; j < njobs; j++) {
+      if (in_of[j] < 0 || in_of[j] >= nin) return pf_fail(0, "pf_debug_strided_jobs: in_of");
+      p.job[j].in = (char *)d_in + (size_t)in_of[j] * field * fb; p.job[j].out = (char *)d_out + (size_t)j * field * fb; p.job[j].mul = mul[j];
+    }
+    p.ain.os = (long long)n * pc; p.ain.el_shift = ilog2i(n); p.ain.el_len = n; p.ain.ehs = 0; p.ain.els = pc; p.aout = p.ain;
+    p.ncols = ncols; p.nouter = nouter; p.tw = d_tw; p.band_e = p.band_outer = n; p.dev = dev; p.growth = 1.0;
+    PFCHK0(pf_launch_strided(fb, n, +1, p, nullptr));
+    HIPCHK(nc, hipDeviceSynchronize());
+    for (int j = 0; j < njobs; j++) {
+      if (fb == 8) HIPCHK(nc, hipMemcpy2D(out + (size_t)j * hfield, hrow, (char *)d_out + (size_t)j * field * fb, drow, hrow, nrows, hipMemcpyDeviceToHost));
+      else {
+        hf.resize(hfield);
+        HIPCHK(nc, hipMemcpy2D(hf.data(), hrow, (char *)d_out + (size_t)j * field * fb, drow, hrow, nrows, hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < hfield; k++) out[(size_t)j * hfield + k] = (double)hf[k];
+      }
+    }
+    return 0;
+  };
+  const int rc = body();
+  hipFree(d_in); hipFree(d_out); hipFree(d_tw);
+  return rc;
+}
+
 // used by pf_rccl.cpp
 extern "C" int pf_ctx_set_rccl(pf_ctx *c, void *link) {
   if (!c) return 1;

@@ -828,14 +828,15 @@ template <typename PR> static int pf_launch_collapse_as(int fb, const PfCollapse
   }
   if (p.invariants) {
     if (fb != 8 || p.tabulated) return 2;
-    // (workgroups of several groups of PF_CELL_BLOCK threads: as many threads in the grid, one pair of partial sums per group)
+    // (workgroups of several groups of PF_CELL_BLOCK threads: as many threads in the grid, one pair of partial sums per group; a
+    //  block count that does not divide -- tiny grids -- runs workgroups of one group)
     static_assert(PF_SOLVE_INV_BLOCK % PF_CELL_BLOCK == 0 && PF_SQ_BLOCK % PF_CELL_BLOCK == 0, "whole groups");
-    const int gi = PF_SOLVE_INV_BLOCK / PF_CELL_BLOCK, gq = PF_SQ_BLOCK / PF_CELL_BLOCK;
+    const int gi = p.nblocks % (PF_SOLVE_INV_BLOCK / PF_CELL_BLOCK) == 0 ? PF_SOLVE_INV_BLOCK / PF_CELL_BLOCK : 1;
+    const int gq = PF_SQ_BLOCK / PF_CELL_BLOCK;
     if (p.fast && PF_SOLVE_QUEUE && p.nrows * p.n < (1ll << 32) && p.nblocks % gq == 0)  // (the queue holds 32-bit cell indices)
       hipLaunchKernelGGL((k_collapse_invq<PR>), dim3(p.nblocks / gq), dim3(PF_SQ_BLOCK), 0, st, p);
-    else if (p.nblocks % gi) return 2;
-    else if (p.fast) hipLaunchKernelGGL((k_collapse_inv<true, PR>), dim3(p.nblocks / gi), dim3(PF_SOLVE_INV_BLOCK), 0, st, p);
-    else hipLaunchKernelGGL((k_collapse_inv<false, PR>), dim3(p.nblocks / gi), dim3(PF_SOLVE_INV_BLOCK), 0, st, p);
+    else if (p.fast) hipLaunchKernelGGL((k_collapse_inv<true, PR>), dim3(p.nblocks / gi), dim3(PF_CELL_BLOCK * gi), 0, st, p);
+    else hipLaunchKernelGGL((k_collapse_inv<false, PR>), dim3(p.nblocks / gi), dim3(PF_CELL_BLOCK * gi), 0, st, p);
     return PF_CHECK_LAUNCH();
   }
   PF_BY_FIELD_AND_LIBM(k_collapse);

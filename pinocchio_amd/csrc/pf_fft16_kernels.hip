@@ -49,15 +49,28 @@ __device__ __forceinline__ void pf16_st2(pfc<float> *base, long long u, unsigned
 }
 
 // PRE: the launch carries the filter of the first pass (p.pre); BAND: it is band-limited (p.band_e or p.band_outer < N / 2)
-template <int DIR, bool PRE, bool BAND>
+#ifndef PF_S16_SPLIT
+#define PF_S16_SPLIT 0  // (1 in an A/B build: ONE job per workgroup, see below.  Measured slower: x-pass 1 -> 3 52.5 against 49.0 ms per step,
+                        //  y-pass 3 -> 6 87 against 84 on BASELINE config 5's slab: profiles/r05_notes.md)
+#endif
+template <int DIR, bool PRE, bool BAND, bool SPLIT = PF_S16_SPLIT>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4))) k_strided16(const PfStridedParams p, const long long nwork, const int ntiles) {
   using A = PfCxPk;
   using C = pf_f2;
   constexpr int N = PF16_N, T = 8, NT = N / 16;  // 128 threads per column pair
   extern __shared__ __attribute__((aligned(16))) char smem[];
   C *lds = reinterpret_cast<C *>(smem);  // [2048 slots][T] (re, im) pairs: ONE column of every pair at a time (128 KB)
-  const long long w = pf_xcd_swizzle(blockIdx.x, (nwork + 7) >> 3);
-  if (w >= nwork) return;
+  // PF_S16_SPLIT (A/B): ONE job per workgroup, the jobs of a tile on consecutive work items -- which the hardware deals to the CUs of
+  // ONE XCD back to back (pf_xcd_swizzle) -- in the hope that the tile they all read comes from that XCD's L2 for all but the first.
+  // (A workgroup running its tile's jobs in series reads it again 25 us later, when it has long left the L2 -- 32 CUs x 256 KB of tiles
+  // in flight per 4 MB: counted at the L2's exit, the x-pass 1 -> 3 moves 11.4 GB in for 4.3 GB of input per launch,
+  // profiles/r05_2048_pmc_traffic.json.)  It does not pay: three workgroups that miss together are not served as one miss, and a
+  // workgroup's start-up is paid three times.
+  const long long wid = pf_xcd_swizzle(blockIdx.x, (nwork + 7) >> 3);
+  if (wid >= nwork) return;
+  const int jsplit = SPLIT ? p.njobs : 1;
+  const long long w = wid / jsplit;
+  const int j_first = SPLIT ? (int)(wid - w * jsplit) : 0, j_end = SPLIT ? j_first + 1 : p.njobs;
   const int tid = threadIdx.x;
   const int c = tid % T, tl = tid / T;
   const int tile = (int)(w % ntiles);
@@ -85,7 +98,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4))) 
     }
   }
 #pragma unroll 1
-  for (int j = 0; j < p.njobs; j++) {
+  for (int j = j_first; j < j_end; j++) {
     // (an opaque copy of the thread coordinates per iteration keeps the index math inside the loop: see k_strided)
     int tlj = tl, cj = c;
     asm volatile("" : "+v"(tlj), "+v"(cj));
@@ -427,8 +440,9 @@ int pf_launch_strided16(int fb, int n, int dir, const PfStridedParams &p, hipStr
     }
     raised[k][d].store(true, std::memory_order_release);
   }
-  dim3 grid((unsigned)(((nwork + 7) >> 3) << 3), 1, 1), block(1024, 1, 1);
-  hipLaunchKernelGGL(kern[k], grid, block, shm, st, p, nwork, ntiles);
+  const long long nitems = (n == PF16_N && PF_S16_SPLIT) ? nwork * p.njobs : nwork;  // k_strided16: one job per workgroup
+  dim3 grid((unsigned)(((nitems + 7) >> 3) << 3), 1, 1), block(1024, 1, 1);
+  hipLaunchKernelGGL(kern[k], grid, block, shm, st, p, nitems, ntiles);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 

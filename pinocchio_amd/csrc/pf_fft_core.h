@@ -197,28 +197,6 @@ PF_HD void pf_stage_apply(pfc<F> (&v)[8], const pfc<F> (&w)[NW]) {
   }
 }
 
-// the same with the powers w^1 .. w^(R-1) of each butterfly's twiddle READ from a table (LDS) instead of formed by products: lw[(q' ) ...]
-// layout: for stage S the entries of butterfly position k = jb & (NS - 1) are lw[pf_ltw_offset(N, S, P16) + k * 7 + (r - 1)]  (A/B: PF_TW_LDS)
-constexpr int pf_ltw_offset(int n, int s, bool p16 = false) { return s <= 1 ? 0 : pf_ltw_offset(n, s - 1, p16) + (pf_ns(n, s - 1, p16) > 1 ? 7 * pf_ns(n, s - 1, p16) : 0); }
-constexpr int pf_ltw_size(int n, bool p16 = false) { return pf_ltw_offset(n, pf_nstages(n, p16), p16); }
-template <typename F, int N, int S, int DIR, bool P16 = false>
-PF_HD void pf_stage_apply_tab(pfc<F> (&v)[8], int tl, const pfc<F> *lw) {
-  constexpr int R = pf_radix(N, S, P16), NS = pf_ns(N, S, P16), Q = 8 / R, NT = N / 8;
-  static_assert(R == 8, "table form: radix-8 stages");
-  const int k = tl & (NS - 1);
-  const pfc<F> *w = lw + pf_ltw_offset(N, S, P16) + k * 7;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-  for (int r = 1; r < 8; r++) {
-    pfc<F> x = w[r - 1];
-    if (DIR < 0) x.y = -x.y;
-    v[r] = pf_cmul(v[r], x);
-  }
-  pf_bfly8<DIR>(v);
-  (void)Q; (void)NT;
-}
-
 // stage S with its twiddles fetched on the spot
 template <typename F, int N, int S, int DIR, int TWS>
 PF_HD void pf_stage(pfc<F> (&v)[8], int tl, const pfc<typename pf_lane<F>::type> *__restrict__ tw) {

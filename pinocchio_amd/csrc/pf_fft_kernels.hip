@@ -112,22 +112,6 @@ __global__ void __launch_bounds__(T *N / 8) __attribute__((amdgpu_waves_per_eu(4
     if (so > p.band_outer || so < -p.band_outer) return;
   }
 
-#ifndef PF_TW_LDS
-#define PF_TW_LDS 0  // (A/B, round 5: VERDICT r04 item 6) 1: 1024-point fp64 lines take the powers of their stage twiddles from a 16 KB table in LDS
-#endif
-  constexpr bool TWL = PF_TW_LDS && P16 && N == 1024 && sizeof(F) == 8;
-  C *ltw = lds + N * T;  // behind the tile
-  if constexpr (TWL) {
-    // entries of stage S, position k: w^r, w = exp(+2 pi i k / (NS R)), r = 1..7: table index k r N / (NS R) (no wrap: k < NS, r < R)
-    for (int i = tid; i < pf_ltw_size(N, true); i += T * NT) {
-      const int S = i < pf_ltw_offset(N, 2, true) ? 1 : 2;
-      const int rel = i - (S == 1 ? 0 : pf_ltw_offset(N, 2, true));
-      const int k = rel / 7, r = rel % 7 + 1;
-      const int NS = S == 1 ? pf_ns(N, 1, true) : pf_ns(N, 2, true);
-      ltw[i] = pf_bcast<F>(tw[k * r * (N / (NS * 8))]);
-    }
-    __syncthreads();
-  }
   C src[8], v[8];
   // a tile of input `in` into src: issued as early as src is free, consumed at the top of the job that uses it
   // (two columns: the pair is loaded whole when its first column exists -- a row's padding holds the odd one out -- and the
@@ -214,9 +198,7 @@ __global__ void __launch_bounds__(T *N / 8) __attribute__((amdgpu_waves_per_eu(4
     }
     // src is free once the last job on this input has taken its copy: the next input's tile travels during the stages
     if (j + 1 < p.njobs && p.job[j + 1].in != p.job[j].in) load_tile(p.job[j + 1].in, tlj, colj);
-    if constexpr (TWL) PfStages<F, N, DIR, 1, 0, false, P16>::run_tab(
-        v, tlj, ltw, [&](int pos, C val) { lds[pos * T + cj] = val; }, [&](int pos) { return lds[pos * T + cj]; });
-    else PfStages<F, N, DIR, 1, 0, false, P16>::run(
+    PfStages<F, N, DIR, 1, 0, false, P16>::run(
         v, tlj, tw, [&](int pos, C val) { lds[pos * T + cj] = val; }, [&](int pos) { return lds[pos * T + cj]; });
 #if defined(PF_DUMMY_VALU) && PF_DUMMY_VALU > 0  // (A/B probe: how much of the arithmetic of a job is hidden behind its memory traffic)
     if constexpr (NL == 1) {
@@ -723,7 +705,7 @@ template <typename F, int N, int DIR, bool FA>
 static int launch_strided_v(const PfStridedParams &p, hipStream_t st, int ntiles, long long nwork) {
   constexpr int T = PfTileCols<F, N>::value;
   dim3 grid((unsigned)(((nwork + 7) >> 3) << 3), 1, 1), block(T * N / 8, 1, 1);
-  const size_t shm = (size_t)N * T * sizeof(pfc<F>) + ((PF_TW_LDS && N == 1024 && sizeof(F) == 8 && T == 8) ? (size_t)pf_ltw_size(N, true) * sizeof(pfc<F>) : 0);
+  const size_t shm = (size_t)N * T * sizeof(pfc<F>);
   if (shm > 64 * 1024) {
     // LDS beyond 64 KB is opt-in per kernel function and device.  The flag is set only once the runtime has accepted the
     // size (a refusal is reported: code 3 = "dynamic LDS opt-in refused", not a bare launch failure later on) and is atomic:

@@ -43,23 +43,6 @@ struct PfStages {
   // tl_tw: the same thread index, as the twiddle side sees it.  A row loop that hides its index from the optimiser (so that
   // addresses are not hoisted into ~250 registers) may pass the plain, loop-invariant one here: the table values AND their
   // powers w^2 .. w^7 are then formed once, outside the loop (48 registers for a 512-point line).
-  // ltw (A/B, PF_TW_LDS): the powers of the later stages' twiddles from a table in LDS (pf_stage_apply_tab) instead of one table value
-  // from memory and six complex products per stage
-  template <typename WR, typename RD>
-  static __device__ __forceinline__ void run_tab(pfc<F> (&v)[8], int tl, const pfc<F> *ltw, WR wr, RD rd) {
-    if constexpr (S == 0 && P16) {
-      pf_pair16_local<DIR>(v, tl);
-      typedef typename pf_lane<F>::type SC;
-      const F sgn = (F)((tl & 1) ? (SC)-1 : (SC)1);
-#pragma unroll
-      for (int m = 0; m < 8; m++) v[m] = pf_pair16_combine1(v[m], pf_lane_xor8(v[m]), sgn);
-    } else if constexpr (S == 0) pf_bfly8<DIR>(v);
-    if constexpr (S + 1 < pf_nstages(N, P16)) {
-      exchange(v, tl, wr, rd);
-      pf_stage_apply_tab<F, N, S + 1, DIR, P16>(v, tl, ltw);
-      PfStages<F, N, DIR, TWS, S + 1, WAVE_LOCAL, P16>::run_tab(v, tl, ltw, wr, rd);
-    }
-  }
   template <typename WR, typename RD>
   static __device__ __forceinline__ void run(pfc<F> (&v)[8], int tl, const pfc<typename pf_lane<F>::type> *__restrict__ tw, WR wr, RD rd, int tl_tw = -1) {
     static_assert(!WAVE_LOCAL || N / 8 <= 64, "a wave-local transform has at most 64 threads");

@@ -229,3 +229,23 @@ def test_chirp_z_transforms_of_the_general_path(L, n):
     assert L.pf_debug_gfft(n, +1, _dp(np.ascontiguousarray(s).view(np.float64)), _dp(back)) == 0
     want = np.fft.irfftn(s, s=(n, n, n)) * n ** 3
     assert np.max(np.abs(back - want)) <= 2e-14 * np.max(np.abs(want))
+
+
+@pytest.mark.parametrize("n,fb", [(2048, 4), (1024, 4), (1024, 8), (2048, 8), (256, 4)])
+def test_strided_launch_with_several_jobs_per_tile(L, n, fb):
+    """one launch, six jobs on three inputs as the y-pass of the sweep issues them (A2 -> 1, A1 -> 2, A0 -> 3 outputs with their
+    k factors): tiles kept in registers over their jobs (k_strided, k_strided_pk8) or read again by one workgroup per job (k_strided16)"""
+    rng = np.random.default_rng(7 * n + fb)
+    nouter, ncols, nin = 2, 37, 3
+    x = rng.standard_normal((nin, nouter, n, ncols)) + 1j * rng.standard_normal((nin, nouter, n, ncols))
+    in_of = np.array([0, 1, 1, 2, 2, 2], dtype=np.int32)
+    mul = np.array([0, 1, 0, 2, 1, 3], dtype=np.int32)
+    out = np.zeros((6, nouter, n, ncols), dtype=np.complex128)
+    ip = C.POINTER(C.c_int)
+    rc = L.pf_debug_strided_jobs(fb, n, 6, nin, in_of.ctypes.data_as(ip), mul.ctypes.data_as(ip), nouter, ncols,
+                                 _dp(np.ascontiguousarray(x).view(np.float64)), _dp(out.view(np.float64)))
+    assert rc == 0, L.pf_last_error()
+    k = 2 * np.pi / n * signed(n)
+    for j in range(6):
+        want = np.fft.ifft(x[in_of[j]] * kfactor(int(mul[j]), k)[None, :, None], axis=1) * n
+        assert np.max(np.abs(out[j] - want)) <= tol(fb, n) * np.max(np.abs(want)), (n, fb, j)
