@@ -59,6 +59,11 @@ def alg_bytes_per_cell(ns: int, w: int, lpt: bool) -> float:
     return ns * (49 * w + 16) + ((207 * w + 48) if lpt else 0)
 
 
+# grid sizes whose stage plans csrc/pf_mixed_kernels.hip knows at compile time: (strided passes, z-passes on n / 2)
+# (spelled as rocprofv3 prints a nested template argument: with a blank before the closing bracket of the outer list)
+MIXED_CT_PLANS = {768: ("PfPlanCT<8, 8, 4, 3> ", "PfPlanCT<8, 8, 2, 3> "), 200: ("PfPlanCT<8, 5, 5> ", "PfPlanCT<4, 5, 5> ")}
+
+
 def symbol_of(cls: str, n: int, fb: int, fast: bool = True) -> str:
     """kernel function behind a launch class, spelled as rocprofv3 prints it (csrc/pf_fft_kernels.hip dispatch tables)"""
     F = "double" if fb == 8 else "float"
@@ -70,16 +75,19 @@ def symbol_of(cls: str, n: int, fb: int, fast: bool = True) -> str:
     nt = n // 16
     tl = 1 if nt >= 256 else 256 // nt
     b = "true" if fast else "false"
-    if n & (n - 1):   # not a power of two: the run-time stage plans of csrc/pf_mixed_kernels.hip
+    if n & (n - 1):   # not a power of two: the stage plans of csrc/pf_mixed_kernels.hip (compile-time for the sizes it names, else run-time)
         r0 = 8 if (n // 2) % 8 == 0 else 4
+        ps, pz = MIXED_CT_PLANS.get(n, ("PfPlanRT", "PfPlanRT"))
         if cls in ("xpass_hess_1to3", "ypass_hess_3to6", "xpass_disp_1to2", "ypass_disp_2to3", "xpass_plain", "ypass_plain"):
-            return f"k_mixed_strided<{F}, 1>"
+            return f"k_mixed_strided<{F}, 1, {ps}>"
         if cls in ("xpass_fwd", "ypass_fwd"):
-            return f"k_mixed_strided<{F}, -1>"
+            return f"k_mixed_strided<{F}, -1, {ps}>"
         if cls in ("zpass_c2r_hess_6", "zpass_c2r_disp_3", "zpass_c2r_plain"):
-            return f"k_mixed_c2r<{F}, {r0}>"
+            return f"k_mixed_c2r<{F}, {r0}, {pz}>"
         if cls == "zpass_r2c":
-            return f"k_mixed_r2c<{F}, {r0}>"
+            return f"k_mixed_r2c<{F}, {r0}, {pz}>"
+        if cls in ("zpass_c2r_hess_6to3inv", "zpass_c2r_hess_6_lpt3b"):
+            return f"k_mixed_c2r_invariants<{F}, {r0}, {pz.strip()}, {0 if cls.endswith('inv') else 1}, false>"
     # fp32 lines of 1024 / 2048 points: the kernels in packed (re, im) arithmetic (csrc/pf_fft16_kernels.hip), one instantiation per
     # (direction, first-pass filter, band limit) -- a launch class runs several of them (pruned and unpruned radii): the family is named
     if fb == 4 and n in (1024, 2048) and cls in ("xpass_hess_1to3", "ypass_hess_3to6", "xpass_disp_1to2", "ypass_disp_2to3", "xpass_plain", "ypass_plain", "xpass_fwd", "ypass_fwd"):

@@ -1329,7 +1329,7 @@ static int sweep_body_run(pf_ctx *c, int ns, const double *radius_cells, double 
   c->sources_fresh = false;
   // (n <= 1024: the six-line workgroup of a 2048-point row would need 110 KB of dynamic LDS, a size this build never launches)
   // (n <= 1024 with fp64 fields, n <= 2048 with fp32 ones: the six lines of a row must fit the LDS of a workgroup)
-  const bool invariants_ok = c->n <= (c->fb == 8 ? 1024 : 2048) && !(c->n & (c->n - 1)) && !c->general && c->tab_ns == 0 && c->model == 0 && c->tune.invariants && !six_components;
+  const bool invariants_ok = pf_c2r_invariants_preferred(c->fb, (int)c->n) && !c->general && c->tab_ns == 0 && c->model == 0 && c->tune.invariants && !six_components;
   HIPCHK(c, hipMemsetAsync(c->scal + SC_INV_FLAG, 0, sizeof(double), c->stream));
   const bool rep = c->replicate;
   if (rep) PFCHK(c, ensure_dk_full(c));
@@ -1520,7 +1520,7 @@ extern "C" int pf_displacements(pf_ctx *c, int compute_sources, int recompute_sd
       // Hessian of the 2LPT potential contracted with the first-order one into the 3LPT(b) source (src/LPT.c:112-137).  fp64
       // fields: the z-pass does the contraction while it holds a row's six components (nothing of that Hessian is stored;
       // PF_LPT_FUSE=0: six fields out, then k_lpt_accum); same operations per cell either way
-      const bool fuse3b = c->n <= (c->fb == 8 ? 1024 : 2048) && !(c->n & (c->n - 1)) && !c->general && c->tune.lpt_fuse;
+      const bool fuse3b = pf_c2r_invariants_preferred(c->fb, (int)c->n) && !c->general && c->tune.lpt_fuse;
       if (c->lpt_order < 3) {  // no THREE_LPT (src/LPT.c:78-92, 113-175): the 2LPT source alone
       } else if (fuse3b) {
         PFCHK(c, hessian_of(c, c->S[0], 0.0, c->scal + SC_DC_S2, c->B2, c->S[2], c->B));
@@ -1899,10 +1899,11 @@ extern "C" int pf_debug_lines(int field_bytes, int n, int pass, int mul, int ban
     return pf_fail(0, "pf_debug_lines: bad argument");
   if (n & (n - 1)) {  // not a power of two: the run-time stage plans (pf_mixed_kernels.hip), where they apply
     PfMixedPlan pl;
-    if (pass == 4 || !(pass <= 1 ? pf_mixed_plan(n, false, &pl) : (n % 2 == 0 && pf_mixed_plan(n / 2, true, &pl))))
+    if (!(pass <= 1 ? pf_mixed_plan(n, false, &pl) : (n % 2 == 0 && pf_mixed_plan(n / 2, true, &pl))))
       return pf_fail(0, "pf_debug_lines: no stage plan for %d points in pass %d", n, pass);
   } else if (n < 16) return pf_fail(0, "pf_debug_lines: bad argument");
-  if (pass == 4 && n > (field_bytes == 8 ? 1024 : 2048)) return pf_fail(0, "pf_debug_lines: the invariant z-pass takes fp64 rows of at most 1024 points, fp32 rows of at most 2048");
+  if (pass == 4 && !pf_c2r_invariants_supported(field_bytes, n))
+    return pf_fail(0, "pf_debug_lines: the invariant z-pass takes rows whose six lines fit a workgroup (fp64 rows of at most 1024 points, fp32 rows of at most 2048; n = 8 m as the grids)");
   const int fb = field_bytes, nzh = n / 2 + 1;
   pf_ctx *nc = nullptr;  // for the error macros
   size_t n_in, n_out;    // scalars of type F
@@ -2003,7 +2004,7 @@ extern "C" int pf_debug_lines(int field_bytes, int n, int pass, int mul, int ban
 extern "C" int pf_debug_strided_jobs(int field_bytes, int n, int njobs, int nin, const int *in_of, const int *mul, int nouter, int ncols,
                                      const double *in, double *out) {
   if (!in || !out || !in_of || !mul || njobs < 1 || njobs > PF_MAX_JOBS || nin < 1 || nin > njobs || nouter < 1 || ncols < 1 || (field_bytes != 8 && field_bytes != 4) ||
-      n < 16 || n > 2048 || (n & (n - 1)))
+      n < 16 || n > 2048 || ((n & (n - 1)) && !pf_mixed_supported(n)))
     return pf_fail(0, "pf_debug_strided_jobs: bad argument");
   const int fb = field_bytes, pc = (ncols + 15) & ~15;
   pf_ctx *nc = nullptr;
@@ -2033,7 +2034,7 @@ extern "C" int pf_debug_strided_jobs(int field_bytes, int n, int njobs, int nin,
       if (in_of[j] < 0 || in_of[j] >= nin) return pf_fail(0, "pf_debug_strided_jobs: in_of");
       p.job[j].in = (char *)d_in + (size_t)in_of[j] * field * fb; p.job[j].out = (char *)d_out + (size_t)j * field * fb; p.job[j].mul = mul[j];
     }
-    p.ain.os = (long long)n * pc; p.ain.el_shift = ilog2i(n); p.ain.el_len = n; p.ain.ehs = 0; p.ain.els = pc; p.aout = p.ain;
+    p.ain.os = (long long)n * pc; p.ain.el_shift = (n & (n - 1)) ? 0 : ilog2i(n); p.ain.el_len = n; p.ain.ehs = 0; p.ain.els = pc; p.aout = p.ain;
     p.ncols = ncols; p.nouter = nouter; p.tw = d_tw; p.band_e = p.band_outer = n; p.dev = dev; p.growth = 1.0;
     PFCHK0(pf_launch_strided(fb, n, +1, p, nullptr));
     HIPCHK(nc, hipDeviceSynchronize());

@@ -859,9 +859,21 @@ int pf_launch_c2r(int fb, int n, const PfC2RParams &p, hipStream_t st) {
   }
 }
 
-int pf_launch_c2r_invariants(int fb, int n, const PfC2RParams &p, hipStream_t st, int mode) {
+bool pf_c2r_invariants_supported(int fb, int n) {
   // (the six lines of a 2048-point fp64 row would need 110 KB of LDS; fp32 fields go up to 2048)
-  if (p.njobs != 6 || (mode == 1 && !p.acc) || (mode == 0 && !p.flag) || n > (fb == 8 ? 1024 : 2048) || (n & (n - 1))) return 2;
+  if (n & (n - 1)) return pf_mixed_invariants_supported(fb, n);
+  return n >= 16 && n <= (fb == 8 ? 1024 : 2048);
+}
+// ... and the sweep takes it: always where the line length is a power of two; for the other sizes with fp64 fields only -- three fp64
+// invariants are as many bytes as six fp32 components, and the six-component z-pass of those sizes is the faster kernel
+// (768^3, fp32 fields: 273 ms per step with six components, 288 with invariants; profiles/r05_notes.md)
+bool pf_c2r_invariants_preferred(int fb, int n) {
+  return pf_c2r_invariants_supported(fb, n) && (!(n & (n - 1)) || fb == 8);
+}
+int pf_launch_c2r_invariants(int fb, int n, const PfC2RParams &p, hipStream_t st, int mode) {
+  if (p.njobs != 6 || (mode == 1 && !p.acc) || (mode == 0 && !p.flag) || !pf_c2r_invariants_supported(fb, n)) return 2;
+  if (fb == 4 && mode == 0 && (!p.inv_out[0] || !p.inv_out[1] || !p.inv_out[2])) return 2;
+  if (n & (n - 1)) return pf_launch_mixed_c2r_invariants(fb, n, p, st, mode);
   if (fb == 8) {
 #define CALL(NN) launch_c2r_invariants_n<double, NN>(p, st, mode)
     PF_SWITCH_N(n, CALL)

@@ -118,6 +118,10 @@ bool pf_mixed_supported(int n);   // n = 8 m with m = 2^a 3^b 5^c, up to 2048: s
 int pf_launch_mixed_strided(int field_bytes, int n, int dir, const PfStridedParams &p, hipStream_t st);
 int pf_launch_mixed_c2r(int field_bytes, int n, const PfC2RParams &p, hipStream_t st);
 int pf_launch_mixed_r2c(int field_bytes, int n, const PfR2CParams &p, hipStream_t st);
+bool pf_mixed_invariants_supported(int field_bytes, int n);  // six lines of a row fit one workgroup
+int pf_launch_mixed_c2r_invariants(int field_bytes, int n, const PfC2RParams &p, hipStream_t st, int mode);
+bool pf_c2r_invariants_preferred(int field_bytes, int n);   // ... and the sweep uses it (pf_fft_kernels.hip)
+bool pf_c2r_invariants_supported(int field_bytes, int n);    // pf_launch_c2r_invariants takes rows of n points (either kind of plan)
 
 // ---- per-cell kernels (pf_cell_kernels.hip) ----
 #define PF_KNOT_CAP 512  // knots per spline at most; the five arrays of a spline lie PF_KNOT_CAP doubles apart (y = x + PF_KNOT_CAP ...: spline_for)

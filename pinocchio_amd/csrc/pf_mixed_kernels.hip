@@ -20,7 +20,14 @@
 #include "pf_internal.h"
 #include "pf_fft_core.h"
 #include "pf_fft_stages.h"
+#include "pf_collapse_core.h"  // pf_invariants, pf_lpt3b_accumulate
 
+#ifndef PF_MIXED_TW_POWERS
+#define PF_MIXED_TW_POWERS 1
+#endif
+#ifndef PF_MIXED_KEEP
+#define PF_MIXED_KEEP 1
+#endif
 // hardware deals consecutive workgroups round-robin over the 8 XCDs: a contiguous range of tiles per XCD (as pf_fft_kernels.hip)
 __device__ __forceinline__ long long pf_xcd_swizzle_mixed(long long b, long long per_xcd) { return (b & 7) * per_xcd + (b >> 3); }
 
@@ -63,11 +70,17 @@ __device__ __forceinline__ void pf_mixed_stage(int n, int ns, unsigned magic, in
   constexpr int LOOPS = (R0 + R - 1) / R;  // butterflies per thread: ceil((n / R) / (n / R0))
   const int nb = n / R;                    // butterflies of the stage = distance of a butterfly's inputs (uniform: scalar unit)
   const int twm = n / (ns * R);
-  pfc<F> u[LOOPS][R];
+  pfc<F> u[LOOPS][R], w1[LOOPS];
+  // one table value per butterfly, w = exp(+-2 pi i k / (NS R)), its powers by multiplication below (depth three for w^7): the lanes of
+  // a wave ask for 64 different table entries per request, and R - 1 such requests per butterfly kept the L1 busier than the rows
+  // themselves (without them the z-passes ran 25 % faster: profiles/r05_notes.md).  Asked for in front of the exchange: in flight
+  // while the line's threads meet.  (PF_MIXED_TW_POWERS=0, A/B: every power from the table.)
 #pragma unroll
   for (int i = 0; i < LOOPS; i++) {
     const int b = tl + i * nt;
     if (b < nb) {
+      const int k = b - ns * (int)__umulhi((unsigned)b, magic);  // b mod ns (magic = ceil(2^32 / ns), exact for b < 2^11)
+      if (PF_MIXED_TW_POWERS) w1[i] = tw[k * twm * tws];
 #pragma unroll
       for (int q = 0; q < R; q++) u[i][q] = rd(b + q * nb);
     }
@@ -77,8 +90,18 @@ __device__ __forceinline__ void pf_mixed_stage(int n, int ns, unsigned magic, in
   for (int i = 0; i < LOOPS; i++) {
     const int b = tl + i * nt;
     if (b < nb) {
-      const int k = b - ns * (int)__umulhi((unsigned)b, magic);  // b mod ns (magic = ceil(2^32 / ns), exact for b < 2^11)
-      {
+      const int k = b - ns * (int)__umulhi((unsigned)b, magic);
+      if (PF_MIXED_TW_POWERS) {
+        pfc<F> w[R];
+        w[1] = w1[i];
+        if (DIR < 0) w[1].y = -w[1].y;
+        if constexpr (R > 2) w[2] = pf_cmul(w[1], w[1]);
+        if constexpr (R > 3) w[3] = pf_cmul(w[2], w[1]);
+        if constexpr (R > 4) w[4] = pf_cmul(w[2], w[2]);
+        if constexpr (R > 5) { w[5] = pf_cmul(w[4], w[1]); w[6] = pf_cmul(w[3], w[3]); w[7] = pf_cmul(w[4], w[3]); }
+#pragma unroll
+        for (int q = 1; q < R; q++) u[i][q] = pf_cmul(u[i][q], w[q]);
+      } else {
         const int step = k * twm * tws;  // k twm < n / R: the index q k twm stays below n, no reduction needed
         int idx = 0;
 #pragma unroll
@@ -135,6 +158,33 @@ __device__ __forceinline__ void pf_mixed_tail(const PfMixedPlan &pl, int tl, con
   }
 }
 
+// A plan known at compile time: the same stages with every divisor, stride and trip count a constant (no switch over the radix, no
+// multiply-high, no predicate where the butterflies divide evenly) -- the sizes the launchers know by name (PF_MIXED_CT_SIZES).
+// PfPlanRT: the run-time plan of the argument block.
+template <int... R> struct PfPlanCT {
+  static constexpr int nstages = (int)sizeof...(R);
+  static constexpr int radix[sizeof...(R)] = {R...};
+  static constexpr int n = (R * ...);
+  static constexpr int ns(int s) { int v = 1; for (int i = 0; i < s; i++) v *= radix[i]; return v; }
+};
+struct PfPlanRT { static constexpr int nstages = 0, n = 0; };
+template <typename PLAN, int S, int R0, int DIR, typename F, typename RD, typename WR, typename SYNC, typename OUT>
+__device__ __forceinline__ void pf_mixed_tail_ct(int tl, const pfc<F> *__restrict__ tw, int tws, RD rd, WR wr, SYNC sync, OUT out) {
+  if constexpr (S < PLAN::nstages) {
+    constexpr int R = PLAN::radix[S], NS = PLAN::ns(S);
+    constexpr unsigned magic = (unsigned)(((1ull << 32) + NS - 1) / NS);
+    pf_mixed_stage<R, R0, DIR, S + 1 == PLAN::nstages>(PLAN::n, NS, magic, PLAN::n / R0, tl, tw, tws, rd, wr, sync, out);
+    pf_mixed_tail_ct<PLAN, S + 1, R0, DIR, F>(tl, tw, tws, rd, wr, sync, out);
+  }
+}
+template <typename PLAN, int R0, int DIR, typename F, typename RD, typename WR, typename SYNC, typename OUT>
+__device__ __forceinline__ void pf_mixed_tail_any(const PfMixedPlan &pl, int tl, const pfc<F> *__restrict__ tw, int tws, RD rd, WR wr, SYNC sync, OUT out) {
+  if constexpr (PLAN::nstages > 0) {
+    static_assert(PLAN::radix[0] == R0, "first radix of the plan");
+    pf_mixed_tail_ct<PLAN, 1, R0, DIR, F>(tl, tw, tws, rd, wr, sync, out);
+  } else pf_mixed_tail<R0, DIR, F>(pl, tl, tw, tws, rd, wr, sync, out);
+}
+
 // ------------------------------------------------------------------------------------------------ strided passes ----
 // x- or y-pass: a workgroup owns T adjacent columns of one line of tiles and all n points along the transformed axis
 // (n / 8 threads per column).  Parameters and semantics: PfStridedParams, as k_strided.
@@ -142,14 +192,15 @@ __device__ __forceinline__ void pf_mixed_tail(const PfMixedPlan &pl, int tl, con
 // e % el_len (PfAddr: the blocks of a multi-rank layout; one rank: e * els) -- the quotient by multiply-high, any slab length.
 // The tile is loaded for every job (jobs on the same input find it in L2): the eight points of a thread then live only
 // through one job, which is what lets the run-time plan fit the register file.
-template <typename F, int DIR>
+template <typename F, int DIR, typename PLAN = PfPlanRT>
 __global__ void __launch_bounds__(1024) k_mixed_strided(const PfStridedParams p, const PfMixedPlan pl, const long long nwork, const int ntiles) {
   using C = pfc<F>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   C *lds = reinterpret_cast<C *>(smem);  // [n][T]
   const long long w = pf_xcd_swizzle_mixed(blockIdx.x, (nwork + 7) >> 3);
   if (w >= nwork) return;
-  const int n = pl.n, nt = n / 8, T = blockDim.x;
+  const int n = PLAN::n ? PLAN::n : pl.n, nt = n / 8, T = blockDim.x;
+  const int nstages = PLAN::n ? PLAN::nstages : pl.nstages;
   const int c = threadIdx.x, tl = threadIdx.y;
   const int tile = (int)(w % ntiles), outer = (int)(w / ntiles);
   const int col = tile * T + c;
@@ -182,6 +233,10 @@ __global__ void __launch_bounds__(1024) k_mixed_strided(const PfStridedParams p,
     woc = (p.rs != 0.0 ? exp(-0.5 * ko2kc2 * p.rs * p.rs) : 1.0) * p.growth;
   }
   auto sync = [&]() { __syncthreads(); };
+  // a plan known at compile time leaves room to hold the loaded (and filtered) points while the jobs on the same input follow each other
+  constexpr bool KEEP = PLAN::n != 0 && PF_MIXED_KEEP;
+  C src[KEEP ? 8 : 1];
+  const C *held = nullptr;
 #pragma unroll 1
   for (int j = 0; j < p.njobs; j++) {
     const C *__restrict__ in = reinterpret_cast<const C *>(p.job[j].in) + base_in;
@@ -189,18 +244,24 @@ __global__ void __launch_bounds__(1024) k_mixed_strided(const PfStridedParams p,
     int tlj = tl;
     asm volatile("" : "+v"(tlj));  // (keeps the per-element index and filter arithmetic inside the job loop: hoisted, it spills)
     C v[8];
+    const bool fresh = !KEEP || in != held;  // (uniform)
+    held = in;
 #pragma unroll
     for (int m = 0; m < 8; m++) {
       const int e = tlj + m * nt;
       const int se = e > half ? e - n : e;
-      const bool inband = se <= p.band_e && se >= -p.band_e;
-      C x = (valid && inband) ? pf_ld_stream(in + off_in((unsigned)e)) : pf_zero<F>();
       const double ke = kf * se;
-      if (p.pre) {  // exp(-k^2 rs^2 / 2) g / k^2, zero at k = 0 (src/fmax-pfft.c:366-384)
-        const double k2 = ke * ke + ko2kc2;
-        const double we = p.rs != 0.0 ? p.etab[e] : 1.0;
-        x = pf_scale(x, (F)((k2 != 0.0) ? we * woc / k2 : 0.0));
-      }
+      C x;
+      if (fresh) {
+        const bool inband = se <= p.band_e && se >= -p.band_e;
+        x = (valid && inband) ? pf_ld_stream(in + off_in((unsigned)e)) : pf_zero<F>();
+        if (p.pre) {  // exp(-k^2 rs^2 / 2) g / k^2, zero at k = 0 (src/fmax-pfft.c:366-384)
+          const double k2 = ke * ke + ko2kc2;
+          const double we = p.rs != 0.0 ? p.etab[e] : 1.0;
+          x = pf_scale(x, (F)((k2 != 0.0) ? we * woc / k2 : 0.0));
+        }
+        if (KEEP) src[m] = x;
+      } else x = src[m];
       const F kef = (F)ke;
       if (mul == PF_MUL_K) x = pf_scale(x, kef);
       else if (mul == PF_MUL_K2) x = pf_scale(x, kef * kef);
@@ -214,14 +275,14 @@ __global__ void __launch_bounds__(1024) k_mixed_strided(const PfStridedParams p,
       pf_st_stream(outp + off_out((unsigned)e), val);
     };
     pf_bfly8<DIR>(v);  // stage 0: the thread's own eight points (NS = 1: no twiddles)
-    if (pl.nstages == 1) {
+    if (nstages == 1) {
 #pragma unroll
       for (int t = 0; t < 8; t++) store(tlj + t * nt, v[t]);  // n = 8: (b - k) R + k + t NS with b = k = 0
     } else {
 #pragma unroll
       for (int t = 0; t < 8; t++) lds[(tlj * 8 + t) * T + c] = v[t];  // outputs of butterfly b = tl: b R + t
       __syncthreads();
-      pf_mixed_tail<8, DIR, F>(
+      pf_mixed_tail_any<PLAN, 8, DIR, F>(
           pl, tlj, tw, 1, [&](int pos) { return lds[pos * T + c]; }, [&](int pos, C val) { lds[pos * T + c] = val; }, sync, store);
       __syncthreads();  // the next job rewrites the exchange area
     }
@@ -229,13 +290,21 @@ __global__ void __launch_bounds__(1024) k_mixed_strided(const PfStridedParams p,
 }
 
 // --------------------------------------------------------------------------------------------------------- z-pass ----
+// A line's element p sits at LDS slot p + p / R0: the writes of stage 0 (a thread's R0 outputs are neighbours, the threads of a wave
+// R0 apart) then fall on distinct banks instead of two (R0 = 8, 16-byte elements) -- PF_MIXED_PAD=0: A/B.
+#ifndef PF_MIXED_PAD
+#define PF_MIXED_PAD 1
+#endif
+
+#define PFP(q) (PF_MIXED_PAD ? (q) + ((q) >> (R0 == 8 ? 3 : 2)) : (q))
 // c2r rows: Hermitian rows of n/2+1 -> n reals through the half-length complex transform (pf_c2r_pre), kz factor, 1/N^3 and
 // the DC constant as k_c2r.  TL rows per workgroup, M / R0 threads per row (M = n / 2, R0 = 8 or 4).
-template <typename F, int R0>
+template <typename F, int R0, typename PLAN = PfPlanRT>
 __global__ void __launch_bounds__(256) k_mixed_c2r(const PfC2RParams p, const PfMixedPlan pl) {
   using C = pfc<F>;
-  const int M = pl.n, n = 2 * M, nt = M / R0, TL = blockDim.y;
-  const int LPL = M + 1;
+  const int M = PLAN::n ? PLAN::n : pl.n, n = 2 * M, nt = M / R0, TL = blockDim.y;
+  const int nstages = PLAN::n ? PLAN::nstages : pl.nstages;
+  const int LPL = PFP(M) + 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   C *lds = reinterpret_cast<C *>(smem);
   const int tl = threadIdx.x, l = threadIdx.y;  // (thread of the row, row of the tile)
@@ -246,14 +315,16 @@ __global__ void __launch_bounds__(256) k_mixed_c2r(const PfC2RParams p, const Pf
   const int mul = p.job[job].mul;
   const C *__restrict__ tw = reinterpret_cast<const C *>(p.tw);   // exp(+2 pi i j / n), n entries
   C *L = lds + l * LPL;
-  for (int k = tl; k <= M; k += nt) L[k] = (rvalid && k <= p.band_k) ? pf_ld_stream(in + k) : pf_mk<F>(0, 0);  // the row's own threads stage it
+  for (int k = tl; k <= M; k += nt) L[PFP(k)] = (rvalid && k <= p.band_k) ? pf_ld_stream(in + k) : pf_mk<F>(0, 0);  // the row's own threads stage it
+  C v[R0];
+#pragma unroll
+  for (int m = 0; m < R0; m++) v[m] = tw[tl + m * nt];  // the fold's table values, asked for in front of the barrier
   __syncthreads();
   const F kf = (F)(2.0 * 3.14159265358979323846 / (double)n);
-  C v[R0];
 #pragma unroll
   for (int m = 0; m < R0; m++) {
     const int e = tl + m * nt;
-    v[m] = pf_zfold<F>(L[e], L[M - e], e, M, mul, kf, tw[e]);
+    v[m] = pf_zfold<F>(L[PFP(e)], L[PFP(M - e)], e, M, mul, kf, v[m]);
   }
   __syncthreads();
   const F norm = (F)p.norm;
@@ -269,24 +340,25 @@ __global__ void __launch_bounds__(256) k_mixed_c2r(const PfC2RParams p, const Pf
   };
   auto sync = [&]() { __syncthreads(); };
   pf_dft_small<R0, +1>(v);
-  if (pl.nstages == 1) {
+  if (nstages == 1) {
 #pragma unroll
     for (int t = 0; t < R0; t++) store(tl + t * nt, v[t]);
   } else {
 #pragma unroll
-    for (int t = 0; t < R0; t++) L[tl * R0 + t] = v[t];
+    for (int t = 0; t < R0; t++) L[PFP(tl * R0 + t)] = v[t];
     __syncthreads();
-    pf_mixed_tail<R0, +1, F>(
-        pl, tl, tw, 2, [&](int pos) { return L[pos]; }, [&](int pos, C val) { L[pos] = val; }, sync, store);
+    pf_mixed_tail_any<PLAN, R0, +1, F>(
+        pl, tl, tw, 2, [&](int pos) { return L[PFP(pos)]; }, [&](int pos, C val) { L[PFP(pos)] = val; }, sync, store);
   }
 }
 
 // r2c rows (forward z-pass of the LPT sources), in place like k_r2c: real row -> n/2+1 complex
-template <typename F, int R0>
+template <typename F, int R0, typename PLAN = PfPlanRT>
 __global__ void __launch_bounds__(256) k_mixed_r2c(const PfR2CParams p, const PfMixedPlan pl) {
   using C = pfc<F>;
-  const int M = pl.n, nt = M / R0, TL = blockDim.y;
-  const int LPL = M + 1;
+  const int M = PLAN::n ? PLAN::n : pl.n, nt = M / R0, TL = blockDim.y;
+  const int nstages = PLAN::n ? PLAN::nstages : pl.nstages;
+  const int LPL = PFP(M) + 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   C *lds = reinterpret_cast<C *>(smem);
   const int tl = threadIdx.x, l = threadIdx.y;
@@ -301,30 +373,142 @@ __global__ void __launch_bounds__(256) k_mixed_r2c(const PfR2CParams p, const Pf
     for (int m = 0; m < R0; m++) v[m] = valid ? pf_ld_stream(in + tl + m * nt) : pf_mk<F>(0, 0);
   }
   auto sync = [&]() { __syncthreads(); };
-  auto keep = [&](int pos, C val) { L[pos] = val; };  // the last stage leaves Z in LDS: the post-processing reads Z[k] and Z[M - k]
+  auto keep = [&](int pos, C val) { L[PFP(pos)] = val; };  // the last stage leaves Z in LDS: the post-processing reads Z[k] and Z[M - k]
   __syncthreads();  // (in place: every row of the tile is in registers before anything is stored)
   pf_dft_small<R0, -1>(v);
-  if (pl.nstages == 1) {
+  if (nstages == 1) {
 #pragma unroll
-    for (int t = 0; t < R0; t++) L[tl + t * nt] = v[t];
+    for (int t = 0; t < R0; t++) L[PFP(tl + t * nt)] = v[t];
   } else {
 #pragma unroll
-    for (int t = 0; t < R0; t++) L[tl * R0 + t] = v[t];
+    for (int t = 0; t < R0; t++) L[PFP(tl * R0 + t)] = v[t];
     __syncthreads();
-    pf_mixed_tail<R0, -1, F>(
-        pl, tl, tw, 2, [&](int pos) { return L[pos]; }, keep, sync, keep);
+    pf_mixed_tail_any<PLAN, R0, -1, F>(
+        pl, tl, tw, 2, [&](int pos) { return L[PFP(pos)]; }, keep, sync, keep);
   }
   __syncthreads();
   if (valid) {  // the row's own threads write it back: X[k] from Z[k] and Z[M - k]
     C *out = reinterpret_cast<C *>(p.out) + row * p.out_pitch;
     for (int k = tl; k <= M; k += nt) {
-      if (k == M) out[M] = pf_mk<F>(L[0].x - L[0].y, (F)0);
-      else pf_st_stream(out + k, pf_r2c_post<F>(L[k], L[k == 0 ? 0 : M - k], tw[k]));
+      if (k == M) out[M] = pf_mk<F>(L[PFP(0)].x - L[PFP(0)].y, (F)0);
+      else pf_st_stream(out + k, pf_r2c_post<F>(L[PFP(k)], L[PFP(k == 0 ? 0 : M - k)], tw[k]));
     }
   }
 }
 
+// The z-pass of the sweep for these sizes, as k_c2r_invariants (pf_fft_kernels.hip): the six components of one row per workgroup
+// (line l = threadIdx.y is component l), each transformed as in k_mixed_c2r with the real row left in its LDS line; then every
+// thread of the workgroup reduces cells of the row -- MODE 0: the three invariants of the tensor, stored in place of the first three
+// components (fp64 fields) or as fp64 rows of their own (fp32 fields: inv_out, inv_pitch); MODE 1: the 3LPT(b) source updated in
+// place from the six rows and the first-order Hessian in job[].out.  The values are formed by the expressions of the six-field
+// path (pf_norm_dc, pf_invariants, pf_lpt3b_accumulate): the same bits.  Workgroups walk over rows (grid-stride).
+// (Run-time plans with R0 = 8: rows of at most 2048 points, 128 threads per line -- 768 threads at most.)
+template <typename F, int R0, typename PLAN, int MODE>
+__global__ void __launch_bounds__(PLAN::n ? 6 * (PLAN::n / R0) : (R0 == 8 ? 768 : 1024)) k_mixed_c2r_invariants(const PfC2RParams p, const PfMixedPlan pl) {
+  using C = pfc<F>;
+  using F2 = typename pf_vec2<F>::type;
+  constexpr bool IN_PLACE = sizeof(F) == 8;
+  const int M = PLAN::n ? PLAN::n : pl.n, n = 2 * M, nt = M / R0;
+  const int nstages = PLAN::n ? PLAN::nstages : pl.nstages;
+  const int LPL = M + 1;  // (no padding here: the six lines of a 768-point fp64 row then fit a CU four times, and a fourth workgroup is worth
+                          //  more than the banks -- 11.3 against 11.5 ms per launch at 768^3)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  C *lds = reinterpret_cast<C *>(smem);
+  const int tl = threadIdx.x, l = threadIdx.y;
+  const int tid = l * nt + tl, nthr = 6 * nt;
+  const C *__restrict__ in0 = reinterpret_cast<const C *>(p.job[l].in);
+  const int mul = p.job[l].mul;
+  const C *__restrict__ tw = reinterpret_cast<const C *>(p.tw);
+  C *L = lds + l * LPL;
+  const F kf = (F)(2.0 * 3.14159265358979323846 / (double)n);
+  const F norm = (F)p.norm;
+  const F dcv = p.dc ? (F)(*p.dc) : (F)0;
+  double *__restrict__ o1 = IN_PLACE ? reinterpret_cast<double *>(p.job[0].out) : p.inv_out[0],
+         *__restrict__ o2 = IN_PLACE ? reinterpret_cast<double *>(p.job[1].out) : p.inv_out[1],
+         *__restrict__ o3 = IN_PLACE ? reinterpret_cast<double *>(p.job[2].out) : p.inv_out[2];
+  auto sync = [&]() { __syncthreads(); };
+  auto keep = [&](int pos, C val) { L[pos] = pf_mk<F>(pf_norm_dc(val.x, norm, dcv), pf_norm_dc(val.y, norm, dcv)); };  // complex j = reals 2 j, 2 j + 1
+#pragma unroll 1
+  for (long long row = blockIdx.x; row < p.nlines; row += gridDim.x) {
+    int tlj = tl, tidj = tid;
+    asm volatile("" : "+v"(tlj), "+v"(tidj));
+    const C *__restrict__ in = in0 + row * p.in_pitch;
+    for (int k = tlj; k <= M; k += nt) L[k] = (k <= p.band_k) ? pf_ld_stream(in + k) : pf_mk<F>(0, 0);
+    C v[R0];
+#pragma unroll
+    for (int m = 0; m < R0; m++) v[m] = tw[tlj + m * nt];  // the fold's table values, asked for in front of the barrier
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < R0; m++) {
+      const int e = tlj + m * nt;
+      v[m] = pf_zfold<F>(L[e], L[M - e], e, M, mul, kf, v[m]);
+    }
+    __syncthreads();
+    pf_dft_small<R0, +1>(v);
+    if (nstages == 1) {
+#pragma unroll
+      for (int t = 0; t < R0; t++) keep(tlj + t * nt, v[t]);
+    } else {
+#pragma unroll
+      for (int t = 0; t < R0; t++) L[tlj * R0 + t] = v[t];
+      __syncthreads();
+      pf_mixed_tail_any<PLAN, R0, +1, F>(
+          pl, tlj, tw, 2, [&](int pos) { return L[pos]; }, [&](int pos, C val) { L[pos] = val; }, sync, keep);
+    }
+    __syncthreads();
+    // per cell: six components -> three invariants (or the contraction); two neighbouring cells per thread
+    for (int c = 2 * tidj; c < n; c += 2 * nthr) {
+      F2 h[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) h[k] = *reinterpret_cast<const F2 *>(reinterpret_cast<const F *>(lds + k * LPL) + c);
+      const double da[6] = {(double)h[0].x, (double)h[1].x, (double)h[2].x, (double)h[3].x, (double)h[4].x, (double)h[5].x},
+                   db[6] = {(double)h[0].y, (double)h[1].y, (double)h[2].y, (double)h[3].y, (double)h[4].y, (double)h[5].y};
+      const long long a = row * p.out_pitch + c;
+      if (MODE == 0) {
+        double a1, a2, a3, b1, b2, b3;
+        pf_invariants(da, a1, a2, a3);
+        pf_invariants(db, b1, b2, b3);
+        if (pf_invariants_lose_diagonal(da, a1, a2) || pf_invariants_lose_diagonal(db, b1, b2)) *p.flag = 1.0;  // (as k_c2r_invariants: the sweep is repeated)
+        const long long ao = IN_PLACE ? a : row * p.inv_pitch + c;
+        typedef double pf_d2 __attribute__((ext_vector_type(2)));
+        pf_d2 w1, w2, w3;
+        w1.x = a1; w1.y = b1; w2.x = a2; w2.y = b2; w3.x = a3; w3.y = b3;
+        __builtin_nontemporal_store(w1, reinterpret_cast<pf_d2 *>(o1 + ao));
+        __builtin_nontemporal_store(w2, reinterpret_cast<pf_d2 *>(o2 + ao));
+        __builtin_nontemporal_store(w3, reinterpret_cast<pf_d2 *>(o3 + ao));
+      } else {
+        double ha[6], hb[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          const F2 g = *reinterpret_cast<const F2 *>(reinterpret_cast<const F *>(p.job[k].out) + a);
+          ha[k] = (double)g.x; hb[k] = (double)g.y;
+        }
+        F2 *acc = reinterpret_cast<F2 *>(reinterpret_cast<F *>(p.acc) + a);
+        const F2 s = *acc;
+        F2 r;
+        r.x = (F)pf_lpt3b_accumulate((double)s.x, da, ha);
+        r.y = (F)pf_lpt3b_accumulate((double)s.y, db, hb);
+        *acc = r;
+      }
+    }
+    __syncthreads();  // the lines are rewritten by the next row
+  }
+}
+
 // --------------------------------------------------------------------------------------------------------- launch ----
+// sizes with a compile-time plan (the stage lists are what pf_mixed_plan returns for them -- checked at the launch)
+#ifndef PF_MIXED_CT
+#define PF_MIXED_CT 1
+#endif
+using PF_PLAN_768 = PfPlanCT<8, 8, 4, 3>;  // strided passes of a 768 grid
+using PF_PLAN_384 = PfPlanCT<8, 8, 2, 3>;  // its z-pass: half-length lines
+using PF_PLAN_200 = PfPlanCT<8, 5, 5>;     // the example parameter file's grid
+using PF_PLAN_100 = PfPlanCT<4, 5, 5>;
+template <typename PLAN> static bool pf_plan_matches(const PfMixedPlan &pl) {
+  if (pl.n != PLAN::n || pl.nstages != PLAN::nstages) return false;
+  for (int s = 0; s < PLAN::nstages; s++) if (pl.radix[s] != PLAN::radix[s]) return false;
+  return true;
+}
 // radices of a line of n points: first R0 (8, or 4 where allowed), then 8s, a 4 or a 2, 5s and 3s.  false: n has another
 // prime factor (or no admissible first radix) -- the caller keeps the library-transform path for such sizes.
 bool pf_mixed_plan(int n, bool allow4, PfMixedPlan *pl) {
@@ -361,6 +545,7 @@ template <typename F> static int pf_mixed_raise_lds(const void *fn, size_t shm) 
 int pf_launch_mixed_strided(int fb, int n, int dir, const PfStridedParams &p, hipStream_t st) {
   PfMixedPlan pl;
   if (!pf_mixed_plan(n, false, &pl)) return 2;
+  if ((n == 768 && !pf_plan_matches<PF_PLAN_768>(pl)) || (n == 200 && !pf_plan_matches<PF_PLAN_200>(pl))) return 2;
   const int nt = n / 8;
   const int w = fb == 8 ? 16 : 8;  // bytes of a complex element
   int T = 128 / w;                 // whole 128-byte row segments where LDS and the thread budget allow
@@ -374,52 +559,108 @@ int pf_launch_mixed_strided(int fb, int n, int dir, const PfStridedParams &p, hi
   pl.magic_out = (unsigned)((0x100000000ull + (unsigned)p.aout.el_len - 1) / (unsigned)p.aout.el_len);
   const dim3 grid((unsigned)(((nwork + 7) >> 3) << 3)), block(T, nt);
   const size_t shm = (size_t)n * T * w;
+#define PF_MIXED_LAUNCH_P(FF, DD, PP)                                                                                \
+  do {                                                                                                               \
+    if (pf_mixed_raise_lds<FF>(reinterpret_cast<const void *>(&k_mixed_strided<FF, DD, PP>), shm)) return 3;         \
+    hipLaunchKernelGGL((k_mixed_strided<FF, DD, PP>), grid, block, shm, st, p, pl, nwork, ntiles);                \
+  } while (0)
 #define PF_MIXED_LAUNCH(FF, DD)                                                                                      \
   do {                                                                                                               \
-    if (pf_mixed_raise_lds<FF>(reinterpret_cast<const void *>(&k_mixed_strided<FF, DD>), shm)) return 3;             \
-    hipLaunchKernelGGL((k_mixed_strided<FF, DD>), grid, block, shm, st, p, pl, nwork, ntiles);                    \
+    if (PF_MIXED_CT && n == 768) PF_MIXED_LAUNCH_P(FF, DD, PF_PLAN_768);                                             \
+    else if (PF_MIXED_CT && n == 200) PF_MIXED_LAUNCH_P(FF, DD, PF_PLAN_200);                                        \
+    else PF_MIXED_LAUNCH_P(FF, DD, PfPlanRT);                                                                        \
   } while (0)
   if (fb == 8) { if (dir > 0) PF_MIXED_LAUNCH(double, +1); else PF_MIXED_LAUNCH(double, -1); }
   else { if (dir > 0) PF_MIXED_LAUNCH(float, +1); else PF_MIXED_LAUNCH(float, -1); }
 #undef PF_MIXED_LAUNCH
+#undef PF_MIXED_LAUNCH_P
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
+static int pf_mixed_line_slots(int M, int r0) { return (PF_MIXED_PAD ? M + (M >> (r0 == 8 ? 3 : 2)) : M) + 1; }  // (PFP(M) + 1)
 static int pf_mixed_rows_per_wg(int nt) { int tl = 256 / nt; return tl < 1 ? 1 : tl; }  // (z-pass workgroups: at most 256 threads)
 int pf_launch_mixed_c2r(int fb, int n, const PfC2RParams &p, hipStream_t st) {
   PfMixedPlan pl;
   const int M = n / 2;
   if (!pf_mixed_plan(M, true, &pl)) return 2;
+  if ((M == 384 && !pf_plan_matches<PF_PLAN_384>(pl)) || (M == 100 && !pf_plan_matches<PF_PLAN_100>(pl))) return 2;
   const int r0 = pl.radix[0], nt = M / r0, TL = pf_mixed_rows_per_wg(nt);
   if (TL * nt > 256) return 2;
   const long long nblk = (p.nlines + TL - 1) / TL;
   const dim3 grid((unsigned)(nblk * p.njobs)), block(nt, TL);
-  const size_t shm = (size_t)TL * (M + 1) * (fb == 8 ? 16 : 8);
-#define PF_MIXED_LAUNCH(FF, RR)                                                                                      \
+  const size_t shm = (size_t)TL * pf_mixed_line_slots(M, r0) * (fb == 8 ? 16 : 8);
+#define PF_MIXED_LAUNCH_P(FF, RR, PP)                                                                                \
   do {                                                                                                               \
-    if (pf_mixed_raise_lds<FF>(reinterpret_cast<const void *>(&k_mixed_c2r<FF, RR>), shm)) return 3;                 \
-    hipLaunchKernelGGL((k_mixed_c2r<FF, RR>), grid, block, shm, st, p, pl);                                      \
+    if (pf_mixed_raise_lds<FF>(reinterpret_cast<const void *>(&k_mixed_c2r<FF, RR, PP>), shm)) return 3;             \
+    hipLaunchKernelGGL((k_mixed_c2r<FF, RR, PP>), grid, block, shm, st, p, pl);                                  \
   } while (0)
-  if (fb == 8) { if (r0 == 8) PF_MIXED_LAUNCH(double, 8); else PF_MIXED_LAUNCH(double, 4); }
-  else { if (r0 == 8) PF_MIXED_LAUNCH(float, 8); else PF_MIXED_LAUNCH(float, 4); }
-#undef PF_MIXED_LAUNCH
+  if (PF_MIXED_CT && M == 384) { if (fb == 8) PF_MIXED_LAUNCH_P(double, 8, PF_PLAN_384); else PF_MIXED_LAUNCH_P(float, 8, PF_PLAN_384); }
+  else if (PF_MIXED_CT && M == 100) { if (fb == 8) PF_MIXED_LAUNCH_P(double, 4, PF_PLAN_100); else PF_MIXED_LAUNCH_P(float, 4, PF_PLAN_100); }
+  else if (fb == 8) { if (r0 == 8) PF_MIXED_LAUNCH_P(double, 8, PfPlanRT); else PF_MIXED_LAUNCH_P(double, 4, PfPlanRT); }
+  else { if (r0 == 8) PF_MIXED_LAUNCH_P(float, 8, PfPlanRT); else PF_MIXED_LAUNCH_P(float, 4, PfPlanRT); }
+#undef PF_MIXED_LAUNCH_P
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 int pf_launch_mixed_r2c(int fb, int n, const PfR2CParams &p, hipStream_t st) {
   PfMixedPlan pl;
   const int M = n / 2;
   if (!pf_mixed_plan(M, true, &pl)) return 2;
+  if ((M == 384 && !pf_plan_matches<PF_PLAN_384>(pl)) || (M == 100 && !pf_plan_matches<PF_PLAN_100>(pl))) return 2;
   const int r0 = pl.radix[0], nt = M / r0, TL = pf_mixed_rows_per_wg(nt);
   if (TL * nt > 256) return 2;
   const long long nblk = (p.nlines + TL - 1) / TL;
   const dim3 grid((unsigned)nblk), block(nt, TL);
-  const size_t shm = (size_t)TL * (M + 1) * (fb == 8 ? 16 : 8);
-#define PF_MIXED_LAUNCH(FF, RR)                                                                                      \
+  const size_t shm = (size_t)TL * pf_mixed_line_slots(M, r0) * (fb == 8 ? 16 : 8);
+#define PF_MIXED_LAUNCH_P(FF, RR, PP)                                                                                \
   do {                                                                                                               \
-    if (pf_mixed_raise_lds<FF>(reinterpret_cast<const void *>(&k_mixed_r2c<FF, RR>), shm)) return 3;                 \
-    hipLaunchKernelGGL((k_mixed_r2c<FF, RR>), grid, block, shm, st, p, pl);                          \
+    if (pf_mixed_raise_lds<FF>(reinterpret_cast<const void *>(&k_mixed_r2c<FF, RR, PP>), shm)) return 3;             \
+    hipLaunchKernelGGL((k_mixed_r2c<FF, RR, PP>), grid, block, shm, st, p, pl);                                  \
   } while (0)
-  if (fb == 8) { if (r0 == 8) PF_MIXED_LAUNCH(double, 8); else PF_MIXED_LAUNCH(double, 4); }
-  else { if (r0 == 8) PF_MIXED_LAUNCH(float, 8); else PF_MIXED_LAUNCH(float, 4); }
+  if (PF_MIXED_CT && M == 384) { if (fb == 8) PF_MIXED_LAUNCH_P(double, 8, PF_PLAN_384); else PF_MIXED_LAUNCH_P(float, 8, PF_PLAN_384); }
+  else if (PF_MIXED_CT && M == 100) { if (fb == 8) PF_MIXED_LAUNCH_P(double, 4, PF_PLAN_100); else PF_MIXED_LAUNCH_P(float, 4, PF_PLAN_100); }
+  else if (fb == 8) { if (r0 == 8) PF_MIXED_LAUNCH_P(double, 8, PfPlanRT); else PF_MIXED_LAUNCH_P(double, 4, PfPlanRT); }
+  else { if (r0 == 8) PF_MIXED_LAUNCH_P(float, 8, PfPlanRT); else PF_MIXED_LAUNCH_P(float, 4, PfPlanRT); }
+#undef PF_MIXED_LAUNCH_P
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// the invariant z-pass: six lines of n / 2 + 1 complex in LDS, six times (n / 2) / R0 threads
+bool pf_mixed_invariants_supported(int fb, int n) {
+  PfMixedPlan pl;
+  if (!pf_mixed_supported(n) || !pf_mixed_plan(n / 2, true, &pl)) return false;
+  const int nt = (n / 2) / pl.radix[0];
+  return 6 * nt <= 1024 && (size_t)6 * (n / 2 + 1) * (fb == 8 ? 16 : 8) <= 128 * 1024;
+}
+int pf_launch_mixed_c2r_invariants(int fb, int n, const PfC2RParams &p, hipStream_t st, int mode) {
+  if (!pf_mixed_invariants_supported(fb, n)) return 2;
+  PfMixedPlan pl;
+  const int M = n / 2;
+  if (!pf_mixed_plan(M, true, &pl)) return 2;
+  if ((M == 384 && !pf_plan_matches<PF_PLAN_384>(pl)) || (M == 100 && !pf_plan_matches<PF_PLAN_100>(pl))) return 2;
+  const int r0 = pl.radix[0], nt = M / r0;
+  const size_t shm = (size_t)6 * (M + 1) * (fb == 8 ? 16 : 8);
+  int per_cu = (int)((160 * 1024) / (shm + 512));
+  const int by_threads = 2048 / (6 * nt);
+  if (per_cu > by_threads) per_cu = by_threads;
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 8) per_cu = 8;
+  long long g = (long long)(p.ncu > 0 ? p.ncu : 256) * per_cu;
+  if (g > p.nlines) g = p.nlines;
+  const dim3 grid((unsigned)g), block(nt, 6);
+#define PF_MIXED_LAUNCH_P(FF, RR, PP, MM)                                                                            \
+  do {                                                                                                               \
+    if (pf_mixed_raise_lds<FF>(reinterpret_cast<const void *>(&k_mixed_c2r_invariants<FF, RR, PP, MM>), shm)) return 3; \
+    hipLaunchKernelGGL((k_mixed_c2r_invariants<FF, RR, PP, MM>), grid, block, shm, st, p, pl);                    \
+  } while (0)
+#define PF_MIXED_LAUNCH(FF, MM)                                                                                      \
+  do {                                                                                                               \
+    if (PF_MIXED_CT && M == 384) PF_MIXED_LAUNCH_P(FF, 8, PF_PLAN_384, MM);                                          \
+    else if (PF_MIXED_CT && M == 100) PF_MIXED_LAUNCH_P(FF, 4, PF_PLAN_100, MM);                                     \
+    else if (r0 == 8) PF_MIXED_LAUNCH_P(FF, 8, PfPlanRT, MM);                                                        \
+    else PF_MIXED_LAUNCH_P(FF, 4, PfPlanRT, MM);                                                                     \
+  } while (0)
+  if (fb == 8) { if (mode == 0) PF_MIXED_LAUNCH(double, 0); else PF_MIXED_LAUNCH(double, 1); }
+  else { if (mode == 0) PF_MIXED_LAUNCH(float, 0); else PF_MIXED_LAUNCH(float, 1); }
 #undef PF_MIXED_LAUNCH
+#undef PF_MIXED_LAUNCH_P
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }

@@ -36,6 +36,7 @@ pmc write WRITE_SIZE
 pmc valu SQ_INSTS_VALU SQ_WAVES
 pmc busy SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES
 pmc clk GRBM_GUI_ACTIVE
+[ -n "$PF_COLLECT_LDS" ] && pmc lds SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES
 unset PF_SOLVE_BESIDE_Z
 cd $R
 python3 profiles/tools/summarise.py $tag

@@ -107,7 +107,7 @@ def main():
                        "engine clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel time of the same run",
             "kernel_source_sha": sha, "config": dict({"grid": N, "field_bytes": FB}, **({"slab_of": SLAB_OF} if SLAB_OF > 1 else {})), "kernels": {}}
     for k, (v, nv) in va.items():
-        if "collapse" not in k and "invariants" not in k and "strided" not in k:
+        if not any(w in k for w in ("collapse", "invariants", "strided", "mixed", "c2r", "r2c")):
             continue
         insts = v.get("SQ_INSTS_VALU", 0.0) / nv
         if insts < 1e6:
@@ -123,6 +123,12 @@ def main():
         if k in bu and bu[k][0].get("SQ_BUSY_CYCLES"):
             ent["active_valu_over_busy_cycles"] = bu[k][0]["SQ_ACTIVE_INST_VALU"] / bu[k][0]["SQ_BUSY_CYCLES"]
         valu["kernels"][k] = ent
+    # (optional pass, PF_COLLECT_LDS=1 in collect.sh: LDS instruction cycles and bank-conflict cycles against the busy cycles of the same run)
+    ld, _ = counters("lds", ("SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_LDS", "SQ_BUSY_CYCLES"))
+    for k, (v, nv) in ld.items():
+        if k in valu["kernels"] and v.get("SQ_BUSY_CYCLES"):
+            valu["kernels"][k]["active_lds_over_busy_cycles"] = v.get("SQ_ACTIVE_INST_LDS", 0.0) / v["SQ_BUSY_CYCLES"]
+            valu["kernels"][k]["lds_bank_conflict_over_busy_cycles"] = v.get("SQ_LDS_BANK_CONFLICT", 0.0) / v["SQ_BUSY_CYCLES"]
     json.dump(valu, open(os.path.join(GO, f"{tag}_pmc_valu.json"), "w"), indent=1)
     print(json.dumps({"traffic": traffic["kernels"], "valu": valu["kernels"]}, indent=1)[:6000])
 

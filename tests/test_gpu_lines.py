@@ -132,7 +132,7 @@ def test_zpass_r2c_lines(L, n, fb):
     assert np.max(np.abs(got - want)) <= tol(fb, n) * np.max(np.abs(want)), (n, fb)
 
 
-@pytest.mark.parametrize("n", [16, 64, 256, 512, 1024, 2048])      # (512, 1024, 2048: the forms with waves that only reduce)
+@pytest.mark.parametrize("n", [16, 64, 256, 512, 1024, 2048, 24, 200, 768, 1000, 2000])      # (512, 1024, 2048: the forms with waves that only reduce; 24 ...: k_mixed_c2r_invariants)
 def test_invariant_zpass_lines_fp32_fields(L, n):
     """the same pass on fp32 fields (BASELINE config 5's arithmetic; rows of up to 2048 points fit): transforms in fp32, the
     reduction in fp64 from the fp32 components, fp64 invariants out"""
@@ -152,7 +152,7 @@ def test_invariant_zpass_lines_fp32_fields(L, n):
         assert np.max(np.abs(gi - wi)) <= 8 * tol(4, n) * amp ** p, (n, p)
 
 
-@pytest.mark.parametrize("n", [16, 64, 256, 512, 1024])
+@pytest.mark.parametrize("n", [16, 64, 256, 512, 1024, 24, 40, 200, 768, 1000, 1536, 2000])   # (24 ...: k_mixed_c2r_invariants)
 def test_invariant_zpass_lines(L, n):
     """six rows in, the three invariants of each cell's tensor out (what the solve of every radius but the last reads)"""
     rng = np.random.default_rng(11 * n)
@@ -231,10 +231,11 @@ def test_chirp_z_transforms_of_the_general_path(L, n):
     assert np.max(np.abs(back - want)) <= 2e-14 * np.max(np.abs(want))
 
 
-@pytest.mark.parametrize("n,fb", [(2048, 4), (1024, 4), (1024, 8), (2048, 8), (256, 4)])
+@pytest.mark.parametrize("n,fb", [(2048, 4), (1024, 4), (1024, 8), (2048, 8), (256, 4), (768, 8), (768, 4), (200, 8), (200, 4), (120, 8)])
 def test_strided_launch_with_several_jobs_per_tile(L, n, fb):
     """one launch, six jobs on three inputs as the y-pass of the sweep issues them (A2 -> 1, A1 -> 2, A0 -> 3 outputs with their
-    k factors): tiles kept in registers over their jobs (k_strided, k_strided_pk8) or read again by one workgroup per job (k_strided16)"""
+    k factors): tiles kept in registers over their jobs (k_strided, k_strided_pk8, k_mixed_strided with a compile-time plan) or
+    read again per job (k_strided16, k_mixed_strided with a run-time plan)"""
     rng = np.random.default_rng(7 * n + fb)
     nouter, ncols, nin = 2, 37, 3
     x = rng.standard_normal((nin, nouter, n, ncols)) + 1j * rng.standard_normal((nin, nouter, n, ncols))

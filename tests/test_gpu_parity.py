@@ -397,7 +397,7 @@ def test_properties_on_the_box_of_the_metric(api):
         assert f.sweep(radii[1:]) == pytest.approx(4.0 * tv[1:], rel=1e-12)
 
 
-@pytest.mark.parametrize("n", [16, 64, 256])
+@pytest.mark.parametrize("n", [16, 64, 256, 24, 40, 200])   # (24, 40, 200: k_mixed_c2r_invariants)
 def test_invariant_zpass_equals_six_component_path_fp32_fields(api, n, monkeypatch):
     """the same with fp32 fields: the invariants are formed in fp64 from the fp32 components the transforms produce, exactly
     as the six-component solve forms them, and kept as fp64 rows of their own; the 3LPT(b) contraction inside the z-pass
@@ -425,7 +425,7 @@ def test_invariant_zpass_equals_six_component_path_fp32_fields(api, n, monkeypat
     assert np.array_equal(out["0"][2], out["1"][2])
 
 
-@pytest.mark.parametrize("n", [16, 64, 128, 256])
+@pytest.mark.parametrize("n", [16, 64, 128, 256, 24, 96, 200])   # (24, 96, 200: k_mixed_c2r_invariants)
 def test_invariant_zpass_equals_six_component_path(api, n, monkeypatch):
     """Default sweep: for every radius but the last the z-pass stores the three invariants of the tensor (k_c2r_invariants)
     and the solve starts from them; PF_INVARIANTS=0 keeps six components throughout.  The component values and the
