@@ -59,9 +59,35 @@ def alg_bytes_per_cell(ns: int, w: int, lpt: bool) -> float:
     return ns * (49 * w + 16) + ((207 * w + 48) if lpt else 0)
 
 
-# grid sizes whose stage plans csrc/pf_mixed_kernels.hip knows at compile time: (strided passes, z-passes on n / 2)
-# (spelled as rocprofv3 prints a nested template argument: with a blank before the closing bracket of the outer list)
-MIXED_CT_PLANS = {768: ("PfPlanCT<8, 8, 4, 3> ", "PfPlanCT<8, 8, 2, 3> "), 200: ("PfPlanCT<8, 5, 5> ", "PfPlanCT<4, 5, 5> ")}
+# grid sizes whose stage plans csrc/pf_mixed_kernels.hip compiles in (PF_MIXED_CT_SIZES there; tests/test_bench_report.py holds the two
+# lists against each other), and the rule that makes a plan (pf_radices): first radix 8 (or 4 for the half-length lines of the z-pass
+# where 8 does not divide), then 8s, a 4 or a 2, 5s and 3s
+MIXED_CT_SIZES = (200, 384, 400, 640, 768, 800, 1000, 1280, 1536, 1600, 2000)
+
+
+def mixed_radices(n: int, allow4: bool):
+    r0 = 8 if n % 8 == 0 else (4 if allow4 and n % 4 == 0 else 0)
+    if not r0:
+        return None
+    rest, r = n // r0, [r0]
+    while rest % 8 == 0:
+        r.append(8); rest //= 8
+    if rest % 4 == 0:
+        r.append(4); rest //= 4
+    if rest % 2 == 0:
+        r.append(2); rest //= 2
+    while rest % 5 == 0:
+        r.append(5); rest //= 5
+    while rest % 3 == 0:
+        r.append(3); rest //= 3
+    return r if rest == 1 else None
+
+
+def mixed_plan_names(n: int):
+    """(strided plan, z-pass plan) as the template argument rocprofv3 prints"""
+    if n not in MIXED_CT_SIZES:
+        return "PfPlanRT", "PfPlanRT"
+    return tuple("PfPlanCT<%s>" % ", ".join(str(x) for x in mixed_radices(m, a4)) for m, a4 in ((n, False), (n // 2, True)))
 
 
 def symbol_of(cls: str, n: int, fb: int, fast: bool = True) -> str:
@@ -77,17 +103,18 @@ def symbol_of(cls: str, n: int, fb: int, fast: bool = True) -> str:
     b = "true" if fast else "false"
     if n & (n - 1):   # not a power of two: the stage plans of csrc/pf_mixed_kernels.hip (compile-time for the sizes it names, else run-time)
         r0 = 8 if (n // 2) % 8 == 0 else 4
-        ps, pz = MIXED_CT_PLANS.get(n, ("PfPlanRT", "PfPlanRT"))
+        ps, pz = mixed_plan_names(n)
+        e = " " if n in MIXED_CT_SIZES else ""   # (a nested template argument list closes with a blank in rocprofv3's spelling)
         if cls in ("xpass_hess_1to3", "ypass_hess_3to6", "xpass_disp_1to2", "ypass_disp_2to3", "xpass_plain", "ypass_plain"):
-            return f"k_mixed_strided<{F}, 1, {ps}>"
+            return f"k_mixed_strided<{F}, 1, {ps}{e}>"
         if cls in ("xpass_fwd", "ypass_fwd"):
-            return f"k_mixed_strided<{F}, -1, {ps}>"
+            return f"k_mixed_strided<{F}, -1, {ps}{e}>"
         if cls in ("zpass_c2r_hess_6", "zpass_c2r_disp_3", "zpass_c2r_plain"):
-            return f"k_mixed_c2r<{F}, {r0}, {pz}>"
+            return f"k_mixed_c2r<{F}, {r0}, {pz}{e}>"
         if cls == "zpass_r2c":
-            return f"k_mixed_r2c<{F}, {r0}, {pz}>"
+            return f"k_mixed_r2c<{F}, {r0}, {pz}{e}>"
         if cls in ("zpass_c2r_hess_6to3inv", "zpass_c2r_hess_6_lpt3b"):
-            return f"k_mixed_c2r_invariants<{F}, {r0}, {pz.strip()}, {0 if cls.endswith('inv') else 1}, false>"
+            return f"k_mixed_c2r_invariants<{F}, {r0}, {pz}, {0 if cls.endswith('inv') else 1}>"
     # fp32 lines of 1024 / 2048 points: the kernels in packed (re, im) arithmetic (csrc/pf_fft16_kernels.hip), one instantiation per
     # (direction, first-pass filter, band limit) -- a launch class runs several of them (pruned and unpruned radii): the family is named
     if fb == 4 and n in (1024, 2048) and cls in ("xpass_hess_1to3", "ypass_hess_3to6", "xpass_disp_1to2", "ypass_disp_2to3", "xpass_plain", "ypass_plain", "xpass_fwd", "ypass_fwd"):

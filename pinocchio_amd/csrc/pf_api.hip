@@ -260,8 +260,8 @@ static void read_tuning(PfTuning *t) {
   if (t->zpass_inv_wg_per_cu <= 0) t->zpass_inv_wg_per_cu = 32;
   t->spline_lut = env_int("PF_SPLINE_LUT", 1) != 0;
   t->exchange_rows = env_int("PF_EXCHANGE_ROWS", 1) != 0;
-  t->invariants = env_int("PF_INVARIANTS", 1) != 0;
-  t->lpt_fuse = env_int("PF_LPT_FUSE", 1) != 0;
+  t->invariants = env_int("PF_INVARIANTS", 1);
+  t->lpt_fuse = env_int("PF_LPT_FUSE", 1);
   t->collapse_wg_per_cu = env_int("PF_COLLAPSE_WG_PER_CU", 8);
   if (t->collapse_wg_per_cu <= 0) t->collapse_wg_per_cu = 8;
   t->general = env_int("PF_GENERAL", 0) != 0;
@@ -1329,7 +1329,7 @@ static int sweep_body_run(pf_ctx *c, int ns, const double *radius_cells, double 
   c->sources_fresh = false;
   // (n <= 1024: the six-line workgroup of a 2048-point row would need 110 KB of dynamic LDS, a size this build never launches)
   // (n <= 1024 with fp64 fields, n <= 2048 with fp32 ones: the six lines of a row must fit the LDS of a workgroup)
-  const bool invariants_ok = pf_c2r_invariants_preferred(c->fb, (int)c->n) && !c->general && c->tab_ns == 0 && c->model == 0 && c->tune.invariants && !six_components;
+  const bool invariants_ok = (c->tune.invariants >= 2 ? pf_c2r_invariants_supported(c->fb, (int)c->n) : pf_c2r_invariants_preferred(c->fb, (int)c->n)) && !c->general && c->tab_ns == 0 && c->model == 0 && c->tune.invariants && !six_components;
   HIPCHK(c, hipMemsetAsync(c->scal + SC_INV_FLAG, 0, sizeof(double), c->stream));
   const bool rep = c->replicate;
   if (rep) PFCHK(c, ensure_dk_full(c));
@@ -1520,7 +1520,7 @@ extern "C" int pf_displacements(pf_ctx *c, int compute_sources, int recompute_sd
       // Hessian of the 2LPT potential contracted with the first-order one into the 3LPT(b) source (src/LPT.c:112-137).  fp64
       // fields: the z-pass does the contraction while it holds a row's six components (nothing of that Hessian is stored;
       // PF_LPT_FUSE=0: six fields out, then k_lpt_accum); same operations per cell either way
-      const bool fuse3b = pf_c2r_invariants_preferred(c->fb, (int)c->n) && !c->general && c->tune.lpt_fuse;
+      const bool fuse3b = (c->tune.lpt_fuse >= 2 ? pf_c2r_invariants_supported(c->fb, (int)c->n) : pf_c2r_invariants_preferred(c->fb, (int)c->n)) && !c->general && c->tune.lpt_fuse;
       if (c->lpt_order < 3) {  // no THREE_LPT (src/LPT.c:78-92, 113-175): the 2LPT source alone
       } else if (fuse3b) {
         PFCHK(c, hessian_of(c, c->S[0], 0.0, c->scal + SC_DC_S2, c->B2, c->S[2], c->B));

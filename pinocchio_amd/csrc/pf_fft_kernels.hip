@@ -867,8 +867,10 @@ bool pf_c2r_invariants_supported(int fb, int n) {
 // ... and the sweep takes it: always where the line length is a power of two; for the other sizes with fp64 fields only -- three fp64
 // invariants are as many bytes as six fp32 components, and the six-component z-pass of those sizes is the faster kernel
 // (768^3, fp32 fields: 273 ms per step with six components, 288 with invariants; profiles/r05_notes.md)
+// -- and with a stage plan compiled in: with a run-time plan the six lines of a row in one workgroup are the slower way again
+// (768^3, fp64, run-time plans: 23.2 ms per launch against 11.5 + 8.0 for six components and their reduction in the solve).
 bool pf_c2r_invariants_preferred(int fb, int n) {
-  return pf_c2r_invariants_supported(fb, n) && (!(n & (n - 1)) || fb == 8);
+  return pf_c2r_invariants_supported(fb, n) && (!(n & (n - 1)) || (fb == 8 && pf_mixed_plan_compiled_in(n)));
 }
 int pf_launch_c2r_invariants(int fb, int n, const PfC2RParams &p, hipStream_t st, int mode) {
   if (p.njobs != 6 || (mode == 1 && !p.acc) || (mode == 0 && !p.flag) || !pf_c2r_invariants_supported(fb, n)) return 2;

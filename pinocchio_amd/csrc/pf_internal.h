@@ -15,7 +15,8 @@ struct PfTuning {
   int zpass_persist;        // PF_ZPASS_PERSIST: workgroups per CU of the persistent z-pass, 0 = one-shot workgroups
   int zpass_inv_wg_per_cu;  // PF_ZPASS_INV_WG_PER_CU
   int collapse_wg_per_cu;   // PF_COLLAPSE_WG_PER_CU
-  bool spline_lut, exchange_rows, invariants, lpt_fuse, general, pipeline, exact_libm;
+  bool spline_lut, exchange_rows, general, pipeline, exact_libm;
+  int invariants, lpt_fuse;  // PF_INVARIANTS / PF_LPT_FUSE: 0 off, 1 where the invariant z-pass is the faster way (pf_c2r_invariants_preferred), 2 wherever it exists
   int replicate;  // PF_REPLICATE_DK: -1 by rank count, 0 off, 1 on
   double prune_eps;
   int debug_fault;          // PF_DEBUG_PIPELINE_FAULT (tests only): 1 / 2 = one wait of the exchange pipeline left out
@@ -121,6 +122,7 @@ int pf_launch_mixed_r2c(int field_bytes, int n, const PfR2CParams &p, hipStream_
 bool pf_mixed_invariants_supported(int field_bytes, int n);  // six lines of a row fit one workgroup
 int pf_launch_mixed_c2r_invariants(int field_bytes, int n, const PfC2RParams &p, hipStream_t st, int mode);
 bool pf_c2r_invariants_preferred(int field_bytes, int n);   // ... and the sweep uses it (pf_fft_kernels.hip)
+bool pf_mixed_plan_compiled_in(int n);                       // n is one of PF_MIXED_CT_SIZES (pf_mixed_kernels.hip)
 bool pf_c2r_invariants_supported(int field_bytes, int n);    // pf_launch_c2r_invariants takes rows of n points (either kind of plan)
 
 // ---- per-cell kernels (pf_cell_kernels.hip) ----

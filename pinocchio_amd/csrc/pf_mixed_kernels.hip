@@ -16,6 +16,7 @@
 // What these kernels do not have: tile prefetch, the paired radix-16 stage, two columns per thread, the invariant z-pass
 // (six components per cell are stored), workgroups that walk over rows.  One rank.
 #include <cstring>
+#include <utility>
 
 #include "pf_internal.h"
 #include "pf_fft_core.h"
@@ -496,40 +497,36 @@ __global__ void __launch_bounds__(PLAN::n ? 6 * (PLAN::n / R0) : (R0 == 8 ? 768 
 }
 
 // --------------------------------------------------------------------------------------------------------- launch ----
-// sizes with a compile-time plan (the stage lists are what pf_mixed_plan returns for them -- checked at the launch)
-#ifndef PF_MIXED_CT
-#define PF_MIXED_CT 1
-#endif
-using PF_PLAN_768 = PfPlanCT<8, 8, 4, 3>;  // strided passes of a 768 grid
-using PF_PLAN_384 = PfPlanCT<8, 8, 2, 3>;  // its z-pass: half-length lines
-using PF_PLAN_200 = PfPlanCT<8, 5, 5>;     // the example parameter file's grid
-using PF_PLAN_100 = PfPlanCT<4, 5, 5>;
-template <typename PLAN> static bool pf_plan_matches(const PfMixedPlan &pl) {
-  if (pl.n != PLAN::n || pl.nstages != PLAN::nstages) return false;
-  for (int s = 0; s < PLAN::nstages; s++) if (pl.radix[s] != PLAN::radix[s]) return false;
-  return true;
+// radices of a line of n points: first R0 (8, or 4 where allowed), then 8s, a 4 or a 2, 5s and 3s.  ok = false: n has another
+// prime factor (or no admissible first radix) -- the caller keeps the chirp-z path for such sizes.  One rule, evaluated at run time
+// (pf_mixed_plan) and at compile time (PfPlanOf: the sizes of PF_MIXED_CT_SIZES get kernels with the plan built in).
+struct PfRadices { bool ok; int n, ns; int r[PF_MIXED_MAX_STAGES]; };
+constexpr PfRadices pf_radices(int n, bool allow4) {
+  PfRadices p{};
+  p.n = n;
+  const int r0 = (n % 8 == 0) ? 8 : ((allow4 && n % 4 == 0) ? 4 : 0);
+  if (!r0 || n < r0) return p;
+  int rest = n / r0;
+  p.r[p.ns++] = r0;
+  while (rest % 8 == 0) { if (p.ns >= PF_MIXED_MAX_STAGES) return p; p.r[p.ns++] = 8; rest /= 8; }
+  if (rest % 4 == 0) { if (p.ns >= PF_MIXED_MAX_STAGES) return p; p.r[p.ns++] = 4; rest /= 4; }
+  if (rest % 2 == 0) { if (p.ns >= PF_MIXED_MAX_STAGES) return p; p.r[p.ns++] = 2; rest /= 2; }
+  while (rest % 5 == 0) { if (p.ns >= PF_MIXED_MAX_STAGES) return p; p.r[p.ns++] = 5; rest /= 5; }
+  while (rest % 3 == 0) { if (p.ns >= PF_MIXED_MAX_STAGES) return p; p.r[p.ns++] = 3; rest /= 3; }
+  p.ok = rest == 1;
+  return p;
 }
-// radices of a line of n points: first R0 (8, or 4 where allowed), then 8s, a 4 or a 2, 5s and 3s.  false: n has another
-// prime factor (or no admissible first radix) -- the caller keeps the library-transform path for such sizes.
 bool pf_mixed_plan(int n, bool allow4, PfMixedPlan *pl) {
   memset(pl, 0, sizeof(*pl));
   pl->n = n;
-  int r0 = (n % 8 == 0) ? 8 : ((allow4 && n % 4 == 0) ? 4 : 0);
-  if (!r0 || n < r0) return false;
-  int rest = n / r0, ns = 0;
-  pl->radix[ns++] = r0;
-  while (rest % 8 == 0) { if (ns >= PF_MIXED_MAX_STAGES) return false; pl->radix[ns++] = 8; rest /= 8; }
-  if (rest % 4 == 0) { if (ns >= PF_MIXED_MAX_STAGES) return false; pl->radix[ns++] = 4; rest /= 4; }
-  if (rest % 2 == 0) { if (ns >= PF_MIXED_MAX_STAGES) return false; pl->radix[ns++] = 2; rest /= 2; }
-  while (rest % 5 == 0) { if (ns >= PF_MIXED_MAX_STAGES) return false; pl->radix[ns++] = 5; rest /= 5; }
-  while (rest % 3 == 0) { if (ns >= PF_MIXED_MAX_STAGES) return false; pl->radix[ns++] = 3; rest /= 3; }
-  if (rest != 1) return false;
-  if (r0 == 4) for (int s = 1; s < ns; s++) if (pl->radix[s] == 8) return false;  // (cannot happen: n / 4 odd multiple... kept as a guard)
-  pl->nstages = ns;
+  const PfRadices r = pf_radices(n, allow4);
+  if (!r.ok) return false;
+  pl->nstages = r.ns;
   unsigned long long nsv = 1;
-  for (int s = 0; s < ns; s++) {  // ceil(2^32 / NS_s): b mod NS_s by one multiply-high (pf_mixed_stage); stage 0 needs none
+  for (int s = 0; s < r.ns; s++) {  // ceil(2^32 / NS_s): b mod NS_s by one multiply-high (pf_mixed_stage); stage 0 needs none
+    pl->radix[s] = r.r[s];
     pl->magic[s] = s == 0 ? 0u : (unsigned)(((1ull << 32) + nsv - 1) / nsv);
-    nsv *= (unsigned long long)pl->radix[s];
+    nsv *= (unsigned long long)r.r[s];
   }
   return true;
 }
@@ -537,7 +534,30 @@ bool pf_mixed_supported(int n) {
   PfMixedPlan a, b;
   return n >= 8 && n <= 2048 && n % 8 == 0 && pf_mixed_plan(n, false, &a) && pf_mixed_plan(n / 2, true, &b);
 }
+// Grid sizes whose plans are compiled in: the strided passes on N points (first radix 8) and the z-passes on N / 2 (8 or 4).
+// (bench.py names the kernels of a run from the same list: MIXED_CT_SIZES there, held against this line by tests/test_bench_report.py.)
+#ifndef PF_MIXED_CT
+#define PF_MIXED_CT 1   // (0 in an A/B build: every size through the run-time plans)
+#endif
+#define PF_MIXED_CT_SIZES(X) X(200) X(384) X(400) X(640) X(768) X(800) X(1000) X(1280) X(1536) X(1600) X(2000)
+template <int N, bool A4, typename = std::make_index_sequence<(size_t)pf_radices(N, A4).ns>> struct PfPlanOf;
+template <int N, bool A4, size_t... I> struct PfPlanOf<N, A4, std::index_sequence<I...>> {
+  static_assert(pf_radices(N, A4).ok, "a size of PF_MIXED_CT_SIZES without a plan");
+  using type = PfPlanCT<pf_radices(N, A4).r[I]...>;
+};
+template <int N> using PfPlanS = typename PfPlanOf<N, false>::type;      // strided passes of an N grid
+template <int N> using PfPlanZ = typename PfPlanOf<N / 2, true>::type;   // its z-passes: half-length lines
+template <int N> constexpr bool pf_mixed_inv_fits() {  // (the six lines of a row in one workgroup: k_mixed_c2r_invariants)
+  static_assert(6 * ((N / 2) / PfPlanZ<N>::radix[0]) <= 1024, "a size of PF_MIXED_CT_SIZES whose invariant z-pass has no workgroup");
+  return true;
+}
 
+bool pf_mixed_plan_compiled_in(int n) {
+#define PF_MIXED_CASE(NN) if (n == NN) return PF_MIXED_CT != 0;
+  PF_MIXED_CT_SIZES(PF_MIXED_CASE)
+#undef PF_MIXED_CASE
+  return false;
+}
 template <typename F> static int pf_mixed_raise_lds(const void *fn, size_t shm) {
   if (shm <= 64 * 1024) return 0;
   return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess ? 0 : 3;
@@ -545,7 +565,6 @@ template <typename F> static int pf_mixed_raise_lds(const void *fn, size_t shm) 
 int pf_launch_mixed_strided(int fb, int n, int dir, const PfStridedParams &p, hipStream_t st) {
   PfMixedPlan pl;
   if (!pf_mixed_plan(n, false, &pl)) return 2;
-  if ((n == 768 && !pf_plan_matches<PF_PLAN_768>(pl)) || (n == 200 && !pf_plan_matches<PF_PLAN_200>(pl))) return 2;
   const int nt = n / 8;
   const int w = fb == 8 ? 16 : 8;  // bytes of a complex element
   int T = 128 / w;                 // whole 128-byte row segments where LDS and the thread budget allow
@@ -564,15 +583,17 @@ int pf_launch_mixed_strided(int fb, int n, int dir, const PfStridedParams &p, hi
     if (pf_mixed_raise_lds<FF>(reinterpret_cast<const void *>(&k_mixed_strided<FF, DD, PP>), shm)) return 3;         \
     hipLaunchKernelGGL((k_mixed_strided<FF, DD, PP>), grid, block, shm, st, p, pl, nwork, ntiles);                \
   } while (0)
+#define PF_MIXED_CASE(NN) if (PF_MIXED_CT && n == NN) PF_MIXED_LAUNCH_P(FF_, DD_, PfPlanS<NN>); else
 #define PF_MIXED_LAUNCH(FF, DD)                                                                                      \
   do {                                                                                                               \
-    if (PF_MIXED_CT && n == 768) PF_MIXED_LAUNCH_P(FF, DD, PF_PLAN_768);                                             \
-    else if (PF_MIXED_CT && n == 200) PF_MIXED_LAUNCH_P(FF, DD, PF_PLAN_200);                                        \
-    else PF_MIXED_LAUNCH_P(FF, DD, PfPlanRT);                                                                        \
+    using FF_ = FF;                                                                                                  \
+    constexpr int DD_ = DD;                                                                                          \
+    PF_MIXED_CT_SIZES(PF_MIXED_CASE) PF_MIXED_LAUNCH_P(FF_, DD_, PfPlanRT);                                          \
   } while (0)
   if (fb == 8) { if (dir > 0) PF_MIXED_LAUNCH(double, +1); else PF_MIXED_LAUNCH(double, -1); }
   else { if (dir > 0) PF_MIXED_LAUNCH(float, +1); else PF_MIXED_LAUNCH(float, -1); }
 #undef PF_MIXED_LAUNCH
+#undef PF_MIXED_CASE
 #undef PF_MIXED_LAUNCH_P
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
@@ -582,7 +603,6 @@ int pf_launch_mixed_c2r(int fb, int n, const PfC2RParams &p, hipStream_t st) {
   PfMixedPlan pl;
   const int M = n / 2;
   if (!pf_mixed_plan(M, true, &pl)) return 2;
-  if ((M == 384 && !pf_plan_matches<PF_PLAN_384>(pl)) || (M == 100 && !pf_plan_matches<PF_PLAN_100>(pl))) return 2;
   const int r0 = pl.radix[0], nt = M / r0, TL = pf_mixed_rows_per_wg(nt);
   if (TL * nt > 256) return 2;
   const long long nblk = (p.nlines + TL - 1) / TL;
@@ -593,9 +613,13 @@ int pf_launch_mixed_c2r(int fb, int n, const PfC2RParams &p, hipStream_t st) {
     if (pf_mixed_raise_lds<FF>(reinterpret_cast<const void *>(&k_mixed_c2r<FF, RR, PP>), shm)) return 3;             \
     hipLaunchKernelGGL((k_mixed_c2r<FF, RR, PP>), grid, block, shm, st, p, pl);                                  \
   } while (0)
-  if (PF_MIXED_CT && M == 384) { if (fb == 8) PF_MIXED_LAUNCH_P(double, 8, PF_PLAN_384); else PF_MIXED_LAUNCH_P(float, 8, PF_PLAN_384); }
-  else if (PF_MIXED_CT && M == 100) { if (fb == 8) PF_MIXED_LAUNCH_P(double, 4, PF_PLAN_100); else PF_MIXED_LAUNCH_P(float, 4, PF_PLAN_100); }
-  else if (fb == 8) { if (r0 == 8) PF_MIXED_LAUNCH_P(double, 8, PfPlanRT); else PF_MIXED_LAUNCH_P(double, 4, PfPlanRT); }
+#define PF_MIXED_CASE(NN)                                                                                            \
+  if (PF_MIXED_CT && n == NN) {                                                                                      \
+    if (fb == 8) PF_MIXED_LAUNCH_P(double, PfPlanZ<NN>::radix[0], PfPlanZ<NN>); else PF_MIXED_LAUNCH_P(float, PfPlanZ<NN>::radix[0], PfPlanZ<NN>); \
+  } else
+  PF_MIXED_CT_SIZES(PF_MIXED_CASE)
+#undef PF_MIXED_CASE
+  if (fb == 8) { if (r0 == 8) PF_MIXED_LAUNCH_P(double, 8, PfPlanRT); else PF_MIXED_LAUNCH_P(double, 4, PfPlanRT); }
   else { if (r0 == 8) PF_MIXED_LAUNCH_P(float, 8, PfPlanRT); else PF_MIXED_LAUNCH_P(float, 4, PfPlanRT); }
 #undef PF_MIXED_LAUNCH_P
   return hipGetLastError() == hipSuccess ? 0 : 1;
@@ -604,7 +628,6 @@ int pf_launch_mixed_r2c(int fb, int n, const PfR2CParams &p, hipStream_t st) {
   PfMixedPlan pl;
   const int M = n / 2;
   if (!pf_mixed_plan(M, true, &pl)) return 2;
-  if ((M == 384 && !pf_plan_matches<PF_PLAN_384>(pl)) || (M == 100 && !pf_plan_matches<PF_PLAN_100>(pl))) return 2;
   const int r0 = pl.radix[0], nt = M / r0, TL = pf_mixed_rows_per_wg(nt);
   if (TL * nt > 256) return 2;
   const long long nblk = (p.nlines + TL - 1) / TL;
@@ -615,9 +638,13 @@ int pf_launch_mixed_r2c(int fb, int n, const PfR2CParams &p, hipStream_t st) {
     if (pf_mixed_raise_lds<FF>(reinterpret_cast<const void *>(&k_mixed_r2c<FF, RR, PP>), shm)) return 3;             \
     hipLaunchKernelGGL((k_mixed_r2c<FF, RR, PP>), grid, block, shm, st, p, pl);                                  \
   } while (0)
-  if (PF_MIXED_CT && M == 384) { if (fb == 8) PF_MIXED_LAUNCH_P(double, 8, PF_PLAN_384); else PF_MIXED_LAUNCH_P(float, 8, PF_PLAN_384); }
-  else if (PF_MIXED_CT && M == 100) { if (fb == 8) PF_MIXED_LAUNCH_P(double, 4, PF_PLAN_100); else PF_MIXED_LAUNCH_P(float, 4, PF_PLAN_100); }
-  else if (fb == 8) { if (r0 == 8) PF_MIXED_LAUNCH_P(double, 8, PfPlanRT); else PF_MIXED_LAUNCH_P(double, 4, PfPlanRT); }
+#define PF_MIXED_CASE(NN)                                                                                            \
+  if (PF_MIXED_CT && n == NN) {                                                                                      \
+    if (fb == 8) PF_MIXED_LAUNCH_P(double, PfPlanZ<NN>::radix[0], PfPlanZ<NN>); else PF_MIXED_LAUNCH_P(float, PfPlanZ<NN>::radix[0], PfPlanZ<NN>); \
+  } else
+  PF_MIXED_CT_SIZES(PF_MIXED_CASE)
+#undef PF_MIXED_CASE
+  if (fb == 8) { if (r0 == 8) PF_MIXED_LAUNCH_P(double, 8, PfPlanRT); else PF_MIXED_LAUNCH_P(double, 4, PfPlanRT); }
   else { if (r0 == 8) PF_MIXED_LAUNCH_P(float, 8, PfPlanRT); else PF_MIXED_LAUNCH_P(float, 4, PfPlanRT); }
 #undef PF_MIXED_LAUNCH_P
   return hipGetLastError() == hipSuccess ? 0 : 1;
@@ -635,7 +662,6 @@ int pf_launch_mixed_c2r_invariants(int fb, int n, const PfC2RParams &p, hipStrea
   PfMixedPlan pl;
   const int M = n / 2;
   if (!pf_mixed_plan(M, true, &pl)) return 2;
-  if ((M == 384 && !pf_plan_matches<PF_PLAN_384>(pl)) || (M == 100 && !pf_plan_matches<PF_PLAN_100>(pl))) return 2;
   const int r0 = pl.radix[0], nt = M / r0;
   const size_t shm = (size_t)6 * (M + 1) * (fb == 8 ? 16 : 8);
   int per_cu = (int)((160 * 1024) / (shm + 512));
@@ -651,16 +677,19 @@ int pf_launch_mixed_c2r_invariants(int fb, int n, const PfC2RParams &p, hipStrea
     if (pf_mixed_raise_lds<FF>(reinterpret_cast<const void *>(&k_mixed_c2r_invariants<FF, RR, PP, MM>), shm)) return 3; \
     hipLaunchKernelGGL((k_mixed_c2r_invariants<FF, RR, PP, MM>), grid, block, shm, st, p, pl);                    \
   } while (0)
+#define PF_MIXED_CASE(NN) if (PF_MIXED_CT && n == NN && pf_mixed_inv_fits<NN>()) PF_MIXED_LAUNCH_P(FF_, PfPlanZ<NN>::radix[0], PfPlanZ<NN>, MM_); else
 #define PF_MIXED_LAUNCH(FF, MM)                                                                                      \
   do {                                                                                                               \
-    if (PF_MIXED_CT && M == 384) PF_MIXED_LAUNCH_P(FF, 8, PF_PLAN_384, MM);                                          \
-    else if (PF_MIXED_CT && M == 100) PF_MIXED_LAUNCH_P(FF, 4, PF_PLAN_100, MM);                                     \
-    else if (r0 == 8) PF_MIXED_LAUNCH_P(FF, 8, PfPlanRT, MM);                                                        \
-    else PF_MIXED_LAUNCH_P(FF, 4, PfPlanRT, MM);                                                                     \
+    using FF_ = FF;                                                                                                  \
+    constexpr int MM_ = MM;                                                                                          \
+    PF_MIXED_CT_SIZES(PF_MIXED_CASE)                                                                                 \
+    if (r0 == 8) PF_MIXED_LAUNCH_P(FF_, 8, PfPlanRT, MM_);                                                           \
+    else PF_MIXED_LAUNCH_P(FF_, 4, PfPlanRT, MM_);                                                                   \
   } while (0)
   if (fb == 8) { if (mode == 0) PF_MIXED_LAUNCH(double, 0); else PF_MIXED_LAUNCH(double, 1); }
   else { if (mode == 0) PF_MIXED_LAUNCH(float, 0); else PF_MIXED_LAUNCH(float, 1); }
 #undef PF_MIXED_LAUNCH
+#undef PF_MIXED_CASE
 #undef PF_MIXED_LAUNCH_P
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }

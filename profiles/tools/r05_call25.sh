@@ -1,0 +1,7 @@
+#!/bin/bash
+timeout 1200 python3 -m pytest tests/test_gpu_lines.py -x -q 2>&1 | tail -3
+timeout 1200 python3 -m pytest tests/test_gpu_parity.py -x -q -k "invariant_zpass or general or example_size_200 or grid_200" 2>&1 | tail -3
+for n in 768 200 1000 1536 640; do
+st=2; [ $n = 200 ] && st=5
+AB_ARGS="--n $n" AB_STEPS=$st bash profiles/tools/ab.sh default noct 2>&1 | tail -15
+done

@@ -7,6 +7,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
 import bench  # noqa: E402
 
 STEPS = 2
@@ -67,6 +68,26 @@ def test_fp32_symbols():
     assert bench.symbol_of("zpass_c2r_hess_6to3inv", 256, 8) == "k_c2r_invariants<double, 256, 0>"
     assert bench.symbol_of("zpass_c2r_hess_6to3inv", 512, 8) == "k_c2r_invariants_spec<double, 512, 0>"
     assert bench.symbol_of("zpass_c2r_hess_6to3inv", 1024, 8) == "k_c2r_invariants_spec<double, 1024, 0>"
+
+
+def test_mixed_plan_names_follow_the_kernel_sources():
+    """sizes that are not a power of two: bench.py names a run's kernels from the list of sizes whose stage plans
+    csrc/pf_mixed_kernels.hip compiles in, and from the rule that makes a plan -- both restated there"""
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pinocchio_amd", "csrc", "pf_mixed_kernels.hip")).read()
+    line = re.search(r"#define PF_MIXED_CT_SIZES\(X\)(.*)", src).group(1)
+    assert tuple(int(v) for v in re.findall(r"X\((\d+)\)", line)) == bench.MIXED_CT_SIZES
+    assert bench.mixed_radices(768, False) == [8, 8, 4, 3] and bench.mixed_radices(384, True) == [8, 8, 2, 3]
+    assert bench.mixed_radices(200, False) == [8, 5, 5] and bench.mixed_radices(100, True) == [4, 5, 5]
+    assert bench.mixed_radices(100, False) is None and bench.mixed_radices(56, False) is None
+    for n in bench.MIXED_CT_SIZES:
+        rs, rz = bench.mixed_radices(n, False), bench.mixed_radices(n // 2, True)
+        assert rs and rz and rs[0] == 8 and int(np.prod(rs)) == n and int(np.prod(rz)) == n // 2
+    assert bench.symbol_of("ypass_hess_3to6", 768, 8) == "k_mixed_strided<double, 1, PfPlanCT<8, 8, 4, 3> >"
+    assert bench.symbol_of("zpass_c2r_hess_6to3inv", 200, 8) == "k_mixed_c2r_invariants<double, 4, PfPlanCT<4, 5, 5>, 0>"
+    assert bench.symbol_of("zpass_c2r_disp_3", 200, 4) == "k_mixed_c2r<float, 4, PfPlanCT<4, 5, 5> >"
+    assert bench.symbol_of("zpass_r2c", 120, 8) == "k_mixed_r2c<double, 4, PfPlanRT>"
+    assert bench.symbol_of("xpass_fwd", 120, 8) == "k_mixed_strided<double, -1, PfPlanRT>"
 
 
 def test_result_fingerprint_adds_up_over_any_decomposition():

@@ -14,7 +14,7 @@ SIZES = [16, 64, 256, 1024, 2048]
 # grid sizes that are not a power of two: the run-time stage plans of csrc/pf_mixed_kernels.hip (radices 8, 5, 4, 3, 2) --
 # 24 = 8.3, 40 = 8.5, 96 = 8.4.3, 120 = 8.5.3, 200 = 8.5.5 (the reference's example size), 384 = 8.8.2.3, 768 = 8.8.4.3,
 # 1000 = 8.5.5.5, 1536 = 8.8.8.3; their z-passes run on the half lengths 12 = 4.3, 20 = 4.5, 48, 60, 100 = 4.5.5, 192, ...
-MIXED = [24, 40, 96, 120, 200, 384, 768, 1000, 1536]
+MIXED = [24, 40, 96, 120, 200, 384, 768, 1000, 1536, 400, 640, 800, 1280, 1600, 2000]   # (200, 384 ... 2000 but 24 - 120: plans compiled in)
 ALL_SIZES = SIZES + MIXED
 
 

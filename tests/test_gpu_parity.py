@@ -407,7 +407,8 @@ def test_invariant_zpass_equals_six_component_path_fp32_fields(api, n, monkeypat
     x, y = synth.invgrow_table("lcdm")
     radii = np.array([n / 16.0, n / 40.0, 1.5, 0.6, 0.0])
     out = {}
-    for mode in ("0", "1"):
+    on = "1" if n & (n - 1) == 0 else "2"   # (sizes that are not a power of two take six fp32 components by default: "2" asks for the invariants)
+    for mode in ("0", on):
         monkeypatch.setenv("PF_INVARIANTS", mode)
         monkeypatch.setenv("PF_LPT_FUSE", mode)
         with api.Fmax(n, field_bytes=4, timing=True) as f:
@@ -417,8 +418,8 @@ def test_invariant_zpass_equals_six_component_path_fp32_fields(api, n, monkeypat
             f.reset_kernel_stats()
             tv = f.compute_fmax(radii, do_lpt=True)
             classes = {k["name"] for k in f.kernel_stats()}
-            assert ("zpass_c2r_hess_6to3inv" in classes) == (mode == "1") and ("zpass_c2r_hess_6_lpt3b" in classes) == (mode == "1"), classes
-            out[mode] = (tv, f.products(), f.Fmax_PDF())
+            assert ("zpass_c2r_hess_6to3inv" in classes) == (mode != "0") and ("zpass_c2r_hess_6_lpt3b" in classes) == (mode != "0"), classes
+            out["0" if mode == "0" else "1"] = (tv, f.products(), f.Fmax_PDF())
     assert np.array_equal(out["0"][0], out["1"][0])
     for name in ("Fmax", "Rmax", "Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
         assert np.array_equal(out["0"][1][name], out["1"][1][name]), name
@@ -436,14 +437,17 @@ def test_invariant_zpass_equals_six_component_path(api, n, monkeypatch):
     x, y = synth.invgrow_table("lcdm")
     radii = np.array([n / 16.0, n / 40.0, 1.5, 0.6, 0.0])
     out = {}
-    for mode in ("0", "1"):
+    for mode in ("0", "2"):   # ("2": the invariant z-pass wherever it exists -- the run-time plans of 24 and 96 points would not take it by themselves)
         monkeypatch.setenv("PF_INVARIANTS", mode)
-        with api.Fmax(n) as f:
+        monkeypatch.setenv("PF_LPT_FUSE", mode)
+        with api.Fmax(n, timing=True) as f:
             f.set_density(dk)
             f.set_invgrow(x, y)
             f.set_growth(synth.growth_multipliers())
+            f.reset_kernel_stats()
             tv = f.compute_fmax(radii, do_lpt=True)
-            out[mode] = (tv, f.products(), f.Fmax_PDF())
+            assert ("zpass_c2r_hess_6to3inv" in {k["name"] for k in f.kernel_stats()}) == (mode != "0")
+            out["0" if mode == "0" else "1"] = (tv, f.products(), f.Fmax_PDF())
     assert np.array_equal(out["0"][0], out["1"][0])
     for name in ("Fmax", "Rmax", "Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
         assert np.array_equal(out["0"][1][name], out["1"][1][name]), name
