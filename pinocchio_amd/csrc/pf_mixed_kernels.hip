@@ -26,6 +26,9 @@
 #ifndef PF_MIXED_TW_POWERS
 #define PF_MIXED_TW_POWERS 1
 #endif
+#ifndef PF_MIXED_ZI_ONE_ROW
+#define PF_MIXED_ZI_ONE_ROW 1
+#endif
 #ifndef PF_MIXED_KEEP
 #define PF_MIXED_KEEP 1
 #endif
@@ -193,26 +196,22 @@ __device__ __forceinline__ void pf_mixed_tail_any(const PfMixedPlan &pl, int tl,
 // e % el_len (PfAddr: the blocks of a multi-rank layout; one rank: e * els) -- the quotient by multiply-high, any slab length.
 // The tile is loaded for every job (jobs on the same input find it in L2): the eight points of a thread then live only
 // through one job, which is what lets the run-time plan fit the register file.
+// Plans known at compile time (KEEP): the loaded and filtered points are held while the jobs on the same input follow each other.
+// A thread asks for its eight points in one go and filters them when they are there (asked for and filtered one by one the y-pass
+// 3 -> 6 of a 768^3 box took 6.1 instead of 5.2 ms).  Not here, measured (profiles/r05_notes.md): workgroups that walk over tiles
+// and request the next input while the jobs on the current one run -- 6.0 ms: the wait for those loads is a wait for every store
+// issued after them as well (one counter), where a workgroup that ends leaves its stores behind and the next one starts loading.
 template <typename F, int DIR, typename PLAN = PfPlanRT>
 __global__ void __launch_bounds__(1024) k_mixed_strided(const PfStridedParams p, const PfMixedPlan pl, const long long nwork, const int ntiles) {
   using C = pfc<F>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   C *lds = reinterpret_cast<C *>(smem);  // [n][T]
-  const long long w = pf_xcd_swizzle_mixed(blockIdx.x, (nwork + 7) >> 3);
-  if (w >= nwork) return;
   const int n = PLAN::n ? PLAN::n : pl.n, nt = n / 8, T = blockDim.x;
   const int nstages = PLAN::n ? PLAN::nstages : pl.nstages;
   const int c = threadIdx.x, tl = threadIdx.y;
-  const int tile = (int)(w % ntiles), outer = (int)(w / ntiles);
-  const int col = tile * T + c;
-  const bool valid = col < p.ncols;
   const C *__restrict__ tw = reinterpret_cast<const C *>(p.tw);
   const double kf = 2.0 * 3.14159265358979323846 / (double)n;
   const int half = n / 2;
-  int so = outer + p.outer_offset;
-  if (so > half) so -= n;
-  if (p.band_outer < half && (so > p.band_outer || so < -p.band_outer)) return;  // (uniform: the whole workgroup leaves)
-  const long long base_in = (long long)outer * p.ain.os + col, base_out = (long long)outer * p.aout.os + col;
   // element e of a line: slab e / el_len, row e % el_len of it (PfAddr) -- one rank, or a layout whose slabs follow each other
   // at their own length: e * els.  The quotient by multiply-high (exact for e < 2^16 with the rounded-up reciprocal).
   const unsigned len_in = (unsigned)p.ain.el_len, len_out = (unsigned)p.aout.el_len;
@@ -227,65 +226,91 @@ __global__ void __launch_bounds__(1024) k_mixed_strided(const PfStridedParams p,
     const unsigned q = __umulhi(e, mg_out), s = e - q * len_out;
     return (size_t)q * (size_t)p.aout.ehs + (size_t)s * (size_t)p.aout.els;
   };
-  double ko2kc2 = 0.0, woc = 1.0;
-  if (p.pre) {
-    const double ko = kf * so, kc = kf * col;
-    ko2kc2 = ko * ko + kc * kc;
-    woc = (p.rs != 0.0 ? exp(-0.5 * ko2kc2 * p.rs * p.rs) : 1.0) * p.growth;
-  }
-  auto sync = [&]() { __syncthreads(); };
-  // a plan known at compile time leaves room to hold the loaded (and filtered) points while the jobs on the same input follow each other
-  constexpr bool KEEP = PLAN::n != 0 && PF_MIXED_KEEP;
-  C src[KEEP ? 8 : 1];
-  const C *held = nullptr;
-#pragma unroll 1
-  for (int j = 0; j < p.njobs; j++) {
-    const C *__restrict__ in = reinterpret_cast<const C *>(p.job[j].in) + base_in;
-    const int mul = p.job[j].mul;
-    int tlj = tl;
-    asm volatile("" : "+v"(tlj));  // (keeps the per-element index and filter arithmetic inside the job loop: hoisted, it spills)
-    C v[8];
-    const bool fresh = !KEEP || in != held;  // (uniform)
-    held = in;
+  const long long w = pf_xcd_swizzle_mixed(blockIdx.x, (nwork + 7) >> 3);  // XCDs take contiguous ranges of tiles
+  if (w >= nwork) return;
+  const int tile = (int)(w % ntiles), outer = (int)(w / ntiles);
+  int so = outer + p.outer_offset;
+  if (so > half) so -= n;
+  if (p.band_outer < half && (so > p.band_outer || so < -p.band_outer)) return;  // (uniform: the whole workgroup leaves)
+  const int col = tile * T + c;
+  const bool valid = col < p.ncols;
+  // the eight points of a thread as they lie in memory (zeros beyond the band limit of the transformed axis); tlx: the thread's index
+  // along the line, an opaque copy where the caller sits in a loop (left to itself the compiler hoists the eight offsets out of it)
+  auto load_raw = [&](const C *__restrict__ field, C *dst, int tlx) {
+    const C *__restrict__ in = field + ((long long)outer * p.ain.os + col);
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-      const int e = tlj + m * nt;
+      const int e = tlx + m * nt;
       const int se = e > half ? e - n : e;
-      const double ke = kf * se;
-      C x;
-      if (fresh) {
-        const bool inband = se <= p.band_e && se >= -p.band_e;
-        x = (valid && inband) ? pf_ld_stream(in + off_in((unsigned)e)) : pf_zero<F>();
-        if (p.pre) {  // exp(-k^2 rs^2 / 2) g / k^2, zero at k = 0 (src/fmax-pfft.c:366-384)
-          const double k2 = ke * ke + ko2kc2;
-          const double we = p.rs != 0.0 ? p.etab[e] : 1.0;
-          x = pf_scale(x, (F)((k2 != 0.0) ? we * woc / k2 : 0.0));
-        }
-        if (KEEP) src[m] = x;
-      } else x = src[m];
-      const F kef = (F)ke;
-      if (mul == PF_MUL_K) x = pf_scale(x, kef);
-      else if (mul == PF_MUL_K2) x = pf_scale(x, kef * kef);
-      else if (mul == PF_MUL_IK) x = pf_mul_i<+1>(pf_scale(x, kef));
-      v[m] = x;
+      const bool inband = se <= p.band_e && se >= -p.band_e;
+      dst[m] = (valid && inband) ? pf_ld_stream(in + off_in((unsigned)e)) : pf_zero<F>();
     }
-    C *__restrict__ outp = reinterpret_cast<C *>(p.job[j].out) + base_out;
-    auto store = [&](int e, C val) {
-      if (!valid) return;
-      if (p.out_ne > 0 && (unsigned)(e - p.out_e0) >= (unsigned)p.out_ne) return;
-      pf_st_stream(outp + off_out((unsigned)e), val);
-    };
-    pf_bfly8<DIR>(v);  // stage 0: the thread's own eight points (NS = 1: no twiddles)
-    if (nstages == 1) {
+  };
+  auto sync = [&]() { __syncthreads(); };
+  constexpr bool KEEP = PLAN::n != 0 && PF_MIXED_KEEP;
+  C src[KEEP ? 8 : 1];
+  {
+    double ko2kc2 = 0.0, woc = 1.0;
+    if (p.pre) {
+      const double ko = kf * so, kc = kf * col;
+      ko2kc2 = ko * ko + kc * kc;
+      woc = (p.rs != 0.0 ? exp(-0.5 * ko2kc2 * p.rs * p.rs) : 1.0) * p.growth;
+    }
+    const void *held = nullptr;
+#pragma unroll 1
+    for (int j = 0; j < p.njobs; j++) {
+      const int mul = p.job[j].mul;
+      int tlj = tl;
+      asm volatile("" : "+v"(tlj));  // (keeps the per-element index and filter arithmetic inside the job loop: hoisted, it spills)
+      C v[8];
+      const bool fresh = !KEEP || p.job[j].in != held;  // (uniform)
+      held = p.job[j].in;
+      if (fresh) {
+        C raw[8];
+        load_raw(reinterpret_cast<const C *>(p.job[j].in), raw, tlj);
 #pragma unroll
-      for (int t = 0; t < 8; t++) store(tlj + t * nt, v[t]);  // n = 8: (b - k) R + k + t NS with b = k = 0
-    } else {
+        for (int m = 0; m < 8; m++) {
+          C x = raw[m];
+          if (p.pre) {  // exp(-k^2 rs^2 / 2) g / k^2, zero at k = 0 (src/fmax-pfft.c:366-384)
+            const int e = tlj + m * nt;
+            const int se = e > half ? e - n : e;
+            const double ke = kf * se;
+            const double k2 = ke * ke + ko2kc2;
+            const double we = p.rs != 0.0 ? p.etab[e] : 1.0;
+            x = pf_scale(x, (F)((k2 != 0.0) ? we * woc / k2 : 0.0));
+          }
+          if (KEEP) src[m] = x; else v[m] = x;
+        }
+      }
 #pragma unroll
-      for (int t = 0; t < 8; t++) lds[(tlj * 8 + t) * T + c] = v[t];  // outputs of butterfly b = tl: b R + t
-      __syncthreads();
-      pf_mixed_tail_any<PLAN, 8, DIR, F>(
-          pl, tlj, tw, 1, [&](int pos) { return lds[pos * T + c]; }, [&](int pos, C val) { lds[pos * T + c] = val; }, sync, store);
-      __syncthreads();  // the next job rewrites the exchange area
+      for (int m = 0; m < 8; m++) {
+        const int e = tlj + m * nt;
+        const int se = e > half ? e - n : e;
+        C x = KEEP ? src[m] : v[m];
+        const F kef = (F)(kf * se);
+        if (mul == PF_MUL_K) x = pf_scale(x, kef);
+        else if (mul == PF_MUL_K2) x = pf_scale(x, kef * kef);
+        else if (mul == PF_MUL_IK) x = pf_mul_i<+1>(pf_scale(x, kef));
+        v[m] = x;
+      }
+      C *__restrict__ outp = reinterpret_cast<C *>(p.job[j].out) + ((long long)outer * p.aout.os + col);
+      auto store = [&](int e, C val) {
+        if (!valid) return;
+        if (p.out_ne > 0 && (unsigned)(e - p.out_e0) >= (unsigned)p.out_ne) return;
+        pf_st_stream(outp + off_out((unsigned)e), val);
+      };
+      pf_bfly8<DIR>(v);  // stage 0: the thread's own eight points (NS = 1: no twiddles)
+      if (nstages == 1) {
+#pragma unroll
+        for (int t = 0; t < 8; t++) store(tlj + t * nt, v[t]);  // n = 8: (b - k) R + k + t NS with b = k = 0
+      } else {
+#pragma unroll
+        for (int t = 0; t < 8; t++) lds[(tlj * 8 + t) * T + c] = v[t];  // outputs of butterfly b = tl: b R + t
+        __syncthreads();
+        pf_mixed_tail_any<PLAN, 8, DIR, F>(
+            pl, tlj, tw, 1, [&](int pos) { return lds[pos * T + c]; }, [&](int pos, C val) { lds[pos * T + c] = val; }, sync, store);
+        __syncthreads();  // the next job rewrites the exchange area
+      }
     }
   }
 }
@@ -316,16 +341,25 @@ __global__ void __launch_bounds__(256) k_mixed_c2r(const PfC2RParams p, const Pf
   const int mul = p.job[job].mul;
   const C *__restrict__ tw = reinterpret_cast<const C *>(p.tw);   // exp(+2 pi i j / n), n entries
   C *L = lds + l * LPL;
-  for (int k = tl; k <= M; k += nt) L[PFP(k)] = (rvalid && k <= p.band_k) ? pf_ld_stream(in + k) : pf_mk<F>(0, 0);  // the row's own threads stage it
-  C v[R0];
+  // the row's own threads stage it: R0 elements each, asked for in one go (M = R0 nt), and element M by the first thread; a thread's
+  // own elements stay in its registers for the fold
+  C own[R0], v[R0];
+#pragma unroll
+  for (int m = 0; m < R0; m++) {
+    const int k = tl + m * nt;
+    own[m] = (rvalid && k <= p.band_k) ? pf_ld_stream(in + k) : pf_mk<F>(0, 0);
+  }
+  if (tl == 0) L[PFP(M)] = (rvalid && M <= p.band_k) ? pf_ld_stream(in + M) : pf_mk<F>(0, 0);
 #pragma unroll
   for (int m = 0; m < R0; m++) v[m] = tw[tl + m * nt];  // the fold's table values, asked for in front of the barrier
+#pragma unroll
+  for (int m = 0; m < R0; m++) L[PFP(tl + m * nt)] = own[m];
   __syncthreads();
   const F kf = (F)(2.0 * 3.14159265358979323846 / (double)n);
 #pragma unroll
   for (int m = 0; m < R0; m++) {
     const int e = tl + m * nt;
-    v[m] = pf_zfold<F>(L[PFP(e)], L[PFP(M - e)], e, M, mul, kf, v[m]);
+    v[m] = pf_zfold<F>(own[m], L[PFP(M - e)], e, M, mul, kf, v[m]);
   }
   __syncthreads();
   const F norm = (F)p.norm;
@@ -434,15 +468,22 @@ __global__ void __launch_bounds__(PLAN::n ? 6 * (PLAN::n / R0) : (R0 == 8 ? 768 
     int tlj = tl, tidj = tid;
     asm volatile("" : "+v"(tlj), "+v"(tidj));
     const C *__restrict__ in = in0 + row * p.in_pitch;
-    for (int k = tlj; k <= M; k += nt) L[k] = (k <= p.band_k) ? pf_ld_stream(in + k) : pf_mk<F>(0, 0);
-    C v[R0];
+    C own[R0], v[R0];  // (as k_mixed_c2r: the row asked for in one go, a thread's own elements kept for the fold)
+#pragma unroll
+    for (int m = 0; m < R0; m++) {
+      const int k = tlj + m * nt;
+      own[m] = (k <= p.band_k) ? pf_ld_stream(in + k) : pf_mk<F>(0, 0);
+    }
+    if (tlj == 0) L[M] = (M <= p.band_k) ? pf_ld_stream(in + M) : pf_mk<F>(0, 0);
 #pragma unroll
     for (int m = 0; m < R0; m++) v[m] = tw[tlj + m * nt];  // the fold's table values, asked for in front of the barrier
+#pragma unroll
+    for (int m = 0; m < R0; m++) L[tlj + m * nt] = own[m];
     __syncthreads();
 #pragma unroll
     for (int m = 0; m < R0; m++) {
       const int e = tlj + m * nt;
-      v[m] = pf_zfold<F>(L[e], L[M - e], e, M, mul, kf, v[m]);
+      v[m] = pf_zfold<F>(own[m], L[M - e], e, M, mul, kf, v[m]);
     }
     __syncthreads();
     pf_dft_small<R0, +1>(v);
@@ -671,6 +712,7 @@ int pf_launch_mixed_c2r_invariants(int fb, int n, const PfC2RParams &p, hipStrea
   if (per_cu > 8) per_cu = 8;
   long long g = (long long)(p.ncu > 0 ? p.ncu : 256) * per_cu;
   if (g > p.nlines) g = p.nlines;
+  if (PF_MIXED_ZI_ONE_ROW) g = p.nlines;  // one row per workgroup
   const dim3 grid((unsigned)g), block(nt, 6);
 #define PF_MIXED_LAUNCH_P(FF, RR, PP, MM)                                                                            \
   do {                                                                                                               \
