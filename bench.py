@@ -134,6 +134,19 @@ def symbol_of(cls: str, n: int, fb: int, fast: bool = True) -> str:
             "lpt_accum": f"k_lpt_accum<{F}>", "zpass_r2c": f"k_r2c<{F}, {n}, {tl}>"}.get(cls, cls)
 
 
+def counter_symbol(kernels: dict, symbol: str):
+    """the key of `kernels` (a counter summary of profiles/) that holds `symbol`: itself, or -- k_strided only -- the instantiation with
+    whole 64-bit addresses per lane (last template argument false), which the launcher takes where a lane's byte offset does not fit 32
+    bits (slabs thinner than n / 8, the replicated spectrum of a 2048 box with fp32 fields: launch_strided_n)"""
+    if symbol in kernels:
+        return symbol
+    if symbol.startswith("k_strided<") and symbol.endswith(", true>"):
+        alt = symbol[:-len("true>")] + "false>"
+        if alt in kernels:
+            return alt
+    return None
+
+
 def committed_counters(kind: str, n: int, fb: int):
     """profiles/<round>[_fp32]_pmc_<kind>.json if it was measured on the kernel sources loaded now, else None"""
     from pinocchio_amd import _lib
@@ -539,8 +552,11 @@ def kernel_report(stats, steps, n, w, inline=None, solve_beside=False, stream=No
     # HBM bytes per launch from the PMC counters of the same command (profiles/tools/collect.sh), only if measured on these sources
     pmc = committed_counters("traffic", n, w)
     for r in (roofline, roofline_cls):
-        if pmc and r["kernel"] in pmc["kernels"]:
-            k = pmc["kernels"][r["kernel"]]
+        sym = counter_symbol(pmc["kernels"], r["kernel"]) if pmc else None
+        if sym:
+            k = pmc["kernels"][sym]
+            if sym != r["kernel"]:
+                r["traffic_kernel"] = sym
             r["traffic"] = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
             r["traffic_source"] = f"profiles/{PROFILE_ROUND}_pmc_traffic.json (counter passes of this command on these kernel sources, not of this process)"
     # the same kernels against what THIS memory system gives plain streaming kernels (measured above, in this process): reads and

@@ -36,7 +36,9 @@ typedef struct {
   int64_t n;        /* GSglobal[_x_] = [_y_] = [_z_] : cubic grid (the reference accepts any GridSize: src/fmax-pfft.c:139-188).
                        Power of two in 16..2048: the hand-written transform passes (any nranks, fp64 or fp32 fields).
                        n = 8 m, m = 2^a 3^b 5^c, up to 2048 (24, 40, 200, 384, 768, 1000, 1536 ...): the hand-written passes on
-                       run-time stage plans, any nranks (a power of two), fp64 or fp32 fields.  Any other even size in 4..2048: hand-written
+                       stage plans of radices 8, 5, 4, 3, 2 -- built into the kernels for 200, 384, 400, 640, 768, 800, 1000, 1280,
+                       1536, 1600 and 2000 (the fast way: 768^3 runs at 0.82 of the per-cell rate of 1024^3), a run-time table for the
+                       others -- any nranks (a power of two), fp64 or fp32 fields.  Any other even size in 4..2048: hand-written
                        chirp-z (Bluestein) transforms on the power-of-two stages, one per component, one rank and fp64 fields only
                        (csrc/pf_gfft.hip; no library transform anywhere).  pf_transform_path() says which */
   int     rank;     /* ThisTask */
@@ -360,7 +362,7 @@ int pf_debug_invariant_reruns(pf_ctx *ctx);
    times of pf_kernel_stats are spans, not shares of the step; 0 when every kernel ran in line */
 int pf_solve_ran_beside_zpass(pf_ctx *ctx);
 /* which transforms serve the context's grid size (the reference plans any GridSize, src/fmax-pfft.c:139-188): 0 the hand-written
-   power-of-two passes, 1 the hand-written passes with run-time stage plans (n = 8 m, m = 2^a 3^b 5^c; any power-of-two number of ranks),
+   power-of-two passes, 1 the hand-written passes with mixed-radix stage plans (n = 8 m, m = 2^a 3^b 5^c; any power-of-two number of ranks),
    2 chirp-z transforms, one 3-D transform per component (any other even n on one rank, or PF_GENERAL=1) */
 int pf_transform_path(pf_ctx *ctx);
 /* 1: in the default (fast) arithmetic the inverse growing mode of radius `ismooth` (-1: the shared spline) comes from the

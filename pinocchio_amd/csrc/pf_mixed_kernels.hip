@@ -1,20 +1,21 @@
 // pf_mixed_kernels.hip -- the three 1-D passes for grid sizes that are NOT a power of two (gfx950).
 //
 // The reference takes any GridSize through FFTW / PFFT (plans at src/fmax-pfft.c:139-188; the example parameter file uses
-// 200).  The passes of pf_fft_kernels.hip are specialised on the line length (compile-time stage plans of 8 points per
-// thread) and cover N = 2^k; here the line length is a RUN-TIME argument and the stage plan a small table (PfMixedPlan):
-// N = R0 * R1 * ... with radices from {8, 5, 4, 3, 2}, R0 = 8 (strided passes; N a multiple of 8) or 8 / 4 (half-length
-// lines of the z-pass), Stockham auto-sort as in pf_fft_core.h:
+// 200).  The passes of pf_fft_kernels.hip are specialised on the line length (stage plans of 8 points per thread) and cover
+// N = 2^k; here a line of N = R0 * R1 * ... points with radices from {8, 5, 4, 3, 2}, R0 = 8 (strided passes; N a multiple of 8) or
+// 8 / 4 (half-length lines of the z-pass), Stockham auto-sort as in pf_fft_core.h:
 //   stage s, butterfly b of N / R_s:  inputs line[b + q N / R_s], q < R_s, times w^(q k), k = b mod NS_s,
 //                                     w = exp(+-2 pi i / (NS_s R_s)), NS_s = R_0 ... R_{s-1};  DFT_{R_s};
 //                                     outputs to (b - k) R_s + k + t NS_s, t < R_s.
-// A line has N / R0 threads; stage 0 is one butterfly per thread on the points it loaded from HBM (kept for every job on
-// the same input), later stages deal their N / R_s butterflies over the same threads (ceil(R0 / R_s) each)
-// and exchange through LDS; the last stage stores straight to HBM.  Same semantics, same parameter blocks and the same
-// layouts as the power-of-two kernels -- filter on load, k multipliers, band limits, fp32 product rows -- so that the
-// sweep keeps its shared passes (x 1 -> 3, y 3 -> 6, z 6 -> 6) instead of one library transform per component.
-// What these kernels do not have: tile prefetch, the paired radix-16 stage, two columns per thread, the invariant z-pass
-// (six components per cell are stored), workgroups that walk over rows.  One rank.
+// The plan is a RUN-TIME table (PfMixedPlan: any such N up to 2048) or, for the grid sizes of PF_MIXED_CT_SIZES, built into the
+// kernel (PfPlanCT: every divisor, stride and trip count a constant, 79 instead of 128 registers in the strided pass, room to hold a
+// tile over its jobs; 768^3: 587 -> 452 ms per step by that alone).
+// A line has N / R0 threads; stage 0 is one butterfly per thread on the points it loaded from HBM, later stages deal their N / R_s
+// butterflies over the same threads (ceil(R0 / R_s) each) and exchange through LDS; the last stage stores straight to HBM.  Same
+// semantics, same parameter blocks and the same layouts as the power-of-two kernels -- filter on load, k multipliers, band limits,
+// fp32 product rows, slabs of a multi-rank box -- so that the sweep keeps its shared passes (x 1 -> 3, y 3 -> 6, z 6 -> 3 invariants
+// or 6 components) instead of one library transform per component.
+// What these kernels do not have: the paired radix-16 stage, two columns per thread, waves that only reduce in the invariant z-pass.
 #include <cstring>
 #include <utility>
 

@@ -10,7 +10,13 @@ BENCH_ARGS="--field-bytes 4" PF_SUMMARY_FB=4 bash profiles/tools/collect.sh r05_
 BENCH_ARGS="--slab-of 8 --n 2048 --field-bytes 4" PF_SUMMARY_N=2048 PF_SUMMARY_FB=4 PF_SUMMARY_SLAB_OF=8 PROFILE_ROUND=r05 bash profiles/tools/collect.sh r05_2048 > gpurun_out/r05/collect_r05_2048.log 2>&1; tail -2 gpurun_out/r05/collect_r05_2048.log
 bash profiles/tools/slab_matrix.sh r05 > gpurun_out/r05/slab_matrix.log 2>&1; tail -14 gpurun_out/r05/slab_matrix.log
 PF_SOLVE_BESIDE_Z=0 timeout 600 python3 bench.py --slab-of 8 --n 2048 --field-bytes 4 --steps 3 --warmup 1 > gpurun_out/r05_slab_2048_p8_fp32_inline.json 2> gpurun_out/r05/slab2048_inline.err
+BENCH_ARGS="--n 768" PF_SUMMARY_N=768 bash profiles/tools/collect.sh r05_768 > gpurun_out/r05/collect_r05_768.log 2>&1; tail -2 gpurun_out/r05/collect_r05_768.log
 timeout 900 python3 bench.py --n 768 --steps 3 --warmup 1 --cpu-n 0 --exact-steps 0 > gpurun_out/r05_bench_768.json 2> gpurun_out/r05/bench_768.err
+timeout 900 python3 bench.py --n 768 --field-bytes 4 --steps 3 --warmup 1 --cpu-n 0 --exact-steps 0 > gpurun_out/r05_bench_768_fp32.json 2> gpurun_out/r05/bench_768_fp32.err
+timeout 900 python3 bench.py --n 1000 --steps 2 --warmup 1 --cpu-n 0 --exact-steps 0 > gpurun_out/r05_bench_1000.json 2> gpurun_out/r05/bench_1000.err
+timeout 300 python3 bench.py --n 640 --steps 3 --warmup 1 --cpu-n 0 --exact-steps 0 > gpurun_out/r05_bench_640.json 2> gpurun_out/r05/bench_640.err
+timeout 300 python3 bench.py --n 720 --steps 3 --warmup 1 --cpu-n 0 --exact-steps 0 > gpurun_out/r05_bench_720_runtime_plan.json 2> gpurun_out/r05/bench_720.err
+timeout 300 python3 bench.py --n 256 --steps 5 --warmup 1 --cpu-n 0 --exact-steps 0 > gpurun_out/r05_bench_256.json 2> gpurun_out/r05/bench_256.err
 timeout 300 python3 bench.py --n 200 --steps 5 --warmup 1 --cpu-n 0 --exact-steps 0 > gpurun_out/r05_bench_200.json 2> gpurun_out/r05/bench_200.err
 PF_GENERAL=1 timeout 300 python3 bench.py --n 200 --steps 3 --warmup 1 --cpu-n 0 --exact-steps 0 > gpurun_out/r05_bench_200_chirpz.json 2> gpurun_out/r05/bench_200_chirpz.err
 ls gpurun_out | head -80
