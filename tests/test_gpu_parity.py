@@ -1231,8 +1231,9 @@ def test_reference_example_size_200(api, general, monkeypatch):
 
 
 def test_grid_200_mixed_passes_vs_chirp_z_transforms_and_oracle(api, monkeypatch):
-    """200^3 (the reference's example size): the shared-pass path on run-time stage plans against the chirp-z transform path
-    (products of a three-radius sweep with displacements), and its Hessian at one radius against the oracle"""
+    """200^3 (the reference's example size): the shared-pass path on the mixed-radix kernels against the chirp-z transform path
+    (products of a three-radius sweep with displacements), its Hessian at one radius against the oracle, and the whole path --
+    TrueVariance, Fmax, Rmax, the four displacement fields -- against the oracle"""
     n = 200
     x, y = synth.invgrow_table("lcdm")
     g = synth.growth_multipliers()
@@ -1259,6 +1260,16 @@ def test_grid_200_mixed_passes_vs_chirp_z_transforms_and_oracle(api, monkeypatch
     o.set_density(dk)
     for a, b in zip(h0, o.second_derivatives(1.5)):
         assert np.max(np.abs(a - b)) <= 1e-12 * np.max(np.abs(b))
+    # ... and the whole path against the oracle at this size: the sweep over the three radii and the 2LPT / 3LPT displacements
+    # (the mixed-radix kernels with the plan of 200 points built in, the invariant z-pass and the fused 3LPT(b) contraction included)
+    o.set_invgrow(x, y); o.set_growth(g)
+    tv_o = o.compute_fmax(radii, do_lpt=True)
+    po = o.products()
+    assert np.allclose(tv0, tv_o, rtol=1e-12)
+    _fmax_close(p0["Fmax"], po["Fmax"])
+    assert np.mean(p0["Rmax"] != po["Rmax"]) < 1e-3
+    for name in ("Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
+        assert np.max(np.abs(p0[name].astype(np.float64) - po[name])) <= 4e-7 * np.max(np.abs(po[name])), name
 
 
 def test_contexts_release_their_memory(api):
