@@ -504,9 +504,12 @@ def kernel_report(stats, steps, n, w, inline=None, solve_beside=False, stream=No
         table, table_steps = [s for s in inline["stats"] if s["name"] != "exchange"], inline["steps"]
         for s in table:
             s["symbol"] = symbol_of(s["name"], n, w)
-        overlapped = {"zpass_c2r_hess_6to3inv", "collapse_inv"}     # the two classes that share the chip in the timed region
+        # the solve of radius i starts beside the z-pass of radius i + 1 and, where it does not fit a CU beside that pass's workgroups,
+        # trails into the strided passes that follow: NO span of the timed region is a kernel time then (round 5: the x- and y-passes
+        # of a 1024^3 fp32 run showed 282 ms per step in the timed region and 125 in line) -- every per-kernel number comes from the in-line pass
+        overlapped = {s["name"] for s in table}
     elif solve_beside:
-        overlapped = {"zpass_c2r_hess_6to3inv", "collapse_inv"}
+        overlapped = {s["name"] for s in kern}
     table_total = sum(s["total_ms"] for s in table)
 
     def roof(group, label, steps):
@@ -527,15 +530,15 @@ def kernel_report(stats, steps, n, w, inline=None, solve_beside=False, stream=No
         tgroup = [s for s in table if s["name"] in names]
         r["share_of_gpu_time"] = sum(s["total_ms"] for s in tgroup) / table_total
         r["measured"] = ("HIP events of the timed region" if live else
-                         f"HIP events of the in-line pass ({table_steps} steps, PF_SOLVE_BESIDE_Z=0): in the timed region this kernel shares the chip "
-                         "with another one and its span is not its time")
+                         f"HIP events of the in-line pass ({table_steps} steps, PF_SOLVE_BESIDE_Z=0): in the timed region the collapse solve runs on "
+                         "its own stream beside the passes of the next radius, and a span there is not a kernel's time")
         if live and inline:
             r["avg_ms_in_line_pass"] = sum(s["total_ms"] for s in tgroup) / max(1, sum(s["launches"] for s in tgroup))
         return r
 
     # ranking: by kernel time.  Without the in-line pass (--table-steps 0) the spans of the two classes that share the chip are
     # no kernel times and cannot be ranked: the dominant kernel is then taken among the others, and the line says so
-    rank_pool = [s for s in table if s["name"] not in overlapped] if (overlapped and not inline) else table
+    rank_pool = [s for s in table if s["name"] not in ("zpass_c2r_hess_6to3inv", "collapse_inv")] if (overlapped and not inline) else table
     by_symbol = {}
     for s in rank_pool:
         by_symbol.setdefault(s["symbol"], []).append(s)
@@ -546,8 +549,9 @@ def kernel_report(stats, steps, n, w, inline=None, solve_beside=False, stream=No
     roofline_cls["class"] = dom_cls["name"]
     if overlapped and not inline:
         for r in (roofline, roofline_cls):
-            r["ranking"] = ("among the kernels whose spans do not overlap: no in-line pass was made (--table-steps 0), and the spans of "
-                            + " and ".join(sorted(overlapped)) + " -- which run beside each other -- are not their times")
+            r["ranking"] = ("by HIP-event spans of a timed region in which the collapse solve runs on its own stream beside the passes of the next "
+                            "radius: spans, not kernel times -- no in-line pass was made (--table-steps 0); the z-pass and the solve of the "
+                            "invariant radii, whose spans overlap most, are left out of the ranking")
             r["share_of_gpu_time"] = None
     # HBM bytes per launch from the PMC counters of the same command (profiles/tools/collect.sh), only if measured on these sources
     pmc = committed_counters("traffic", n, w)
@@ -841,10 +845,10 @@ def main():
             "kernel_table": ({"order": "in line", "steps": table_steps, "ms_per_step": 1e3 * inline["dt"] / inline["steps"],
                               "note": "per-kernel times of a second pass of the same step with every kernel in line (PF_SOLVE_BESIDE_Z=0): in the "
                                       "timed region the solve of sweep radius i runs on its own stream beside the z-pass of radius i + 1 "
-                                      "(DESIGN.md section 3), their HIP-event spans overlap (span_ms_per_step_in_timed_region) and add up to more "
-                                      "than the step; every other class has the same time in both passes"} if inline else
+                                      "and what follows it (DESIGN.md section 3): the HIP-event spans there overlap "
+                                      "(span_ms_per_step_in_timed_region) and add up to more than the step"} if inline else
                              {"order": "timed region", "steps": args.steps,
-                              "note": ("the spans of zpass_c2r_hess_6to3inv and collapse_inv overlap (solve stream): they are not shares of the step"
+                              "note": ("the collapse solve ran on its own stream beside the passes of the next radius: spans overlap, they are not shares of the step"
                                        if res.get("solve_beside") else "every kernel in line")}),
             "phases_s_per_step": {k: v / args.steps for k, v in cput.items()},
         }

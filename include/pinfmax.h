@@ -144,7 +144,8 @@ int pf_loopback_active(pf_ctx *ctx);                      /* 1 when the loopback
 int pf_exchange_buffers(pf_ctx *ctx, void **sendbuf, void **recvbuf, size_t *bytes);
 /* stream the work is enqueued on (hipStream_t); pf_set_stream adopts a caller stream.  Two internal streams run beside it, ordered
    against it by events and joined before an entry point returns: the communication stream of a pipelined multi-rank run and the
-   solve stream of a sweep (the collapse solve of radius i beside the z-pass of radius i + 1; PF_SOLVE_BESIDE_Z=0: in line).  What
+   solve stream of a sweep (the collapse solve of radius i beside the z-pass of radius i + 1: the default with fp32 fields, PF_SOLVE_BESIDE_Z=1
+   with fp64 fields, where it gains nothing since round 5; PF_SOLVE_BESIDE_Z=0: every kernel in line).  What
    follows an entry point on this stream sees all of its results. */
 int pf_set_stream(pf_ctx *ctx, void *stream);
 void *pf_get_stream(pf_ctx *ctx);
@@ -358,8 +359,8 @@ int pf_debug_strided_jobs(int field_bytes, int n, int njobs, int nin, const int 
    with q == 0 that is not exactly isotropic (the reference's "already diagonal" branch, src/collapse_times.c:722-727) */
 int pf_debug_invariant_reruns(pf_ctx *ctx);
 /* 1 when the last sweep of this context ran the collapse solve of its invariant radii on the solve stream, beside the z-pass of
-   the radius that follows (PF_SOLVE_BESIDE_Z): the two kernels' HIP-event spans then overlap -- per-kernel
-   times of pf_kernel_stats are spans, not shares of the step; 0 when every kernel ran in line */
+   the radius that follows (PF_SOLVE_BESIDE_Z): HIP-event spans then overlap (the solve trails into the passes after
+   that z-pass too) -- per-kernel times of pf_kernel_stats are spans, not kernel times or shares of the step; 0 when every kernel ran in line */
 int pf_solve_ran_beside_zpass(pf_ctx *ctx);
 /* which transforms serve the context's grid size (the reference plans any GridSize, src/fmax-pfft.c:139-188): 0 the hand-written
    power-of-two passes, 1 the hand-written passes with mixed-radix stage plans (n = 8 m, m = 2^a 3^b 5^c; any power-of-two number of ranks),

@@ -269,7 +269,7 @@ static void read_tuning(PfTuning *t) {
   t->pipeline = env_int("PF_PIPELINE", 1) != 0;
   t->replicate = env_int("PF_REPLICATE_DK", -1);  // -1: by the number of ranks (pf_create), 0 / 1: off / on
   t->exact_libm = env_int("PF_EXACT_LIBM", 0) != 0;
-  t->solve_beside_z = env_int("PF_SOLVE_BESIDE_Z", 1) != 0;
+  t->solve_beside_z = env_int("PF_SOLVE_BESIDE_Z", -1);
   t->gtab = env_int("PF_GTAB", 1) != 0;
   // fault injection for the tests of the exchange pipeline (tests/test_gpu_multirank.py): "recv" drops the wait of the
   // compute stream for the exchange it is about to consume, "send" the wait of the exchange for the x-pass that fills its blocks
@@ -1342,7 +1342,12 @@ static int sweep_body_run(pf_ctx *c, int ns, const double *radius_cells, double 
   // running maximum: results are bit for bit those of the in-line order.  792 against 806 ms per step at 1024^3 (three boxes);
   // a partition of the chip by CUs instead (the solve in 1024-thread workgroups holding 96 .. 144 CUs, the passes of the next
   // radius on the others) gained nothing: 806 .. 874 ms, the passes lose what the solve wins (profiles/r03_experiments.md).
-  bool beside_z = invariants_ok && c->tune.solve_beside_z;
+  // Round 5: with fp64 fields the default is the in-line order again.  The z-pass of 1024-point fp64 rows now holds three workgroups
+  // per CU (156 KB of LDS) and the strided passes one of 128 KB: a workgroup of the solve (41 KB) fits beside neither, runs in what
+  // gaps there are and trails into the strided passes of the next radius, whose times then grow by what the overlap saved --
+  // 720.2 / 723.6 ms per step beside, 720.2 / 719.0 in line on one box (profiles/r05_notes.md).  fp32 fields (28 KB of lines per
+  // z-pass workgroup) keep it: 507 / 509 against 511 / 512.5 at 1024^3, 566 against 573 for BASELINE config 5's slab.
+  bool beside_z = invariants_ok && (c->tune.solve_beside_z < 0 ? c->fb == 4 : c->tune.solve_beside_z != 0);
   // the second field set B2 (six fields: 52 GB at 1024^3 on one rank) is what the LPT part allocates anyway; an Fmax-only run that
   // cannot have it keeps every kernel in line on one field set instead of failing
   if (beside_z && c->fb == 8) {

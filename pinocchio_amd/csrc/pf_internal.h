@@ -20,7 +20,8 @@ struct PfTuning {
   int replicate;  // PF_REPLICATE_DK: -1 by rank count, 0 off, 1 on
   double prune_eps;
   int debug_fault;          // PF_DEBUG_PIPELINE_FAULT (tests only): 1 / 2 = one wait of the exchange pipeline left out
-  bool solve_beside_z;      // PF_SOLVE_BESIDE_Z: the solve of sweep radius i runs on its own stream beside the z-pass of radius i + 1
+  int solve_beside_z;       // PF_SOLVE_BESIDE_Z: the solve of sweep radius i runs on its own stream beside the z-pass of radius i + 1 (1), every
+                            // kernel in line (0), or -- the default, -1 -- beside with fp32 fields and in line with fp64 fields (pf_sweep)
   bool gtab;                // PF_GTAB: the inverse growing mode of the fast flavour from the polynomial table (pf_gtab.h)
 };
 
