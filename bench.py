@@ -90,9 +90,17 @@ def mixed_plan_names(n: int):
     return tuple("PfPlanCT<%s>" % ", ".join(str(x) for x in mixed_radices(m, a4)) for m, a4 in ((n, False), (n // 2, True)))
 
 
+GENERAL_PATH = False   # set by run_config when the context says pf_transform_path() == 2: chirp-z transforms, one 3-D transform per component
+
+
 def symbol_of(cls: str, n: int, fb: int, fast: bool = True) -> str:
     """kernel function behind a launch class, spelled as rocprofv3 prints it (csrc/pf_fft_kernels.hip dispatch tables)"""
     F = "double" if fb == 8 else "float"
+    if GENERAL_PATH and cls in ("zpass_c2r_plain", "zpass_r2c", "zpass_c2r_hess_6", "zpass_c2r_disp_3"):
+        # csrc/pf_gfft.hip: a 3-D transform is three passes of k_blue<M, MODE> (M = 2^p >= 2 n - 1; MODE 0 complex lines, 1 / 2 the
+        # Hermitian <-> real lines along z), timed as one launch of this class: the family is named
+        m = 1 << max(4, (2 * n - 2).bit_length())
+        return f"k_blue<{m}, mode> x 3"
     t = max(1, min(128 // (2 * fb), (128 * 1024) // (n * 2 * fb), 8192 // n))     # PfTileCols (128 KB of LDS per tile)
     FS = F
     if fb == 4 and n >= 1024:      # fp32 lines of 1024 points and more: two columns per thread, 16-byte elements (launch_strided_f32)
@@ -476,6 +484,8 @@ def run_config(args, rank, world, device, dist, torch, replicate_env, votes_out,
             for kind, name in ((0, "read_GBps"), (1, "write_GBps"), (2, "copy_GBps")):
                 if f.L.pf_debug_stream_rate(f.h, kind, 5, C.byref(v)) == 0:
                     stream[name] = v.value
+        global GENERAL_PATH
+        GENERAL_PATH = int(f.L.pf_transform_path(f.h)) == 2
         res.update(dt=dt, stats=f.kernel_stats(), cput=f.cputime(), device_gb=f.device_bytes / 1e9, stream=stream,
                    reruns=int(f.L.pf_debug_invariant_reruns(f.h)), sigma_R0=float(np.sqrt(tv[-1])), step=step,
                    solve_beside=int(f.L.pf_solve_ran_beside_zpass(f.h)) == 1)
