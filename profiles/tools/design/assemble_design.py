@@ -56,7 +56,7 @@ for pref,label in (('k_strided<double, 1024, 8, 1','`k_strided<…, 1, true>`'),
 st=d['hbm_streaming']
 ph=d['path_roofline']
 rep={
- '@STEP@': f"{d['ms_per_step']:.1f}", '@VALUE@': f"{d['value']:.3g}".replace('e+09','·10⁹'), '@STEP_RANGE@':'700–716 by box and day',
+ '@STEP@': f"{d['ms_per_step']:.1f}", '@VALUE@': f"{d['value']:.3g}".replace('e+09','·10⁹'), '@STEP_RANGE@':'700–723 by box and day',
  '@KERNEL_TABLE@': ktab, '@EV_MS@': f"{prof['roofline']['avg_ms']:.3f}", '@PROF_MS@': f"{prof_ms:.3f}" if prof_ms else 'n/a',
  '@DESIGN_TB@': f"{ph['design_bytes_per_step_per_gpu']/1e12:.2f}", '@BPC@': f"{ph['design_bytes_per_cell']:.0f}", '@PATH_FRAC@': f"{ph['frac_of_hbm_peak_design']:.2f}",
  '@TRAFFIC@': '; '.join(tstr), '@STREAM@': f"read {st['read_GBps']/1000:.2f}, write {st['write_GBps']/1000:.2f}, copy {st['copy_GBps']/1000:.2f} TB/s",
