@@ -30,6 +30,9 @@
 #ifndef PF_MIXED_ZI_ONE_ROW
 #define PF_MIXED_ZI_ONE_ROW 1
 #endif
+#ifndef PF_MIXED_NEXT_INPUT
+#define PF_MIXED_NEXT_INPUT 1
+#endif
 #ifndef PF_MIXED_KEEP
 #define PF_MIXED_KEEP 1
 #endif
@@ -258,6 +261,7 @@ __global__ void __launch_bounds__(1024) k_mixed_strided(const PfStridedParams p,
       woc = (p.rs != 0.0 ? exp(-0.5 * ko2kc2 * p.rs * p.rs) : 1.0) * p.growth;
     }
     const void *held = nullptr;
+    bool ahead = false;  // src holds the untreated points of the next job's input
 #pragma unroll 1
     for (int j = 0; j < p.njobs; j++) {
       const int mul = p.job[j].mul;
@@ -268,7 +272,10 @@ __global__ void __launch_bounds__(1024) k_mixed_strided(const PfStridedParams p,
       held = p.job[j].in;
       if (fresh) {
         C raw[8];
-        load_raw(reinterpret_cast<const C *>(p.job[j].in), raw, tlj);
+        if (KEEP && PF_MIXED_NEXT_INPUT && ahead) {
+#pragma unroll
+          for (int m = 0; m < 8; m++) raw[m] = src[m];  // (requested by the job before, below)
+        } else load_raw(reinterpret_cast<const C *>(p.job[j].in), raw, tlj);
 #pragma unroll
         for (int m = 0; m < 8; m++) {
           C x = raw[m];
@@ -293,6 +300,13 @@ __global__ void __launch_bounds__(1024) k_mixed_strided(const PfStridedParams p,
         else if (mul == PF_MUL_K2) x = pf_scale(x, kef * kef);
         else if (mul == PF_MUL_IK) x = pf_mul_i<+1>(pf_scale(x, kef));
         v[m] = x;
+      }
+      // the last job on this input has its copy: the points of the NEXT input are requested into the registers that held it, and
+      // travel during this job's stages and stores -- requested before those stores, so that waiting for them is not waiting for
+      // the stores (as k_strided does it; y-pass 3 -> 6: two of three inputs arrive behind a job)
+      if (KEEP && PF_MIXED_NEXT_INPUT) {
+        ahead = j + 1 < p.njobs && p.job[j + 1].in != p.job[j].in;
+        if (ahead) load_raw(reinterpret_cast<const C *>(p.job[j + 1].in), src, tlj);
       }
       C *__restrict__ outp = reinterpret_cast<C *>(p.job[j].out) + ((long long)outer * p.aout.os + col);
       auto store = [&](int e, C val) {
