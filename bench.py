@@ -610,7 +610,9 @@ def run_slab(args):
         for _ in range(max(1, args.warmup)):
             f.compute_fmax(radii, do_lpt=lpt)
         f.synchronize()
-        f._chk(f.L.pf_set_loopback_exchange(f.h, 0))                # timed: nothing moves
+        # timed: nothing moves (PF_BENCH_LOOPBACK_COPIES=n, an experiment: the first n hand-backs of the timed region copy as in the
+        # warm-up, so that the passes behind the exchange see this step's data instead of the warm-up's)
+        f._chk(f.L.pf_set_loopback_exchange(f.h, int(os.environ.get("PF_BENCH_LOOPBACK_COPIES", "0"))))
         f.reset_kernel_stats()
         t0 = time.perf_counter()
         for _ in range(args.steps):
