@@ -634,7 +634,10 @@ def run_slab(args):
                "kernels": [{"name": s["name"], "symbol": symbol_of(s["name"], n, w), "launches": s["launches"], "ms_per_step": s["total_ms"] / args.steps,
                             "GBps": s["alg_bytes"] / max(s["total_ms"], 1e-9) / 1e6} for s in stats],
                "note": ("kernel spans: zpass_c2r_hess_6to3inv and collapse_inv run beside each other (solve stream) and overlap; " if beside else "") +
-                       "an upper bound on what P GPUs can reach on this box: the all-to-alls (P - 1 of P of every field per transform) are not in it"}
+                       "an upper bound on what P GPUs can reach on this box: the all-to-alls (P - 1 of P of every field per transform) are not in it.  "
+                       "The rank gets its own blocks back as every peer's: the field that makes is not a physical one (its variance is 10^5 times the "
+                       "box's, nearly every cell collapses), which the transform passes do not notice and the per-cell classes do -- collapse_inv takes "
+                       "about 12 % longer on it than on as many cells of a physical field (profiles/r05_notes.md section 6)"}
         print(json.dumps(out), flush=True)
     finally:
         f.close()
