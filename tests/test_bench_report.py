@@ -71,6 +71,22 @@ def test_fp32_symbols():
     assert bench.symbol_of("zpass_c2r_hess_6to3inv", 1024, 8) == "k_c2r_invariants_spec<double, 1024, 0>"
 
 
+def test_counter_lookup_by_symbol():
+    """the counter summaries of profiles/ are keyed by rocprofv3's symbol: a k_strided launch class whose launcher took the instantiation
+    with whole 64-bit addresses per lane (last template argument false) is found under that spelling; the chirp-z path names its family"""
+    k = {"k_strided<float __vector(2), 2048, 4, 1, false>": 1, "k_collapse_inv<true, float>": 2}
+    assert bench.counter_symbol(k, "k_strided<float __vector(2), 2048, 4, 1, true>") == "k_strided<float __vector(2), 2048, 4, 1, false>"
+    assert bench.counter_symbol(k, "k_collapse_inv<true, float>") == "k_collapse_inv<true, float>"
+    assert bench.counter_symbol(k, "k_c2r<double, 64, 4>") is None
+    bench.GENERAL_PATH = True
+    try:
+        assert bench.symbol_of("zpass_c2r_plain", 200, 8) == "k_blue<512, mode> x 3" and bench.symbol_of("zpass_r2c", 100, 8) == "k_blue<256, mode> x 3"
+        assert bench.symbol_of("collapse", 200, 8) == "k_collapse<double, true, float>"
+    finally:
+        bench.GENERAL_PATH = False
+    assert bench.symbol_of("zpass_c2r_plain", 200, 8).startswith("k_mixed_c2r<double, 4, PfPlanCT<4, 5, 5>")
+
+
 def test_mixed_plan_names_follow_the_kernel_sources():
     """sizes that are not a power of two: bench.py names a run's kernels from the list of sizes whose stage plans
     csrc/pf_mixed_kernels.hip compiles in, and from the rule that makes a plan -- both restated there"""
