@@ -33,6 +33,9 @@
 #ifndef PF_MIXED_NEXT_INPUT
 #define PF_MIXED_NEXT_INPUT 1
 #endif
+#ifndef PF_MIXED_KEEP_RT
+#define PF_MIXED_KEEP_RT 1
+#endif
 #ifndef PF_MIXED_KEEP
 #define PF_MIXED_KEEP 1
 #endif
@@ -205,8 +208,10 @@ __device__ __forceinline__ void pf_mixed_tail_any(const PfMixedPlan &pl, int tl,
 // 3 -> 6 of a 768^3 box took 6.1 instead of 5.2 ms).  Not here, measured (profiles/r05_notes.md): workgroups that walk over tiles
 // and request the next input while the jobs on the current one run -- 6.0 ms: the wait for those loads is a wait for every store
 // issued after them as well (one counter), where a workgroup that ends leaves its stores behind and the next one starts loading.
-template <typename F, int DIR, typename PLAN = PfPlanRT>
-__global__ void __launch_bounds__(1024) k_mixed_strided(const PfStridedParams p, const PfMixedPlan pl, const long long nwork, const int ntiles) {
+// SMALL (run-time plans): the launch has at most 768 threads per workgroup -- 170 registers instead of 128, room to keep a tile over
+// its jobs as the built-in plans do (PF_MIXED_KEEP_RT).
+template <typename F, int DIR, typename PLAN = PfPlanRT, bool SMALL = false>
+__global__ void __launch_bounds__(SMALL ? 768 : 1024) k_mixed_strided(const PfStridedParams p, const PfMixedPlan pl, const long long nwork, const int ntiles) {
   using C = pfc<F>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   C *lds = reinterpret_cast<C *>(smem);  // [n][T]
@@ -251,7 +256,7 @@ __global__ void __launch_bounds__(1024) k_mixed_strided(const PfStridedParams p,
     }
   };
   auto sync = [&]() { __syncthreads(); };
-  constexpr bool KEEP = PLAN::n != 0 && PF_MIXED_KEEP;
+  constexpr bool KEEP = (PLAN::n != 0 || SMALL) && PF_MIXED_KEEP;
   C src[KEEP ? 8 : 1];
   {
     double ko2kc2 = 0.0, woc = 1.0;
@@ -618,6 +623,18 @@ template <typename F> static int pf_mixed_raise_lds(const void *fn, size_t shm) 
   if (shm <= 64 * 1024) return 0;
   return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess ? 0 : 3;
 }
+// workgroups of a kernel that fit one CU (asked once per kernel and shape)
+static int pf_mixed_resident(const void *fn, int threads, size_t shm) {
+  struct Ent { const void *fn; int threads; size_t shm; int nb; };
+  static Ent tab[64];
+  static int used = 0;
+  for (int i = 0; i < used; i++)
+    if (tab[i].fn == fn && tab[i].threads == threads && tab[i].shm == shm) return tab[i].nb;
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, shm) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  if (used < 64) tab[used++] = Ent{fn, threads, shm, nb};
+  return nb;
+}
 int pf_launch_mixed_strided(int fb, int n, int dir, const PfStridedParams &p, hipStream_t st) {
   PfMixedPlan pl;
   if (!pf_mixed_plan(n, false, &pl)) return 2;
@@ -636,6 +653,20 @@ int pf_launch_mixed_strided(int fb, int n, int dir, const PfStridedParams &p, hi
   const size_t shm = (size_t)n * T * w;
 #define PF_MIXED_LAUNCH_P(FF, DD, PP)                                                                                \
   do {                                                                                                               \
+    if (PF_MIXED_KEEP_RT && PP::n == 0 && block.x * block.y <= 768 && p.njobs > 1) {                                 \
+      /* the form that keeps a tile over its jobs needs 156 registers for 124 (fp32: 106 for 94): taken where that costs no workgroup */ \
+      /* per CU -- and with fp64 fields only where a tile fills the CU anyway (720^3: 395 -> 353 ms per step; 360^3, two workgroups */ \
+      /* per CU either way: 49.8 -> 51.5, not taken); fp32 fields 720^3 349 -> 286, 360^3 44.0 -> 35.5 */ \
+      if (pf_mixed_raise_lds<FF>(reinterpret_cast<const void *>(&k_mixed_strided<FF, DD, PfPlanRT, true>), shm)) return 3; \
+      if (pf_mixed_raise_lds<FF>(reinterpret_cast<const void *>(&k_mixed_strided<FF, DD, PfPlanRT, false>), shm)) return 3; \
+      const int threads = (int)(block.x * block.y);                                                                  \
+      const int occ_keep = pf_mixed_resident(reinterpret_cast<const void *>(&k_mixed_strided<FF, DD, PfPlanRT, true>), threads, shm);  \
+      const int occ_base = pf_mixed_resident(reinterpret_cast<const void *>(&k_mixed_strided<FF, DD, PfPlanRT, false>), threads, shm); \
+      if (occ_keep >= occ_base && occ_keep >= 1 && (sizeof(FF) == 4 || occ_base == 1)) {                              \
+        hipLaunchKernelGGL((k_mixed_strided<FF, DD, PfPlanRT, true>), grid, block, shm, st, p, pl, nwork, ntiles); \
+        break;                                                                                                       \
+      }                                                                                                              \
+    }                                                                                                                \
     if (pf_mixed_raise_lds<FF>(reinterpret_cast<const void *>(&k_mixed_strided<FF, DD, PP>), shm)) return 3;         \
     hipLaunchKernelGGL((k_mixed_strided<FF, DD, PP>), grid, block, shm, st, p, pl, nwork, ntiles);                \
   } while (0)

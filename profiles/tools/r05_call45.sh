@@ -1,0 +1,8 @@
+#!/bin/bash
+timeout 1200 python3 -m pytest tests/test_gpu_lines.py -x -q 2>&1 | tail -2
+timeout 1200 python3 -m pytest tests/test_gpu_parity.py -x -q -k "general or slab" 2>&1 | tail -2
+for n in 720 360 480 120; do
+AB_ARGS="--n $n" AB_STEPS=3 bash profiles/tools/ab.sh default nokeeprt 2>&1 | grep "ms per\|[xy]pass_hess\|pass_disp"
+done
+AB_ARGS="--n 720 --field-bytes 4" AB_STEPS=2 bash profiles/tools/ab.sh default nokeeprt 2>&1 | grep "ms per step"
+AB_ARGS="--n 360 --field-bytes 4" AB_STEPS=2 bash profiles/tools/ab.sh default nokeeprt 2>&1 | grep "ms per step"
