@@ -37,7 +37,7 @@ typedef struct {
                        Power of two in 16..2048: the hand-written transform passes (any nranks, fp64 or fp32 fields).
                        n = 8 m, m = 2^a 3^b 5^c, up to 2048 (24, 40, 200, 384, 768, 1000, 1536 ...): the hand-written passes on
                        stage plans of radices 8, 5, 4, 3, 2 -- built into the kernels for 200, 384, 400, 640, 768, 800, 1000, 1280,
-                       1536, 1600 and 2000 (the fast way: 768^3 runs at 0.83 of the per-cell rate of 1024^3), a run-time table for the
+                       1536, 1600 and 2000 (the fast way: 768^3 runs at 0.84 of the per-cell rate of 1024^3), a run-time table for the
                        others -- any nranks (a power of two), fp64 or fp32 fields.  Any other even size in 4..2048: hand-written
                        chirp-z (Bluestein) transforms on the power-of-two stages, one per component, one rank and fp64 fields only
                        (csrc/pf_gfft.hip; no library transform anywhere).  pf_transform_path() says which */
