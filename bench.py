@@ -934,7 +934,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_n, ns, lpt)
         print(json.dumps(out), flush=True)
     if world > 1:
-        bad_flag = torch.tensor([1 if invalid else 0])
+        bad_flag = torch.tensor([1 if invalid else 0], device="cpu" if args.backend == "gloo-host" else "cuda")   # (an NCCL-only group has no CPU backend)
         dist.broadcast(bad_flag, src=0)   # every rank leaves with rank 0's verdict (the launcher reports the first non-zero exit)
         invalid = bool(bad_flag.item())
         dist.destroy_process_group()

@@ -79,6 +79,12 @@ typedef struct {
   double fmax, deriv, fft, coll, lpt, mem_transf;
 } pf_cputime;
 
+/* Device memory a context of this configuration holds, in bytes: *at_create by pf_create itself, *peak once a sweep and the LPT part
+   have run (the second field set is allocated at first use).  pf_create compares *peak with the free memory of the device
+   (hipMemGetInfo) BEFORE allocating anything and fails in the usual format when it does not fit (PF_PREFLIGHT=0: no check).  The
+   host's counterpart of the memory report of src/allocations.c:60-160.  Needs no device. */
+int pf_plan_bytes(const pf_config *cfg, size_t *at_create, size_t *peak);
+
 /* --- life cycle: replaces set_one_grid + compute_fft_plans + the FFT-buffer
        part of allocate_main_memory (src/fmax-pfft.c:80-188, src/allocations.c:382) --- */
 int  pf_create(pf_ctx **out, const pf_config *cfg);
@@ -138,6 +144,11 @@ int pf_debug_exchange(pf_ctx *ctx, size_t bytes_per_peer);
    geometry of the real run; the results are NOT those of the box.  Used by `bench.py --slab-of P` to time the compute side of a
    configuration whose box does not fit one GPU (BASELINE config 5: 2048^3 with fp32 fields on eight GPUs). */
 int pf_set_loopback_exchange(pf_ctx *ctx, int copies);   /* refused when a real exchange (RCCL, callbacks, fabric) is installed */
+/* ... with ONE exception, which is how a configuration that fits no single GPU is CHECKED rank by rank on one (BASELINE config 5,
+   tests/test_gpu_config5.py): a context that keeps the whole spectrum (PF_REPLICATE_DK=1) and whose density came from
+   pf_genic_density -- a function of (seed, cosmology) alone -- generates every rank's slab of delta(k) itself; the sweep of such a
+   context exchanges nothing, so its Fmax / Rmax / variance contributions / histogram ARE those of this rank's slab of the box.
+   (The LPT part still transposes the source spectra: its displacements behind a loopback are no box's.) */
 int pf_loopback_active(pf_ctx *ctx);                      /* 1 when the loopback stands in for the exchange (results are no box's) */
 /* device pointers + size (bytes) of the exchange buffers, so that a host
    harness can wrap them (e.g. torch tensors for torch.distributed) */
@@ -308,6 +319,9 @@ int pf_get_block(pf_ctx *ctx, const char *name, int id_bytes, void *host);
 int pf_get_second_derivative(pf_ctx *ctx, int i, double *host);
 int pf_get_kvector(pf_ctx *ctx, int which, double *host);
 int pf_get_density(pf_ctx *ctx, double *host);  /* resident delta(k), boundary layout */
+/* test tap: rows kx0 .. kx0 + nkx - 1 of the replicated spectrum (pf_replicated_spectrum) as this rank transforms it,
+   [nkx][n (ky)][n/2+1] complex fp64, natural order (gathered -- or, behind the loopback exchange, generated -- first) */
+int pf_debug_replicated_rows(pf_ctx *ctx, int kx0, int nkx, double *host);
 /* The FFT-module seam of the reference (src/pinocchio.h:551-562), host in and host out in the boundary layouts
    (this rank's x-slab: real [n/nranks][n][n], spectrum [n/nranks][n][n/2+1][2]); collective over the ranks.
    forward_transform / reverse_transform (src/fmax-pfft.c:191-228): unnormalised r2c, and c2r followed by the
@@ -350,6 +364,10 @@ int pf_debug_pk(int which, const float *a, const float *b, float *out, int count
 /* test tap without a context: the chirp-z 3-D transforms of the general path (csrc/pf_gfft.hip: any even n in 4..2048, no library) on
    host arrays in the natural layouts; dir > 0: spectrum [n][n][n/2+1] complex -> real [n][n][n] (unnormalised), dir < 0: real -> spectrum */
 int pf_debug_gfft(int n, int dir, const double *in, double *out);
+/* ... and ONE chirp-z pass on a few lines of n points (any even n in 4..2048, so that the convolution lengths 1024, 2048 and 4096 --
+   whose n^3 boxes no test can afford -- are run too).  mode 0: complex lines laid out [n][nlines] as the x- and y-passes meet them,
+   dir > 0 inverse / < 0 forward; mode 1: Hermitian rows [nlines][n/2+1] -> real rows [nlines][n]; mode 2: real rows -> Hermitian rows */
+int pf_debug_gfft_lines(int n, int mode, int dir, int nlines, const double *in, double *out);
 /* test tap without a context: ONE strided (inverse) launch with several jobs as the passes of the sweep issue them: job j transforms
    input field in_of[j] (of `nin` complex fields [nouter][n][ncols], fp64 on the host) with the factor mul[j] (0 one, 1 k, 2 k^2, 3 i k)
    along the transformed axis into out[j] ([njobs][nouter][n][ncols]); jobs on the same input must be adjacent.  n a power of two. */

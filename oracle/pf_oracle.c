@@ -1191,6 +1191,37 @@ size_t orc_select_sorted(orc_ctx *c, float flast, unsigned int *indices, float *
   return m;
 }
 
+/* the y and z transforms of nfields planes G[nfields][n][nzh] (complex, [ky][kz]) into out[nfields][n][n] reals times 1/n^3:
+   y lines of every plane (fixed kz, stride nzh), then the c2r rows along z -- what c2r_3d does for a whole box */
+static void plane_finish(orc_ctx *c, double *G, int nfields, double *out) {
+  const int n = c->n, nzh = c->nzh;
+  const size_t plane_c = (size_t)n * nzh;
+#pragma omp parallel num_threads(c->nthreads)
+  {
+    double *lines = (double *)malloc(sizeof(double) * 2 * n * ORC_FFT_BLOCK);
+    const int nblk = (nzh + ORC_FFT_BLOCK - 1) / ORC_FFT_BLOCK;
+#pragma omp for schedule(dynamic, 1)
+    for (int w = 0; w < nfields * nblk; w++) {
+      const int kz = (w % nblk) * ORC_FFT_BLOCK;
+      double *g = G + 2 * ((size_t)(w / nblk) * plane_c);
+      fft_strided_lines(c, g + 2 * kz, (size_t)nzh, nzh - kz < ORC_FFT_BLOCK ? nzh - kz : ORC_FFT_BLOCK, +1, lines);
+    }
+    free(lines);
+    double *line = (double *)malloc(sizeof(double) * 2 * n);
+#pragma omp for schedule(dynamic, 16)
+    for (long long w = 0; w < (long long)nfields * n; w++) {
+      const double *h = G + 2 * ((size_t)w * nzh);
+      for (int k = 0; k < nzh; k++) { line[2 * k] = h[2 * k]; line[2 * k + 1] = h[2 * k + 1]; }
+      for (int k = nzh; k < n; k++) { line[2 * k] = h[2 * (n - k)]; line[2 * k + 1] = -h[2 * (n - k) + 1]; }
+      line[1] = 0.0; line[2 * (n / 2) + 1] = 0.0;
+      fft1d(line, n, +1, c->tw, c->brev);
+      double *r = out + (size_t)w * n;
+      for (int z = 0; z < n; z++) r[z] = line[2 * z] * c->norm;
+    }
+    free(line);
+  }
+}
+
 /* ----------------------------------------------------------------------------------------------------------------
  * Sampled x-planes of a box that is too large for the whole oracle.
  *
@@ -1271,31 +1302,106 @@ int orc_plane_derivatives(orc_ctx *c, const double *spec, double rs_cells, int n
                  sizeof(double) * 2 * nzh);
     }
     free(acc);
-    /* y lines of every plane (fixed kz, stride nzh), then the c2r rows along z: what c2r_3d does for a whole box */
-    double *lines = (double *)malloc(sizeof(double) * 2 * n * ORC_FFT_BLOCK);
-    const int nblk = (nzh + ORC_FFT_BLOCK - 1) / ORC_FFT_BLOCK;
-#pragma omp for schedule(dynamic, 1)
-    for (int w = 0; w < ncomp * nplanes * nblk; w++) {
-      const int kz = (w % nblk) * ORC_FFT_BLOCK;
-      double *g = G + 2 * ((size_t)(w / nblk) * plane_c);
-      fft_strided_lines(c, g + 2 * kz, (size_t)nzh, nzh - kz < ORC_FFT_BLOCK ? nzh - kz : ORC_FFT_BLOCK, +1, lines);
-    }
-    free(lines);
-    double *line = (double *)malloc(sizeof(double) * 2 * n);
-#pragma omp for schedule(dynamic, 16)
-    for (long long w = 0; w < (long long)ncomp * nplanes * n; w++) {
-      const double *h = G + 2 * ((size_t)w * nzh);
-      for (int k = 0; k < nzh; k++) { line[2 * k] = h[2 * k]; line[2 * k + 1] = h[2 * k + 1]; }
-      for (int k = nzh; k < n; k++) { line[2 * k] = h[2 * (n - k)]; line[2 * k + 1] = -h[2 * (n - k) + 1]; }
-      line[1] = 0.0; line[2 * (n / 2) + 1] = 0.0;
-      fft1d(line, n, +1, c->tw, c->brev);
-      double *r = out + (size_t)w * n;
-      for (int z = 0; z < n; z++) r[z] = line[2 * z] * c->norm;
-    }
-    free(line);
   }
+  plane_finish(c, G, ncomp * nplanes, out);
   free(E); free(G);
   return 0;
+}
+
+/* The same on a spectrum that does not fit the host (BASELINE config 5: 2048^3): the rows of the spectrum arrive in pieces of
+   consecutive kx, in ascending order, and several radii are accumulated in one go.  Per (ky, kz) the sum over kx runs in the order of
+   orc_plane_derivatives, with the same expressions per mode: one radius streamed gives that function's result to the bit
+   (tests/test_oracle.py).  G: [nrad][ncomp][nplanes][n][nzh] complex. */
+struct orc_plane_acc {
+  orc_ctx *c;
+  int nrad, ncomp, nplanes, next_kx;
+  double rs[ORC_MAX_SMOOTH];
+  int ia[6], ib[6];
+  int *xs;
+  double *E, *G;
+};
+orc_plane_acc *orc_plane_acc_create(orc_ctx *c, int nrad, const double *rs_cells, int ncomp, const int *ia, const int *ib, int nplanes, const int *xs) {
+  if (!c || nrad < 1 || nrad > ORC_MAX_SMOOTH || ncomp < 1 || ncomp > 6 || nplanes < 1) return NULL;
+  const int n = c->n, nzh = c->nzh;
+  for (int k = 0; k < ncomp; k++) {
+    const int plain = ia[k] == -1 && ib[k] == -1;
+    if (!plain && !(ia[k] >= 1 && ia[k] <= 3 && ib[k] >= 1 && ib[k] <= 3)) return NULL;
+  }
+  for (int p = 0; p < nplanes; p++) if (xs[p] < 0 || xs[p] >= n) return NULL;
+  orc_plane_acc *a = (orc_plane_acc *)calloc(1, sizeof(*a));
+  a->c = c; a->nrad = nrad; a->ncomp = ncomp; a->nplanes = nplanes; a->next_kx = 0;
+  memcpy(a->rs, rs_cells, sizeof(double) * nrad); memcpy(a->ia, ia, sizeof(int) * ncomp); memcpy(a->ib, ib, sizeof(int) * ncomp);
+  a->xs = (int *)malloc(sizeof(int) * nplanes); memcpy(a->xs, xs, sizeof(int) * nplanes);
+  a->E = (double *)malloc(sizeof(double) * 2 * (size_t)n * nplanes);
+  for (int p = 0; p < nplanes; p++)
+    for (int idx = 0; idx < n; idx++) {
+      const int j = (int)(((long long)idx * xs[p]) % n);
+      a->E[2 * ((size_t)p * n + idx)] = c->tw[2 * j]; a->E[2 * ((size_t)p * n + idx) + 1] = c->tw[2 * j + 1];
+    }
+  a->G = (double *)calloc((size_t)2 * n * nzh * nrad * ncomp * nplanes, sizeof(double));
+  if (!a->G) { free(a->E); free(a->xs); free(a); return NULL; }
+  return a;
+}
+/* rows kx0 .. kx0 + nkx - 1: [nkx][n][nzh] complex.  Pieces must follow each other (kx0 = where the last one ended). */
+int orc_plane_acc_add(orc_plane_acc *a, const double *rows, int kx0, int nkx) {
+  orc_ctx *c = a->c;
+  const int n = c->n, nzh = c->nzh, Nhalf = n / 2, nrad = a->nrad, ncomp = a->ncomp, nplanes = a->nplanes;
+  const double knorm = 2. * ORC_PI / (double)n;
+  if (kx0 != a->next_kx || nkx < 1 || kx0 + nkx > n) return 1;
+  const size_t plane_c = (size_t)n * nzh;
+#pragma omp parallel for num_threads(c->nthreads) schedule(dynamic, 1)
+  for (int idy = 0; idy < n; idy++) {
+    int ii[3];
+    ii[1] = idy; if (ii[1] > Nhalf) ii[1] -= n;
+    const double k_y = knorm * ii[1];
+    for (int idx = kx0; idx < kx0 + nkx; idx++) {
+      ii[0] = idx; if (ii[0] > Nhalf) ii[0] -= n;
+      const double k_x = knorm * ii[0];
+      const double k2_0 = k_x * k_x;
+      const double k2_1 = k2_0 + k_y * k_y;
+      const double *row = rows + 2 * (((size_t)(idx - kx0) * n + idy) * nzh);
+      for (int idz = 0; idz < nzh; idz++) {
+        ii[2] = idz; if (ii[2] > Nhalf) ii[2] -= n;
+        const double k_z = knorm * ii[2];
+        const double k_squared = k2_1 + k_z * k_z;
+        double diff_comp[4];
+        diff_comp[0] = 1.0; diff_comp[1] = k_x; diff_comp[2] = k_y; diff_comp[3] = k_z;
+        double green[6];
+        for (int k = 0; k < ncomp; k++) green[k] = k_squared != 0. ? greens_function(diff_comp, k_squared, a->ia[k], a->ib[k]) : 1.0;
+        for (int r = 0; r < nrad; r++) {
+          const double Rsmooth = a->rs[r];
+          double smoothing = 1.0;
+          if (k_squared != 0.) smoothing = exp(-0.5 * k_squared * Rsmooth * Rsmooth);
+          for (int k = 0; k < ncomp; k++) {
+            double re = row[2 * idz], im = row[2 * idz + 1];
+            if (k_squared != 0.) {  /* the k = 0 mode is left untouched (:368) */
+              const double growth_rate = 1.0;
+              re *= green[k] * smoothing * growth_rate;
+              im *= green[k] * smoothing * growth_rate;
+            }
+            for (int p = 0; p < nplanes; p++) {
+              const double er = a->E[2 * ((size_t)p * n + idx)], ei = a->E[2 * ((size_t)p * n + idx) + 1];
+              double *g = a->G + 2 * ((((size_t)r * ncomp + k) * nplanes + p) * plane_c + (size_t)idy * nzh + idz);
+              g[0] += re * er - im * ei;
+              g[1] += re * ei + im * er;
+            }
+          }
+        }
+      }
+    }
+  }
+  a->next_kx = kx0 + nkx;
+  return 0;
+}
+/* every row added: the planes of radius irad, out [ncomp][nplanes][n][n].  (Transforms that radius' accumulators in place: once per radius.) */
+int orc_plane_acc_finish(orc_plane_acc *a, int irad, double *out) {
+  if (a->next_kx != a->c->n || irad < 0 || irad >= a->nrad) return 1;
+  plane_finish(a->c, a->G + 2 * ((size_t)irad * a->ncomp * a->nplanes * a->c->n * a->c->nzh), a->ncomp * a->nplanes, out);
+  return 0;
+}
+void orc_plane_acc_destroy(orc_plane_acc *a) {
+  if (!a) return;
+  free(a->G); free(a->E); free(a->xs); free(a);
 }
 
 /* compute_collapse_times (src/collapse_times.c:431-673) on a list of cells: d6 = [6][ncells] in the storage order

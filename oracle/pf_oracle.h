@@ -155,5 +155,13 @@ orc_ctx *orc_create_planes(int n, int nthreads);
 int orc_plane_derivatives(orc_ctx *c, const double *spec, double rs_cells, int ncomp, const int *ia, const int *ib,
                           int nplanes, const int *xs, double *out);
 int orc_plane_collapse_times(orc_ctx *c, int ismooth, size_t ncells, const double *d6, ORC_PRODFLOAT *fmax, int *rmax);
+/* orc_plane_derivatives for a spectrum that does not fit the host (BASELINE config 5, 2048^3: 69 GB in fp64): the rows of the
+   spectrum are added in pieces of consecutive kx (ascending, all of them), several radii at once; then the planes of each radius
+   are finished.  The per-mode expressions and the order of the sum over kx are those of orc_plane_derivatives. */
+typedef struct orc_plane_acc orc_plane_acc;
+orc_plane_acc *orc_plane_acc_create(orc_ctx *c, int nrad, const double *rs_cells, int ncomp, const int *ia, const int *ib, int nplanes, const int *xs);
+int orc_plane_acc_add(orc_plane_acc *a, const double *rows, int kx0, int nkx);
+int orc_plane_acc_finish(orc_plane_acc *a, int irad, double *out);
+void orc_plane_acc_destroy(orc_plane_acc *a);
 
 #endif

@@ -100,6 +100,7 @@ PROTOTYPES = {
     "pf_debug_lines": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, _dp, _dp]),
     "pf_debug_pk": (C.c_int, [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]),
     "pf_debug_gfft": (C.c_int, [C.c_int, C.c_int, _dp, _dp]),
+    "pf_debug_gfft_lines": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp]),
     "pf_debug_strided_jobs": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, _dp, _dp]),
     "pf_debug_invariant_reruns": (C.c_int, [_vp]),
     "pf_solve_ran_beside_zpass": (C.c_int, [_vp]),
@@ -117,6 +118,8 @@ PROTOTYPES = {
     "pf_get_second_derivative": (C.c_int, [_vp, C.c_int, _dp]),
     "pf_get_kvector": (C.c_int, [_vp, C.c_int, _dp]),
     "pf_get_density": (C.c_int, [_vp, _dp]),
+    "pf_debug_replicated_rows": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
+    "pf_plan_bytes": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "pf_forward_transform": (C.c_int, [_vp, _dp, _dp]),
     "pf_reverse_transform": (C.c_int, [_vp, _dp, _dp]),
     "pf_collapse_cells": (C.c_int, [_vp, C.c_int, _dp, C.c_size_t, _dp]),

@@ -31,6 +31,16 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+def plan_bytes(n: int, nranks: int = 1, field_bytes: int = 8, double_products: bool = False):
+    """(bytes pf_create allocates, bytes held at most) per rank of this configuration -- pf_plan_bytes; no device needed"""
+    L = _lib.load()
+    cfg = _lib.Config(n=n, rank=0, nranks=nranks, device=0, field_bytes=field_bytes, flags=_lib.FLAG_DOUBLE_PRODUCTS if double_products else 0)
+    a, b = C.c_size_t(), C.c_size_t()
+    if L.pf_plan_bytes(C.byref(cfg), C.byref(a), C.byref(b)):
+        raise PinfmaxError("pf_plan_bytes: bad configuration")
+    return a.value, b.value
+
+
 class Fmax:
     """One rank's context: an x-slab of an n^3 grid on one MI355X."""
 
@@ -259,6 +269,12 @@ class Fmax:
     def density(self) -> np.ndarray:
         out = np.empty((self.nxl, self.n, self.n // 2 + 1), dtype=np.complex128)
         self._chk(self.L.pf_get_density(self.h, _dp(out.view(np.float64))))
+        return out
+
+    def replicated_rows(self, kx0: int, nkx: int) -> np.ndarray:
+        """rows kx0 .. kx0 + nkx - 1 of the whole delta(k) a PF_REPLICATE_DK context transforms -> [nkx][n][n/2+1] complex128"""
+        out = np.empty((nkx, self.n, self.n // 2 + 1), dtype=np.complex128)
+        self._chk(self.L.pf_debug_replicated_rows(self.h, int(kx0), int(nkx), _dp(out.view(np.float64))))
         return out
 
     def forward_transform(self, real: np.ndarray) -> np.ndarray:

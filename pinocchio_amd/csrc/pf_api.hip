@@ -99,6 +99,11 @@ struct pf_ctx {
   size_t dev_bytes;
   char *blockA;        // A[0..2] contiguous (also host<->device staging through A[1..2])
   void *dk, *A[3], *B[6], *B2[6], *S[3];
+  // S[0..2] and B2[0..5] are pieces of ONE allocation each (blockS at pf_create, blockB2 at first use: the LPT part, or a sweep that
+  // needs a second field set).  fp32 fields: the fp64 invariant rows of the sweep live in them -- a row set of ncell doubles is two
+  // fields long to within the row padding -- since the sweep and the LPT part never hold both (inv_rows; 234 -> 200 GB per rank for
+  // BASELINE config 5)
+  char *blockS, *blockB2;
   void *recvA;         // P > 1: 3 fields, all-to-all destination
   // P > 1 (PF_REPLICATE_DK, default on): every rank also holds the WHOLE delta(k), [kx][ky][kz] with row pitch nzp.  The
   // passes that start from delta(k) -- the second derivatives of every radius and the Zel'dovich displacements -- then
@@ -106,8 +111,15 @@ struct pf_ctx {
   // a 12-radius step, at the price of an x-pass that does not shrink with P.  Gathered once per density (dk_full_valid).
   void *dk_full;
   bool replicate, dk_full_valid;
-  double *INV[2][3];   // fp32 fields: the fp64 invariant rows of the sweep's z-pass (compact, pitch n), allocated at first use; two
-                       // sets for the solve stream (the z-pass writes set inv_w while the solve of the radius before reads the other)
+  // the recipe of the resident density when it came from pf_genic_density (with its own copies of a tabulated spectrum's knots): a rank
+  // that runs on its own behind the loopback exchange generates the WHOLE replicated spectrum from it (ensure_dk_full)
+  bool have_genic;
+  pf_genic_params genic;
+  std::vector<double> genic_logk, genic_logk3p;
+  double *INV[2][3];   // fp32 fields: the fp64 invariant rows of the sweep's z-pass (compact, pitch n), placed at first use (inv_rows); two
+                       // sets for the solve stream (the z-pass writes set inv_w while the solve of the radius before reads the other).
+                       // Set 1 is blockB2, INV[0][0] is blockS (fields 0, 1); INV[0][1..2] are allocations of their own (inv_own)
+  double *inv_own[2];
   int inv_w;
   // P > 1: second set of send/receive fields and a communication stream, so that the all-to-all of transform i+1
   // runs beside the y/z passes (and the collapse solve) of transform i (pipelined(), PF_PIPELINE=0 to disable)
@@ -225,9 +237,41 @@ static void resolve_events(pf_ctx *c) {
   c->phase_evs.clear();
 }
 
+static size_t ncell_of(const pf_ctx *c) { return (size_t)c->nxl * c->n * c->n; }
 static int dev_alloc(pf_ctx *c, void **p, size_t bytes) {
   HIPCHK(c, hipMalloc(p, bytes));
   c->dev_bytes += bytes;
+  return 0;
+}
+
+// the second field set B2[0..5] (one allocation): the Hessian of the 2LPT potential and the scratch of the displacement passes, the
+// second field set of a sweep with the solve stream and fp64 fields, the second set of invariant rows with fp32 fields.
+// quiet: a failure is the caller's to handle (a sweep falls back to one field set), nothing is printed
+static int ensure_b2(pf_ctx *c, bool quiet = false) {
+  if (c->blockB2) return 0;
+  if (hipMalloc((void **)&c->blockB2, 6 * c->field_bytes) != hipSuccess) {
+    (void)hipGetLastError(); c->blockB2 = nullptr;
+    return quiet ? 1 : pf_fail(c->rank, "hipMalloc of the second field set failed (%.1f GB; %.1f GB held by this context)", 6e-9 * c->field_bytes, 1e-9 * c->dev_bytes);
+  }
+  c->dev_bytes += 6 * c->field_bytes;
+  for (int i = 0; i < 6; i++) c->B2[i] = c->blockB2 + i * c->field_bytes;
+  return 0;
+}
+// fp32 fields: where the three fp64 invariant rows (ncell doubles each, pitch n) of set 0 / 1 live.  Set 1: the six fields of
+// blockB2, two per row set; set 0: blockS (fields 0 and 1) and two allocations of its own.  2 fields = n nyl (n + 32) 8 bytes
+// >= ncell 8 bytes, whatever P.  The LPT source spectra that may be resident in S are gone after a sweep that uses them so.
+static int inv_rows(pf_ctx *c, int set, bool quiet = false) {
+  if (c->INV[set][0]) return 0;
+  const size_t row_set = ncell_of(c) * sizeof(double);
+  if (2 * c->field_bytes < row_set) return pf_fail(c->rank, "internal: an invariant row set does not fit two fields");
+  if (set == 1) {
+    if (ensure_b2(c, quiet)) return 1;
+    for (int k = 0; k < 3; k++) c->INV[1][k] = (double *)(c->blockB2 + 2 * k * c->field_bytes);
+    return 0;
+  }
+  for (int k = 0; k < 2; k++)
+    if (!c->inv_own[k]) PFCHK(c, dev_alloc(c, (void **)&c->inv_own[k], row_set));
+  c->INV[0][0] = (double *)c->blockS; c->INV[0][1] = c->inv_own[0]; c->INV[0][2] = c->inv_own[1];
   return 0;
 }
 
@@ -271,6 +315,7 @@ static void read_tuning(PfTuning *t) {
   t->exact_libm = env_int("PF_EXACT_LIBM", 0) != 0;
   t->solve_beside_z = env_int("PF_SOLVE_BESIDE_Z", -1);
   t->gtab = env_int("PF_GTAB", 1) != 0;
+  t->preflight = env_int("PF_PREFLIGHT", 1) != 0;
   // fault injection for the tests of the exchange pipeline (tests/test_gpu_multirank.py): "recv" drops the wait of the
   // compute stream for the exchange it is about to consume, "send" the wait of the exchange for the x-pass that fills its blocks
   const char *fault = getenv("PF_DEBUG_PIPELINE_FAULT");
@@ -279,9 +324,58 @@ static void read_tuning(PfTuning *t) {
   if (const char *e = getenv("PF_PRUNE_EPS")) t->prune_eps = atof(e);
 }
 
+// Device memory of a context, in bytes: what pf_create allocates (*at_create) and the most it holds once a sweep and the LPT part
+// have run (*peak: + the second field set, + two invariant row sets of their own with fp32 fields).  The formula create_body and
+// the lazy allocations follow; pf_create holds it against hipMemGetInfo before it allocates anything.
+static void plan_bytes(const pf_ctx *c, size_t *at_create, size_t *peak) {
+  const size_t field = c->field_bytes, nc = ncell_of(c);
+  size_t fields = 1 + 3 + 6 + 3;                       // dk, A, B, S
+  if (c->P > 1) fields += 3;                            // recvA
+  if (c->replicate) fields += (size_t)c->P;             // dk_full
+  if (c->pipeline) fields += 6;                         // blockA2, recvA2
+  if (c->general) fields += 1;                          // W
+  size_t b = fields * field + nc * ((size_t)c->pb + sizeof(int) + 12 * (size_t)c->pb);
+  b += (2 * PF_NBLK + PF_NBLK + SC_COUNT) * sizeof(double) + PF_NBINS * sizeof(unsigned long long) +
+       (size_t)(PF_MAX_SMOOTH + 1) * (5 * PF_KNOT_CAP * sizeof(double) + PF_GT_DOUBLES * sizeof(double) + PF_GT_MAX_BINS * sizeof(unsigned short)) +
+       4 * PF_KBIN_CAP * sizeof(double) + (size_t)c->n * sizeof(double) + (size_t)c->n * 2 * c->fb;
+  *at_create = b;
+  b += 6 * field;                                       // blockB2
+  if (c->fb == 4 && !c->general && pf_c2r_invariants_supported(c->fb, c->n)) b += 2 * nc * sizeof(double);  // inv_own
+  *peak = b;
+}
+extern "C" int pf_plan_bytes(const pf_config *cfg, size_t *at_create, size_t *peak) {
+  if (!cfg || cfg->nranks < 1 || cfg->n < 4 || cfg->n % cfg->nranks || (cfg->field_bytes != 4 && cfg->field_bytes != 8)) return 1;
+  PfTuning tune;
+  read_tuning(&tune);
+  pf_ctx v;   // (a view that is never created: geometry only)
+  const int n = (int)cfg->n;
+  const bool pow2 = !(n & (n - 1));
+  v.n = n; v.P = cfg->nranks; v.fb = cfg->field_bytes; v.pb = (cfg->flags & PF_FLAG_DOUBLE_PRODUCTS) ? 8 : 4;
+  v.general = tune.general || (!pow2 && !pf_mixed_supported(n));
+  v.nzh = n / 2 + 1; v.nzp = v.general ? v.nzh : n / 2 + 64 / v.fb; v.nxl = v.nyl = n / v.P;
+  v.field_bytes = (size_t)v.n * v.nyl * v.nzp * 2 * v.fb;
+  v.pipeline = v.P > 1 && tune.pipeline;
+  v.replicate = v.P > 1 && !v.general && (tune.replicate < 0 ? v.P <= 4 : tune.replicate != 0);
+  size_t a = 0, b = 0;
+  plan_bytes(&v, &a, &b);
+  if (at_create) *at_create = a;
+  if (peak) *peak = b;
+  return 0;
+}
+
 static int create_body(pf_ctx *c, const pf_config *cfg) {
   const int rank = cfg->rank;
   HIPCHK(c, hipSetDevice(cfg->device));
+  c->field_bytes = (size_t)c->n * c->nyl * c->nzp * 2 * c->fb;
+  c->replicate = c->P > 1 && !c->general && (c->tune.replicate < 0 ? c->P <= 4 : c->tune.replicate != 0);
+  if (c->tune.preflight) {  // the whole plan against the device's free memory, before anything is allocated (PF_PREFLIGHT=0: no check)
+    size_t at_create = 0, peak = 0, free_b = 0, total_b = 0;
+    plan_bytes(c, &at_create, &peak);
+    HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
+    if (peak > free_b)
+      return pf_fail(rank, "pf_create: %d^3 on %d ranks with %d-byte fields needs %.1f GB of device memory per rank (%.1f GB at creation, the rest with the "
+                           "LPT part), device %d has %.1f GB free of %.1f GB", c->n, c->P, c->fb, 1e-9 * peak, 1e-9 * at_create, cfg->device, 1e-9 * free_b, 1e-9 * total_b);
+  }
   HIPCHK(c, hipStreamCreate(&c->stream));
   HIPCHK(c, hipStreamCreate(&c->cstream));
   {  // the solve stream takes what the compute stream leaves: lowest priority
@@ -307,17 +401,16 @@ static int create_body(pf_ctx *c, const pf_config *cfg) {
     c->collapse_blocks = prop.multiProcessorCount * c->tune.collapse_wg_per_cu;
     if (c->collapse_blocks > PF_NBLK) c->collapse_blocks = PF_NBLK;
   }
-  c->field_bytes = (size_t)c->n * c->nyl * c->nzp * 2 * c->fb;
   PFCHK(c, dev_alloc(c, &c->dk, c->field_bytes));
   PFCHK(c, dev_alloc(c, (void **)&c->blockA, 3 * c->field_bytes));
   for (int i = 0; i < 3; i++) c->A[i] = c->blockA + i * c->field_bytes;
   for (int i = 0; i < 6; i++) PFCHK(c, dev_alloc(c, &c->B[i], c->field_bytes));
-  for (int i = 0; i < 3; i++) PFCHK(c, dev_alloc(c, &c->S[i], c->field_bytes));
+  PFCHK(c, dev_alloc(c, (void **)&c->blockS, 3 * c->field_bytes));
+  for (int i = 0; i < 3; i++) c->S[i] = c->blockS + i * c->field_bytes;
   if (c->P > 1) PFCHK(c, dev_alloc(c, &c->recvA, 3 * c->field_bytes));
   // default: up to four ranks.  There the all-to-alls of the sweep cost more link time than its kernels take (one xGMI link
   // per peer pair: N^3 W / P^2 bytes per field and link), while the replicated x-pass costs each rank one more read of the
   // whole delta(k) per radius; from eight ranks on the transposes are small enough to hide behind the kernels
-  c->replicate = c->P > 1 && !c->general && (c->tune.replicate < 0 ? c->P <= 4 : c->tune.replicate != 0);
   if (c->replicate) PFCHK(c, dev_alloc(c, &c->dk_full, (size_t)c->P * c->field_bytes));
   if (c->pipeline) {
     PFCHK(c, dev_alloc(c, (void **)&c->blockA2, 3 * c->field_bytes));
@@ -390,13 +483,13 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   c->a2a = nullptr; c->a2av = nullptr; c->a2av_user = nullptr; c->ared = nullptr; c->a2a_user = c->ared_user = nullptr; c->rccl = nullptr;
   c->have_density = c->have_hessian = c->have_sources = c->products_init = false; c->last_ns = 0;
   c->sweep_sources = c->sources_fresh = false; c->partials_src = nullptr; c->lpt_order = 3; c->ct_flavour = 0; c->transposed = false;
-  c->vel_zero_pending = false;
+  c->vel_zero_pending = false; c->have_genic = false;
   memset(c->ks_ms, 0, sizeof(c->ks_ms)); memset(c->ks_bytes, 0, sizeof(c->ks_bytes)); memset(c->ks_n, 0, sizeof(c->ks_n));
   memset(&c->cpu, 0, sizeof(c->cpu)); memset(c->spl_set, 0, sizeof(c->spl_set)); memset(c->spl_n, 0, sizeof(c->spl_n));
   c->growth[0] = 1.0; c->growth[1] = 3. / 7.; c->growth[2] = -1. / 9.; c->growth[3] = 5. / 42.;
   for (int i = 0; i < 6; i++) { c->B[i] = nullptr; c->B2[i] = nullptr; }
   c->blockA = nullptr; c->dk = nullptr; c->recvA = nullptr; c->tw = nullptr;
-  c->blockA2 = nullptr; c->recvA2 = nullptr; c->cstream = nullptr; c->dk_full = nullptr; c->replicate = false; c->dk_full_valid = false; for (int k = 0; k < 3; k++) c->INV[0][k] = c->INV[1][k] = nullptr; c->inv_w = 0;
+  c->blockA2 = nullptr; c->recvA2 = nullptr; c->cstream = nullptr; c->dk_full = nullptr; c->replicate = false; c->dk_full_valid = false; for (int k = 0; k < 3; k++) c->INV[0][k] = c->INV[1][k] = nullptr; c->inv_w = 0; c->inv_own[0] = c->inv_own[1] = nullptr; c->blockS = c->blockB2 = nullptr;
   c->fmax = nullptr; c->rmax = nullptr; c->vel12 = nullptr; c->partials = nullptr; c->scal = nullptr; c->hist = nullptr; c->spl = nullptr;
   c->gtab = nullptr; c->etab = nullptr; c->ct_block = nullptr; c->gt = nullptr; c->gt_lut = nullptr;
   memset(c->gt_ok, 0, sizeof(c->gt_ok)); memset(c->gt_err, 0, sizeof(c->gt_err));
@@ -424,9 +517,9 @@ extern "C" int pf_destroy(pf_ctx *c) {
   if (c->sstream) hipStreamSynchronize(c->sstream);
   pf_rccl_release(c->rccl); c->rccl = nullptr;
   delete c->loopback; c->loopback = nullptr;
-  hipFree(c->dk); hipFree(c->blockA); hipFree(c->recvA); hipFree(c->tw); hipFree(c->blockA2); hipFree(c->recvA2); hipFree(c->dk_full); for (int k = 0; k < 3; k++) { hipFree(c->INV[0][k]); hipFree(c->INV[1][k]); }
-  for (int i = 0; i < 6; i++) { hipFree(c->B[i]); hipFree(c->B2[i]); }
-  for (int i = 0; i < 3; i++) hipFree(c->S[i]);
+  hipFree(c->dk); hipFree(c->blockA); hipFree(c->recvA); hipFree(c->tw); hipFree(c->blockA2); hipFree(c->recvA2); hipFree(c->dk_full); hipFree(c->inv_own[0]); hipFree(c->inv_own[1]);
+  for (int i = 0; i < 6; i++) hipFree(c->B[i]);
+  hipFree(c->blockS); hipFree(c->blockB2);
   hipFree(c->fmax); hipFree(c->rmax); hipFree(c->vel12); hipFree(c->partials); hipFree(c->partials_src); hipFree(c->scal); hipFree(c->hist); hipFree(c->spl); hipFree(c->gt); hipFree(c->gt_lut); hipFree(c->gtab); hipFree(c->etab); hipFree(c->ct_block); hipFree(c->W);
   pf_gfft_destroy(c->fft_c2r);
   if (c->fft_r2c != c->fft_c2r) pf_gfft_destroy(c->fft_r2c);
@@ -653,11 +746,10 @@ static int zpass_c2r(pf_ctx *c, int kind, int njobs, const ZJob *jobs, const dou
   }
   if (invariants) {  // six components in, the three invariants of the tensor out (fields 0..2; fp32 fields: fp64 rows in INV)
     if (c->fb == 4) {
-      for (int k = 0; k < 3; k++) {
-        if (!c->INV[c->inv_w][k]) PFCHK(c, dev_alloc(c, (void **)&c->INV[c->inv_w][k], ncell(c) * sizeof(double)));
-        p.inv_out[k] = c->INV[c->inv_w][k];
-      }
+      if (inv_rows(c, c->inv_w)) return 1;
+      for (int k = 0; k < 3; k++) p.inv_out[k] = c->INV[c->inv_w][k];
       p.inv_pitch = c->n;
+      if (c->inv_w == 0) c->have_sources = false;  // (row 0 of set 0 lies in S[0..1]: LPT spectra resident there are overwritten)
     }
     KTimer t(c, KS_ZPASS_INV, njobs * frac_in * spec_bytes_alg(c) + 3.0 * (double)ncell(c) * 8.0);
     PFCHK(c, pf_launch_c2r_invariants(c->fb, c->n, p, c->stream));
@@ -810,6 +902,20 @@ static int hess_x(pf_ctx *c, const void *spec, double rs, void *const A[3], int 
 // and an integer all-reduce adds the other ranks' zeros to it (exact for either field type; ~2 x 8.6 GB per rank at 1024^3)
 static int ensure_dk_full(pf_ctx *c) {
   if (!c->replicate || c->dk_full_valid) return 0;
+  if (c->a2a == loopback_a2a) {
+    // One rank on its own (pf_set_loopback_exchange): no peer contributes its slab.  A density that came from pf_genic_density is a
+    // function of (seed, cosmology) alone, every column on its own: the rank generates all P ky-slabs itself -- the KY layout of ONE
+    // rank of the whole box is the layout of dk_full -- and the sweep that follows runs on the box's own delta(k), exchange-free.
+    if (!c->have_genic)
+      return pf_fail(c->rank, "a replicated spectrum behind the loopback exchange needs a density every rank can generate whole (pf_genic_density)");
+    unsigned int *dseed = nullptr;
+    const int rc = pf_genic_launch(c->fb, c->dk_full, c->n, c->nzp, c->n, 0, &c->genic, c->stream, &dseed);
+    if (!rc) HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(dseed);
+    if (rc) return pf_fail(c->rank, "pf_genic_density (whole spectrum): launch failed");
+    c->dk_full_valid = true;
+    return 0;
+  }
   const size_t rows = (size_t)c->nyl * c->nzp * 2 * c->fb;  // the nyl rows this rank holds of one kx plane
   HIPCHK(c, hipMemsetAsync(c->dk_full, 0, (size_t)c->P * c->field_bytes, c->stream));
   HIPCHK(c, hipMemcpy2DAsync((char *)c->dk_full + (size_t)c->rank * rows, (size_t)c->P * rows, c->dk, rows, rows, (size_t)c->n,
@@ -1015,6 +1121,7 @@ extern "C" int pf_set_density(pf_ctx *c, const double *kd) {
   // boundary layout: this rank's x-slab [nxl][n][nzh] (non-transposed PFFT output, src/fmax-pfft.c:366)
   PFCHK(c, import_spec(c, kd, c->dk));
   PFCHK(c, dc_of_host_spec(c, kd, SC_DC_DK));
+  c->have_genic = false;
   c->have_density = true; c->have_hessian = false; c->have_sources = false; c->sources_fresh = false; c->dk_full_valid = false;
   return 0;
 }
@@ -1040,6 +1147,7 @@ extern "C" int pf_synth_density(pf_ctx *c, uint64_t seed, double sigma0, double 
   PFCHK(c, pf_launch_shape(c->fb, p, c->stream));
   HIPCHK(c, hipMemsetAsync(c->scal + SC_DC_DK, 0, sizeof(double), c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->have_genic = false;
   c->have_density = true; c->have_hessian = false; c->have_sources = false; c->sources_fresh = false; c->dk_full_valid = false;
   return 0;
 }
@@ -1056,6 +1164,12 @@ extern "C" int pf_genic_density(pf_ctx *c, const pf_genic_params *p) {
   HIPCHK(c, hipMemsetAsync(c->scal + SC_DC_DK, 0, sizeof(double), c->stream));  // the DC mode is left at zero
   HIPCHK(c, hipStreamSynchronize(c->stream));
   hipFree(dseed);
+  c->genic = *p;
+  if (p->pk_n > 0 && p->pk_logk && p->pk_logk3p) {
+    c->genic_logk.assign(p->pk_logk, p->pk_logk + p->pk_n); c->genic_logk3p.assign(p->pk_logk3p, p->pk_logk3p + p->pk_n);
+    c->genic.pk_logk = c->genic_logk.data(); c->genic.pk_logk3p = c->genic_logk3p.data();
+  }
+  c->have_genic = true;
   c->have_density = true; c->have_hessian = false; c->have_sources = false; c->sources_fresh = false; c->dk_full_valid = false;
   return 0;
 }
@@ -1350,17 +1464,8 @@ static int sweep_body_run(pf_ctx *c, int ns, const double *radius_cells, double 
   bool beside_z = invariants_ok && (c->tune.solve_beside_z < 0 ? c->fb == 4 : c->tune.solve_beside_z != 0);
   // the second field set B2 (six fields: 52 GB at 1024^3 on one rank) is what the LPT part allocates anyway; an Fmax-only run that
   // cannot have it keeps every kernel in line on one field set instead of failing
-  if (beside_z && c->fb == 8) {
-    void *fresh[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    for (int i = 0; i < 6; i++) {
-      if (c->B2[i]) continue;
-      if (hipMalloc(&c->B2[i], c->field_bytes) != hipSuccess) { (void)hipGetLastError(); c->B2[i] = nullptr; beside_z = false; break; }
-      fresh[i] = c->B2[i]; c->dev_bytes += c->field_bytes;
-    }
-    if (!beside_z)
-      for (int i = 0; i < 6; i++)
-        if (fresh[i]) { hipFree(fresh[i]); c->B2[i] = nullptr; c->dev_bytes -= c->field_bytes; }
-  }
+  if (beside_z && c->fb == 8 && ensure_b2(c, true)) beside_z = false;
+  if (beside_z && c->fb == 4 && inv_rows(c, 1, true)) beside_z = false;  // (fp32 fields: the second set of invariant rows is that block)
   const bool two_field_sets = beside_z && c->fb == 8;  // (fp32 fields keep their invariants apart, in INV: two sets of those)
   struct { bool valid; int ismooth, set; } pending = {false, 0, 0};  // the solve that waits for the next z-pass
   bool s_live[2] = {false, false};  // a solve on the solve stream reads set s; ev_s[s] tells when it is done
@@ -1490,8 +1595,7 @@ extern "C" int pf_set_sources_in_sweep(pf_ctx *c, int on) {
 extern "C" int pf_displacements(pf_ctx *c, int compute_sources, int recompute_sd) {
   if (!c) return 1;
   if (!c->have_density) return pf_fail(c->rank, "pf_displacements: density not set");
-  for (int i = 0; i < 6; i++)
-    if (!c->B2[i]) PFCHK(c, dev_alloc(c, &c->B2[i], c->field_bytes));
+  if (ensure_b2(c)) return 1;
   if (!c->products_init) {
     PFCHK(c, pf_launch_fill_products(c->fmax, c->rmax, c->vel12, ncell(c), c->pb, c->stream));
     c->products_init = true;
@@ -1674,6 +1778,21 @@ extern "C" int pf_get_kvector(pf_ctx *c, int which, double *host) {
   if (!c || !host || which < 0 || which > 2) return pf_fail(0, "pf_get_kvector: bad argument");
   if (!c->have_sources) return pf_fail(c->rank, "pf_get_kvector: LPT sources not computed");
   return export_spec(c, c->S[which], host);
+}
+// test tap: rows kx0 .. kx0 + nkx - 1 of the replicated spectrum this rank transforms, [nkx][n (ky)][n/2+1] complex fp64 (gathered or
+// generated first if it is not in place yet)
+extern "C" int pf_debug_replicated_rows(pf_ctx *c, int kx0, int nkx, double *host) {
+  if (!c || !host || kx0 < 0 || nkx < 1 || kx0 + nkx > c->n) return pf_fail(0, "pf_debug_replicated_rows: bad argument");
+  if (!c->replicate) return pf_fail(c->rank, "pf_debug_replicated_rows: this context does not keep the whole spectrum (PF_REPLICATE_DK)");
+  if (!c->have_density) return pf_fail(c->rank, "pf_debug_replicated_rows: density not set");
+  PFCHK(c, ensure_dk_full(c));
+  const long long nrows = (long long)nkx * c->n;
+  if ((size_t)nrows * c->nzh * 2 * sizeof(double) > 2 * c->field_bytes) return pf_fail(c->rank, "pf_debug_replicated_rows: %d rows exceed the staging area", nkx);
+  const char *src = (const char *)c->dk_full + (size_t)kx0 * c->n * c->nzp * 2 * c->fb;
+  PFCHK(c, pf_launch_spec_export(c->fb, src, (double *)staging(c), nrows, c->nzh, c->nzp, c->stream));
+  HIPCHK(c, hipMemcpyAsync(host, staging(c), (size_t)nrows * c->nzh * 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
 }
 extern "C" int pf_get_density(pf_ctx *c, double *host) {
   if (!c || !host) return 1;

@@ -15,6 +15,7 @@
 // spectrum, z between the spectrum rows and the real rows (Hermitian rows extended to n points; FFTW semantics: the imaginary
 // parts of the DC and Nyquist modes are ignored).  ~6 M log M operations per line where a direct plan needs n log n: this is the
 // path of completeness, at a fraction of the hand-planned sizes' speed (profiles/r05_notes.md).
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -111,10 +112,13 @@ __global__ void __launch_bounds__(1024) k_blue(const PfBlueParams p) {
 template <int M, int MODE> static int blue_launch_m(const PfBlueParams &p, hipStream_t st) {
   constexpr int NT = M / 8, T = 1024 / NT < 1 ? 1 : 1024 / NT;
   const size_t shm = (size_t)M * T * sizeof(pfc<double>);
-  static bool raised = false;
-  if (shm > 64 * 1024 && !raised) {
+  // (the attribute belongs to the kernel ON ONE DEVICE: a flag per device, as pf_launch_strided16 keeps them)
+  static std::atomic<bool> raised[PF_MAX_DEVICES];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PF_MAX_DEVICES) return 3;
+  if (shm > 64 * 1024 && !raised[dev].load(std::memory_order_acquire)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blue<M, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return 3;
-    raised = true;
+    raised[dev].store(true, std::memory_order_release);
   }
   const long long nblk = (p.nlines + T - 1) / T;
   hipLaunchKernelGGL((k_blue<M, MODE>), dim3((unsigned)nblk), dim3(NT * T), shm, st, p);
@@ -238,17 +242,14 @@ int pf_gfft_r2c(void *plan, void *real, void *spec) {
   const long long n = pl->n, nzh = n / 2 + 1;
   PfBlueParams p;
   blue_common(pl, p, 1);
-  const char *dbg = getenv("PF_GFFT_DEBUG_PASSES");  // (debugging aid: bit 0 z, bit 1 y, bit 2 x; unset: all)
-  const int passes = dbg ? atoi(dbg) : 7;
   p.in = real; p.out = spec; p.mode = 2;
   p.os_in = 0; p.ls_in = n; p.es_in = 1; p.os_out = 0; p.ls_out = nzh; p.es_out = 1; p.ninner = (int)(n * n); p.nlines = n * n;
-  if (passes & 1) if (int rc = blue_dispatch(pl->M, p, pl->st)) return rc;
+  if (int rc = blue_dispatch(pl->M, p, pl->st)) return rc;
   p.in = spec; p.mode = 0;
   p.os_in = p.os_out = n * nzh; p.ls_in = p.ls_out = 1; p.es_in = p.es_out = nzh; p.ninner = (int)nzh; p.nlines = n * nzh;
-  if (passes & 2) if (int rc = blue_dispatch(pl->M, p, pl->st)) return rc;
+  if (int rc = blue_dispatch(pl->M, p, pl->st)) return rc;
   p.os_in = p.os_out = 0; p.ls_in = p.ls_out = 1; p.es_in = p.es_out = n * nzh; p.ninner = (int)(n * nzh); p.nlines = n * nzh;
-  if (passes & 4) return blue_dispatch(pl->M, p, pl->st);
-  return 0;
+  return blue_dispatch(pl->M, p, pl->st);
 }
 void pf_gfft_destroy(void *plan) {
   if (!plan) return;
@@ -276,6 +277,36 @@ extern "C" int pf_debug_gfft(int n, int dir, const double *in, double *out) {
     }
   }
   (void)hipFree(dspec); (void)hipFree(dreal);
+  pf_gfft_destroy(a);
+  return rc;
+}
+
+// test tap without a context: ONE pass of k_blue on a few lines of n points (any even n in 4..2048: M = 16 .. 4096 -- the sizes a
+// whole n^3 box of which no test can afford), host in / host out.  mode 0: complex lines stored as the x- and y-passes of the 3-D
+// transforms meet them, [n][nlines] (adjacent lines adjacent in memory, elements nlines apart), dir > 0 inverse, < 0 forward;
+// mode 1: Hermitian rows [nlines][n/2+1] -> real rows [nlines][n] (inverse); mode 2: real rows -> Hermitian rows (forward).  Unnormalised.
+extern "C" int pf_debug_gfft_lines(int n, int mode, int dir, int nlines, const double *in, double *out) {
+  if (!in || !out || nlines < 1 || mode < 0 || mode > 2) return 1;
+  void *a = nullptr, *b = nullptr;
+  if (pf_gfft_create(n, nullptr, &a, &b)) return 1;
+  const PfBluePlan *pl = (const PfBluePlan *)a;
+  const long long nzh = n / 2 + 1;
+  const size_t n_in = mode == 0 ? (size_t)2 * n * nlines : mode == 1 ? (size_t)2 * nzh * nlines : (size_t)n * nlines;
+  const size_t n_out = mode == 0 ? (size_t)2 * n * nlines : mode == 1 ? (size_t)n * nlines : (size_t)2 * nzh * nlines;
+  double *din = nullptr, *dout = nullptr;
+  int rc = 1;
+  if (hipMalloc((void **)&din, n_in * sizeof(double)) == hipSuccess && hipMalloc((void **)&dout, n_out * sizeof(double)) == hipSuccess &&
+      hipMemcpy(din, in, n_in * sizeof(double), hipMemcpyHostToDevice) == hipSuccess && hipMemset(dout, 0, n_out * sizeof(double)) == hipSuccess) {
+    PfBlueParams p;
+    blue_common(pl, p, mode == 0 ? (dir > 0 ? 0 : 1) : mode == 1 ? 0 : 1);
+    p.in = din; p.out = dout; p.mode = mode; p.nlines = nlines; p.ninner = nlines;
+    if (mode == 0) { p.os_in = p.os_out = 0; p.ls_in = p.ls_out = 1; p.es_in = p.es_out = nlines; }
+    else if (mode == 1) { p.os_in = 0; p.ls_in = nzh; p.es_in = 1; p.os_out = 0; p.ls_out = n; p.es_out = 1; }
+    else { p.os_in = 0; p.ls_in = n; p.es_in = 1; p.os_out = 0; p.ls_out = nzh; p.es_out = 1; }
+    if (blue_dispatch(pl->M, p, nullptr) == 0 && hipDeviceSynchronize() == hipSuccess &&
+        hipMemcpy(out, dout, n_out * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess) rc = 0;
+  }
+  (void)hipFree(din); (void)hipFree(dout);
   pf_gfft_destroy(a);
   return rc;
 }

@@ -17,7 +17,9 @@
 // or 6 components) instead of one library transform per component.
 // What these kernels do not have: the paired radix-16 stage, two columns per thread, waves that only reduce in the invariant z-pass.
 #include <cstring>
+#include <mutex>
 #include <utility>
+#include <vector>
 
 #include "pf_internal.h"
 #include "pf_fft_core.h"
@@ -619,20 +621,34 @@ bool pf_mixed_plan_compiled_in(int n) {
 #undef PF_MIXED_CASE
   return false;
 }
+// (the LDS attribute and the occupancy belong to a kernel ON ONE DEVICE; asked once per (kernel, device[, shape]) under a lock, so that
+//  ranks run as threads of one process on several devices neither race nor inherit each other's answers)
+static std::mutex pf_mixed_mu;
 template <typename F> static int pf_mixed_raise_lds(const void *fn, size_t shm) {
   if (shm <= 64 * 1024) return 0;
-  return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess ? 0 : 3;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 3;
+  struct Ent { const void *fn; int dev; size_t shm; };
+  static std::vector<Ent> done;
+  std::lock_guard<std::mutex> lock(pf_mixed_mu);
+  for (const Ent &e : done)
+    if (e.fn == fn && e.dev == dev && e.shm >= shm) return 0;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return 3;
+  done.push_back(Ent{fn, dev, shm});
+  return 0;
 }
-// workgroups of a kernel that fit one CU (asked once per kernel and shape)
+// workgroups of a kernel that fit one CU (asked once per kernel, device and shape)
 static int pf_mixed_resident(const void *fn, int threads, size_t shm) {
-  struct Ent { const void *fn; int threads; size_t shm; int nb; };
-  static Ent tab[64];
-  static int used = 0;
-  for (int i = 0; i < used; i++)
-    if (tab[i].fn == fn && tab[i].threads == threads && tab[i].shm == shm) return tab[i].nb;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  struct Ent { const void *fn; int dev, threads; size_t shm; int nb; };
+  static std::vector<Ent> tab;
+  std::lock_guard<std::mutex> lock(pf_mixed_mu);
+  for (const Ent &e : tab)
+    if (e.fn == fn && e.dev == dev && e.threads == threads && e.shm == shm) return e.nb;
   int nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, shm) != hipSuccess) { (void)hipGetLastError(); return 0; }
-  if (used < 64) tab[used++] = Ent{fn, threads, shm, nb};
+  tab.push_back(Ent{fn, dev, threads, shm, nb});
   return nb;
 }
 int pf_launch_mixed_strided(int fb, int n, int dir, const PfStridedParams &p, hipStream_t st) {

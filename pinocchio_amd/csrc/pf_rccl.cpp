@@ -10,6 +10,7 @@
 // single GPU without it and never clashes with an RCCL already in the process.
 #include <dlfcn.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/pinfmax.h"
@@ -75,7 +76,15 @@ extern "C" int pf_rccl_version(int *build_code) {
   return g_api.h ? g_api.version : 0;
 }
 
-struct RcclLink { ncclComm_t comm; int rank, nranks; };
+struct RcclLink {
+  ncclComm_t comm; int rank, nranks;
+  bool self_send;  // PF_RCCL_SELF_SEND=1 (read once, in pf_init_rccl): the rank's own block goes through ncclSend / ncclRecv to itself
+                   // inside the group, as in rounds 1-5; default: a device-to-device copy on the same stream, outside RCCL (no self
+                   // connection, no proxy work for 1/P of every field) -- the first run on eight GPUs can A/B the two
+};
+static int self_copy(const void *src, void *dst, size_t bytes, void *stream) {
+  return bytes && hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess;
+}
 
 // (a group that was opened is always closed, also when a call inside it fails: an open group would swallow every later
 //  RCCL call of the process, the fallback exchange's included)
@@ -84,10 +93,13 @@ static int rccl_alltoall(void *user, const void *send, void *recv, size_t bytes,
   if (g_api.GroupStart()) return 1;
   int bad = 0;
   for (int q = 0; q < l->nranks && !bad; q++) {
+    if (q == l->rank && !l->self_send) continue;
     bad |= g_api.Send((const char *)send + (size_t)q * bytes, bytes, ncclChar, q, l->comm, (hipStream_t)stream) != ncclSuccess;
     if (!bad) bad |= g_api.Recv((char *)recv + (size_t)q * bytes, bytes, ncclChar, q, l->comm, (hipStream_t)stream) != ncclSuccess;
   }
-  return (g_api.GroupEnd() != 0) | bad;
+  bad |= g_api.GroupEnd() != 0;
+  if (!bad && !l->self_send) bad |= self_copy((const char *)send + (size_t)l->rank * bytes, (char *)recv + (size_t)l->rank * bytes, bytes, stream);
+  return bad;
 }
 // the same exchange restricted to one row range per block (band-limited spectra): variable message sizes, empty ones skipped
 static int rccl_alltoallv(void *user, const void *send, void *recv, size_t block_bytes, size_t send_off, size_t send_bytes,
@@ -96,10 +108,15 @@ static int rccl_alltoallv(void *user, const void *send, void *recv, size_t block
   if (g_api.GroupStart()) return 1;
   int bad = 0;
   for (int q = 0; q < l->nranks && !bad; q++) {
+    if (q == l->rank && !l->self_send) continue;
     if (send_bytes) bad |= g_api.Send((const char *)send + (size_t)q * block_bytes + send_off, send_bytes, ncclChar, q, l->comm, (hipStream_t)stream) != ncclSuccess;
     if (!bad && recv_bytes[q]) bad |= g_api.Recv((char *)recv + (size_t)q * block_bytes + recv_off[q], recv_bytes[q], ncclChar, q, l->comm, (hipStream_t)stream) != ncclSuccess;
   }
-  return (g_api.GroupEnd() != 0) | bad;
+  bad |= g_api.GroupEnd() != 0;
+  // (the rank's own row range: what it sends is what it receives from itself -- recv_off[rank] == send_off, recv_bytes[rank] == send_bytes)
+  if (!bad && !l->self_send)
+    bad |= self_copy((const char *)send + (size_t)l->rank * block_bytes + send_off, (char *)recv + (size_t)l->rank * block_bytes + recv_off[l->rank], recv_bytes[l->rank], stream);
+  return bad;
 }
 static int rccl_allreduce(void *user, void *buf, size_t count, int is_u64, void *stream) {
   RcclLink *l = (RcclLink *)user;
@@ -141,6 +158,7 @@ extern "C" int pf_init_rccl(pf_ctx *ctx, const void *id128) {
   if (!ctx || !id128 || load_rccl()) return 1;
   RcclLink *l = new RcclLink();
   if (pf_ctx_rank_size(ctx, &l->rank, &l->nranks)) { delete l; return 1; }
+  { const char *e = getenv("PF_RCCL_SELF_SEND"); l->self_send = e && atoi(e) != 0; }
   ncclUniqueId id;
   memcpy(&id, id128, sizeof(id));
   const ncclResult_t rc = g_api.CommInitRank(&l->comm, l->nranks, id, l->rank);

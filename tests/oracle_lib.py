@@ -98,6 +98,12 @@ def lib(double_products: bool = False):
         L.orc_create_planes.argtypes = [C.c_int, C.c_int]
         L.orc_plane_derivatives.argtypes = [C.c_void_p, dp, C.c_double, C.c_int, ip, ip, C.c_int, ip, dp]
         L.orc_plane_collapse_times.argtypes = [C.c_void_p, C.c_int, C.c_size_t, dp, C.c_void_p, ip]
+        L.orc_plane_acc_create.restype = C.c_void_p
+        L.orc_plane_acc_create.argtypes = [C.c_void_p, C.c_int, dp, C.c_int, ip, ip, C.c_int, ip]
+        L.orc_plane_acc_add.argtypes = [C.c_void_p, dp, C.c_int, C.c_int]
+        L.orc_plane_acc_finish.argtypes = [C.c_void_p, C.c_int, dp]
+        L.orc_plane_acc_destroy.argtypes = [C.c_void_p]
+        L.orc_plane_acc_destroy.restype = None
         if double_products:
             _lib_dp = L
         else:
@@ -310,6 +316,12 @@ class PlaneOracle:
         assert rc == 0
         return out
 
+    def stream(self, radii_cells, comps):
+        """the streaming form of derivatives() for a spectrum that does not fit the host: -> an accumulator with
+        add(rows, kx0) for consecutive pieces [nkx][n][n/2+1] of the spectrum (ascending kx, all of them) and finish(irad) ->
+        [ncomp][nplanes][n][n] of radius irad (orc_plane_acc_*)"""
+        return PlaneStream(self, radii_cells, comps)
+
     def collapse_times(self, ismooth: int, d6: np.ndarray):
         """the collapse pass of radius ismooth on the planes' cells; d6 = [6][nplanes][n][n]"""
         d6 = np.ascontiguousarray(d6, dtype=np.float64).reshape(6, -1)
@@ -324,6 +336,38 @@ class PlaneOracle:
             self.collapse_times(ismooth, self.derivatives(dk, rs, self.HESSIAN))
         shape = (len(self.planes), self.n, self.n)
         return self.fmax.reshape(shape), self.rmax.reshape(shape)
+
+
+class PlaneStream:
+    def __init__(self, po: PlaneOracle, radii_cells, comps):
+        self.po, self.L, self.n = po, po.L, po.n
+        self.ncomp, self.nplanes = len(comps), len(po.planes)
+        r = np.ascontiguousarray(radii_cells, dtype=np.float64)
+        ia = np.ascontiguousarray([c[0] for c in comps], dtype=np.int32)
+        ib = np.ascontiguousarray([c[1] for c in comps], dtype=np.int32)
+        ip = C.POINTER(C.c_int)
+        self.h = self.L.orc_plane_acc_create(po.h, len(r), _dp(r), len(comps), ia.ctypes.data_as(ip), ib.ctypes.data_as(ip),
+                                             len(po.planes), po.planes.ctypes.data_as(ip))
+        if not self.h:
+            raise ValueError("orc_plane_acc_create failed")
+
+    def add(self, rows: np.ndarray, kx0: int):
+        n = self.n
+        assert rows.dtype == np.complex128 and rows.shape[1:] == (n, n // 2 + 1) and rows.flags.c_contiguous
+        assert self.L.orc_plane_acc_add(self.h, _dp(rows.view(np.float64)), int(kx0), rows.shape[0]) == 0
+
+    def finish(self, irad: int) -> np.ndarray:
+        out = np.empty((self.ncomp, self.nplanes, self.n, self.n))
+        assert self.L.orc_plane_acc_finish(self.h, int(irad), _dp(out)) == 0
+        return out
+
+    def close(self):
+        if self.h:
+            self.L.orc_plane_acc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
 
 
 def ell_classic(l1, l2, l3) -> float:

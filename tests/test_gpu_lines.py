@@ -231,6 +231,30 @@ def test_chirp_z_transforms_of_the_general_path(L, n):
     assert np.max(np.abs(back - want)) <= 2e-14 * np.max(np.abs(want))
 
 
+@pytest.mark.parametrize("n", [300, 514, 700, 1022, 1026, 1500, 2046])
+def test_chirp_z_lines_of_every_convolution_length(L, n):
+    """one k_blue pass on a few lines: the convolution lengths M = 1024 (n = 300, 514), 2048 (700, 1022) and 4096 (1026, 1500, 2046 -- the
+    only four-stage 8.8.8.8 plan of the library) that the whole-box tests above (M <= 512) never reach, in the three forms of the pass"""
+    rng = np.random.default_rng(n)
+    nl, h = 5, n // 2
+    x = rng.standard_normal((n, nl)) + 1j * rng.standard_normal((n, nl))
+    for d in (+1, -1):
+        out = np.zeros((n, nl), dtype=np.complex128)
+        assert L.pf_debug_gfft_lines(n, 0, d, nl, _dp(np.ascontiguousarray(x).view(np.float64)), _dp(out.view(np.float64))) == 0
+        want = np.fft.ifft(x, axis=0) * n if d > 0 else np.fft.fft(x, axis=0)
+        assert np.max(np.abs(out - want)) <= 4e-14 * np.max(np.abs(want)), (n, d)
+    s = rng.standard_normal((nl, h + 1)) + 1j * rng.standard_normal((nl, h + 1))
+    real = np.zeros((nl, n))
+    assert L.pf_debug_gfft_lines(n, 1, +1, nl, _dp(np.ascontiguousarray(s).view(np.float64)), _dp(real)) == 0
+    want = np.fft.irfft(s, n=n, axis=1) * n
+    assert np.max(np.abs(real - want)) <= 4e-14 * np.max(np.abs(want)), n
+    r = rng.standard_normal((nl, n))
+    spec = np.zeros((nl, h + 1), dtype=np.complex128)
+    assert L.pf_debug_gfft_lines(n, 2, -1, nl, _dp(r), _dp(spec.view(np.float64))) == 0
+    want = np.fft.rfft(r, axis=1)
+    assert np.max(np.abs(spec - want)) <= 4e-14 * np.max(np.abs(want)), n
+
+
 @pytest.mark.parametrize("n,fb", [(2048, 4), (1024, 4), (1024, 8), (2048, 8), (256, 4), (768, 8), (768, 4), (200, 8), (200, 4), (120, 8)])
 def test_strided_launch_with_several_jobs_per_tile(L, n, fb):
     """one launch, six jobs on three inputs as the y-pass of the sweep issues them (A2 -> 1, A1 -> 2, A0 -> 3 outputs with their

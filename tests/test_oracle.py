@@ -550,3 +550,25 @@ def test_sampled_plane_oracle_is_the_whole_oracle_on_its_planes(n):
     assert np.mean(diff > 2 * ulp) <= 1e-3 and np.mean(diff > 0) < 5e-3   # two correct transforms differ by rounding
     assert np.mean(rmax != wr) < 1e-3
     assert fmax.max() > 1.0
+
+
+@pytest.mark.parametrize("n", [16, 24])
+def test_streamed_plane_oracle_is_the_plane_oracle_to_the_bit(n):
+    """orc_plane_acc_* (the form the 2048^3 test of BASELINE config 5 uses: its spectrum is 69 GB in fp64 and arrives in pieces of
+    consecutive kx, three radii at once) gives orc_plane_derivatives' planes bit for bit, whatever the pieces"""
+    dk = synth.make_density(n, seed=3 + n)
+    radii = np.array([3.0, 1.1, 0.0])
+    planes = [0, n // 3, n - 1]
+    po = oracle_lib.PlaneOracle(n, planes, 2)
+    st = po.stream(radii, po.HESSIAN)
+    kx = 0
+    for piece in (1, 5, 2, n):
+        m = min(piece, n - kx)
+        if m:
+            st.add(np.ascontiguousarray(dk[kx:kx + m]), kx)
+        kx += m
+    with pytest.raises(AssertionError):
+        st.add(np.ascontiguousarray(dk[:1]), 0)         # every row was added already
+    for i, rs in enumerate(radii):
+        assert np.array_equal(st.finish(i), po.derivatives(dk, rs, po.HESSIAN)), rs
+    st.close()
