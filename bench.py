@@ -272,6 +272,8 @@ def parse_args(argv=None):
                          "exercises this script's multi-rank code end to end (tests/test_gpu_gloo_ranks.py); its numbers mean nothing")
     ap.add_argument("--check", type=int, default=1,
                     help="1: after the timed region, fingerprint Fmax / Rmax / the displacements and compare with the single-GPU golden of the configuration (tests/golden/bench_fingerprints.json)")
+    ap.add_argument("--boundary", type=int, default=1,
+                    help="1 (one GPU): after the timed region, time the hand-off itself -- pf_get_products, pf_update_products, pf_set_density -- and print it as `boundary`")
     ap.add_argument("--slab-of", type=int, default=0,
                     help="P > 1: time the kernels of ONE rank of a P-rank run of the n^3 box on this GPU, exchange short-circuited (see run_slab)")
     ap.add_argument("--dry-launch", action="store_true",
@@ -484,6 +486,13 @@ def run_config(args, rank, world, device, dist, torch, replicate_env, votes_out,
             for kind, name in ((0, "read_GBps"), (1, "write_GBps"), (2, "copy_GBps")):
                 if f.L.pf_debug_stream_rate(f.h, kind, 5, C.byref(v)) == 0:
                     stream[name] = v.value
+        boundary = None
+        if world == 1 and args.boundary:
+            try:
+                boundary = boundary_report(f, api, n, dt / args.steps)
+            except (RuntimeError, MemoryError, api.PinfmaxError) as e:
+                boundary = {"error": str(e)}
+        res["boundary"] = boundary
         global GENERAL_PATH
         GENERAL_PATH = int(f.L.pf_transform_path(f.h)) == 2
         res.update(dt=dt, stats=f.kernel_stats(), cput=f.cputime(), device_gb=f.device_bytes / 1e9, stream=stream,
@@ -498,6 +507,54 @@ def run_config(args, rank, world, device, dist, torch, replicate_env, votes_out,
         f.close()
         del keep
     return res
+
+
+def boundary_report(f, api, n, step_s):
+    """What the boundary itself costs at the bench size ("report separately with the D2H of products"), after the
+    timed region and NEVER part of `value`: compute_fmax() of the reference leaves `products` in host memory (src/fmax-pfft.c:563-631
+    writes the AoS) and takes kdensity from host memory; the re-entrant compute_displacements of src/fragment.c:398-410 rewrites the
+    Vel* fields of records the caller holds.  Every call is timed twice: the first one pays the first touch of the caller's pages."""
+    from pinocchio_amd import _lib
+    nc = n ** 3
+    out = {"host_threads_env": os.environ.get("PF_HANDOFF_THREADS"), "registered": os.environ.get("PF_HOST_REGISTER", "0") == "1"}
+
+    def timed(fn):
+        f.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        f.synchronize()
+        return 1e3 * (time.perf_counter() - t0)
+
+    lay = _lib.ProductLayout()
+    f.L.pf_layout_3lpt(C.byref(lay))
+    rec = np.empty(nc * lay.stride, dtype=np.uint8)          # untouched pages: the first call faults them in
+    get = lambda: f._chk(f.L.pf_get_products(f.h, rec.ctypes.data_as(C.c_void_p), C.byref(lay)))   # noqa: E731
+    out["records_GB"] = rec.nbytes / 1e9
+    out["d2h_ms_first_call"] = timed(get)
+    out["d2h_ms"] = timed(get)
+    out["d2h_GBps"] = rec.nbytes / 1e6 / out["d2h_ms"]
+    del rec
+    # the 104-byte record of the default build with RECOMPUTE_DISPLACEMENTS (src/pinocchio.h:233-259: the 56 bytes above + four *_prev vectors)
+    lay2 = _lib.ProductLayout(stride=104, off_Rmax=-1, off_Fmax=-1, off_Vel=8, off_Vel_2LPT=20, off_Vel_3LPT_1=32, off_Vel_3LPT_2=44)
+    rec2 = np.empty(nc * 104, dtype=np.uint8)
+    upd = lambda: f._chk(f.L.pf_update_products(f.h, rec2.ctypes.data_as(C.c_void_p), C.byref(lay2)))   # noqa: E731
+    out["update_records_GB"] = rec2.nbytes / 1e9
+    out["update_link_GB"] = nc * 48 / 1e9
+    out["update_ms_first_call"] = timed(upd)
+    out["update_ms"] = timed(upd)
+    out["update_link_GBps"] = nc * 48 / 1e6 / out["update_ms"]
+    del rec2
+    dk = np.empty((n, n, n // 2 + 1), dtype=np.complex128)
+    dpp = dk.view(np.float64).ctypes.data_as(C.POINTER(C.c_double))
+    out["density_GB"] = dk.nbytes / 1e9
+    out["density_d2h_ms_first_call"] = timed(lambda: f._chk(f.L.pf_get_density(f.h, dpp)))
+    out["h2d_ms"] = timed(lambda: f._chk(f.L.pf_set_density(f.h, dpp)))
+    out["h2d_GBps"] = dk.nbytes / 1e6 / out["h2d_ms"]
+    del dk
+    out["cells_per_s_including_handoff"] = nc / (step_s + 1e-3 * (out["d2h_ms"] + out["h2d_ms"]))
+    out["note"] = ("after the timed region; kdensity in (pf_set_density) + one step + products out (pf_get_products), pageable host arrays, second calls "
+                   "(pages touched); never part of `value`")
+    return out
 
 
 def kernel_report(stats, steps, n, w, inline=None, solve_beside=False, stream=None):
@@ -930,6 +987,8 @@ def main():
                 invalid = True
         if exact:
             out["exact_libm"] = exact
+        if res.get("boundary") is not None:
+            out["boundary"] = res["boundary"]
         if world == 1 and args.cpu_n:
             out["cpu_baseline"] = cpu_baseline(args.cpu_n, ns, lpt)
         print(json.dumps(out), flush=True)

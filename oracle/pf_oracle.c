@@ -1319,6 +1319,7 @@ struct orc_plane_acc {
   int ia[6], ib[6];
   int *xs;
   double *E, *G;
+  double *pw;   /* [n (ky)][nrad]: sum over the rows added so far of w |spec|^2 smoothing^2, w = 2 for 0 < kz < n/2 (the half-spectrum) */
 };
 orc_plane_acc *orc_plane_acc_create(orc_ctx *c, int nrad, const double *rs_cells, int ncomp, const int *ia, const int *ib, int nplanes, const int *xs) {
   if (!c || nrad < 1 || nrad > ORC_MAX_SMOOTH || ncomp < 1 || ncomp > 6 || nplanes < 1) return NULL;
@@ -1339,7 +1340,8 @@ orc_plane_acc *orc_plane_acc_create(orc_ctx *c, int nrad, const double *rs_cells
       a->E[2 * ((size_t)p * n + idx)] = c->tw[2 * j]; a->E[2 * ((size_t)p * n + idx) + 1] = c->tw[2 * j + 1];
     }
   a->G = (double *)calloc((size_t)2 * n * nzh * nrad * ncomp * nplanes, sizeof(double));
-  if (!a->G) { free(a->E); free(a->xs); free(a); return NULL; }
+  a->pw = (double *)calloc((size_t)n * nrad, sizeof(double));
+  if (!a->G || !a->pw) { free(a->G); free(a->pw); free(a->E); free(a->xs); free(a); return NULL; }
   return a;
 }
 /* rows kx0 .. kx0 + nkx - 1: [nkx][n][nzh] complex.  Pieces must follow each other (kx0 = where the last one ended). */
@@ -1372,6 +1374,10 @@ int orc_plane_acc_add(orc_plane_acc *a, const double *rows, int kx0, int nkx) {
           const double Rsmooth = a->rs[r];
           double smoothing = 1.0;
           if (k_squared != 0.) smoothing = exp(-0.5 * k_squared * Rsmooth * Rsmooth);
+          {
+            const double sre = row[2 * idz] * smoothing, sim = row[2 * idz + 1] * smoothing;
+            a->pw[(size_t)idy * nrad + r] += ((idz == 0 || 2 * idz == n) ? 1.0 : 2.0) * (sre * sre + sim * sim);
+          }
           for (int k = 0; k < ncomp; k++) {
             double re = row[2 * idz], im = row[2 * idz + 1];
             if (k_squared != 0.) {  /* the k = 0 mode is left untouched (:368) */
@@ -1399,9 +1405,17 @@ int orc_plane_acc_finish(orc_plane_acc *a, int irad, double *out) {
   plane_finish(a->c, a->G + 2 * ((size_t)irad * a->ncomp * a->nplanes * a->c->n * a->c->nzh), a->ncomp * a->nplanes, out);
   return 0;
 }
+/* Parseval's side of the rows added so far: sum over their modes of |spec|^2 smoothing^2 (both halves of the spectrum counted) -- over
+   all rows, n^6 times the variance of the smoothed density (the k = 0 mode counts unsmoothed, as compute_derivative leaves it) */
+double orc_plane_acc_power(orc_plane_acc *a, int irad) {
+  double s = 0.0;
+  if (irad < 0 || irad >= a->nrad) return -1.0;
+  for (int idy = 0; idy < a->c->n; idy++) s += a->pw[(size_t)idy * a->nrad + irad];
+  return s;
+}
 void orc_plane_acc_destroy(orc_plane_acc *a) {
   if (!a) return;
-  free(a->G); free(a->E); free(a->xs); free(a);
+  free(a->G); free(a->pw); free(a->E); free(a->xs); free(a);
 }
 
 /* compute_collapse_times (src/collapse_times.c:431-673) on a list of cells: d6 = [6][ncells] in the storage order

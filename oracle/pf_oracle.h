@@ -162,6 +162,7 @@ typedef struct orc_plane_acc orc_plane_acc;
 orc_plane_acc *orc_plane_acc_create(orc_ctx *c, int nrad, const double *rs_cells, int ncomp, const int *ia, const int *ib, int nplanes, const int *xs);
 int orc_plane_acc_add(orc_plane_acc *a, const double *rows, int kx0, int nkx);
 int orc_plane_acc_finish(orc_plane_acc *a, int irad, double *out);
+double orc_plane_acc_power(orc_plane_acc *a, int irad);   /* sum of |spec|^2 smoothing^2 over the modes of the rows added (Parseval) */
 void orc_plane_acc_destroy(orc_plane_acc *a);
 
 #endif

@@ -28,6 +28,7 @@
 
 #include "../../include/pinfmax.h"
 #include "pf_collapse_core.h"
+#include "pf_hostpool.h"
 #include "pf_internal.h"
 
 extern "C" void pf_rccl_release(void *link);  // pf_rccl.cpp
@@ -81,6 +82,21 @@ struct EvPair { int kind; hipEvent_t a, b; double bytes; };
 struct SplineHost { std::vector<double> x, y, c; };
 
 struct PfLoopback { int copies_left; int nranks; };  // pf_set_loopback_exchange
+// Host side of the boundary.  Everything that crosses it in bulk -- products out (src/fmax-pfft.c:563-631 writes them into host
+// memory), kdensity in -- goes through two pinned buffers on two streams: the DMA of piece i + 1 runs while the host threads move
+// piece i between its buffer and the caller's pageable array (a copy, or the scatter of the named fields for pf_update_products).
+// PF_HANDOFF_CHUNK_MB (256), PF_HANDOFF_THREADS (the cores of the cgroup, at most 16), PF_HOST_REGISTER=1: the caller's product
+// array is registered with the driver at first sight (hipHostRegister, page-aligned arrays only; silently not when that fails) and
+// the DMA writes into it directly.
+struct PfHandoff {
+  hipStream_t st[2];
+  char *pin[2];
+  size_t chunk;
+  PfHostPool *pool;
+  hipEvent_t ev;
+  bool want_register;
+  void *reg_ptr; size_t reg_bytes;
+};
 
 struct pf_ctx {
   pf_config cfg;
@@ -180,6 +196,7 @@ struct pf_ctx {
   void *fft_c2r, *fft_r2c;  // the chirp-z plan of the general path (pf_gfft.hip: one plan under both names)
   bool vel_zero_pending;  // the Vel* columns are to read as zero (src/collapse_times.c:472-489) but have not been cleared yet
   int last_ns;
+  struct PfHandoff *handoff;  // host side of the boundary (handoff_get): two streams, two pinned buffers, the host threads
   PfLoopback *loopback;
   pf_alltoall_fn a2a; void *a2a_user;
   pf_alltoallv_fn a2av; void *a2av_user;  // optional: exchange of a row range of every block (pruned radii)
@@ -194,6 +211,7 @@ struct pf_ctx {
   std::vector<EvPair> phase_evs;  // kind: 0 deriv 1 coll 2 lpt 3 mem
 };
 
+static void handoff_release(pf_ctx *c);
 #define PF_GT_DOUBLES (PF_GT_HEADER + (PF_GT_MAX_INT + 1) * PF_GT_REC)
 #define PF_NBLK 2048
 #define PF_KBIN_CAP 32
@@ -316,6 +334,10 @@ static void read_tuning(PfTuning *t) {
   t->solve_beside_z = env_int("PF_SOLVE_BESIDE_Z", -1);
   t->gtab = env_int("PF_GTAB", 1) != 0;
   t->preflight = env_int("PF_PREFLIGHT", 1) != 0;
+  t->handoff_chunk_mb = env_int("PF_HANDOFF_CHUNK_MB", 256);
+  if (t->handoff_chunk_mb <= 0) t->handoff_chunk_mb = 256;
+  t->handoff_threads = env_int("PF_HANDOFF_THREADS", 0);
+  t->host_register = env_int("PF_HOST_REGISTER", 0) != 0;
   // fault injection for the tests of the exchange pipeline (tests/test_gpu_multirank.py): "recv" drops the wait of the
   // compute stream for the exchange it is about to consume, "send" the wait of the exchange for the x-pass that fills its blocks
   const char *fault = getenv("PF_DEBUG_PIPELINE_FAULT");
@@ -494,7 +516,7 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
   c->gtab = nullptr; c->etab = nullptr; c->ct_block = nullptr; c->gt = nullptr; c->gt_lut = nullptr;
   memset(c->gt_ok, 0, sizeof(c->gt_ok)); memset(c->gt_err, 0, sizeof(c->gt_err));
   for (int i = 0; i < 2; i++) c->ev_x[i] = c->ev_r[i] = c->ev_y[i] = c->ev_s[i] = nullptr;
-  c->sstream = nullptr; c->solve_ran_beside = false; c->loopback = nullptr;
+  c->sstream = nullptr; c->solve_ran_beside = false; c->loopback = nullptr; c->handoff = nullptr;
   c->pipeline = c->P > 1 && tune.pipeline;
   for (int i = 0; i < 3; i++) { c->A[i] = nullptr; c->S[i] = nullptr; }
   memset(c->gt_n, 0, sizeof(c->gt_n));
@@ -517,6 +539,7 @@ extern "C" int pf_destroy(pf_ctx *c) {
   if (c->sstream) hipStreamSynchronize(c->sstream);
   pf_rccl_release(c->rccl); c->rccl = nullptr;
   delete c->loopback; c->loopback = nullptr;
+  handoff_release(c);
   hipFree(c->dk); hipFree(c->blockA); hipFree(c->recvA); hipFree(c->tw); hipFree(c->blockA2); hipFree(c->recvA2); hipFree(c->dk_full); hipFree(c->inv_own[0]); hipFree(c->inv_own[1]);
   for (int i = 0; i < 6; i++) hipFree(c->B[i]);
   hipFree(c->blockS); hipFree(c->blockB2);
@@ -635,6 +658,105 @@ static int allreduce_dev(pf_ctx *c, void *buf, size_t count, int is_u64) {
   if (!c->ared) return pf_fail(c->rank, "no all-reduce installed for %d ranks (pf_set_allreduce / pf_init_rccl)", c->P);
   if (c->ared(c->ared_user, buf, count, is_u64, (void *)c->stream)) return pf_fail(c->rank, "all-reduce failed");
   return 0;
+}
+
+
+// ---------------------------------------------------------------- hand-off --
+static void handoff_release(pf_ctx *c) {
+  PfHandoff *h = c->handoff;
+  if (!h) return;
+  for (int i = 0; i < 2; i++) { if (h->st[i]) { hipStreamSynchronize(h->st[i]); hipStreamDestroy(h->st[i]); } if (h->pin[i]) hipHostFree(h->pin[i]); }
+  if (h->ev) hipEventDestroy(h->ev);
+  if (h->reg_ptr) (void)hipHostUnregister(h->reg_ptr);
+  delete h->pool;
+  delete h;
+  c->handoff = nullptr;
+}
+static int handoff_get(pf_ctx *c, PfHandoff **out) {
+  if (!c->handoff) {
+    PfHandoff *h = new PfHandoff();
+    h->st[0] = h->st[1] = nullptr; h->pin[0] = h->pin[1] = nullptr; h->ev = nullptr; h->pool = nullptr; h->reg_ptr = nullptr; h->reg_bytes = 0;
+    c->handoff = h;
+    size_t chunk = (size_t)c->tune.handoff_chunk_mb << 20;
+    if (chunk > c->field_bytes) chunk = c->field_bytes;  // (a piece is staged in ONE of the two staging fields on the device)
+    h->chunk = chunk & ~(size_t)4095;
+    if (h->chunk < 4096) h->chunk = c->field_bytes;
+    int nt = c->tune.handoff_threads;
+    if (nt <= 0) { nt = pf_host_cores(); if (nt > 16) nt = 16; }
+    h->want_register = c->tune.host_register;
+    for (int i = 0; i < 2; i++) {
+      HIPCHK(c, hipStreamCreateWithFlags(&h->st[i], hipStreamNonBlocking));
+      HIPCHK(c, hipHostMalloc((void **)&h->pin[i], h->chunk, hipHostMallocDefault));
+    }
+    HIPCHK(c, hipEventCreateWithFlags(&h->ev, hipEventDisableTiming));
+    h->pool = new PfHostPool(nt);
+  }
+  *out = c->handoff;
+  return 0;
+}
+// the two hand-off streams start behind everything the compute stream holds
+static int handoff_begin(pf_ctx *c, PfHandoff *h) {
+  HIPCHK(c, hipEventRecord(h->ev, c->stream));
+  for (int i = 0; i < 2; i++) HIPCHK(c, hipStreamWaitEvent(h->st[i], h->ev, 0));
+  return 0;
+}
+// ... and the compute stream goes on behind them (both are idle when a hand-off returns: it has synchronised them)
+static char *handoff_dev(pf_ctx *c, int b) { return (char *)c->A[1 + b]; }
+// `bytes` from the device to the caller's pageable memory; fill(piece_offset, piece_bytes, device_staging, stream) puts a piece in place
+// on the device first (null: src_dev is copied as it lies)
+template <class Fill>
+static int handoff_d2h(pf_ctx *c, char *host, const char *src_dev, size_t bytes, size_t granule, Fill fill) {
+  PfHandoff *h;
+  if (handoff_get(c, &h)) return 1;
+  PFCHK(c, handoff_begin(c, h));
+  const size_t piece = (h->chunk / granule) * granule;
+  if (!piece) return pf_fail(c->rank, "hand-off: a record of %zu bytes does not fit the staging pieces", granule);
+  const size_t np = (bytes + piece - 1) / piece;
+  auto issue = [&](size_t k) -> int {
+    const int b = (int)(k & 1);
+    const size_t off = k * piece, len = bytes - off < piece ? bytes - off : piece;
+    const char *src = src_dev ? src_dev + off : handoff_dev(c, b);
+    if (fill(off, len, handoff_dev(c, b), h->st[b])) return 1;
+    HIPCHK(c, hipMemcpyAsync(h->pin[b], src, len, hipMemcpyDeviceToHost, h->st[b]));
+    return 0;
+  };
+  if (np && issue(0)) return 1;
+  for (size_t k = 0; k < np; k++) {
+    if (k + 1 < np && issue(k + 1)) return 1;
+    const int b = (int)(k & 1);
+    HIPCHK(c, hipStreamSynchronize(h->st[b]));
+    const size_t off = k * piece, len = bytes - off < piece ? bytes - off : piece;
+    char *dst = host + off; const char *src = h->pin[b];
+    h->pool->run(len, [=](size_t a, size_t e) { memcpy(dst + a, src + a, e - a); });
+  }
+  return 0;
+}
+static int no_fill(size_t, size_t, char *, hipStream_t) { return 0; }
+// `bytes` from the caller's pageable memory to dst_dev: the host threads fill one pinned buffer while the DMA empties the other
+static int handoff_h2d(pf_ctx *c, char *dst_dev, const char *host, size_t bytes) {
+  PfHandoff *h;
+  if (handoff_get(c, &h)) return 1;
+  PFCHK(c, handoff_begin(c, h));
+  const size_t piece = h->chunk, np = (bytes + piece - 1) / piece;
+  for (size_t k = 0; k < np; k++) {
+    const int b = (int)(k & 1);
+    const size_t off = k * piece, len = bytes - off < piece ? bytes - off : piece;
+    HIPCHK(c, hipStreamSynchronize(h->st[b]));  // the DMA that last read this buffer (piece k - 2)
+    char *dst = h->pin[b]; const char *src = host + off;
+    h->pool->run(len, [=](size_t a, size_t e) { memcpy(dst + a, src + a, e - a); });
+    HIPCHK(c, hipMemcpyAsync(dst_dev + off, h->pin[b], len, hipMemcpyHostToDevice, h->st[b]));
+  }
+  for (int i = 0; i < 2; i++) HIPCHK(c, hipStreamSynchronize(h->st[i]));
+  return 0;
+}
+// the caller's product array, registered with the driver once (PF_HOST_REGISTER=1): true when the DMA may write into it directly
+static bool handoff_registered(pf_ctx *c, PfHandoff *h, void *host, size_t bytes) {
+  if (!h->want_register || ((uintptr_t)host & 4095)) return false;
+  if (h->reg_ptr == host && h->reg_bytes >= bytes) return true;
+  if (h->reg_ptr) { (void)hipHostUnregister(h->reg_ptr); h->reg_ptr = nullptr; h->reg_bytes = 0; }
+  if (hipHostRegister(host, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
+  h->reg_ptr = host; h->reg_bytes = bytes;
+  return true;
 }
 
 // ---------------------------------------------------------- pass helpers ----
@@ -902,12 +1024,11 @@ static int hess_x(pf_ctx *c, const void *spec, double rs, void *const A[3], int 
 // and an integer all-reduce adds the other ranks' zeros to it (exact for either field type; ~2 x 8.6 GB per rank at 1024^3)
 static int ensure_dk_full(pf_ctx *c) {
   if (!c->replicate || c->dk_full_valid) return 0;
-  if (c->a2a == loopback_a2a) {
+  if (c->a2a == loopback_a2a && c->have_genic) {
     // One rank on its own (pf_set_loopback_exchange): no peer contributes its slab.  A density that came from pf_genic_density is a
     // function of (seed, cosmology) alone, every column on its own: the rank generates all P ky-slabs itself -- the KY layout of ONE
     // rank of the whole box is the layout of dk_full -- and the sweep that follows runs on the box's own delta(k), exchange-free.
-    if (!c->have_genic)
-      return pf_fail(c->rank, "a replicated spectrum behind the loopback exchange needs a density every rank can generate whole (pf_genic_density)");
+    // (Any other density behind the loopback: the rank's own slab among zeros, below -- a timing aid whose numbers are no box's.)
     unsigned int *dseed = nullptr;
     const int rc = pf_genic_launch(c->fb, c->dk_full, c->n, c->nzp, c->n, 0, &c->genic, c->stream, &dseed);
     if (!rc) HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1065,7 +1186,7 @@ static char *staging(pf_ctx *c) { return (char *)c->A[1]; }  // 2 fields of scra
 // field 0 or the Hessian buffers, so the transform taps can run between sweep and displacements).
 static int import_spec(pf_ctx *c, const double *host, void *dst) {
   const long long nrows = (long long)c->nxl * c->n;
-  HIPCHK(c, hipMemcpyAsync(staging(c), host, (size_t)nrows * c->nzh * 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (handoff_h2d(c, staging(c), (const char *)host, (size_t)nrows * c->nzh * 2 * sizeof(double))) return 1;
   if (c->transposed) {  // the caller's slab is a ky-slab already: a local swap of the two leading indices, nothing to exchange
     HIPCHK(c, hipMemsetAsync(dst, 0, c->field_bytes, c->stream));
     PFCHK(c, pf_launch_spec_import_t(c->fb, (const double *)staging(c), dst, c->n, c->nyl, c->nzh, c->nzp, c->stream));
@@ -1088,9 +1209,7 @@ static int export_spec(pf_ctx *c, const void *spec, double *host) {
   const void *rows = spec;
   if (c->transposed) {
     PFCHK(c, pf_launch_spec_export_t(c->fb, spec, (double *)staging(c), c->n, c->nyl, c->nzh, c->nzp, c->stream));
-    HIPCHK(c, hipMemcpyAsync(host, staging(c), (size_t)nrows * c->nzh * 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return handoff_d2h(c, (char *)host, staging(c), (size_t)nrows * c->nzh * 2 * sizeof(double), 1, no_fill);
   }
   if (c->P > 1) {  // KY has x slowest: the block for the owner of an x-slab is contiguous, no pack
     void *blocks = recv_field(c, 0, 1), *r = recv_field(c, 0, 2);
@@ -1099,9 +1218,7 @@ static int export_spec(pf_ctx *c, const void *spec, double *host) {
     rows = r;
   }
   PFCHK(c, pf_launch_spec_export(c->fb, rows, (double *)staging(c), nrows, c->nzh, c->nzp, c->stream));
-  HIPCHK(c, hipMemcpyAsync(host, staging(c), (size_t)nrows * c->nzh * 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  return 0;
+  return handoff_d2h(c, (char *)host, staging(c), (size_t)nrows * c->nzh * 2 * sizeof(double), 1, no_fill);
 }
 // Re of the k = 0 mode / N^3 on every rank: the k-filter leaves that mode untouched (k^2 = 0, src/fmax-pfft.c:368), so a
 // second derivative carries it as a constant; it lives on the rank that owns x = 0
@@ -1680,39 +1797,103 @@ extern "C" int pf_fmax_pdf(pf_ctx *c, unsigned long long hist[PF_NBINS]) {
 extern "C" int pf_get_products(pf_ctx *c, void *host, const pf_product_layout *l) {
   if (!c || !host || !l) return pf_fail(0, "pf_get_products: null argument");
   if (l->stride < 8 || l->stride % 4) return pf_fail(c->rank, "pf_get_products: bad stride %zu", l->stride);
+  if (l->stride > c->field_bytes) return pf_fail(c->rank, "pf_get_products: a record of %zu bytes exceeds the staging area", l->stride);
   PFCHK(c, velocities_ready(c));
   PhaseTimer pt(c, 3);
-  const size_t nc = ncell(c);
-  const size_t cap = (2 * c->field_bytes) / l->stride;  // records per chunk in the staging area
+  const size_t nc = ncell(c), stride = l->stride;
   const int ov[4] = {l->off_Vel, l->off_Vel_2LPT, l->off_Vel_3LPT_1, l->off_Vel_3LPT_2};
-  for (size_t first = 0; first < nc; first += cap) {
-    const size_t cnt = (nc - first < cap) ? nc - first : cap;
-    HIPCHK(c, hipMemsetAsync(staging(c), 0, cnt * l->stride, c->stream));
-    PFCHK(c, pf_launch_pack_products(c->pb, c->fmax, c->rmax, c->vel12, nc, first, cnt, staging(c), l->stride, l->off_Rmax, l->off_Fmax, ov, c->stream));
-    HIPCHK(c, hipMemcpyAsync((char *)host + first * l->stride, staging(c), cnt * l->stride, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int off_rmax = l->off_Rmax, off_fmax = l->off_Fmax;
+  // a piece of whole records is packed into one of the two staging fields and copied out while the other is being packed / moved on the host
+  auto fill = [&](size_t off, size_t len, char *stage, hipStream_t st) -> int {
+    HIPCHK(c, hipMemsetAsync(stage, 0, len, st));
+    PFCHK(c, pf_launch_pack_products(c->pb, c->fmax, c->rmax, c->vel12, nc, off / stride, len / stride, stage, stride, off_rmax, off_fmax, ov, st));
+    return 0;
+  };
+  PfHandoff *h;
+  if (handoff_get(c, &h)) return 1;
+  if (handoff_registered(c, h, host, nc * stride)) {  // the DMA writes into the caller's array itself
+    PFCHK(c, handoff_begin(c, h));
+    const size_t piece = (c->field_bytes / stride) * stride, bytes = nc * stride;
+    size_t k = 0;
+    for (size_t off = 0; off < bytes; off += piece, k++) {
+      const int b = (int)(k & 1);
+      const size_t len = bytes - off < piece ? bytes - off : piece;
+      if (fill(off, len, handoff_dev(c, b), h->st[b])) return 1;
+      HIPCHK(c, hipMemcpyAsync((char *)host + off, handoff_dev(c, b), len, hipMemcpyDeviceToHost, h->st[b]));
+    }
+    for (int i = 0; i < 2; i++) HIPCHK(c, hipStreamSynchronize(h->st[i]));
+    return 0;
   }
-  return 0;
+  return handoff_d2h(c, (char *)host, nullptr, nc * stride, stride, fill);
 }
 
-// Same columns into records the caller already holds: each chunk goes host -> device, the selected fields are
-// overwritten, and it goes back, so every other byte of the record (Fmax/Rmax when their offsets are negative, the
-// *_prev copies of a RECOMPUTE_DISPLACEMENTS build, padding) is preserved.  The re-entrant compute_displacements
-// of src/fragment.c:398-410 writes only the twelve Vel* columns.
+// Same columns into records the caller already holds; every other byte of a record (Fmax / Rmax when their offsets are negative, the
+// *_prev copies of a RECOMPUTE_DISPLACEMENTS build, padding) keeps its host value.  The re-entrant compute_displacements of
+// src/fragment.c:398-410 rewrites only the twelve Vel* columns: only the named fields cross the link -- packed on the device into
+// compact records (48 bytes per cell for the float build), copied into pinned memory, scattered into the caller's records by the
+// host threads while the next piece travels.  Rounds 1-5 uploaded and downloaded the whole records: 2 x 112 GB at 1024^3 for the
+// 104-byte records of the default build, to change 48 bytes per cell.
 extern "C" int pf_update_products(pf_ctx *c, void *host, const pf_product_layout *l) {
   if (!c || !host || !l) return pf_fail(0, "pf_update_products: null argument");
   if (l->stride < 8 || l->stride % 4) return pf_fail(c->rank, "pf_update_products: bad stride %zu", l->stride);
   PFCHK(c, velocities_ready(c));
   PhaseTimer pt(c, 3);
-  const size_t nc = ncell(c);
-  const size_t cap = (2 * c->field_bytes) / l->stride;
-  const int ov[4] = {l->off_Vel, l->off_Vel_2LPT, l->off_Vel_3LPT_1, l->off_Vel_3LPT_2};
-  for (size_t first = 0; first < nc; first += cap) {
-    const size_t cnt = (nc - first < cap) ? nc - first : cap;
-    HIPCHK(c, hipMemcpyAsync(staging(c), (const char *)host + first * l->stride, cnt * l->stride, hipMemcpyHostToDevice, c->stream));
-    PFCHK(c, pf_launch_pack_products(c->pb, c->fmax, c->rmax, c->vel12, nc, first, cnt, staging(c), l->stride, l->off_Rmax, l->off_Fmax, ov, c->stream));
-    HIPCHK(c, hipMemcpyAsync((char *)host + first * l->stride, staging(c), cnt * l->stride, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+  const size_t nc = ncell(c), stride = l->stride;
+  // the named fields in the order of their offsets -> compact record (each field aligned as in a C struct), runs of bytes that are
+  // adjacent on both sides merged into one segment
+  struct Fld { int uoff, len, align, which; };
+  Fld fl[6]; int nf = 0;
+  if (l->off_Rmax >= 0) fl[nf++] = Fld{l->off_Rmax, 4, 4, 0};
+  if (l->off_Fmax >= 0) fl[nf++] = Fld{l->off_Fmax, c->pb, c->pb, 1};
+  const int ovu[4] = {l->off_Vel, l->off_Vel_2LPT, l->off_Vel_3LPT_1, l->off_Vel_3LPT_2};
+  for (int o = 0; o < 4; o++) if (ovu[o] >= 0) fl[nf++] = Fld{ovu[o], 3 * c->pb, c->pb, 2 + o};
+  if (!nf) return 0;
+  for (int i = 1; i < nf; i++) for (int j = i; j > 0 && fl[j].uoff < fl[j - 1].uoff; j--) { const Fld t = fl[j]; fl[j] = fl[j - 1]; fl[j - 1] = t; }
+  struct Seg { int uoff, coff, len; };
+  Seg seg[6]; int nseg = 0;
+  int coff_of[6] = {-1, -1, -1, -1, -1, -1}, cpos = 0;
+  for (int i = 0; i < nf; i++) {
+    if ((size_t)fl[i].uoff + fl[i].len > stride || (i && fl[i].uoff < fl[i - 1].uoff + fl[i - 1].len))
+      return pf_fail(c->rank, "pf_update_products: fields of the layout overlap or leave the record");
+    cpos = (cpos + fl[i].align - 1) / fl[i].align * fl[i].align;
+    coff_of[fl[i].which] = cpos;
+    if (nseg && seg[nseg - 1].uoff + seg[nseg - 1].len == fl[i].uoff && seg[nseg - 1].coff + seg[nseg - 1].len == cpos) seg[nseg - 1].len += fl[i].len;
+    else seg[nseg++] = Seg{fl[i].uoff, cpos, fl[i].len};
+    cpos += fl[i].len;
+  }
+  const size_t cstride = (size_t)((cpos + 7) / 8 * 8);
+  const int cov[4] = {coff_of[2], coff_of[3], coff_of[4], coff_of[5]};
+  PfHandoff *h;
+  if (handoff_get(c, &h)) return 1;
+  PFCHK(c, handoff_begin(c, h));
+  const size_t per = h->chunk / cstride;
+  if (!per) return pf_fail(c->rank, "pf_update_products: a record does not fit the staging pieces");
+  const size_t np = (nc + per - 1) / per;
+  auto issue = [&](size_t k) -> int {
+    const int b = (int)(k & 1);
+    const size_t first = k * per, cnt = nc - first < per ? nc - first : per;
+    PFCHK(c, pf_launch_pack_products(c->pb, c->fmax, c->rmax, c->vel12, nc, first, cnt, handoff_dev(c, b), cstride, coff_of[0], coff_of[1], cov, h->st[b]));
+    HIPCHK(c, hipMemcpyAsync(h->pin[b], handoff_dev(c, b), cnt * cstride, hipMemcpyDeviceToHost, h->st[b]));
+    return 0;
+  };
+  if (issue(0)) return 1;
+  for (size_t k = 0; k < np; k++) {
+    if (k + 1 < np && issue(k + 1)) return 1;
+    const int b = (int)(k & 1);
+    HIPCHK(c, hipStreamSynchronize(h->st[b]));
+    const size_t first = k * per, cnt = nc - first < per ? nc - first : per;
+    char *dst = (char *)host + first * stride; const char *src = h->pin[b];
+    if (nseg == 1) {
+      const Seg s0 = seg[0];
+      h->pool->run(cnt, [=](size_t a, size_t e) { for (size_t i = a; i < e; i++) memcpy(dst + i * stride + s0.uoff, src + i * cstride + s0.coff, (size_t)s0.len); });
+    } else {
+      Seg sg[6]; for (int q = 0; q < nseg; q++) sg[q] = seg[q];
+      const int ns_ = nseg;
+      h->pool->run(cnt, [=](size_t a, size_t e) {
+        for (size_t i = a; i < e; i++)
+          for (int q = 0; q < ns_; q++) memcpy(dst + i * stride + sg[q].uoff, src + i * cstride + sg[q].coff, (size_t)sg[q].len);
+      });
+    }
   }
   return 0;
 }
@@ -1740,28 +1921,22 @@ extern "C" int pf_get_block(pf_ctx *c, const char *name, int id_bytes, void *hos
   if (c->pb != 4) return pf_fail(c->rank, "pf_get_block: the fp32 snapshot blocks are served from fp32 products only (not with PF_FLAG_DOUBLE_PRODUCTS)");
   PFCHK(c, velocities_ready(c));
   const size_t nc = ncell(c);
-  if (!strncmp(name, "FMAX", 4)) { HIPCHK(c, hipMemcpyAsync(host, c->fmax, nc * sizeof(float), hipMemcpyDeviceToHost, c->stream)); }
-  else if (!strncmp(name, "RMAX", 4)) { HIPCHK(c, hipMemcpyAsync(host, c->rmax, nc * sizeof(int), hipMemcpyDeviceToHost, c->stream)); }
-  else {
-    static const char *vec[4] = {"ZEL ", "2LPT", "31PT", "32PT"};
-    int o = -1;
-    for (int i = 0; i < 4; i++) if (!strncmp(name, vec[i], 4)) o = i;
-    const bool id = !strncmp(name, "ID  ", 4);
-    if (o < 0 && !id) return pf_fail(c->rank, "pf_get_block: unknown block '%.4s'", name);
-    if (id && id_bytes != 4 && id_bytes != 8) return pf_fail(c->rank, "pf_get_block: MYIDTYPE is 4 or 8 bytes");
-    const size_t rec = id ? (size_t)id_bytes : 3 * sizeof(float);
-    const size_t cap = (2 * c->field_bytes) / rec;
-    const unsigned long long gfirst = (unsigned long long)c->rank * nc;  // x-slabs: global index = rank * ncell + local
-    for (size_t first = 0; first < nc; first += cap) {
-      const size_t cnt = (nc - first < cap) ? nc - first : cap;
-      if (id) PFCHK(c, pf_launch_block_id(id_bytes, gfirst + first, cnt, staging(c), c->stream));
-      else PFCHK(c, pf_launch_block_vec3((const float *)c->vel12, nc, o, first, cnt, (float *)staging(c), c->stream));
-      HIPCHK(c, hipMemcpyAsync((char *)host + first * rec, staging(c), cnt * rec, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-    }
-  }
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  return 0;
+  if (!strncmp(name, "FMAX", 4)) return handoff_d2h(c, (char *)host, (const char *)c->fmax, nc * sizeof(float), 4, no_fill);
+  if (!strncmp(name, "RMAX", 4)) return handoff_d2h(c, (char *)host, (const char *)c->rmax, nc * sizeof(int), 4, no_fill);
+  static const char *vec[4] = {"ZEL ", "2LPT", "31PT", "32PT"};
+  int o = -1;
+  for (int i = 0; i < 4; i++) if (!strncmp(name, vec[i], 4)) o = i;
+  const bool id = !strncmp(name, "ID  ", 4);
+  if (o < 0 && !id) return pf_fail(c->rank, "pf_get_block: unknown block '%.4s'", name);
+  if (id && id_bytes != 4 && id_bytes != 8) return pf_fail(c->rank, "pf_get_block: MYIDTYPE is 4 or 8 bytes");
+  const size_t rec = id ? (size_t)id_bytes : 3 * sizeof(float);
+  const unsigned long long gfirst = (unsigned long long)c->rank * nc;  // x-slabs: global index = rank * ncell + local
+  auto fill = [&](size_t off, size_t len, char *stage, hipStream_t st) -> int {
+    if (id) PFCHK(c, pf_launch_block_id(id_bytes, gfirst + off / rec, len / rec, stage, st));
+    else PFCHK(c, pf_launch_block_vec3((const float *)c->vel12, nc, o, off / rec, len / rec, (float *)stage, st));
+    return 0;
+  };
+  return handoff_d2h(c, (char *)host, nullptr, nc * rec, rec, fill);
 }
 
 extern "C" int pf_get_second_derivative(pf_ctx *c, int i, double *host) {
@@ -1769,9 +1944,7 @@ extern "C" int pf_get_second_derivative(pf_ctx *c, int i, double *host) {
   if (!c->have_hessian) return pf_fail(c->rank, "pf_get_second_derivative: not computed");
   const long long nrows = (long long)c->nxl * c->n;
   PFCHK(c, pf_launch_real_export(c->fb, c->B[i], (double *)staging(c), nrows, c->n, rpitch(c), c->stream));
-  HIPCHK(c, hipMemcpyAsync(host, staging(c), (size_t)nrows * c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  return 0;
+  return handoff_d2h(c, (char *)host, staging(c), (size_t)nrows * c->n * sizeof(double), 1, no_fill);
 }
 
 extern "C" int pf_get_kvector(pf_ctx *c, int which, double *host) {
@@ -1790,9 +1963,7 @@ extern "C" int pf_debug_replicated_rows(pf_ctx *c, int kx0, int nkx, double *hos
   if ((size_t)nrows * c->nzh * 2 * sizeof(double) > 2 * c->field_bytes) return pf_fail(c->rank, "pf_debug_replicated_rows: %d rows exceed the staging area", nkx);
   const char *src = (const char *)c->dk_full + (size_t)kx0 * c->n * c->nzp * 2 * c->fb;
   PFCHK(c, pf_launch_spec_export(c->fb, src, (double *)staging(c), nrows, c->nzh, c->nzp, c->stream));
-  HIPCHK(c, hipMemcpyAsync(host, staging(c), (size_t)nrows * c->nzh * 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  return 0;
+  return handoff_d2h(c, (char *)host, staging(c), (size_t)nrows * c->nzh * 2 * sizeof(double), 1, no_fill);
 }
 extern "C" int pf_get_density(pf_ctx *c, double *host) {
   if (!c || !host) return 1;
@@ -1802,16 +1973,14 @@ extern "C" int pf_get_density(pf_ctx *c, double *host) {
 
 static int import_real(pf_ctx *c, const double *host, void *dst) {
   const long long nrows = (long long)c->nxl * c->n;
-  HIPCHK(c, hipMemcpyAsync(staging(c), host, (size_t)nrows * c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (handoff_h2d(c, staging(c), (const char *)host, (size_t)nrows * c->n * sizeof(double))) return 1;
   PFCHK(c, pf_launch_real_import(c->fb, (const double *)staging(c), dst, nrows, c->n, rpitch(c), c->stream));
   return 0;
 }
 static int export_real(pf_ctx *c, const void *src, double *host) {
   const long long nrows = (long long)c->nxl * c->n;
   PFCHK(c, pf_launch_real_export(c->fb, src, (double *)staging(c), nrows, c->n, rpitch(c), c->stream));
-  HIPCHK(c, hipMemcpyAsync(host, staging(c), (size_t)nrows * c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  return 0;
+  return handoff_d2h(c, (char *)host, staging(c), (size_t)nrows * c->n * sizeof(double), 1, no_fill);
 }
 extern "C" int pf_forward_transform(pf_ctx *c, const double *real_host, double *spec_host) {
   if (!c || !real_host || !spec_host) return 1;

@@ -22,6 +22,8 @@ struct PfTuning {
   int debug_fault;          // PF_DEBUG_PIPELINE_FAULT (tests only): 1 / 2 = one wait of the exchange pipeline left out
   int solve_beside_z;       // PF_SOLVE_BESIDE_Z: the solve of sweep radius i runs on its own stream beside the z-pass of radius i + 1 (1), every
                             // kernel in line (0), or -- the default, -1 -- beside with fp32 fields and in line with fp64 fields (pf_sweep)
+  int handoff_chunk_mb, handoff_threads;  // PF_HANDOFF_CHUNK_MB, PF_HANDOFF_THREADS: pieces and host threads of the hand-off (pf_api.hip PfHandoff)
+  bool host_register;       // PF_HOST_REGISTER: register the caller's product array with the driver, DMA straight into it
   bool preflight;           // PF_PREFLIGHT: pf_create holds the plan's bytes against the device's free memory before it allocates
   bool gtab;                // PF_GTAB: the inverse growing mode of the fast flavour from the polynomial table (pf_gtab.h)
 };

@@ -103,6 +103,8 @@ def lib(double_products: bool = False):
         L.orc_plane_acc_add.argtypes = [C.c_void_p, dp, C.c_int, C.c_int]
         L.orc_plane_acc_finish.argtypes = [C.c_void_p, C.c_int, dp]
         L.orc_plane_acc_destroy.argtypes = [C.c_void_p]
+        L.orc_plane_acc_power.restype = C.c_double
+        L.orc_plane_acc_power.argtypes = [C.c_void_p, C.c_int]
         L.orc_plane_acc_destroy.restype = None
         if double_products:
             _lib_dp = L
@@ -355,6 +357,10 @@ class PlaneStream:
         n = self.n
         assert rows.dtype == np.complex128 and rows.shape[1:] == (n, n // 2 + 1) and rows.flags.c_contiguous
         assert self.L.orc_plane_acc_add(self.h, _dp(rows.view(np.float64)), int(kx0), rows.shape[0]) == 0
+
+    def power(self, irad: int) -> float:
+        """sum over the modes added so far of |spec|^2 W(k R)^2, both halves of the spectrum: n^6 times the variance of the smoothed field"""
+        return float(self.L.orc_plane_acc_power(self.h, int(irad)))
 
     def finish(self, irad: int) -> np.ndarray:
         out = np.empty((self.ncomp, self.nplanes, self.n, self.n))

@@ -1,0 +1,137 @@
+"""BASELINE config 5 on its own workload, checked, on ONE GPU: the 2048^3 box with fp32 fields on eight ranks -- the largest box the
+reference's `unsigned int total_local_size` (src/pinocchio.h:297) allows per task on eight tasks (src/fmax-pfft.c:95-111 slabs).
+
+The box fits no single GPU (its spectrum alone is 35 GB in fp32, a rank's working set 200 GB).  What one GPU can do is run every
+rank of the decomposition in turn: a context that keeps the whole delta(k) (PF_REPLICATE_DK=1) needs no exchange in the sweep, and
+behind the loopback exchange it generates the whole spectrum itself from (seed, cosmology) -- pf_genic_density is a function of those
+alone (include/pinfmax.h, pf_set_loopback_exchange).  The rank's Fmax / Rmax / variance contributions / histogram are then those of
+its slab of the box, and are held against
+  (a) the plane oracle (the reference's filter per mode, the x-transform as the plain sum, its per-cell collapse pass) on sampled
+      x-planes, the device's own delta(k) streamed to the host in pieces of 64 kx rows (69 GB in fp64 otherwise);
+  (b) Parseval: the ranks' contributions to Smoothing.TrueVariance summed against the k-space sum of |delta(k)|^2 W(kR)^2, and the
+      210-bin Fmax histogram of the ranks summing to 2048^3 cells;
+  (c) the memory plan: what the rank holds against the 288 GB of the device.
+The LPT half needs peers (the source spectra are transposed between ranks): it cannot run checked on one GPU at this size and is
+covered at 512^3 by the multi-rank tests of this suite (fabric, gloo) and by the closed forms."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from pinocchio_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+# fp32 fields: |Fmax(device) - Fmax(oracle on the same fp32 delta(k))| on the cells with Fmax >= 0.5 -- the bound of DESIGN.md section 4,
+# set from the measured distributions in profiles/r06_fp32_contract.json (99.9 % quantile x 2)
+FP32_Q999_BOUND = 1.0e-3
+
+
+@pytest.fixture(scope="module")
+def api():
+    from pinocchio_amd import api as _api
+    return _api
+
+
+def run_config(api, n, P, fb, radii, checked, all_ranks, rows_per_piece, report=None):
+    x, y = synth.invgrow_table("lcdm")
+    nxl = n // P
+    planes = np.array([r * nxl + (7 * r + 3) % nxl for r in checked], dtype=np.int32)   # one x-plane inside every checked slab
+    genic = dict(seed=5 * n + P, box_true_mpc=float(n) / 0.7, omega0=0.25, omega_baryon=0.044, hubble100=0.7, primordial_index=0.96, sigma8=0.8)
+    po = oracle_lib.PlaneOracle(n, planes, 0)
+    po.set_invgrow(x, y)
+    st = po.stream(radii, po.HESSIAN)
+    tv_sum = np.zeros(len(radii))
+    hist = np.zeros(210, dtype=np.uint64)
+    got = {}
+    dev_gb, t_rank = [], []
+    os.environ["PF_REPLICATE_DK"] = "1"
+    try:
+        plan = api.plan_bytes(n, P, fb)
+        for r in all_ranks:
+            t0 = time.perf_counter()
+            with api.Fmax(n, rank=r, nranks=P, field_bytes=fb) as f:
+                assert int(f.L.pf_replicated_spectrum(f.h)) == 1
+                f.set_invgrow(x, y)
+                f._chk(f.L.pf_set_loopback_exchange(f.h, 0))      # nothing may move: a sweep that exchanged anything would read zeros
+                assert int(f.L.pf_loopback_active(f.h)) == 1
+                f.genic_density(**genic)
+                tv = f.sweep(radii)                                # this rank's contributions (the loopback all-reduce leaves them alone)
+                tv_sum += tv
+                hist += f.Fmax_PDF()
+                dev_gb.append(f.device_bytes / 1e9)
+                if r in checked:
+                    xl = int(planes[list(checked).index(r)]) - r * nxl
+                    got[r] = (f.block("FMAX").reshape(nxl, n, n)[xl].copy(), f.block("RMAX").view(np.int32).reshape(nxl, n, n)[xl].copy())
+                if r == all_ranks[0]:                              # the device's own delta(k), streamed into the oracle's accumulators
+                    for kx0 in range(0, n, rows_per_piece):
+                        rows = f.replicated_rows(kx0, min(rows_per_piece, n - kx0))
+                        st.add(rows, kx0)
+                    del rows
+            t_rank.append(time.perf_counter() - t0)
+    finally:
+        del os.environ["PF_REPLICATE_DK"]
+    # (c) the memory plan
+    assert max(dev_gb) <= plan[1] / 1e9 + 1e-6, (dev_gb, plan)
+    assert plan[1] / 1e9 < 288.0
+    # (b) Parseval and the histogram
+    n3, n6 = float(n) ** 3, float(n) ** 6
+    var_k = np.array([st.power(i) / n6 for i in range(len(radii))])
+    complete = len(all_ranks) == P
+    if complete:
+        assert int(hist.sum()) == n ** 3
+        rel = np.abs(tv_sum / var_k - 1.0)
+        assert np.all(rel <= (2e-5 if fb == 4 else 1e-11)), (tv_sum, var_k)
+    # (a) Fmax / Rmax of the checked slabs' planes against the plane oracle
+    for i in range(len(radii)):
+        po.collapse_times(i, st.finish(i))
+    wf = po.fmax.reshape(len(planes), n, n)
+    wr = po.rmax.reshape(len(planes), n, n)
+    stats = {}
+    for j, r in enumerate(checked):
+        gf, gr = got[r]
+        d = np.abs(gf.astype(np.float64) - wf[j].astype(np.float64))
+        sel = wf[j] >= 0.5                                  # the cells that matter downstream (collapse by z = 1: F >= 0.5)
+        q = np.quantile(d[sel], [0.5, 0.99, 0.999]) if sel.any() else np.zeros(3)
+        stats[int(r)] = {"plane": int(planes[j]), "cells": int(d.size), "cells_F_ge_0.5": int(sel.sum()), "q50": float(q[0]), "q99": float(q[1]),
+                         "q999": float(q[2]), "max": float(d[sel].max()) if sel.any() else 0.0, "rmax_differs": float(np.mean(gr != wr[j])),
+                         "collapsed_fraction_device": float(np.mean(gf >= 1.0)), "collapsed_fraction_oracle": float(np.mean(wf[j] >= 1.0))}
+        if fb == 4:
+            assert q[2] <= FP32_Q999_BOUND, stats[int(r)]
+            assert np.mean(gr != wr[j]) < 2e-3, stats[int(r)]
+        else:
+            ulp = np.spacing(np.maximum(np.abs(wf[j]), 1.0).astype(np.float32)).astype(np.float64)
+            # (the usual contract of fp64 fields: within 2 ulp(fp32) except where the reference's cubic is ill-conditioned, ~1e-5 of the cells)
+            assert np.sum(d > 2 * ulp) <= max(2, int(2e-5 * d.size)) and np.mean(gr != wr[j]) < 1e-3, stats[int(r)]
+        assert abs(stats[int(r)]["collapsed_fraction_device"] - stats[int(r)]["collapsed_fraction_oracle"]) < 1e-4
+        assert 0.05 < stats[int(r)]["collapsed_fraction_oracle"] < 0.95      # a physical field: neither empty nor everything collapsed
+    st.close(); po.close()
+    out = {"n": n, "ranks": P, "field_bytes": fb, "radii_cells": [float(v) for v in radii], "checked_ranks": [int(r) for r in checked],
+           "ranks_run": [int(r) for r in all_ranks], "device_GB_per_rank": max(dev_gb), "plan_GB_at_create_peak": [plan[0] / 1e9, plan[1] / 1e9],
+           "margin_GB_of_288": 288.0 - plan[1] / 1e9, "true_variance_ranks_summed": [float(v) for v in tv_sum],
+           "variance_k_space": [float(v) for v in var_k], "cells_in_histogram": int(hist.sum()), "seconds_per_rank": t_rank, "fmax_vs_plane_oracle": stats}
+    if report:
+        os.makedirs(os.path.dirname(report), exist_ok=True)
+        with open(report, "w") as fh:
+            json.dump(out, fh, indent=1)
+    print(json.dumps(out))
+    return out
+
+
+def test_a_small_box_the_same_way(api):
+    """256^3 on four ranks, fp32 and fp64 fields: the machinery of the test below at a size whose every rank is cheap -- all planes of
+    the argument are the same ones (whole spectrum generated per rank behind the loopback exchange, streamed plane oracle, Parseval)"""
+    for fb in (8, 4):
+        run_config(api, 256, 4, fb, np.array([6.0, 1.5, 0.0]), checked=(0, 3), all_ranks=(0, 1, 2, 3), rows_per_piece=50)
+
+
+def test_config5_every_rank_of_the_2048_box_on_one_gpu(api):
+    """2048^3, fp32 fields, eight ranks, three radii (one band-limited: R = 6 cells keeps |k| <= 496; one full: R = 1.5; R = 0): ranks 0
+    and 5 against the plane oracle, all eight for Parseval and the histogram"""
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = run_config(api, 2048, 8, 4, np.array([6.0, 1.5, 0.0]), checked=(0, 5), all_ranks=tuple(range(8)), rows_per_piece=64,
+                     report=os.path.join(here, "gpurun_out", "r06", "config5_2048.json"))
+    assert out["device_GB_per_rank"] < 288.0 and out["cells_in_histogram"] == 2048 ** 3

@@ -386,14 +386,16 @@ def test_fabric_exchange_selftest(api):
 
 
 _RCCL_CODE = """
-import ctypes as C, sys
+import ctypes as C, os, sys
 sys.path.insert(0, %r)
 from pinocchio_amd import api
-with api.Fmax(64) as f:
-    idbuf = (C.c_ubyte * 128)()
-    assert f.L.pf_rccl_unique_id(C.cast(idbuf, C.c_void_p)) == 0
-    assert f.L.pf_init_rccl(f.h, C.cast(idbuf, C.c_void_p)) == 0
-    assert f.L.pf_debug_exchange(f.h, 1 << 20) == 0
+for self_send in ("0", "1"):          # the rank's own block: a local copy beside the group (default), or ncclSend / ncclRecv to itself inside it
+    os.environ["PF_RCCL_SELF_SEND"] = self_send
+    with api.Fmax(64) as f:
+        idbuf = (C.c_ubyte * 128)()
+        assert f.L.pf_rccl_unique_id(C.cast(idbuf, C.c_void_p)) == 0
+        assert f.L.pf_init_rccl(f.h, C.cast(idbuf, C.c_void_p)) == 0
+        assert f.L.pf_debug_exchange(f.h, 1 << 20) == 0, self_send
 print("RCCL_OK")
 """
 
@@ -678,11 +680,88 @@ def test_late_communication_exposes_a_missing_wait(api, fault, n, P, delay_us, m
     assert any(not np.array_equal(res[r], fm1[r * nxl:(r + 1) * nxl]) for r in range(P))
 
 
+@pytest.mark.parametrize("fb", [8, 4])
+def test_loopback_slab_passes_on_fields_whose_answer_is_known(api, fb):
+    """512^3 on eight ranks, ONE rank on its own behind the loopback exchange, spectrum exchanged (PF_REPLICATE_DK=0): every pass of
+    such a slab is linear, and a field that repeats with the slab thickness along x and whose spectrum repeats with it along ky comes
+    back from the loopback exactly as it would from the peers (every rank holds the same numbers).  So the x-pass, the block layout the
+    exchange moves, the y-pass on the received blocks and the z-passes are held against numpy at the slab geometry of the run, in
+    both directions: reverse_transform (x, exchange, y, c2r) and forward_transform (r2c, y, exchange, x)."""
+    n, P = 512, 8
+    nxl, h = n // P, n // 2
+    rng = np.random.default_rng(40 + fb)
+    tol = 2e-13 if fb == 8 else 3e-5
+    os.environ["PF_REPLICATE_DK"] = "0"
+    try:
+        for r in (0, 5):
+            with api.Fmax(n, rank=r, nranks=P, field_bytes=fb) as f:
+                f.set_transposed_spectra(True)                       # spectra cross the boundary as this rank's ky-slab: no regrouping exchange
+                f._chk(f.L.pf_set_loopback_exchange(f.h, 1 << 20))   # every hand-back copies
+                # reverse: S[kx, ky, kz] = a[kx] g[ky mod nyl, kz], a on multiples of P and Hermitian (so that A(x) = ifft(a) is real, of period nxl)
+                a = np.zeros(n, dtype=np.complex128)
+                for kx in range(0, h + 1, P):
+                    a[kx] = rng.standard_normal() + (0.0 if kx in (0, h) else 1j * rng.standard_normal())
+                    a[(-kx) % n] = np.conj(a[kx])
+                A = np.fft.ifft(a)
+                assert np.max(np.abs(A.imag)) < 1e-15 and np.allclose(A[:nxl], A[nxl:2 * nxl])
+                g = rng.standard_normal((nxl, h + 1)) + 1j * rng.standard_normal((nxl, h + 1))
+                spec = np.ascontiguousarray(g[:, None, :] * a[None, :, None])                # this rank's ky-slab [nyl][kx][kz]: the same for every rank
+                got = f.reverse_transform(spec)
+                R = np.fft.irfft(np.fft.ifft(np.tile(g, (P, 1)), axis=0), n=n, axis=1)     # the (y, z) factor of the whole box's field
+                want = A.real[r * nxl:(r + 1) * nxl, None, None] * R[None, :, :]
+                assert np.max(np.abs(got - want)) <= tol * np.max(np.abs(want)), ("reverse", r, fb)
+                # forward: f(x, y, z) = A(x mod nxl) c(y) w(z), c on multiples of P (its spectrum repeats with nyl)
+                Ax = rng.standard_normal(nxl)
+                cy = np.zeros(n); cy[::P] = rng.standard_normal(n // P)
+                wz = rng.standard_normal(n)
+                real = np.ascontiguousarray(Ax[:, None, None] * cy[None, :, None] * wz[None, None, :])
+                got = f.forward_transform(real)                                               # [nyl (ky of this rank)][kx][kz]
+                Fy = np.fft.fft(cy)
+                want = Fy[r * nxl:(r + 1) * nxl, None, None] * np.fft.fft(np.tile(Ax, P))[None, :, None] * np.fft.rfft(wz)[None, None, :]
+                assert np.max(np.abs(got - want)) <= tol * np.max(np.abs(want)), ("forward", r, fb)
+    finally:
+        del os.environ["PF_REPLICATE_DK"]
+
+
+@pytest.mark.parametrize("fb", [8, 4])
+def test_loopback_slab_with_the_whole_spectrum_is_the_single_gpu_runs_slab(api, fb):
+    """512^3 on eight ranks, ONE rank on its own, the whole delta(k) on the rank (PF_REPLICATE_DK=1) and generated by it (pf_genic_density
+    behind the loopback exchange): the sweep exchanges nothing, and the rank's Fmax / Rmax are the single-GPU run's on its slab, bit for
+    bit -- what tests/test_gpu_config5.py relies on at 2048^3, where no single-GPU run exists"""
+    n, P = 512, 8
+    nxl = n // P
+    x, y = synth.invgrow_table("lcdm")
+    radii = np.array([6.0, 1.5, 0.0])
+    genic = dict(seed=77, box_true_mpc=float(n) / 0.7, omega0=0.25, omega_baryon=0.044, hubble100=0.7, primordial_index=0.96, pknorm=2.0e7)
+    with api.Fmax(n, field_bytes=fb) as f1:
+        f1.genic_density(**genic)
+        f1.set_invgrow(x, y)
+        tv1 = f1.sweep(radii)
+        fm1 = f1.block("FMAX").reshape(n, n, n)
+        rm1 = f1.block("RMAX").reshape(n, n, n)
+        pdf1 = f1.Fmax_PDF()
+    os.environ["PF_REPLICATE_DK"] = "1"
+    try:
+        tv, pdf = np.zeros(3), np.zeros(210, dtype=np.uint64)
+        for r in range(P):
+            with api.Fmax(n, rank=r, nranks=P, field_bytes=fb) as f:
+                f.set_invgrow(x, y)
+                f._chk(f.L.pf_set_loopback_exchange(f.h, 0))
+                f.genic_density(**genic)
+                tv += f.sweep(radii)
+                pdf += f.Fmax_PDF()
+                assert np.array_equal(f.block("FMAX").reshape(nxl, n, n), fm1[r * nxl:(r + 1) * nxl]), (r, fb)
+                assert np.array_equal(f.block("RMAX").reshape(nxl, n, n), rm1[r * nxl:(r + 1) * nxl]), (r, fb)
+        assert np.allclose(tv, tv1, rtol=1e-12) and np.array_equal(pdf, pdf1)
+    finally:
+        del os.environ["PF_REPLICATE_DK"]
+
+
 def test_one_rank_slab_with_loopback_exchange(api):
     """the measurement aid behind `bench.py --slab-of P` (pf_set_loopback_exchange): one rank of a P-rank decomposition runs the whole
     step on its own, its own blocks handed back by the all-to-all -- copied at first, then not moved at all.  Nothing about the
     numbers is claimed except that they are finite and that the step runs in both modes, with fp64 and fp32 fields, with the
-    spectrum replicated or exchanged; a context without an exchange refuses."""
+    spectrum replicated or exchanged; a context without an exchange refuses.  (What a loopback slab CAN be held against: the two tests above.)"""
     x, y = synth.invgrow_table("lcdm")
     radii = synth.radii_ladder(12)[[0, 6, 11]] * (64 / 1024.0)
     radii[-1] = 0.0

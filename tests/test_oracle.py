@@ -569,6 +569,12 @@ def test_streamed_plane_oracle_is_the_plane_oracle_to_the_bit(n):
         kx += m
     with pytest.raises(AssertionError):
         st.add(np.ascontiguousarray(dk[:1]), 0)         # every row was added already
+    o = oracle_lib.Oracle(n, 2)
+    o.set_density(dk)
+    x, y = synth.invgrow_table("lcdm")
+    o.set_invgrow(x, y)
+    tv = o.compute_fmax(radii, do_lpt=False)
     for i, rs in enumerate(radii):
+        assert abs(st.power(i) / float(n) ** 6 - tv[i]) <= 1e-12 * tv[i], (rs, st.power(i) / float(n) ** 6, tv[i])   # Parseval against TrueVariance
         assert np.array_equal(st.finish(i), po.derivatives(dk, rs, po.HESSIAN)), rs
     st.close()
