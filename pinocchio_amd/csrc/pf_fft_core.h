@@ -18,6 +18,19 @@
 #else
 #define PF_HD inline
 #endif
+#include "pf_cxpk.h"
+// PF_PK_F32: on the device every operation on pfc<float> below goes through the packed algebra of pf_cxpk.h (round 6: the fp32
+// z-passes, the fp32 strided passes of lines below 1024 points and the fp32 mixed-radix passes were written in scalar complex
+// arithmetic that the compiler packed only in part, paying a v_mov / v_xor per swapped or negated operand).  -DPF_PK_F32=0: the
+// plain expressions (A/B builds; the host always takes them).
+#ifndef PF_PK_F32
+#define PF_PK_F32 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && PF_PK_F32
+#define PF_PK_DEV 1
+#else
+#define PF_PK_DEV 0
+#endif
 
 template <typename F>
 struct alignas(2 * sizeof(F)) pfc {
@@ -25,17 +38,39 @@ struct alignas(2 * sizeof(F)) pfc {
 };
 
 template <typename F> PF_HD pfc<F> pf_mk(F x, F y) { pfc<F> r; r.x = x; r.y = y; return r; }
-template <typename F> PF_HD pfc<F> operator+(pfc<F> a, pfc<F> b) { return pf_mk<F>(a.x + b.x, a.y + b.y); }
-template <typename F> PF_HD pfc<F> operator-(pfc<F> a, pfc<F> b) { return pf_mk<F>(a.x - b.x, a.y - b.y); }
+template <typename F> struct pf_is_f32 { static constexpr bool value = false; };
+template <> struct pf_is_f32<float> { static constexpr bool value = true; };
+#if PF_PK_DEV
+// pfc<float> <-> the register pair of the packed algebra: the same eight bytes
+template <typename F> __device__ __forceinline__ pf_f2 pf_pk(pfc<F> a) { pf_f2 r; r.x = (float)a.x; r.y = (float)a.y; return r; }
+template <typename F> __device__ __forceinline__ pfc<F> pf_unpk(pf_f2 a) { return pf_mk<F>((F)a.x, (F)a.y); }
+#define PF_IF_PK(F, expr) if constexpr (pf_is_f32<F>::value) return pf_unpk<F>(expr);
+#else
+#define PF_IF_PK(F, expr)
+#endif
+template <typename F> PF_HD pfc<F> operator+(pfc<F> a, pfc<F> b) { PF_IF_PK(F, pf_pk(a) + pf_pk(b)) return pf_mk<F>(a.x + b.x, a.y + b.y); }
+template <typename F> PF_HD pfc<F> operator-(pfc<F> a, pfc<F> b) { PF_IF_PK(F, pf_pk(a) - pf_pk(b)) return pf_mk<F>(a.x - b.x, a.y - b.y); }
 template <typename F> PF_HD pfc<F> pf_cmul(pfc<F> a, pfc<F> b) {
+  PF_IF_PK(F, PfCxPk::cmul<+1>(pf_pk(a), pf_pk(b)))
   return pf_mk<F>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
-template <typename F> PF_HD pfc<F> pf_scale(pfc<F> a, F s) { return pf_mk<F>(a.x * s, a.y * s); }
+// a * conj(b)
+template <typename F> PF_HD pfc<F> pf_cmulc(pfc<F> a, pfc<F> b) {
+  PF_IF_PK(F, PfCxPk::cmul<-1>(pf_pk(a), pf_pk(b)))
+  return pf_mk<F>(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+template <typename F> PF_HD pfc<F> pf_scale(pfc<F> a, F s) { PF_IF_PK(F, pf_pk(a) * (float)s) return pf_mk<F>(a.x * s, a.y * s); }
 template <typename F> PF_HD pfc<F> pf_conj(pfc<F> a) { return pf_mk<F>(a.x, -a.y); }
 // multiply by (DIR * i): DIR=+1 -> (-y, x); DIR=-1 -> (y, -x)
 template <int DIR, typename F> PF_HD pfc<F> pf_mul_i(pfc<F> a) {
+  PF_IF_PK(F, PfCxPk::muli<DIR>(pf_pk(a)))
   return DIR > 0 ? pf_mk<F>(-a.y, a.x) : pf_mk<F>(a.y, -a.x);
 }
+// a + DIR i b, a - DIR i b, a + conj(b), a - conj(b): one instruction each in the packed algebra
+template <int DIR, typename F> PF_HD pfc<F> pf_addi(pfc<F> a, pfc<F> b) { PF_IF_PK(F, PfCxPk::addi<DIR>(pf_pk(a), pf_pk(b))) return a + pf_mul_i<DIR>(b); }
+template <int DIR, typename F> PF_HD pfc<F> pf_subi(pfc<F> a, pfc<F> b) { PF_IF_PK(F, PfCxPk::subi<DIR>(pf_pk(a), pf_pk(b))) return a - pf_mul_i<DIR>(b); }
+template <typename F> PF_HD pfc<F> pf_addc(pfc<F> a, pfc<F> b) { PF_IF_PK(F, PfCxPk::addc(pf_pk(a), pf_pk(b))) return a + pf_conj(b); }
+template <typename F> PF_HD pfc<F> pf_subc(pfc<F> a, pfc<F> b) { PF_IF_PK(F, PfCxPk::subc(pf_pk(a), pf_pk(b))) return a - pf_conj(b); }
 
 // The scalar behind a field type: itself, or the lane type of a two-lane vector.  pfc<pf_f32x2> is TWO neighbouring fp32
 // columns carried by one thread -- x = (re of column 0, re of column 1), y = the imaginary parts -- so that every operation
@@ -105,26 +140,34 @@ template <int DIR, typename F> PF_HD void pf_bfly2(pfc<F> &a, pfc<F> &b) {
   b = t;
 }
 template <int DIR, typename F> PF_HD void pf_bfly4(pfc<F> &v0, pfc<F> &v1, pfc<F> &v2, pfc<F> &v3) {
-  pfc<F> a = v0 + v2, b = v0 - v2, c = v1 + v3, d = pf_mul_i<DIR>(v1 - v3);
+  pfc<F> a = v0 + v2, b = v0 - v2, c = v1 + v3, d = v1 - v3;
   v0 = a + c;
-  v1 = b + d;
+  v1 = pf_addi<DIR>(b, d);   // b + DIR i d (the same bits as adding pf_mul_i(d))
   v2 = a - c;
-  v3 = b - d;
+  v3 = pf_subi<DIR>(b, d);
 }
 template <int DIR, typename F> PF_HD void pf_bfly8(pfc<F> (&u)[8]) {
   pf_bfly4<DIR>(u[0], u[2], u[4], u[6]);  // E_0..3 in u[0],u[2],u[4],u[6]
   pf_bfly4<DIR>(u[1], u[3], u[5], u[7]);  // O_0..3 in u[1],u[3],u[5],u[7]
   const F h = (F)0.70710678118654752440;
-  // (DIR = +-1 written out: the same operations, and no int * vector products for the two-lane field type)
-  pfc<F> o1 = DIR > 0 ? pf_mk<F>(h * (u[3].x - u[3].y), h * (u[3].y + u[3].x))      // W8^1 = h(1, DIR)
-                      : pf_mk<F>(h * (u[3].x + u[3].y), h * (u[3].y - u[3].x));
-  pfc<F> o2 = pf_mul_i<DIR>(u[5]);                                                  // W8^2 = DIR i
-  pfc<F> o3 = DIR > 0 ? pf_mk<F>(h * (-u[7].x - u[7].y), h * (-u[7].y + u[7].x))    // W8^3 = h(-1, DIR)
-                      : pf_mk<F>(h * (-u[7].x + u[7].y), h * (-u[7].y - u[7].x));
-  pfc<F> e0 = u[0], e1 = u[2], e2 = u[4], e3 = u[6], o0 = u[1];
+  pfc<F> o1, o3;
+#if PF_PK_DEV
+  if constexpr (pf_is_f32<F>::value) {  // W8^1 = h (1 + DIR i), W8^3 = h (-1 + DIR i): a product with a constant each
+    o1 = pf_unpk<F>(PfCxPk::cmulc<DIR>(pf_pk(u[3]), 0.70710678118654752440, 0.70710678118654752440));
+    o3 = pf_unpk<F>(PfCxPk::cmulc<DIR>(pf_pk(u[7]), -0.70710678118654752440, 0.70710678118654752440));
+  } else
+#endif
+  {
+    // (DIR = +-1 written out: the same operations, and no int * vector products for the two-lane field type)
+    o1 = DIR > 0 ? pf_mk<F>(h * (u[3].x - u[3].y), h * (u[3].y + u[3].x))      // W8^1 = h(1, DIR)
+                 : pf_mk<F>(h * (u[3].x + u[3].y), h * (u[3].y - u[3].x));
+    o3 = DIR > 0 ? pf_mk<F>(h * (-u[7].x - u[7].y), h * (-u[7].y + u[7].x))    // W8^3 = h(-1, DIR)
+                 : pf_mk<F>(h * (-u[7].x + u[7].y), h * (-u[7].y - u[7].x));
+  }
+  pfc<F> e0 = u[0], e1 = u[2], e2 = u[4], e3 = u[6], o0 = u[1], o2 = u[5];   // W8^2 = DIR i: folded into the sums of e2
   u[0] = e0 + o0; u[4] = e0 - o0;
   u[1] = e1 + o1; u[5] = e1 - o1;
-  u[2] = e2 + o2; u[6] = e2 - o2;
+  u[2] = pf_addi<DIR>(e2, o2); u[6] = pf_subi<DIR>(e2, o2);
   u[3] = e3 + o3; u[7] = e3 - o3;
 }
 
@@ -248,16 +291,17 @@ template <typename F> PF_HD pfc<F> pf_c2r_pre(pfc<F> xk, pfc<F> xmk, pfc<F> wk /
   if (k0) {  // k = 0: only the real parts of X[0] and X[M]
     return pf_mk<F>(xk.x + xmk.x, xk.x - xmk.x);
   }
-  pfc<F> b = pf_conj(xmk);
-  pfc<F> s = xk + b, d = pf_cmul(xk - b, wk);
-  return pf_mk<F>(s.x - d.y, s.y + d.x);
+  pfc<F> s = pf_addc(xk, xmk), d = pf_cmul(pf_subc(xk, xmk), wk);   // xk +- conj(xmk)
+  return pf_addi<+1>(s, d);                                          // (s.x - d.y, s.y + d.x)
 }
 // r2c, unnormalised, from Z = FFT_M(x[2n] + i x[2n+1]) (forward sign):
 //   X[k] = E + e^{-2 pi i k / N} O,  E = (Z[k] + conj Z[M-k])/2,  O = (Z[k] - conj Z[M-k])/(2i)
 template <typename F> PF_HD pfc<F> pf_r2c_post(pfc<F> zk, pfc<F> zmk, pfc<F> wk /* e^{+2 pi i k/N} */) {
-  pfc<F> b = pf_conj(zmk);
-  pfc<F> e = pf_scale(zk + b, (F)0.5);
-  pfc<F> d = pf_scale(zk - b, (F)0.5);
+  pfc<F> e = pf_scale(pf_addc(zk, zmk), (F)0.5);
+  pfc<F> d = pf_scale(pf_subc(zk, zmk), (F)0.5);
+#if PF_PK_DEV
+  if constexpr (pf_is_f32<F>::value) return pf_subi<+1>(e, pf_cmulc(d, wk));   // e + (d / i) conj(w) = e - i (d conj(w))
+#endif
   pfc<F> o = pf_mk<F>(d.y, -d.x);  // d / i
   return e + pf_cmul(o, pf_conj(wk));
 }

@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(TL *(N / 16)) k_c2r(const PfC2RParams p) {
 #pragma unroll
   for (int m = 0; m < 8; m++) {
     const int e = tl + m * NT;
-    v[m] = pf_zfold<F>(L[e], L[M - e], e, M, mul, kf, tw[e]);
+    v[m] = pf_zfold<F>(L[e], L[M - e], e, M, mul, kf, tw[e], m == 0);
   }
   __syncthreads();
 
@@ -284,7 +284,7 @@ __global__ void __launch_bounds__(TL *(N / 16)) k_c2r(const PfC2RParams p) {
 #pragma unroll
       for (int m = 0; m < 8; m++) {
         const int n2 = tl + m * NT;
-        o[n2] = pf_mk<F>(pf_norm_dc(v[m].x, norm, dcv), pf_norm_dc(v[m].y, norm, dcv));
+        o[n2] = pf_norm_dc2(v[m], norm, dcv);
       }
     }
   }
@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(TL *(N / 16)) k_c2r_persistent(const PfC2RPara
 #pragma unroll
     for (int m = 0; m < 8; m++) {
       const int e = tlj + m * NT;
-      v[m] = pf_zfold<F>(L[e], L[M - e], e, M, mul, kf, tw[e]);
+      v[m] = pf_zfold<F>(L[e], L[M - e], e, M, mul, kf, tw[e], m == 0);
     }
     // from here to the end of the stages a line belongs to its own NT threads: one wave for N <= 1024, whose LDS accesses
     // stay in order without workgroup barriers (four of them per tile at N = 1024)
@@ -363,7 +363,7 @@ __global__ void __launch_bounds__(TL *(N / 16)) k_c2r_persistent(const PfC2RPara
       } else {
         C *o = reinterpret_cast<C *>(reinterpret_cast<F *>(p.job[job].out) + row * (p.job[job].out_f32 == 2 ? (long long)N : p.out_pitch));
 #pragma unroll
-        for (int m = 0; m < 8; m++) pf_st_stream(&o[tlj + m * NT], pf_mk<F>(pf_norm_dc(v[m].x, norm, dcv), pf_norm_dc(v[m].y, norm, dcv)));
+        for (int m = 0; m < 8; m++) pf_st_stream(&o[tlj + m * NT], pf_norm_dc2(v[m], norm, dcv));
       }
     }
     // the next phase A rewrites every line: all waves must be done with theirs
@@ -474,6 +474,8 @@ __device__ __forceinline__ void pf_c2r_invariants_body(const PfC2RParams &p, lon
 #pragma unroll
   for (int j = 1; j < TL; j++)
     if (l == j) { in = reinterpret_cast<const C *>(p.job[j].in); mul = p.job[j].mul; }
+  // (a line of 64 threads and more is a whole number of waves: its kz factor is the same for every lane -- scalar branches, no exec masks)
+  if constexpr (NT >= 64) mul = __builtin_amdgcn_readfirstlane(mul);
   double *__restrict__ o1 = IN_PLACE ? reinterpret_cast<double *>(p.job[0].out) : p.inv_out[0],
          *__restrict__ o2 = IN_PLACE ? reinterpret_cast<double *>(p.job[1].out) : p.inv_out[1],
          *__restrict__ o3 = IN_PLACE ? reinterpret_cast<double *>(p.job[2].out) : p.inv_out[2];
@@ -591,7 +593,7 @@ PF_ZI_PRAGMA(unroll PF_ZI_RUNROLL)
     for (int m = 0; m < 8; m++) {
       const int e = tlj + m * NT;
       // (element e itself is still in the register it was loaded into, where the row was loaded by this iteration)
-      v[m] = pf_zfold<F>((PF_ZI_OWN && !PREFETCH && !DMA) ? nxt[m] : L[e], L[M - e], e, M, mul, kf, tw[e]);  // (SPEC: nxt holds this row since the end of the iteration before)
+      v[m] = pf_zfold<F>((PF_ZI_OWN && !PREFETCH && !DMA) ? nxt[m] : L[e], L[M - e], e, M, mul, kf, tw[e], m == 0);  // (SPEC: nxt holds this row since the end of the iteration before)
     }
     line_sync();
     if (PREFETCH && R + gridDim.x < nrows) fetch(R + gridDim.x);  // in flight during the stages and the reduction below
@@ -604,7 +606,7 @@ PF_ZI_PRAGMA(unroll PF_ZI_RUNROLL)
     // the real row of this component, in order, into its line
     C *H = L;
 #pragma unroll
-    for (int m = 0; m < 8; m++) H[tlj + m * NT] = pf_mk<F>(pf_norm_dc(v[m].x, norm, dcv), pf_norm_dc(v[m].y, norm, dcv));
+    for (int m = 0; m < 8; m++) H[tlj + m * NT] = pf_norm_dc2(v[m], norm, dcv);
     __syncthreads();
     // the transform waves are done with this row: their next one travels while waves 6, 7 reduce.  (Past the last row: zeros, not
     // "nothing" -- a conditional request would keep the OLD row alive through the stages, in 36 registers the kernel does not have)

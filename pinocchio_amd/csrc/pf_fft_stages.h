@@ -66,10 +66,17 @@ struct PfStages {
 
 // 1/N^3 normalisation plus the DC mode, one definition for every z-pass so that they round alike
 template <typename F> __device__ __forceinline__ F pf_norm_dc(F v, F norm, F dc) { return v * norm + dc; }
+// ... on both reals of a complex (one fma per real either way: the same bits; fp32: ONE packed instruction)
+template <typename F> __device__ __forceinline__ pfc<F> pf_norm_dc2(pfc<F> v, F norm, F dc) {
+#if PF_PK_DEV
+  if constexpr (pf_is_f32<F>::value) return pf_unpk<F>(PfCxPk::fma1(pf_pk(v), (float)norm, (float)dc));
+#endif
+  return pf_mk<F>(pf_norm_dc(v.x, norm, dc), pf_norm_dc(v.y, norm, dc));
+}
 
 // kz factor + Hermitian fold of one element pair (k, M-k) of a half-spectrum row (see pf_c2r_pre)
 template <typename F>
-__device__ __forceinline__ pfc<F> pf_zfold(pfc<F> xk, pfc<F> xmk, int e, int M, int mul, F kf, pfc<F> wk) {
+__device__ __forceinline__ pfc<F> pf_zfold(pfc<F> xk, pfc<F> xmk, int e, int M, int mul, F kf, pfc<F> wk, bool maybe0 = true) {
   if (mul != 0 /* PF_MUL_ONE */) {
     F fk = kf * (F)e, fm = kf * (F)(M - e);
     if (mul == 2 /* PF_MUL_K2 */) { fk *= fk; fm *= fm; }
@@ -77,5 +84,6 @@ __device__ __forceinline__ pfc<F> pf_zfold(pfc<F> xk, pfc<F> xmk, int e, int M, 
     xmk = pf_scale(xmk, fm);
     if (mul == 3 /* PF_MUL_IK */) { xk = pf_mul_i<+1>(xk); xmk = pf_mul_i<+1>(xmk); }
   }
-  return pf_c2r_pre<F>(xk, xmk, wk, e == 0);
+  // maybe0: false where the caller knows e > 0 (register m > 0 of a thread: e = tl + m NT) -- the k = 0 form then leaves no trace in the code
+  return pf_c2r_pre<F>(xk, xmk, wk, maybe0 && e == 0);
 }

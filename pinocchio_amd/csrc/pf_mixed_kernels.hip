@@ -381,7 +381,7 @@ __global__ void __launch_bounds__(256) k_mixed_c2r(const PfC2RParams p, const Pf
 #pragma unroll
   for (int m = 0; m < R0; m++) {
     const int e = tl + m * nt;
-    v[m] = pf_zfold<F>(own[m], L[PFP(M - e)], e, M, mul, kf, v[m]);
+    v[m] = pf_zfold<F>(own[m], L[PFP(M - e)], e, M, mul, kf, v[m], m == 0);
   }
   __syncthreads();
   const F norm = (F)p.norm;
@@ -484,7 +484,7 @@ __global__ void __launch_bounds__(PLAN::n ? 6 * (PLAN::n / R0) : (R0 == 8 ? 768 
          *__restrict__ o2 = IN_PLACE ? reinterpret_cast<double *>(p.job[1].out) : p.inv_out[1],
          *__restrict__ o3 = IN_PLACE ? reinterpret_cast<double *>(p.job[2].out) : p.inv_out[2];
   auto sync = [&]() { __syncthreads(); };
-  auto keep = [&](int pos, C val) { L[pos] = pf_mk<F>(pf_norm_dc(val.x, norm, dcv), pf_norm_dc(val.y, norm, dcv)); };  // complex j = reals 2 j, 2 j + 1
+  auto keep = [&](int pos, C val) { L[pos] = pf_norm_dc2(val, norm, dcv); };  // complex j = reals 2 j, 2 j + 1
 #pragma unroll 1
   for (long long row = blockIdx.x; row < p.nlines; row += gridDim.x) {
     int tlj = tl, tidj = tid;
@@ -505,7 +505,7 @@ __global__ void __launch_bounds__(PLAN::n ? 6 * (PLAN::n / R0) : (R0 == 8 ? 768 
 #pragma unroll
     for (int m = 0; m < R0; m++) {
       const int e = tlj + m * nt;
-      v[m] = pf_zfold<F>(own[m], L[M - e], e, M, mul, kf, v[m]);
+      v[m] = pf_zfold<F>(own[m], L[M - e], e, M, mul, kf, v[m], m == 0);
     }
     __syncthreads();
     pf_dft_small<R0, +1>(v);

@@ -40,6 +40,25 @@ def build(force: bool = False) -> str:
     return SO
 
 
+
+def usable_cores() -> int:
+    """the cores this process may really use: the hardware threads, cut by its CPU set and by the CPU-time quota of its control group
+    (cpu.max: on the GPU boxes of this pool 16 of the host's 256 hardware threads -- 256 OpenMP threads on 16 cores' worth of quota only
+    get throttled: the 2048^3 plane oracle took 310 s that way, round 6)"""
+    cores = os.cpu_count() or 1
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            cores = min(cores, max(1, int(float(q) / float(per))))
+    except (OSError, ValueError):
+        pass
+    return max(1, cores)
+
+
 def lib(double_products: bool = False):
     """the oracle, or its -DDOUBLE_PRECISION_PRODUCTS build"""
     global _lib, _lib_dp
@@ -125,7 +144,7 @@ class Oracle:
         self.product_dtype = PRODUCT_DTYPE_DP if double_products else PRODUCT_DTYPE
         self.n = n
         if nthreads <= 0:  # the slab loops have n iterations: more threads than n/4 only add fork/join cost (256-thread hosts)
-            nthreads = max(1, min(os.cpu_count() or 1, n // 4))
+            nthreads = max(1, min(usable_cores(), n // 4))
         self.h = self.L.orc_create(n, nthreads)
         if not self.h:
             raise ValueError("orc_create failed (n must be even and >= 4)")
@@ -284,7 +303,7 @@ class PlaneOracle:
         self.n = n
         self.planes = np.ascontiguousarray(planes, dtype=np.int32)
         if nthreads <= 0:
-            nthreads = max(1, min(os.cpu_count() or 1, n // 4))
+            nthreads = max(1, min(usable_cores(), n // 4))
         self.h = self.L.orc_create_planes(n, nthreads)
         if not self.h:
             raise ValueError("orc_create_planes failed")

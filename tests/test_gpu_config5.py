@@ -26,8 +26,9 @@ from pinocchio_amd import synth
 pytestmark = pytest.mark.gpu
 
 # fp32 fields: |Fmax(device) - Fmax(oracle on the same fp32 delta(k))| on the cells with Fmax >= 0.5 -- the bound of DESIGN.md section 4,
-# set from the measured distributions in profiles/r06_fp32_contract.json (99.9 % quantile x 2)
-FP32_Q999_BOUND = 1.0e-3
+# set from the measured distributions in profiles/r06_fp32_contract.json (99.9 % quantile x 2, rounded up: 2.4e-6 at 256^3, 3.8e-6 at 1024^3,
+# 3.1e-6 on the planes of this test)
+FP32_Q999_BOUND = 1.0e-5
 
 
 @pytest.fixture(scope="module")
@@ -100,7 +101,7 @@ def run_config(api, n, P, fb, radii, checked, all_ranks, rows_per_piece, report=
                          "q999": float(q[2]), "max": float(d[sel].max()) if sel.any() else 0.0, "rmax_differs": float(np.mean(gr != wr[j])),
                          "collapsed_fraction_device": float(np.mean(gf >= 1.0)), "collapsed_fraction_oracle": float(np.mean(wf[j] >= 1.0))}
         if fb == 4:
-            assert q[2] <= FP32_Q999_BOUND, stats[int(r)]
+            assert q[2] <= FP32_Q999_BOUND and np.sum(d[sel] > 1e-4) <= max(2, int(1e-5 * sel.sum())), stats[int(r)]
             assert np.mean(gr != wr[j]) < 2e-3, stats[int(r)]
         else:
             ulp = np.spacing(np.maximum(np.abs(wf[j]), 1.0).astype(np.float32)).astype(np.float64)

@@ -270,14 +270,17 @@ def test_fmax_only_skips_lpt_and_reentry(api):
 
 @pytest.mark.parametrize("n", [64, 256])
 def test_fp32_field_path(api, n):
-    """config 5: fp32 density/derivative fields, fp64 collapse solve.  Stated
-    tolerance: Hessian rel-L2 <= 1e-5; |dFmax| <= 1e-3 on 99.9 % of cells with F >= 0.5."""
+    """config 5: fp32 density/derivative fields, fp64 collapse solve.  The contract of DESIGN.md section 4, set from the measured
+    distributions of profiles/r06_fp32_contract.json (256^3 against the oracle: 99.9 % of the cells with F >= 0.5 within 2.4e-6, 99.99 %
+    within 2.9e-6; 1024^3 against fp64 fields: 3.8e-6 / 4.9e-6; the rest are the ill-conditioned cells of the cubic, where fp64 fields
+    differ from the oracle as much): the 99.9 % quantile of |dFmax| <= 1e-5 (twice the measured one, rounded up) and all but 1e-5 of
+    the cells within the survey's 1e-4."""
     radii = np.array([4.0, 2.0, 1.0, 0.0]) * (n / 64.0) ** 0.5
     (tv, p, pdf, _), (tv_o, po, pdf_o, _) = _run_both(api, n, radii, field_bytes=4)
     assert np.allclose(tv, tv_o, rtol=1e-5)
     sel = po["Fmax"] >= 0.5
     d = np.abs(p["Fmax"][sel].astype(np.float64) - po["Fmax"][sel].astype(np.float64))
-    assert np.mean(d <= 1e-3) > 0.999
+    assert np.quantile(d, 0.999) <= 1e-5 and np.sum(d > 1e-4) <= max(2, int(1e-5 * d.size)), (float(np.quantile(d, 0.999)), int(np.sum(d > 1e-4)), d.size)
     for name in ("Vel", "Vel_2LPT", "Vel_3LPT_1", "Vel_3LPT_2"):
         a, b = p[name].astype(np.float64), po[name].astype(np.float64)
         assert np.sqrt(np.mean((a - b) ** 2)) <= 2e-5 * np.sqrt(np.mean(b ** 2)), name
@@ -311,7 +314,8 @@ def test_fp32_fields_on_the_largest_box_one_gpu_holds(api):
     assert rm.min() >= -1 and rm.max() == 2
     sel = fm64 >= 0.5
     d = np.abs(fm[sel].astype(np.float64) - fm64[sel].astype(np.float64))
-    assert np.mean(d <= 1e-3) > 0.999, float(np.mean(d <= 1e-3))
+    nfar = int(np.sum(d > 1e-4))   # (the quantile of 6.8e8 numbers by a partition of a subsample: every 16th cell)
+    assert np.quantile(d[::16], 0.999) <= 1e-5 and nfar <= 1e-5 * d.size, (float(np.quantile(d[::16], 0.999)), nfar, d.size)
     assert abs(float((fm >= 1.0).mean()) - float((fm64 >= 1.0).mean())) < 1e-4   # collapsed fraction
 
 
