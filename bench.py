@@ -62,7 +62,9 @@ def alg_bytes_per_cell(ns: int, w: int, lpt: bool) -> float:
 # grid sizes whose stage plans csrc/pf_mixed_kernels.hip compiles in (PF_MIXED_CT_SIZES there; tests/test_bench_report.py holds the two
 # lists against each other), and the rule that makes a plan (pf_radices): first radix 8 (or 4 for the half-length lines of the z-pass
 # where 8 does not divide), then 8s, a 4 or a 2, 5s and 3s
-MIXED_CT_SIZES = (200, 384, 400, 640, 768, 800, 1000, 1280, 1536, 1600, 2000)
+MIXED_CT_SIZES = (200, 384, 400, 640, 768, 800, 1000, 1280, 1536, 1600, 2000,
+                  96, 120, 144, 160, 192, 216, 240, 288, 320, 360, 432, 480, 576,
+                  600, 648, 720, 864, 960, 1080, 1152, 1200, 1296, 1440, 1728, 1800, 1920, 1944)   # (the three lists of the three translation units)
 
 
 def mixed_radices(n: int, allow4: bool):

@@ -421,6 +421,12 @@ __global__ void __launch_bounds__(TL *(N / 16)) k_c2r_persistent(const PfC2RPara
 #ifndef PF_ZI_SPEC
 #define PF_ZI_SPEC 1        // (0 in an A/B build: every wave transforms a line and takes part in the reduction)
 #endif
+#ifndef PF_ZI_UNIFORM_MUL
+#define PF_ZI_UNIFORM_MUL(F) (sizeof(F) == 4)   // (fp64 rows: the kernel sits at its 80 registers, and with the factor in a scalar register the compiler's schedule spills)
+#endif
+#ifndef PF_ZFOLD_K0_ALL
+#define PF_ZFOLD_K0_ALL(F) (sizeof(F) == 8)
+#endif
 #ifndef PF_ZI_ROT
 #define PF_ZI_ROT 2         // wave w of a workgroup takes component (w + PF_ZI_ROT) % 6: with 2 the two components with a kz factor fall on
                             // waves 2 and 3, which have a SIMD to themselves within the workgroup (A/B: 14.84 -> 14.68 ms per launch)
@@ -475,7 +481,7 @@ __device__ __forceinline__ void pf_c2r_invariants_body(const PfC2RParams &p, lon
   for (int j = 1; j < TL; j++)
     if (l == j) { in = reinterpret_cast<const C *>(p.job[j].in); mul = p.job[j].mul; }
   // (a line of 64 threads and more is a whole number of waves: its kz factor is the same for every lane -- scalar branches, no exec masks)
-  if constexpr (NT >= 64) mul = __builtin_amdgcn_readfirstlane(mul);
+  if constexpr (NT >= 64 && PF_ZI_UNIFORM_MUL(F)) mul = __builtin_amdgcn_readfirstlane(mul);
   double *__restrict__ o1 = IN_PLACE ? reinterpret_cast<double *>(p.job[0].out) : p.inv_out[0],
          *__restrict__ o2 = IN_PLACE ? reinterpret_cast<double *>(p.job[1].out) : p.inv_out[1],
          *__restrict__ o3 = IN_PLACE ? reinterpret_cast<double *>(p.job[2].out) : p.inv_out[2];
@@ -593,7 +599,7 @@ PF_ZI_PRAGMA(unroll PF_ZI_RUNROLL)
     for (int m = 0; m < 8; m++) {
       const int e = tlj + m * NT;
       // (element e itself is still in the register it was loaded into, where the row was loaded by this iteration)
-      v[m] = pf_zfold<F>((PF_ZI_OWN && !PREFETCH && !DMA) ? nxt[m] : L[e], L[M - e], e, M, mul, kf, tw[e], m == 0);  // (SPEC: nxt holds this row since the end of the iteration before)
+      v[m] = pf_zfold<F>((PF_ZI_OWN && !PREFETCH && !DMA) ? nxt[m] : L[e], L[M - e], e, M, mul, kf, tw[e], m == 0 || PF_ZFOLD_K0_ALL(F));  // (SPEC: nxt holds this row since the end of the iteration before)
     }
     line_sync();
     if (PREFETCH && R + gridDim.x < nrows) fetch(R + gridDim.x);  // in flight during the stages and the reduction below

@@ -559,6 +559,137 @@ __global__ void __launch_bounds__(PLAN::n ? 6 * (PLAN::n / R0) : (R0 == 8 ? 768 
   }
 }
 
+// The same pass (MODE 0) with REDUCING threads, as k_c2r_invariants_spec of the power-of-two sizes (round 6): the 6 (M / R0) threads that
+// transform are followed by the rest of their last wave and by `extra` more waves that only reduce.  When a row's six real lines are in LDS
+// the transforming threads ask for their next row at once -- it travels while the others fold the row into its invariants, so a row's
+// load latency is off the workgroup's critical path, and the reduction no longer waits behind it either.  One loop for every thread
+// (a wave may hold threads of both kinds: 6 M / R0 is rarely a multiple of 64), every barrier met by all; the reducing threads pass
+// through the stages with a butterfly index beyond the last one.  Same expressions per cell, same bits.
+#ifndef PF_MIXED_ZI_SPEC
+#define PF_MIXED_ZI_SPEC 1
+#endif
+#ifndef PF_MIXED_ZI_EXTRA
+#define PF_MIXED_ZI_EXTRA 1   // whole waves of reducing threads beyond the one that the transforming threads leave half empty
+#endif
+template <typename F, int R0, typename PLAN>
+__global__ void __launch_bounds__(PLAN::n ? ((6 * (PLAN::n / R0) + 63) / 64 + PF_MIXED_ZI_EXTRA) * 64 : 1024)
+k_mixed_c2r_invariants_spec(const PfC2RParams p, const PfMixedPlan pl) {
+  using C = pfc<F>;
+  using F2 = typename pf_vec2<F>::type;
+  constexpr bool IN_PLACE = sizeof(F) == 8;
+  const int M = PLAN::n ? PLAN::n : pl.n, n = 2 * M, nt = M / R0;
+  const int nstages = PLAN::n ? PLAN::nstages : pl.nstages;
+  const int LPL = M + 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  C *lds = reinterpret_cast<C *>(smem);
+  const int tid = threadIdx.x, ntr = 6 * nt, ntr_w = (ntr + 63) & ~63;   // the transforming threads fill whole waves (the last one in part)
+  if (tid >= ntr_w) {
+    // ---- the reducing waves: a loop of their own (nothing of the transforms' state is alive here), the same barriers as below
+    const int nred = (int)blockDim.x - ntr_w;
+    const int nbar = 2 + (nstages > 1 ? 2 * (nstages - 1) : 0);   // barriers of a row in front of its reduction
+    double *__restrict__ o1 = IN_PLACE ? reinterpret_cast<double *>(p.job[0].out) : p.inv_out[0],
+           *__restrict__ o2 = IN_PLACE ? reinterpret_cast<double *>(p.job[1].out) : p.inv_out[1],
+           *__restrict__ o3 = IN_PLACE ? reinterpret_cast<double *>(p.job[2].out) : p.inv_out[2];
+#pragma unroll 1
+    for (long long row = blockIdx.x; row < p.nlines; row += gridDim.x) {
+      int trj = tid - ntr_w;
+      asm volatile("" : "+v"(trj));
+      for (int i = 0; i < nbar; i++) __syncthreads();
+      __syncthreads();
+      for (int c = 2 * trj; c < n; c += 2 * nred) {
+        F2 h[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) h[k] = *reinterpret_cast<const F2 *>(reinterpret_cast<const F *>(lds + k * LPL) + c);
+        const double da[6] = {(double)h[0].x, (double)h[1].x, (double)h[2].x, (double)h[3].x, (double)h[4].x, (double)h[5].x},
+                     db[6] = {(double)h[0].y, (double)h[1].y, (double)h[2].y, (double)h[3].y, (double)h[4].y, (double)h[5].y};
+        double a1, a2, a3, b1, b2, b3;
+        pf_invariants(da, a1, a2, a3);
+        pf_invariants(db, b1, b2, b3);
+        if (pf_invariants_lose_diagonal(da, a1, a2) || pf_invariants_lose_diagonal(db, b1, b2)) *p.flag = 1.0;  // (as k_c2r_invariants: the sweep is repeated)
+        const long long ao = IN_PLACE ? row * p.out_pitch + c : row * p.inv_pitch + c;
+        typedef double pf_d2 __attribute__((ext_vector_type(2)));
+        pf_d2 w1, w2, w3;
+        w1.x = a1; w1.y = b1; w2.x = a2; w2.y = b2; w3.x = a3; w3.y = b3;
+        __builtin_nontemporal_store(w1, reinterpret_cast<pf_d2 *>(o1 + ao));
+        __builtin_nontemporal_store(w2, reinterpret_cast<pf_d2 *>(o2 + ao));
+        __builtin_nontemporal_store(w3, reinterpret_cast<pf_d2 *>(o3 + ao));
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  // ---- the transforming waves (threads ntr .. ntr_w - 1 of the last one only keep the barriers company)
+  const bool is_tr = tid < ntr;
+  const int l = is_tr ? tid / nt : 0;
+  const int tl = is_tr ? tid - l * nt : (1 << 20);   // (idle threads: beyond every butterfly of every stage)
+  const C *__restrict__ in0 = reinterpret_cast<const C *>(p.job[l].in);
+  const int mul = p.job[l].mul;
+  const C *__restrict__ tw = reinterpret_cast<const C *>(p.tw);
+  C *L = lds + l * LPL;
+  const F kf = (F)(2.0 * 3.14159265358979323846 / (double)n);
+  const F norm = (F)p.norm;
+  const F dcv = p.dc ? (F)(*p.dc) : (F)0;
+  auto sync = [&]() { __syncthreads(); };
+  auto keep = [&](int pos, C val) { L[pos] = pf_norm_dc2(val, norm, dcv); };  // complex j = reals 2 j, 2 j + 1
+  C own[R0 + 1];
+  auto fetch = [&](long long row) {
+    const C *__restrict__ in = in0 + row * p.in_pitch;
+#pragma unroll
+    for (int m = 0; m < R0; m++) {
+      const int k = tl + m * nt;
+      own[m] = (is_tr && k <= p.band_k) ? pf_ld_stream(in + k) : pf_mk<F>(0, 0);
+    }
+    own[R0] = (tl == 0 && M <= p.band_k) ? pf_ld_stream(in + M) : pf_mk<F>(0, 0);
+  };
+  if ((long long)blockIdx.x < p.nlines) fetch(blockIdx.x);
+#pragma unroll 1
+  for (long long row = blockIdx.x; row < p.nlines; row += gridDim.x) {
+    int tlj = tl;
+    asm volatile("" : "+v"(tlj));
+    C v[R0];
+    if (is_tr) {
+#pragma unroll
+      for (int m = 0; m < R0; m++) v[m] = tw[tlj + m * nt];  // the fold's table values, asked for in front of the barrier
+#pragma unroll
+      for (int m = 0; m < R0; m++) L[tlj + m * nt] = own[m];
+      if (tlj == 0) L[M] = own[R0];
+    }
+    __syncthreads();
+    if (is_tr) {
+#pragma unroll
+      for (int m = 0; m < R0; m++) {
+        const int e = tlj + m * nt;
+        v[m] = pf_zfold<F>(own[m], L[M - e], e, M, mul, kf, v[m], m == 0);
+      }
+    }
+    __syncthreads();
+    if (is_tr) {
+      pf_dft_small<R0, +1>(v);
+      if (nstages == 1) {
+#pragma unroll
+        for (int t = 0; t < R0; t++) keep(tlj + t * nt, v[t]);
+      } else {
+#pragma unroll
+        for (int t = 0; t < R0; t++) L[tlj * R0 + t] = v[t];
+      }
+    }
+    if (nstages > 1) {
+      __syncthreads();
+      pf_mixed_tail_any<PLAN, R0, +1, F>(
+          pl, tlj, tw, 2, [&](int pos) { return L[pos]; }, [&](int pos, C val) { L[pos] = val; }, sync, keep);
+    }
+    __syncthreads();
+    // this row is the reducing waves' now: the next one travels meanwhile.  (Past the last row: zeros, not "nothing" -- a conditional
+    // request would keep the old row alive through the stages)
+    if (row + gridDim.x < p.nlines) fetch(row + gridDim.x);
+    else {
+#pragma unroll
+      for (int m = 0; m <= R0; m++) own[m] = pf_mk<F>(0, 0);
+    }
+    __syncthreads();  // the lines are rewritten by the next row
+  }
+}
+
 // --------------------------------------------------------------------------------------------------------- launch ----
 // radices of a line of n points: first R0 (8, or 4 where allowed), then 8s, a 4 or a 2, 5s and 3s.  ok = false: n has another
 // prime factor (or no admissible first radix) -- the caller keeps the chirp-z path for such sizes.  One rule, evaluated at run time
@@ -579,6 +710,7 @@ constexpr PfRadices pf_radices(int n, bool allow4) {
   p.ok = rest == 1;
   return p;
 }
+#if PF_MIXED_PART == 0
 bool pf_mixed_plan(int n, bool allow4, PfMixedPlan *pl) {
   memset(pl, 0, sizeof(*pl));
   pl->n = n;
@@ -597,12 +729,70 @@ bool pf_mixed_supported(int n) {
   PfMixedPlan a, b;
   return n >= 8 && n <= 2048 && n % 8 == 0 && pf_mixed_plan(n, false, &a) && pf_mixed_plan(n / 2, true, &b);
 }
+#endif
 // Grid sizes whose plans are compiled in: the strided passes on N points (first radix 8) and the z-passes on N / 2 (8 or 4).
 // (bench.py names the kernels of a run from the same list: MIXED_CT_SIZES there, held against this line by tests/test_bench_report.py.)
 #ifndef PF_MIXED_CT
 #define PF_MIXED_CT 1   // (0 in an A/B build: every size through the run-time plans)
 #endif
+// Round 6: every n = 8 m >= 96, m = 2^a 3^b 5^c, has its plan compiled in (38 sizes; the run-time plans, at 0.6-0.7 of their rate, are left
+// with the sizes below 96).  The kernels of 38 sizes are too many for one translation unit to compile in reasonable time: this file is
+// compiled three times (csrc/Makefile) -- PF_MIXED_PART 0: everything but the kernels of the sizes of lists 1 and 2; PF_MIXED_PART 1, 2:
+// only the launchers of their own list, under the names pf_launch_mixed_*_p1 / _p2, which part 0 calls for those sizes.
 #define PF_MIXED_CT_SIZES(X) X(200) X(384) X(400) X(640) X(768) X(800) X(1000) X(1280) X(1536) X(1600) X(2000)
+#define PF_MIXED_CT_SIZES_1(X) X(96) X(120) X(144) X(160) X(192) X(216) X(240) X(288) X(320) X(360) X(432) X(480) X(576)
+#define PF_MIXED_CT_SIZES_2(X) X(600) X(648) X(720) X(864) X(960) X(1080) X(1152) X(1200) X(1296) X(1440) X(1728) X(1800) X(1920) X(1944)
+#ifndef PF_MIXED_PART
+#define PF_MIXED_PART 0
+#endif
+#if PF_MIXED_PART == 0
+#define PF_MIXED_MY_SIZES(X) PF_MIXED_CT_SIZES(X)
+#elif PF_MIXED_PART == 1
+#define PF_MIXED_MY_SIZES(X) PF_MIXED_CT_SIZES_1(X)
+#else
+#define PF_MIXED_MY_SIZES(X) PF_MIXED_CT_SIZES_2(X)
+#endif
+// which part holds the plan of n: 0 this list, 1 / 2 the others, -1 none (run-time plan)
+static int pf_mixed_part_of(int n) {
+  if (!PF_MIXED_CT) return -1;
+#define PF_MIXED_CASE(NN) if (n == NN) return 0;
+  PF_MIXED_CT_SIZES(PF_MIXED_CASE)
+#undef PF_MIXED_CASE
+#define PF_MIXED_CASE(NN) if (n == NN) return 1;
+  PF_MIXED_CT_SIZES_1(PF_MIXED_CASE)
+#undef PF_MIXED_CASE
+#define PF_MIXED_CASE(NN) if (n == NN) return 2;
+  PF_MIXED_CT_SIZES_2(PF_MIXED_CASE)
+#undef PF_MIXED_CASE
+  return -1;
+}
+int pf_launch_mixed_strided_p1(int fb, int n, int dir, const PfStridedParams &p, hipStream_t st);
+int pf_launch_mixed_strided_p2(int fb, int n, int dir, const PfStridedParams &p, hipStream_t st);
+int pf_launch_mixed_c2r_p1(int fb, int n, const PfC2RParams &p, hipStream_t st);
+int pf_launch_mixed_c2r_p2(int fb, int n, const PfC2RParams &p, hipStream_t st);
+int pf_launch_mixed_r2c_p1(int fb, int n, const PfR2CParams &p, hipStream_t st);
+int pf_launch_mixed_r2c_p2(int fb, int n, const PfR2CParams &p, hipStream_t st);
+int pf_launch_mixed_c2r_invariants_p1(int fb, int n, const PfC2RParams &p, hipStream_t st, int mode);
+int pf_launch_mixed_c2r_invariants_p2(int fb, int n, const PfC2RParams &p, hipStream_t st, int mode);
+#if PF_MIXED_PART == 1
+#define pf_launch_mixed_strided pf_launch_mixed_strided_p1
+#define pf_launch_mixed_c2r pf_launch_mixed_c2r_p1
+#define pf_launch_mixed_r2c pf_launch_mixed_r2c_p1
+#define pf_launch_mixed_c2r_invariants pf_launch_mixed_c2r_invariants_p1
+#elif PF_MIXED_PART == 2
+#define pf_launch_mixed_strided pf_launch_mixed_strided_p2
+#define pf_launch_mixed_c2r pf_launch_mixed_c2r_p2
+#define pf_launch_mixed_r2c pf_launch_mixed_r2c_p2
+#define pf_launch_mixed_c2r_invariants pf_launch_mixed_c2r_invariants_p2
+#endif
+// part 0: a size of another part goes to that part's launcher; parts 1, 2: a size that is not theirs is nobody's business here
+#if PF_MIXED_PART == 0
+#define PF_MIXED_ROUTE(call1, call2) do { const int part__ = pf_mixed_part_of(n); if (part__ == 1) return call1; if (part__ == 2) return call2; } while (0)
+#define PF_MIXED_RT(stmt) stmt
+#else
+#define PF_MIXED_ROUTE(call1, call2) do { if (pf_mixed_part_of(n) != PF_MIXED_PART) return 2; } while (0)
+#define PF_MIXED_RT(stmt) return 2
+#endif
 template <int N, bool A4, typename = std::make_index_sequence<(size_t)pf_radices(N, A4).ns>> struct PfPlanOf;
 template <int N, bool A4, size_t... I> struct PfPlanOf<N, A4, std::index_sequence<I...>> {
   static_assert(pf_radices(N, A4).ok, "a size of PF_MIXED_CT_SIZES without a plan");
@@ -610,17 +800,13 @@ template <int N, bool A4, size_t... I> struct PfPlanOf<N, A4, std::index_sequenc
 };
 template <int N> using PfPlanS = typename PfPlanOf<N, false>::type;      // strided passes of an N grid
 template <int N> using PfPlanZ = typename PfPlanOf<N / 2, true>::type;   // its z-passes: half-length lines
-template <int N> constexpr bool pf_mixed_inv_fits() {  // (the six lines of a row in one workgroup: k_mixed_c2r_invariants)
-  static_assert(6 * ((N / 2) / PfPlanZ<N>::radix[0]) <= 1024, "a size of PF_MIXED_CT_SIZES whose invariant z-pass has no workgroup");
-  return true;
+template <int N> constexpr bool pf_mixed_inv_fits() {  // (the six lines of a row in one workgroup: k_mixed_c2r_invariants; 1800 and 1944 do not)
+  return 6 * ((N / 2) / PfPlanZ<N>::radix[0]) <= 1024;
 }
 
-bool pf_mixed_plan_compiled_in(int n) {
-#define PF_MIXED_CASE(NN) if (n == NN) return PF_MIXED_CT != 0;
-  PF_MIXED_CT_SIZES(PF_MIXED_CASE)
-#undef PF_MIXED_CASE
-  return false;
-}
+#if PF_MIXED_PART == 0
+bool pf_mixed_plan_compiled_in(int n) { return pf_mixed_part_of(n) >= 0; }
+#endif
 // (the LDS attribute and the occupancy belong to a kernel ON ONE DEVICE; asked once per (kernel, device[, shape]) under a lock, so that
 //  ranks run as threads of one process on several devices neither race nor inherit each other's answers)
 static std::mutex pf_mixed_mu;
@@ -652,6 +838,7 @@ static int pf_mixed_resident(const void *fn, int threads, size_t shm) {
   return nb;
 }
 int pf_launch_mixed_strided(int fb, int n, int dir, const PfStridedParams &p, hipStream_t st) {
+  PF_MIXED_ROUTE(pf_launch_mixed_strided_p1(fb, n, dir, p, st), pf_launch_mixed_strided_p2(fb, n, dir, p, st));
   PfMixedPlan pl;
   if (!pf_mixed_plan(n, false, &pl)) return 2;
   const int nt = n / 8;
@@ -667,8 +854,8 @@ int pf_launch_mixed_strided(int fb, int n, int dir, const PfStridedParams &p, hi
   pl.magic_out = (unsigned)((0x100000000ull + (unsigned)p.aout.el_len - 1) / (unsigned)p.aout.el_len);
   const dim3 grid((unsigned)(((nwork + 7) >> 3) << 3)), block(T, nt);
   const size_t shm = (size_t)n * T * w;
-#define PF_MIXED_LAUNCH_P(FF, DD, PP)                                                                                \
-  do {                                                                                                               \
+#if PF_MIXED_PART == 0
+#define PF_MIXED_KEEP_TRY(FF, DD, PP)                                                                                \
     if (PF_MIXED_KEEP_RT && PP::n == 0 && block.x * block.y <= 768 && p.njobs > 1) {                                 \
       /* the form that keeps a tile over its jobs needs 156 registers for 124 (fp32: 106 for 94): taken where that costs no workgroup */ \
       /* per CU -- and with fp64 fields only where a tile fills the CU anyway (720^3: 395 -> 353 ms per step; 360^3, two workgroups */ \
@@ -682,7 +869,13 @@ int pf_launch_mixed_strided(int fb, int n, int dir, const PfStridedParams &p, hi
         hipLaunchKernelGGL((k_mixed_strided<FF, DD, PfPlanRT, true>), grid, block, shm, st, p, pl, nwork, ntiles); \
         break;                                                                                                       \
       }                                                                                                              \
-    }                                                                                                                \
+    }
+#else
+#define PF_MIXED_KEEP_TRY(FF, DD, PP)   // (the run-time plans live in part 0)
+#endif
+#define PF_MIXED_LAUNCH_P(FF, DD, PP)                                                                                \
+  do {                                                                                                               \
+    PF_MIXED_KEEP_TRY(FF, DD, PP)                                                                                    \
     if (pf_mixed_raise_lds<FF>(reinterpret_cast<const void *>(&k_mixed_strided<FF, DD, PP>), shm)) return 3;         \
     hipLaunchKernelGGL((k_mixed_strided<FF, DD, PP>), grid, block, shm, st, p, pl, nwork, ntiles);                \
   } while (0)
@@ -691,7 +884,7 @@ int pf_launch_mixed_strided(int fb, int n, int dir, const PfStridedParams &p, hi
   do {                                                                                                               \
     using FF_ = FF;                                                                                                  \
     constexpr int DD_ = DD;                                                                                          \
-    PF_MIXED_CT_SIZES(PF_MIXED_CASE) PF_MIXED_LAUNCH_P(FF_, DD_, PfPlanRT);                                          \
+    PF_MIXED_MY_SIZES(PF_MIXED_CASE) PF_MIXED_RT(PF_MIXED_LAUNCH_P(FF_, DD_, PfPlanRT));                              \
   } while (0)
   if (fb == 8) { if (dir > 0) PF_MIXED_LAUNCH(double, +1); else PF_MIXED_LAUNCH(double, -1); }
   else { if (dir > 0) PF_MIXED_LAUNCH(float, +1); else PF_MIXED_LAUNCH(float, -1); }
@@ -703,6 +896,7 @@ int pf_launch_mixed_strided(int fb, int n, int dir, const PfStridedParams &p, hi
 static int pf_mixed_line_slots(int M, int r0) { return (PF_MIXED_PAD ? M + (M >> (r0 == 8 ? 3 : 2)) : M) + 1; }  // (PFP(M) + 1)
 static int pf_mixed_rows_per_wg(int nt) { int tl = 256 / nt; return tl < 1 ? 1 : tl; }  // (z-pass workgroups: at most 256 threads)
 int pf_launch_mixed_c2r(int fb, int n, const PfC2RParams &p, hipStream_t st) {
+  PF_MIXED_ROUTE(pf_launch_mixed_c2r_p1(fb, n, p, st), pf_launch_mixed_c2r_p2(fb, n, p, st));
   PfMixedPlan pl;
   const int M = n / 2;
   if (!pf_mixed_plan(M, true, &pl)) return 2;
@@ -720,14 +914,17 @@ int pf_launch_mixed_c2r(int fb, int n, const PfC2RParams &p, hipStream_t st) {
   if (PF_MIXED_CT && n == NN) {                                                                                      \
     if (fb == 8) PF_MIXED_LAUNCH_P(double, PfPlanZ<NN>::radix[0], PfPlanZ<NN>); else PF_MIXED_LAUNCH_P(float, PfPlanZ<NN>::radix[0], PfPlanZ<NN>); \
   } else
-  PF_MIXED_CT_SIZES(PF_MIXED_CASE)
+  PF_MIXED_MY_SIZES(PF_MIXED_CASE)
 #undef PF_MIXED_CASE
-  if (fb == 8) { if (r0 == 8) PF_MIXED_LAUNCH_P(double, 8, PfPlanRT); else PF_MIXED_LAUNCH_P(double, 4, PfPlanRT); }
-  else { if (r0 == 8) PF_MIXED_LAUNCH_P(float, 8, PfPlanRT); else PF_MIXED_LAUNCH_P(float, 4, PfPlanRT); }
+  PF_MIXED_RT(do {
+    if (fb == 8) { if (r0 == 8) PF_MIXED_LAUNCH_P(double, 8, PfPlanRT); else PF_MIXED_LAUNCH_P(double, 4, PfPlanRT); }
+    else { if (r0 == 8) PF_MIXED_LAUNCH_P(float, 8, PfPlanRT); else PF_MIXED_LAUNCH_P(float, 4, PfPlanRT); }
+  } while (0));
 #undef PF_MIXED_LAUNCH_P
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 int pf_launch_mixed_r2c(int fb, int n, const PfR2CParams &p, hipStream_t st) {
+  PF_MIXED_ROUTE(pf_launch_mixed_r2c_p1(fb, n, p, st), pf_launch_mixed_r2c_p2(fb, n, p, st));
   PfMixedPlan pl;
   const int M = n / 2;
   if (!pf_mixed_plan(M, true, &pl)) return 2;
@@ -745,23 +942,28 @@ int pf_launch_mixed_r2c(int fb, int n, const PfR2CParams &p, hipStream_t st) {
   if (PF_MIXED_CT && n == NN) {                                                                                      \
     if (fb == 8) PF_MIXED_LAUNCH_P(double, PfPlanZ<NN>::radix[0], PfPlanZ<NN>); else PF_MIXED_LAUNCH_P(float, PfPlanZ<NN>::radix[0], PfPlanZ<NN>); \
   } else
-  PF_MIXED_CT_SIZES(PF_MIXED_CASE)
+  PF_MIXED_MY_SIZES(PF_MIXED_CASE)
 #undef PF_MIXED_CASE
-  if (fb == 8) { if (r0 == 8) PF_MIXED_LAUNCH_P(double, 8, PfPlanRT); else PF_MIXED_LAUNCH_P(double, 4, PfPlanRT); }
-  else { if (r0 == 8) PF_MIXED_LAUNCH_P(float, 8, PfPlanRT); else PF_MIXED_LAUNCH_P(float, 4, PfPlanRT); }
+  PF_MIXED_RT(do {
+    if (fb == 8) { if (r0 == 8) PF_MIXED_LAUNCH_P(double, 8, PfPlanRT); else PF_MIXED_LAUNCH_P(double, 4, PfPlanRT); }
+    else { if (r0 == 8) PF_MIXED_LAUNCH_P(float, 8, PfPlanRT); else PF_MIXED_LAUNCH_P(float, 4, PfPlanRT); }
+  } while (0));
 #undef PF_MIXED_LAUNCH_P
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 // the invariant z-pass: six lines of n / 2 + 1 complex in LDS, six times (n / 2) / R0 threads
+#if PF_MIXED_PART == 0
 bool pf_mixed_invariants_supported(int fb, int n) {
   PfMixedPlan pl;
   if (!pf_mixed_supported(n) || !pf_mixed_plan(n / 2, true, &pl)) return false;
   const int nt = (n / 2) / pl.radix[0];
   return 6 * nt <= 1024 && (size_t)6 * (n / 2 + 1) * (fb == 8 ? 16 : 8) <= 128 * 1024;
 }
+#endif
 int pf_launch_mixed_c2r_invariants(int fb, int n, const PfC2RParams &p, hipStream_t st, int mode) {
   if (!pf_mixed_invariants_supported(fb, n)) return 2;
+  PF_MIXED_ROUTE(pf_launch_mixed_c2r_invariants_p1(fb, n, p, st, mode), pf_launch_mixed_c2r_invariants_p2(fb, n, p, st, mode));
   PfMixedPlan pl;
   const int M = n / 2;
   if (!pf_mixed_plan(M, true, &pl)) return 2;
@@ -776,19 +978,32 @@ int pf_launch_mixed_c2r_invariants(int fb, int n, const PfC2RParams &p, hipStrea
   if (g > p.nlines) g = p.nlines;
   if (PF_MIXED_ZI_ONE_ROW) g = p.nlines;  // one row per workgroup
   const dim3 grid((unsigned)g), block(nt, 6);
+  // MODE 0 with reducing threads (k_mixed_c2r_invariants_spec): the transforming threads, the rest of their last wave, PF_MIXED_ZI_EXTRA waves more
+  const int spec_threads = ((6 * nt + 63) / 64 + PF_MIXED_ZI_EXTRA) * 64;   // (whole waves of either kind)
+  const bool spec_ok = PF_MIXED_ZI_SPEC && spec_threads <= 1024;
 #define PF_MIXED_LAUNCH_P(FF, RR, PP, MM)                                                                            \
   do {                                                                                                               \
+    if constexpr (MM == 0) {                                                                                         \
+      if (spec_ok) {                                                                                                 \
+        if (pf_mixed_raise_lds<FF>(reinterpret_cast<const void *>(&k_mixed_c2r_invariants_spec<FF, RR, PP>), shm)) return 3; \
+        /* workgroups that stay: as many as the chip holds at once, each walking over rows (the next row is what a workgroup asks for early) */ \
+        const int occ = pf_mixed_resident(reinterpret_cast<const void *>(&k_mixed_c2r_invariants_spec<FF, RR, PP>), spec_threads, shm); \
+        long long gs = (long long)(p.ncu > 0 ? p.ncu : 256) * (occ > 0 ? occ : 1);                                    \
+        if (gs > p.nlines) gs = p.nlines;                                                                            \
+        hipLaunchKernelGGL((k_mixed_c2r_invariants_spec<FF, RR, PP>), dim3((unsigned)gs), dim3(spec_threads), shm, st, p, pl); \
+        break;                                                                                                       \
+      }                                                                                                              \
+    }                                                                                                                \
     if (pf_mixed_raise_lds<FF>(reinterpret_cast<const void *>(&k_mixed_c2r_invariants<FF, RR, PP, MM>), shm)) return 3; \
     hipLaunchKernelGGL((k_mixed_c2r_invariants<FF, RR, PP, MM>), grid, block, shm, st, p, pl);                    \
   } while (0)
-#define PF_MIXED_CASE(NN) if (PF_MIXED_CT && n == NN && pf_mixed_inv_fits<NN>()) PF_MIXED_LAUNCH_P(FF_, PfPlanZ<NN>::radix[0], PfPlanZ<NN>, MM_); else
+#define PF_MIXED_CASE(NN) if constexpr (pf_mixed_inv_fits<NN>()) if (PF_MIXED_CT && n == NN) { PF_MIXED_LAUNCH_P(FF_, PfPlanZ<NN>::radix[0], PfPlanZ<NN>, MM_); break; }
 #define PF_MIXED_LAUNCH(FF, MM)                                                                                      \
   do {                                                                                                               \
     using FF_ = FF;                                                                                                  \
     constexpr int MM_ = MM;                                                                                          \
-    PF_MIXED_CT_SIZES(PF_MIXED_CASE)                                                                                 \
-    if (r0 == 8) PF_MIXED_LAUNCH_P(FF_, 8, PfPlanRT, MM_);                                                           \
-    else PF_MIXED_LAUNCH_P(FF_, 4, PfPlanRT, MM_);                                                                   \
+    PF_MIXED_MY_SIZES(PF_MIXED_CASE)                                                                                 \
+    PF_MIXED_RT(do { if (r0 == 8) PF_MIXED_LAUNCH_P(FF_, 8, PfPlanRT, MM_); else PF_MIXED_LAUNCH_P(FF_, 4, PfPlanRT, MM_); } while (0)); \
   } while (0)
   if (fb == 8) { if (mode == 0) PF_MIXED_LAUNCH(double, 0); else PF_MIXED_LAUNCH(double, 1); }
   else { if (mode == 0) PF_MIXED_LAUNCH(float, 0); else PF_MIXED_LAUNCH(float, 1); }

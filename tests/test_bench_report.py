@@ -87,13 +87,24 @@ def test_counter_lookup_by_symbol():
     assert bench.symbol_of("zpass_c2r_plain", 200, 8).startswith("k_mixed_c2r<double, 4, PfPlanCT<4, 5, 5>")
 
 
+def _prime_factors(v):
+    out, p = [], 2
+    while v > 1:
+        while v % p == 0:
+            out.append(p); v //= p
+        p += 1
+    return out
+
+
 def test_mixed_plan_names_follow_the_kernel_sources():
     """sizes that are not a power of two: bench.py names a run's kernels from the list of sizes whose stage plans
     csrc/pf_mixed_kernels.hip compiles in, and from the rule that makes a plan -- both restated there"""
     import re
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pinocchio_amd", "csrc", "pf_mixed_kernels.hip")).read()
-    line = re.search(r"#define PF_MIXED_CT_SIZES\(X\)(.*)", src).group(1)
-    assert tuple(int(v) for v in re.findall(r"X\((\d+)\)", line)) == bench.MIXED_CT_SIZES
+    lines = [re.search(r"#define PF_MIXED_CT_SIZES%s\(X\)(.*)" % sfx, src).group(1) for sfx in ("", "_1", "_2")]   # (one list per translation unit)
+    assert tuple(int(v) for line in lines for v in re.findall(r"X\((\d+)\)", line)) == bench.MIXED_CT_SIZES
+    m = [v for v in range(12, 257) if v & (v - 1) and all(p in (2, 3, 5) for p in _prime_factors(v))]
+    assert sorted(bench.MIXED_CT_SIZES) == [8 * v for v in m]        # every n = 8 m >= 96 with m = 2^a 3^b 5^c that is not a power of two
     assert bench.mixed_radices(768, False) == [8, 8, 4, 3] and bench.mixed_radices(384, True) == [8, 8, 2, 3]
     assert bench.mixed_radices(200, False) == [8, 5, 5] and bench.mixed_radices(100, True) == [4, 5, 5]
     assert bench.mixed_radices(100, False) is None and bench.mixed_radices(56, False) is None
@@ -103,8 +114,8 @@ def test_mixed_plan_names_follow_the_kernel_sources():
     assert bench.symbol_of("ypass_hess_3to6", 768, 8) == "k_mixed_strided<double, 1, PfPlanCT<8, 8, 4, 3> >"
     assert bench.symbol_of("zpass_c2r_hess_6to3inv", 200, 8) == "k_mixed_c2r_invariants<double, 4, PfPlanCT<4, 5, 5>, 0>"
     assert bench.symbol_of("zpass_c2r_disp_3", 200, 4) == "k_mixed_c2r<float, 4, PfPlanCT<4, 5, 5> >"
-    assert bench.symbol_of("zpass_r2c", 120, 8) == "k_mixed_r2c<double, 4, PfPlanRT>"
-    assert bench.symbol_of("xpass_fwd", 120, 8) == "k_mixed_strided<double, -1, PfPlanRT>"
+    assert bench.symbol_of("zpass_r2c", 72, 8) == "k_mixed_r2c<double, 4, PfPlanRT>"
+    assert bench.symbol_of("xpass_fwd", 72, 8) == "k_mixed_strided<double, -1, PfPlanRT>"
 
 
 def test_result_fingerprint_adds_up_over_any_decomposition():

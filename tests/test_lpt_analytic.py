@@ -286,10 +286,13 @@ def test_full_bench_workload_on_the_box_of_the_metric(api):
         # is ill-conditioned in the oracle itself (it moves as much under 2-ulp noise on its own Hessian).
         po = oracle_lib.PlaneOracle(n, planes, 0)
         po.set_invgrow(x, y)
+        st = po.stream(radii, po.HESSIAN)          # every radius in ONE pass over delta(k) (orc_plane_acc_*: 12 x 6 x 5 planes of accumulators, 3 GB)
+        st.add(dk, 0)
         hess = []
-        for ismooth, rs in enumerate(radii):
-            hess.append(po.derivatives(dk, rs, po.HESSIAN))
+        for ismooth in range(len(radii)):
+            hess.append(st.finish(ismooth))
             po.collapse_times(ismooth, hess[-1])
+        st.close()
         hamp = max(float(np.max(np.abs(hh))) for hh in hess[-1])
         for i in range(6):   # the R = 0 Hessian still in place on the device
             assert np.max(np.abs(d[i] - hess[-1][i])) <= 1e-12 * hamp, ("hessian", i)
