@@ -14,7 +14,8 @@ SIZES = [16, 64, 256, 1024, 2048]
 # grid sizes that are not a power of two: the run-time stage plans of csrc/pf_mixed_kernels.hip (radices 8, 5, 4, 3, 2) --
 # 24 = 8.3, 40 = 8.5, 96 = 8.4.3, 120 = 8.5.3, 200 = 8.5.5 (the reference's example size), 384 = 8.8.2.3, 768 = 8.8.4.3,
 # 1000 = 8.5.5.5, 1536 = 8.8.8.3; their z-passes run on the half lengths 12 = 4.3, 20 = 4.5, 48, 60, 100 = 4.5.5, 192, ...
-MIXED = [24, 40, 96, 120, 200, 384, 768, 1000, 1536, 400, 640, 800, 1280, 1600, 2000]   # (200, 384 ... 2000 but 24 - 120: plans compiled in)
+MIXED = [24, 40, 96, 120, 200, 384, 768, 1000, 1536, 400, 640, 800, 1280, 1600, 2000,   # (24, 40: run-time plans; from 96 on every plan is compiled in)
+         144, 360, 720, 1080, 1440, 1800, 1944]                                         # (round 6: the sizes of the second and third translation unit)
 ALL_SIZES = SIZES + MIXED
 
 
@@ -132,7 +133,7 @@ def test_zpass_r2c_lines(L, n, fb):
     assert np.max(np.abs(got - want)) <= tol(fb, n) * np.max(np.abs(want)), (n, fb)
 
 
-@pytest.mark.parametrize("n", [16, 64, 256, 512, 1024, 2048, 24, 200, 768, 1000, 2000])      # (512, 1024, 2048: the forms with waves that only reduce; 24 ...: k_mixed_c2r_invariants)
+@pytest.mark.parametrize("n", [16, 64, 256, 512, 1024, 2048, 24, 200, 768, 1000, 2000, 96, 720, 1440, 1920])      # (512, 1024, 2048: the forms with waves that only reduce; 24 ...: k_mixed_c2r_invariants, from 96 on with reducing waves too)
 def test_invariant_zpass_lines_fp32_fields(L, n):
     """the same pass on fp32 fields (BASELINE config 5's arithmetic; rows of up to 2048 points fit): transforms in fp32, the
     reduction in fp64 from the fp32 components, fp64 invariants out"""
@@ -152,7 +153,7 @@ def test_invariant_zpass_lines_fp32_fields(L, n):
         assert np.max(np.abs(gi - wi)) <= 8 * tol(4, n) * amp ** p, (n, p)
 
 
-@pytest.mark.parametrize("n", [16, 64, 256, 512, 1024, 24, 40, 200, 768, 1000, 1536, 2000])   # (24 ...: k_mixed_c2r_invariants)
+@pytest.mark.parametrize("n", [16, 64, 256, 512, 1024, 24, 40, 200, 768, 1000, 1536, 2000, 96, 120, 360, 720, 1080, 1440, 1728])   # (24 ...: k_mixed_c2r_invariants; from 96 on plans built in, reducing waves)
 def test_invariant_zpass_lines(L, n):
     """six rows in, the three invariants of each cell's tensor out (what the solve of every radius but the last reads)"""
     rng = np.random.default_rng(11 * n)
