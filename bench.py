@@ -511,6 +511,15 @@ def run_config(args, rank, world, device, dist, torch, replicate_env, votes_out,
     return res
 
 
+def broadcast_verdict(dist, torch, invalid: bool, backend: str) -> bool:
+    """every rank leaves with rank 0's verdict (the launcher reports the first non-zero exit).  The flag lives where the process group
+    has a backend: an NCCL-only group (the measurement) has none for CPU tensors -- round 5 built it on the CPU and every rank of a real
+    multi-GPU run would have died here after printing its line (tests: gloo world 2 on the CPU, nccl world 1 on the GPU)"""
+    flag = torch.tensor([1 if invalid else 0], device="cpu" if backend == "gloo-host" else "cuda")
+    dist.broadcast(flag, src=0)
+    return bool(flag.item())
+
+
 def boundary_report(f, api, n, step_s):
     """What the boundary itself costs at the bench size ("report separately with the D2H of products"), after the
     timed region and NEVER part of `value`: compute_fmax() of the reference leaves `products` in host memory (src/fmax-pfft.c:563-631
@@ -661,7 +670,14 @@ def run_slab(args):
     f = api.Fmax(n, rank=0, nranks=P, device=0, field_bytes=args.field_bytes, timing=True)
     try:
         f._chk(f.L.pf_set_loopback_exchange(f.h, 1 << 20))          # warm-up: every hand-back copies
-        f.synth_density(synth.SEED, 2.5, -2.0)
+        physical = int(f.L.pf_replicated_spectrum(f.h)) == 1
+        if physical:
+            # the rank keeps the whole delta(k) (PF_REPLICATE_DK=1): a GenIC density is generated whole by the rank itself (pf_genic_density
+            # behind the loopback exchange), so the SWEEP of this run is the box's own -- physical fields in every per-cell kernel
+            # (round 6; tests/test_gpu_config5.py checks exactly this configuration against the plane oracle)
+            f.genic_density(seed=5 * n + P, box_true_mpc=float(n) / 0.7, omega0=0.25, omega_baryon=0.044, hubble100=0.7, primordial_index=0.96, sigma8=0.8)
+        else:
+            f.synth_density(synth.SEED, 2.5, -2.0)
         x, y = synth.invgrow_table("lcdm")
         f.set_invgrow(x, y)
         f.set_growth(synth.growth_multipliers())
@@ -686,6 +702,7 @@ def run_slab(args):
                "value": slab_cells / dt, "unit": "grid-cells/s per rank (kernels only)", "n_gpus": 1, "steps": args.steps, "warmup": max(1, args.warmup),
                "ms_per_step": 1e3 * dt, "higher_is_better": True, "data": "synthetic, exchanged blocks replaced by the rank's own",
                "dtype": "f64" if w == 8 else "f32 fields / f64 collapse",
+               "sweep_on_the_box_s_own_fields": physical,
                "config": {"workload": f"rank 0 of {P}: slab of {n // P} planes of the {n}^3 box, {ns} radii{' + 3LPT' if lpt else ''}", "grid": n, "slab_of": P,
                           "device_GB": f.device_bytes / 1e9, "kernel_source_sha": _lib.source_sha(),
                           "replicated_spectrum": int(f.L.pf_replicated_spectrum(f.h)) == 1},
@@ -995,9 +1012,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_n, ns, lpt)
         print(json.dumps(out), flush=True)
     if world > 1:
-        bad_flag = torch.tensor([1 if invalid else 0], device="cpu" if args.backend == "gloo-host" else "cuda")   # (an NCCL-only group has no CPU backend)
-        dist.broadcast(bad_flag, src=0)   # every rank leaves with rank 0's verdict (the launcher reports the first non-zero exit)
-        invalid = bool(bad_flag.item())
+        invalid = broadcast_verdict(dist, torch, invalid, args.backend)
         dist.destroy_process_group()
     if invalid:
         sys.exit(5)

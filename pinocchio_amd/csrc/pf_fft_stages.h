@@ -85,5 +85,7 @@ __device__ __forceinline__ pfc<F> pf_zfold(pfc<F> xk, pfc<F> xmk, int e, int M, 
     if (mul == 3 /* PF_MUL_IK */) { xk = pf_mul_i<+1>(xk); xmk = pf_mul_i<+1>(xmk); }
   }
   // maybe0: false where the caller knows e > 0 (register m > 0 of a thread: e = tl + m NT) -- the k = 0 form then leaves no trace in the code
-  return pf_c2r_pre<F>(xk, xmk, wk, maybe0 && e == 0);
+  // (fp64 callers keep the test on every element: their kernels sit at register limits -- 80 for the invariant z-pass of 1024 points,
+  //  94 -> 108 for the mixed-radix one -- that the shorter code, scheduled differently, breaks: measured, round 6)
+  return pf_c2r_pre<F>(xk, xmk, wk, (maybe0 || sizeof(F) == 8) && e == 0);
 }

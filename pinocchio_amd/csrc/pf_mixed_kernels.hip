@@ -566,11 +566,13 @@ __global__ void __launch_bounds__(PLAN::n ? 6 * (PLAN::n / R0) : (R0 == 8 ? 768 
 // (a wave may hold threads of both kinds: 6 M / R0 is rarely a multiple of 64), every barrier met by all; the reducing threads pass
 // through the stages with a butterfly index beyond the last one.  Same expressions per cell, same bits.
 #ifndef PF_MIXED_ZI_SPEC
-#define PF_MIXED_ZI_SPEC 1
+#define PF_MIXED_ZI_SPEC 0   // measured and not kept (profiles/r06_notes.md): 768^3 11.6 against 11.4 ms per launch, 1000^3 27.4 against 18.5 -- fewer workgroups
+                              // fit a CU (six waves of 108 registers: two instead of four), and four resident workgroups hide a row's latency better than one early request
 #endif
 #ifndef PF_MIXED_ZI_EXTRA
 #define PF_MIXED_ZI_EXTRA 1   // whole waves of reducing threads beyond the one that the transforming threads leave half empty
 #endif
+#if PF_MIXED_ZI_SPEC
 template <typename F, int R0, typename PLAN>
 __global__ void __launch_bounds__(PLAN::n ? ((6 * (PLAN::n / R0) + 63) / 64 + PF_MIXED_ZI_EXTRA) * 64 : 1024)
 k_mixed_c2r_invariants_spec(const PfC2RParams p, const PfMixedPlan pl) {
@@ -689,6 +691,7 @@ k_mixed_c2r_invariants_spec(const PfC2RParams p, const PfMixedPlan pl) {
     __syncthreads();  // the lines are rewritten by the next row
   }
 }
+#endif  // PF_MIXED_ZI_SPEC
 
 // --------------------------------------------------------------------------------------------------------- launch ----
 // radices of a line of n points: first R0 (8, or 4 where allowed), then 8s, a 4 or a 2, 5s and 3s.  ok = false: n has another
@@ -980,9 +983,10 @@ int pf_launch_mixed_c2r_invariants(int fb, int n, const PfC2RParams &p, hipStrea
   const dim3 grid((unsigned)g), block(nt, 6);
   // MODE 0 with reducing threads (k_mixed_c2r_invariants_spec): the transforming threads, the rest of their last wave, PF_MIXED_ZI_EXTRA waves more
   const int spec_threads = ((6 * nt + 63) / 64 + PF_MIXED_ZI_EXTRA) * 64;   // (whole waves of either kind)
-  const bool spec_ok = PF_MIXED_ZI_SPEC && spec_threads <= 1024;
-#define PF_MIXED_LAUNCH_P(FF, RR, PP, MM)                                                                            \
-  do {                                                                                                               \
+  const bool spec_ok = PF_MIXED_ZI_SPEC && spec_threads <= 1024 && pf_mixed_part_of(n) >= 0;   // (compiled-in plans only: with a run-time plan the kernel spills)
+  (void)spec_ok;
+#if PF_MIXED_ZI_SPEC
+#define PF_MIXED_SPEC_TRY(FF, RR, PP, MM)                                                                            \
     if constexpr (MM == 0) {                                                                                         \
       if (spec_ok) {                                                                                                 \
         if (pf_mixed_raise_lds<FF>(reinterpret_cast<const void *>(&k_mixed_c2r_invariants_spec<FF, RR, PP>), shm)) return 3; \
@@ -993,7 +997,13 @@ int pf_launch_mixed_c2r_invariants(int fb, int n, const PfC2RParams &p, hipStrea
         hipLaunchKernelGGL((k_mixed_c2r_invariants_spec<FF, RR, PP>), dim3((unsigned)gs), dim3(spec_threads), shm, st, p, pl); \
         break;                                                                                                       \
       }                                                                                                              \
-    }                                                                                                                \
+    }
+#else
+#define PF_MIXED_SPEC_TRY(FF, RR, PP, MM)
+#endif
+#define PF_MIXED_LAUNCH_P(FF, RR, PP, MM)                                                                            \
+  do {                                                                                                               \
+    PF_MIXED_SPEC_TRY(FF, RR, PP, MM)                                                                                \
     if (pf_mixed_raise_lds<FF>(reinterpret_cast<const void *>(&k_mixed_c2r_invariants<FF, RR, PP, MM>), shm)) return 3; \
     hipLaunchKernelGGL((k_mixed_c2r_invariants<FF, RR, PP, MM>), grid, block, shm, st, p, pl);                    \
   } while (0)

@@ -216,3 +216,35 @@ def test_bench_self_launches_its_ranks_without_touching_the_gpu():
     r2 = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--dry-launch"], env=env2,
                         capture_output=True, text=True, timeout=120)
     assert r2.returncode != 0 and "WORLD_SIZE=1" in r2.stderr
+
+
+def _verdict_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, os.path.dirname(HERE))
+        import torch
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import bench
+        # rank 0 holds the verdict; the others arrive with the opposite opinion and leave with rank 0's
+        got = [bench.broadcast_verdict(dist, torch, (rank == 0) == v, "gloo-host") for v in (True, False)]
+        dist.destroy_process_group()
+        q.put((rank, got))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, repr(e)))
+
+
+def test_bench_exit_verdict_reaches_every_rank():
+    """bench.broadcast_verdict on a gloo group of two: the flag that makes every rank of a multi-GPU run exit non-zero after a failed result check"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_verdict_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res[0] == [True, False] and res[1] == [True, False], res

@@ -423,6 +423,8 @@ for pref in ("rccl", "torch"):
             assert f.L.pf_release_rccl(f.h) == 0      # communicator destroyed, callbacks cleared
             assert f.L.pf_debug_exchange(f.h, 1 << 16) != 0
         del keep
+import bench     # the exit verdict of a multi-rank bench run travels on the backend's device (an NCCL-only group has no CPU backend)
+assert bench.broadcast_verdict(dist, torch, True, "nccl") is True and bench.broadcast_verdict(dist, torch, False, "nccl") is False
 dist.destroy_process_group()
 print("TORCH_OK")
 """
