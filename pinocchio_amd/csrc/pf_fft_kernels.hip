@@ -21,6 +21,7 @@
 #include "pf_fft_core.h"
 
 #include "pf_fft_stages.h"
+#include "pf_fft16.h"   // pfx_bfly4 / pfx_bfly8 on the packed algebra (the two-row invariant z-pass)
 #include "pf_strided_addr.h"
 #include "pf_collapse_core.h"  // pf_invariants
 
@@ -639,6 +640,227 @@ template <typename F, int N, int MODE = 0>
 __global__ void __launch_bounds__(6 * (N / 16) + 64 * (N / 512)) __attribute__((amdgpu_waves_per_eu(N >= 2048 ? 8 : 6)))
 k_c2r_invariants_spec(const PfC2RParams p, long long nrows) { pf_c2r_invariants_body<F, N, MODE, true>(p, nrows); }
 
+// ---- the invariant z-pass of fp32 fields, TWO ROWS PER THREAD (round 6) ------------------------------------------------------------
+// k_c2r_invariants_spec<float, N, 0> in the packed algebra still spends half of its vector instructions on what is not arithmetic --
+// indices, band tests, LDS addresses, twiddle powers, waits -- and moves its lines through LDS in 8-byte accesses, with a barrier pair
+// per exchange.  None of that depends on the row.  Here a thread owns the same eight points of TWO neighbouring rows (2 q, 2 q + 1) of
+// its component: every complex is a (re, im) register pair as it lies in memory (PfCxPk), an LDS element is the pair of both rows
+// (16 bytes: ds_read_b128 / ds_write_b128), and the index arithmetic, the twiddles and their powers, the barriers and the waits are
+// paid once for two rows.  Waves that only reduce as before; the next pair of rows is requested when this one is handed over.
+// Same operations per cell as the one-row kernel (the same PfCxPk expressions in the same order): the same bits.
+#ifndef PF_ZI_PK2
+#define PF_ZI_PK2 1         // (0 in an A/B build: k_c2r_invariants_spec<float, N, 0> as in round 5)
+#endif
+struct alignas(16) PfRow2 { pf_f2 a, b; };   // one complex of row 2 q (a) and of row 2 q + 1 (b)
+
+template <int M, int S, int NW>
+__device__ __forceinline__ void pf_pk2_stage(pf_f2 (&a)[8], pf_f2 (&b)[8], const pf_f2 (&w)[NW]) {
+  using A = PfCxPk;
+  constexpr int R = pf_radix(M, S), NS = pf_ns(M, S), Q = 8 / R;
+#pragma unroll
+  for (int q = 0; q < Q; q++) {
+    if constexpr (NS > 1) {
+      const pf_f2 w1 = w[q];
+      a[q + Q] = A::cmul<+1>(a[q + Q], w1); b[q + Q] = A::cmul<+1>(b[q + Q], w1);
+      if constexpr (R >= 4) {
+        const pf_f2 w2 = A::twmul(w1, w1), w3 = A::twmul(w2, w1);
+        a[q + 2 * Q] = A::cmul<+1>(a[q + 2 * Q], w2); b[q + 2 * Q] = A::cmul<+1>(b[q + 2 * Q], w2);
+        a[q + 3 * Q] = A::cmul<+1>(a[q + 3 * Q], w3); b[q + 3 * Q] = A::cmul<+1>(b[q + 3 * Q], w3);
+        if constexpr (R == 8) {
+          const pf_f2 w4 = A::twmul(w2, w2), w5 = A::twmul(w4, w1), w6 = A::twmul(w3, w3), w7 = A::twmul(w4, w3);
+          a[4] = A::cmul<+1>(a[4], w4); b[4] = A::cmul<+1>(b[4], w4);
+          a[5] = A::cmul<+1>(a[5], w5); b[5] = A::cmul<+1>(b[5], w5);
+          a[6] = A::cmul<+1>(a[6], w6); b[6] = A::cmul<+1>(b[6], w6);
+          a[7] = A::cmul<+1>(a[7], w7); b[7] = A::cmul<+1>(b[7], w7);
+        }
+      }
+    }
+    if constexpr (R == 8) { pfx_bfly8<A, +1>(a); pfx_bfly8<A, +1>(b); }
+    else if constexpr (R == 4) {
+      pfx_bfly4<A, +1>(a[q], a[q + Q], a[q + 2 * Q], a[q + 3 * Q]);
+      pfx_bfly4<A, +1>(b[q], b[q + Q], b[q + 2 * Q], b[q + 3 * Q]);
+    } else {
+      const pf_f2 ta = A::sub(a[q], a[q + Q]), tb = A::sub(b[q], b[q + Q]);
+      a[q] = A::add(a[q], a[q + Q]); b[q] = A::add(b[q], b[q + Q]);
+      a[q + Q] = ta; b[q + Q] = tb;
+    }
+  }
+}
+// stages S .. last of an M-point line on both rows (stage S already applied on entry when S > 0)
+template <int M, int S, bool WAVE_LOCAL>
+struct PfPk2Stages {
+  template <typename WR, typename RD>
+  static __device__ __forceinline__ void run(pf_f2 (&a)[8], pf_f2 (&b)[8], int tl, const pf_f2 *__restrict__ tw, WR wr, RD rd) {
+    constexpr int NT = M / 8;
+    if constexpr (S == 0) {
+      const pf_f2 none[1] = {PfCxPk::mk(1.f, 0.f)};
+      pf_pk2_stage<M, 0>(a, b, none);
+    }
+    if constexpr (S + 1 < pf_nstages(M)) {
+      constexpr int R1 = pf_radix(M, S + 1), NS1 = pf_ns(M, S + 1), Q1 = 8 / R1;
+      constexpr int TWM1 = (M / (NS1 * R1)) * 2;   // the table is exp(+2 pi i j / N), N = 2 M
+      pf_f2 w[Q1];
+#pragma unroll
+      for (int q = 0; q < Q1; q++) w[q] = tw[((tl + q * NT) & (NS1 - 1)) * TWM1];   // asked for in front of the exchange
+#pragma unroll
+      for (int m = 0; m < 8; m++) wr(pf_stage_pos<M, S>(tl, m), a[m], b[m]);
+      if constexpr (WAVE_LOCAL) pf_wave_sync(); else __syncthreads();
+#pragma unroll
+      for (int m = 0; m < 8; m++) rd(tl + m * NT, a[m], b[m]);
+      if constexpr (WAVE_LOCAL) pf_wave_sync(); else __syncthreads();
+      pf_pk2_stage<M, S + 1>(a, b, w);
+      PfPk2Stages<M, S + 1, WAVE_LOCAL>::run(a, b, tl, tw, wr, rd);
+    }
+  }
+};
+
+template <int N, int RW>
+__global__ void __launch_bounds__(6 * (N / 16) + 64 * RW) k_c2r_invariants_pk2(const PfC2RParams p, long long nrows) {
+  using A = PfCxPk;
+  constexpr int M = N / 2, NT = M / 8, TL = 6;
+  constexpr int LPL = M + M / 16 + 1;                 // 16-byte elements of a line (exchange positions padded by p >> 4)
+  constexpr bool WAVE_LOCAL = NT <= 64;               // a line's threads sit in one wave
+  constexpr int NSTAGES = pf_nstages(M);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  PfRow2 *lds = reinterpret_cast<PfRow2 *>(smem);
+  const int tid = threadIdx.x;
+  const long long npairs = (nrows + 1) >> 1;
+  double *__restrict__ o1 = p.inv_out[0], *__restrict__ o2 = p.inv_out[1], *__restrict__ o3 = p.inv_out[2];
+  if (tid >= TL * NT) {
+    // ---- the reducing waves: between the two barriers of a pair of rows, its reduction
+    constexpr int LINE_BARRIERS = WAVE_LOCAL ? 0 : 3 + 2 * (NSTAGES - 1);
+#pragma unroll 1
+    for (long long q = blockIdx.x; q < npairs; q += gridDim.x) {
+      int tr = tid - TL * NT;
+      asm volatile("" : "+v"(tr));
+#pragma unroll
+      for (int i = 0; i < LINE_BARRIERS; i++) __syncthreads();
+      __syncthreads();
+      const long long R0 = 2 * q;
+      const bool two = R0 + 1 < nrows;
+#pragma unroll 1
+      for (int j = tr; j < M; j += 64 * RW) {
+        PfRow2 e[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) e[k] = lds[k * LPL + j];
+        typedef double pf_d2 __attribute__((ext_vector_type(2)));
+        {
+          const double da[6] = {(double)e[0].a.x, (double)e[1].a.x, (double)e[2].a.x, (double)e[3].a.x, (double)e[4].a.x, (double)e[5].a.x},
+                       db[6] = {(double)e[0].a.y, (double)e[1].a.y, (double)e[2].a.y, (double)e[3].a.y, (double)e[4].a.y, (double)e[5].a.y};
+          double a1, a2, a3, b1, b2, b3;
+          pf_invariants(da, a1, a2, a3);
+          pf_invariants(db, b1, b2, b3);
+          if (pf_invariants_lose_diagonal(da, a1, a2) || pf_invariants_lose_diagonal(db, b1, b2)) *p.flag = 1.0;
+          const long long ao = R0 * p.inv_pitch + 2 * j;
+          pf_d2 w1, w2, w3;
+          w1.x = a1; w1.y = b1; w2.x = a2; w2.y = b2; w3.x = a3; w3.y = b3;
+          __builtin_nontemporal_store(w1, reinterpret_cast<pf_d2 *>(o1 + ao));
+          __builtin_nontemporal_store(w2, reinterpret_cast<pf_d2 *>(o2 + ao));
+          __builtin_nontemporal_store(w3, reinterpret_cast<pf_d2 *>(o3 + ao));
+        }
+        if (two) {
+          const double da[6] = {(double)e[0].b.x, (double)e[1].b.x, (double)e[2].b.x, (double)e[3].b.x, (double)e[4].b.x, (double)e[5].b.x},
+                       db[6] = {(double)e[0].b.y, (double)e[1].b.y, (double)e[2].b.y, (double)e[3].b.y, (double)e[4].b.y, (double)e[5].b.y};
+          double a1, a2, a3, b1, b2, b3;
+          pf_invariants(da, a1, a2, a3);
+          pf_invariants(db, b1, b2, b3);
+          if (pf_invariants_lose_diagonal(da, a1, a2) || pf_invariants_lose_diagonal(db, b1, b2)) *p.flag = 1.0;
+          const long long ao = (R0 + 1) * p.inv_pitch + 2 * j;
+          pf_d2 w1, w2, w3;
+          w1.x = a1; w1.y = b1; w2.x = a2; w2.y = b2; w3.x = a3; w3.y = b3;
+          __builtin_nontemporal_store(w1, reinterpret_cast<pf_d2 *>(o1 + ao));
+          __builtin_nontemporal_store(w2, reinterpret_cast<pf_d2 *>(o2 + ao));
+          __builtin_nontemporal_store(w3, reinterpret_cast<pf_d2 *>(o3 + ao));
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  // ---- the transforming waves
+  const int lw = tid / NT, tl = tid % NT;
+  const int l = (lw + PF_ZI_ROT) % TL;
+  const pf_f2 *__restrict__ tw = reinterpret_cast<const pf_f2 *>(p.tw);
+  const float kf = (float)(2.0 * 3.14159265358979323846 / (double)N);
+  const float norm = (float)p.norm;
+  const float dcv = p.dc ? (float)(*p.dc) : 0.f;
+  const pf_f2 *in = reinterpret_cast<const pf_f2 *>(p.job[0].in);
+  int mul = p.job[0].mul;
+#pragma unroll
+  for (int j = 1; j < TL; j++)
+    if (l == j) { in = reinterpret_cast<const pf_f2 *>(p.job[j].in); mul = p.job[j].mul; }
+  if constexpr (NT >= 64) mul = __builtin_amdgcn_readfirstlane(mul);
+  auto line_sync = [&]() { if constexpr (WAVE_LOCAL) pf_wave_sync(); else __syncthreads(); };
+  const pf_f2 zero = A::mk(0.f, 0.f);
+  pf_f2 na[9], nb[9];
+  auto fetch = [&](long long q) {
+    const long long R0 = 2 * q;
+    const bool two = R0 + 1 < nrows;
+    const pf_f2 *__restrict__ r0 = in + R0 * p.in_pitch, *__restrict__ r1 = r0 + p.in_pitch;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int k = tl + m * NT;
+      const bool inb = k <= p.band_k;
+      na[m] = inb ? __builtin_nontemporal_load(r0 + k) : zero;
+      nb[m] = (inb && two) ? __builtin_nontemporal_load(r1 + k) : zero;
+    }
+    const bool last = tl == 0 && M <= p.band_k;
+    na[8] = last ? __builtin_nontemporal_load(r0 + M) : zero;
+    nb[8] = (last && two) ? __builtin_nontemporal_load(r1 + M) : zero;
+  };
+  long long q = blockIdx.x;
+  if (q < npairs) fetch(q);
+#pragma unroll 1
+  for (; q < npairs; q += gridDim.x) {
+    int tlj = tl, lj = l;
+    asm volatile("" : "+v"(tlj), "+v"(lj));  // keep the index math inside the loop (see k_strided)
+    PfRow2 *L = lds + lj * LPL;
+    // phase A: the rows of this component -> its LDS line
+#pragma unroll
+    for (int m = 0; m < 8; m++) { PfRow2 e; e.a = na[m]; e.b = nb[m]; L[tlj + m * NT] = e; }
+    if (tlj == 0) { PfRow2 e; e.a = na[8]; e.b = nb[8]; L[M] = e; }
+    line_sync();
+    // phase B: kz factor + Hermitian fold into the half-length complex lines (pf_zfold / pf_c2r_pre in the packed algebra)
+    pf_f2 a[8], b[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int e = tlj + m * NT;
+      const PfRow2 mk = L[M - e];
+      pf_f2 xa = na[m], xb = nb[m], ya = mk.a, yb = mk.b;
+      if (mul != 0 /* PF_MUL_ONE */) {
+        float fk = kf * (float)e, fm = kf * (float)(M - e);
+        if (mul == 2 /* PF_MUL_K2 */) { fk *= fk; fm *= fm; }
+        xa = A::scale(xa, fk); xb = A::scale(xb, fk); ya = A::scale(ya, fm); yb = A::scale(yb, fm);
+      }
+      if (m == 0 && e == 0) {   // k = 0: only the real parts of X[0] and X[M]
+        a[m] = A::mk(xa.x + ya.x, xa.x - ya.x);
+        b[m] = A::mk(xb.x + yb.x, xb.x - yb.x);
+      } else {
+        const pf_f2 wk = tw[e];
+        a[m] = A::addi<+1>(A::addc(xa, ya), A::cmul<+1>(A::subc(xa, ya), wk));
+        b[m] = A::addi<+1>(A::addc(xb, yb), A::cmul<+1>(A::subc(xb, yb), wk));
+      }
+    }
+    line_sync();
+    PfPk2Stages<M, 0, WAVE_LOCAL>::run(
+        a, b, tlj, tw, [&](int pos, pf_f2 va, pf_f2 vb) { PfRow2 e; e.a = va; e.b = vb; L[pos + (pos >> 4)] = e; },
+        [&](int pos, pf_f2 &va, pf_f2 &vb) { const PfRow2 e = L[pos + (pos >> 4)]; va = e.a; vb = e.b; });
+    line_sync();  // every thread of the line is done with the exchange area
+    // the real rows of this component, in order, into its line (complex j = reals 2 j, 2 j + 1)
+#pragma unroll
+    for (int m = 0; m < 8; m++) { PfRow2 e; e.a = A::fma1(a[m], norm, dcv); e.b = A::fma1(b[m], norm, dcv); L[tlj + m * NT] = e; }
+    __syncthreads();
+    // handed over to the reducing waves: the next pair of rows travels meanwhile (past the last pair: zeros, not "nothing" -- a
+    // conditional request would keep the old rows alive through the stages)
+    if (q + gridDim.x < npairs) fetch(q + gridDim.x);
+    else {
+#pragma unroll
+      for (int m = 0; m < 9; m++) { na[m] = zero; nb[m] = zero; }
+    }
+    __syncthreads();  // the lines are rewritten by the next phase A
+  }
+}
+
 template <typename F, int N, int TL>
 __global__ void __launch_bounds__(TL *(N / 16)) k_r2c(const PfR2CParams p) {
   using C = pfc<F>;
@@ -799,6 +1021,22 @@ static int launch_c2r_invariants_n(const PfC2RParams &p, hipStream_t st, int mod
   if (mode == 1) {
     if constexpr (PfZiPlan<F, M>::spec(1)) hipLaunchKernelGGL((k_c2r_invariants_spec<F, N, 1>), dim3((unsigned)g), dim3(6 * NT + 64 * PfZiPlan<F, M>::reducer_waves), shm, st, p, p.nlines);
     else hipLaunchKernelGGL((k_c2r_invariants<F, N, 1>), dim3((unsigned)g), dim3(6 * NT), shm, st, p, p.nlines);
+  } else if constexpr (PF_ZI_PK2 && sizeof(F) == 4 && N >= 512) {
+    // fp32 rows of 512 points and more: two rows per thread (k_c2r_invariants_pk2); a job with the factor i k has no place in the sweep's z-pass
+    for (int j = 0; j < 6; j++) if (p.job[j].mul == PF_MUL_IK) return 2;
+    constexpr int RW = N >= 2048 ? 4 : (N >= 1024 ? 2 : 1);
+    constexpr int LPL2 = M + M / 16 + 1;
+    const size_t shm2 = (size_t)6 * LPL2 * sizeof(PfRow2);
+    const int threads = 6 * NT + 64 * RW;
+    static std::atomic<bool> raised2[PF_MAX_DEVICES];
+    if (shm2 > 64 * 1024 && p.dev >= 0 && p.dev < PF_MAX_DEVICES && !raised2[p.dev].load(std::memory_order_acquire)) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_c2r_invariants_pk2<N, RW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2) != hipSuccess) return 3;
+      raised2[p.dev].store(true, std::memory_order_release);
+    }
+    long long g2 = g;
+    const long long npairs = (p.nlines + 1) / 2;
+    if (g2 > npairs) g2 = npairs;
+    hipLaunchKernelGGL((k_c2r_invariants_pk2<N, RW>), dim3((unsigned)g2), dim3(threads), shm2, st, p, p.nlines);
   } else if constexpr (PfZiPlan<F, M>::spec(0)) hipLaunchKernelGGL((k_c2r_invariants_spec<F, N, 0>), dim3((unsigned)g), dim3(6 * NT + 64 * PfZiPlan<F, M>::reducer_waves), shm, st, p, p.nlines);
   else hipLaunchKernelGGL((k_c2r_invariants<F, N, 0>), dim3((unsigned)g), dim3(6 * NT), shm, st, p, p.nlines);
   return hipGetLastError() == hipSuccess ? 0 : 1;
