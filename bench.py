@@ -51,7 +51,7 @@ import numpy as np  # noqa: E402
 # (launch_ranks) must neither load the HIP library nor touch the GPU.
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-PROFILE_ROUND = os.environ.get("PROFILE_ROUND", "r05")  # which profiles/<round>_pmc_*.json the counters come from
+PROFILE_ROUND = os.environ.get("PROFILE_ROUND", "r06")  # which profiles/<round>_pmc_*.json the counters come from
 
 
 def alg_bytes_per_cell(ns: int, w: int, lpt: bool) -> float:

@@ -651,6 +651,10 @@ k_c2r_invariants_spec(const PfC2RParams p, long long nrows) { pf_c2r_invariants_
 #ifndef PF_ZI_PK2
 #define PF_ZI_PK2 1         // (0 in an A/B build: k_c2r_invariants_spec<float, N, 0> as in round 5)
 #endif
+#ifndef PF_ZI_PK2_MAXN
+#define PF_ZI_PK2_MAXN 1024  // measured on one box (profiles/r06_notes.md): 512 points 1.31 -> 1.10 ms per launch, 1024 points 9.66 -> 9.44, 2048 points (BASELINE
+                            // config 5's slab) 121.7 -> 131.3 ms per step: two rows of 2048 points are 104 KB of lines, one workgroup per CU instead of two
+#endif
 struct alignas(16) PfRow2 { pf_f2 a, b; };   // one complex of row 2 q (a) and of row 2 q + 1 (b)
 
 template <int M, int S, int NW>
@@ -1021,8 +1025,8 @@ static int launch_c2r_invariants_n(const PfC2RParams &p, hipStream_t st, int mod
   if (mode == 1) {
     if constexpr (PfZiPlan<F, M>::spec(1)) hipLaunchKernelGGL((k_c2r_invariants_spec<F, N, 1>), dim3((unsigned)g), dim3(6 * NT + 64 * PfZiPlan<F, M>::reducer_waves), shm, st, p, p.nlines);
     else hipLaunchKernelGGL((k_c2r_invariants<F, N, 1>), dim3((unsigned)g), dim3(6 * NT), shm, st, p, p.nlines);
-  } else if constexpr (PF_ZI_PK2 && sizeof(F) == 4 && N >= 512) {
-    // fp32 rows of 512 points and more: two rows per thread (k_c2r_invariants_pk2); a job with the factor i k has no place in the sweep's z-pass
+  } else if constexpr (PF_ZI_PK2 && sizeof(F) == 4 && N >= 512 && N <= PF_ZI_PK2_MAXN) {
+    // fp32 rows of 512 and 1024 points: two rows per thread (k_c2r_invariants_pk2); a job with the factor i k has no place in the sweep's z-pass
     for (int j = 0; j < 6; j++) if (p.job[j].mul == PF_MUL_IK) return 2;
     constexpr int RW = N >= 2048 ? 4 : (N >= 1024 ? 2 : 1);
     constexpr int LPL2 = M + M / 16 + 1;
