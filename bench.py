@@ -138,7 +138,10 @@ def symbol_of(cls: str, n: int, fb: int, fast: bool = True) -> str:
         return f"k_c2r_persistent<{F}, {n}, {tl}>"
     # the invariant z-pass of rows of 512 and 1024 points (and of 2048 with fp32 fields) runs with two (four) more waves that only reduce: PfZiPlan::spec
     zinv = "k_c2r_invariants_spec" if (n in (512, 1024) or (n == 2048 and fb == 4)) else "k_c2r_invariants"
-    return {"zpass_c2r_hess_6to3inv": f"{zinv}<{F}, {n}, 0>", "zpass_c2r_hess_6_lpt3b": f"k_c2r_invariants<{F}, {n}, 1>",
+    zinv_sym = f"{zinv}<{F}, {n}, 0>"
+    if fb == 4 and n in (512, 1024):   # round 6: fp32 rows of 512 and 1024 points, two rows per thread (second argument: the waves that only reduce)
+        zinv_sym = f"k_c2r_invariants_pk2<{n}, {2 if n == 1024 else 1}>"
+    return {"zpass_c2r_hess_6to3inv": zinv_sym, "zpass_c2r_hess_6_lpt3b": f"k_c2r_invariants<{F}, {n}, 1>",
             "collapse": f"k_collapse<{F}, {b}, float>", "collapse_inv": f"k_collapse_inv<{b}, float>", "lpt_sources": f"k_lpt_sources<{F}>",
             "collapse_lpt_sources": f"k_collapse_src<{F}, {b}, float>",      # last argument: PRODFLOAT of the build
             "lpt_accum": f"k_lpt_accum<{F}>", "zpass_r2c": f"k_r2c<{F}, {n}, {tl}>"}.get(cls, cls)

@@ -66,6 +66,7 @@ def test_fp32_symbols():
     assert bench.symbol_of("xpass_fwd", 2048, 4) == "k_strided16<-1, pre, band>"
     assert bench.symbol_of("ypass_hess_3to6", 512, 4) == "k_strided<float, 512, 16, 1, true>"
     assert bench.symbol_of("zpass_c2r_hess_6to3inv", 2048, 4) == "k_c2r_invariants_spec<float, 2048, 0>"
+    assert bench.symbol_of("zpass_c2r_hess_6to3inv", 1024, 4) == "k_c2r_invariants_pk2<1024, 2>" and bench.symbol_of("zpass_c2r_hess_6to3inv", 512, 4) == "k_c2r_invariants_pk2<512, 1>"
     assert bench.symbol_of("zpass_c2r_hess_6to3inv", 256, 8) == "k_c2r_invariants<double, 256, 0>"
     assert bench.symbol_of("zpass_c2r_hess_6to3inv", 512, 8) == "k_c2r_invariants_spec<double, 512, 0>"
     assert bench.symbol_of("zpass_c2r_hess_6to3inv", 1024, 8) == "k_c2r_invariants_spec<double, 1024, 0>"
