@@ -65,3 +65,20 @@ def test_create_rejects_bad_configs_and_missing_gpu(lib, capfd):
         from pinocchio_amd import api
         with pytest.raises(api.PinfmaxError):
             api.Fmax(64)
+
+
+def test_memory_plan_of_the_baseline_configurations(lib, monkeypatch):
+    """pf_plan_bytes (no device needed): what a rank of each BASELINE configuration holds at most -- the numbers the documents quote, and
+    the formula pf_create's preflight holds against hipMemGetInfo.  Config 5 (2048^3 on eight ranks, fp32 fields): 199.5 GB per rank
+    (round 5: 234), 234.3 with the spectrum replicated (how tests/test_gpu_config5.py runs it)"""
+    from pinocchio_amd import api
+    monkeypatch.delenv("PF_REPLICATE_DK", raising=False)
+    at_create, peak = api.plan_bytes(2048, 8, 4)
+    assert 199.0e9 < peak < 200.0e9 and at_create < peak
+    assert 225.0e9 < api.plan_bytes(1024, 1, 8)[1] < 227.0e9             # the metric's box on one GPU
+    assert api.plan_bytes(1024, 8, 8)[1] < 39.0e9                        # config 4, per rank
+    assert api.plan_bytes(2048, 1, 8)[1] > 288.0e9                       # ... and what no single GPU holds
+    monkeypatch.setenv("PF_REPLICATE_DK", "1")
+    assert 234.0e9 < api.plan_bytes(2048, 8, 4)[1] < 235.0e9
+    with pytest.raises(api.PinfmaxError):
+        api.plan_bytes(100, 3, 8)

@@ -814,6 +814,48 @@ def test_update_products_merges_into_recompute_records(api):
     assert np.array_equal(recs["Fmax"], p0["Fmax"] + np.float32(100.0)) and np.array_equal(recs["Rmax"], p0["Rmax"])
 
 
+def test_preflight_refuses_a_box_the_device_cannot_hold(api, capfd):
+    """pf_create compares the memory plan with hipMemGetInfo BEFORE it allocates anything and fails in the reference's format (2048^3 with
+    fp64 fields on one rank: 1.8 TB); PF_PREFLIGHT=0 lets the allocations find out themselves"""
+    with pytest.raises(api.PinfmaxError) as e:
+        api.Fmax(2048)
+    assert "needs" in str(e.value) and "GB of device memory" in str(e.value)
+    assert "ERROR on task 0: pf_create: 2048^3 on 1 ranks" in capfd.readouterr().out
+    with api.Fmax(64) as f:      # nothing of the refused context stayed behind
+        assert f.device_bytes > 0
+
+
+@pytest.mark.parametrize("env", [{"PF_HANDOFF_THREADS": "3", "PF_HANDOFF_CHUNK_MB": "1"}, {"PF_HOST_REGISTER": "1"}, {"PF_HANDOFF_THREADS": "1"}])
+def test_handoff_variants_move_the_same_bytes(api, env, monkeypatch):
+    """the host side of the boundary (PfHandoff, csrc/pf_api.hip) with other piece sizes and thread counts, and with the caller's array
+    registered with the driver: products, a re-entrant update into 104-byte records, blocks and the density come out as by default"""
+    from pinocchio_amd import _lib
+    n = 64
+    dk = synth.make_density(n, seed=21)
+    x, y = synth.invgrow_table("lcdm")
+    rec = np.dtype([("Rmax", "<i4"), ("Fmax", "<f4"), ("Vel", "<f4", 3), ("Vel_2LPT", "<f4", 3), ("Vel_3LPT_1", "<f4", 3),
+                    ("Vel_3LPT_2", "<f4", 3), ("prev", "<f4", 12)])
+
+    def run():
+        with api.Fmax(n) as f:
+            f.set_density(dk); f.set_invgrow(x, y); f.set_growth(synth.growth_multipliers())
+            f.compute_fmax(np.array([2.0, 0.0]), do_lpt=True)
+            p = f.products()
+            recs = np.full((n, n, n), 7, dtype=np.uint8).repeat(104, axis=2).view(rec).reshape(n, n, n)   # every byte of the records set
+            f.update_products(recs, _lib.ProductLayout(104, -1, 4, 8, 20, 32, 44))                           # (Fmax named too, Rmax not)
+            return p, recs.copy(), f.block("2LPT"), f.block("ID  ", 8), f.density()
+
+    base = run()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    got = run()
+    for a, b in zip(base, got):
+        assert a.tobytes() == b.tobytes()
+    p, recs = got[0], got[1]
+    assert np.array_equal(recs["Fmax"], p["Fmax"]) and np.array_equal(recs["Vel_3LPT_2"], p["Vel_3LPT_2"])
+    assert np.all(recs["Rmax"].view(np.uint8) == 7) and np.all(recs["prev"].view(np.uint8) == 7)                # what was not named kept its bytes
+
+
 def test_fft_module_seam_single_components(api):
     """pf_derivative = compute_derivative(ThisGrid, a, b) (src/fmax-pfft.c:255-441) for every (a, b) the reference can be
     called with: second derivatives, first derivatives (re/im swap), the potential (-1/k^2), with smoothing and growth"""
