@@ -853,7 +853,7 @@ def test_handoff_variants_move_the_same_bytes(api, env, monkeypatch):
         assert a.tobytes() == b.tobytes()
     p, recs = got[0], got[1]
     assert np.array_equal(recs["Fmax"], p["Fmax"]) and np.array_equal(recs["Vel_3LPT_2"], p["Vel_3LPT_2"])
-    assert np.all(recs["Rmax"].view(np.uint8) == 7) and np.all(recs["prev"].view(np.uint8) == 7)                # what was not named kept its bytes
+    assert np.all(np.ascontiguousarray(recs["Rmax"]).view(np.uint8) == 7) and np.all(np.ascontiguousarray(recs["prev"]).view(np.uint8) == 7)   # what was not named kept its bytes
 
 
 def test_fft_module_seam_single_components(api):
