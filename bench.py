@@ -531,6 +531,22 @@ def boundary_report(f, api, n, step_s):
     from pinocchio_amd import _lib
     nc = n ** 3
     out = {"host_threads_env": os.environ.get("PF_HANDOFF_THREADS"), "registered": os.environ.get("PF_HOST_REGISTER", "0") == "1"}
+    # host memory this process may still take: the smaller of what the machine has available and what its control group leaves (the
+    # caller's arrays here are 60 and 112 GB at 1024^3: a measurement that the kernel's out-of-memory killer ends would take the line with it)
+    avail = None
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                avail = int(ln.split()[1]) * 1024
+        lim, cur = open("/sys/fs/cgroup/memory.max").read().strip(), open("/sys/fs/cgroup/memory.current").read().strip()
+        if lim != "max":
+            avail = min(avail, int(lim) - int(cur)) if avail is not None else int(lim) - int(cur)
+    except (OSError, ValueError):
+        pass
+    out["host_bytes_available"] = avail
+
+    def fits(nbytes):
+        return avail is None or nbytes * 1.25 + (8 << 30) < avail
 
     def timed(fn):
         f.synchronize()
@@ -541,6 +557,9 @@ def boundary_report(f, api, n, step_s):
 
     lay = _lib.ProductLayout()
     f.L.pf_layout_3lpt(C.byref(lay))
+    if not fits(nc * lay.stride):
+        out["skipped"] = "the host does not leave room for the caller's product array"
+        return out
     rec = np.empty(nc * lay.stride, dtype=np.uint8)          # untouched pages: the first call faults them in
     get = lambda: f._chk(f.L.pf_get_products(f.h, rec.ctypes.data_as(C.c_void_p), C.byref(lay)))   # noqa: E731
     out["records_GB"] = rec.nbytes / 1e9
@@ -550,14 +569,17 @@ def boundary_report(f, api, n, step_s):
     del rec
     # the 104-byte record of the default build with RECOMPUTE_DISPLACEMENTS (src/pinocchio.h:233-259: the 56 bytes above + four *_prev vectors)
     lay2 = _lib.ProductLayout(stride=104, off_Rmax=-1, off_Fmax=-1, off_Vel=8, off_Vel_2LPT=20, off_Vel_3LPT_1=32, off_Vel_3LPT_2=44)
-    rec2 = np.empty(nc * 104, dtype=np.uint8)
-    upd = lambda: f._chk(f.L.pf_update_products(f.h, rec2.ctypes.data_as(C.c_void_p), C.byref(lay2)))   # noqa: E731
-    out["update_records_GB"] = rec2.nbytes / 1e9
-    out["update_link_GB"] = nc * 48 / 1e9
-    out["update_ms_first_call"] = timed(upd)
-    out["update_ms"] = timed(upd)
-    out["update_link_GBps"] = nc * 48 / 1e6 / out["update_ms"]
-    del rec2
+    if fits(nc * 104):
+        rec2 = np.empty(nc * 104, dtype=np.uint8)
+        upd = lambda: f._chk(f.L.pf_update_products(f.h, rec2.ctypes.data_as(C.c_void_p), C.byref(lay2)))   # noqa: E731
+        out["update_records_GB"] = rec2.nbytes / 1e9
+        out["update_link_GB"] = nc * 48 / 1e9
+        out["update_ms_first_call"] = timed(upd)
+        out["update_ms"] = timed(upd)
+        out["update_link_GBps"] = nc * 48 / 1e6 / out["update_ms"]
+        del rec2
+    else:
+        out["update_skipped"] = "the host does not leave room for 104-byte records"
     dk = np.empty((n, n, n // 2 + 1), dtype=np.complex128)
     dpp = dk.view(np.float64).ctypes.data_as(C.POINTER(C.c_double))
     out["density_GB"] = dk.nbytes / 1e9
