@@ -42,7 +42,8 @@ typedef struct {
                        chirp-z (Bluestein) transforms on the power-of-two stages, one per component, one rank and fp64 fields only
                        (csrc/pf_gfft.hip; no library transform anywhere).  pf_transform_path() says which */
   int     rank;     /* ThisTask */
-  int     nranks;   /* NTasks; x-slabs, nranks must divide n */
+  int     nranks;   /* NTasks; x-slabs, nranks must divide n (src/fmax-pfft.c:95-111 without the ragged last slab).  A power of two for n = 2^k; any
+                       divisor that leaves slabs of two planes and more for n = 8 m that is not a power of two (96^3 on 3, 120^3 on 6, 200^3 on 5 ...) */
   int     device;   /* HIP device ordinal of this rank */
   int     field_bytes; /* 8: fp64 density/derivative fields (reference); 4: fp32 fields, fp64 collapse solve */
   int     flags;    /* PF_FLAG_* */
@@ -381,7 +382,7 @@ int pf_debug_invariant_reruns(pf_ctx *ctx);
    that z-pass too) -- per-kernel times of pf_kernel_stats are spans, not kernel times or shares of the step; 0 when every kernel ran in line */
 int pf_solve_ran_beside_zpass(pf_ctx *ctx);
 /* which transforms serve the context's grid size (the reference plans any GridSize, src/fmax-pfft.c:139-188): 0 the hand-written
-   power-of-two passes, 1 the hand-written passes with mixed-radix stage plans (n = 8 m, m = 2^a 3^b 5^c; any power-of-two number of ranks),
+   power-of-two passes, 1 the hand-written passes with mixed-radix stage plans (n = 8 m, m = 2^a 3^b 5^c; any number of ranks that divides n),
    2 chirp-z transforms, one 3-D transform per component (any other even n on one rank, or PF_GENERAL=1) */
 int pf_transform_path(pf_ctx *ctx);
 /* 1: in the default (fast) arithmetic the inverse growing mode of radius `ismooth` (-1: the shared spline) comes from the

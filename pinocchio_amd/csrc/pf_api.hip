@@ -483,11 +483,16 @@ extern "C" int pf_create(pf_ctx **out, const pf_config *cfg) {
     if (n < 4 || n > 2048 || (n & 1)) return pf_fail(rank, "pf_create: grid size %lld must be even, in [4, 2048]", n);
     if (cfg->nranks != 1 || cfg->field_bytes != 8)
       return pf_fail(rank, "pf_create: grid size %lld is not 8 * 2^a 3^b 5^c: the chirp-z transform path (any even size) takes one rank and fp64 fields; "
-                           "slab decomposition and fp32 fields need n = 8 * 2^a 3^b 5^c in [16, 2048] and a power-of-two number of ranks", n);
-  } else if (!mixed && (n < 16 || n > 2048)) return pf_fail(rank, "pf_create: grid size %lld must lie in [16, 2048] (n = 8 * 2^a 3^b 5^c on any power-of-two number of ranks, any even size on one rank)", n);
+                           "slab decomposition and fp32 fields need n = 8 * 2^a 3^b 5^c in [16, 2048]", n);
+  } else if (!mixed && (n < 16 || n > 2048)) return pf_fail(rank, "pf_create: grid size %lld must lie in [16, 2048] (n = 8 * 2^a 3^b 5^c on slabs, any even size on one rank)", n);
   if (cfg->nranks < 1 || n % cfg->nranks || cfg->rank < 0 || cfg->rank >= cfg->nranks)
     return pf_fail(rank, "pf_create: nranks %d must divide the grid size %lld (slab decomposition)", cfg->nranks, n);
-  if (cfg->nranks & (cfg->nranks - 1)) return pf_fail(rank, "pf_create: nranks %d must be a power of two", cfg->nranks);
+  // a power-of-two grid splits by shifts and masks (PfAddr::el_shift): a power-of-two number of ranks.  The mixed-radix passes split a line over
+  // the slabs by multiply-high (PfAddr::el_len), any slab thickness of two planes and more: any number of ranks that divides the grid
+  // (round 6: 96^3 on 3, 120^3 on 6, 200^3 on 5 ... -- the reference takes any NTasks its slabs allow, src/fmax-pfft.c:95-111)
+  if ((cfg->nranks & (cfg->nranks - 1)) && !mixed)
+    return pf_fail(rank, "pf_create: nranks %d must be a power of two for a grid of %lld = 2^k points per side (any divisor of the grid size for n = 8 * 2^a 3^b 5^c that is not a power of two)", cfg->nranks, n);
+  if (mixed && cfg->nranks > 1 && n / cfg->nranks < 2) return pf_fail(rank, "pf_create: slabs of one plane are not supported (grid %lld on %d ranks)", n, cfg->nranks);
   if (cfg->field_bytes != 8 && cfg->field_bytes != 4) return pf_fail(rank, "pf_create: field_bytes must be 8 or 4");
   if ((cfg->flags & PF_FLAG_DOUBLE_PRODUCTS) && cfg->field_bytes != 8)
     return pf_fail(rank, "pf_create: PF_FLAG_DOUBLE_PRODUCTS (fp64 Fmax and displacements) needs fp64 fields");
@@ -634,6 +639,10 @@ static void band_rows(const pf_ctx *c, int p, int band, int *lo, int *hi) {
   *lo = *hi = 0;
   if (y0 <= band) { *lo = 0; *hi = (band + 1 < y1 ? band + 1 : y1) - y0; }
   else if (y1 > c->n - band) { *lo = (c->n - band > y0 ? c->n - band : y0) - y0; *hi = c->nyl; }
+  // an odd number of ranks (mixed-radix grids, round 6): the middle slab straddles n / 2 and can hold rows of BOTH ends of the band.  One
+  // piece per rank is what the exchange moves: the rows between the two ends travel with them (never written by the x-pass, never read
+  // by the y-pass: stale bytes that nobody looks at)
+  if (y0 <= band && y1 > c->n - band) { *lo = 0; *hi = c->nyl; }
 }
 static int exchange_band(pf_ctx *c, const void *send, void *recv, int band, hipStream_t st = nullptr) {
   if (c->P == 1) return 0;

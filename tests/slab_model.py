@@ -39,6 +39,8 @@ def band_rows(n, P, p, band):
     """pf_api.hip band_rows: the in-band local ky rows [lo, hi) of rank p's slab (one interval for P >= 2)"""
     nyl = n // P
     y0, y1 = p * nyl, (p + 1) * nyl
+    if y0 <= band and y1 > n - band:      # an odd number of ranks: the middle slab holds rows of both ends of the band -- one piece, the whole slab
+        return 0, nyl
     if y0 <= band:
         return 0, min(band + 1, y1) - y0
     if y1 > n - band:

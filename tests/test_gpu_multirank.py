@@ -63,7 +63,8 @@ def api():
 @pytest.mark.parametrize("replicate", [1, 0])
 # (48, 96, 120: grid sizes that are not a power of two -- slabs of 24, 24 and 15 planes, split by multiply-high in the mixed-radix passes)
 @pytest.mark.parametrize("n,P,pipeline", [(32, 2, 1), (64, 4, 1), (64, 8, 1), (64, 4, 0), (16, 16, 1), (32, 16, 0), (256, 8, 1),
-                                          (48, 2, 1), (96, 4, 1), (120, 8, 0), (200, 8, 1)])
+                                          (48, 2, 1), (96, 4, 1), (120, 8, 0), (200, 8, 1),
+                                          (96, 3, 1), (120, 6, 1), (200, 5, 0), (240, 12, 1)])   # (rank counts that are not a power of two: mixed-radix grids take any divisor)
 def test_slab_ranks_match_single_rank(api, n, P, pipeline, replicate, monkeypatch):
     # replicate = 1 (default): every rank holds the whole delta(k) and the passes that start from it exchange nothing;
     # 0: every transform goes through the all-to-all
