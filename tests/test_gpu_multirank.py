@@ -683,6 +683,48 @@ def test_late_communication_exposes_a_missing_wait(api, fault, n, P, delay_us, m
     assert any(not np.array_equal(res[r], fm1[r * nxl:(r + 1) * nxl]) for r in range(P))
 
 
+def test_config4_all_eight_ranks_at_full_size_on_one_gpu(api, monkeypatch):
+    """BASELINE config 4 on its own workload -- 1024^3, fp64, eight ranks, Fmax sweep + 2LPT / 3LPT -- with all eight ranks alive on ONE GPU,
+    their all-to-alls moved by the in-process fabric (device-to-device copies where an 8-GPU node has RCCL over xGMI): 128-plane slabs, the
+    band-limited exchanges of the smoothed radii, the transposes of the LPT source spectra, every reduction.  One buffer set per rank
+    (PF_PIPELINE=0: 31.5 GB each; the pipeline's second set -- 38 GB each -- would not fit eight times, and is covered at 64^3 .. 256^3
+    above).  Fmax, Rmax and the first three displacement fields bit for bit the single-GPU run, the 3LPT(b) field to the order of its
+    all-reduced sum.  What is left for real peers: the RCCL transport itself."""
+    n, P = 1024, 8
+    monkeypatch.setenv("PF_PIPELINE", "0")
+    monkeypatch.setenv("PF_REPLICATE_DK", "0")
+    nxl = n // P
+    x, y = synth.invgrow_table("lcdm")
+    g = synth.growth_multipliers()
+    radii = synth.radii_ladder(12)[[2, 8, 11]]          # one band-limited radius, one full, R = 0
+    names = ("FMAX", "RMAX", "ZEL ", "2LPT", "31PT", "32PT")
+    with api.Fmax(n) as f1:
+        f1.synth_density(synth.SEED, 2.5, -2.0)
+        f1.set_invgrow(x, y); f1.set_growth(g)
+        tv1 = f1.compute_fmax(radii, do_lpt=True)
+        pdf1 = f1.Fmax_PDF()
+        gold = {nm: f1.block(nm) for nm in names}
+
+    def body(f, r):
+        f.synth_density(synth.SEED, 2.5, -2.0)
+        f.set_invgrow(x, y); f.set_growth(g)
+        tv = f.compute_fmax(radii, do_lpt=True)
+        pdf = f.Fmax_PDF()
+        return tv, pdf, {nm: f.block(nm) for nm in names}, f.device_bytes
+
+    res = run_ranks(api, n, P, body)
+    nc = nxl * n * n
+    for r in range(P):
+        tv, pdf, blk, dev = res[r]
+        assert np.allclose(tv, tv1, rtol=1e-13) and np.array_equal(pdf, pdf1), r
+        assert dev < 32e9
+        for nm in names[:5]:
+            assert np.array_equal(blk[nm], gold[nm][r * nc:(r + 1) * nc]), (r, nm)
+        a, b = blk["32PT"].astype(np.float64), gold["32PT"][r * nc:(r + 1) * nc].astype(np.float64)
+        assert np.max(np.abs(a - b)) <= 2e-7 * np.max(np.abs(b)), r
+    assert np.sqrt(tv1[-1]) == pytest.approx(2.5, rel=1e-10)
+
+
 @pytest.mark.parametrize("fb", [8, 4])
 def test_loopback_slab_passes_on_fields_whose_answer_is_known(api, fb):
     """512^3 on eight ranks, ONE rank on its own behind the loopback exchange, spectrum exchanged (PF_REPLICATE_DK=0): every pass of
